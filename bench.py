@@ -1,0 +1,218 @@
+"""bench.py -- point-clouds/sec of one UPP / Point-MAE training step on MI355X.
+
+Workload (BASELINE.json configs[2] / SURVEY 8d): Point_MAE_unify, cfgs/unify_modelnet_cls.yaml,
+noisy-train recipe (B=32 clouds per GPU of N = 1024 + 48 lidar + 24 shell-noise points; rectify +
+completion prompters on), PEFT stage-1 freezing (619,176 trainable parameters), cross-entropy,
+backward, gradient clipping and AdamW step -- all inside the timed region.  FPS / kNN / grouping
+run on the hand-written gfx950 kernels through the C ABI; inputs are resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant hand-written kernel, timed live
+with HIP events on the launch stream), `stages` (stand-alone FPS+kNN+Group timings and GB/s),
+`cpu_baseline` (same step on the host cores with the CPU oracle, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "iccv2025-upp_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEFT_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'bnorm', 'cls_pos', 'cls_token',
+             'cls_head_finetune']  # reference tools/runner_module.py:62-66
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_model(device):
+    from models import build_model_from_cfg
+    from utils.config import builtin_cfg
+    torch.manual_seed(0)
+    model = build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model).to(device)
+    for name, p in model.named_parameters():
+        p.requires_grad_(any(k in name for k in PEFT_KEYS))       # freeze FIRST, then set up the exchange
+    return model
+
+
+def make_optimizer(model):
+    """AdamW, two groups (reference tools/builder.py:40-55): no decay for 1-D / bias / 'token' params."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.dim() == 1 or name.endswith(".bias") or 'token' in name) else decay).append(p)
+    return torch.optim.AdamW([{'params': no_decay, 'weight_decay': 0.}, {'params': decay, 'weight_decay': 0.05}], lr=5e-4)
+
+
+class Trainer:
+    def __init__(self, device, batch, distributed):
+        import _seeded
+        from utils.dist_utils import FlatGradAllReduce
+        self.model = build_model(device).train()
+        self.opt = make_optimizer(self.model)
+        self.flat = FlatGradAllReduce(self.model.parameters())
+        self.trainable = self.flat.params
+        rank = dist.get_rank() if distributed else 0
+        self.pts = _seeded.noisy_clouds(batch, 1024, seed=rank).to(device)       # (B,1096,3) resident in HBM
+        g = torch.Generator().manual_seed(rank)
+        self.labels = torch.randint(0, 40, (batch,), generator=g).to(device)
+        self.distributed = distributed
+
+    def step(self):
+        self.flat.zero()
+        logits = self.model(self.pts, completion_prompt=True, denoise=True, point_num=1024)
+        loss, acc = self.model.get_loss_acc(logits, self.labels)
+        loss.backward()
+        self.flat.scalars[0] = loss.detach()
+        self.flat.scalars[1] = acc.detach()
+        if self.distributed:
+            self.flat.reduce()                     # ONE all-reduce: grads + the two logging scalars
+        torch.nn.utils.clip_grad_norm_(self.trainable, 10, norm_type=2)
+        self.opt.step()
+        return loss
+
+
+def time_kernel(fn, iters=50, warm=5):
+    """Average duration (ms) of fn(), HIP events on the stream the kernels are launched on
+    (torch's current stream: upp_hip.ops passes torch.cuda.current_stream() to the C ABI)."""
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def stage_report(device, B):
+    """Stand-alone FPS / kNN(+group) at the headline shape (BASELINE configs[1]) and the longest FPS
+    of the model (1228 -> 1024).  Algorithmic bytes per cloud: SURVEY 8(d)."""
+    import _seeded
+    from upp_hip import ops
+    x = _seeded.unit_ball_clouds(B, 1024, seed=7).to(device)
+    _, cen = ops.fps(x, 64, want_centers=True)
+    x1228 = _seeded.unit_ball_clouds(B, 1228, seed=8).to(device)
+    out = {}
+    t = time_kernel(lambda: ops.fps(x, 64, want_centers=True))
+    by = B * (1024 * 12 + 64 * 4 + 64 * 12)
+    out["fps_1024_64"] = {"ms": t, "bytes": by, "GBps": by / t / 1e6}
+    t = time_kernel(lambda: ops.knn(x, cen, 32, want_dist=False, want_neigh=True))
+    by = B * (1024 * 12 + 64 * 12 + 64 * 32 * 8 + 64 * 32 * 12)
+    out["knn_group_1024_64_32"] = {"ms": t, "bytes": by, "GBps": by / t / 1e6}
+    t = time_kernel(lambda: ops.fps(x1228, 1024, want_centers=True), iters=20)
+    by = B * (1228 * 12 + 1024 * 4 + 1024 * 12)
+    out["fps_1228_1024"] = {"ms": t, "bytes": by, "GBps": by / t / 1e6}
+    return out
+
+
+def cpu_baseline(budget_s=20.0):
+    """The same training step on the host cores: torch-CPU dense ops + the C oracle (OpenMP) for
+    FPS / kNN.  Bounded sample: B=4 clouds, as many steps as fit ~budget_s (at least 1)."""
+    import oracle
+    from models import upp_layers
+    from upp_hip import functional as HF
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    saved = dict(upp_layers.OPS), HF.fps_gather
+    try:
+        ops = oracle.torch_ops()
+        upp_layers.OPS.update(ops)
+        HF.fps_gather = ops["fps_gather"]
+        tr = Trainer(torch.device("cpu"), 4, False)
+        tr.step()                                   # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            tr.step()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 20:
+                break
+        return {"value": 4 * n / el, "unit": "clouds/s", "cores": cores, "kind": "port",
+                "sample": "%d steps of B=4 noisy-train fwd+bwd+AdamW on torch-CPU + C oracle (OpenMP %d thr) in %.1f s"
+                          % (n, oracle.num_threads(), el)}
+    finally:
+        upp_layers.OPS.clear()
+        upp_layers.OPS.update(saved[0])
+        HF.fps_gather = saved[1]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")           # RCCL on ROCm
+    rank = dist.get_rank() if distributed else 0
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    from upp_hip import _abi
+    _abi.load()                                           # fail loudly if the HIP library is missing
+
+    tr = Trainer(device, args.batch, distributed)
+    for _ in range(args.warmup):
+        tr.step()
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        clouds = args.batch * world * args.steps
+        stages = stage_report(device, args.batch)
+        dom = stages["fps_1228_1024"]                     # longest hand-written kernel of the step
+        line = {
+            "metric": "point-clouds/sec fwd+bwd, UPP/Point-MAE N=1024 G=64 k=32",
+            "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Point_MAE_unify unify_modelnet_cls noisy-train fwd+bwd+AdamW, PEFT stage-1, "
+                                   "B=%d/GPU x (1024+72) pts, G=64 k=32" % args.batch,
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "roofline": {"kernel": "fps_kernel (B,1228)->1024", "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                         "note": "FPS is a 1023-round serial dependency chain: latency-bound by construction"},
+            "stages": stages,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

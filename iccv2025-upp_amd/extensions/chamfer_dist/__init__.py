@@ -1,0 +1,44 @@
+"""extensions.chamfer_dist (reference extensions/chamfer_dist/__init__.py:13-84)."""
+import torch
+
+from upp_hip.functional import ChamferFunction  # noqa: F401
+
+
+def _strip_zero_points(xyz1, xyz2):
+    # reference :37-41 -- only ever applied to a batch of one
+    keep1 = torch.sum(xyz1, dim=2).ne(0)
+    keep2 = torch.sum(xyz2, dim=2).ne(0)
+    return xyz1[keep1].unsqueeze(dim=0), xyz2[keep2].unsqueeze(dim=0)
+
+
+class _ChamferBase(torch.nn.Module):
+    def __init__(self, ignore_zeros=False):
+        super().__init__()
+        self.ignore_zeros = ignore_zeros
+
+    def _dists(self, xyz1, xyz2):
+        if xyz1.size(0) == 1 and self.ignore_zeros:
+            xyz1, xyz2 = _strip_zero_points(xyz1, xyz2)
+        return ChamferFunction.apply(xyz1, xyz2)
+
+
+class ChamferDistanceL2(_ChamferBase):
+    """mean(d1) + mean(d2) of squared nearest-neighbour distances."""
+
+    def forward(self, xyz1, xyz2):
+        d1, d2 = self._dists(xyz1, xyz2)
+        return torch.mean(d1) + torch.mean(d2)
+
+
+class ChamferDistanceL2_split(_ChamferBase):
+    def forward(self, xyz1, xyz2):
+        d1, d2 = self._dists(xyz1, xyz2)
+        return torch.mean(d1), torch.mean(d2)
+
+
+class ChamferDistanceL1(_ChamferBase):
+    """(mean(sqrt d1) + mean(sqrt d2)) / 2."""
+
+    def forward(self, xyz1, xyz2):
+        d1, d2 = self._dists(xyz1, xyz2)
+        return (torch.mean(torch.sqrt(d1)) + torch.mean(torch.sqrt(d2))) / 2

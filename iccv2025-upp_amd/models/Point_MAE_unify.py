@@ -1,0 +1,167 @@
+"""Point_MAE_unify -- the UPP classifier (rectify prompter -> completion prompter -> downstream
+Point-MAE backbone with prompts/adapters), drop-in for reference models/Point_MAE_unify.py:390-655:
+same registry name, constructor contract `cls(config)`, forward kwargs, methods and state-dict
+keys; grouping runs on the gfx950 FPS / kNN kernels of libupp_hip.so.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from utils import misc
+from .build import MODELS
+from .upp_layers import (  # noqa: F401  (re-exported: the reference's sibling modules import these from here)
+    Block, Encoder, Group, RectifyPrompter, TransformerDecoder, TransformerEncoder,
+    pooling, propagate, trunc_normal_,
+)
+
+
+def _mlp2(i, h, o):
+    return nn.Sequential(nn.Linear(i, h), nn.GELU(), nn.Linear(h, o))
+
+
+@MODELS.register_module()
+class Point_MAE_unify(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        tc = config.transformer_config
+        self.trans_dim = tc.trans_dim
+        self.mask_ratio = tc.mask_ratio
+        self.depth = tc.depth
+        self.num_heads = tc.num_heads
+        self.encoder_dims = tc.encoder_dims
+        self.drop_path_rate = tc.drop_path_rate
+        self.group_size = config.group_size
+        self.num_group = config.num_group
+        self.vis_num = 64 - int(self.mask_ratio * 64)   # hard-wired to 64, not num_group (reference :404)
+        self.vis_short = 16
+        self.cls_dim = config.cls_dim
+        D = self.trans_dim
+
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder(embed_dim=D, depth=self.depth, drop_path_rate=dpr,
+                                         num_heads=self.num_heads, **self.config.prompter_config)
+        self.norm = nn.LayerNorm(D)
+        self.shape_pred = _mlp2(D, D // 2, self.vis_short)
+        self.coarse_pred = _mlp2(self.vis_short * self.vis_num, D, 3 * int(64 - self.vis_num))
+        self.predict_token_generator = _mlp2(D, 128, D)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, D))
+        self.decoder_pos_embed = _mlp2(3, 128, D)
+        self.decoder_depth = tc.decoder_depth
+        self.decoder_num_heads = tc.decoder_num_heads
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.decoder_depth)]
+        self.MAE_decoder = TransformerDecoder(embed_dim=D, depth=self.decoder_depth, drop_path_rate=dpr,
+                                              num_heads=self.decoder_num_heads, pretask_adapter=True, pretask_depth=4)
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.dense_pred = nn.Sequential(nn.Conv1d(D, 3 * self.group_size, 1))
+        self.rectify_prompter = RectifyPrompter(in_channels=3, out_channels=3, hidden_dimesion=D, embedding_level=4,
+                                                num_group=32, group_size=16, top_center_dim=12)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
+        self.cls_pos = nn.Parameter(torch.randn(1, 1, D))
+        self.pos_embed = _mlp2(3, 128, D)
+        self.cls_head_finetune = nn.Sequential(
+            nn.Linear(D * 2, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+            nn.Linear(256, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+            nn.Linear(256, self.cls_dim))
+        for layer in self.cls_head_finetune:
+            if isinstance(layer, nn.Linear):
+                nn.init.kaiming_uniform_(layer.weight, a=math.sqrt(5.0))
+        trunc_normal_(self.mask_token, std=.02)
+        trunc_normal_(self.cls_token, std=.02)
+        trunc_normal_(self.cls_pos, std=.02)
+        self.build_loss_func()
+
+    # ------------------------------------------------------------------ loss / checkpoints
+    def build_loss_func(self):
+        self.loss_ce = nn.CrossEntropyLoss()
+
+    def get_loss_acc(self, ret, gt):
+        loss = self.loss_ce(ret, gt.long())
+        acc = (ret.argmax(-1) == gt).sum() / float(gt.size(0))
+        return loss, acc * 100
+
+    def load_model_from_ckpt(self, bert_ckpt_path, logger=None):
+        """Key rewrites of reference :505-536: strip 'module.', '_block', 'MAE_encoder.', 'base_model.'."""
+        if bert_ckpt_path is None:
+            return None
+        ckpt = torch.load(bert_ckpt_path, map_location='cpu')
+        base = {k.replace("module.", "").replace('_block', ''): v for k, v in ckpt['base_model'].items()}
+        for k in list(base.keys()):
+            for prefix in ('MAE_encoder.', 'base_model.'):
+                if k.startswith(prefix[:-1]):
+                    base[k[len(prefix):]] = base.pop(k)
+                    break
+        return self.load_state_dict(base, strict=False)
+
+    # ------------------------------------------------------------------ forward
+    def _rectify(self, pts, point_num):
+        """Denoising prompter (reference :541-570): score every input point, nudge the cloud by
+        0.2 * predicted offset, keep the int(0.95 * point_num) least suspicious points."""
+        grouper = Group(num_group=self.vis_num, group_size=16)
+        neighborhood, vis_center = grouper(pts)
+        tokens = self.encoder(neighborhood)
+        pos = self.pos_embed(vis_center)
+        tokens = self.blocks(tokens, pos, path='rectify', rectify_adapter=True, rectify_prompts=True,
+                             rectify_depth=self.config.prompter_config['rectify_depth'])
+        pred_vector = self.rectify_prompter(pts, vis_center, tokens, require_shape_feature=False)
+        score = torch.norm(pred_vector, p=2, dim=-1)
+        order = torch.argsort(score, dim=1, descending=True)
+        pts = pts + pred_vector * 0.2
+        keep = order[:, -int(point_num * 0.95):, None].expand(-1, -1, 3)
+        return torch.gather(pts, 1, keep)
+
+    def _complete(self, pts, point_num):
+        """Completion prompter (reference :572-610): predict 32 missing centres and 32x32 points
+        around them, append a quarter of them and re-sample to point_num."""
+        B = pts.shape[0]
+        grouper = Group(num_group=self.vis_num, group_size=16)
+        neighborhood, vis_center = grouper(pts)
+        x_vis = self.encoder(neighborhood).reshape(B, -1, self.trans_dim)
+        pos = self.pos_embed(vis_center)
+        x_vis = self.blocks(x_vis, pos, path='pretask', pretask_adapter=True, pretask_prompts=True,
+                            pretask_depth=self.config.prompter_config['pretask_depth'])
+        x_vis = self.norm(x_vis)
+        pos_vis = self.decoder_pos_embed(vis_center).reshape(B, -1, self.trans_dim)
+        shape_feature = self.shape_pred(x_vis).reshape(B, self.vis_short * self.vis_num)
+        predict_center = self.coarse_pred(shape_feature).reshape(B, int(64 - self.vis_num), 3)
+        predict_token = self.predict_token_generator(x_vis)
+        pos_mask = self.decoder_pos_embed(predict_center).reshape(B, -1, self.trans_dim)
+        N = pos_mask.shape[1]
+        mask_token = propagate(predict_center, vis_center, self.mask_token.expand(B, N, -1), predict_token,
+                               de_neighbors=6)
+        x_rec = self.MAE_decoder(torch.cat([x_vis, mask_token], dim=1), torch.cat([pos_vis, pos_mask], dim=1), N,
+                                 pretask_adapter=True, path='pretask')
+        M = x_rec.shape[1]
+        rel = self.dense_pred(x_rec.transpose(1, 2)).transpose(1, 2).reshape(B, M, -1, 3)
+        rebuild = (rel + predict_center.unsqueeze(-2)).reshape(B, -1, 3)
+        sampled, _ = misc.fps(rebuild, point_num // 4)
+        pts = torch.cat([pts, sampled], dim=1).contiguous()
+        if pts.shape[1] > point_num:
+            pts = misc.fps(pts, point_num)[0]
+        return pts
+
+    def forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
+        if denoise:
+            pts = self._rectify(pts, point_num)
+        if completion_prompt:
+            pts = self._complete(pts, point_num)
+
+        neighborhood, center = self.group_divider(pts)
+        tokens = self.encoder(neighborhood)
+        B = tokens.size(0)
+        x = torch.cat((self.cls_token.expand(B, -1, -1), tokens), dim=1)
+        pos = torch.cat((self.cls_pos.expand(B, -1, -1), self.pos_embed(center)), dim=1)
+
+        propagation = {}
+        if self.config.prompt_propagation_after:
+            level2 = Group(num_group=self.num_group // 2, group_size=8)
+            _, center2, center1_idx, center2_idx = level2(center, require_index=True, gather_idx=self.config.gather_idx)
+            propagation = dict(center1=center, center1_idx=center1_idx, center2=center2, center2_idx=center2_idx,
+                               gather_idx=self.config.gather_idx,
+                               prompt_propagation_after=self.config.prompt_propagation_after)
+        x = self.blocks(x, pos, path='downstream', downstream_adapter=True, downstream_prompts=True,
+                        classification=True, **propagation)
+        x = self.norm(x)
+        return self.cls_head_finetune(torch.cat([x[:, 0], x[:, 1:].max(1)[0]], dim=-1))

@@ -1,0 +1,3 @@
+from .build import build_model_from_cfg, MODELS  # noqa: F401
+
+from . import Point_MAE_unify  # noqa: F401  (registers Point_MAE_unify)

@@ -1,0 +1,76 @@
+"""ctypes binding of the C ABI declared in include/upp_hip.h.
+
+There is NO fallback: if libupp_hip.so is missing or an entry point is absent,
+importing an operator raises.  The operators only accept tensors that live on
+a HIP device; CPU tensors are rejected loudly (the CPU restatement under
+oracle/ is test infrastructure and is never reachable from here).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libupp_hip.so")
+
+_c_f = ctypes.c_void_p   # device pointers travel as void*
+_c_i = ctypes.c_int
+
+# name -> (restype, argtypes); must list every symbol of include/upp_hip.h
+SIGNATURES = {
+    "upp_abi_version": (_c_i, []),
+    "upp_error_string": (ctypes.c_char_p, [_c_i]),
+    "upp_fps": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f]),
+    "upp_gather_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
+    "upp_gather_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
+    "upp_knn": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
+    "upp_group_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
+    "upp_group_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
+    "upp_chamfer_fwd": (_c_i, [_c_f] * 6 + [_c_i] * 3 + [_c_f]),
+    "upp_chamfer_bwd": (_c_i, [_c_f] * 8 + [_c_i] * 3 + [_c_f]),
+    "upp_emd_work_floats": (ctypes.c_longlong, [_c_i, _c_i, _c_i]),
+    "upp_emd_approxmatch": (_c_i, [_c_f] * 4 + [_c_i] * 3 + [_c_f]),
+    "upp_emd_matchcost": (_c_i, [_c_f] * 4 + [_c_i] * 3 + [_c_f]),
+    "upp_emd_matchcost_bwd": (_c_i, [_c_f] * 6 + [_c_i] * 3 + [_c_f]),
+}
+# tuning hooks (not part of the reference-facing ABI)
+_EXTRA = {
+    "upp_fps_set_waves": (_c_i, [_c_i]),
+    "upp_knn_set_prefilter": (_c_i, [_c_i]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libupp_hip.so once; raise if it (or any declared symbol) is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libupp_hip.so is not built (%s). Run `python __graft_entry__.py` or "
+            "`python iccv2025-upp_amd/upp_hip/build.py`; there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for table in (SIGNATURES, _EXTRA):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)  # AttributeError -> loud failure on a stale build
+            fn.restype = res
+            fn.argtypes = args
+    if lib.upp_abi_version() != 1:
+        raise RuntimeError("libupp_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise RuntimeError(load().upp_error_string(code).decode())
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,121 @@
+// chamfer.hip -- bidirectional nearest-neighbour squared distance + arg-min, and its
+// gradient, for gfx950.  Replaces chamfer.forward / chamfer.backward of the
+// reference torch extension (extensions/chamfer_dist/chamfer.cu:15-145, :173-201;
+// bindings chamfer_cuda.cpp:36-39).
+//
+// Forward mapping: a workgroup owns 64 query points of one cloud (one per lane)
+// and its 4 waves split the other cloud four ways, so B=32, n=1024 gives 2048
+// waves (2 per SIMD) instead of the 512 the CUDA launch shape would.  The other
+// cloud is staged through LDS as float4 and read with one broadcast ds_read_b128
+// per point.  Strict '<' inside a wave (ascending index) and a (distance, index)
+// lexicographic combine across waves give "lowest index among equal minima",
+// which is what chamfer.cu's tiles (:47,57 strict '<', :137 strict '>') produce.
+// Per-pair arithmetic is the contracted form nvcc emits for chamfer.cu:42-45.
+#include "common.h"
+
+namespace {
+
+constexpr int kTile = 2048;  // points of the other cloud per LDS tile (32 KiB)
+
+__global__ __launch_bounds__(256) void chamfer_dir_kernel(const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                          float *__restrict__ dist, int32_t *__restrict__ idx, int n, int m) {
+    __shared__ float4 tile[kTile];
+    __shared__ float cd[4][64];
+    __shared__ int ci[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 64 + lane;
+    const int jc = j < n ? j : n - 1;
+    const float *a = xyz1 + ((size_t)b * n + jc) * 3;
+    const float x1 = a[0], y1 = a[1], z1 = a[2];
+    const float *other = xyz2 + (size_t)b * m * 3;
+
+    float best = __builtin_inff();
+    int besti = 0;
+    for (int c0 = 0; c0 < m; c0 += kTile) {
+        const int len = min(kTile, m - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += 256) {
+            const float *s = other + (size_t)(c0 + i) * 3;
+            tile[i] = make_float4(s[0], s[1], s[2], 0.0f);
+        }
+        __syncthreads();
+        const int seg = (len + 3) >> 2;
+        const int k0 = wave * seg;
+        const int k1 = min(len, k0 + seg);
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) {
+            const float4 p = tile[k];
+            const float d = sumsq3(p.x - x1, p.y - y1, p.z - z1);  // x2 = buf - x1; x2*x2 + y2*y2 + z2*z2
+            const bool lt = d < best;
+            besti = lt ? c0 + k : besti;
+            best = lt ? d : best;
+        }
+    }
+    cd[wave][lane] = best;
+    ci[wave][lane] = besti;
+    __syncthreads();
+    if (wave == 0 && j < n) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float d = cd[w][lane];
+            const int i = ci[w][lane];
+            const bool take = (d < best) || (d == best && i < besti);
+            best = take ? d : best;
+            besti = take ? i : besti;
+        }
+        dist[(size_t)b * n + j] = best;
+        idx[(size_t)b * n + j] = besti;
+    }
+}
+
+// Both launches of chamfer_dist_grad_kernel (chamfer.cu:215-222) in one grid:
+// element e < B*n is point j of xyz1 (direction 1), otherwise a point of xyz2.
+__global__ void chamfer_grad_kernel(const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                    const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
+                                    const float *__restrict__ gd1, const float *__restrict__ gd2, float *__restrict__ g1,
+                                    float *__restrict__ g2, int B, int n, int m) {
+    const long long total = (long long)B * (n + m);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const bool dir1 = e < (long long)B * n;
+        const long long r = dir1 ? e : e - (long long)B * n;
+        const int na = dir1 ? n : m, nb = dir1 ? m : n;
+        const long long b = r / na;
+        const float *pa = (dir1 ? xyz1 : xyz2) + r * 3;
+        const int j2 = (dir1 ? idx1 : idx2)[r];
+        const float *pb = (dir1 ? xyz2 : xyz1) + (b * nb + j2) * 3;
+        const float g = (dir1 ? gd1 : gd2)[r] * 2;
+        float *ga = (dir1 ? g1 : g2) + r * 3;
+        float *gb = (dir1 ? g2 : g1) + (b * nb + j2) * 3;
+        const float vx = g * (pa[0] - pb[0]), vy = g * (pa[1] - pb[1]), vz = g * (pa[2] - pb[2]);
+        atomicAdd(ga + 0, vx); atomicAdd(ga + 1, vy); atomicAdd(ga + 2, vz);
+        atomicAdd(gb + 0, -vx); atomicAdd(gb + 1, -vy); atomicAdd(gb + 2, -vz);
+    }
+}
+
+}  // namespace
+
+extern "C" int upp_chamfer_fwd(const float *xyz1, const float *xyz2, float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
+                               int B, int n, int m, void *stream) {
+    if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2 || B < 0 || n < 1 || m < 1) return UPP_E_BADARG;
+    if (B == 0) return 0;
+    if (B > 65535) return UPP_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(chamfer_dir_kernel, dim3((n + 63) / 64, B), dim3(256), 0, st, xyz1, xyz2, dist1, idx1, n, m);
+    hipLaunchKernelGGL(chamfer_dir_kernel, dim3((m + 63) / 64, B), dim3(256), 0, st, xyz2, xyz1, dist2, idx2, m, n);
+    return upp_launch_status();
+}
+
+extern "C" int upp_chamfer_bwd(const float *xyz1, const float *xyz2, const int32_t *idx1, const int32_t *idx2,
+                               const float *grad_dist1, const float *grad_dist2, float *g1, float *g2, int B, int n, int m,
+                               void *stream) {
+    if (!xyz1 || !xyz2 || !idx1 || !idx2 || !grad_dist1 || !grad_dist2 || !g1 || !g2 || B < 0 || n < 1 || m < 1)
+        return UPP_E_BADARG;
+    if (B == 0) return 0;
+    const long long total = (long long)B * (n + m);
+    long long grid = (total + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(chamfer_grad_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, xyz1, xyz2, idx1, idx2,
+                       grad_dist1, grad_dist2, g1, g2, B, n, m);
+    return upp_launch_status();
+}

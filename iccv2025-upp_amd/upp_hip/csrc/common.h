@@ -1,0 +1,80 @@
+// common.h -- device helpers shared by the gfx950 kernels of libupp_hip.so.
+// CDNA4 only: 64-lane wavefronts, DPP row operations, v_readlane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../../include/upp_hip.h"
+
+#define UPP_WAVE 64
+
+// Squared length (x*x) + (y*y) + (z*z) with the contraction nvcc applies to the
+// reference sources (t = y*y; t = fma(x,x,t); t = fma(z,z,t)).  Compiled with
+// -ffp-contract=off, so the fma placement is exactly what is written here.
+// Must stay identical to sumsq3() in oracle/upp_oracle.c.
+__device__ __forceinline__ float sumsq3(float x, float y, float z) {
+    float t = y * y;
+    t = __builtin_fmaf(x, x, t);
+    t = __builtin_fmaf(z, z, t);
+    return t;
+}
+
+// KNN_CUDA's running  ssd += tmp*tmp  over d = 0,1,2  (fma(t,t,acc) chain).
+__device__ __forceinline__ float ssd3(float dx, float dy, float dz) {
+    float s = dx * dx;  // fma(dx,dx,0) is exact dx*dx
+    s = __builtin_fmaf(dy, dy, s);
+    s = __builtin_fmaf(dz, dz, s);
+    return s;
+}
+
+// ---- DPP lane permutes (all lanes active, whole rows valid) ----------------
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+#define DPP_QUAD_XOR1 0xB1        // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E        // quad_perm:[2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141 // lane i <- lane 7-i inside each 8 lanes
+#define DPP_ROW_MIRROR 0x140      // lane i <- lane 15-i inside each 16 lanes
+#define DPP_WAVE_SHR1 0x138       // lane i <- lane i-1 across the whole wave
+
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+// Wave-wide max / min of a u32, result uniform (SGPR).  Four DPP steps make
+// every row of 16 lanes uniform, then the four rows are combined on the SALU.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, dpp_u32<DPP_QUAD_XOR1>(v));
+    v = max(v, dpp_u32<DPP_QUAD_XOR2>(v));
+    v = max(v, dpp_u32<DPP_ROW_HALF_MIRROR>(v));
+    v = max(v, dpp_u32<DPP_ROW_MIRROR>(v));
+    const uint32_t a = readlane_u32(v, 0), b = readlane_u32(v, 16);
+    const uint32_t c = readlane_u32(v, 32), d = readlane_u32(v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_u32<DPP_QUAD_XOR1>(v));
+    v = min(v, dpp_u32<DPP_QUAD_XOR2>(v));
+    v = min(v, dpp_u32<DPP_ROW_HALF_MIRROR>(v));
+    v = min(v, dpp_u32<DPP_ROW_MIRROR>(v));
+    const uint32_t a = readlane_u32(v, 0), b = readlane_u32(v, 16);
+    const uint32_t c = readlane_u32(v, 32), d = readlane_u32(v, 48);
+    return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    // fixed combination order -> deterministic
+    v += __uint_as_float(dpp_u32<DPP_QUAD_XOR1>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_u32<DPP_QUAD_XOR2>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_u32<DPP_ROW_HALF_MIRROR>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_u32<DPP_ROW_MIRROR>(__float_as_uint(v)));
+    const float a = __uint_as_float(readlane_u32(__float_as_uint(v), 0));
+    const float b = __uint_as_float(readlane_u32(__float_as_uint(v), 16));
+    const float c = __uint_as_float(readlane_u32(__float_as_uint(v), 32));
+    const float d = __uint_as_float(readlane_u32(__float_as_uint(v), 48));
+    return (a + b) + (c + d);
+}
+
+static inline int upp_launch_status(void) {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

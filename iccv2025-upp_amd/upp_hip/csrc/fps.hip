@@ -1,0 +1,212 @@
+// fps.hip -- furthest point sampling for gfx950.
+//
+// Replaces pointnet2_ops furthest_point_sampling_kernel (sampling_gpu.cu), the
+// operator behind reference utils/misc.py:18.  Same results, different machine
+// mapping:
+//
+//  * One workgroup of W wavefronts per cloud (W = 1,2,4,8).  Every lane keeps
+//    its points AND their running min-distances in VGPRs for the whole call
+//    (S "slots" per lane), so an iteration touches no memory except one
+//    broadcast LDS read of the winner's coordinates: HBM traffic is the
+//    algorithmic minimum (the cloud once in, the indices once out).
+//  * The arg-max is a two-phase wave reduction on DPP row operations
+//    (u32 max of the distance bits, then u32 min of a tie-break key among the
+//    lanes that hold the max).  With W = 1 an iteration has no barrier at all;
+//    with W > 1 the waves exchange one 8-byte record through LDS and meet at a
+//    single barrier per iteration (double-buffered records).
+//
+// Tie-breaking.  The CUDA kernel runs T = min(512, 2^floor(log2 N)) threads per
+// cloud; thread t scans k = t, t+T, ... with a strict '>', then a shared-memory
+// tree  dists_i[a] = v[b] > v[a] ? i[b] : i[a]  folds t+s into t for
+// s = T/2 .. 1.  Among equal maxima the survivor is therefore the candidate
+// with the smallest  rank(k) = bitrev_log2T(k mod T) * ceil(N/T) + k div T.
+// Lanes here own whole "virtual threads" (t = lane + L*u) and visit their
+// points in increasing rank, so a strict '>' inside the lane plus a min over
+// rank across lanes reproduces the CUDA result for every input.
+#include "common.h"
+
+namespace {
+
+struct FpsGeom {
+    int N, M;
+    int T, log2T;  // CUDA block size of the reference kernel and its log2
+    int Q;         // ceil(N / T): points per virtual thread
+    int U, log2U;  // virtual threads per lane = max(1, T / L)
+};
+
+template <int S, int W, bool USE_LDS>
+__global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ xyz, int32_t *__restrict__ idx,
+                                                     float *__restrict__ centers, FpsGeom g) {
+    constexpr int L = 64 * W;
+    extern __shared__ float lds[];  // 2*W*2 words of wave records, then a [3*N] copy of the cloud
+    const int N = g.N, M = g.M;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const float *p = xyz + (size_t)b * N * 3;
+    uint32_t *rec = reinterpret_cast<uint32_t *>(lds);
+    float *cloud = lds + 4 * W;
+    // Coordinates of a point: from the LDS copy (N <= 8192) or, for larger
+    // clouds that do not fit LDS, straight from global memory (L2-resident).
+    auto coord = [&](int k, int c) -> float { return USE_LDS ? cloud[k * 3 + c] : p[k * 3 + c]; };
+    if (USE_LDS) {
+        for (int i = tid; i < 3 * N; i += L) cloud[i] = p[i];
+        __syncthreads();
+    }
+
+    // Slot s = u' * Q + q  holds point  k = t + T*q  of virtual thread
+    // t = tid + L * bitrev_log2U(u')   (increasing rank inside the lane).
+    float px[S], py[S], pz[S], tmp[S];
+    int kk[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int up = s / g.Q, q = s - up * g.Q;
+        const int u = g.log2U ? (int)(__builtin_bitreverse32((uint32_t)up) >> (32 - g.log2U)) : 0;
+        const int t = tid + L * u;
+        const int k = t + g.T * q;
+        const bool valid = (up < g.U) && (t < g.T) && (k < N);
+        const int kc = valid ? k : 0;
+        const float x = coord(kc, 0), y = coord(kc, 1), z = coord(kc, 2);
+        px[s] = x; py[s] = y; pz[s] = z;
+        kk[s] = kc;
+        // |p|^2 <= 1e-3 (double compare, as the literal in the CUDA source is a
+        // double) -> never a candidate.  A slot with tmp = -1 can never beat
+        // best (init -1, strict '>') and min(d, -1) keeps it at -1.
+        const float mag = sumsq3(x, y, z);
+        tmp[s] = (valid && !((double)mag <= 1e-3)) ? 1e10f : -1.0f;
+    }
+
+    float x1 = coord(0, 0), y1 = coord(0, 1), z1 = coord(0, 2);
+    if (tid == 0) {
+        idx[(size_t)b * M] = 0;
+        if (centers) {
+            float *c = centers + (size_t)b * M * 3;
+            c[0] = x1; c[1] = y1; c[2] = z1;
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+
+    for (int j = 1; j < M; ++j) {
+        float best = -1.0f;
+        int bk = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float d = sumsq3(px[s] - x1, py[s] - y1, pz[s] - z1);
+            const float d2 = fminf(d, tmp[s]);
+            tmp[s] = d2;
+            const bool gt = d2 > best;
+            bk = gt ? kk[s] : bk;
+            best = gt ? d2 : best;
+        }
+        // distance bits are monotone for d >= 0; +1 so that "no candidate" = 0
+        const uint32_t kb = best < 0.0f ? 0u : __float_as_uint(best) + 1u;
+        uint32_t m = wave_max_u32(kb);
+        const uint32_t t = (uint32_t)bk & (uint32_t)(g.T - 1);
+        const uint32_t rank =
+            (g.log2T ? (__builtin_bitreverse32(t) >> (32 - g.log2T)) : 0u) * (uint32_t)g.Q + ((uint32_t)bk >> g.log2T);
+        const uint32_t key = (kb == m && kb != 0u) ? ((rank << 15) | (uint32_t)bk) : 0xFFFFFFFFu;
+        uint32_t kmin = wave_min_u32(key);
+        if (W > 1) {
+            uint32_t *r = rec + (j & 1) * (2 * W);
+            if (lane == 0) { r[2 * wave] = m; r[2 * wave + 1] = kmin; }
+            __syncthreads();
+            m = r[0]; kmin = r[1];
+#pragma unroll
+            for (int w = 1; w < W; ++w) {
+                const uint32_t mw = r[2 * w], kw = r[2 * w + 1];
+                const bool take = (mw > m) || (mw == m && kw < kmin);
+                m = take ? mw : m;
+                kmin = take ? kw : kmin;
+            }
+        }
+        const int old = (m == 0u) ? 0 : (int)(kmin & 0x7FFFu);
+        x1 = coord(old, 0); y1 = coord(old, 1); z1 = coord(old, 2);
+        if (tid == 0) {
+            idx[(size_t)b * M + j] = old;
+            if (centers) {
+                float *c = centers + ((size_t)b * M + j) * 3;
+                c[0] = x1; c[1] = y1; c[2] = z1;
+            }
+        }
+    }
+}
+
+int ilog2_floor(int v) { int l = 0; while ((1 << (l + 1)) <= v) ++l; return l; }
+
+// pointnet2_ops cuda_utils.h opt_n_threads(): through double log, as upstream.
+int fps_block_size(int n) {
+    const int pow_2 = (int)(log((double)n) / log(2.0));
+    int t = 1 << pow_2;
+    if (t > 512) t = 512;
+    if (t < 1) t = 1;
+    return t;
+}
+
+constexpr int kFpsLdsMaxN = 8192;  // 96 KiB cloud copy
+
+template <int S, int W>
+int launch(const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom &g, hipStream_t st) {
+    if (g.N <= kFpsLdsMaxN) {
+        const size_t lds_bytes = (size_t)(4 * W + 3 * g.N) * 4;
+        if (lds_bytes > 64 * 1024) {
+            static bool raised = false;  // one attribute call per instantiation
+            if (!raised) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fps_kernel<S, W, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (4 * W + 3 * kFpsLdsMaxN) * 4);
+                if (e != hipSuccess) return (int)e;
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL((fps_kernel<S, W, true>), dim3(B), dim3(64 * W), lds_bytes, st, xyz, idx, centers, g);
+    } else {
+        hipLaunchKernelGGL((fps_kernel<S, W, false>), dim3(B), dim3(64 * W), (size_t)(4 * W) * 4, st, xyz, idx, centers, g);
+    }
+    return upp_launch_status();
+}
+
+template <int W>
+int dispatch_s(int slots, const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom &g, hipStream_t st) {
+    if (slots <= 1) return launch<1, W>(xyz, idx, centers, B, g, st);
+    if (slots <= 2) return launch<2, W>(xyz, idx, centers, B, g, st);
+    if (slots <= 4) return launch<4, W>(xyz, idx, centers, B, g, st);
+    if (slots <= 8) return launch<8, W>(xyz, idx, centers, B, g, st);
+    if (slots <= 16) return launch<16, W>(xyz, idx, centers, B, g, st);
+    if (slots <= 32) return launch<32, W>(xyz, idx, centers, B, g, st);
+    if (slots <= 64) return launch<64, W>(xyz, idx, centers, B, g, st);
+    return UPP_E_RANGE;
+}
+
+int g_fps_waves = 0;  // 0 = heuristic; set through upp_fps_set_waves (tuning hook)
+
+}  // namespace
+
+extern "C" int upp_fps_set_waves(int w) {
+    if (w != 0 && w != 1 && w != 2 && w != 4 && w != 8) return UPP_E_BADARG;
+    g_fps_waves = w;
+    return 0;
+}
+
+extern "C" int upp_fps(const float *xyz, int32_t *idx, float *centers, int B, int N, int M, void *stream) {
+    if (!xyz || !idx || B < 0 || N < 1 || M < 1) return UPP_E_BADARG;
+    if (N > 32768) return UPP_E_RANGE;  // 15-bit point ids, 64 slots x 512 lanes
+    if (B == 0) return 0;
+    FpsGeom g;
+    g.N = N; g.M = M;
+    g.T = fps_block_size(N);
+    g.log2T = ilog2_floor(g.T);
+    g.Q = (N + g.T - 1) / g.T;
+    // waves per cloud: never more lanes than virtual threads
+    int W = g_fps_waves ? g_fps_waves : (N <= 128 ? 1 : (N <= 512 ? 2 : 4));
+    while (W > 1 && 64 * W > g.T) W >>= 1;
+    while (W < 8 && 64 * W < g.T && (g.T / (64 * W)) * g.Q > 64) W <<= 1;  // at most 64 slots per lane
+    const int L = 64 * W;
+    g.U = g.T / L > 0 ? g.T / L : 1;
+    g.log2U = ilog2_floor(g.U);
+    const int slots = g.U * g.Q;
+    hipStream_t st = (hipStream_t)stream;
+    switch (W) {
+        case 1: return dispatch_s<1>(slots, xyz, idx, centers, B, g, st);
+        case 2: return dispatch_s<2>(slots, xyz, idx, centers, B, g, st);
+        case 4: return dispatch_s<4>(slots, xyz, idx, centers, B, g, st);
+        default: return dispatch_s<8>(slots, xyz, idx, centers, B, g, st);
+    }
+}

@@ -1,0 +1,151 @@
+"""Autograd Functions over upp_hip.ops with the reference operators' contracts."""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+class FurthestPointSampling(Function):
+    """pointnet2_utils.furthest_point_sample: (B,N,3) f32, npoint -> (B,npoint) int32, non-differentiable."""
+
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        idx = ops.fps(xyz, npoint)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return None, None
+
+
+class GatherOperation(Function):
+    """pointnet2_utils.gather_operation: features (B,C,N), idx (B,M) int32 -> (B,C,M); grad w.r.t. features."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.save_for_backward(idx)
+        ctx.N = features.shape[2]
+        return ops.gather_fwd(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return ops.gather_bwd(grad_out.contiguous(), idx, ctx.N), None
+
+
+class _FpsGather(Function):
+    """FPS + coordinate gather in one launch (reference utils/misc.py:13-20 fps())."""
+
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        idx, centers = ops.fps(xyz, npoint, want_centers=True)
+        ctx.save_for_backward(idx)
+        ctx.N = xyz.shape[1]
+        ctx.mark_non_differentiable(idx)
+        return centers, idx
+
+    @staticmethod
+    def backward(ctx, grad_centers, _grad_idx):
+        (idx,) = ctx.saved_tensors
+        B, M = idx.shape
+        gx, _ = ops.group_bwd(grad_centers.contiguous().view(B, M, 1, 3), idx.long().view(B, M, 1), ctx.N,
+                              need_xyz=True, need_center=False)
+        return gx, None
+
+
+class _KnnGroup(Function):
+    """kNN + neighbourhood gather + centre subtraction in one launch
+    (reference models/Point_MAE_unify.py:69-88).  Differentiable w.r.t. xyz and center
+    through the gather/subtraction, not through the neighbour selection."""
+
+    @staticmethod
+    def forward(ctx, xyz, center, k):
+        _, idx, neigh = ops.knn(xyz, center, k, want_dist=False, want_neigh=True)
+        ctx.save_for_backward(idx)
+        ctx.N = xyz.shape[1]
+        ctx.mark_non_differentiable(idx)
+        return neigh, idx
+
+    @staticmethod
+    def backward(ctx, grad_neigh, _grad_idx):
+        (idx,) = ctx.saved_tensors
+        gx, gc = ops.group_bwd(grad_neigh.contiguous(), idx, ctx.N,
+                               need_xyz=ctx.needs_input_grad[0], need_center=ctx.needs_input_grad[1])
+        return gx, gc, None
+
+
+class _GroupPoints(Function):
+    """out[b,g,k] = xyz[b, idx[b,g,k]] - center[b,g] for given indices."""
+
+    @staticmethod
+    def forward(ctx, xyz, center, idx):
+        ctx.save_for_backward(idx)
+        ctx.N = xyz.shape[1]
+        return ops.group_fwd(xyz, center, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        gx, gc = ops.group_bwd(grad_out.contiguous(), idx, ctx.N,
+                               need_xyz=ctx.needs_input_grad[0], need_center=ctx.needs_input_grad[1])
+        return gx, gc, None
+
+
+class ChamferFunction(Function):
+    """extensions.chamfer_dist.ChamferFunction (reference extensions/chamfer_dist/__init__.py:13-25)."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        dist1, dist2, idx1, idx2 = ops.chamfer_fwd(xyz1, xyz2)
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        return dist1, dist2
+
+    @staticmethod
+    def backward(ctx, grad_dist1, grad_dist2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        return ops.chamfer_bwd(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)
+
+
+class EarthMoverDistanceFunction(Function):
+    """extensions.emd.emd.EarthMoverDistanceFunction (reference extensions/emd/emd.py:5-21)."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        xyz1 = xyz1.contiguous()
+        xyz2 = xyz2.contiguous()
+        assert xyz1.is_cuda and xyz2.is_cuda, "Only support cuda currently."
+        match = ops.emd_approxmatch(xyz1, xyz2)
+        cost = ops.emd_matchcost(xyz1, xyz2, match)
+        ctx.save_for_backward(xyz1, xyz2, match)
+        return cost
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        xyz1, xyz2, match = ctx.saved_tensors
+        return ops.emd_matchcost_bwd(grad_cost.contiguous(), xyz1, xyz2, match)
+
+
+furthest_point_sample = FurthestPointSampling.apply
+gather_operation = GatherOperation.apply
+
+
+def fps_gather(xyz, npoint):
+    """-> (centers (B,npoint,3), idx (B,npoint) int32)."""
+    return _FpsGather.apply(xyz, int(npoint))
+
+
+def knn_query(ref, query, k):
+    """-> (dist (B,Q,k) f32, idx (B,Q,k) int64); no gradient (the reference wraps it in no_grad)."""
+    with torch.no_grad():
+        dist, idx, _ = ops.knn(ref, query, k, want_dist=True, want_neigh=False)
+    return dist, idx
+
+
+def knn_group(xyz, center, k):
+    """-> (neighborhood (B,G,k,3) centred on `center`, idx (B,G,k) int64)."""
+    return _KnnGroup.apply(xyz, center, int(k))
+
+
+def group_points(xyz, center, idx):
+    return _GroupPoints.apply(xyz, center, idx)

@@ -1,0 +1,190 @@
+"""Torch-facing operators over the C ABI (include/upp_hip.h).
+
+Each function validates its tensors the way the reference extensions do
+(device, dtype, contiguity, shape), allocates outputs with torch (the library
+never allocates), and enqueues the HIP kernels on torch's current stream.
+CPU tensors raise: there is no fallback path.
+"""
+import torch
+
+from . import _abi
+
+
+def _need(t, name, dtype, ndim=None, last=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a HIP (cuda) tensor; upp_hip has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"{name} must have {ndim} dims, got {tuple(t.shape)}")
+    if last is not None and t.shape[-1] != last:
+        raise RuntimeError(f"{name} last dim must be {last}, got {tuple(t.shape)}")
+
+
+def _same_device(*ts):
+    d = ts[0].device
+    for t in ts[1:]:
+        if t.device != d:
+            raise RuntimeError("all tensors must be on the same device")
+
+
+def _call(dev, name, *args):
+    """Enqueue one C-ABI entry point on `dev`'s current stream; raise on a non-zero status."""
+    with torch.cuda.device(dev):
+        _abi.check(getattr(_abi.load(), name)(*args, _abi.stream()))
+
+
+# ------------------------------------------------------------------ FPS / gather
+def fps(xyz, npoint, want_centers=False):
+    """(B,N,3) f32 -> idx (B,npoint) int32 [, centers (B,npoint,3)]."""
+    _need(xyz, "xyz", torch.float32, 3, 3)
+    B, N, _ = xyz.shape
+    npoint = int(npoint)
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    centers = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if want_centers else None
+    _call(xyz.device, "upp_fps", _abi.ptr(xyz), _abi.ptr(idx), _abi.ptr(centers), B, N, npoint)
+    return (idx, centers) if want_centers else idx
+
+
+def gather_fwd(features, idx):
+    _need(features, "features", torch.float32, 3)
+    _need(idx, "idx", torch.int32, 2)
+    _same_device(features, idx)
+    B, C, N = features.shape
+    M = idx.shape[1]
+    out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)
+    _call(features.device, "upp_gather_fwd", _abi.ptr(features), _abi.ptr(idx), _abi.ptr(out), B, C, N, M)
+    return out
+
+
+def gather_bwd(grad_out, idx, N):
+    _need(grad_out, "grad_out", torch.float32, 3)
+    _need(idx, "idx", torch.int32, 2)
+    B, C, M = grad_out.shape
+    grad = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+    _call(grad_out.device, "upp_gather_bwd", _abi.ptr(grad_out), _abi.ptr(idx), _abi.ptr(grad), B, C, N, M)
+    return grad
+
+
+# ------------------------------------------------------------------ kNN / group
+def knn(ref, query, k, want_dist=True, want_neigh=False):
+    """ref (B,N,3), query (B,Q,3) -> dist (B,Q,k) f32 | None, idx (B,Q,k) int64 [, neigh (B,Q,k,3)]."""
+    _need(ref, "ref", torch.float32, 3, 3)
+    _need(query, "query", torch.float32, 3, 3)
+    _same_device(ref, query)
+    B, N, _ = ref.shape
+    Q = query.shape[1]
+    if query.shape[0] != B:
+        raise RuntimeError("ref and query batch sizes differ")
+    k = int(k)
+    idx = torch.empty((B, Q, k), dtype=torch.int64, device=ref.device)
+    dist = torch.empty((B, Q, k), dtype=torch.float32, device=ref.device) if want_dist else None
+    neigh = torch.empty((B, Q, k, 3), dtype=torch.float32, device=ref.device) if want_neigh else None
+    _call(ref.device, "upp_knn", _abi.ptr(ref), _abi.ptr(query), _abi.ptr(dist), _abi.ptr(idx), _abi.ptr(neigh), B, N, Q, k)
+    return dist, idx, neigh
+
+
+def group_fwd(xyz, center, idx):
+    _need(xyz, "xyz", torch.float32, 3, 3)
+    _need(center, "center", torch.float32, 3, 3)
+    _need(idx, "idx", torch.int64, 3)
+    _same_device(xyz, center, idx)
+    B, N, _ = xyz.shape
+    _, G, K = idx.shape
+    out = torch.empty((B, G, K, 3), dtype=torch.float32, device=xyz.device)
+    _call(xyz.device, "upp_group_fwd", _abi.ptr(xyz), _abi.ptr(center), _abi.ptr(idx), _abi.ptr(out), B, N, G, K)
+    return out
+
+
+def group_bwd(grad_out, idx, N, need_xyz=True, need_center=True):
+    _need(grad_out, "grad_out", torch.float32, 4, 3)
+    _need(idx, "idx", torch.int64, 3)
+    B, G, K = idx.shape
+    gx = torch.zeros((B, N, 3), dtype=torch.float32, device=grad_out.device) if need_xyz else None
+    gc = torch.empty((B, G, 3), dtype=torch.float32, device=grad_out.device) if need_center else None
+    _call(grad_out.device, "upp_group_bwd", _abi.ptr(grad_out), _abi.ptr(idx), _abi.ptr(gx), _abi.ptr(gc), B, N, G, K)
+    return gx, gc
+
+
+# ------------------------------------------------------------------ Chamfer
+def chamfer_fwd(xyz1, xyz2):
+    _need(xyz1, "xyz1", torch.float32, 3, 3)
+    _need(xyz2, "xyz2", torch.float32, 3, 3)
+    _same_device(xyz1, xyz2)
+    B, n, _ = xyz1.shape
+    if xyz2.shape[0] != B:
+        raise RuntimeError("xyz1 and xyz2 batch sizes differ")
+    m = xyz2.shape[1]
+    dev = xyz1.device
+    dist1 = torch.empty((B, n), dtype=torch.float32, device=dev)
+    dist2 = torch.empty((B, m), dtype=torch.float32, device=dev)
+    idx1 = torch.empty((B, n), dtype=torch.int32, device=dev)
+    idx2 = torch.empty((B, m), dtype=torch.int32, device=dev)
+    _call(xyz1.device, "upp_chamfer_fwd", _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(dist1), _abi.ptr(dist2),
+          _abi.ptr(idx1), _abi.ptr(idx2), B, n, m)
+    return dist1, dist2, idx1, idx2
+
+
+def chamfer_bwd(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2):
+    _need(xyz1, "xyz1", torch.float32, 3, 3)
+    _need(xyz2, "xyz2", torch.float32, 3, 3)
+    _need(idx1, "idx1", torch.int32, 2)
+    _need(idx2, "idx2", torch.int32, 2)
+    grad_dist1 = grad_dist1.contiguous()
+    grad_dist2 = grad_dist2.contiguous()
+    _need(grad_dist1, "grad_dist1", torch.float32, 2)
+    _need(grad_dist2, "grad_dist2", torch.float32, 2)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1 = torch.zeros_like(xyz1)
+    g2 = torch.zeros_like(xyz2)
+    _call(xyz1.device, "upp_chamfer_bwd", _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(idx1), _abi.ptr(idx2),
+          _abi.ptr(grad_dist1), _abi.ptr(grad_dist2), _abi.ptr(g1), _abi.ptr(g2), B, n, m)
+    return g1, g2
+
+
+# ------------------------------------------------------------------ EMD
+def emd_approxmatch(xyz1, xyz2):
+    _need(xyz1, "xyz1", torch.float32, 3, 3)
+    _need(xyz2, "xyz2", torch.float32, 3, 3)
+    _same_device(xyz1, xyz2)
+    B, n, _ = xyz1.shape
+    if xyz2.shape[0] != B:
+        raise RuntimeError("xyz1 and xyz2 batch sizes differ")
+    m = xyz2.shape[1]
+    match = torch.empty((B, m, n), dtype=torch.float32, device=xyz1.device)
+    nwork = int(_abi.load().upp_emd_work_floats(B, n, m))
+    work = torch.empty((max(nwork, 1),), dtype=torch.float32, device=xyz1.device)
+    _call(xyz1.device, "upp_emd_approxmatch", _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(match), _abi.ptr(work), B, n, m)
+    return match
+
+
+def emd_matchcost(xyz1, xyz2, match):
+    _need(xyz1, "xyz1", torch.float32, 3, 3)
+    _need(xyz2, "xyz2", torch.float32, 3, 3)
+    _need(match, "match", torch.float32, 3)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    if tuple(match.shape) != (B, m, n):
+        raise RuntimeError("match must be (B, n2, n1)")
+    cost = torch.empty((B,), dtype=torch.float32, device=xyz1.device)
+    _call(xyz1.device, "upp_emd_matchcost", _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(match), _abi.ptr(cost), B, n, m)
+    return cost
+
+
+def emd_matchcost_bwd(grad_cost, xyz1, xyz2, match):
+    _need(grad_cost, "grad_cost", torch.float32, 1)
+    _need(xyz1, "xyz1", torch.float32, 3, 3)
+    _need(xyz2, "xyz2", torch.float32, 3, 3)
+    _need(match, "match", torch.float32, 3)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1 = torch.empty_like(xyz1)
+    g2 = torch.empty_like(xyz2)
+    _call(xyz1.device, "upp_emd_matchcost_bwd", _abi.ptr(grad_cost), _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(match),
+          _abi.ptr(g1), _abi.ptr(g2), B, n, m)
+    return g1, g2

@@ -1,0 +1,76 @@
+"""Data-parallel plumbing (reference utils/dist_utils.py:9-54).
+
+backend='nccl' on PyTorch-ROCm is RCCL; inside one MI355X node the transport is xGMI.
+The hot path itself never communicates: training shards the batch across ranks and
+exchanges ONE flat buffer of trainable gradients per step (FlatGradAllReduce)."""
+import os
+
+import torch
+from torch import distributed as dist
+
+
+def init_dist(launcher, backend='nccl', **kwargs):
+    if launcher != 'pytorch':
+        raise ValueError(f'Invalid launcher type: {launcher}')
+    rank = int(os.environ['RANK'])
+    local_rank = int(os.environ.get('LOCAL_RANK', rank))
+    if backend == 'nccl':
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    dist.init_process_group(backend=backend, **kwargs)
+
+
+def get_dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def reduce_tensor(tensor, args=None):
+    """mean over ranks (reference :41-48)"""
+    rt = tensor.clone()
+    dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+    rt /= (args.world_size if args is not None else dist.get_world_size())
+    return rt
+
+
+def gather_tensor(tensor, args=None):
+    world = args.world_size if args is not None else dist.get_world_size()
+    out = [tensor.clone() for _ in range(world)]
+    dist.all_gather(out, tensor)
+    return torch.cat(out, dim=0)
+
+
+class FlatGradAllReduce:
+    """Gradient exchange for batch-parallel training: every trainable parameter's .grad is a
+    view into one contiguous f32 buffer, so a step needs exactly one all-reduce (2.48 MB for
+    the 619,176 PEFT-stage parameters: latency-bound on xGMI, so one message beats buckets).
+    Two extra slots at the end carry scalars to average for logging (loss, acc), replacing
+    the reference's two separate scalar all-reduces (tools/runner_module.py:209-212).
+
+    Freeze first, then construct (the reference wraps in DDP before freezing, which would
+    all-reduce 30.4 M parameters: tools/runner_module.py:53 vs :68-73)."""
+
+    def __init__(self, params, extra_scalars=2):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        n = sum(p.numel() for p in self.params)
+        self.numel = n
+        self.flat = torch.zeros(n + extra_scalars, device=dev, dtype=dt)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.scalars = self.flat[n:]
+
+    def zero(self):
+        self.flat.zero_()
+
+    def reduce(self, average=True):
+        """SUM over ranks then divide by world size; no-op without a process group."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if average:
+            self.flat /= dist.get_world_size()

@@ -1,0 +1,131 @@
+/*
+ * upp_hip.h -- C ABI of libupp_hip.so, the MI355X (gfx950) implementation of
+ * the UPP / Point-MAE hot-path operators.
+ *
+ * This is the drop-in boundary: every entry point replaces one native
+ * operator the reference binds through a torch C++/CUDA extension (file:line
+ * of the replaced interface is cited per function).  The signatures use only
+ * plain device pointers, sizes and a HIP stream (passed as void*): no torch
+ * types, no allocation inside the library, no global state.  The caller owns
+ * every buffer (including scratch) and the library never synchronises; all
+ * work is enqueued on `stream` (hipStream_t; NULL = the default stream).
+ *
+ * Return value: 0 on success; a negative UPP_E_* code for an argument the
+ * kernels cannot serve (nothing is launched); a positive value is a
+ * hipError_t from the launch.  upp_error_string() renders either.
+ *
+ * All tensors are dense row-major ("contiguous") f32 unless noted; indices
+ * are int32 or int64 exactly as the reference operators return them.
+ */
+#ifndef UPP_HIP_H
+#define UPP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UPP_ABI_VERSION 1
+
+#define UPP_E_BADARG   (-1)  /* null pointer / non-positive size                   */
+#define UPP_E_RANGE    (-2)  /* size outside what the kernels support (see below)  */
+#define UPP_E_KGTN     (-3)  /* kNN: k > number of reference points                */
+
+int         upp_abi_version(void);
+const char *upp_error_string(int code);
+
+/* ---- furthest point sampling ------------------------------------------------
+ * Replaces pointnet2_ops._ext.furthest_point_sampling(xyz, npoint)
+ * (pointnet2_ops 3.0.0 sampling_gpu.cu furthest_point_sampling_kernel; called
+ * from reference utils/misc.py:18, tools/runner_module.py:151,450).
+ *   xyz     (B,N,3) f32
+ *   idx     (B,M)   int32 out: idx[b,0] = 0, then the farthest-point sequence
+ *   centers (B,M,3) f32 out or NULL: xyz[b, idx[b,j]] (fuses the
+ *           gather_operation of utils/misc.py:19)
+ * Semantics reproduced: running min-distance initialised to 1e10, points with
+ * |p|^2 <= 1e-3 never sampled, ties broken exactly as the T-thread block
+ * reduction of the CUDA kernel does (T = min(512, 2^floor(log2 N))).
+ * Limits: 1 <= M, 1 <= N <= 32768. */
+int upp_fps(const float *xyz, int32_t *idx, float *centers,
+            int B, int N, int M, void *stream);
+
+/* ---- gather_operation ---------------------------------------------------------
+ * Replaces pointnet2_ops._ext.gather_points / gather_points_grad
+ * (sampling_gpu.cu gather_points_kernel / gather_points_grad_kernel; called
+ * from reference utils/misc.py:19).
+ *   feat (B,C,N) f32, idx (B,M) int32 -> out (B,C,M) f32
+ * Backward: grad_feat (B,C,N) must be zero-filled by the caller; grad_out
+ * (B,C,M) is scatter-added into it (f32 atomics, order unspecified -- as in
+ * the CUDA kernel). */
+int upp_gather_fwd(const float *feat, const int32_t *idx, float *out,
+                   int B, int C, int N, int M, void *stream);
+int upp_gather_bwd(const float *grad_out, const int32_t *idx, float *grad_feat,
+                   int B, int C, int N, int M, void *stream);
+
+/* ---- k nearest neighbours ------------------------------------------------------
+ * Replaces knn_cuda.KNN(k, transpose_mode=True).forward(ref, query)
+ * (KNN_CUDA 0.2 knn.cu cuComputeDistanceGlobal + cuInsertionSort +
+ * cuParallelSqrt, looped over the batch in Python; constructed at reference
+ * models/Point_MAE_unify.py:56, called :69).  One launch for the whole batch.
+ *   ref   (B,N,3) f32, query (B,Q,3) f32
+ *   dist  (B,Q,K) f32 out or NULL: Euclidean distances, ascending
+ *   idx   (B,Q,K) int64 out: 0-based, ordered by (distance, index)
+ *   neigh (B,Q,K,3) f32 out or NULL: ref[b, idx[b,q,j]] - query[b,q]  (fuses
+ *         the gather + centre subtraction of Group.forward,
+ *         models/Point_MAE_unify.py:73-88)
+ * Limits: 1 <= K <= min(N, 64). */
+int upp_knn(const float *ref, const float *query, float *dist, int64_t *idx, float *neigh,
+            int B, int N, int Q, int K, void *stream);
+
+/* ---- grouping gather (stand-alone) and its backward ----------------------------
+ * Replaces the torch indexing of Group.forward (reference
+ * models/Point_MAE_unify.py:73-88): out[b,g,k] = xyz[b, idx[b,g,k]] - center[b,g].
+ *   xyz (B,N,3), center (B,G,3), idx (B,G,K) int64 in [0,N), out (B,G,K,3)
+ * Backward: grad_xyz (B,N,3) must be zero-filled by the caller (scatter-add,
+ * f32 atomics); grad_center (B,G,3) is overwritten with -sum_k grad_out.
+ * Either gradient pointer may be NULL. */
+int upp_group_fwd(const float *xyz, const float *center, const int64_t *idx, float *out,
+                  int B, int N, int G, int K, void *stream);
+int upp_group_bwd(const float *grad_out, const int64_t *idx, float *grad_xyz, float *grad_center,
+                  int B, int N, int G, int K, void *stream);
+
+/* ---- Chamfer distance ----------------------------------------------------------
+ * Replaces chamfer.forward / chamfer.backward (reference
+ * extensions/chamfer_dist/chamfer_cuda.cpp:36-39, kernels chamfer.cu:15-145 and
+ * :173-201).
+ *   xyz1 (B,n,3), xyz2 (B,m,3)
+ *   dist1 (B,n) f32, idx1 (B,n) int32: squared distance to, and index of, the
+ *         nearest xyz2 point (lowest index among equal minima); dist2/idx2 the
+ *         other direction.
+ * Backward: g1 (B,n,3) and g2 (B,m,3) must be zero-filled by the caller; f32
+ * atomics as in chamfer.cu:194-199. */
+int upp_chamfer_fwd(const float *xyz1, const float *xyz2,
+                    float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
+                    int B, int n, int m, void *stream);
+int upp_chamfer_bwd(const float *xyz1, const float *xyz2, const int32_t *idx1, const int32_t *idx2,
+                    const float *grad_dist1, const float *grad_dist2, float *g1, float *g2,
+                    int B, int n, int m, void *stream);
+
+/* ---- approximate earth mover's distance ----------------------------------------
+ * Replaces emd_cuda.approxmatch_forward / matchcost_forward / matchcost_backward
+ * (reference extensions/emd/cuda/emd.cpp:23-27, kernels emd_kernel.cu:24-157,
+ * :199-242, :285-354).
+ *   xyz1 (B,n,3), xyz2 (B,m,3)
+ *   match (B,m,n) f32 out (overwritten)
+ *   work  f32 scratch of upp_emd_work_floats(B,n,m) elements
+ *   cost  (B) f32 out: sum_{k,l} |xyz1[k]-xyz2[l]|^2 * match[l,k]
+ *   grad1 (B,n,3), grad2 (B,m,3) out (overwritten); match is a constant.
+ * Limits: n, m >= 1. */
+long long upp_emd_work_floats(int B, int n, int m);
+int upp_emd_approxmatch(const float *xyz1, const float *xyz2, float *match, float *work,
+                        int B, int n, int m, void *stream);
+int upp_emd_matchcost(const float *xyz1, const float *xyz2, const float *match, float *cost,
+                      int B, int n, int m, void *stream);
+int upp_emd_matchcost_bwd(const float *grad_cost, const float *xyz1, const float *xyz2, const float *match,
+                          float *grad1, float *grad2, int B, int n, int m, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UPP_HIP_H */

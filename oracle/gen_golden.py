@@ -1,0 +1,113 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own model code (oracle/ref_shim.py)
+in the build container.  Committed together with its outputs; never runs on the GPU box.
+
+    python oracle/gen_golden.py
+
+Fixtures (all eval mode, key-seeded weights from tests/_seeded.py):
+  upp_model.npz    end-to-end logits of Point_MAE_unify: clean (B,1024,3) and noisy-train
+                   (B,1096,3, denoise + completion prompters), CE loss and gradients of a few
+                   PEFT-trainable tensors (+ L2 norm of every trainable gradient)
+  upp_modules.npz  per-module input/output pairs: Encoder, Attention, Block (downstream path
+                   with prompt propagation incl. the index-stride behaviour), TransformerDecoder,
+                   RectifyPrompter, propagate, Group index outputs
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+
+import _seeded  # noqa: E402
+import ref_shim  # noqa: E402
+
+PEFT_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'bnorm', 'cls_pos', 'cls_token',
+             'cls_head_finetune']  # reference tools/runner_module.py:62-66
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    R = ref_shim.load()
+    cfg = ref_shim.model_cfg()
+    model = R.MODELS.build(cfg)
+    _seeded.fill(model).eval()
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+
+    # ---------------- end to end
+    B = 2
+    clean = _seeded.unit_ball_clouds(B, 1024, seed=0)
+    noisy = _seeded.noisy_clouds(B, 1024, seed=0)
+    labels = torch.tensor([3, 17])
+    for name, p in model.named_parameters():
+        p.requires_grad_(any(k in name for k in PEFT_KEYS))
+    logits_clean = model(clean, completion_prompt=False, denoise=False, point_num=1024)
+    logits_noisy = model(noisy, completion_prompt=True, denoise=True, point_num=1024)
+    loss, acc = model.get_loss_acc(logits_noisy, labels)
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    keep = ['cls_token', 'cls_pos', 'blocks.blocks.0.downstream_prompts', 'blocks.blocks.5.downstream_adapter.ln1.weight',
+            'blocks.blocks.11.downstream_adapter.ln2.bias', 'blocks.blocks.2.bnorm.weight', 'cls_head_finetune.8.bias',
+            'cls_head_finetune.0.weight']
+    names = sorted(grads)
+    np.savez_compressed(
+        os.path.join(out_dir, "upp_model.npz"),
+        labels=labels.numpy(), logits_clean=logits_clean.detach().numpy(), logits_noisy=logits_noisy.detach().numpy(),
+        loss=loss.detach().numpy(), grad_names=np.array(names),
+        grad_norms=np.array([grads[n].norm().item() for n in names], dtype=np.float64),
+        **{"grad::" + k: grads[k].numpy() for k in keep})
+    print("logits_clean", logits_clean[0, :5].tolist(), "loss", loss.item(), "n_trainable", sum(g.numel() for g in grads.values()))
+
+    # ---------------- per module
+    mods = {}
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(7)
+        pts = _seeded.unit_ball_clouds(2, 1024, seed=3)
+        grp = model.group_divider
+        nb, center, idx, cidx = grp(pts, require_index=True, gather_idx=False)
+        mods.update(group_pts=pts, group_neighborhood=nb, group_center=center, group_idx=idx, group_center_idx=cidx)
+        tokens = model.encoder(nb)
+        mods.update(encoder_out=tokens)
+        x = torch.randn(2, 75, 384, generator=g)
+        mods.update(attn_in=x, attn_out=model.blocks.blocks[0].attn(x))
+        mods.update(mlp_out=model.blocks.blocks[0].mlp(x), adapter_out=model.blocks.blocks[0].downstream_adapter(x))
+        # Block, downstream path with propagation (gather_idx False -> flat, batch-offset indices)
+        lvl2 = R.uni.Group(num_group=32, group_size=8)
+        _, c2, c1_idx, c2_idx = lvl2(center, require_index=True, gather_idx=False)
+        xb = torch.randn(2, 65, 384, generator=g)
+        kw = dict(path='downstream', downstream_adapter=True, downstream_prompts=True, classification=True,
+                  center1=center, center1_idx=c1_idx, center2=c2, center2_idx=c2_idx, gather_idx=False,
+                  prompt_propagation_after=True)
+        mods.update(block_in=xb, block_center2=c2, block_c1_idx=c1_idx, block_c2_idx=c2_idx,
+                    block0_out=model.blocks.blocks[0](xb, **kw), block7_out=model.blocks.blocks[7](xb, **kw))
+        # same block with gather_idx=True indices (seg / pretask configs)
+        _, c2g, c1g, c2ig = lvl2(center, require_index=True, gather_idx=True)
+        kwg = dict(kw, center1_idx=c1g, center2_idx=c2ig, gather_idx=True)
+        mods.update(block0_gather_out=model.blocks.blocks[0](xb, **kwg))
+        xr = torch.randn(2, 32, 384, generator=g)
+        mods.update(rect_in=xr, block1_rectify_out=model.blocks.blocks[1](xr, path='rectify', rectify_adapter=True,
+                                                                          rectify_prompts=True, rectify_depth=3),
+                    block4_pretask_out=model.blocks.blocks[4](xr, path='pretask', pretask_adapter=True,
+                                                              pretask_prompts=True, pretask_depth=6))
+        xd = torch.randn(2, 64, 384, generator=g)
+        pd = torch.randn(2, 64, 384, generator=g)
+        mods.update(dec_in=xd, dec_pos=pd, dec_out=model.MAE_decoder(xd, pd, 32, pretask_adapter=True, path='pretask'))
+        npts = _seeded.noisy_clouds(2, 1024, seed=5)
+        c32 = center[:, :32].contiguous()
+        mods.update(rp_pts=npts, rp_center=c32, rp_tokens=xr, rp_out=model.rectify_prompter(npts, c32, xr))
+        p2 = torch.randn(2, 32, 384, generator=g)
+        p1 = torch.randn(2, 64, 384, generator=g)
+        mods.update(prop_p1=p1, prop_p2=p2, prop_out=R.uni.propagate(center, c2, p1, p2, de_neighbors=8, dist_e=1e-3))
+    np.savez_compressed(os.path.join(out_dir, "upp_modules.npz"),
+                        **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in mods.items()})
+    for f in ("upp_model.npz", "upp_modules.npz"):
+        print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

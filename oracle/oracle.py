@@ -1,0 +1,178 @@
+"""Python face of the CPU oracle (oracle/upp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.  numpy in, numpy out.
+
+Parity status: Chamfer / EMD restate the reference's in-tree CUDA and are pinned by the
+reference's own known answers (tests/test_oracle_golden.py).  FPS / gather / kNN restate
+third-party kernels that are not vendored in the reference (pointnet2_ops 3.0.0,
+KNN_CUDA 0.2) and that the reference never tests: PARITY UNPINNED for those three.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libupp_oracle.so")
+_lib = None
+
+_f = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i64 = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_int = ctypes.c_int
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "upp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        L.oracle_fps_block_size.argtypes = [_int]
+        L.oracle_fps.argtypes = [_f, _int, _int, _int, _i32, ctypes.c_void_p]
+        L.oracle_gather.argtypes = [_f, _i32, _f, _int, _int, _int, _int]
+        L.oracle_gather_grad.argtypes = [_f, _i32, _f, _int, _int, _int, _int]
+        L.oracle_knn.argtypes = [_f, _f, _int, _int, _int, _int, ctypes.c_void_p, _i64]
+        L.oracle_group.argtypes = [_f, _f, _i64, _f, _int, _int, _int, _int]
+        L.oracle_chamfer_fwd.argtypes = [_f, _f, _int, _int, _int, _f, _f, _i32, _i32]
+        L.oracle_chamfer_bwd.argtypes = [_f, _f, _i32, _i32, _f, _f, _int, _int, _int, _f, _f]
+        L.oracle_emd_approxmatch.argtypes = [_f, _f, _int, _int, _int, _f]
+        L.oracle_emd_matchcost.argtypes = [_f, _f, _f, _int, _int, _int, _f]
+        L.oracle_emd_matchcost_grad.argtypes = [_f, _f, _f, _f, _int, _int, _int, _f, _f]
+        L.oracle_num_threads.restype = _int
+        _lib = L
+    return _lib
+
+
+def _c(a, dt=np.float32):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def num_threads():
+    return lib().oracle_num_threads()
+
+
+def fps_block_size(n):
+    return lib().oracle_fps_block_size(int(n))
+
+
+def fps(xyz, npoint):
+    xyz = _c(xyz)
+    B, N, _ = xyz.shape
+    idx = np.empty((B, npoint), dtype=np.int32)
+    lib().oracle_fps(xyz, B, N, npoint, idx, None)
+    return idx
+
+
+def gather(feat, idx):
+    feat, idx = _c(feat), _c(idx, np.int32)
+    B, C, N = feat.shape
+    M = idx.shape[1]
+    out = np.empty((B, C, M), dtype=np.float32)
+    lib().oracle_gather(feat, idx, out, B, C, N, M)
+    return out
+
+
+def gather_grad(grad_out, idx, N):
+    grad_out, idx = _c(grad_out), _c(idx, np.int32)
+    B, C, M = grad_out.shape
+    g = np.empty((B, C, N), dtype=np.float32)
+    lib().oracle_gather_grad(grad_out, idx, g, B, C, N, M)
+    return g
+
+
+def knn(ref, query, k, want_dist=True):
+    ref, query = _c(ref), _c(query)
+    B, N, _ = ref.shape
+    Q = query.shape[1]
+    idx = np.empty((B, Q, k), dtype=np.int64)
+    dist = np.empty((B, Q, k), dtype=np.float32) if want_dist else None
+    rc = lib().oracle_knn(ref, query, B, N, Q, k, dist.ctypes.data if want_dist else None, idx)
+    if rc != 0:
+        raise ValueError("oracle_knn: k must satisfy 1 <= k <= N")
+    return dist, idx
+
+
+def group(xyz, center, idx):
+    xyz, center, idx = _c(xyz), _c(center), _c(idx, np.int64)
+    B, N, _ = xyz.shape
+    _, G, K = idx.shape
+    out = np.empty((B, G, K, 3), dtype=np.float32)
+    lib().oracle_group(xyz, center, idx, out, B, N, G, K)
+    return out
+
+
+def chamfer_fwd(xyz1, xyz2):
+    xyz1, xyz2 = _c(xyz1), _c(xyz2)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = np.empty((B, n), np.float32); d2 = np.empty((B, m), np.float32)
+    i1 = np.empty((B, n), np.int32); i2 = np.empty((B, m), np.int32)
+    lib().oracle_chamfer_fwd(xyz1, xyz2, B, n, m, d1, d2, i1, i2)
+    return d1, d2, i1, i2
+
+
+def chamfer_bwd(xyz1, xyz2, idx1, idx2, gd1, gd2):
+    xyz1, xyz2 = _c(xyz1), _c(xyz2)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1 = np.empty((B, n, 3), np.float32); g2 = np.empty((B, m, 3), np.float32)
+    lib().oracle_chamfer_bwd(xyz1, xyz2, _c(idx1, np.int32), _c(idx2, np.int32), _c(gd1), _c(gd2), B, n, m, g1, g2)
+    return g1, g2
+
+
+def emd_approxmatch(xyz1, xyz2):
+    xyz1, xyz2 = _c(xyz1), _c(xyz2)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    match = np.empty((B, m, n), np.float32)
+    lib().oracle_emd_approxmatch(xyz1, xyz2, B, n, m, match)
+    return match
+
+
+def emd_matchcost(xyz1, xyz2, match):
+    xyz1, xyz2, match = _c(xyz1), _c(xyz2), _c(match)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    cost = np.empty((B,), np.float32)
+    lib().oracle_emd_matchcost(xyz1, xyz2, match, B, n, m, cost)
+    return cost
+
+
+def emd_matchcost_grad(grad_cost, xyz1, xyz2, match):
+    xyz1, xyz2, match = _c(xyz1), _c(xyz2), _c(match)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1 = np.empty((B, n, 3), np.float32); g2 = np.empty((B, m, 3), np.float32)
+    lib().oracle_emd_matchcost_grad(_c(grad_cost), xyz1, xyz2, match, B, n, m, g1, g2)
+    return g1, g2
+
+
+# ---------------------------------------------------------------- torch-facing stand-ins (tests only)
+def torch_ops():
+    """Oracle-backed callables with the signatures of models.upp_layers.OPS, for running the
+    model on a GPU-less host in tests.  Differentiable w.r.t. the coordinates through torch
+    gathers (indices come from the oracle)."""
+    import torch
+
+    def fps_gather(xyz, npoint):
+        idx = torch.from_numpy(fps(xyz.detach().cpu().numpy(), int(npoint))).to(xyz.device)
+        centers = torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+        return centers, idx
+
+    def knn_group(xyz, center, k):
+        _, idx = knn(xyz.detach().cpu().numpy(), center.detach().cpu().numpy(), int(k), want_dist=False)
+        idx = torch.from_numpy(idx).to(xyz.device)
+        B, G, K = idx.shape
+        nb = torch.gather(xyz, 1, idx.reshape(B, G * K, 1).expand(-1, -1, 3)).reshape(B, G, K, 3)
+        return nb - center.unsqueeze(2), idx
+
+    return {"fps_gather": fps_gather, "knn_group": knn_group}

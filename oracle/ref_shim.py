@@ -1,0 +1,127 @@
+"""Import the reference's own model code (read-only /root/reference) in THIS container.
+
+TEST INFRASTRUCTURE, build-container only: used by oracle/gen_golden.py to produce the
+fixtures under tests/golden/.  Nothing here travels to the GPU box as an import: tests read
+only the .npz fixtures.
+
+The reference cannot be imported as shipped (circular import between
+Point_MAE_unify and Point_MAE_pretask_dev, undefined `pooling`, missing third-party CUDA
+packages).  The shim:
+  * stubs timm / easydict / ipdb / termcolor / pytorch3d / chamfer / emd_cuda,
+  * serves pointnet2_ops and knn_cuda from the CPU oracle (oracle/upp_oracle.c),
+  * breaks the import cycle in two phases and supplies `pooling` (SURVEY D.3 assumption).
+"""
+import importlib
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def available():
+    return os.path.isdir(os.path.join(REF, "models"))
+
+
+class EasyDict(dict):
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = EasyDict(v) if isinstance(v, dict) else v
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class DropPath(nn.Module):  # timm 0.4.5 semantics
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if not self.drop_prob or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        mask = (keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)).floor_()
+        return x.div(keep) * mask
+
+
+def pooling(x, transform):
+    """SURVEY D.3 (assumption; `pooling` is undefined in the reference)."""
+    lc = x.max(dim=2)[0] + x.mean(dim=2)
+    return transform(lc.permute(0, 2, 1)).permute(0, 2, 1)
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+_loaded = None
+
+
+def load():
+    """-> namespace with .uni (models.Point_MAE_unify), .dev (models.Point_MAE_pretask_dev), .MODELS, .EasyDict"""
+    global _loaded
+    if _loaded is not None:
+        return _loaded
+    if not available():
+        raise RuntimeError("reference tree not present")
+    sys.path.insert(0, _HERE)
+    import oracle as O
+
+    class KNN(nn.Module):
+        def __init__(self, k, transpose_mode=False):
+            super().__init__()
+            self.k, self.t = k, transpose_mode
+
+        def forward(self, ref, query):
+            assert self.t
+            d, i = O.knn(ref.detach().numpy(), query.detach().numpy(), self.k)
+            return torch.from_numpy(d), torch.from_numpy(i)
+
+    def furthest_point_sample(xyz, npoint):
+        return torch.from_numpy(O.fps(xyz.detach().numpy(), int(npoint)))
+
+    def gather_operation(features, idx):
+        return torch.gather(features, 2, idx.long().unsqueeze(1).expand(-1, features.shape[1], -1))
+
+    _mod('timm'); _mod('timm.models')
+    _mod('timm.models.layers', DropPath=DropPath, trunc_normal_=lambda t, std=.02: nn.init.trunc_normal_(t, std=std))
+    _mod('timm.scheduler', CosineLRScheduler=object)
+    _mod('ipdb'); _mod('termcolor', colored=lambda s, *a, **k: s)
+    _mod('easydict', EasyDict=EasyDict)
+    _mod('pytorch3d'); _mod('pytorch3d.ops'); _mod('chamfer'); _mod('emd_cuda')
+    _mod('knn_cuda', KNN=KNN)
+    p2u = _mod('pointnet2_ops.pointnet2_utils', furthest_point_sample=furthest_point_sample,
+               gather_operation=gather_operation)
+    _mod('pointnet2_ops', pointnet2_utils=p2u)
+    # keep our own drop-in packages out of the way: the reference must resolve ITS utils/models/extensions
+    for name in list(sys.modules):
+        if name.split('.')[0] in ('utils', 'models', 'extensions', 'emd'):
+            del sys.modules[name]
+    sys.path[:] = [p for p in sys.path if 'iccv2025-upp_amd' not in p]
+    sys.path[:0] = [REF, os.path.join(REF, 'extensions')]
+    pkg = types.ModuleType('models'); pkg.__path__ = [os.path.join(REF, 'models')]
+    sys.modules['models'] = pkg
+    fake = types.ModuleType('models.Point_MAE_unify')
+    fake.Group = fake.propagate = fake.pooling = None
+    sys.modules['models.Point_MAE_unify'] = fake
+    dev = importlib.import_module('models.Point_MAE_pretask_dev')
+    del sys.modules['models.Point_MAE_unify']
+    uni = importlib.import_module('models.Point_MAE_unify')
+    dev.Group, dev.propagate, dev.pooling = uni.Group, uni.propagate, pooling
+    from models.build import MODELS
+    _loaded = types.SimpleNamespace(uni=uni, dev=dev, MODELS=MODELS, EasyDict=EasyDict, pooling=pooling)
+    return _loaded
+
+
+def model_cfg():
+    import yaml
+    with open(os.path.join(REF, 'cfgs', 'unify_modelnet_cls.yaml')) as f:
+        return EasyDict(yaml.safe_load(f)['model'])

@@ -1,0 +1,63 @@
+"""The C-ABI library builds, loads on a GPU-less host and exports every symbol include/upp_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from upp_hip import _abi
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "upp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(upp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_abi.SIGNATURES), "ctypes table and header disagree"
+
+
+def test_version_and_error_strings():
+    lib = _abi.load()
+    assert lib.upp_abi_version() == 1
+    assert b"null pointer" in lib.upp_error_string(-1)
+    assert b"range" in lib.upp_error_string(-2)
+    assert b"knn" in lib.upp_error_string(-3)
+    assert lib.upp_emd_work_floats(2, 10, 20) == 2 * 30 * 11
+
+
+def test_argument_validation_happens_before_any_launch():
+    lib = _abi.load()
+    # null pointers / bad sizes are rejected on the host: no GPU is needed to see the error code
+    assert lib.upp_fps(None, None, None, 1, 8, 4, None) == -1
+    assert lib.upp_knn(None, None, None, None, None, 1, 8, 4, 2, None) == -1
+    assert lib.upp_chamfer_fwd(None, None, None, None, None, None, 1, 8, 8, None) == -1
+    with pytest.raises(RuntimeError, match="null pointer"):
+        _abi.check(-1)
+
+
+def test_cpu_tensors_are_rejected_not_silently_served():
+    from upp_hip import ops
+    from knn_cuda import KNN
+    from pointnet2_ops import pointnet2_utils
+    from extensions.chamfer_dist import ChamferDistanceL1
+    import emd
+    x = torch.rand(2, 16, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.fps(x, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pointnet2_utils.furthest_point_sample(x, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        KNN(k=4, transpose_mode=True)(x, x[:, :4])       # constructible without a GPU, unusable on CPU
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ChamferDistanceL1()(x, x)
+    with pytest.raises((RuntimeError, AssertionError)):
+        emd.emd()(x, x)

@@ -1,0 +1,263 @@
+"""Parity of the gfx950 kernels (through the C ABI) against the CPU oracle: bit-exact for FPS
+indices, kNN neighbour lists, gathers and Chamfer argmins / distances; stated tolerance for EMD.
+Run on the GPU box with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import _seeded
+import oracle as O
+from upp_hip import ops, functional as HF
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def clouds(B, N, kind, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "ball":
+        return _seeded.unit_ball_clouds(B, N, seed).numpy()
+    if kind == "sphere":   # surface-like: many near-ties for kNN
+        p = rng.standard_normal((B, N, 3))
+        p = p / np.linalg.norm(p, axis=-1, keepdims=True) + rng.normal(0, 0.01, (B, N, 3))
+        return p.astype(np.float32)
+    if kind == "lattice":  # exact ties everywhere
+        g = rng.integers(0, 6, (B, N, 3)).astype(np.float32) * 0.25 - 0.6
+        return g
+    if kind == "dup":      # duplicated points
+        p = rng.random((B, N, 3), dtype=np.float32) - 0.5
+        p[:, N // 2:] = p[:, : N - N // 2]
+        return p
+    raise ValueError(kind)
+
+
+FPS_SHAPES = [(32, 1024, 64), (4, 1096, 32), (4, 32, 32), (4, 972, 32), (4, 1024, 256), (3, 1228, 1024), (4, 64, 32),
+              (2, 1624, 32), (2, 1843, 1536), (2, 1536, 128), (2, 6144, 1024), (1, 8192, 64), (1, 9000, 33),
+              (3, 1, 1), (3, 2, 2), (2, 7, 7), (2, 63, 10), (2, 65, 65), (2, 129, 40), (2, 513, 100), (2, 300, 300)]
+
+
+@pytest.mark.parametrize("B,N,M", FPS_SHAPES)
+@pytest.mark.parametrize("kind", ["ball", "lattice"])
+def test_fps_indices_bit_exact(B, N, M, kind):
+    x = clouds(B, N, kind, seed=N * 7 + M)
+    want = O.fps(x, M)
+    idx, centers = ops.fps(dev(x), M, want_centers=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    np.testing.assert_array_equal(centers.cpu().numpy(), np.take_along_axis(x, want[..., None].astype(np.int64), 1))
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+def test_fps_every_wave_count_gives_the_same_answer(waves):
+    from upp_hip import _abi
+    x = clouds(4, 1228, "dup", 3)
+    want = O.fps(x, 300)
+    try:
+        assert _abi.load().upp_fps_set_waves(waves) == 0
+        np.testing.assert_array_equal(ops.fps(dev(x), 300).cpu().numpy(), want)
+    finally:
+        _abi.load().upp_fps_set_waves(0)
+
+
+def test_fps_origin_skip_rule():
+    x = _seeded.unit_ball_clouds(2, 1024, 11).numpy()
+    x[:, 100:108] *= 0.02 / np.linalg.norm(x[:, 100:108], axis=-1, keepdims=True)   # 8 points inside r = 0.0316
+    want = O.fps(x, 1024)
+    got = ops.fps(dev(x), 1024).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert not np.isin(got[:, 1:], np.arange(100, 108)).any()
+    z = np.zeros((2, 40, 3), np.float32)                  # nothing is ever a candidate -> index 0 repeated
+    np.testing.assert_array_equal(ops.fps(dev(z), 9).cpu().numpy(), 0)
+
+
+KNN_SHAPES = [(32, 1024, 64, 32), (4, 1096, 32, 16), (4, 32, 32, 16), (4, 972, 32, 16), (4, 64, 32, 8), (2, 1536, 128, 32),
+              (2, 1624, 32, 16), (2, 8192, 16, 4), (1, 5000, 9, 64), (2, 64, 64, 64), (3, 5, 3, 1), (2, 100, 7, 50), (2, 255, 5, 32),
+              (2, 256, 5, 32), (2, 4097, 3, 8)]
+
+
+@pytest.mark.parametrize("B,N,Q,K", KNN_SHAPES)
+@pytest.mark.parametrize("kind", ["ball", "sphere", "lattice", "dup"])
+def test_knn_neighbour_lists_bit_exact(B, N, Q, K, kind):
+    ref = clouds(B, N, kind, seed=N + Q + K)
+    rng = np.random.default_rng(1)
+    qry = ref[:, rng.permutation(N)[:Q]] if Q <= N else clouds(B, Q, kind, 5)
+    qry = np.ascontiguousarray(qry)
+    wd, wi = O.knn(ref, qry, K)
+    d, i, nb = ops.knn(dev(ref), dev(qry), K, want_dist=True, want_neigh=True)
+    np.testing.assert_array_equal(i.cpu().numpy(), wi)
+    np.testing.assert_array_equal(d.cpu().numpy(), wd)
+    np.testing.assert_array_equal(nb.cpu().numpy(), O.group(ref, qry, wi))
+
+
+def test_knn_prefilter_on_off_identical_and_errors():
+    from upp_hip import _abi
+    ref = clouds(3, 2000, "lattice", 2)
+    qry = np.ascontiguousarray(ref[:, :50])
+    _, wi = O.knn(ref, qry, 32)
+    try:
+        for on in (0, 1):
+            _abi.load().upp_knn_set_prefilter(on)
+            np.testing.assert_array_equal(ops.knn(dev(ref), dev(qry), 32)[1].cpu().numpy(), wi)
+    finally:
+        _abi.load().upp_knn_set_prefilter(1)
+    with pytest.raises(RuntimeError, match="exceeds"):
+        ops.knn(dev(ref[:, :10]), dev(qry), 11)
+    with pytest.raises(RuntimeError, match="range"):
+        ops.knn(dev(ref), dev(qry), 65)
+
+
+def test_knn_module_and_group_module_surfaces():
+    from knn_cuda import KNN
+    from models.upp_layers import Group
+    x = dev(clouds(4, 1024, "ball", 9))
+    nb, center, idx, cidx = Group(64, 32)(x, require_index=True, gather_idx=False)
+    xc = x.cpu().numpy()
+    wc = O.fps(xc, 64)
+    np.testing.assert_array_equal(cidx.cpu().numpy(), (wc + np.arange(4)[:, None] * 1024).reshape(-1))
+    cen = np.take_along_axis(xc, wc[..., None].astype(np.int64), 1)
+    _, wi = O.knn(xc, cen, 32)
+    np.testing.assert_array_equal(idx.cpu().numpy(), (wi + np.arange(4)[:, None, None] * 1024).reshape(-1))
+    np.testing.assert_array_equal(nb.cpu().numpy(), O.group(xc, cen, wi))
+    d, i = KNN(k=32, transpose_mode=True)(x, center)
+    assert i.dtype == torch.int64 and d.dtype == torch.float32
+    np.testing.assert_array_equal(i.cpu().numpy(), wi)
+    d2, i2 = KNN(k=32, transpose_mode=False)(x.transpose(1, 2).contiguous(), center.transpose(1, 2).contiguous())
+    np.testing.assert_array_equal(i2.transpose(1, 2).cpu().numpy(), wi)
+
+
+def test_gather_operation_forward_backward():
+    from pointnet2_ops import pointnet2_utils as p2
+    rng = np.random.default_rng(5)
+    feat = rng.random((3, 7, 200), dtype=np.float32)
+    idx = rng.integers(0, 200, (3, 50)).astype(np.int32)
+    f = dev(feat).requires_grad_(True)
+    out = p2.gather_operation(f, dev(idx))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), O.gather(feat, idx))
+    go = rng.random((3, 7, 50), dtype=np.float32)
+    out.backward(dev(go))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), O.gather_grad(go, idx, 200), rtol=1e-6, atol=1e-7)
+    idx2 = p2.furthest_point_sample(dev(feat.transpose(0, 2, 1)[:, :, :3].copy()), 10)
+    assert idx2.dtype == torch.int32 and not idx2.requires_grad
+
+
+def test_group_backward_scatter_add():
+    x = dev(clouds(2, 300, "ball", 1)).requires_grad_(True)
+    c, ci = HF.fps_gather(x, 20)
+    nb, idx = HF.knn_group(x, c, 12)
+    w = torch.rand_like(nb)
+    (nb * w).sum().backward()
+    xr = x.detach().clone().requires_grad_(True)
+    cr = torch.gather(xr, 1, ci.long().unsqueeze(-1).expand(-1, -1, 3))
+    nbr = torch.gather(xr, 1, idx.reshape(2, -1, 1).expand(-1, -1, 3)).reshape(2, 20, 12, 3) - cr.unsqueeze(2)
+    (nbr * w).sum().backward()
+    np.testing.assert_array_equal(nb.detach().cpu().numpy(), nbr.detach().cpu().numpy())
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+CH_SHAPES = [(32, 1024, 1024), (4, 32, 1024), (2, 2048, 8192), (38, 32, 32), (4, 64, 128), (3, 1, 1), (2, 70, 2049), (1, 5000, 3)]
+
+
+@pytest.mark.parametrize("B,n,m", CH_SHAPES)
+@pytest.mark.parametrize("kind", ["ball", "lattice"])
+def test_chamfer_forward_bit_exact_and_backward(B, n, m, kind):
+    a, b = clouds(B, n, kind, n + 1), clouds(B, m, kind, m + 2)
+    w1, w2, wi1, wi2 = O.chamfer_fwd(a, b)
+    d1, d2, i1, i2 = ops.chamfer_fwd(dev(a), dev(b))
+    np.testing.assert_array_equal(i1.cpu().numpy(), wi1)
+    np.testing.assert_array_equal(i2.cpu().numpy(), wi2)
+    np.testing.assert_array_equal(d1.cpu().numpy(), w1)
+    np.testing.assert_array_equal(d2.cpu().numpy(), w2)
+    rng = np.random.default_rng(0)
+    g1, g2 = rng.random((B, n), dtype=np.float32), rng.random((B, m), dtype=np.float32)
+    wg1, wg2 = O.chamfer_bwd(a, b, wi1, wi2, g1, g2)
+    hg1, hg2 = ops.chamfer_bwd(dev(a), dev(b), i1, i2, dev(g1), dev(g2))
+    # f32 atomics: summation order differs -> 1e-5 rel (north_star tolerance for Chamfer)
+    scale = max(np.abs(wg1).max(), np.abs(wg2).max(), 1e-6)
+    np.testing.assert_allclose(hg1.cpu().numpy(), wg1, rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(hg2.cpu().numpy(), wg2, rtol=1e-5, atol=1e-5 * scale)
+
+
+def test_chamfer_modules_and_autograd():
+    from extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2, ChamferDistanceL2_split, ChamferFunction
+    a, b = clouds(4, 64, "ball", 1), clouds(4, 128, "ball", 2)
+    w1, w2, _, _ = O.chamfer_fwd(a, b)
+    x, y = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+    l2 = ChamferDistanceL2().cuda()(x, y)
+    np.testing.assert_allclose(l2.item(), w1.mean() + w2.mean(), rtol=1e-5)
+    s1, s2 = ChamferDistanceL2_split()(x, y)
+    np.testing.assert_allclose([s1.item(), s2.item()], [w1.mean(), w2.mean()], rtol=1e-5)
+    l1 = ChamferDistanceL1()(x, y)
+    np.testing.assert_allclose(l1.item(), (np.sqrt(w1).mean() + np.sqrt(w2).mean()) / 2, rtol=1e-5)
+    l1.backward()
+    assert torch.isfinite(x.grad).all() and torch.isfinite(y.grad).all()
+    # gradcheck of the reference's extensions/chamfer_dist/test.py, by central differences on the f32 forward
+    x0 = x.detach().clone()
+    eps = 1e-3
+    for (bi, j, c) in [(0, 0, 0), (2, 33, 1)]:
+        xp, xm = x0.clone(), x0.clone()
+        xp[bi, j, c] += eps; xm[bi, j, c] -= eps
+        num = (ChamferDistanceL1()(xp, y.detach()) - ChamferDistanceL1()(xm, y.detach())).item() / (2 * eps)
+        assert abs(num - x.grad[bi, j, c].item()) < 5e-2 * max(abs(num), 1e-3) + 1e-5
+    one = dev(np.concatenate([a[:1], np.zeros((1, 5, 3), np.float32)], 1))
+    assert torch.isfinite(ChamferDistanceL2(ignore_zeros=True)(one, one))
+
+
+EMD_SHAPES = [(3, 2, 2), (4, 64, 64), (2, 96, 32), (2, 40, 100), (2, 300, 300), (8, 1024, 1024)]
+
+
+@pytest.mark.parametrize("B,n,m", EMD_SHAPES)
+def test_emd_against_oracle(B, n, m):
+    if (n, m) == (2, 2):
+        a = np.array([[[1.7, -0.1, 0.1], [0.1, 1.2, 0.3]]], np.float32).repeat(3, 0)     # reference test_emd_loss.py
+        b = np.array([[[0.3, 1.8, 0.2], [1.2, -0.2, 0.3]]], np.float32).repeat(3, 0)
+    else:
+        a, b = clouds(B, n, "ball", n), clouds(B, m, "ball", m + 1)
+    wm = O.emd_approxmatch(a, b)
+    wc = O.emd_matchcost(a, b, wm)
+    hm = ops.emd_approxmatch(dev(a), dev(b))
+    hc = ops.emd_matchcost(dev(a), dev(b), hm)
+    # the reference uses the approximate __expf (so does the HIP kernel) and the oracle expf: tolerance-based
+    np.testing.assert_allclose(hm.cpu().numpy(), wm, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(hc.cpu().numpy(), wc, rtol=1e-4)
+    # cost / gradients for a FIXED match are plain sums: tight tolerance
+    hc2 = ops.emd_matchcost(dev(a), dev(b), dev(wm))
+    np.testing.assert_allclose(hc2.cpu().numpy(), wc, rtol=2e-5)
+    gc = np.linspace(0.5, 2.0, B).astype(np.float32)
+    wg1, wg2 = O.emd_matchcost_grad(gc, a, b, wm)
+    hg1, hg2 = ops.emd_matchcost_bwd(dev(gc), dev(a), dev(b), dev(wm))
+    np.testing.assert_allclose(hg1.cpu().numpy(), wg1, rtol=1e-4, atol=1e-5 * np.abs(wg1).max())
+    np.testing.assert_allclose(hg2.cpu().numpy(), wg2, rtol=1e-4, atol=1e-5 * np.abs(wg2).max())
+    if (n, m) == (2, 2):
+        np.testing.assert_allclose(hc.cpu().numpy(), 0.71, rtol=1e-5)
+
+
+def test_emd_module_surface():
+    import emd
+    a, b = dev(clouds(4, 128, "ball", 1)).requires_grad_(True), dev(clouds(4, 128, "ball", 2)).requires_grad_(True)
+    loss = emd.emd()(a, b)
+    assert loss.dim() == 0
+    loss.backward()
+    assert torch.isfinite(a.grad).all() and a.grad.abs().sum() > 0 and b.grad.abs().sum() > 0
+    m = O.emd_approxmatch(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+    want = (O.emd_matchcost(a.detach().cpu().numpy(), b.detach().cpu().numpy(), m) / 128).mean()
+    np.testing.assert_allclose(loss.item(), want, rtol=1e-4)
+
+
+def test_full_size_properties():
+    """BASELINE sizes: size-independent properties on top of the oracle comparisons above."""
+    x = dev(clouds(32, 1024, "ball", 42))
+    c, ci = HF.fps_gather(x, 64)
+    assert (ci[:, 0] == 0).all()
+    assert all(len(set(r.tolist())) == 64 for r in ci.cpu())               # a sample never repeats on distinct points
+    nb, idx = HF.knn_group(x, c, 32)
+    d = nb.norm(dim=-1)
+    assert (d[:, :, 0] == 0).all()                                         # a centre is its own nearest neighbour
+    assert (d[:, :, 1:] >= d[:, :, :-1] - 1e-6).all()                      # sortedness
+    assert idx.min() >= 0 and idx.max() < 1024
+    d1, d2, i1, i2 = ops.chamfer_fwd(x, x)
+    assert (d1 == 0).all() and (i1.cpu() == torch.arange(1024)).all()       # identical clouds: zero distance, identity map
+    perm = torch.randperm(1024, device='cuda')
+    e1, e2, _, _ = ops.chamfer_fwd(x, x[:, perm].contiguous())
+    assert (e1 == 0).all() and (e2 == 0).all()                             # permutation invariance

@@ -1,0 +1,48 @@
+"""Host-side mirror of the reference interface: registry, config, misc helpers."""
+import pytest
+import torch
+
+from utils import registry
+from utils.config import EasyDict, builtin_cfg
+from utils import misc
+
+
+def test_registry_contract():
+    R = registry.Registry('things')
+
+    @R.register_module()
+    class Foo:
+        def __init__(self, cfg):
+            self.v = cfg.v
+
+    assert R.get('Foo') is Foo and 'Foo' in R and len(R) == 1
+    assert R.build(EasyDict(NAME='Foo', v=3)).v == 3
+    with pytest.raises(KeyError, match='already registered'):
+        R.register_module()(Foo)
+    with pytest.raises(KeyError, match='not in the things registry'):
+        R.build(EasyDict(NAME='Bar'))
+    with pytest.raises(KeyError, match='NAME'):
+        R.build(EasyDict(v=1))
+    with pytest.raises(TypeError):
+        R.build([1, 2])
+    with pytest.raises(AttributeError, match='Foo'):       # constructor errors are re-raised naming the class
+        R.build(EasyDict(NAME='Foo'))
+
+
+def test_builtin_config_fields():
+    cfg = builtin_cfg('unify_modelnet_cls')
+    m = cfg.model
+    assert m.NAME == 'Point_MAE_unify' and m.num_group == 64 and m.group_size == 32
+    assert m.transformer_config.trans_dim == 384 and m.transformer_config.depth == 12
+    assert m.prompter_config['rectify_depth'] == 3 and dict(**m.prompter_config)['downstream_prompts_num'] == 10
+    assert m.gather_idx is False and m.prompt_propagation_after is True
+
+
+def test_misc_helpers():
+    assert misc.peft_detect('blocks.blocks.0.bnorm.weight', ['bnorm']) and not misc.peft_detect('norm.weight', ['bnorm'])
+    p = torch.rand(2, 100, 3)
+    n = misc.lidar_noise(p, 48, low=1.2, scale=1.5)
+    assert n.shape == (2, 48, 3)
+    g = misc.gaussian_noise([2, 24, 3], scale=0.1)
+    r = g.norm(dim=-1)
+    assert g.shape == (2, 24, 3) and (r > 0.5).all() and (r < 1.5).all()
