@@ -48,6 +48,7 @@ def lib():
         L.oracle_emd_matchcost.argtypes = [_f, _f, _f, _int, _int, _int, _f]
         L.oracle_emd_matchcost_grad.argtypes = [_f, _f, _f, _f, _int, _int, _int, _f, _f]
         L.oracle_num_threads.restype = _int
+        L.oracle_set_threads.argtypes = [_int]
         _lib = L
     return _lib
 
@@ -58,6 +59,10 @@ def _c(a, dt=np.float32):
 
 def num_threads():
     return lib().oracle_num_threads()
+
+
+def set_threads(n):
+    lib().oracle_set_threads(int(n))
 
 
 def fps_block_size(n):

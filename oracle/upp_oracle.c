@@ -443,6 +443,14 @@ void oracle_emd_matchcost_grad(const float *grad_cost, const float *xyz1, const 
     }
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -19,6 +19,8 @@ def dev(a):
 def clouds(B, N, kind, seed):
     rng = np.random.default_rng(seed)
     if kind == "ball":
+        if N < 4:   # centring + max-norm scaling degenerates (0/0) for tiny clouds
+            return (rng.random((B, N, 3), dtype=np.float32) - 0.5)
         return _seeded.unit_ball_clouds(B, N, seed).numpy()
     if kind == "sphere":   # surface-like: many near-ties for kNN
         p = rng.standard_normal((B, N, 3))
