@@ -27,57 +27,36 @@ for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.joi
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEFT_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'bnorm', 'cls_pos', 'cls_token',
-             'cls_head_finetune']  # reference tools/runner_module.py:62-66
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def build_model(device):
     from models import build_model_from_cfg
     from utils.config import builtin_cfg
+    from upp_hip.train import freeze_for_peft
     torch.manual_seed(0)
     model = build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model).to(device)
-    for name, p in model.named_parameters():
-        p.requires_grad_(any(k in name for k in PEFT_KEYS))       # freeze FIRST, then set up the exchange
+    freeze_for_peft(model)                                          # freeze FIRST, then set up the exchange
     return model
 
 
-def make_optimizer(model):
-    """AdamW, two groups (reference tools/builder.py:40-55): no decay for 1-D / bias / 'token' params."""
-    decay, no_decay = [], []
-    for name, p in model.named_parameters():
-        if not p.requires_grad:
-            continue
-        (no_decay if (p.dim() == 1 or name.endswith(".bias") or 'token' in name) else decay).append(p)
-    return torch.optim.AdamW([{'params': no_decay, 'weight_decay': 0.}, {'params': decay, 'weight_decay': 0.05}], lr=5e-4)
-
-
 class Trainer:
-    def __init__(self, device, batch, distributed):
+    """Synthetic-data wrapper around upp_hip.train.TrainStep (the product's step driver)."""
+
+    def __init__(self, device, batch, distributed, use_graph=True):
         import _seeded
-        from utils.dist_utils import FlatGradAllReduce
+        from upp_hip.train import TrainStep
         self.model = build_model(device).train()
-        self.opt = make_optimizer(self.model)
-        self.flat = FlatGradAllReduce(self.model.parameters())
-        self.trainable = self.flat.params
         rank = dist.get_rank() if distributed else 0
-        self.pts = _seeded.noisy_clouds(batch, 1024, seed=rank).to(device)       # (B,1096,3) resident in HBM
+        pts = _seeded.noisy_clouds(batch, 1024, seed=rank).to(device)             # (B,1096,3) resident in HBM
         g = torch.Generator().manual_seed(rank)
-        self.labels = torch.randint(0, 40, (batch,), generator=g).to(device)
-        self.distributed = distributed
+        labels = torch.randint(0, 40, (batch,), generator=g).to(device)
+        self.ts = TrainStep(self.model, tuple(pts.shape), use_graph=use_graph)
+        self.ts.pts.copy_(pts)
+        self.ts.labels.copy_(labels)
 
     def step(self):
-        self.flat.zero()
-        logits = self.model(self.pts, completion_prompt=True, denoise=True, point_num=1024)
-        loss, acc = self.model.get_loss_acc(logits, self.labels)
-        loss.backward()
-        self.flat.scalars[0] = loss.detach()
-        self.flat.scalars[1] = acc.detach()
-        if self.distributed:
-            self.flat.reduce()                     # ONE all-reduce: grads + the two logging scalars
-        torch.nn.utils.clip_grad_norm_(self.trainable, 10, norm_type=2)
-        self.opt.step()
-        return loss
+        return self.ts.step()
 
 
 def time_kernel(fn, iters=50, warm=5):
@@ -132,7 +111,7 @@ def cpu_baseline(budget_s=20.0):
         ops = oracle.torch_ops()
         upp_layers.OPS.update(ops)
         HF.fps_gather = ops["fps_gather"]
-        tr = Trainer(torch.device("cpu"), 4, False)
+        tr = Trainer(torch.device("cpu"), 4, False, use_graph=False)
         tr.step()                                   # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
@@ -157,6 +136,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (debug)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,7 +152,7 @@ def main():
     from upp_hip import _abi
     _abi.load()                                           # fail loudly if the HIP library is missing
 
-    tr = Trainer(device, args.batch, distributed)
+    tr = Trainer(device, args.batch, distributed, use_graph=not args.no_graph)
     for _ in range(args.warmup):
         tr.step()
 
@@ -203,7 +183,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Point_MAE_unify unify_modelnet_cls noisy-train fwd+bwd+AdamW, PEFT stage-1, "
                                    "B=%d/GPU x (1024+72) pts, G=64 k=32" % args.batch,
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "hip_graph": not args.no_graph},
             "roofline": {"kernel": "fps_kernel (B,1228)->1024", "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
                          "note": "FPS is a 1023-round serial dependency chain: latency-bound by construction"},

@@ -7,6 +7,7 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from utils import misc
 from .build import MODELS
@@ -134,7 +135,8 @@ class Point_MAE_unify(nn.Module):
         x_rec = self.MAE_decoder(torch.cat([x_vis, mask_token], dim=1), torch.cat([pos_vis, pos_mask], dim=1), N,
                                  pretask_adapter=True, path='pretask')
         M = x_rec.shape[1]
-        rel = self.dense_pred(x_rec.transpose(1, 2)).transpose(1, 2).reshape(B, M, -1, 3)
+        head = self.dense_pred[0]                                  # Conv1d(D, 3*group_size, 1) == a per-token Linear
+        rel = F.linear(x_rec, head.weight.squeeze(-1), head.bias).reshape(B, M, -1, 3)
         rebuild = (rel + predict_center.unsqueeze(-2)).reshape(B, -1, 3)
         sampled, _ = misc.fps(rebuild, point_num // 4)
         pts = torch.cat([pts, sampled], dim=1).contiguous()

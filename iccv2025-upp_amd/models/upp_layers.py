@@ -117,6 +117,15 @@ def _bn_rows(x, bn, training):
                         training, 0.0 if bn.momentum is None else bn.momentum, bn.eps)
 
 
+def _pointwise_bn_relu(x, conv, bn, training):
+    """relu(bn(conv1x1(x))) on a channels-last (rows, C_in) matrix: a 1x1 Conv1d/Conv2d is a GEMM and
+    BatchNorm over (batch, positions) is BatchNorm over rows -- no NCHW permutes, no MIOpen conv."""
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    w = conv.weight.view(conv.weight.shape[0], -1)
+    return F.relu(_bn_rows(F.linear(x, w, conv.bias), bn, training))
+
+
 class Encoder(nn.Module):
     """mini-PointNet patch embedding  (models/Point_MAE_unify.py:191-222).
 
@@ -391,11 +400,11 @@ class PointNetSetAbstraction(nn.Module):
     def forward(self, xyz, points):
         B, N, _ = xyz.shape
         _, center, idx, _ = self.group_divider(xyz.float(), require_index=True)
-        new_points = points.reshape(B * N, -1)[idx].reshape(B, self.num_group, self.group_size, -1)
-        new_points = new_points.permute(0, 3, 2, 1)                     # (B, C, k, G)
+        x = points.reshape(B * N, -1)[idx]                              # (B*G*k, C) rows
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            new_points = F.relu(bn(conv(new_points)))
-        return center.reshape(B, self.num_group, -1), torch.max(new_points, 2)[0].permute(0, 2, 1)
+            x = _pointwise_bn_relu(x, conv, bn, self.training)
+        x = x.view(B, self.num_group, self.group_size, -1).max(dim=2)[0]
+        return center.reshape(B, self.num_group, -1), x
 
 
 class PointNetFeaturePropagation(nn.Module):
@@ -419,10 +428,11 @@ class PointNetFeaturePropagation(nn.Module):
         else:
             interp = _inverse_distance_interp(xyz1, xyz2, points2, self.interpolate_neighbors, 1e-4)
         x = interp if points1 is None else torch.cat([points1, interp], dim=-1)
-        x = x.permute(0, 2, 1)
+        B = x.shape[0]
+        x = x.reshape(B * N, -1)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            x = F.relu(bn(conv(x)))
-        return x.permute(0, 2, 1)
+            x = _pointwise_bn_relu(x, conv, bn, self.training)
+        return x.view(B, N, -1)
 
 
 class RectifyPrompter(nn.Module):

@@ -10,6 +10,7 @@ for p in ("oracle", "tests", "iccv2025-upp_amd"):
 import torch  # noqa: E402
 
 import _seeded  # noqa: E402
+sys.path.insert(0, ROOT)
 from bench import time_kernel  # noqa: E402
 from upp_hip import _abi, ops  # noqa: E402
 
