@@ -30,12 +30,16 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = drop_prob
 
-    def forward(self, x):
+    def sample_scale(self, x):
+        """Per-sample factor floor(keep + U) / keep, or None when the layer is the identity."""
         if self.drop_prob == 0. or not self.training:
-            return x
+            return None
         keep = 1.0 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).uniform_().add_(keep).floor_()
-        return x.div(keep) * mask
+        return x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).uniform_().add_(keep).floor_().div_(keep)
+
+    def forward(self, x):
+        scale = self.sample_scale(x)
+        return x if scale is None else x * scale
 
 
 def trunc_normal_(t, std=.02):
@@ -273,12 +277,17 @@ class Block(nn.Module):
             flat = x.reshape(B * G, -1)
             nb = flat[i1, :].reshape(B * G2, -1, self.dim)
             ctr = flat[i2, :].reshape(B, G2, self.dim)
-        nb = self.drop_path(nb) + nb
+        nb = self._residual(nb, nb)
         ctr = pooling(nb.reshape(B, G2, -1, self.dim), transform=self.bnorm) + 0.3 * ctr
         prompts = x[:, :-R]
         x = propagate(xyz1=c1, xyz2=c2, points1=x[:, -R:], points2=ctr, de_neighbors=8, dist_e=1e-3)
         parts = (cls_x, prompts, x) if is_cls else (prompts, x)
         return torch.cat(parts, dim=1), prompts
+
+    def _residual(self, x, branch):
+        """x + drop_path(branch) in one pass (addcmul with the per-sample stochastic-depth factor)."""
+        scale = self.drop_path.sample_scale(branch) if isinstance(self.drop_path, DropPath) else None
+        return x + branch if scale is None else torch.addcmul(x, branch, scale)
 
     def forward(self, x, **kw):
         path = kw['path']
@@ -289,8 +298,8 @@ class Block(nn.Module):
             prompt_tokens = prompts.repeat(x.shape[0], 1, 1)
             x = torch.cat((x[:, 0:1], prompt_tokens, x[:, 1:]), 1) if is_cls else torch.cat((prompt_tokens, x), 1)
 
-        x = x + self.drop_path(self.attn(self.norm1(x)))
-        x = x + self.drop_path(self.mlp(self.norm2(x)))
+        x = self._residual(x, self.attn(self.norm1(x)))
+        x = self._residual(x, self.mlp(self.norm2(x)))
 
         if prompt_tokens is not None:
             if kw.get('prompt_propagation_after'):

@@ -1,0 +1,125 @@
+"""Batch-parallel training path on CPU: world_size 2, gloo.  The step driver must give the same
+averaged gradients (one flat all-reduce) as a single process on the whole batch, and identical
+parameters on every rank after the optimizer step."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _seeded
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup_model():
+    import oracle
+    from models import build_model_from_cfg, upp_layers
+    from upp_hip import functional as HF
+    from upp_hip.train import freeze_for_peft
+    from utils.config import builtin_cfg
+    ops = oracle.torch_ops()
+    upp_layers.OPS.update(ops)
+    HF.fps_gather = ops["fps_gather"]
+    torch.manual_seed(0)
+    cfg = builtin_cfg('unify_modelnet_cls').model
+    # gather_idx=False reproduces the reference's stride-64-into-stride-74 indexing, which reads rows of
+    # OTHER samples of the shard: sharding then changes results by construction.  The DP
+    # mechanics are checked with per-sample indices.
+    cfg.gather_idx = True
+    m = build_model_from_cfg(cfg)
+    _seeded.fill(m).eval()          # eval: BatchNorm uses running stats, so sharding the batch is exact
+    n = freeze_for_peft(m)
+    assert n == 619_176
+    return m
+
+
+def _data():
+    pts = _seeded.noisy_clouds(4, 1024, seed=0)
+    labels = torch.tensor([1, 7, 30, 12])
+    return pts, labels
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path[:0] = [p for p in os.environ["UPP_TEST_PATHS"].split(os.pathsep)]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from upp_hip.train import TrainStep
+    from utils import dist_utils
+    dist_utils.init_dist('pytorch', backend='gloo')
+    assert dist_utils.get_dist_info() == (rank, world)
+    model = _setup_model()
+    pts, labels = _data()
+    sl = slice(rank * 2, rank * 2 + 2)
+    ts = TrainStep(model, (2, 1096, 3), use_graph=False)
+    assert ts.distributed
+    ts.pts.copy_(pts[sl]); ts.labels.copy_(labels[sl])
+    ts._forward_backward()
+    ts.flat.reduce()                # flat = mean over ranks of [grads..., loss, acc]
+    flat_after = ts.flat.flat.clone()
+    ts._update()
+    loss_mean = dist_utils.reduce_tensor(ts.loss.clone())
+    allp = dist_utils.gather_tensor(torch.tensor([float(rank)]))
+    assert allp.tolist() == [0.0, 1.0]
+    if rank == 0:
+        torch.save({"flat": flat_after, "loss_mean": loss_mean,
+                    "p": model.cls_head_finetune[8].bias.detach().clone()}, os.path.join(out_dir, "r0.pt"))
+    else:
+        torch.save({"p": model.cls_head_finetune[8].bias.detach().clone()}, os.path.join(out_dir, "r1.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_step_matches_single_process(tmp_path):
+    from conftest import ROOT, PKG
+    os.environ["UPP_TEST_PATHS"] = os.pathsep.join([os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), PKG])
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["p"], r1["p"]), "ranks diverged after the optimizer step"
+
+    from upp_hip.train import TrainStep
+    model = _setup_model()
+    pts, labels = _data()
+    ts = TrainStep(model, (4, 1096, 3), use_graph=False)
+    assert not ts.distributed
+    ts.pts.copy_(pts); ts.labels.copy_(labels)
+    ts._forward_backward()
+    full = ts.flat.flat
+    n = ts.flat.numel
+    # gradient of the mean CE over 4 clouds == mean of the two half-batch gradients
+    np.testing.assert_allclose(r0["flat"][:n].numpy(), full[:n].numpy(), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(r0["flat"][n].item(), full[n].item(), rtol=1e-5)        # averaged loss slot
+    np.testing.assert_allclose(r0["loss_mean"].item(), full[n].item(), rtol=1e-5)
+
+
+def test_flat_grad_buffer_views_survive_backward():
+    from utils.dist_utils import FlatGradAllReduce
+    lin = torch.nn.Linear(4, 3)
+    frozen = torch.nn.Linear(3, 3)
+    for p in frozen.parameters():
+        p.requires_grad_(False)
+    f = FlatGradAllReduce(list(lin.parameters()) + list(frozen.parameters()))
+    assert f.numel == 15 and f.flat.numel() == 17
+    for _ in range(2):
+        f.zero()
+        frozen(lin(torch.ones(2, 4))).sum().backward()
+        base = f.flat.data_ptr()
+        for p in lin.parameters():
+            assert base <= p.grad.data_ptr() < base + f.flat.numel() * 4        # still a view of the flat buffer
+        assert f.flat[:15].abs().sum() > 0
+    f.reduce()   # no process group: no-op
+    with pytest.raises(ValueError):
+        FlatGradAllReduce(frozen.parameters())
