@@ -146,7 +146,31 @@ class Encoder(nn.Module):
         self.second_conv = nn.Sequential(
             nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True), nn.Conv1d(512, encoder_channel, 1))
 
+    def _fusable(self, x):
+        """The gfx950 kernel chain is forward-only: usable whenever no gradient has to flow through the
+        encoder (it is frozen in every UPP recipe), for the reference's layer sizes and group sizes."""
+        if not x.is_cuda or x.dtype != torch.float32 or x.shape[2] not in (16, 32):
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        c1, bn1, _, c2 = self.first_conv
+        c3, bn3, _, c4 = self.second_conv
+        return (tuple(c1.weight.shape) == (128, 3, 1) and tuple(c2.weight.shape) == (256, 128, 1)
+                and tuple(c3.weight.shape) == (512, 512, 1) and c4.weight.shape[1] == 512 and c4.weight.shape[0] % 4 == 0
+                and bn1.track_running_stats and bn3.track_running_stats and bn1.momentum == bn3.momentum and bn1.eps == bn3.eps)
+
     def forward(self, point_groups):
+        if self._fusable(point_groups):
+            from upp_hip import ops
+            bn1, bn3 = self.first_conv[1], self.second_conv[1]
+            if self.training:
+                bn1.num_batches_tracked.add_(1)
+                bn3.num_batches_tracked.add_(1)
+            return ops.patch_embed_fwd(point_groups.contiguous(), self, self.training)
+        return self._forward_torch(point_groups)
+
+    def _forward_torch(self, point_groups):
+        """Same math through library GEMMs; differentiable (used when the encoder is being trained)."""
         bs, g, n, _ = point_groups.shape
         c1, bn1, _, c2 = self.first_conv
         c3, bn3, _, c4 = self.second_conv

@@ -30,6 +30,9 @@ SIGNATURES = {
     "upp_emd_approxmatch": (_c_i, [_c_f] * 4 + [_c_i] * 3 + [_c_f]),
     "upp_emd_matchcost": (_c_i, [_c_f] * 4 + [_c_i] * 3 + [_c_f]),
     "upp_emd_matchcost_bwd": (_c_i, [_c_f] * 6 + [_c_i] * 3 + [_c_f]),
+    "upp_patch_embed_work_floats": (ctypes.c_longlong, [_c_i, _c_i]),
+    "upp_patch_embed_fwd": (_c_i, [_c_f, _c_i, _c_i] + [_c_f] * 6 + [_c_f] * 2 + [_c_f] * 6 + [_c_f] * 2 + [_c_i]
+                            + [ctypes.c_float, ctypes.c_float, _c_i] + [_c_f, _c_f, _c_f]),
 }
 # tuning hooks (not part of the reference-facing ABI)
 _EXTRA = {

@@ -188,3 +188,28 @@ def emd_matchcost_bwd(grad_cost, xyz1, xyz2, match):
     _call(xyz1.device, "upp_emd_matchcost_bwd", _abi.ptr(grad_cost), _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(match),
           _abi.ptr(g1), _abi.ptr(g2), B, n, m)
     return g1, g2
+
+
+# ------------------------------------------------------------------ patch embedding (forward only)
+def patch_embed_fwd(point_groups, enc, training):
+    """point_groups (B,G,n,3) -> (B,G,C) through upp_patch_embed_fwd.  `enc` is an Encoder-shaped
+    module (first_conv / second_conv Sequentials with the reference's layer sizes)."""
+    _need(point_groups, "point_groups", torch.float32, 4, 3)
+    B, G, n, _ = point_groups.shape
+    c1, bn1, _, c2 = enc.first_conv
+    c3, bn3, _, c4 = enc.second_conv
+    C = c4.weight.shape[0]
+    R = B * G * n
+    dev = point_groups.device
+    work = torch.empty((int(_abi.load().upp_patch_embed_work_floats(R, n)),), dtype=torch.float32, device=dev)
+    out = torch.empty((B, G, C), dtype=torch.float32, device=dev)
+    mom = 0.1 if bn1.momentum is None else float(bn1.momentum)
+    _call(dev, "upp_patch_embed_fwd", _abi.ptr(point_groups), R, n,
+          _abi.ptr(c1.weight), _abi.ptr(c1.bias), _abi.ptr(bn1.weight), _abi.ptr(bn1.bias),
+          _abi.ptr(bn1.running_mean), _abi.ptr(bn1.running_var),
+          _abi.ptr(c2.weight), _abi.ptr(c2.bias),
+          _abi.ptr(c3.weight), _abi.ptr(c3.bias), _abi.ptr(bn3.weight), _abi.ptr(bn3.bias),
+          _abi.ptr(bn3.running_mean), _abi.ptr(bn3.running_var),
+          _abi.ptr(c4.weight), _abi.ptr(c4.bias), C, mom, float(bn1.eps), 1 if training else 0,
+          _abi.ptr(work), _abi.ptr(out))
+    return out

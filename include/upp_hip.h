@@ -125,6 +125,33 @@ int upp_emd_matchcost(const float *xyz1, const float *xyz2, const float *match, 
 int upp_emd_matchcost_bwd(const float *grad_cost, const float *xyz1, const float *xyz2, const float *match,
                           float *grad1, float *grad2, int B, int n, int m, void *stream);
 
+/* ---- patch embedding (mini-PointNet) forward --------------------------------------
+ * Replaces Encoder.forward (reference models/Point_MAE_unify.py:191-222): the chain
+ * Conv1d(3,128)-BN-ReLU-Conv1d(128,256) -> group max -> concat -> Conv1d(512,512)-BN-ReLU-
+ * Conv1d(512,C) -> group max, as FP32-MFMA GEMMs with BatchNorm statistics, normalisation,
+ * ReLU and both max-pools fused into GEMM prologues / epilogues.
+ *   pts  (R,3) f32: the centred neighbourhoods, R = B*G*n rows, n = points per group (16 or 32)
+ *   w1 (128,3) b1 (128) | w2 (256,128) b2 (256) | w3 (512,512) b3 (512) | w4 (C,512) b4 (C):
+ *        the Conv1d weights with their trailing kernel dimension of 1 dropped
+ *   bn1_* (128), bn3_* (512): BatchNorm1d weight / bias / running_mean / running_var
+ *   training != 0: batch statistics (biased variance) normalise, running stats are updated
+ *        in place with `momentum` and the unbiased variance, as nn.BatchNorm1d does;
+ *        training == 0: running statistics normalise, nothing is written to them.
+ *   work: upp_patch_embed_work_floats(R, n) floats of scratch (16-byte aligned)
+ *   out  (R/n, C) f32
+ * Forward only (the encoder is frozen in every UPP recipe).
+ * Limits: n in {16, 32}, R % n == 0, C % 4 == 0. */
+long long upp_patch_embed_work_floats(int R, int n);
+int upp_patch_embed_fwd(const float *pts, int R, int n,
+                        const float *w1, const float *b1, const float *bn1_gamma, const float *bn1_beta,
+                        float *bn1_rmean, float *bn1_rvar,
+                        const float *w2, const float *b2,
+                        const float *w3, const float *b3, const float *bn3_gamma, const float *bn3_beta,
+                        float *bn3_rmean, float *bn3_rvar,
+                        const float *w4, const float *b4, int C,
+                        float momentum, float eps, int training,
+                        float *work, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -265,3 +265,36 @@ def test_full_size_properties():
     perm = torch.randperm(1024, device='cuda')
     e1, e2, _, _ = ops.chamfer_fwd(x, x[:, perm].contiguous())
     assert (e1 == 0).all() and (e2 == 0).all()                             # permutation invariance
+
+
+@pytest.mark.parametrize("B,G,n", [(32, 64, 32), (4, 32, 16), (3, 5, 32), (2, 7, 16)])
+@pytest.mark.parametrize("training", [False, True])
+def test_patch_embed_mfma_chain_matches_library_path(B, G, n, training):
+    """Fused FP32-MFMA patch embedding vs the same Encoder through torch/rocBLAS ops (which is pinned to the
+    reference's Encoder by the golden fixtures).  1e-5 rel (north_star tolerance for the dense path)."""
+    import copy
+    from models.upp_layers import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(384).cuda()
+    with torch.no_grad():
+        for bn in (enc.first_conv[1], enc.second_conv[1]):
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+            bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    ref = copy.deepcopy(enc)
+    enc.train(training); ref.train(training)
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    x = (torch.randn(B, G, n, 3, device='cuda') * 0.3).contiguous()
+    assert enc._fusable(x)
+    with torch.no_grad():
+        got = enc(x)
+        want = ref._forward_torch(x)
+    scale = want.abs().max().item()
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)
+    for a, b in ((enc.first_conv[1], ref.first_conv[1]), (enc.second_conv[1], ref.second_conv[1])):
+        np.testing.assert_allclose(a.running_mean.cpu().numpy(), b.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(a.running_var.cpu().numpy(), b.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        assert a.num_batches_tracked.item() == b.num_batches_tracked.item()
+    # a trainable encoder must take the differentiable path
+    enc.first_conv[0].weight.requires_grad_(True)
+    assert not enc._fusable(x)
