@@ -219,8 +219,16 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
+    def fusable(self, x):
+        """The gfx950 attention kernel serves head_dim 64, L <= 144 and no attention dropout (all UPP configs)."""
+        return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] // self.num_heads == 64 and x.shape[1] <= 144
+                and not (self.training and self.attn_drop.p > 0))
+
     def forward(self, x):
         B, N, C = x.shape
+        if self.fusable(x):
+            ctx = HF.attention(self.qkv(x), self.num_heads, self.scale)
+            return self.proj_drop(self.proj(ctx))
         qkv = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1))
@@ -313,6 +321,67 @@ class Block(nn.Module):
         scale = self.drop_path.sample_scale(branch) if isinstance(self.drop_path, DropPath) else None
         return x + branch if scale is None else torch.addcmul(x, branch, scale)
 
+    # -- fused gfx950 path ---------------------------------------------------------------------------
+    _tables = {}
+
+    @classmethod
+    def _row_tables(cls, L, P, is_cls, device):
+        """int32 row maps for prompt insertion (L -> L+P) and removal (L+P -> L); -(p+1) selects prompt p."""
+        key = (L, P, is_cls, str(device))
+        if key not in cls._tables:
+            if is_cls:
+                ins = [0] + [-(p + 1) for p in range(P)] + list(range(1, L))
+                rem = [0] + list(range(P + 1, L + P))
+            else:
+                ins = [-(p + 1) for p in range(P)] + list(range(L))
+                rem = list(range(P, L + P))
+            cls._tables[key] = (torch.tensor(ins, dtype=torch.int32, device=device),
+                                torch.tensor(rem, dtype=torch.int32, device=device))
+        return cls._tables[key]
+
+    def fusable(self, x):
+        return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 512 and self.attn.fusable(x)
+                and isinstance(self.norm1, nn.LayerNorm) and self.mlp.drop.p == 0 and self.attn.proj_drop.p == 0
+                and x.shape[1] + 16 <= 144)
+
+    def forward_fused(self, x, pos, **kw):
+        """Same function as forward(x + pos, **kw); the element-wise glue runs in the row kernels of
+        csrc/block.hip (pos add + prompt insert + norm1 | drop-path residual + norm2 | drop-path residual
+        + prompt strip + adapter LayerNorm) and the attention core in attn_fwd/bwd."""
+        path = kw['path']
+        is_cls = bool(kw.get('classification', False))
+        prompts = getattr(self, f'{path}_prompts', None) if path in _PATHS else None
+        B, L, D = x.shape
+        P = 0 if prompts is None else prompts.shape[0]
+        ins = rem = None
+        if P:
+            ins, rem = self._row_tables(L, P, is_cls, x.device)
+        u = None
+        keep = 1.0
+        if isinstance(self.drop_path, DropPath) and self.training and self.drop_path.drop_prob > 0:
+            u = torch.rand(2, B, device=x.device)
+            keep = 1.0 - self.drop_path.drop_prob
+        n1, n2 = self.norm1, self.norm2
+        xa, h1 = HF.rowln(x, add=pos, prompts=prompts, table=ins, gamma=n1.weight, beta=n1.bias, eps=n1.eps)
+        y = self.attn(h1)
+        x2, h2 = HF.rowln(xa, y=y, u=None if u is None else u[0], keep=keep, gamma=n2.weight, beta=n2.bias, eps=n2.eps)
+        m = self.mlp(h2)
+        adapter = getattr(self, f'{path}_adapter') if (path in _PATHS and kw.get(f'{path}_adapter', False)) else None
+        if path in _PATHS and kw.get(f'{path}_adapter', False):
+            assert adapter is not None, 'No adapter inserted in block!'
+        u2 = None if u is None else u[1]
+        if P and kw.get('prompt_propagation_after'):
+            x3, _ = HF.rowln(x2, y=m, u=u2, keep=keep)
+            x3, _ = self._propagate_prompts(x3, kw)
+            m, u2, x2 = None, None, x3
+        if adapter is None:
+            x4, _ = HF.rowln(x2, y=m, u=u2, keep=keep, table=rem, covers_all=not P)
+            return x4
+        ln = adapter.layer_norm
+        x4, ha = HF.rowln(x2, y=m, u=u2, keep=keep, table=rem, gamma=ln.weight, beta=ln.bias, eps=ln.eps, covers_all=not P)
+        z = adapter.ln2(adapter.dropout(adapter.activate(adapter.ln1(ha))))
+        return torch.add(x4, z, alpha=0.7)
+
     def forward(self, x, **kw):
         path = kw['path']
         is_cls = bool(kw.get('classification', False))
@@ -365,7 +434,7 @@ class TransformerEncoder(nn.Module):
         elif kwargs.get('rectify_depth') and kwargs['path'] == 'rectify':
             depth = kwargs['rectify_depth']
         for block in self.blocks[:depth]:
-            x = block(x + pos, **kwargs)
+            x = block.forward_fused(x, pos, **kwargs) if block.fusable(x) else block(x + pos, **kwargs)
         return x
 
 
@@ -393,7 +462,7 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, x, pos, return_token_num, **kwargs):
         for block in self.blocks:
-            x = block(x + pos, **kwargs)
+            x = block.forward_fused(x, pos, **kwargs) if block.fusable(x) else block(x + pos, **kwargs)
         return self.head(self.norm(x[:, -return_token_num:]))
 
 

@@ -1,0 +1,431 @@
+// block.hip -- fused kernels for the Transformer Block of UPP
+// (reference models/Point_MAE_pretask_dev.py: Attention :172-196, Block :199-321).
+//
+// The reference block issues ~60 small kernels per forward (pos add, prompt concat, LayerNorm,
+// qkv permutes, q.k^T, scale, softmax, attn.v, transpose copy, drop-path mask arithmetic, residual
+// adds, ...) and about twice that in backward; at B*L = 2400 tokens every one of them sits on the
+// ~5 us small-kernel floor.  Two kernel families replace the glue around the GEMMs:
+//
+//  * rowln_{fwd,bwd}: "gather rows (+pos) (+ per-sample-scaled residual branch) -> LayerNorm".
+//    One wavefront per token row (D <= 512: up to 8 elements per lane), statistics by DPP wave
+//    reductions.  Covers: pos-add + prompt insertion + norm1; drop-path residual + norm2; drop-path
+//    residual + prompt strip + adapter LayerNorm.  The stochastic-depth factor floor(keep+u)/keep is
+//    computed inline from a per-sample uniform, so no mask kernels exist.
+//  * attn_{fwd,bwd}: softmax(q k^T * scale) v for one (sample, head) per workgroup, reading q/k/v
+//    straight out of the packed qkv GEMM output (B, L, 3, H, 64) and writing the context in the
+//    (B, L, H*64) layout the projection GEMM consumes -- no permute copies, no (B,H,L,L) tensors in
+//    HBM.  Keys live in VGPRs (lane = key), values in LDS; backward recomputes the probabilities from
+//    the saved log-sum-exp and accumulates dK / dV in registers (lane = channel).
+// All arithmetic f32 (parity bar 1e-5 rel against the reference's unfused ops).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxE = 8;  // elements per lane in a row kernel -> D <= 512
+
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_f32(v); }
+
+struct RowLnArgs {
+    const float *x;        // (B, Lin, D) source rows
+    const float *add;      // (B, Lin, D) added to x rows (positional embedding) or null
+    const float *prompts;  // (P, D) rows selected by negative table entries, or null
+    const int *table;      // (Lout) source row per output row; -(p+1) selects prompt p; null = identity
+    const float *y;        // (B, Lout, D) residual branch added as scale_b * y, or null
+    const float *u;        // (B) uniforms for stochastic depth (scale_b = floor(keep+u)/keep), or null (scale 1)
+    float keep;
+    const float *gamma, *beta;  // LayerNorm affine (null gamma: no LayerNorm, only xo is produced)
+    float eps;
+    float *xo;             // (B, Lout, D) assembled rows (may be null)
+    float *h;              // (B, Lout, D) LayerNorm output
+    float *mean, *rstd;    // (B, Lout) saved statistics
+    int B, Lin, Lout, D;
+};
+
+__device__ __forceinline__ float dp_scale(const float *u, float keep, int b) {
+    return u ? floorf(keep + u[b]) / keep : 1.0f;
+}
+
+__global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.B * a.Lout) return;
+    const int b = row / a.Lout, t = row - b * a.Lout;
+    const int src = a.table ? a.table[t] : t;
+    const int D = a.D;
+    float v[kMaxE];
+    const float *xs = src >= 0 ? a.x + ((size_t)b * a.Lin + src) * D : a.prompts + (size_t)(-src - 1) * D;
+    const float *ad = (src >= 0 && a.add) ? a.add + ((size_t)b * a.Lin + src) * D : nullptr;
+    const float *ys = a.y ? a.y + (size_t)row * D : nullptr;
+    const float sc = ys ? dp_scale(a.u, a.keep, b) : 0.0f;
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int c = lane + 64 * e;
+        float val = 0.0f;
+        if (c < D) {
+            val = xs[c];
+            if (ad) val += ad[c];
+            if (ys) val = __builtin_fmaf(ys[c], sc, val);
+        }
+        v[e] = val;
+        s += val;
+    }
+    if (a.xo) {
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) a.xo[(size_t)row * D + c] = v[e]; }
+    }
+    if (!a.gamma) return;
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; const float dv = c < D ? v[e] - mean : 0.0f; q = __builtin_fmaf(dv, dv, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + a.eps);
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int c = lane + 64 * e;
+        if (c < D) a.h[(size_t)row * D + c] = __builtin_fmaf((v[e] - mean) * rstd, a.gamma[c], a.beta[c]);
+    }
+    if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+}
+
+struct RowLnBwdArgs {
+    const float *g_xo;     // (B, Lout, D) gradient w.r.t. the assembled rows (may be null)
+    const float *g_h;      // (B, Lout, D) gradient w.r.t. the LayerNorm output (null when no LayerNorm)
+    const float *xo;       // (B, Lout, D) saved assembled rows
+    const float *mean, *rstd, *gamma;
+    const int *table;
+    const float *u; float keep;
+    float *g_x;            // (B, Lin, D): rows referenced by the table are written (caller zero-fills if not all are)
+    float *g_prompt;       // (B, P, D) per-sample gradient of the prompt rows, or null
+    float *g_y;            // (B, Lout, D) gradient of the residual branch, or null
+    int B, Lin, Lout, D, P;
+};
+
+__global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.B * a.Lout) return;
+    const int b = row / a.Lout, t = row - b * a.Lout;
+    const int src = a.table ? a.table[t] : t;
+    const int D = a.D;
+    float d[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; d[e] = (a.g_xo && c < D) ? a.g_xo[(size_t)row * D + c] : 0.0f; }
+    if (a.g_h) {
+        // dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat)),  dy = g_h * gamma
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        float dy[kMaxE], xh[kMaxE], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) {
+            const int c = lane + 64 * e;
+            dy[e] = c < D ? a.g_h[(size_t)row * D + c] * a.gamma[c] : 0.0f;
+            xh[e] = c < D ? (a.xo[(size_t)row * D + c] - mean) * rstd : 0.0f;
+            s1 += dy[e];
+            s2 = __builtin_fmaf(dy[e], xh[e], s2);
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) d[e] += rstd * (dy[e] - s1 - xh[e] * s2);
+    }
+    float *gx = nullptr;
+    if (src >= 0) { if (a.g_x) gx = a.g_x + ((size_t)b * a.Lin + src) * D; }
+    else if (a.g_prompt) gx = a.g_prompt + ((size_t)b * a.P + (-src - 1)) * D;
+    const float sc = a.g_y ? dp_scale(a.u, a.keep, b) : 0.0f;
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int c = lane + 64 * e;
+        if (c < D) {
+            if (gx) gx[c] = d[e];
+            if (a.g_y) a.g_y[(size_t)row * D + c] = d[e] * sc;
+        }
+    }
+}
+
+// Partial LayerNorm parameter gradients (only for trainable LayerNorms: the adapter's):
+// part[0][chunk][c] = sum over the chunk's rows of g_h * xhat, part[1][chunk][c] = sum of g_h.
+// grid = (ceil(D/64), chunks); lane = column, the 4 waves stride the chunk's rows and are combined in wave
+// order; the caller sums the `chunks` partials (fixed order: deterministic).
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float *__restrict__ g_h, const float *__restrict__ xo,
+                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                            float *__restrict__ part, int rows, int D) {
+    __shared__ float pg[4][64], pb[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int chunks = gridDim.y, per = (rows + chunks - 1) / chunks;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    float sg = 0.0f, sb = 0.0f;
+    if (c < D)
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const float g = g_h[(size_t)r * D + c];
+            sg = __builtin_fmaf(g, (xo[(size_t)r * D + c] - mean[r]) * rstd[r], sg);
+            sb += g;
+        }
+    pg[wave][lane] = sg; pb[wave][lane] = sb;
+    __syncthreads();
+    if (wave == 0 && c < D) {
+        part[((size_t)0 * chunks + blockIdx.y) * D + c] = (pg[0][lane] + pg[1][lane]) + (pg[2][lane] + pg[3][lane]);
+        part[((size_t)1 * chunks + blockIdx.y) * D + c] = (pb[0][lane] + pb[1][lane]) + (pb[2][lane] + pb[3][lane]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention, head dim 64.  qkv (B, L, 3, H, 64); ctx (B, L, H*64); lse (B, H, L).
+// One workgroup (8 waves) per (b, h).  Each wave owns query rows i = wave, wave+8, ...
+//   scores : lane = key j (NS key slots of 64), k_j in VGPRs, q_i through uniform (scalar) loads
+//   softmax: two DPP wave reductions
+//   context: lane = channel d, p_j broadcast from LDS, v_j[d] from LDS
+constexpr int kAW = 8;
+
+template <int NS>
+__global__ __launch_bounds__(64 * kAW) void attn_fwd_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
+                                                            float *__restrict__ lse, int L, int H, float scale) {
+    extern __shared__ float sm[];
+    float *Vs = sm;                         // [L][64]
+    float *Ps = sm + (size_t)L * 64;        // [kAW][2][NS*64]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const size_t rs = (size_t)3 * H * 64;   // row stride of qkv
+    const float *base = qkv + (size_t)b * L * rs + (size_t)hh * 64;
+    for (int i = threadIdx.x; i < L * 64; i += 64 * kAW) Vs[i] = base[(size_t)(i >> 6) * rs + 2 * H * 64 + (i & 63)];
+    float kreg[NS][64];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int j = s * 64 + lane;
+        const float *kr = base + (size_t)(j < L ? j : L - 1) * rs + H * 64;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(kr + d);
+            kreg[s][d] = t.x; kreg[s][d + 1] = t.y; kreg[s][d + 2] = t.z; kreg[s][d + 3] = t.w;
+        }
+    }
+    __syncthreads();
+    float *pw = Ps + wave * (2 * NS * 64);
+    // two query rows per iteration share every v_j read; rows past L are computed on a clamped index and dropped
+    for (int i0 = wave * 2; i0 < L; i0 += 2 * kAW) {
+        const int i1 = min(i0 + 1, L - 1);
+        const float *q0 = base + (size_t)i0 * rs, *q1 = base + (size_t)i1 * rs;   // wave-uniform -> scalar loads
+        float s0[NS], s1[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { s0[s] = 0.0f; s1[s] = 0.0f; }
+#pragma unroll
+        for (int d = 0; d < 64; ++d) {
+            const float a = q0[d], c = q1[d];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { s0[s] = __builtin_fmaf(a, kreg[s][d], s0[s]); s1[s] = __builtin_fmaf(c, kreg[s][d], s1[s]); }
+        }
+        float m0 = -__builtin_inff(), m1 = -__builtin_inff();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bool ok = s * 64 + lane < L;
+            s0[s] = ok ? s0[s] * scale : -__builtin_inff(); m0 = fmaxf(m0, s0[s]);
+            s1[s] = ok ? s1[s] * scale : -__builtin_inff(); m1 = fmaxf(m1, s1[s]);
+        }
+        m0 = wave_max_f32(m0); m1 = wave_max_f32(m1);
+        float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bool ok = s * 64 + lane < L;
+            s0[s] = ok ? expf(s0[s] - m0) : 0.0f; t0 += s0[s];
+            s1[s] = ok ? expf(s1[s] - m1) : 0.0f; t1 += s1[s];
+        }
+        t0 = wave_sum(t0); t1 = wave_sum(t1);
+        const float r0 = 1.0f / t0, r1 = 1.0f / t1;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { pw[s * 64 + lane] = s0[s] * r0; pw[NS * 64 + s * 64 + lane] = s1[s] * r1; }
+        if (lane == 0) {
+            lse[((size_t)b * H + hh) * L + i0] = m0 + logf(t0);
+            if (i0 + 1 < L) lse[((size_t)b * H + hh) * L + i0 + 1] = m1 + logf(t1);
+        }
+        float o0 = 0.0f, o1 = 0.0f;
+        const float4 *p0 = reinterpret_cast<const float4 *>(pw), *p1 = reinterpret_cast<const float4 *>(pw + NS * 64);
+        const int L4 = L & ~3;
+        for (int j = 0; j < L4; j += 4) {
+            const float4 a = p0[j >> 2], c = p1[j >> 2];    // broadcast reads
+            const float v0 = Vs[(j + 0) * 64 + lane], v1 = Vs[(j + 1) * 64 + lane], v2 = Vs[(j + 2) * 64 + lane], v3 = Vs[(j + 3) * 64 + lane];
+            o0 = __builtin_fmaf(a.x, v0, o0); o1 = __builtin_fmaf(c.x, v0, o1);
+            o0 = __builtin_fmaf(a.y, v1, o0); o1 = __builtin_fmaf(c.y, v1, o1);
+            o0 = __builtin_fmaf(a.z, v2, o0); o1 = __builtin_fmaf(c.z, v2, o1);
+            o0 = __builtin_fmaf(a.w, v3, o0); o1 = __builtin_fmaf(c.w, v3, o1);
+        }
+        for (int j = L4; j < L; ++j) {
+            const float v = Vs[j * 64 + lane];
+            o0 = __builtin_fmaf(pw[j], v, o0); o1 = __builtin_fmaf(pw[NS * 64 + j], v, o1);
+        }
+        ctx[((size_t)b * L + i0) * (H * 64) + hh * 64 + lane] = o0;
+        if (i0 + 1 < L) ctx[((size_t)b * L + i0 + 1) * (H * 64) + hh * 64 + lane] = o1;
+    }
+}
+
+// backward: d_qkv (B, L, 3, H, 64) from d_ctx (B, L, H*64); probabilities recomputed from lse.
+template <int NS, int LMAX>
+__global__ __launch_bounds__(64 * kAW) void attn_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ ctx,
+                                                            const float *__restrict__ d_ctx, const float *__restrict__ lse,
+                                                            float *__restrict__ d_qkv, int L, int H, float scale) {
+    extern __shared__ float sm[];
+    float *Ks = sm;                              // [L][65]  (lane = key reads a row: padded)
+    float *Vs = Ks + (size_t)L * 65;             // [L][65]
+    float *Pw = Vs + (size_t)L * 65;             // [kAW][2][NS*64]   p and ds of the wave's current row
+    float *Red = Pw + (size_t)kAW * 2 * NS * 64; // [kAW][2][kAW][64] scratch for the dK/dV combine
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const size_t rs = (size_t)3 * H * 64;
+    const float *base = qkv + (size_t)b * L * rs + (size_t)hh * 64;
+    float *dbase = d_qkv + (size_t)b * L * rs + (size_t)hh * 64;
+    for (int i = threadIdx.x; i < L * 64; i += 64 * kAW) {
+        const int r = i >> 6, c = i & 63;
+        Ks[r * 65 + c] = base[(size_t)r * rs + H * 64 + c];
+        Vs[r * 65 + c] = base[(size_t)r * rs + 2 * H * 64 + c];
+    }
+    __syncthreads();
+    float dk[LMAX], dv[LMAX];   // lane = channel d: dK[j][d], dV[j][d] partial sums over this wave's rows
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j) { dk[j] = 0.0f; dv[j] = 0.0f; }
+    float *pw = Pw + wave * (2 * NS * 64);
+    float *dsw = pw + NS * 64;
+    for (int i = wave; i < L; i += kAW) {
+        const float *q = base + (size_t)i * rs;
+        const size_t orow = ((size_t)b * L + i) * (H * 64) + hh * 64;
+        const float *go = d_ctx + orow;               // wave-uniform rows
+        const float lse_i = lse[((size_t)b * H + hh) * L + i];
+        // lane = key: scores, probabilities, dP = dO . v_j
+        float p[NS], dp[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { p[s] = 0.0f; dp[s] = 0.0f; }
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) {
+            const float qd = q[d], gd = go[d];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int j = min(s * 64 + lane, L - 1);
+                p[s] = __builtin_fmaf(qd, Ks[j * 65 + d], p[s]);
+                dp[s] = __builtin_fmaf(gd, Vs[j * 65 + d], dp[s]);
+            }
+        }
+        float delta = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            p[s] = (s * 64 + lane < L) ? expf(p[s] * scale - lse_i) : 0.0f;
+            delta = __builtin_fmaf(p[s], dp[s], delta);
+        }
+        delta = wave_sum(delta);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            pw[s * 64 + lane] = p[s];
+            dsw[s * 64 + lane] = p[s] * (dp[s] - delta) * scale;   // dS * scale
+        }
+        // lane = channel: dQ_i[d] = sum_j dS_ij k_j[d];  dK[j][d] += dS_ij q_i[d];  dV[j][d] += P_ij dO_i[d]
+        const float qd = q[lane], gd = go[lane];
+        float dq = 0.0f;
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j) {
+            if (j < L) {
+                const float ds = dsw[j], pj = pw[j];
+                dq = __builtin_fmaf(ds, Ks[j * 65 + lane], dq);
+                dk[j] = __builtin_fmaf(ds, qd, dk[j]);
+                dv[j] = __builtin_fmaf(pj, gd, dv[j]);
+            }
+        }
+        dbase[(size_t)i * rs + lane] = dq;
+    }
+    // combine the kAW partial dK / dV through LDS, kAW key rows per round (fixed wave order: deterministic);
+    // wave w of a round finishes key row j0 + w
+#pragma unroll
+    for (int j0 = 0; j0 < LMAX; j0 += kAW) {
+        if (j0 < L) {
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < kAW; ++t) {
+                if (j0 + t < LMAX) {
+                    Red[((wave * 2 + 0) * kAW + t) * 64 + lane] = dk[j0 + t];
+                    Red[((wave * 2 + 1) * kAW + t) * 64 + lane] = dv[j0 + t];
+                }
+            }
+            __syncthreads();
+            const int j = j0 + wave;
+            if (j < L) {
+                float sk = 0.0f, sv = 0.0f;
+#pragma unroll
+                for (int w = 0; w < kAW; ++w) { sk += Red[((w * 2 + 0) * kAW + wave) * 64 + lane]; sv += Red[((w * 2 + 1) * kAW + wave) * 64 + lane]; }
+                dbase[(size_t)j * rs + H * 64 + lane] = sk;
+                dbase[(size_t)j * rs + 2 * H * 64 + lane] = sv;
+            }
+        }
+    }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prompts, const int32_t *table, const float *y,
+                             const float *u, float keep, const float *gamma, const float *beta, float eps, float *xo, float *h,
+                             float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream) {
+    if (!x || B < 0 || Lin < 1 || Lout < 1 || D < 1) return UPP_E_BADARG;
+    if (gamma && (!beta || !h || !mean || !rstd)) return UPP_E_BADARG;
+    if (!gamma && !xo) return UPP_E_BADARG;
+    if (D > 64 * kMaxE) return UPP_E_RANGE;
+    if (B == 0) return 0;
+    RowLnArgs a{x, add, prompts, table, y, u, keep, gamma, beta, eps, xo, h, mean, rstd, B, Lin, Lout, D};
+    hipLaunchKernelGGL(rowln_fwd_kernel, dim3((B * Lout + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    return upp_launch_status();
+}
+
+extern "C" int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
+                             const float *gamma, const int32_t *table, const float *u, float keep, float *g_x, float *g_prompt,
+                             float *g_y, int B, int Lin, int Lout, int D, int P, void *stream) {
+    if ((!g_xo && !g_h) || B < 0 || Lin < 1 || Lout < 1 || D < 1) return UPP_E_BADARG;
+    if (g_h && (!xo || !mean || !rstd || !gamma)) return UPP_E_BADARG;
+    if (D > 64 * kMaxE) return UPP_E_RANGE;
+    if (B == 0) return 0;
+    RowLnBwdArgs a{g_xo, g_h, xo, mean, rstd, gamma, table, u, keep, g_x, g_prompt, g_y, B, Lin, Lout, D, P};
+    hipLaunchKernelGGL(rowln_bwd_kernel, dim3((B * Lout + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    return upp_launch_status();
+}
+
+extern "C" int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, const float *rstd, float *part,
+                                 int rows, int D, int chunks, void *stream) {
+    if (!g_h || !xo || !mean || !rstd || !part || rows < 1 || D < 1 || chunks < 1) return UPP_E_BADARG;
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, g_h, xo, mean, rstd,
+                       part, rows, D);
+    return upp_launch_status();
+}
+
+extern "C" int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, void *stream) {
+    if (!qkv || !ctx || !lse || B < 0 || L < 1 || H < 1) return UPP_E_BADARG;
+    if (head_dim != 64 || L > 192) return UPP_E_RANGE;
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = (L + 63) / 64;
+    const size_t lds = ((size_t)L * 64 + (size_t)kAW * 2 * ns * 64) * sizeof(float);
+    dim3 grid(B * H), block(64 * kAW);
+    int rc = 0;
+    if (ns == 1) { rc = set_lds(attn_fwd_kernel<1>, lds); if (!rc) hipLaunchKernelGGL((attn_fwd_kernel<1>), grid, block, lds, st, qkv, ctx, lse, L, H, scale); }
+    else if (ns == 2) { rc = set_lds(attn_fwd_kernel<2>, lds); if (!rc) hipLaunchKernelGGL((attn_fwd_kernel<2>), grid, block, lds, st, qkv, ctx, lse, L, H, scale); }
+    else { rc = set_lds(attn_fwd_kernel<3>, lds); if (!rc) hipLaunchKernelGGL((attn_fwd_kernel<3>), grid, block, lds, st, qkv, ctx, lse, L, H, scale); }
+    return rc ? rc : upp_launch_status();
+}
+
+extern "C" int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L,
+                            int H, int head_dim, float scale, void *stream) {
+    if (!qkv || !d_ctx || !lse || !d_qkv || B < 0 || L < 1 || H < 1) return UPP_E_BADARG;
+    if (head_dim != 64 || L > 144) return UPP_E_RANGE;
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = (L + 63) / 64;
+    const size_t lds = ((size_t)2 * L * 65 + (size_t)kAW * 2 * ns * 64 + (size_t)2 * kAW * kAW * 64) * sizeof(float);
+    dim3 grid(B * H), block(64 * kAW);
+    int rc = 0;
+    if (L <= 64) { rc = set_lds(attn_bwd_kernel<1, 64>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<1, 64>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
+    else if (L <= 80) { rc = set_lds(attn_bwd_kernel<2, 80>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<2, 80>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
+    else if (L <= 128) { rc = set_lds(attn_bwd_kernel<2, 128>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<2, 128>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
+    else { rc = set_lds(attn_bwd_kernel<3, 144>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<3, 144>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
+    return rc ? rc : upp_launch_status();
+}

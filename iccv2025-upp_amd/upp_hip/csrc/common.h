@@ -61,6 +61,13 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     const uint32_t c = readlane_u32(v, 32), d = readlane_u32(v, 48);
     return min(min(a, b), min(c, d));
 }
+// wave-wide max of a float (exact under any order): order-preserving u32 image + the u32 reducer
+__device__ __forceinline__ float wave_max_f32(float v) {
+    const uint32_t bits = __float_as_uint(v);
+    const uint32_t key = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+    const uint32_t km = wave_max_u32(key);
+    return __uint_as_float((km & 0x80000000u) ? (km & 0x7FFFFFFFu) : ~km);
+}
 __device__ __forceinline__ float wave_sum_f32(float v) {
     // fixed combination order -> deterministic
     v += __uint_as_float(dpp_u32<DPP_QUAD_XOR1>(__float_as_uint(v)));

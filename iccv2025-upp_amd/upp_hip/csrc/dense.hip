@@ -244,18 +244,32 @@ __global__ __launch_bounds__(256) void moments3_kernel(const float *__restrict__
 // MODE 0: statistics from `slabs` partial per-channel sums / sums of squares (stat_part [2][slabs][C]).
 // MODE 1: statistics of the affine map h_c = w_c . x + b_c from the moments of x (w (C,3), b (C)).
 template <int MODE>
-__global__ void bn_finalize_kernel(int C, double count, const float *stat_part, int slabs, const double *mom,
-                                   const float *w, const float *b, const float *gamma, float *rmean, float *rvar,
-                                   float momentum, float eps, int training, float *out_mean, float *out_a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int C, double count, const float *stat_part, int slabs, const double *mom,
+                                                          const float *w, const float *b, const float *gamma, float *rmean, float *rvar,
+                                                          float momentum, float eps, int training, float *out_mean, float *out_a) {
+    // 16 channels per workgroup; the 16 thread-rows split the slab partials, then sum in row order (deterministic)
+    __shared__ double rs[16][16], rq[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
+    const bool live = c < C;
+    if (MODE == 0 && training) {
+        double s = 0.0, q = 0.0;
+        if (live)
+            for (int i = ty; i < slabs; i += 16) {
+                s += (double)stat_part[(size_t)i * C + c];
+                q += (double)stat_part[((size_t)slabs + i) * C + c];
+            }
+        rs[ty][tx] = s; rq[ty][tx] = q;
+        __syncthreads();
+    }
+    if (ty != 0 || !live) return;
     double mean, var;
     if (!training) {
         mean = rmean[c]; var = rvar[c];
     } else {
         if (MODE == 0) {
             double s = 0.0, q = 0.0;
-            for (int i = 0; i < slabs; ++i) { s += (double)stat_part[(size_t)i * C + c]; q += (double)stat_part[((size_t)slabs + i) * C + c]; }
+            for (int i = 0; i < 16; ++i) { s += rs[i][tx]; q += rq[i][tx]; }
             mean = s / count;
             var = q / count - mean * mean;
         } else {
@@ -331,7 +345,7 @@ extern "C" int upp_patch_embed_fwd(const float *pts, int R, int n, const float *
         int blocks = (R + 255) / 256; if (blocks > 1024) blocks = 1024;
         hipLaunchKernelGGL(moments3_kernel, dim3(blocks), dim3(256), 0, st, pts, R, k.mom);
     }
-    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(1), dim3(128), 0, st, 128, (double)R, nullptr, 0, k.mom, w1, b1,
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(8), dim3(256), 0, st, 128, (double)R, nullptr, 0, k.mom, w1, b1,
                        bn1_gamma, bn1_rmean, bn1_rvar, momentum, eps, training, k.mean1, k.a1);
 
     GemmArgs g{};
@@ -351,7 +365,7 @@ extern "C" int upp_patch_embed_fwd(const float *pts, int R, int n, const float *
     g.rowgroup = k.hg; g.ldg = 512; g.n = n; g.stat_part = k.part3;
     if (training) launch_gemm<PRO_NONE, EPI_ROWGROUP | EPI_STORE | EPI_STATS>(g, st);
     else launch_gemm<PRO_NONE, EPI_ROWGROUP | EPI_STORE>(g, st);
-    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(8), dim3(64), 0, st, 512, (double)R, k.part3, (int)slabs_of(R), nullptr,
+    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(32), dim3(256), 0, st, 512, (double)R, k.part3, (int)slabs_of(R), nullptr,
                        nullptr, nullptr, bn3_gamma, bn3_rmean, bn3_rvar, momentum, eps, training, k.mean3, k.a3);
     // out = group max( relu(bn3(h3)) . W4^T + b4 )
     g = GemmArgs{};

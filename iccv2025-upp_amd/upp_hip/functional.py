@@ -149,3 +149,75 @@ def knn_group(xyz, center, k):
 
 def group_points(xyz, center, idx):
     return _GroupPoints.apply(xyz, center, idx)
+
+
+# ------------------------------------------------------------------ Transformer block glue
+class _RowLN(Function):
+    """rows = gather(x (+add), prompts by `table`) (+ dp_scale(u) * y);  returns (rows, LayerNorm(rows)).
+    One kernel forward, one backward (+ one for trainable LayerNorm parameters).  See upp_rowln_fwd."""
+
+    @staticmethod
+    def forward(ctx, x, add, prompts, y, gamma, beta, table, u, keep, eps, covers_all):
+        x = x.contiguous()
+        B, Lin, D = x.shape
+        Lout = table.numel() if table is not None else Lin
+        add_c = add.contiguous() if add is not None else None
+        y_c = y.contiguous() if y is not None else None
+        xo, h, mean, rstd = ops.rowln_fwd(x, add_c, prompts, table, y_c, u, keep, gamma, beta, eps, Lout)
+        ctx.save_for_backward(xo, mean, rstd, gamma, table, u)
+        ctx.dims = (B, Lin, Lout, D, 0 if prompts is None else prompts.shape[0])
+        ctx.keep = keep
+        ctx.covers_all = covers_all
+        ctx.has = (add is not None, prompts is not None, y is not None, gamma is not None)
+        if gamma is None:
+            return xo, xo.new_empty(0)
+        return xo, h
+
+    @staticmethod
+    def backward(ctx, g_xo, g_h):
+        xo, mean, rstd, gamma, table, u = ctx.saved_tensors
+        B, Lin, Lout, D, P = ctx.dims
+        has_add, has_prompts, has_y, has_ln = ctx.has
+        need = ctx.needs_input_grad
+        g_xo = g_xo.contiguous() if g_xo is not None else None
+        g_hc = g_h.contiguous() if (has_ln and g_h is not None) else None
+        if g_xo is None and g_hc is None:
+            return (None,) * 11
+        g_x, g_p, g_y = ops.rowln_bwd(g_xo, g_hc, xo, mean, rstd, gamma, table, u, ctx.keep, B, Lin, Lout, D, P,
+                                      need_x=need[0] or (has_add and need[1]), zero_x=not ctx.covers_all,
+                                      need_prompt=has_prompts and need[2], need_y=has_y and need[3])
+        g_gamma = g_beta = None
+        if has_ln and g_hc is not None and (need[4] or need[5]):
+            g_gamma, g_beta = ops.ln_param_grad(g_hc, xo, mean, rstd)
+        return (g_x if need[0] else None, g_x if (has_add and need[1]) else None,
+                g_p.sum(dim=0) if g_p is not None else None, g_y,
+                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None)
+
+
+def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, table=None, u=None, keep=1.0, eps=1e-5, covers_all=True):
+    """-> (rows (B,Lout,D), LayerNorm(rows) or None)."""
+    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, table, u, float(keep), float(eps), bool(covers_all))
+    return xo, (h if gamma is not None else None)
+
+
+class _Attention(Function):
+    """ctx = softmax(q k^T * scale) v from the packed qkv projection (B, L, 3*H*64)."""
+
+    @staticmethod
+    def forward(ctx, qkv, num_heads, scale):
+        qkv = qkv.contiguous()
+        B, L, _ = qkv.shape
+        out, lse = ops.attn_fwd(qkv, B, L, num_heads, scale)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.meta = (B, L, num_heads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, out, lse = ctx.saved_tensors
+        B, L, H, scale = ctx.meta
+        return ops.attn_bwd(qkv, out, g.contiguous(), lse, B, L, H, scale), None, None
+
+
+def attention(qkv, num_heads, scale):
+    return _Attention.apply(qkv, int(num_heads), float(scale))

@@ -213,3 +213,55 @@ def patch_embed_fwd(point_groups, enc, training):
           _abi.ptr(c4.weight), _abi.ptr(c4.bias), C, mom, float(bn1.eps), 1 if training else 0,
           _abi.ptr(work), _abi.ptr(out))
     return out
+
+
+# ------------------------------------------------------------------ Transformer block glue
+def rowln_fwd(x, add, prompts, table, y, u, keep, gamma, beta, eps, Lout, want_xo=True):
+    B, Lin, D = x.shape
+    dev = x.device
+    xo = torch.empty((B, Lout, D), dtype=torch.float32, device=dev) if want_xo else None
+    if gamma is not None:
+        h = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
+        mean = torch.empty((B, Lout), dtype=torch.float32, device=dev)
+        rstd = torch.empty((B, Lout), dtype=torch.float32, device=dev)
+    else:
+        h = mean = rstd = None
+    _call(dev, "upp_rowln_fwd", _abi.ptr(x), _abi.ptr(add), _abi.ptr(prompts), _abi.ptr(table), _abi.ptr(y), _abi.ptr(u),
+          float(keep), _abi.ptr(gamma), _abi.ptr(beta), float(eps), _abi.ptr(xo), _abi.ptr(h), _abi.ptr(mean), _abi.ptr(rstd),
+          B, Lin, Lout, D)
+    return xo, h, mean, rstd
+
+
+def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, table, u, keep, B, Lin, Lout, D, P, need_x, zero_x, need_prompt, need_y):
+    dev = (g_xo if g_xo is not None else g_h).device
+    g_x = (torch.zeros if zero_x else torch.empty)((B, Lin, D), dtype=torch.float32, device=dev) if need_x else None
+    g_p = torch.empty((B, P, D), dtype=torch.float32, device=dev) if (need_prompt and P > 0) else None
+    g_y = torch.empty((B, Lout, D), dtype=torch.float32, device=dev) if need_y else None
+    _call(dev, "upp_rowln_bwd", _abi.ptr(g_xo), _abi.ptr(g_h), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma),
+          _abi.ptr(table), _abi.ptr(u), float(keep), _abi.ptr(g_x), _abi.ptr(g_p), _abi.ptr(g_y), B, Lin, Lout, D, P)
+    return g_x, g_p, g_y
+
+
+def ln_param_grad(g_h, xo, mean, rstd, chunks=32):
+    rows = g_h.numel() // g_h.shape[-1]
+    D = g_h.shape[-1]
+    part = torch.empty((2, chunks, D), dtype=torch.float32, device=g_h.device)
+    _call(g_h.device, "upp_ln_param_grad", _abi.ptr(g_h), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(part), rows, D, chunks)
+    s = part.sum(dim=1)
+    return s[0], s[1]
+
+
+def attn_fwd(qkv, B, L, H, scale):
+    _need(qkv, "qkv", torch.float32)
+    hd = qkv.numel() // (B * L * 3 * H)
+    ctx = torch.empty((B, L, H * hd), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    _call(qkv.device, "upp_attn_fwd", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(lse), B, L, H, hd, float(scale))
+    return ctx, lse
+
+
+def attn_bwd(qkv, ctx, d_ctx, lse, B, L, H, scale):
+    hd = qkv.numel() // (B * L * 3 * H)
+    d_qkv = torch.empty_like(qkv)
+    _call(qkv.device, "upp_attn_bwd", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(d_ctx), _abi.ptr(lse), _abi.ptr(d_qkv), B, L, H, hd, float(scale))
+    return d_qkv

@@ -152,6 +152,41 @@ int upp_patch_embed_fwd(const float *pts, int R, int n,
                         float momentum, float eps, int training,
                         float *work, float *out, void *stream);
 
+/* ---- Transformer block glue: row gather (+pos) (+scaled residual) -> LayerNorm -----------
+ * Fuses the element-wise steps of Block.forward around its GEMMs (reference
+ * models/Point_MAE_pretask_dev.py:245-321): `x + pos` (TransformerEncoder :348), prompt insertion
+ * (:247-264) or removal (:305-310), `x + drop_path(branch)` (:266,273; timm DropPath: per-sample factor
+ * floor(keep + u) / keep), and the following LayerNorm (norm1 / norm2 / Adapter.layer_norm :97).
+ *   out row (b,t) = x[b, table[t]] (+ add[b, table[t]])   if table[t] >= 0   (table NULL: identity)
+ *                 = prompts[-table[t]-1]                   otherwise
+ *                 (+ floor(keep + u[b]) / keep * y[b,t])   if y            (u NULL: factor 1)
+ *   xo (B,Lout,D) = those rows (optional);  h = LayerNorm(rows) * gamma + beta, mean / rstd (B,Lout) saved
+ *   (gamma NULL: no LayerNorm, only xo).
+ * Backward: d = g_xo + LayerNormBackward(g_h); written to g_x[b, table[t]] (caller zero-fills g_x when the
+ * table does not cover every input row), g_prompt (B,P,D) (caller sums over B), g_y = factor * d.
+ * upp_ln_param_grad: per-chunk partial sums of d_gamma / d_beta, part (2, chunks, D).
+ * Limits: D <= 512. */
+int upp_rowln_fwd(const float *x, const float *add, const float *prompts, const int32_t *table, const float *y,
+                  const float *u, float keep, const float *gamma, const float *beta, float eps,
+                  float *xo, float *h, float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream);
+int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
+                  const float *gamma, const int32_t *table, const float *u, float keep,
+                  float *g_x, float *g_prompt, float *g_y, int B, int Lin, int Lout, int D, int P, void *stream);
+int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, const float *rstd, float *part,
+                      int rows, int D, int chunks, void *stream);
+
+/* ---- multi-head attention core ------------------------------------------------------------
+ * Replaces the unfused q@k^T -> *scale -> softmax -> @v of Attention.forward (reference
+ * models/Point_MAE_pretask_dev.py:186-193) and its autograd.
+ *   qkv (B,L,3,H,64): the qkv Linear output as the reference reshapes it (:186)
+ *   ctx (B,L,H*64): softmax(q k^T * scale) v, already in the layout of (:193) `.transpose(1,2).reshape(B,N,C)`
+ *   lse (B,H,L): log-sum-exp of the scaled scores (saved for backward)
+ *   d_qkv (B,L,3,H,64) from d_ctx (B,L,H*64)
+ * Limits: head_dim == 64; L <= 192 forward, L <= 144 backward. */
+int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, void *stream);
+int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv,
+                 int B, int L, int H, int head_dim, float scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

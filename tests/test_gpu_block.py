@@ -1,0 +1,154 @@
+"""Fused Transformer-block kernels (csrc/block.hip) against the unfused torch composition that the golden
+fixtures pin to the reference's Block / Attention.  Tolerance 1e-5 rel (north_star) + small abs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _seeded
+from models import build_model_from_cfg, upp_layers
+from upp_hip import functional as HF
+from utils.config import builtin_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-5, atol_scale=2e-6):
+    a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_scale * max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("L", [35, 64, 65, 75, 129])
+def test_attention_core_forward_backward(L):
+    torch.manual_seed(L)
+    B, H = 3, 6
+    qkv = torch.randn(B, L, 3 * H * 64, device='cuda', requires_grad=True)
+    w = torch.randn(B, L, H * 64, device='cuda')
+    out = HF.attention(qkv, H, 0.125)
+    (out * w).sum().backward()
+    g = qkv.grad.clone(); qkv.grad = None
+    q, k, v = qkv.view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = (((q @ k.transpose(-2, -1)) * 0.125).softmax(-1) @ v).transpose(1, 2).reshape(B, L, H * 64)
+    (ref * w).sum().backward()
+    close(out, ref)
+    close(g, qkv.grad, rtol=2e-5, atol_scale=5e-6)
+
+
+@pytest.mark.parametrize("case", ["insert_cls", "insert", "strip_cls", "residual", "plain_noln"])
+def test_rowln_forward_backward(case):
+    torch.manual_seed(1)
+    B, L, D, P = 4, 65, 384, 10
+    dev = 'cuda'
+    x = torch.randn(B, L + (P if case == "strip_cls" else 0), D, device=dev, requires_grad=True)
+    pos = torch.randn_like(x).requires_grad_(True)
+    prm = torch.randn(P, D, device=dev, requires_grad=True)
+    gam = (1 + 0.1 * torch.randn(D, device=dev)).requires_grad_(True)
+    bet = (0.1 * torch.randn(D, device=dev)).requires_grad_(True)
+    ins_c, rem_c = upp_layers.Block._row_tables(L, P, True, torch.device(dev))
+    ins_n, _ = upp_layers.Block._row_tables(L, P, False, torch.device(dev))
+    u = torch.rand(B, device=dev)
+    keep = 0.7
+
+    def scale():
+        return ((keep + u).floor() / keep).view(B, 1, 1)
+
+    if case == "insert_cls":
+        xo, h = HF.rowln(x, add=pos, prompts=prm, table=ins_c, gamma=gam, beta=bet)
+        xp = x + pos
+        rxo = torch.cat((xp[:, :1], prm.expand(B, -1, -1), xp[:, 1:]), 1)
+    elif case == "insert":
+        xo, h = HF.rowln(x, add=pos, prompts=prm, table=ins_n, gamma=gam, beta=bet)
+        rxo = torch.cat((prm.expand(B, -1, -1), x + pos), 1)
+    elif case == "strip_cls":
+        y = torch.randn_like(x).requires_grad_(True)
+        xo, h = HF.rowln(x, y=y, u=u, keep=keep, table=rem_c, gamma=gam, beta=bet, covers_all=False)
+        full = x + scale() * y
+        rxo = torch.cat((full[:, :1], full[:, P + 1:]), 1)
+    elif case == "residual":
+        y = torch.randn_like(x).requires_grad_(True)
+        xo, h = HF.rowln(x, y=y, u=u, keep=keep, gamma=gam, beta=bet)
+        rxo = x + scale() * y
+    else:
+        y = torch.randn_like(x).requires_grad_(True)
+        xo, h = HF.rowln(x, y=y)
+        rxo = x + y
+        assert h is None
+    params = [t for t in (x, pos, prm, gam, bet) if True]
+    w1, w2 = torch.randn_like(rxo), torch.randn_like(rxo)
+    loss = (xo * w1).sum() + ((h * w2).sum() if h is not None else 0)
+    grads = torch.autograd.grad(loss, [t for t in (x, pos, prm, gam, bet, locals().get('y')) if t is not None], allow_unused=True)
+    rh = F.layer_norm(rxo, (D,), gam, bet, 1e-5) if h is not None else None
+    rloss = (rxo * w1).sum() + ((rh * w2).sum() if rh is not None else 0)
+    rgrads = torch.autograd.grad(rloss, [t for t in (x, pos, prm, gam, bet, locals().get('y')) if t is not None], allow_unused=True)
+    close(xo, rxo)
+    if h is not None:
+        close(h, rh)
+    for g, r in zip(grads, rgrads):
+        assert (g is None) == (r is None)
+        if g is not None:
+            close(g, r, rtol=2e-5, atol_scale=5e-6)
+
+
+@pytest.fixture(scope="module")
+def model():
+    m = build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)
+    return _seeded.fill(m).eval().cuda()
+
+
+def _block_case(model, name):
+    g = torch.Generator(device='cuda').manual_seed(3)
+    B = 4
+    pts = _seeded.unit_ball_clouds(B, 1024, seed=2).cuda()
+    with torch.no_grad():
+        _, center = model.group_divider(pts)
+        lvl2 = upp_layers.Group(32, 8)
+        _, c2, i1, i2 = lvl2(center, require_index=True, gather_idx=False)
+    if name in ("down0", "down7"):
+        L, blk = 65, model.blocks.blocks[0 if name == "down0" else 7]
+        kw = dict(path='downstream', downstream_adapter=True, downstream_prompts=True, classification=True, center1=center,
+                  center1_idx=i1, center2=c2, center2_idx=i2, gather_idx=False, prompt_propagation_after=True)
+    elif name == "rectify":
+        L, blk, kw = 32, model.blocks.blocks[1], dict(path='rectify', rectify_adapter=True, rectify_prompts=True, rectify_depth=3)
+    elif name == "pretask":
+        L, blk, kw = 32, model.blocks.blocks[4], dict(path='pretask', pretask_adapter=True, pretask_prompts=True, pretask_depth=6)
+    else:
+        L, blk, kw = 64, model.MAE_decoder.blocks[2], dict(path='pretask', pretask_adapter=True)
+    x = torch.randn(B, L, 384, device='cuda', generator=g)
+    pos = torch.randn(B, L, 384, device='cuda', generator=g)
+    return blk, x, pos, kw
+
+
+@pytest.mark.parametrize("name", ["down0", "down7", "rectify", "pretask", "decoder"])
+def test_block_fused_equals_unfused_with_gradients(model, name):
+    blk, x, pos, kw = _block_case(model, name)
+    assert blk.fusable(x)
+    params = [p for n, p in blk.named_parameters() if ('adapter' in n or 'prompts' in n or 'bnorm' in n or 'norm1' in n)]
+    outs = []
+    for fused in (True, False):
+        xi, pi = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+        out = blk.forward_fused(xi, pi, **kw) if fused else blk(xi + pi, **kw)
+        w = torch.linspace(-1, 1, out.numel(), device='cuda').view_as(out)
+        grads = torch.autograd.grad((out * w).sum(), [xi, pi] + params, allow_unused=True)
+        outs.append((out.detach(), grads))
+    close(outs[0][0], outs[1][0], rtol=1e-5, atol_scale=3e-6)
+    for g, r in zip(outs[0][1], outs[1][1]):
+        assert (g is None) == (r is None)
+        if g is not None:
+            close(g, r, rtol=5e-5, atol_scale=1e-5)
+
+
+def test_train_mode_drop_path_statistics(model):
+    """Stochastic depth cannot be compared draw by draw; check the per-sample factor takes the two legal values."""
+    blk, x, pos, kw = _block_case(model, "down7")
+    blk.train()
+    try:
+        ref = blk.forward_fused(x, pos, **kw)
+        assert torch.isfinite(ref).all()
+        u = torch.tensor([0.0, 0.95, 0.5, 0.99], device='cuda')
+        keep = 0.9
+        y = torch.ones_like(x)
+        xo, _ = HF.rowln(torch.zeros_like(x), y=y, u=u, keep=keep)
+        got = xo[:, 0, 0].cpu().numpy()
+        np.testing.assert_allclose(got, np.floor(keep + u.cpu().numpy()) / keep, rtol=1e-6)
+    finally:
+        blk.eval()
