@@ -30,7 +30,7 @@ struct RowLnArgs {
     const float *add;      // (B, Lin, D) added to x rows (positional embedding) or null
     const float *prompts;  // (P, D) rows selected by negative table entries, or null
     const int *table;      // (Lout) source row per output row; -(p+1) selects prompt p; null = identity
-    const float *y;        // (B, Lout, D) residual branch added as scale_b * y, or null
+    const float *y;        // (B, Lin, D) residual branch, row-aligned with x: added as scale_b * y, or null
     const float *u;        // (B) uniforms for stochastic depth (scale_b = floor(keep+u)/keep), or null (scale 1)
     float keep;
     const float *gamma, *beta;  // LayerNorm affine (null gamma: no LayerNorm, only xo is produced)
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
     float v[kMaxE];
     const float *xs = src >= 0 ? a.x + ((size_t)b * a.Lin + src) * D : a.prompts + (size_t)(-src - 1) * D;
     const float *ad = (src >= 0 && a.add) ? a.add + ((size_t)b * a.Lin + src) * D : nullptr;
-    const float *ys = a.y ? a.y + (size_t)row * D : nullptr;
+    const float *ys = (src >= 0 && a.y) ? a.y + ((size_t)b * a.Lin + src) * D : nullptr;
     const float sc = ys ? dp_scale(a.u, a.keep, b) : 0.0f;
     float s = 0.0f;
 #pragma unroll
@@ -97,7 +97,7 @@ struct RowLnBwdArgs {
     const float *u; float keep;
     float *g_x;            // (B, Lin, D): rows referenced by the table are written (caller zero-fills if not all are)
     float *g_prompt;       // (B, P, D) per-sample gradient of the prompt rows, or null
-    float *g_y;            // (B, Lout, D) gradient of the residual branch, or null
+    float *g_y;            // (B, Lin, D) gradient of the residual branch (same rows as g_x), or null
     int B, Lin, Lout, D, P;
 };
 
@@ -131,13 +131,14 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
     float *gx = nullptr;
     if (src >= 0) { if (a.g_x) gx = a.g_x + ((size_t)b * a.Lin + src) * D; }
     else if (a.g_prompt) gx = a.g_prompt + ((size_t)b * a.P + (-src - 1)) * D;
-    const float sc = a.g_y ? dp_scale(a.u, a.keep, b) : 0.0f;
+    float *gy = (src >= 0 && a.g_y) ? a.g_y + ((size_t)b * a.Lin + src) * D : nullptr;
+    const float sc = gy ? dp_scale(a.u, a.keep, b) : 0.0f;
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) {
         const int c = lane + 64 * e;
         if (c < D) {
             if (gx) gx[c] = d[e];
-            if (a.g_y) a.g_y[(size_t)row * D + c] = d[e] * sc;
+            if (gy) gy[c] = d[e] * sc;
         }
     }
 }

@@ -236,7 +236,7 @@ def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, table, u, keep, B, Lin, Lout, D,
     dev = (g_xo if g_xo is not None else g_h).device
     g_x = (torch.zeros if zero_x else torch.empty)((B, Lin, D), dtype=torch.float32, device=dev) if need_x else None
     g_p = torch.empty((B, P, D), dtype=torch.float32, device=dev) if (need_prompt and P > 0) else None
-    g_y = torch.empty((B, Lout, D), dtype=torch.float32, device=dev) if need_y else None
+    g_y = (torch.zeros if zero_x else torch.empty)((B, Lin, D), dtype=torch.float32, device=dev) if need_y else None
     _call(dev, "upp_rowln_bwd", _abi.ptr(g_xo), _abi.ptr(g_h), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma),
           _abi.ptr(table), _abi.ptr(u), float(keep), _abi.ptr(g_x), _abi.ptr(g_p), _abi.ptr(g_y), B, Lin, Lout, D, P)
     return g_x, g_p, g_y

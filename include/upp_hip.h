@@ -159,11 +159,11 @@ int upp_patch_embed_fwd(const float *pts, int R, int n,
  * floor(keep + u) / keep), and the following LayerNorm (norm1 / norm2 / Adapter.layer_norm :97).
  *   out row (b,t) = x[b, table[t]] (+ add[b, table[t]])   if table[t] >= 0   (table NULL: identity)
  *                 = prompts[-table[t]-1]                   otherwise
- *                 (+ floor(keep + u[b]) / keep * y[b,t])   if y            (u NULL: factor 1)
+ *                 (+ floor(keep + u[b]) / keep * y[b, table[t]])  if y (row-aligned with x; u NULL: factor 1)
  *   xo (B,Lout,D) = those rows (optional);  h = LayerNorm(rows) * gamma + beta, mean / rstd (B,Lout) saved
  *   (gamma NULL: no LayerNorm, only xo).
  * Backward: d = g_xo + LayerNormBackward(g_h); written to g_x[b, table[t]] (caller zero-fills g_x when the
- * table does not cover every input row), g_prompt (B,P,D) (caller sums over B), g_y = factor * d.
+ * table does not cover every input row), g_prompt (B,P,D) (caller sums over B), g_y[b, table[t]] = factor * d.
  * upp_ln_param_grad: per-chunk partial sums of d_gamma / d_beta, part (2, chunks, D).
  * Limits: D <= 512. */
 int upp_rowln_fwd(const float *x, const float *add, const float *prompts, const int32_t *table, const float *y,
