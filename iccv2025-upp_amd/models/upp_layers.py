@@ -339,6 +339,46 @@ class Block(nn.Module):
                                 torch.tensor(rem, dtype=torch.int32, device=device))
         return cls._tables[key]
 
+    def _propagate_fused(self, x, kw):
+        """_propagate_prompts on the row kernels of csrc/prop.hip.  The neighbour weights and the absolute row
+        indices depend only on the centres / the token layout, so they are built once per forward (shared dict
+        `_prop_cache` put into the kwargs by TransformerEncoder) with exactly the reference's torch ops."""
+        B, Lp, D = x.shape
+        off = 1 if kw.get('classification') else 0
+        c1, c2 = kw['center1'], kw['center2']
+        T, G2 = c1.shape[1], c2.shape[1]
+        cache = kw.get('_prop_cache')
+        key = (Lp, off)
+        if cache is None or key not in cache:
+            with torch.no_grad():
+                dists, idx = square_distance(c1, c2).sort(dim=-1)
+                d8, idx8 = dists[:, :, :8], idx[:, :, :8]
+                recip = 1.0 / (d8 + 1e-3)
+                w8 = (recip / torch.sum(recip, dim=2, keepdim=True)).contiguous()
+                i1, i2 = kw['center1_idx'], kw['center2_idx']
+                if kw.get('gather_idx'):
+                    base = (torch.arange(B, device=x.device) * Lp + off).view(B, 1)
+                    i1a, i2a = base + i1.reshape(B, -1), base + i2.reshape(B, -1)
+                else:
+                    G = Lp - off      # the reference indexes the cls-stripped tokens as a flat (B*G)-row matrix
+                    i1a = torch.div(i1, G, rounding_mode='floor') * Lp + off + i1 % G
+                    i2a = torch.div(i2, G, rounding_mode='floor') * Lp + off + i2 % G
+                entry = (i1a.reshape(-1).int().contiguous(), i2a.reshape(-1).int().contiguous(), idx8.int().contiguous(), w8)
+            if cache is not None:
+                cache[key] = entry
+        else:
+            entry = cache[key]
+        i1a, i2a, idx8, w8 = entry
+        u, keep = None, 1.0
+        if isinstance(self.drop_path, DropPath) and self.training and self.drop_path.drop_prob > 0:
+            u = torch.rand(B * G2, device=x.device)
+            keep = 1.0 - self.drop_path.drop_prob
+        pooled = HF.prop_pool(x, i1a, u, keep)
+        if self.training and self.bnorm.track_running_stats:
+            self.bnorm.num_batches_tracked.add_(1)
+        lc = _bn_rows(pooled, self.bnorm, self.training).view(B, G2, D)
+        return HF.prop_interp(x, lc, i2a, idx8, w8)
+
     def fusable(self, x):
         return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 512 and self.attn.fusable(x)
                 and isinstance(self.norm1, nn.LayerNorm) and self.mlp.drop.p == 0 and self.attn.proj_drop.p == 0
@@ -372,7 +412,10 @@ class Block(nn.Module):
         u2 = None if u is None else u[1]
         if P and kw.get('prompt_propagation_after'):
             x3, _ = HF.rowln(x2, y=m, u=u2, keep=keep)
-            x3, _ = self._propagate_prompts(x3, kw)
+            if kw['center1_idx'].numel() == B * kw['center2'].shape[1] * 8:
+                x3 = self._propagate_fused(x3, kw)
+            else:
+                x3, _ = self._propagate_prompts(x3, kw)
             m, u2, x2 = None, None, x3
         if adapter is None:
             x4, _ = HF.rowln(x2, y=m, u=u2, keep=keep, table=rem, covers_all=not P)
@@ -433,6 +476,8 @@ class TransformerEncoder(nn.Module):
             depth = kwargs['pretask_depth']
         elif kwargs.get('rectify_depth') and kwargs['path'] == 'rectify':
             depth = kwargs['rectify_depth']
+        if 'center1' in kwargs:
+            kwargs['_prop_cache'] = {}      # per-forward scratch shared by the blocks (see Block._propagate_fused)
         for block in self.blocks[:depth]:
             x = block.forward_fused(x, pos, **kwargs) if block.fusable(x) else block(x + pos, **kwargs)
         return x

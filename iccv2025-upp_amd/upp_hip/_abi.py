@@ -38,6 +38,10 @@ SIGNATURES = {
     "upp_ln_param_grad": (_c_i, [_c_f] * 5 + [_c_i] * 3 + [_c_f]),
     "upp_attn_fwd": (_c_i, [_c_f] * 3 + [_c_i] * 4 + [ctypes.c_float, _c_f]),
     "upp_attn_bwd": (_c_i, [_c_f] * 5 + [_c_i] * 4 + [ctypes.c_float, _c_f]),
+    "upp_prop_pool_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 2 + [_c_i] * 2 + [_c_f]),
+    "upp_prop_pool_bwd": (_c_i, [_c_f] * 4 + [ctypes.c_float] + [_c_f] + [_c_i] * 3 + [_c_f]),
+    "upp_prop_interp_fwd": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f]),
+    "upp_prop_interp_bwd": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f]),
 }
 # tuning hooks (not part of the reference-facing ABI)
 _EXTRA = {

@@ -1,0 +1,213 @@
+// prop.hip -- the prompt-propagation step of Block.forward
+// (reference models/Point_MAE_pretask_dev.py:275-303, `pooling` per SURVEY D.3, `propagate`
+// models/Point_MAE_unify.py:22-48) as four row kernels for gfx950.
+//
+// Reference data flow per block (6 blocks per forward), on the token matrix X (B, L', D) whose rows are
+// [cls | P prompts | 64 centre tokens]:
+//   nb   = X[i1]                      8 "level-1 neighbour" rows for each of the B*32 level-2 groups
+//   nb   = nb + drop_path(nb)         per-group stochastic-depth factor
+//   pool = max_k nb + mean_k nb   ->  BatchNorm1d over the B*32 rows  -> lc
+//   c2   = lc + 0.3 * X[i2]           the level-2 centre's own token
+//   X[tok i] += 0.3 * sum_k w8[i,k] * c2[idx8[i,k]]        (8 nearest level-2 centres, inverse-distance weights)
+// The reference does this with ~35 kernels forward and ~100 in backward (advanced indexing, index_put with
+// sorts, a full sort of the distances in every block).  Here: idx8 / w8 depend only on the centres and are
+// computed once per forward by the host; the row indices are handed over as absolute rows of X (the host
+// converts the reference's flat / per-sample index conventions, including its stride-64-into-stride-74
+// behaviour, into that form); pool and interpolate are one kernel each, one wavefront per row, and the
+// backward scatter-adds are done as deterministic "scan the index list for my row" gathers, no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxE = 8;   // D <= 512
+constexpr int kNb = 8;     // neighbours per level-2 group and per interpolation (reference: group_size=8, de_neighbors=8)
+
+// pooled[g][c] = max_k v_k + (sum_k v_k) / 8,  v_k = X[i1[g][k]][c] * (1 + s_g);  amax[g][c] = arg max
+__global__ __launch_bounds__(256) void prop_pool_fwd_kernel(const float *__restrict__ X, const int32_t *__restrict__ i1,
+                                                            const float *__restrict__ u, float keep, float *__restrict__ pooled,
+                                                            uint8_t *__restrict__ amax, int groups, int D) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= groups) return;
+    const float f = 1.0f + (u ? floorf(keep + u[g]) / keep : 1.0f);   // x + drop_path(x): factor 1 + s
+    float mx[kMaxE], sm[kMaxE];
+    int am[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { mx[e] = -__builtin_inff(); sm[e] = 0.0f; am[e] = 0; }
+    for (int k = 0; k < kNb; ++k) {
+        const float *row = X + (size_t)i1[g * kNb + k] * D;
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) {
+            const int c = lane + 64 * e;
+            if (c < D) {
+                const float v = row[c] * f;
+                if (v > mx[e]) { mx[e] = v; am[e] = k; }   // first maximum wins, as torch.max
+                sm[e] += v;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int c = lane + 64 * e;
+        if (c < D) { pooled[(size_t)g * D + c] = mx[e] + sm[e] * 0.125f; amax[(size_t)g * D + c] = (uint8_t)am[e]; }
+    }
+}
+
+// g_X[r][c] = sum over (g,k) with i1[g][k] == r of  (1 + s_g) * g_pooled[g][c] * (1/8 + [amax[g][c] == k])
+__global__ __launch_bounds__(256) void prop_pool_bwd_kernel(const float *__restrict__ g_pooled, const uint8_t *__restrict__ amax,
+                                                            const int32_t *__restrict__ i1, const float *__restrict__ u, float keep,
+                                                            float *__restrict__ g_X, int rows, int groups, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float acc[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) acc[e] = 0.0f;
+    const int n = groups * kNb;
+    for (int base = 0; base < n; base += 64) {
+        const int q = base + lane;
+        unsigned long long mask = __ballot(q < n && i1[q] == r);
+        while (mask) {                                   // matches in ascending list order: deterministic
+            const int hit = base + __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int g = hit / kNb, k = hit - g * kNb;
+            const float f = 1.0f + (u ? floorf(keep + u[g]) / keep : 1.0f);
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) {
+                const int c = lane + 64 * e;
+                if (c < D) {
+                    const float gp = g_pooled[(size_t)g * D + c];
+                    acc[e] += gp * f * (0.125f + (amax[(size_t)g * D + c] == k ? 1.0f : 0.0f));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) g_X[(size_t)r * D + c] = acc[e]; }
+}
+
+// out[b][t] = X[b][t]                                                     for t < L' - T   (cls, prompts)
+//           = X[b][t] + 0.3 * sum_k w8[b][i][k] * (lc[b][j] + 0.3 * X[i2[b][j]]),  j = idx8[b][i][k], i = t - (L' - T)
+__global__ __launch_bounds__(256) void prop_interp_fwd_kernel(const float *__restrict__ X, const float *__restrict__ lc,
+                                                              const int32_t *__restrict__ i2, const int32_t *__restrict__ idx8,
+                                                              const float *__restrict__ w8, float *__restrict__ out, int B, int Lp,
+                                                              int T, int G2, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * Lp) return;
+    const int b = r / Lp, t = r - b * Lp;
+    const int i = t - (Lp - T);
+    float acc[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) acc[e] = 0.0f;
+    if (i >= 0) {
+        for (int k = 0; k < kNb; ++k) {
+            const int j = idx8[((size_t)b * T + i) * kNb + k];
+            const float w = w8[((size_t)b * T + i) * kNb + k];
+            const float *lrow = lc + ((size_t)b * G2 + j) * D;
+            const float *crow = X + (size_t)i2[b * G2 + j] * D;
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) {
+                const int c = lane + 64 * e;
+                if (c < D) acc[e] += (lrow[c] + 0.3f * crow[c]) * w;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int c = lane + 64 * e;
+        if (c < D) out[(size_t)r * D + c] = X[(size_t)r * D + c] + (i >= 0 ? 0.3f * acc[e] : 0.0f);
+    }
+}
+
+// g_c2[b][j][c] = 0.3 * sum over (i,k) with idx8[b][i][k] == j of w8[b][i][k] * g_out[b][L'-T+i][c]
+__global__ __launch_bounds__(256) void prop_interp_bwd_c2_kernel(const float *__restrict__ g_out, const int32_t *__restrict__ idx8,
+                                                                 const float *__restrict__ w8, float *__restrict__ g_c2, int B, int Lp,
+                                                                 int T, int G2, int D) {
+    const int lane = threadIdx.x & 63;
+    const int gj = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gj >= B * G2) return;
+    const int b = gj / G2, j = gj - b * G2;
+    float acc[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) acc[e] = 0.0f;
+    const int n = T * kNb;
+    const int32_t *ib = idx8 + (size_t)b * n;
+    for (int base = 0; base < n; base += 64) {
+        const int q = base + lane;
+        unsigned long long mask = __ballot(q < n && ib[q] == j);
+        while (mask) {
+            const int hit = base + __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int i = hit / kNb;
+            const float w = w8[(size_t)b * n + hit];
+            const float *grow = g_out + ((size_t)b * Lp + (Lp - T) + i) * D;
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) acc[e] += grow[c] * w; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) g_c2[(size_t)gj * D + c] = 0.3f * acc[e]; }
+}
+
+// g_X[r] = g_out[r] + 0.3 * g_c2[m]  for the (unique) m with i2[m] == r, else g_out[r]
+__global__ __launch_bounds__(256) void prop_interp_bwd_x_kernel(const float *__restrict__ g_out, const float *__restrict__ g_c2,
+                                                                const int32_t *__restrict__ i2, float *__restrict__ g_X, int rows,
+                                                                int groups, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float acc[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; acc[e] = c < D ? g_out[(size_t)r * D + c] : 0.0f; }
+    for (int base = 0; base < groups; base += 64) {
+        const int q = base + lane;
+        unsigned long long mask = __ballot(q < groups && i2[q] == r);
+        while (mask) {
+            const int m = base + __builtin_ctzll(mask);
+            mask &= mask - 1;
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) acc[e] += 0.3f * g_c2[(size_t)m * D + c]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) g_X[(size_t)r * D + c] = acc[e]; }
+}
+
+inline dim3 rows_grid(long long rows) { return dim3((unsigned)((rows + 3) / 4)); }
+
+}  // namespace
+
+extern "C" int upp_prop_pool_fwd(const float *X, const int32_t *i1, const float *u, float keep, float *pooled, uint8_t *amax,
+                                 int groups, int D, void *stream) {
+    if (!X || !i1 || !pooled || !amax || groups < 1 || D < 1) return UPP_E_BADARG;
+    if (D > 64 * kMaxE) return UPP_E_RANGE;
+    hipLaunchKernelGGL(prop_pool_fwd_kernel, rows_grid(groups), dim3(256), 0, (hipStream_t)stream, X, i1, u, keep, pooled, amax, groups, D);
+    return upp_launch_status();
+}
+
+extern "C" int upp_prop_pool_bwd(const float *g_pooled, const uint8_t *amax, const int32_t *i1, const float *u, float keep,
+                                 float *g_X, int rows, int groups, int D, void *stream) {
+    if (!g_pooled || !amax || !i1 || !g_X || rows < 1 || groups < 1 || D < 1) return UPP_E_BADARG;
+    if (D > 64 * kMaxE) return UPP_E_RANGE;
+    hipLaunchKernelGGL(prop_pool_bwd_kernel, rows_grid(rows), dim3(256), 0, (hipStream_t)stream, g_pooled, amax, i1, u, keep, g_X, rows, groups, D);
+    return upp_launch_status();
+}
+
+extern "C" int upp_prop_interp_fwd(const float *X, const float *lc, const int32_t *i2, const int32_t *idx8, const float *w8,
+                                   float *out, int B, int Lp, int T, int G2, int D, void *stream) {
+    if (!X || !lc || !i2 || !idx8 || !w8 || !out || B < 1 || Lp < T || T < 1 || G2 < 1 || D < 1) return UPP_E_BADARG;
+    if (D > 64 * kMaxE) return UPP_E_RANGE;
+    hipLaunchKernelGGL(prop_interp_fwd_kernel, rows_grid((long long)B * Lp), dim3(256), 0, (hipStream_t)stream, X, lc, i2, idx8, w8, out, B, Lp, T, G2, D);
+    return upp_launch_status();
+}
+
+extern "C" int upp_prop_interp_bwd(const float *g_out, const int32_t *i2, const int32_t *idx8, const float *w8, float *g_c2,
+                                   float *g_X, int B, int Lp, int T, int G2, int D, void *stream) {
+    if (!g_out || !i2 || !idx8 || !w8 || !g_c2 || !g_X || B < 1 || Lp < T || T < 1 || G2 < 1 || D < 1) return UPP_E_BADARG;
+    if (D > 64 * kMaxE) return UPP_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(prop_interp_bwd_c2_kernel, rows_grid((long long)B * G2), dim3(256), 0, st, g_out, idx8, w8, g_c2, B, Lp, T, G2, D);
+    hipLaunchKernelGGL(prop_interp_bwd_x_kernel, rows_grid((long long)B * Lp), dim3(256), 0, st, g_out, g_c2, i2, g_X, B * Lp, B * G2, D);
+    return upp_launch_status();
+}

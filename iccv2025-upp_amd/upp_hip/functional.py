@@ -221,3 +221,51 @@ class _Attention(Function):
 
 def attention(qkv, num_heads, scale):
     return _Attention.apply(qkv, int(num_heads), float(scale))
+
+
+# ------------------------------------------------------------------ prompt propagation
+class _PropPool(Function):
+    """X (B,L',D), absolute neighbour rows i1 (B*G2*8) -> max_k + mean_k of the (drop-path scaled) rows, (B*G2, D)."""
+
+    @staticmethod
+    def forward(ctx, X, i1, u, keep):
+        X = X.contiguous()
+        groups = i1.numel() // 8
+        pooled, amax = ops.prop_pool_fwd(X, i1, u, keep, groups)
+        ctx.save_for_backward(amax, i1, u)
+        ctx.meta = (keep, X.shape)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        amax, i1, u = ctx.saved_tensors
+        keep, shape = ctx.meta
+        return ops.prop_pool_bwd(g.contiguous(), amax, i1, u, keep, shape[0] * shape[1]).view(shape), None, None, None
+
+
+class _PropInterp(Function):
+    """X (B,L',D), lc (B,G2,D) -> X with its last T rows += 0.3 * sum_k w8 * (lc + 0.3 * X[i2])[idx8]."""
+
+    @staticmethod
+    def forward(ctx, X, lc, i2, idx8, w8):
+        X, lc = X.contiguous(), lc.contiguous()
+        B, Lp, D = X.shape
+        T, G2 = idx8.shape[1], lc.shape[1]
+        ctx.save_for_backward(i2, idx8, w8)
+        ctx.meta = (B, Lp, T, G2)
+        return ops.prop_interp_fwd(X, lc, i2, idx8, w8, B, Lp, T, G2)
+
+    @staticmethod
+    def backward(ctx, g):
+        i2, idx8, w8 = ctx.saved_tensors
+        B, Lp, T, G2 = ctx.meta
+        g_c2, g_X = ops.prop_interp_bwd(g.contiguous(), i2, idx8, w8, B, Lp, T, G2)
+        return g_X, g_c2.view(B, G2, -1), None, None, None
+
+
+def prop_pool(X, i1, u=None, keep=1.0):
+    return _PropPool.apply(X, i1, u, float(keep))
+
+
+def prop_interp(X, lc, i2, idx8, w8):
+    return _PropInterp.apply(X, lc, i2, idx8, w8)

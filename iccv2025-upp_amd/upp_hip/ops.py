@@ -265,3 +265,36 @@ def attn_bwd(qkv, ctx, d_ctx, lse, B, L, H, scale):
     d_qkv = torch.empty_like(qkv)
     _call(qkv.device, "upp_attn_bwd", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(d_ctx), _abi.ptr(lse), _abi.ptr(d_qkv), B, L, H, hd, float(scale))
     return d_qkv
+
+
+# ------------------------------------------------------------------ prompt propagation
+def prop_pool_fwd(X, i1, u, keep, groups):
+    D = X.shape[-1]
+    pooled = torch.empty((groups, D), dtype=torch.float32, device=X.device)
+    amax = torch.empty((groups, D), dtype=torch.uint8, device=X.device)
+    _call(X.device, "upp_prop_pool_fwd", _abi.ptr(X), _abi.ptr(i1), _abi.ptr(u), float(keep), _abi.ptr(pooled), _abi.ptr(amax), groups, D)
+    return pooled, amax
+
+
+def prop_pool_bwd(g_pooled, amax, i1, u, keep, rows):
+    groups, D = g_pooled.shape
+    g_X = torch.empty((rows, D), dtype=torch.float32, device=g_pooled.device)
+    _call(g_pooled.device, "upp_prop_pool_bwd", _abi.ptr(g_pooled), _abi.ptr(amax), _abi.ptr(i1), _abi.ptr(u), float(keep),
+          _abi.ptr(g_X), rows, groups, D)
+    return g_X
+
+
+def prop_interp_fwd(X, lc, i2, idx8, w8, B, Lp, T, G2):
+    D = X.shape[-1]
+    out = torch.empty_like(X)
+    _call(X.device, "upp_prop_interp_fwd", _abi.ptr(X), _abi.ptr(lc), _abi.ptr(i2), _abi.ptr(idx8), _abi.ptr(w8), _abi.ptr(out), B, Lp, T, G2, D)
+    return out
+
+
+def prop_interp_bwd(g_out, i2, idx8, w8, B, Lp, T, G2):
+    D = g_out.shape[-1]
+    g_c2 = torch.empty((B * G2, D), dtype=torch.float32, device=g_out.device)
+    g_X = torch.empty_like(g_out)
+    _call(g_out.device, "upp_prop_interp_bwd", _abi.ptr(g_out), _abi.ptr(i2), _abi.ptr(idx8), _abi.ptr(w8), _abi.ptr(g_c2), _abi.ptr(g_X),
+          B, Lp, T, G2, D)
+    return g_c2, g_X

@@ -187,6 +187,28 @@ int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, 
 int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv,
                  int B, int L, int H, int head_dim, float scale, void *stream);
 
+/* ---- prompt propagation (Block.forward, reference models/Point_MAE_pretask_dev.py:275-303) ----
+ * X (rows, D): the block's token matrix viewed as rows = B*L' rows [cls | prompts | T centre tokens] per sample.
+ * Index arguments are ABSOLUTE row numbers of X (the host converts the reference's flat / per-sample index
+ * conventions, including its stride-64-into-stride-74 addressing when gather_idx is False).
+ *   upp_prop_pool_fwd : pooled[g] = max_k v + mean_k v over v_k = X[i1[g*8+k]] * (1 + s_g), s_g = floor(keep+u[g])/keep
+ *                       (u NULL: s = 1, i.e. eval-mode `x + drop_path(x)` = 2x); amax (groups, D) uint8 = arg max k.
+ *                       (`pooling` is undefined in the reference: SURVEY D.3 assumption; BatchNorm is applied by the caller.)
+ *   upp_prop_pool_bwd : g_X (rows, D), fully written (zeros where no group references a row).
+ *   upp_prop_interp_fwd: out[b,t] = X[b,t] (+ 0.3 * sum_k w8[b,i,k] * (lc[b,j] + 0.3 * X[i2[b*G2+j]]), j = idx8[b,i,k])
+ *                       for the last T rows (i = t - (L'-T)); `propagate(..., de_neighbors=8)` of models/Point_MAE_unify.py:22-48
+ *                       with idx8 / w8 (B,T,8) precomputed once per forward from the centres.
+ *   upp_prop_interp_bwd: g_c2 (B*G2, D) = gradient w.r.t. lc; g_X (rows, D) = g_out + 0.3 * g_c2 scattered to rows i2.
+ * Limits: D <= 512; 8 neighbours per group / per interpolation. */
+int upp_prop_pool_fwd(const float *X, const int32_t *i1, const float *u, float keep, float *pooled, uint8_t *amax,
+                      int groups, int D, void *stream);
+int upp_prop_pool_bwd(const float *g_pooled, const uint8_t *amax, const int32_t *i1, const float *u, float keep,
+                      float *g_X, int rows, int groups, int D, void *stream);
+int upp_prop_interp_fwd(const float *X, const float *lc, const int32_t *i2, const int32_t *idx8, const float *w8,
+                        float *out, int B, int Lp, int T, int G2, int D, void *stream);
+int upp_prop_interp_bwd(const float *g_out, const int32_t *i2, const int32_t *idx8, const float *w8, float *g_c2,
+                        float *g_X, int B, int Lp, int T, int G2, int D, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

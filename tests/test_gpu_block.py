@@ -103,10 +103,14 @@ def _block_case(model, name):
         _, center = model.group_divider(pts)
         lvl2 = upp_layers.Group(32, 8)
         _, c2, i1, i2 = lvl2(center, require_index=True, gather_idx=False)
-    if name in ("down0", "down7"):
-        L, blk = 65, model.blocks.blocks[0 if name == "down0" else 7]
+    if name in ("down0", "down7", "down3_gather"):
+        L, blk = 65, model.blocks.blocks[{"down0": 0, "down7": 7, "down3_gather": 3}[name]]
+        gi = name.endswith("gather")
+        if gi:
+            with torch.no_grad():
+                _, c2, i1, i2 = lvl2(center, require_index=True, gather_idx=True)
         kw = dict(path='downstream', downstream_adapter=True, downstream_prompts=True, classification=True, center1=center,
-                  center1_idx=i1, center2=c2, center2_idx=i2, gather_idx=False, prompt_propagation_after=True)
+                  center1_idx=i1, center2=c2, center2_idx=i2, gather_idx=gi, prompt_propagation_after=True, _prop_cache={})
     elif name == "rectify":
         L, blk, kw = 32, model.blocks.blocks[1], dict(path='rectify', rectify_adapter=True, rectify_prompts=True, rectify_depth=3)
     elif name == "pretask":
@@ -118,7 +122,7 @@ def _block_case(model, name):
     return blk, x, pos, kw
 
 
-@pytest.mark.parametrize("name", ["down0", "down7", "rectify", "pretask", "decoder"])
+@pytest.mark.parametrize("name", ["down0", "down3_gather", "down7", "rectify", "pretask", "decoder"])
 def test_block_fused_equals_unfused_with_gradients(model, name):
     blk, x, pos, kw = _block_case(model, name)
     assert blk.fusable(x)
