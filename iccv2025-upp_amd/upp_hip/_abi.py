@@ -42,6 +42,8 @@ SIGNATURES = {
     "upp_prop_pool_bwd": (_c_i, [_c_f] * 4 + [ctypes.c_float] + [_c_f] + [_c_i] * 3 + [_c_f]),
     "upp_prop_interp_fwd": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f]),
     "upp_prop_interp_bwd": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f]),
+    "upp_adamw_scratch_floats": (ctypes.c_longlong, []),
+    "upp_adamw_flat": (_c_i, [_c_f] * 4 + [ctypes.c_longlong] * 2 + [_c_f] * 2 + [ctypes.c_float] * 6 + [_c_f]),
 }
 # tuning hooks (not part of the reference-facing ABI)
 _EXTRA = {

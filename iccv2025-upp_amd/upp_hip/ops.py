@@ -298,3 +298,11 @@ def prop_interp_bwd(g_out, i2, idx8, w8, B, Lp, T, G2):
     _call(g_out.device, "upp_prop_interp_bwd", _abi.ptr(g_out), _abi.ptr(i2), _abi.ptr(idx8), _abi.ptr(w8), _abi.ptr(g_c2), _abi.ptr(g_X),
           B, Lp, T, G2, D)
     return g_c2, g_X
+
+
+# ------------------------------------------------------------------ optimizer tail
+def adamw_flat(p, g, m, v, n, split, state, scratch, lr, beta1, beta2, eps, weight_decay, max_norm):
+    for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (state, "state"), (scratch, "scratch")):
+        _need(t, name, torch.float32)
+    _call(p.device, "upp_adamw_flat", _abi.ptr(p), _abi.ptr(g), _abi.ptr(m), _abi.ptr(v), int(n), int(split), _abi.ptr(state),
+          _abi.ptr(scratch), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), float(max_norm))

@@ -38,6 +38,47 @@ def make_adamw(model, lr=5e-4, weight_decay=0.05, capturable=False):
     return torch.optim.AdamW(groups, lr=lr, capturable=capturable)
 
 
+def split_decay(model):
+    """(no_decay, decay) trainable parameters by the reference's rule (tools/builder.py:44-49)."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.dim() == 1 or name.endswith(".bias") or 'token' in name) else decay).append(p)
+    return no_decay, decay
+
+
+class FlatAdamW:
+    """clip_grad_norm_ + AdamW as three gfx950 kernels (csrc/optim.hip) over flat buffers: the parameters are
+    re-pointed into one flat buffer (no-decay group first), the gradients are FlatGradAllReduce's buffer."""
+
+    def __init__(self, no_decay, decay, flat_grad, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_norm=10.0):
+        from . import ops, _abi
+        self._ops = ops
+        params = list(no_decay) + list(decay)
+        dev = params[0].device
+        self.n = sum(p.numel() for p in params)
+        self.split = sum(p.numel() for p in no_decay)
+        self.p = torch.empty(self.n, device=dev)
+        off = 0
+        with torch.no_grad():
+            for q in params:
+                view = self.p[off:off + q.numel()].view_as(q)
+                view.copy_(q)
+                q.data = view                      # the model now reads its trainable weights from the flat buffer
+                off += q.numel()
+        self.g = flat_grad
+        self.m = torch.zeros(self.n, device=dev)
+        self.v = torch.zeros(self.n, device=dev)
+        self.state = torch.zeros(8, device=dev)
+        self.scratch = torch.empty(int(_abi.load().upp_adamw_scratch_floats()), device=dev)
+        self.hyper = (lr, betas[0], betas[1], eps, weight_decay, -1.0 if max_norm is None else max_norm)
+
+    def step(self):
+        lr, b1, b2, eps, wd, mn = self.hyper
+        self._ops.adamw_flat(self.p, self.g, self.m, self.v, self.n, self.split, self.state, self.scratch, lr, b1, b2, eps, wd, mn)
+
+
 class TrainStep:
     """step(pts, labels) -> loss (device tensor).  With use_graph=True the inputs are copied into
     static buffers and the captured graphs are replayed."""
@@ -48,9 +89,13 @@ class TrainStep:
         self.grad_clip = grad_clip
         self.kw = forward_kwargs or dict(completion_prompt=True, denoise=True, point_num=1024)
         self.use_graph = bool(use_graph) and self.device.type == 'cuda'
-        self.opt = make_adamw(model, lr=lr, capturable=self.use_graph)
-        self.flat = FlatGradAllReduce(model.parameters())
+        no_decay, decay = split_decay(model)
+        self.flat = FlatGradAllReduce(no_decay + decay)          # flat order: no-decay group, then decay group
         self.trainable = self.flat.params
+        if self.device.type == 'cuda':
+            self.opt = FlatAdamW(no_decay, decay, self.flat.flat, lr=lr, max_norm=grad_clip)
+        else:                                                   # host runs (gloo tests, CPU baseline): library optimizer
+            self.opt = make_adamw(model, lr=lr)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.pts = torch.zeros(batch_shape, device=self.device)
         self.labels = torch.zeros(batch_shape[0], dtype=torch.long, device=self.device)
@@ -60,14 +105,23 @@ class TrainStep:
     # -- the two halves of a step ------------------------------------------------------------
     def _forward_backward(self):
         self.flat.zero()
+        for p in self.trainable:
+            p.grad = None              # let autograd write fresh gradients: no per-parameter accumulate kernels
         logits = self.model(self.pts, **self.kw)
         loss, acc = self.model.get_loss_acc(logits, self.labels)
         loss.backward()
+        got = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None]
+        torch._foreach_copy_([v for v, _ in got], [g for _, g in got])   # one multi-tensor copy into the flat buffer
+        for p, v in zip(self.trainable, self.flat.views):
+            p.grad = v
         self.flat.scalars[0].copy_(loss.detach())
         self.flat.scalars[1].copy_(acc.detach())
         self.loss.copy_(loss.detach())
 
     def _update(self):
+        if isinstance(self.opt, FlatAdamW):
+            self.opt.step()            # clipping is fused into the flat update
+            return
         if self.grad_clip is not None:
             torch.nn.utils.clip_grad_norm_(self.trainable, self.grad_clip, norm_type=2)
         self.opt.step()

@@ -59,8 +59,10 @@ class FlatGradAllReduce:
         self.numel = n
         self.flat = torch.zeros(n + extra_scalars, device=dev, dtype=dt)
         off = 0
+        self.views = []
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            p.grad = self.views[-1]
             off += p.numel()
         self.scalars = self.flat[n:]
 

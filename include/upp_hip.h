@@ -209,6 +209,18 @@ int upp_prop_interp_fwd(const float *X, const float *lc, const int32_t *i2, cons
 int upp_prop_interp_bwd(const float *g_out, const int32_t *i2, const int32_t *idx8, const float *w8, float *g_c2,
                         float *g_X, int B, int Lp, int T, int G2, int D, void *stream);
 
+/* ---- training step tail: gradient clipping + AdamW on flat buffers ------------------------
+ * Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.AdamW.step() of the reference loop
+ * (tools/runner_module.py:202-207; parameter groups of tools/builder.py:40-55) for parameters that live in one
+ * flat buffer: p, g, m (exp_avg), v (exp_avg_sq) all (n) f32; elements [0, split) have weight decay 0,
+ * [split, n) have `weight_decay`.  state (8 floats, zero-initialised once): [0] step count, [1] gradient L2 norm,
+ * [2] clip coefficient min(max_norm / (norm + 1e-6), 1), [3] 1 - beta1^step, [4] sqrt(1 - beta2^step).
+ * g is overwritten with the clipped gradient (as clip_grad_norm_ does).  max_norm <= 0 disables clipping.
+ * scratch: upp_adamw_scratch_floats() floats. */
+long long upp_adamw_scratch_floats(void);
+int upp_adamw_flat(float *p, float *g, float *m, float *v, long long n, long long split, float *state, float *scratch,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,3 +156,30 @@ def test_train_mode_drop_path_statistics(model):
         np.testing.assert_allclose(got, np.floor(keep + u.cpu().numpy()) / keep, rtol=1e-6)
     finally:
         blk.eval()
+
+
+def test_flat_adamw_matches_torch_clip_and_adamw():
+    """csrc/optim.hip against clip_grad_norm_(10) + torch.optim.AdamW (the reference's step tail)."""
+    from upp_hip.train import FlatAdamW
+    from utils.dist_utils import FlatGradAllReduce
+    torch.manual_seed(0)
+    shapes_nd, shapes_d = [(384,), (32,), (1, 1, 384)], [(32, 384), (384, 32), (10, 384)]
+    mk = lambda shp: [torch.nn.Parameter(torch.randn(s, device='cuda') * 0.1) for s in shp]
+    nd, d = mk(shapes_nd), mk(shapes_d)
+    rnd, rd = [torch.nn.Parameter(p.detach().clone()) for p in nd], [torch.nn.Parameter(p.detach().clone()) for p in d]
+    ref = torch.optim.AdamW([{'params': rnd, 'weight_decay': 0.}, {'params': rd, 'weight_decay': 0.05}], lr=5e-4)
+    flat = FlatGradAllReduce(nd + d)
+    opt = FlatAdamW(nd, d, flat.flat, lr=5e-4, max_norm=10.0)
+    for it in range(5):
+        scale = 50.0 if it % 2 == 0 else 0.01          # with and without active clipping
+        for p, q, v in zip(nd + d, rnd + rd, flat.views):
+            gr = torch.randn_like(p) * scale
+            v.copy_(gr)
+            q.grad = gr.clone()
+        total = torch.nn.utils.clip_grad_norm_(rnd + rd, 10.0)
+        ref.step()
+        opt.step()
+        np.testing.assert_allclose(opt.state[1].item(), total.item(), rtol=1e-5)
+        for p, q in zip(nd + d, rnd + rd):
+            close(p, q, rtol=2e-5, atol_scale=2e-6)
+    assert opt.state[0].item() == 5
