@@ -49,6 +49,7 @@ SIGNATURES = {
 _EXTRA = {
     "upp_fps_set_waves": (_c_i, [_c_i]),
     "upp_knn_set_prefilter": (_c_i, [_c_i]),
+    "upp_attn_set_mfma": (_c_i, [_c_i]),
 }
 
 _lib = None

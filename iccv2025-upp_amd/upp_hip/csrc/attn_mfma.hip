@@ -1,0 +1,214 @@
+// attn_mfma.hip -- attention core (forward and backward) on FP32 MFMA for sequences up to 96 tokens, head dim 64.
+// Same contract as attn_fwd / attn_bwd in block.hip (which remain the general path for longer sequences); see
+// include/upp_hip.h upp_attn_fwd / upp_attn_bwd and reference models/Point_MAE_pretask_dev.py:186-193.
+//
+// One workgroup (4 waves) per (sample, head).  Q, K, V (and dO) are staged once in LDS (rows padded to 65 floats so
+// that both the row-major and the transposed one-dword-per-lane MFMA operand reads are bank-conflict free), every
+// product is a set of 32x32 output tiles of v_mfma_f32_32x32x2_f32 dealt round-robin to the waves:
+//   forward : S = Q K^T (9 tiles) -> row softmax in LDS -> O = P V (6 tiles)
+//   backward: S and dP = dO V^T (9+9 tiles) -> P = exp(S*scale - lse), dS = P*(dP - delta)*scale in registers ->
+//             dV = P^T dO, dK = dS^T Q, dQ = dS K (6 tiles each); P and dS share one 96x97 LDS buffer.
+// The (L x L) score matrix never leaves the CU.  delta_i = dO_i . O_i (the usual rewrite of sum_j P_ij dP_ij).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kLP = 96;          // padded sequence length
+constexpr int kLD = 65;          // row stride of the (L x 64) operand tiles
+constexpr int kLS = 97;          // row stride of the (L x L) score buffer
+
+// acc(32x32) += A(32 x K) . B(K x 32).  Element A(i,k): TA ? a[k*lda + i] : a[i*lda + k];  B(k,j): TB ? b[j*ldb + k] : b[k*ldb + j]
+template <bool TA, bool TB>
+__device__ __forceinline__ void mfma_tile(f32x16 &acc, const float *a, int lda, const float *b, int ldb, int K, int lr, int lk) {
+#pragma unroll 8
+    for (int k0 = 0; k0 < K; k0 += 2) {
+        const float av = TA ? a[(k0 + lk) * lda + lr] : a[lr * lda + k0 + lk];
+        const float bv = TB ? b[lr * ldb + k0 + lk] : b[(k0 + lk) * ldb + lr];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void zero(f32x16 &a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+}
+__device__ __forceinline__ int tile_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+
+// stage rows [0, L) x 64 of `src` (row stride rs floats) into dst[kLP][kLD], zero rows >= L
+__device__ __forceinline__ void stage64(float *dst, const float *src, size_t rs, int L) {
+    for (int i = threadIdx.x; i < kLP * 16; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < L) v = *reinterpret_cast<const float4 *>(src + (size_t)r * rs + c);
+        float *d = dst + r * kLD + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
+                                                            float *__restrict__ lse, int L, int H, float scale) {
+    extern __shared__ float sm[];
+    float *Qs = sm, *Ks = Qs + kLP * kLD, *Vs = Ks + kLP * kLD, *Ss = Vs + kLP * kLD;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 31, lk = lane >> 5;
+    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const size_t rs = (size_t)3 * H * 64;
+    const float *base = qkv + (size_t)b * L * rs + (size_t)hh * 64;
+    stage64(Qs, base, rs, L);
+    stage64(Ks, base + H * 64, rs, L);
+    stage64(Vs, base + 2 * H * 64, rs, L);
+    __syncthreads();
+    const int nt = (L + 31) / 32;                       // tiles along the sequence
+    for (int t = wave; t < nt * nt; t += 4) {           // S = Q K^T, scaled
+        const int it = t / nt, jt = t - it * nt;
+        f32x16 acc; zero(acc);
+        mfma_tile<false, true>(acc, Qs + it * 32 * kLD, kLD, Ks + jt * 32 * kLD, kLD, 64, lr, lk);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ss[(it * 32 + tile_row(r, lk)) * kLS + jt * 32 + lr] = acc[r] * scale;
+    }
+    __syncthreads();
+    for (int i = wave; i < L; i += 4) {                 // row softmax, lane = key (2 slots cover 96 columns... 64+32)
+        float *row = Ss + i * kLS;
+        const float s0 = lane < L ? row[lane] : -__builtin_inff();
+        const float s1 = lane + 64 < L ? row[lane + 64] : -__builtin_inff();
+        const float mx = wave_max_f32(fmaxf(s0, s1));
+        const float e0 = lane < L ? expf(s0 - mx) : 0.0f, e1 = lane + 64 < L ? expf(s1 - mx) : 0.0f;
+        const float sum = wave_sum_f32(e0 + e1);
+        const float inv = 1.0f / sum;
+        row[lane] = e0 * inv;
+        if (lane + 64 < kLP) row[lane + 64] = e1 * inv;
+        if (lane == 0) lse[((size_t)b * H + hh) * L + i] = mx + logf(sum);
+    }
+    for (int i = L + wave; i < nt * 32; i += 4) {       // padded query rows contribute nothing
+        Ss[i * kLS + lane] = 0.0f;
+        if (lane + 64 < kLP) Ss[i * kLS + lane + 64] = 0.0f;
+    }
+    __syncthreads();
+    for (int t = wave; t < nt * 2; t += 4) {            // O = P V
+        const int it = t >> 1, dt = t & 1;
+        f32x16 acc; zero(acc);
+        mfma_tile<false, false>(acc, Ss + it * 32 * kLS, kLS, Vs + dt * 32, kLD, nt * 32, lr, lk);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = it * 32 + tile_row(r, lk);
+            if (i < L) ctx[((size_t)b * L + i) * (H * 64) + hh * 64 + dt * 32 + lr] = acc[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float *__restrict__ qkv, const float *__restrict__ ctx,
+                                                            const float *__restrict__ d_ctx, const float *__restrict__ lse,
+                                                            float *__restrict__ d_qkv, int L, int H, float scale) {
+    extern __shared__ float sm[];
+    float *Qs = sm, *Ks = Qs + kLP * kLD, *Vs = Ks + kLP * kLD, *Gs = Vs + kLP * kLD, *Ss = Gs + kLP * kLD;
+    float *delta = Ss + kLP * kLS, *lses = delta + kLP;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 31, lk = lane >> 5;
+    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const size_t rs = (size_t)3 * H * 64, cs = (size_t)H * 64;
+    const float *base = qkv + (size_t)b * L * rs + (size_t)hh * 64;
+    float *dbase = d_qkv + (size_t)b * L * rs + (size_t)hh * 64;
+    const float *gbase = d_ctx + (size_t)b * L * cs + (size_t)hh * 64;
+    const float *obase = ctx + (size_t)b * L * cs + (size_t)hh * 64;
+    stage64(Qs, base, rs, L);
+    stage64(Ks, base + H * 64, rs, L);
+    stage64(Vs, base + 2 * H * 64, rs, L);
+    stage64(Gs, gbase, cs, L);
+    for (int i = wave; i < kLP; i += 4) {               // delta_i = dO_i . O_i ; lse_i
+        float d = 0.0f;
+        if (i < L) d = gbase[(size_t)i * cs + lane] * obase[(size_t)i * cs + lane];
+        d = wave_sum_f32(d);
+        if (lane == 0) { delta[i] = d; lses[i] = i < L ? lse[((size_t)b * H + hh) * L + i] : 0.0f; }
+    }
+    __syncthreads();
+    const int nt = (L + 31) / 32;
+    // phase 1: P and dS tiles in registers (a wave owns at most 3 of the <= 9 tiles)
+    f32x16 pt[3], dst[3];
+    int nown = 0;
+    for (int t = wave; t < nt * nt; t += 4, ++nown) {
+        const int it = t / nt, jt = t - it * nt;
+        f32x16 s, dp; zero(s); zero(dp);
+        mfma_tile<false, true>(s, Qs + it * 32 * kLD, kLD, Ks + jt * 32 * kLD, kLD, 64, lr, lk);
+        mfma_tile<false, true>(dp, Gs + it * 32 * kLD, kLD, Vs + jt * 32 * kLD, kLD, 64, lr, lk);
+        const int j = jt * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = it * 32 + tile_row(r, lk);
+            const float p = (i < L && j < L) ? expf(s[r] * scale - lses[i]) : 0.0f;
+            s[r] = p;
+            dp[r] = p * (dp[r] - delta[i]) * scale;
+        }
+        // static register indexing of the per-wave tile store
+        if (nown == 0) { pt[0] = s; dst[0] = dp; } else if (nown == 1) { pt[1] = s; dst[1] = dp; } else { pt[2] = s; dst[2] = dp; }
+    }
+    // phase 2: P -> LDS, dV = P^T dO
+    nown = 0;
+    for (int t = wave; t < nt * nt; t += 4, ++nown) {
+        const int it = t / nt, jt = t - it * nt;
+        const f32x16 v = nown == 0 ? pt[0] : (nown == 1 ? pt[1] : pt[2]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ss[(it * 32 + tile_row(r, lk)) * kLS + jt * 32 + lr] = v[r];
+    }
+    __syncthreads();
+    for (int t = wave; t < nt * 2; t += 4) {
+        const int jt = t >> 1, dt = t & 1;
+        f32x16 acc; zero(acc);
+        mfma_tile<true, false>(acc, Ss + jt * 32, kLS, Gs + dt * 32, kLD, nt * 32, lr, lk);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jt * 32 + tile_row(r, lk);
+            if (j < L) dbase[(size_t)j * rs + 2 * H * 64 + dt * 32 + lr] = acc[r];
+        }
+    }
+    __syncthreads();
+    // phase 3: dS -> LDS, dK = dS^T Q, dQ = dS K
+    nown = 0;
+    for (int t = wave; t < nt * nt; t += 4, ++nown) {
+        const int it = t / nt, jt = t - it * nt;
+        const f32x16 v = nown == 0 ? dst[0] : (nown == 1 ? dst[1] : dst[2]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ss[(it * 32 + tile_row(r, lk)) * kLS + jt * 32 + lr] = v[r];
+    }
+    __syncthreads();
+    for (int t = wave; t < nt * 4; t += 4) {
+        const int which = t / (nt * 2), u = t - which * nt * 2;   // 0: dK tiles, 1: dQ tiles
+        const int rt = u >> 1, dt = u & 1;
+        f32x16 acc; zero(acc);
+        if (which == 0) mfma_tile<true, false>(acc, Ss + rt * 32, kLS, Qs + dt * 32, kLD, nt * 32, lr, lk);
+        else mfma_tile<false, false>(acc, Ss + rt * 32 * kLS, kLS, Ks + dt * 32, kLD, nt * 32, lr, lk);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rt * 32 + tile_row(r, lk);
+            if (row < L) dbase[(size_t)row * rs + (which == 0 ? H * 64 : 0) + dt * 32 + lr] = acc[r];
+        }
+    }
+}
+
+constexpr size_t kFwdLds = ((size_t)3 * kLP * kLD + (size_t)kLP * kLS) * sizeof(float);
+constexpr size_t kBwdLds = ((size_t)4 * kLP * kLD + (size_t)kLP * kLS + 2 * kLP) * sizeof(float);
+
+}  // namespace
+
+// called by upp_attn_fwd / upp_attn_bwd (block.hip) for L <= 96
+int upp_attn_fwd_mfma(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st) {
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
+        if (e != hipSuccess) return (int)e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), kFwdLds, st, qkv, ctx, lse, L, H, scale);
+    return upp_launch_status();
+}
+
+int upp_attn_bwd_mfma(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
+                      float scale, hipStream_t st) {
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds);
+        if (e != hipSuccess) return (int)e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), kBwdLds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
+    return upp_launch_status();
+}

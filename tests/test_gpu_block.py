@@ -18,8 +18,18 @@ def close(a, b, rtol=1e-5, atol_scale=2e-6):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_scale * max(np.abs(b).max(), 1e-30))
 
 
-@pytest.mark.parametrize("L", [35, 64, 65, 75, 129])
-def test_attention_core_forward_backward(L):
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("L", [1, 31, 35, 64, 65, 75, 96, 97, 129])
+def test_attention_core_forward_backward(L, mfma):
+    from upp_hip import _abi
+    _abi.load().upp_attn_set_mfma(mfma)     # MFMA kernels serve L <= 96; 0 forces the general VALU kernels
+    try:
+        _attention_case(L)
+    finally:
+        _abi.load().upp_attn_set_mfma(1)
+
+
+def _attention_case(L):
     torch.manual_seed(L)
     B, H = 3, 6
     qkv = torch.randn(B, L, 3 * H * 64, device='cuda', requires_grad=True)
