@@ -322,23 +322,6 @@ class Block(nn.Module):
         return x + branch if scale is None else torch.addcmul(x, branch, scale)
 
     # -- fused gfx950 path ---------------------------------------------------------------------------
-    _tables = {}
-
-    @classmethod
-    def _row_tables(cls, L, P, is_cls, device):
-        """int32 row maps for prompt insertion (L -> L+P) and removal (L+P -> L); -(p+1) selects prompt p."""
-        key = (L, P, is_cls, str(device))
-        if key not in cls._tables:
-            if is_cls:
-                ins = [0] + [-(p + 1) for p in range(P)] + list(range(1, L))
-                rem = [0] + list(range(P + 1, L + P))
-            else:
-                ins = [-(p + 1) for p in range(P)] + list(range(L))
-                rem = list(range(P, L + P))
-            cls._tables[key] = (torch.tensor(ins, dtype=torch.int32, device=device),
-                                torch.tensor(rem, dtype=torch.int32, device=device))
-        return cls._tables[key]
-
     def _propagate_fused(self, x, kw):
         """_propagate_prompts on the row kernels of csrc/prop.hip.  The neighbour weights and the absolute row
         indices depend only on the centres / the token layout, so they are built once per forward (shared dict
@@ -393,16 +376,15 @@ class Block(nn.Module):
         prompts = getattr(self, f'{path}_prompts', None) if path in _PATHS else None
         B, L, D = x.shape
         P = 0 if prompts is None else prompts.shape[0]
-        ins = rem = None
-        if P:
-            ins, rem = self._row_tables(L, P, is_cls, x.device)
+        ins = (HF.ROW_INSERT_CLS if is_cls else HF.ROW_INSERT) if P else HF.ROW_IDENTITY
+        rem = (HF.ROW_STRIP_CLS if is_cls else HF.ROW_STRIP) if P else HF.ROW_IDENTITY
         u = None
         keep = 1.0
         if isinstance(self.drop_path, DropPath) and self.training and self.drop_path.drop_prob > 0:
             u = torch.rand(2, B, device=x.device)
             keep = 1.0 - self.drop_path.drop_prob
         n1, n2 = self.norm1, self.norm2
-        xa, h1 = HF.rowln(x, add=pos, prompts=prompts, table=ins, gamma=n1.weight, beta=n1.bias, eps=n1.eps)
+        xa, h1 = HF.rowln(x, add=pos, prompts=prompts, mode=ins, P=P, gamma=n1.weight, beta=n1.bias, eps=n1.eps)
         y = self.attn(h1)
         x2, h2 = HF.rowln(xa, y=y, u=None if u is None else u[0], keep=keep, gamma=n2.weight, beta=n2.bias, eps=n2.eps)
         m = self.mlp(h2)
@@ -418,10 +400,10 @@ class Block(nn.Module):
                 x3, _ = self._propagate_prompts(x3, kw)
             m, u2, x2 = None, None, x3
         if adapter is None:
-            x4, _ = HF.rowln(x2, y=m, u=u2, keep=keep, table=rem, covers_all=not P)
+            x4, _ = HF.rowln(x2, y=m, u=u2, keep=keep, mode=rem, P=P)
             return x4
         ln = adapter.layer_norm
-        x4, ha = HF.rowln(x2, y=m, u=u2, keep=keep, table=rem, gamma=ln.weight, beta=ln.bias, eps=ln.eps, covers_all=not P)
+        x4, ha = HF.rowln(x2, y=m, u=u2, keep=keep, mode=rem, P=P, gamma=ln.weight, beta=ln.bias, eps=ln.eps)
         z = adapter.ln2(adapter.dropout(adapter.activate(adapter.ln1(ha))))
         return torch.add(x4, z, alpha=0.7)
 

@@ -19,14 +19,21 @@ constexpr int kLD = 65;          // row stride of the (L x 64) operand tiles
 constexpr int kLS = 97;          // row stride of the (L x L) score buffer
 
 // acc(32x32) += A(32 x K) . B(K x 32).  Element A(i,k): TA ? a[k*lda + i] : a[i*lda + k];  B(k,j): TB ? b[j*ldb + k] : b[k*ldb + j]
-template <bool TA, bool TB>
-__device__ __forceinline__ void mfma_tile(f32x16 &acc, const float *a, int lda, const float *b, int ldb, int K, int lr, int lk) {
-#pragma unroll 8
+template <bool TA, bool TB, int K>
+__device__ __forceinline__ void mfma_tile_k(f32x16 &acc, const float *a, int lda, const float *b, int ldb, int lr, int lk) {
+#pragma unroll
     for (int k0 = 0; k0 < K; k0 += 2) {
         const float av = TA ? a[(k0 + lk) * lda + lr] : a[lr * lda + k0 + lk];
         const float bv = TB ? b[lr * ldb + k0 + lk] : b[(k0 + lk) * ldb + lr];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
+}
+// K is a compile-time constant so that the operand loop unrolls fully and the LDS reads run ahead of the MFMAs
+template <bool TA, bool TB>
+__device__ __forceinline__ void mfma_tile(f32x16 &acc, const float *a, int lda, const float *b, int ldb, int K, int lr, int lk) {
+    if (K == 32) mfma_tile_k<TA, TB, 32>(acc, a, lda, b, ldb, lr, lk);
+    else if (K == 64) mfma_tile_k<TA, TB, 64>(acc, a, lda, b, ldb, lr, lk);
+    else mfma_tile_k<TA, TB, 96>(acc, a, lda, b, ldb, lr, lk);
 }
 __device__ __forceinline__ void zero(f32x16 &a) {
 #pragma unroll

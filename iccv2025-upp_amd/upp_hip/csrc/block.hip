@@ -28,8 +28,8 @@ __device__ __forceinline__ float wave_sum(float v) { return wave_sum_f32(v); }
 struct RowLnArgs {
     const float *x;        // (B, Lin, D) source rows
     const float *add;      // (B, Lin, D) added to x rows (positional embedding) or null
-    const float *prompts;  // (P, D) rows selected by negative table entries, or null
-    const int *table;      // (Lout) source row per output row; -(p+1) selects prompt p; null = identity
+    const float *prompts;  // (P, D) rows selected by negative row_src values, or null
+    int mode, P;           // row map (see row_src): 0 identity, 1/2 insert P prompts (with/without cls), 3/4 strip them
     const float *y;        // (B, Lin, D) residual branch, row-aligned with x: added as scale_b * y, or null
     const float *u;        // (B) uniforms for stochastic depth (scale_b = floor(keep+u)/keep), or null (scale 1)
     float keep;
@@ -41,6 +41,17 @@ struct RowLnArgs {
     int B, Lin, Lout, D;
 };
 
+// Source row of output row t; -(p+1) selects prompt p.  Token layouts: [cls | prompts | tokens] or [prompts | tokens].
+__device__ __forceinline__ int row_src(int t, int mode, int P) {
+    switch (mode) {
+        case 1: return t == 0 ? 0 : (t <= P ? -t : t - P);   // insert P prompts after the cls token
+        case 2: return t < P ? -(t + 1) : t - P;             // insert P prompts in front
+        case 3: return t == 0 ? 0 : t + P;                   // strip the prompts that follow the cls token
+        case 4: return t + P;                                // strip leading prompts
+        default: return t;
+    }
+}
+
 __device__ __forceinline__ float dp_scale(const float *u, float keep, int b) {
     return u ? floorf(keep + u[b]) / keep : 1.0f;
 }
@@ -50,7 +61,7 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.B * a.Lout) return;
     const int b = row / a.Lout, t = row - b * a.Lout;
-    const int src = a.table ? a.table[t] : t;
+    const int src = row_src(t, a.mode, a.P);
     const int D = a.D;
     float v[kMaxE];
     const float *xs = src >= 0 ? a.x + ((size_t)b * a.Lin + src) * D : a.prompts + (size_t)(-src - 1) * D;
@@ -93,7 +104,7 @@ struct RowLnBwdArgs {
     const float *g_h;      // (B, Lout, D) gradient w.r.t. the LayerNorm output (null when no LayerNorm)
     const float *xo;       // (B, Lout, D) saved assembled rows
     const float *mean, *rstd, *gamma;
-    const int *table;
+    int mode;
     const float *u; float keep;
     float *g_x;            // (B, Lin, D): rows referenced by the table are written (caller zero-fills if not all are)
     float *g_prompt;       // (B, P, D) per-sample gradient of the prompt rows, or null
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.B * a.Lout) return;
     const int b = row / a.Lout, t = row - b * a.Lout;
-    const int src = a.table ? a.table[t] : t;
+    const int src = row_src(t, a.mode, a.P);
     const int D = a.D;
     float d[kMaxE];
 #pragma unroll
@@ -366,7 +377,7 @@ int set_lds(K kernel, size_t bytes) {
 
 }  // namespace
 
-extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prompts, const int32_t *table, const float *y,
+extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y,
                              const float *u, float keep, const float *gamma, const float *beta, float eps, float *xo, float *h,
                              float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream) {
     if (!x || B < 0 || Lin < 1 || Lout < 1 || D < 1) return UPP_E_BADARG;
@@ -374,19 +385,23 @@ extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prom
     if (!gamma && !xo) return UPP_E_BADARG;
     if (D > 64 * kMaxE) return UPP_E_RANGE;
     if (B == 0) return 0;
-    RowLnArgs a{x, add, prompts, table, y, u, keep, gamma, beta, eps, xo, h, mean, rstd, B, Lin, Lout, D};
+    if (mode < 0 || mode > 4 || P < 0 || ((mode == 1 || mode == 2) && (Lout != Lin + P || (P > 0 && !prompts))) ||
+        ((mode == 3 || mode == 4) && Lout != Lin - P) || (mode == 0 && Lout != Lin))
+        return UPP_E_BADARG;
+    RowLnArgs a{x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, xo, h, mean, rstd, B, Lin, Lout, D};
     hipLaunchKernelGGL(rowln_fwd_kernel, dim3((B * Lout + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return upp_launch_status();
 }
 
 extern "C" int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
-                             const float *gamma, const int32_t *table, const float *u, float keep, float *g_x, float *g_prompt,
+                             const float *gamma, int mode, const float *u, float keep, float *g_x, float *g_prompt,
                              float *g_y, int B, int Lin, int Lout, int D, int P, void *stream) {
     if ((!g_xo && !g_h) || B < 0 || Lin < 1 || Lout < 1 || D < 1) return UPP_E_BADARG;
     if (g_h && (!xo || !mean || !rstd || !gamma)) return UPP_E_BADARG;
     if (D > 64 * kMaxE) return UPP_E_RANGE;
     if (B == 0) return 0;
-    RowLnBwdArgs a{g_xo, g_h, xo, mean, rstd, gamma, table, u, keep, g_x, g_prompt, g_y, B, Lin, Lout, D, P};
+    if (mode < 0 || mode > 4 || P < 0) return UPP_E_BADARG;
+    RowLnBwdArgs a{g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, g_x, g_prompt, g_y, B, Lin, Lout, D, P};
     hipLaunchKernelGGL(rowln_bwd_kernel, dim3((B * Lout + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return upp_launch_status();
 }

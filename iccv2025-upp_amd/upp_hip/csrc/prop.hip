@@ -53,34 +53,72 @@ __global__ __launch_bounds__(256) void prop_pool_fwd_kernel(const float *__restr
     }
 }
 
+// Positions q in [q0, n) with list[q] == key, appended to hits[] (LDS, per wave) until `cap` could overflow.
+// Returns the number collected and advances q0 (wave-uniform).  list lives in LDS.
+__device__ __forceinline__ int collect_hits(const int32_t *list, int n, int key, int *hits, int cap, int lane, int &q0) {
+    int cnt = 0;
+    int q = q0;
+    for (; q < n && cnt + 64 <= cap; q += 64) {
+        const int me = q + lane;
+        const bool pred = me < n && list[me] == key;
+        const unsigned long long mask = __ballot(pred);
+        if (mask) {
+            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pred) hits[pos] = me;
+            cnt += __popcll(mask);
+        }
+    }
+    q0 = q;
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+}
+
+constexpr int kHitCap = 256;
+
 // g_X[r][c] = sum over (g,k) with i1[g][k] == r of  (1 + s_g) * g_pooled[g][c] * (1/8 + [amax[g][c] == k])
+// The whole index list is staged in LDS once per workgroup; each wave scans it for its row, collects the hits and
+// then accumulates them four at a time (independent row loads in flight), in ascending list order: deterministic.
 __global__ __launch_bounds__(256) void prop_pool_bwd_kernel(const float *__restrict__ g_pooled, const uint8_t *__restrict__ amax,
                                                             const int32_t *__restrict__ i1, const float *__restrict__ u, float keep,
                                                             float *__restrict__ g_X, int rows, int groups, int D) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    extern __shared__ int32_t lds_i[];
+    const int n = groups * kNb;
+    int32_t *list = lds_i;                               // [n]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int *hits = lds_i + n + wave * kHitCap;
+    for (int i = threadIdx.x; i < n; i += 256) list[i] = i1[i];
+    __syncthreads();
+    const int r = blockIdx.x * 4 + wave;
     if (r >= rows) return;
     float acc[kMaxE];
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) acc[e] = 0.0f;
-    const int n = groups * kNb;
-    for (int base = 0; base < n; base += 64) {
-        const int q = base + lane;
-        unsigned long long mask = __ballot(q < n && i1[q] == r);
-        while (mask) {                                   // matches in ascending list order: deterministic
-            const int hit = base + __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const int g = hit / kNb, k = hit - g * kNb;
-            const float f = 1.0f + (u ? floorf(keep + u[g]) / keep : 1.0f);
+    int q0 = 0;
+    while (q0 < n) {
+        const int cnt = collect_hits(list, n, r, hits, kHitCap, lane, q0);
+        for (int h0 = 0; h0 < cnt; h0 += 4) {
+            int g[4], k[4];
+            float f[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool live = h0 + t < cnt;
+                const int hit = hits[live ? h0 + t : h0];
+                g[t] = hit / kNb; k[t] = hit - g[t] * kNb;
+                f[t] = live ? 1.0f + (u ? floorf(keep + u[g[t]]) / keep : 1.0f) : 0.0f;
+            }
 #pragma unroll
             for (int e = 0; e < kMaxE; ++e) {
                 const int c = lane + 64 * e;
                 if (c < D) {
-                    const float gp = g_pooled[(size_t)g * D + c];
-                    acc[e] += gp * f * (0.125f + (amax[(size_t)g * D + c] == k ? 1.0f : 0.0f));
+                    float gp[4]; int am[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { gp[t] = g_pooled[(size_t)g[t] * D + c]; am[t] = amax[(size_t)g[t] * D + c]; }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[e] += gp[t] * f[t] * (0.125f + (am[t] == k[t] ? 1.0f : 0.0f));
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) g_X[(size_t)r * D + c] = acc[e]; }
@@ -121,30 +159,53 @@ __global__ __launch_bounds__(256) void prop_interp_fwd_kernel(const float *__res
 }
 
 // g_c2[b][j][c] = 0.3 * sum over (i,k) with idx8[b][i][k] == j of w8[b][i][k] * g_out[b][L'-T+i][c]
+// A workgroup serves 4 consecutive level-2 centres of one sample (G2 % 4 == 0 is checked by the host), stages that
+// sample's idx8 / w8 in LDS, collects the hits per wave and accumulates four token rows at a time.
 __global__ __launch_bounds__(256) void prop_interp_bwd_c2_kernel(const float *__restrict__ g_out, const int32_t *__restrict__ idx8,
                                                                  const float *__restrict__ w8, float *__restrict__ g_c2, int B, int Lp,
                                                                  int T, int G2, int D) {
-    const int lane = threadIdx.x & 63;
-    const int gj = blockIdx.x * 4 + (threadIdx.x >> 6);
+    extern __shared__ int32_t lds_i[];
+    const int n = T * kNb;
+    int32_t *list = lds_i;                                   // [n]
+    float *wl = reinterpret_cast<float *>(lds_i + n);        // [n]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int *hits = lds_i + 2 * n + wave * kHitCap;
+    const int gj0 = blockIdx.x * 4;
+    const int b = gj0 / G2;
+    for (int i = threadIdx.x; i < n; i += 256) { list[i] = idx8[(size_t)b * n + i]; wl[i] = w8[(size_t)b * n + i]; }
+    __syncthreads();
+    const int gj = gj0 + wave;
     if (gj >= B * G2) return;
-    const int b = gj / G2, j = gj - b * G2;
+    const int j = gj - b * G2;
     float acc[kMaxE];
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) acc[e] = 0.0f;
-    const int n = T * kNb;
-    const int32_t *ib = idx8 + (size_t)b * n;
-    for (int base = 0; base < n; base += 64) {
-        const int q = base + lane;
-        unsigned long long mask = __ballot(q < n && ib[q] == j);
-        while (mask) {
-            const int hit = base + __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const int i = hit / kNb;
-            const float w = w8[(size_t)b * n + hit];
-            const float *grow = g_out + ((size_t)b * Lp + (Lp - T) + i) * D;
+    int q0 = 0;
+    while (q0 < n) {
+        const int cnt = collect_hits(list, n, j, hits, kHitCap, lane, q0);
+        for (int h0 = 0; h0 < cnt; h0 += 4) {
+            const float *grow[4];
+            float w[4];
 #pragma unroll
-            for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) acc[e] += grow[c] * w; }
+            for (int t = 0; t < 4; ++t) {
+                const bool live = h0 + t < cnt;
+                const int hit = hits[live ? h0 + t : h0];
+                w[t] = live ? wl[hit] : 0.0f;
+                grow[t] = g_out + ((size_t)b * Lp + (Lp - T) + hit / kNb) * D;
+            }
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) {
+                const int c = lane + 64 * e;
+                if (c < D) {
+                    float gv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) gv[t] = grow[t][c];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[e] += gv[t] * w[t];
+                }
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) g_c2[(size_t)gj * D + c] = 0.3f * acc[e]; }
@@ -190,7 +251,9 @@ extern "C" int upp_prop_pool_bwd(const float *g_pooled, const uint8_t *amax, con
                                  float *g_X, int rows, int groups, int D, void *stream) {
     if (!g_pooled || !amax || !i1 || !g_X || rows < 1 || groups < 1 || D < 1) return UPP_E_BADARG;
     if (D > 64 * kMaxE) return UPP_E_RANGE;
-    hipLaunchKernelGGL(prop_pool_bwd_kernel, rows_grid(rows), dim3(256), 0, (hipStream_t)stream, g_pooled, amax, i1, u, keep, g_X, rows, groups, D);
+    const size_t lds = ((size_t)groups * kNb + 4 * kHitCap) * sizeof(int32_t);
+    if (lds > 64 * 1024) return UPP_E_RANGE;    // the index list must fit LDS (groups <= ~1900)
+    hipLaunchKernelGGL(prop_pool_bwd_kernel, rows_grid(rows), dim3(256), lds, (hipStream_t)stream, g_pooled, amax, i1, u, keep, g_X, rows, groups, D);
     return upp_launch_status();
 }
 
@@ -206,8 +269,10 @@ extern "C" int upp_prop_interp_bwd(const float *g_out, const int32_t *i2, const 
                                    float *g_X, int B, int Lp, int T, int G2, int D, void *stream) {
     if (!g_out || !i2 || !idx8 || !w8 || !g_c2 || !g_X || B < 1 || Lp < T || T < 1 || G2 < 1 || D < 1) return UPP_E_BADARG;
     if (D > 64 * kMaxE) return UPP_E_RANGE;
+    const size_t lds = ((size_t)2 * T * kNb + 4 * kHitCap) * sizeof(int32_t);
+    if (G2 % 4 != 0 || lds > 64 * 1024) return UPP_E_RANGE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(prop_interp_bwd_c2_kernel, rows_grid((long long)B * G2), dim3(256), 0, st, g_out, idx8, w8, g_c2, B, Lp, T, G2, D);
+    hipLaunchKernelGGL(prop_interp_bwd_c2_kernel, rows_grid((long long)B * G2), dim3(256), lds, st, g_out, idx8, w8, g_c2, B, Lp, T, G2, D);
     hipLaunchKernelGGL(prop_interp_bwd_x_kernel, rows_grid((long long)B * Lp), dim3(256), 0, st, g_out, g_c2, i2, g_X, B * Lp, B * G2, D);
     return upp_launch_status();
 }

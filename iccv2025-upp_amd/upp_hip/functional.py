@@ -152,22 +152,24 @@ def group_points(xyz, center, idx):
 
 
 # ------------------------------------------------------------------ Transformer block glue
+ROW_IDENTITY, ROW_INSERT_CLS, ROW_INSERT, ROW_STRIP_CLS, ROW_STRIP = 0, 1, 2, 3, 4
+
+
 class _RowLN(Function):
-    """rows = gather(x (+add), prompts by `table`) (+ dp_scale(u) * y);  returns (rows, LayerNorm(rows)).
+    """rows = map(x (+add), prompts; mode, P) (+ dp_scale(u) * y);  returns (rows, LayerNorm(rows)).
     One kernel forward, one backward (+ one for trainable LayerNorm parameters).  See upp_rowln_fwd."""
 
     @staticmethod
-    def forward(ctx, x, add, prompts, y, gamma, beta, table, u, keep, eps, covers_all):
+    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps):
         x = x.contiguous()
         B, Lin, D = x.shape
-        Lout = table.numel() if table is not None else Lin
+        Lout = Lin + P if mode in (ROW_INSERT_CLS, ROW_INSERT) else (Lin - P if mode in (ROW_STRIP_CLS, ROW_STRIP) else Lin)
         add_c = add.contiguous() if add is not None else None
         y_c = y.contiguous() if y is not None else None
-        xo, h, mean, rstd = ops.rowln_fwd(x, add_c, prompts, table, y_c, u, keep, gamma, beta, eps, Lout)
-        ctx.save_for_backward(xo, mean, rstd, gamma, table, u)
-        ctx.dims = (B, Lin, Lout, D, 0 if prompts is None else prompts.shape[0])
+        xo, h, mean, rstd = ops.rowln_fwd(x, add_c, prompts, mode, P, y_c, u, keep, gamma, beta, eps, Lout)
+        ctx.save_for_backward(xo, mean, rstd, gamma, u)
+        ctx.dims = (B, Lin, Lout, D, P, mode)
         ctx.keep = keep
-        ctx.covers_all = covers_all
         ctx.has = (add is not None, prompts is not None, y is not None, gamma is not None)
         if gamma is None:
             return xo, xo.new_empty(0)
@@ -175,16 +177,17 @@ class _RowLN(Function):
 
     @staticmethod
     def backward(ctx, g_xo, g_h):
-        xo, mean, rstd, gamma, table, u = ctx.saved_tensors
-        B, Lin, Lout, D, P = ctx.dims
+        xo, mean, rstd, gamma, u = ctx.saved_tensors
+        B, Lin, Lout, D, P, mode = ctx.dims
         has_add, has_prompts, has_y, has_ln = ctx.has
         need = ctx.needs_input_grad
         g_xo = g_xo.contiguous() if g_xo is not None else None
         g_hc = g_h.contiguous() if (has_ln and g_h is not None) else None
         if g_xo is None and g_hc is None:
             return (None,) * 11
-        g_x, g_p, g_y = ops.rowln_bwd(g_xo, g_hc, xo, mean, rstd, gamma, table, u, ctx.keep, B, Lin, Lout, D, P,
-                                      need_x=need[0] or (has_add and need[1]), zero_x=not ctx.covers_all,
+        strip = mode in (ROW_STRIP_CLS, ROW_STRIP) and P > 0
+        g_x, g_p, g_y = ops.rowln_bwd(g_xo, g_hc, xo, mean, rstd, gamma, mode, u, ctx.keep, B, Lin, Lout, D, P,
+                                      need_x=need[0] or (has_add and need[1]), zero_x=strip,
                                       need_prompt=has_prompts and need[2], need_y=has_y and need[3])
         g_gamma = g_beta = None
         if has_ln and g_hc is not None and (need[4] or need[5]):
@@ -194,9 +197,9 @@ class _RowLN(Function):
                 g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None)
 
 
-def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, table=None, u=None, keep=1.0, eps=1e-5, covers_all=True):
-    """-> (rows (B,Lout,D), LayerNorm(rows) or None)."""
-    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, table, u, float(keep), float(eps), bool(covers_all))
+def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDENTITY, P=0, u=None, keep=1.0, eps=1e-5):
+    """-> (rows (B,Lout,D), LayerNorm(rows) or None).  mode / P: see ROW_* and upp_rowln_fwd."""
+    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps))
     return xo, (h if gamma is not None else None)
 
 

@@ -216,7 +216,7 @@ def patch_embed_fwd(point_groups, enc, training):
 
 
 # ------------------------------------------------------------------ Transformer block glue
-def rowln_fwd(x, add, prompts, table, y, u, keep, gamma, beta, eps, Lout, want_xo=True):
+def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want_xo=True):
     B, Lin, D = x.shape
     dev = x.device
     xo = torch.empty((B, Lout, D), dtype=torch.float32, device=dev) if want_xo else None
@@ -226,19 +226,19 @@ def rowln_fwd(x, add, prompts, table, y, u, keep, gamma, beta, eps, Lout, want_x
         rstd = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     else:
         h = mean = rstd = None
-    _call(dev, "upp_rowln_fwd", _abi.ptr(x), _abi.ptr(add), _abi.ptr(prompts), _abi.ptr(table), _abi.ptr(y), _abi.ptr(u),
+    _call(dev, "upp_rowln_fwd", _abi.ptr(x), _abi.ptr(add), _abi.ptr(prompts), int(mode), int(P), _abi.ptr(y), _abi.ptr(u),
           float(keep), _abi.ptr(gamma), _abi.ptr(beta), float(eps), _abi.ptr(xo), _abi.ptr(h), _abi.ptr(mean), _abi.ptr(rstd),
           B, Lin, Lout, D)
     return xo, h, mean, rstd
 
 
-def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, table, u, keep, B, Lin, Lout, D, P, need_x, zero_x, need_prompt, need_y):
+def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, P, need_x, zero_x, need_prompt, need_y):
     dev = (g_xo if g_xo is not None else g_h).device
     g_x = (torch.zeros if zero_x else torch.empty)((B, Lin, D), dtype=torch.float32, device=dev) if need_x else None
-    g_p = torch.empty((B, P, D), dtype=torch.float32, device=dev) if (need_prompt and P > 0) else None
+    g_p = torch.empty((B, P, D), dtype=torch.float32, device=dev) if (need_prompt and P > 0 and mode in (1, 2)) else None
     g_y = (torch.zeros if zero_x else torch.empty)((B, Lin, D), dtype=torch.float32, device=dev) if need_y else None
     _call(dev, "upp_rowln_bwd", _abi.ptr(g_xo), _abi.ptr(g_h), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma),
-          _abi.ptr(table), _abi.ptr(u), float(keep), _abi.ptr(g_x), _abi.ptr(g_p), _abi.ptr(g_y), B, Lin, Lout, D, P)
+          int(mode), _abi.ptr(u), float(keep), _abi.ptr(g_x), _abi.ptr(g_p), _abi.ptr(g_y), B, Lin, Lout, D, P)
     return g_x, g_p, g_y
 
 

@@ -157,20 +157,22 @@ int upp_patch_embed_fwd(const float *pts, int R, int n,
  * models/Point_MAE_pretask_dev.py:245-321): `x + pos` (TransformerEncoder :348), prompt insertion
  * (:247-264) or removal (:305-310), `x + drop_path(branch)` (:266,273; timm DropPath: per-sample factor
  * floor(keep + u) / keep), and the following LayerNorm (norm1 / norm2 / Adapter.layer_norm :97).
- *   out row (b,t) = x[b, table[t]] (+ add[b, table[t]])   if table[t] >= 0   (table NULL: identity)
- *                 = prompts[-table[t]-1]                   otherwise
- *                 (+ floor(keep + u[b]) / keep * y[b, table[t]])  if y (row-aligned with x; u NULL: factor 1)
+ *   s = src(t): mode 0 identity | 1 insert P prompts after the cls row | 2 insert P prompts in front |
+ *                3 strip the P prompts after the cls row | 4 strip P leading prompts
+ *   out row (b,t) = x[b, s] (+ add[b, s])                  if s is a token row
+ *                 = prompts[p]                             if s selects prompt p (modes 1, 2)
+ *                 (+ floor(keep + u[b]) / keep * y[b, s])  if y (row-aligned with x; u NULL: factor 1)
  *   xo (B,Lout,D) = those rows (optional);  h = LayerNorm(rows) * gamma + beta, mean / rstd (B,Lout) saved
  *   (gamma NULL: no LayerNorm, only xo).
- * Backward: d = g_xo + LayerNormBackward(g_h); written to g_x[b, table[t]] (caller zero-fills g_x when the
- * table does not cover every input row), g_prompt (B,P,D) (caller sums over B), g_y[b, table[t]] = factor * d.
+ * Backward: d = g_xo + LayerNormBackward(g_h); written to g_x[b, s] (caller zero-fills g_x for the strip modes,
+ * whose prompt rows receive nothing), g_prompt (B,P,D) (caller sums over B), g_y[b, s] = factor * d.
  * upp_ln_param_grad: per-chunk partial sums of d_gamma / d_beta, part (2, chunks, D).
  * Limits: D <= 512. */
-int upp_rowln_fwd(const float *x, const float *add, const float *prompts, const int32_t *table, const float *y,
+int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y,
                   const float *u, float keep, const float *gamma, const float *beta, float eps,
                   float *xo, float *h, float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream);
 int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
-                  const float *gamma, const int32_t *table, const float *u, float keep,
+                  const float *gamma, int mode, const float *u, float keep,
                   float *g_x, float *g_prompt, float *g_y, int B, int Lin, int Lout, int D, int P, void *stream);
 int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, const float *rstd, float *part,
                       int rows, int D, int chunks, void *stream);

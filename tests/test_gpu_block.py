@@ -44,18 +44,16 @@ def _attention_case(L):
     close(g, qkv.grad, rtol=2e-5, atol_scale=5e-6)
 
 
-@pytest.mark.parametrize("case", ["insert_cls", "insert", "strip_cls", "residual", "plain_noln"])
+@pytest.mark.parametrize("case", ["insert_cls", "insert", "strip_cls", "strip", "residual", "plain_noln"])
 def test_rowln_forward_backward(case):
     torch.manual_seed(1)
     B, L, D, P = 4, 65, 384, 10
     dev = 'cuda'
-    x = torch.randn(B, L + (P if case == "strip_cls" else 0), D, device=dev, requires_grad=True)
+    x = torch.randn(B, L + (P if case.startswith("strip") else 0), D, device=dev, requires_grad=True)
     pos = torch.randn_like(x).requires_grad_(True)
     prm = torch.randn(P, D, device=dev, requires_grad=True)
     gam = (1 + 0.1 * torch.randn(D, device=dev)).requires_grad_(True)
     bet = (0.1 * torch.randn(D, device=dev)).requires_grad_(True)
-    ins_c, rem_c = upp_layers.Block._row_tables(L, P, True, torch.device(dev))
-    ins_n, _ = upp_layers.Block._row_tables(L, P, False, torch.device(dev))
     u = torch.rand(B, device=dev)
     keep = 0.7
 
@@ -63,17 +61,21 @@ def test_rowln_forward_backward(case):
         return ((keep + u).floor() / keep).view(B, 1, 1)
 
     if case == "insert_cls":
-        xo, h = HF.rowln(x, add=pos, prompts=prm, table=ins_c, gamma=gam, beta=bet)
+        xo, h = HF.rowln(x, add=pos, prompts=prm, mode=HF.ROW_INSERT_CLS, P=P, gamma=gam, beta=bet)
         xp = x + pos
         rxo = torch.cat((xp[:, :1], prm.expand(B, -1, -1), xp[:, 1:]), 1)
     elif case == "insert":
-        xo, h = HF.rowln(x, add=pos, prompts=prm, table=ins_n, gamma=gam, beta=bet)
+        xo, h = HF.rowln(x, add=pos, prompts=prm, mode=HF.ROW_INSERT, P=P, gamma=gam, beta=bet)
         rxo = torch.cat((prm.expand(B, -1, -1), x + pos), 1)
     elif case == "strip_cls":
         y = torch.randn_like(x).requires_grad_(True)
-        xo, h = HF.rowln(x, y=y, u=u, keep=keep, table=rem_c, gamma=gam, beta=bet, covers_all=False)
+        xo, h = HF.rowln(x, y=y, u=u, keep=keep, mode=HF.ROW_STRIP_CLS, P=P, gamma=gam, beta=bet)
         full = x + scale() * y
         rxo = torch.cat((full[:, :1], full[:, P + 1:]), 1)
+    elif case == "strip":
+        y = torch.randn_like(x).requires_grad_(True)
+        xo, h = HF.rowln(x, y=y, u=u, keep=keep, mode=HF.ROW_STRIP, P=P, gamma=gam, beta=bet)
+        rxo = (x + scale() * y)[:, P:]
     elif case == "residual":
         y = torch.randn_like(x).requires_grad_(True)
         xo, h = HF.rowln(x, y=y, u=u, keep=keep, gamma=gam, beta=bet)
