@@ -21,11 +21,32 @@ constexpr int kLS = 97;          // row stride of the (L x L) score buffer
 // acc(32x32) += A(32 x K) . B(K x 32).  Element A(i,k): TA ? a[k*lda + i] : a[i*lda + k];  B(k,j): TB ? b[j*ldb + k] : b[k*ldb + j]
 template <bool TA, bool TB, int K>
 __device__ __forceinline__ void mfma_tile_k(f32x16 &acc, const float *a, int lda, const float *b, int ldb, int lr, int lk) {
+    // A wave runs ONE accumulator chain (64 cycles per MFMA): the operands of the next CH k-steps are fetched from
+    // LDS into registers before the current CH MFMAs issue, so the ~100+ cycle ds_read latency hides behind them.
+    constexpr int CH = 8, NCH = K / 2 / CH;
+    static_assert(K % (2 * CH) == 0, "K must be a multiple of 16");
+    float av[CH], bv[CH];
+    auto fetch = [&](int c, float (&x)[CH], float (&y)[CH]) {
 #pragma unroll
-    for (int k0 = 0; k0 < K; k0 += 2) {
-        const float av = TA ? a[(k0 + lk) * lda + lr] : a[lr * lda + k0 + lk];
-        const float bv = TB ? b[lr * ldb + k0 + lk] : b[(k0 + lk) * ldb + lr];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        for (int i = 0; i < CH; ++i) {
+            const int k0 = (c * CH + i) * 2;
+            x[i] = TA ? a[(k0 + lk) * lda + lr] : a[lr * lda + k0 + lk];
+            y[i] = TB ? b[lr * ldb + k0 + lk] : b[(k0 + lk) * ldb + lr];
+        }
+    };
+    fetch(0, av, bv);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float an[CH], bn[CH];
+        if (c + 1 < NCH) fetch(c + 1, an, bn);
+        __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks the reads next to their use (read, wait, mfma, read, ...)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { av[i] = an[i]; bv[i] = bn[i]; }
+        }
     }
 }
 // K is a compile-time constant so that the operand loop unrolls fully and the LDS reads run ahead of the MFMAs
