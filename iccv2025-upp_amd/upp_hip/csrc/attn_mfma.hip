@@ -62,15 +62,29 @@ __device__ __forceinline__ void zero(f32x16 &a) {
 }
 __device__ __forceinline__ int tile_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 
-// stage rows [0, L) x 64 of `src` (row stride rs floats) into dst[kLP][kLD], zero rows >= L
-__device__ __forceinline__ void stage64(float *dst, const float *src, size_t rs, int L) {
-    for (int i = threadIdx.x; i < kLP * 16; i += 256) {
-        const int r = i >> 4, c = (i & 15) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < L) v = *reinterpret_cast<const float4 *>(src + (size_t)r * rs + c);
-        float *d = dst + r * kLD + c;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
+// Stage rows [0, L) x 64 of NARR sources (row stride rs floats each) into dst[a][kLP][kLD], zero rows >= L.
+// A dependent global load costs ~1 us here, so ALL loads of all arrays are issued before the first LDS write
+// (6 float4 per thread and array) instead of load -> wait -> write per iteration.
+template <int NARR>
+__device__ __forceinline__ void stage_rows(float *const (&dst)[NARR], const float *const (&src)[NARR], const size_t (&rs)[NARR], int L) {
+    constexpr int IT = kLP * 16 / 256;
+    float4 v[NARR][IT];
+#pragma unroll
+    for (int a = 0; a < NARR; ++a)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = threadIdx.x + it * 256;
+            const int r = i >> 4, c = (i & 15) * 4;
+            v[a][it] = r < L ? *reinterpret_cast<const float4 *>(src[a] + (size_t)r * rs[a] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+    for (int a = 0; a < NARR; ++a)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = threadIdx.x + it * 256;
+            float *d = dst[a] + (i >> 4) * kLD + (i & 15) * 4;
+            d[0] = v[a][it].x; d[1] = v[a][it].y; d[2] = v[a][it].z; d[3] = v[a][it].w;
+        }
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
@@ -82,9 +96,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float *__restr
     const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
     const size_t rs = (size_t)3 * H * 64;
     const float *base = qkv + (size_t)b * L * rs + (size_t)hh * 64;
-    stage64(Qs, base, rs, L);
-    stage64(Ks, base + H * 64, rs, L);
-    stage64(Vs, base + 2 * H * 64, rs, L);
+    {
+        float *const dst[3] = {Qs, Ks, Vs};
+        const float *const src[3] = {base, base + H * 64, base + 2 * H * 64};
+        const size_t strides[3] = {rs, rs, rs};
+        stage_rows<3>(dst, src, strides, L);
+    }
     __syncthreads();
     const int nt = (L + 31) / 32;                       // tiles along the sequence
     for (int t = wave; t < nt * nt; t += 4) {           // S = Q K^T, scaled
@@ -138,15 +155,28 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float *__restr
     float *dbase = d_qkv + (size_t)b * L * rs + (size_t)hh * 64;
     const float *gbase = d_ctx + (size_t)b * L * cs + (size_t)hh * 64;
     const float *obase = ctx + (size_t)b * L * cs + (size_t)hh * 64;
-    stage64(Qs, base, rs, L);
-    stage64(Ks, base + H * 64, rs, L);
-    stage64(Vs, base + 2 * H * 64, rs, L);
-    stage64(Gs, gbase, cs, L);
-    for (int i = wave; i < kLP; i += 4) {               // delta_i = dO_i . O_i ; lse_i
-        float d = 0.0f;
-        if (i < L) d = gbase[(size_t)i * cs + lane] * obase[(size_t)i * cs + lane];
-        d = wave_sum_f32(d);
-        if (lane == 0) { delta[i] = d; lses[i] = i < L ? lse[((size_t)b * H + hh) * L + i] : 0.0f; }
+    {
+        float *const dst[4] = {Qs, Ks, Vs, Gs};
+        const float *const src[4] = {base, base + H * 64, base + 2 * H * 64, gbase};
+        const size_t strides[4] = {rs, rs, rs, cs};
+        stage_rows<4>(dst, src, strides, L);
+    }
+    {   // delta_i = dO_i . O_i ; lse_i  -- 24 rows per wave, all loads first
+        constexpr int RW = kLP / 4;
+        float g[RW], o[RW], ls[RW];
+#pragma unroll
+        for (int t = 0; t < RW; ++t) {
+            const int i = wave + 4 * t;
+            const bool ok = i < L;
+            g[t] = ok ? gbase[(size_t)i * cs + lane] : 0.0f;
+            o[t] = ok ? obase[(size_t)i * cs + lane] : 0.0f;
+            ls[t] = (ok && lane == 0) ? lse[((size_t)b * H + hh) * L + i] : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < RW; ++t) {
+            const float d = wave_sum_f32(g[t] * o[t]);
+            if (lane == 0) { delta[wave + 4 * t] = d; lses[wave + 4 * t] = ls[t]; }
+        }
     }
     __syncthreads();
     const int nt = (L + 31) / 32;

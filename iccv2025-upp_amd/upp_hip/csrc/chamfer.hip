@@ -35,9 +35,16 @@ __global__ __launch_bounds__(256) void chamfer_dir_kernel(const float *__restric
     for (int c0 = 0; c0 < m; c0 += kTile) {
         const int len = min(kTile, m - c0);
         __syncthreads();
-        for (int i = threadIdx.x; i < len; i += 256) {
-            const float *s = other + (size_t)(c0 + i) * 3;
-            tile[i] = make_float4(s[0], s[1], s[2], 0.0f);
+        for (int i0 = threadIdx.x; i0 < len; i0 += 256 * 4) {   // 12 independent loads in flight per thread
+            float t[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = min(i0 + q * 256, len - 1);
+                const float *s = other + (size_t)(c0 + i) * 3;
+                t[q][0] = s[0]; t[q][1] = s[1]; t[q][2] = s[2];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (i0 + q * 256 < len) tile[i0 + q * 256] = make_float4(t[q][0], t[q][1], t[q][2], 0.0f);
         }
         __syncthreads();
         const int seg = (len + 3) >> 2;

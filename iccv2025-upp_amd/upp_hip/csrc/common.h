@@ -81,6 +81,18 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return (a + b) + (c + d);
 }
 
+// Cooperative global -> LDS copy of n floats by `nthreads` threads.  Each thread keeps 8 independent loads in flight
+// per round: a load -> ds_write -> next load loop pays the full ~1 us memory latency on every iteration.
+__device__ __forceinline__ void stage_floats(float *dst, const float *__restrict__ src, int n, int tid, int nthreads) {
+    for (int i0 = tid; i0 < n; i0 += nthreads * 8) {
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int i = i0 + q * nthreads; t[q] = i < n ? src[i] : 0.0f; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int i = i0 + q * nthreads; if (i < n) dst[i] = t[q]; }
+    }
+}
+
 static inline int upp_launch_status(void) {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

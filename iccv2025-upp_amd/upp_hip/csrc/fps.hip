@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
     // clouds that do not fit LDS, straight from global memory (L2-resident).
     auto coord = [&](int k, int c) -> float { return USE_LDS ? cloud[k * 3 + c] : p[k * 3 + c]; };
     if (USE_LDS) {
-        for (int i = tid; i < 3 * N; i += L) cloud[i] = p[i];
+        stage_floats(cloud, p, 3 * N, tid, L);
         __syncthreads();
     }
 

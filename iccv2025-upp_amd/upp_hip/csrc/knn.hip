@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * kKnnWaves) void knn_kernel(const float *__rest
     const bool single = N <= kKnnChunk;  // the whole cloud fits one chunk: stage it once
     auto stage = [&](int c0, int len) {
         __syncthreads();
-        for (int i = threadIdx.x; i < 3 * len; i += 64 * kKnnWaves) chunk[i] = rp[(size_t)c0 * 3 + i];
+        stage_floats(chunk, rp + (size_t)c0 * 3, 3 * len, threadIdx.x, 64 * kKnnWaves);
         __syncthreads();
     };
     // cuComputeDistanceGlobal: tmp = ref - query; ssd += tmp*tmp over d.  Bits of

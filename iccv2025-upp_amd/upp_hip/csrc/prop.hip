@@ -34,18 +34,23 @@ __global__ __launch_bounds__(256) void prop_pool_fwd_kernel(const float *__restr
     int am[kMaxE];
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) { mx[e] = -__builtin_inff(); sm[e] = 0.0f; am[e] = 0; }
-    for (int k = 0; k < kNb; ++k) {
-        const float *row = X + (size_t)i1[g * kNb + k] * D;
+    // index loads, then all 8 x kMaxE row loads, then the arithmetic: a dependent global load is ~1 us
+    int rows8[kNb];
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) rows8[k] = i1[g * kNb + k];
+    float val[kNb][kMaxE];
+#pragma unroll
+    for (int k = 0; k < kNb; ++k)
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; val[k][e] = c < D ? X[(size_t)rows8[k] * D + c] : 0.0f; }
+#pragma unroll
+    for (int k = 0; k < kNb; ++k)
 #pragma unroll
         for (int e = 0; e < kMaxE; ++e) {
-            const int c = lane + 64 * e;
-            if (c < D) {
-                const float v = row[c] * f;
-                if (v > mx[e]) { mx[e] = v; am[e] = k; }   // first maximum wins, as torch.max
-                sm[e] += v;
-            }
+            const float v = val[k][e] * f;
+            if (v > mx[e]) { mx[e] = v; am[e] = k; }   // first maximum wins, as torch.max
+            sm[e] += v;
         }
-    }
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) {
         const int c = lane + 64 * e;
@@ -86,7 +91,13 @@ __global__ __launch_bounds__(256) void prop_pool_bwd_kernel(const float *__restr
     int32_t *list = lds_i;                               // [n]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int *hits = lds_i + n + wave * kHitCap;
-    for (int i = threadIdx.x; i < n; i += 256) list[i] = i1[i];
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {   // 8 independent loads in flight per thread
+        int32_t t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = i0 + q * 256 < n ? i1[i0 + q * 256] : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (i0 + q * 256 < n) list[i0 + q * 256] = t[q];
+    }
     __syncthreads();
     const int r = blockIdx.x * 4 + wave;
     if (r >= rows) return;
@@ -139,15 +150,22 @@ __global__ __launch_bounds__(256) void prop_interp_fwd_kernel(const float *__res
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) acc[e] = 0.0f;
     if (i >= 0) {
-        for (int k = 0; k < kNb; ++k) {
-            const int j = idx8[((size_t)b * T + i) * kNb + k];
-            const float w = w8[((size_t)b * T + i) * kNb + k];
-            const float *lrow = lc + ((size_t)b * G2 + j) * D;
-            const float *crow = X + (size_t)i2[b * G2 + j] * D;
+        // three dependent hops (idx8 -> i2 -> X row): each hop's loads are issued for all 8 neighbours at once
+        int j[kNb], cr[kNb];
+        float w[kNb];
 #pragma unroll
-            for (int e = 0; e < kMaxE; ++e) {
-                const int c = lane + 64 * e;
-                if (c < D) acc[e] += (lrow[c] + 0.3f * crow[c]) * w;
+        for (int k = 0; k < kNb; ++k) { j[k] = idx8[((size_t)b * T + i) * kNb + k]; w[k] = w8[((size_t)b * T + i) * kNb + k]; }
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) cr[k] = i2[b * G2 + j[k]];
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) {
+            const int c = lane + 64 * e;
+            if (c < D) {
+                float lv[kNb], cv[kNb];
+#pragma unroll
+                for (int k = 0; k < kNb; ++k) { lv[k] = lc[((size_t)b * G2 + j[k]) * D + c]; cv[k] = X[(size_t)cr[k] * D + c]; }
+#pragma unroll
+                for (int k = 0; k < kNb; ++k) acc[e] += (lv[k] + 0.3f * cv[k]) * w[k];
             }
         }
     }
