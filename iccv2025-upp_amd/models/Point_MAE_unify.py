@@ -21,10 +21,12 @@ def _mlp2(i, h, o):
     return nn.Sequential(nn.Linear(i, h), nn.GELU(), nn.Linear(h, o))
 
 
-@MODELS.register_module()
-class Point_MAE_unify(nn.Module):
-    def __init__(self, config):
-        super().__init__()
+class PromptedBackbone(nn.Module):
+    """Everything Point_MAE_unify and Point_MAE_unify_seg share: patch embedding, the 12-block prompted
+    transformer, the rectify (denoising) prompter and the completion prompter with its MAE decoder
+    (reference models/Point_MAE_unify.py:392-474,541-610 == models/Point_MAE_unify_segment.py:330-408,482-561)."""
+
+    def _build_backbone(self, config):
         self.config = config
         tc = config.transformer_config
         self.trans_dim = tc.trans_dim
@@ -59,29 +61,9 @@ class Point_MAE_unify(nn.Module):
         self.dense_pred = nn.Sequential(nn.Conv1d(D, 3 * self.group_size, 1))
         self.rectify_prompter = RectifyPrompter(in_channels=3, out_channels=3, hidden_dimesion=D, embedding_level=4,
                                                 num_group=32, group_size=16, top_center_dim=12)
-        self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
-        self.cls_pos = nn.Parameter(torch.randn(1, 1, D))
         self.pos_embed = _mlp2(3, 128, D)
-        self.cls_head_finetune = nn.Sequential(
-            nn.Linear(D * 2, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
-            nn.Linear(256, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
-            nn.Linear(256, self.cls_dim))
-        for layer in self.cls_head_finetune:
-            if isinstance(layer, nn.Linear):
-                nn.init.kaiming_uniform_(layer.weight, a=math.sqrt(5.0))
         trunc_normal_(self.mask_token, std=.02)
-        trunc_normal_(self.cls_token, std=.02)
-        trunc_normal_(self.cls_pos, std=.02)
-        self.build_loss_func()
-
-    # ------------------------------------------------------------------ loss / checkpoints
-    def build_loss_func(self):
-        self.loss_ce = nn.CrossEntropyLoss()
-
-    def get_loss_acc(self, ret, gt):
-        loss = self.loss_ce(ret, gt.long())
-        acc = (ret.argmax(-1) == gt).sum() / float(gt.size(0))
-        return loss, acc * 100
+        return D
 
     def load_model_from_ckpt(self, bert_ckpt_path, logger=None):
         """Key rewrites of reference :505-536: strip 'module.', '_block', 'MAE_encoder.', 'base_model.'."""
@@ -96,7 +78,15 @@ class Point_MAE_unify(nn.Module):
                     break
         return self.load_state_dict(base, strict=False)
 
-    # ------------------------------------------------------------------ forward
+    def _level2(self, center):
+        """Level-2 centres and index tensors for the prompt-propagation step (reference :631-643)."""
+        if not self.config.prompt_propagation_after:
+            return {}
+        level2 = Group(num_group=self.num_group // 2, group_size=8)
+        _, center2, center1_idx, center2_idx = level2(center, require_index=True, gather_idx=self.config.gather_idx)
+        return dict(center1=center, center1_idx=center1_idx, center2=center2, center2_idx=center2_idx,
+                    gather_idx=self.config.gather_idx, prompt_propagation_after=self.config.prompt_propagation_after)
+
     def _rectify(self, pts, point_num):
         """Denoising prompter (reference :541-570): score every input point, nudge the cloud by
         0.2 * predicted offset, keep the int(0.95 * point_num) least suspicious points."""
@@ -144,6 +134,34 @@ class Point_MAE_unify(nn.Module):
             pts = misc.fps(pts, point_num)[0]
         return pts
 
+
+@MODELS.register_module()
+class Point_MAE_unify(PromptedBackbone):
+    def __init__(self, config):
+        super().__init__()
+        D = self._build_backbone(config)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
+        self.cls_pos = nn.Parameter(torch.randn(1, 1, D))
+        self.cls_head_finetune = nn.Sequential(
+            nn.Linear(D * 2, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+            nn.Linear(256, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+            nn.Linear(256, self.cls_dim))
+        for layer in self.cls_head_finetune:
+            if isinstance(layer, nn.Linear):
+                nn.init.kaiming_uniform_(layer.weight, a=math.sqrt(5.0))
+        trunc_normal_(self.cls_token, std=.02)
+        trunc_normal_(self.cls_pos, std=.02)
+        self.build_loss_func()
+
+    # ------------------------------------------------------------------ loss / checkpoints
+    def build_loss_func(self):
+        self.loss_ce = nn.CrossEntropyLoss()
+
+    def get_loss_acc(self, ret, gt):
+        loss = self.loss_ce(ret, gt.long())
+        acc = (ret.argmax(-1) == gt).sum() / float(gt.size(0))
+        return loss, acc * 100
+
     def forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
         if denoise:
             pts = self._rectify(pts, point_num)
@@ -156,13 +174,7 @@ class Point_MAE_unify(nn.Module):
         x = torch.cat((self.cls_token.expand(B, -1, -1), tokens), dim=1)
         pos = torch.cat((self.cls_pos.expand(B, -1, -1), self.pos_embed(center)), dim=1)
 
-        propagation = {}
-        if self.config.prompt_propagation_after:
-            level2 = Group(num_group=self.num_group // 2, group_size=8)
-            _, center2, center1_idx, center2_idx = level2(center, require_index=True, gather_idx=self.config.gather_idx)
-            propagation = dict(center1=center, center1_idx=center1_idx, center2=center2, center2_idx=center2_idx,
-                               gather_idx=self.config.gather_idx,
-                               prompt_propagation_after=self.config.prompt_propagation_after)
+        propagation = self._level2(center)
         x = self.blocks(x, pos, path='downstream', downstream_adapter=True, downstream_prompts=True,
                         classification=True, **propagation)
         x = self.norm(x)

@@ -460,9 +460,12 @@ class TransformerEncoder(nn.Module):
             depth = kwargs['rectify_depth']
         if 'center1' in kwargs:
             kwargs['_prop_cache'] = {}      # per-forward scratch shared by the blocks (see Block._propagate_fused)
-        for block in self.blocks[:depth]:
+        features = []                       # outputs of blocks 3, 7, 11 for the segmentation head
+        for idx, block in enumerate(self.blocks[:depth]):   # (reference models/Point_MAE_unify_segment.py:223-234)
             x = block.forward_fused(x, pos, **kwargs) if block.fusable(x) else block(x + pos, **kwargs)
-        return x
+            if kwargs.get('feature_list') and idx in (3, 7, 11):
+                features.append(x)
+        return features if kwargs.get('feature_list') else x
 
 
 class TransformerDecoder(nn.Module):

@@ -7,6 +7,8 @@ Fixtures (all eval mode, key-seeded weights from tests/_seeded.py):
   upp_model.npz    end-to-end logits of Point_MAE_unify: clean (B,1024,3) and noisy-train
                    (B,1096,3, denoise + completion prompters), CE loss and gradients of a few
                    PEFT-trainable tensors (+ L2 norm of every trainable gradient)
+  upp_seg.npz      Point_MAE_unify_seg (unify_shapenetpart_seg.yaml): log-probabilities of a noisy (2,1624,3) cloud
+                   at 2048 label points (first 256 points + per-point sums / argmax of all) and of a clean run, NLL loss
   upp_modules.npz  per-module input/output pairs: Encoder, Attention, Block (downstream path
                    with prompt propagation incl. the index-stride behaviour), TransformerDecoder,
                    RectifyPrompter, propagate, Group index outputs
@@ -105,7 +107,23 @@ def main():
         mods.update(prop_p1=p1, prop_p2=p2, prop_out=R.uni.propagate(center, c2, p1, p2, de_neighbors=8, dist_e=1e-3))
     np.savez_compressed(os.path.join(out_dir, "upp_modules.npz"),
                         **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in mods.items()})
-    for f in ("upp_model.npz", "upp_modules.npz"):
+    # ---------------- segmentation model (BASELINE config 5), eval mode
+    seg = R.MODELS.build(ref_shim.model_cfg('unify_shapenetpart_seg'))
+    _seeded.fill(seg).eval()
+    spts = _seeded.noisy_clouds(2, 1552, seed=11)            # (2,1624,3): 1552 + 72 noise points
+    lpts = _seeded.unit_ball_clouds(2, 2048, seed=12)
+    onehot = torch.zeros(2, 16); onehot[0, 3] = 1; onehot[1, 11] = 1
+    tgt = torch.randint(0, 50, (2, 2048), generator=torch.Generator().manual_seed(13))
+    with torch.no_grad():
+        logp = seg(spts, onehot, label_points=lpts, completion_prompt=True, denoise=True, point_num=1536)
+        logp_clean = seg(lpts, onehot, label_points=None, completion_prompt=False, denoise=False, point_num=2048)
+    loss = seg.get_loss(logp.reshape(-1, 50), tgt.reshape(-1))
+    np.savez_compressed(os.path.join(out_dir, "upp_seg.npz"), onehot=onehot.numpy(), target=tgt.numpy(),
+                        logp_head=logp[:, :256].numpy(), logp_sum=logp.double().sum(-1).numpy(), logp_argmax=logp.argmax(-1).numpy(),
+                        logp_clean_head=logp_clean[:, :256].numpy(), loss=loss.numpy(),
+                        n_params=np.array(sum(p.numel() for p in seg.parameters())), n_keys=np.array(len(seg.state_dict())))
+    print("seg logp", tuple(logp.shape), "loss", loss.item(), "params", sum(p.numel() for p in seg.parameters()))
+    for f in ("upp_model.npz", "upp_modules.npz", "upp_seg.npz"):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
 
 

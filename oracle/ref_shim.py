@@ -116,12 +116,14 @@ def load():
     del sys.modules['models.Point_MAE_unify']
     uni = importlib.import_module('models.Point_MAE_unify')
     dev.Group, dev.propagate, dev.pooling = uni.Group, uni.propagate, pooling
+    torch.cuda.empty_cache = lambda: None          # called unconditionally at Point_MAE_unify_segment.py:590
+    seg = importlib.import_module('models.Point_MAE_unify_segment')
     from models.build import MODELS
-    _loaded = types.SimpleNamespace(uni=uni, dev=dev, MODELS=MODELS, EasyDict=EasyDict, pooling=pooling)
+    _loaded = types.SimpleNamespace(uni=uni, dev=dev, seg=seg, MODELS=MODELS, EasyDict=EasyDict, pooling=pooling)
     return _loaded
 
 
-def model_cfg():
+def model_cfg(name='unify_modelnet_cls'):
     import yaml
-    with open(os.path.join(REF, 'cfgs', 'unify_modelnet_cls.yaml')) as f:
+    with open(os.path.join(REF, 'cfgs', name + '.yaml')) as f:
         return EasyDict(yaml.safe_load(f)['model'])
