@@ -64,7 +64,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;           // wave position in the 2x2 grid
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the
+    // column tiles that share one 128-row A panel would land on different L2s and each fetch the panel again
+    // (PMC: FETCH_SIZE = 3-4x the panel bytes).  Give every XCD a contiguous range of logical tiles instead.
+    const int nwg = gridDim.x * gridDim.y;
+    int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((nwg & 7) == 0) lin = (lin & 7) * (nwg >> 3) + (lin >> 3);
+    const int bx = lin % gridDim.x, by = lin / gridDim.x;
+    const int m0 = by * BM, n0 = bx * BN;
     const int M = g.M, N = g.N, K = g.K;
 
     if (PRO != PRO_NONE) {
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             ssum += __shfl_xor(ssum, 32);
             ssq += __shfl_xor(ssq, 32);
             if (cok && lk == 0) {
-                const size_t slab = (size_t)blockIdx.y * 2 + wm, slabs = (size_t)gridDim.y * 2;
+                const size_t slab = (size_t)by * 2 + wm, slabs = (size_t)gridDim.y * 2;
                 g.stat_part[slab * N + col] = ssum;
                 g.stat_part[(slabs + slab) * N + col] = ssq;
             }
