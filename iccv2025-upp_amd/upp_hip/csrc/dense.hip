@@ -152,35 +152,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     for (int s = 0; s < nk; ++s) {
         const int buf = s & 1;
         if (s + 1 < nk) load_tile((s + 1) * BK);
-        // Operand prefetch in two register chunks of 4 k-pairs: the LDS reads of chunk 1 are issued before the 16
-        // MFMAs of chunk 0 (sched_barrier keeps hipcc from sinking them next to their use, which costs a full
-        // ds_read latency in front of every group of four MFMAs).
-        float a0[8], a1[8], b0[8], b1[8];
-        auto fetch = [&](int c) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kk = (c * 4 + i) * 2, q = c * 4 + i;
-                a0[q] = As[buf][kk + lk][wm * 64 + lr]; a1[q] = As[buf][kk + lk][wm * 64 + 32 + lr];
-                b0[q] = Ws[buf][kk + lk][wn * 64 + lr]; b1[q] = Ws[buf][kk + lk][wn * 64 + 32 + lr];
-            }
-        };
-        auto mma = [&](int c) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = c * 4 + i;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b1[q], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b0[q], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1[q], acc[1][1], 0, 0, 0);
-            }
-        };
-        static_assert(BK == 16, "two chunks of four k-pairs");
-        fetch(0);
-        fetch(1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1);
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = As[buf][kk + lk][wm * 64 + lr], a1 = As[buf][kk + lk][wm * 64 + 32 + lr];
+            const float b0 = Ws[buf][kk + lk][wn * 64 + lr], b1 = Ws[buf][kk + lk][wn * 64 + 32 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
         if (s + 1 < nk) {
             store_tile(buf ^ 1, (s + 1) * BK);   // the other buffer: its readers finished before the last barrier
             __syncthreads();
