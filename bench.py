@@ -74,24 +74,79 @@ def time_kernel(fn, iters=50, warm=5):
     return s.elapsed_time(e) / iters
 
 
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32
+
+
+def _pmc_traffic():
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_kernels.json:
+    FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH doubled per the gfx950 note in MI355X_MICROARCH.md)."""
+    try:
+        raw = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")))
+    except Exception:
+        return {}
+    return {k: (2.0 * v["fetch_kb_raw"] + v["write_kb"]) * 1024.0 for k, v in raw.items()}
+
+
 def stage_report(device, B):
-    """Stand-alone FPS / kNN(+group) at the headline shape (BASELINE configs[1]) and the longest FPS
-    of the model (1228 -> 1024).  Algorithmic bytes per cloud: SURVEY 8(d)."""
+    """Stand-alone timings (HIP events on the launch stream) of the main hand-written kernels at the headline shapes,
+    each against the roofline that bounds it.  Algorithmic bytes / flops: SURVEY 8(d) and DESIGN.md section 4."""
     import _seeded
-    from upp_hip import ops
+    from models.upp_layers import Encoder
+    from upp_hip import functional as HF, ops
+    pmc = _pmc_traffic()
+
+    def traffic(prefix):
+        for k, v in pmc.items():
+            if k.startswith(prefix):
+                return v
+        return None
+
+    def hbm(name, ms, nbytes, pmc_key=None, note=None):
+        gbs = nbytes / ms / 1e6
+        return {"kernel": name, "bound": "hbm", "ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": nbytes, "traffic": traffic(pmc_key) if pmc_key else None,
+                **({"note": note} if note else {})}
+
+    def mfma(name, ms, flops, note=None):
+        tf = flops / ms / 1e9
+        return {"kernel": name, "bound": "mfma", "ms": ms, "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tf / MFMA_F32_PEAK_TF, "algorithmic_flops": flops, **({"note": note} if note else {})}
+
     x = _seeded.unit_ball_clouds(B, 1024, seed=7).to(device)
     _, cen = ops.fps(x, 64, want_centers=True)
     x1228 = _seeded.unit_ball_clouds(B, 1228, seed=8).to(device)
     out = {}
-    t = time_kernel(lambda: ops.fps(x, 64, want_centers=True))
-    by = B * (1024 * 12 + 64 * 4 + 64 * 12)
-    out["fps_1024_64"] = {"ms": t, "bytes": by, "GBps": by / t / 1e6}
-    t = time_kernel(lambda: ops.knn(x, cen, 32, want_dist=False, want_neigh=True))
-    by = B * (1024 * 12 + 64 * 12 + 64 * 32 * 8 + 64 * 32 * 12)
-    out["knn_group_1024_64_32"] = {"ms": t, "bytes": by, "GBps": by / t / 1e6}
     t = time_kernel(lambda: ops.fps(x1228, 1024, want_centers=True), iters=20)
-    by = B * (1228 * 12 + 1024 * 4 + 1024 * 12)
-    out["fps_1228_1024"] = {"ms": t, "bytes": by, "GBps": by / t / 1e6}
+    out["fps_1228_1024"] = hbm("fps_kernel<8,4> (B,1228)->1024", t, B * (1228 * 12 + 1024 * 16), "fps_kernel<8, 4",
+                               "1023 dependent arg-max rounds per cloud: latency-bound by construction (0.57 us/round)")
+    t = time_kernel(lambda: ops.fps(x, 64, want_centers=True))
+    out["fps_1024_64"] = hbm("fps_kernel<4,4> (B,1024)->64", t, B * (1024 * 12 + 64 * 16), "fps_kernel<4, 4")
+    t = time_kernel(lambda: ops.knn(x, cen, 32, want_dist=False, want_neigh=True))
+    out["knn_group_1024_64_32"] = hbm("knn_kernel (+group) N=1024 Q=64 k=32", t, B * (1024 * 12 + 64 * 12 + 64 * 32 * 8 + 64 * 32 * 12),
+                                      "knn_kernel")
+    _, _, nb = ops.knn(x, cen, 32, want_dist=False, want_neigh=True)
+    enc = Encoder(384).to(device).train()
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    with torch.no_grad():
+        t = time_kernel(lambda: enc(nb), iters=20)
+    R = B * 64 * 32
+    flops = 2.0 * R * (128 * 256 + 256 * 512 + 512 * 384) + 2.0 * (R / 32) * 256 * 512 + 2.0 * R * 3 * 128
+    out["patch_embed_chain"] = mfma("upp_patch_embed_fwd: 4 gemm_f32_kernel launches + BN finalize (R=%d)" % R, t, flops,
+                                    "whole 7-launch chain; the three big GEMMs alone run at 82/99/106 TFLOP/s (profiles/)")
+    tok = torch.randn(B, 65, 384, device=device)
+    pos = torch.randn(B, 65, 384, device=device)
+    prm = torch.randn(10, 384, device=device)
+    g1, b1 = torch.ones(384, device=device), torch.zeros(384, device=device)
+    t = time_kernel(lambda: HF.rowln(tok, add=pos, prompts=prm, mode=HF.ROW_INSERT_CLS, P=10, gamma=g1, beta=b1))
+    out["rowln_fwd"] = hbm("rowln_fwd_kernel (pos add + prompt insert + LayerNorm, 2400 rows)", t,
+                           B * (2 * 65 + 2 * 75) * 384 * 4, "rowln_fwd_kernel")
+    qkv = torch.randn(B, 75, 1152, device=device)
+    t = time_kernel(lambda: ops.attn_fwd(qkv, B, 75, 6, 0.125))
+    out["attn_fwd"] = mfma("attn_fwd_mfma_kernel L=75 H=6", t, 4.0 * B * 6 * 75 * 75 * 64)
+    ctx, lse = ops.attn_fwd(qkv, B, 75, 6, 0.125)
+    t = time_kernel(lambda: ops.attn_bwd(qkv, ctx, ctx, lse, B, 75, 6, 0.125))
+    out["attn_bwd"] = mfma("attn_bwd_mfma_kernel L=75 H=6", t, 10.0 * B * 6 * 75 * 75 * 64)
     return out
 
 
@@ -175,7 +230,7 @@ def main():
     if rank == 0:
         clouds = args.batch * world * args.steps
         stages = stage_report(device, args.batch)
-        dom = stages["fps_1228_1024"]                     # longest hand-written kernel of the step
+        dom = dict(stages["fps_1228_1024"])               # the single longest hand-written launch of the step
         line = {
             "metric": "point-clouds/sec fwd+bwd, UPP/Point-MAE N=1024 G=64 k=32",
             "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,10 +240,8 @@ def main():
                                    "B=%d/GPU x (1024+72) pts, G=64 k=32" % args.batch,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph},
-            "roofline": {"kernel": "fps_kernel (B,1228)->1024", "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None,
-                         "note": "FPS is a 1023-round serial dependency chain: latency-bound by construction"},
-            "stages": stages,
+            "roofline": dom,
+            "kernels": stages,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
