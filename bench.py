@@ -59,19 +59,33 @@ class Trainer:
         return self.ts.step()
 
 
-def time_kernel(fn, iters=50, warm=5):
-    """Average duration (ms) of fn(), HIP events on the stream the kernels are launched on
-    (torch's current stream: upp_hip.ops passes torch.cuda.current_stream() to the C ABI)."""
+def time_kernel(fn, iters=20, warm=3):
+    """Average device time (ms) of one fn() call: `iters` calls are captured into a HIP graph and the replay is
+    timed with HIP events on the launch stream, so the figure is kernel time, not Python / launch overhead
+    (a small kernel launched from a Python loop is host-bound at ~15-20 us per call)."""
     for _ in range(warm):
         fn()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    s.record()
-    for _ in range(iters):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
         fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(iters):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    s.record()
+    for _ in range(reps):
+        graph.replay()
     e.record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters
+    return s.elapsed_time(e) / (iters * reps)
 
 
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32
@@ -116,7 +130,7 @@ def stage_report(device, B):
     _, cen = ops.fps(x, 64, want_centers=True)
     x1228 = _seeded.unit_ball_clouds(B, 1228, seed=8).to(device)
     out = {}
-    t = time_kernel(lambda: ops.fps(x1228, 1024, want_centers=True), iters=20)
+    t = time_kernel(lambda: ops.fps(x1228, 1024, want_centers=True), iters=5)
     out["fps_1228_1024"] = hbm("fps_kernel<8,4> (B,1228)->1024", t, B * (1228 * 12 + 1024 * 16), "fps_kernel<8, 4",
                                "1023 dependent arg-max rounds per cloud: latency-bound by construction (0.57 us/round)")
     t = time_kernel(lambda: ops.fps(x, 64, want_centers=True))
@@ -129,7 +143,7 @@ def stage_report(device, B):
     for p in enc.parameters():
         p.requires_grad_(False)
     with torch.no_grad():
-        t = time_kernel(lambda: enc(nb), iters=20)
+        t = time_kernel(lambda: enc(nb), iters=5)
     R = B * 64 * 32
     flops = 2.0 * R * (128 * 256 + 256 * 512 + 512 * 384) + 2.0 * (R / 32) * 256 * 512 + 2.0 * R * 3 * 128
     out["patch_embed_chain"] = mfma("upp_patch_embed_fwd: 4 gemm_f32_kernel launches + BN finalize (R=%d)" % R, t, flops,

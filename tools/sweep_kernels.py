@@ -24,9 +24,9 @@ def main():
         row = []
         for w in (1, 2, 4, 8):
             lib.upp_fps_set_waves(w)
-            row.append(time_kernel(lambda: ops.fps(x, M, want_centers=True), iters=20, warm=3))
+            row.append(time_kernel(lambda: ops.fps(x, M, want_centers=True), iters=10, warm=2))
         lib.upp_fps_set_waves(0)
-        row.append(time_kernel(lambda: ops.fps(x, M, want_centers=True), iters=20, warm=3))
+        row.append(time_kernel(lambda: ops.fps(x, M, want_centers=True), iters=10, warm=2))
         print("  N=%5d M=%5d  W1 %.4f  W2 %.4f  W4 %.4f  W8 %.4f  auto %.4f   us/iter(best) %.3f"
               % (N, M, *row, 1000 * min(row[:4]) / max(M - 1, 1)))
     print("kNN (B=%d) ms per call, prefilter off / on" % B)
@@ -36,20 +36,20 @@ def main():
         row = []
         for on in (0, 1):
             lib.upp_knn_set_prefilter(on)
-            row.append(time_kernel(lambda: ops.knn(x, q, K, want_dist=False, want_neigh=True), iters=30, warm=3))
+            row.append(time_kernel(lambda: ops.knn(x, q, K, want_dist=False, want_neigh=True), iters=10, warm=2))
         print("  N=%5d Q=%4d K=%3d  off %.4f  on %.4f" % (N, Q, K, *row))
     lib.upp_knn_set_prefilter(1)
     a = _seeded.unit_ball_clouds(B, 1024, seed=1).cuda()
     b = _seeded.unit_ball_clouds(B, 1024, seed=2).cuda()
-    t = time_kernel(lambda: ops.chamfer_fwd(a, b), iters=30)
+    t = time_kernel(lambda: ops.chamfer_fwd(a, b), iters=10)
     d1, d2, i1, i2 = ops.chamfer_fwd(a, b)
-    tb = time_kernel(lambda: ops.chamfer_bwd(a, b, i1, i2, d1, d2), iters=30)
+    tb = time_kernel(lambda: ops.chamfer_bwd(a, b, i1, i2, d1, d2), iters=10)
     print("chamfer fwd (32,1024,1024) %.4f ms   bwd %.4f ms" % (t, tb))
-    t = time_kernel(lambda: ops.emd_approxmatch(a, b), iters=5, warm=1)
+    t = time_kernel(lambda: ops.emd_approxmatch(a, b), iters=3, warm=1)
     m = ops.emd_approxmatch(a, b)
-    tc = time_kernel(lambda: ops.emd_matchcost(a, b, m), iters=10, warm=1)
+    tc = time_kernel(lambda: ops.emd_matchcost(a, b, m), iters=3, warm=1)
     g = torch.ones(B, device='cuda')
-    tg = time_kernel(lambda: ops.emd_matchcost_bwd(g, a, b, m), iters=10, warm=1)
+    tg = time_kernel(lambda: ops.emd_matchcost_bwd(g, a, b, m), iters=3, warm=1)
     print("emd approxmatch (32,1024,1024) %.3f ms  matchcost %.3f ms  matchcost_bwd %.3f ms" % (t, tc, tg))
 
 
