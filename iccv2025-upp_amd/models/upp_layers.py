@@ -404,6 +404,10 @@ class Block(nn.Module):
             return x4
         ln = adapter.layer_norm
         x4, ha = HF.rowln(x2, y=m, u=u2, keep=keep, mode=rem, P=P, gamma=ln.weight, beta=ln.bias, eps=ln.eps)
+        if D == 384 and adapter.ln1.weight.shape[0] == 32 and isinstance(adapter.activate, nn.GELU):
+            pd = adapter.dropout.p if self.training else 0.0
+            ud = torch.rand(x4.shape[0] * x4.shape[1], 32, device=x.device) if pd > 0 else None
+            return HF.adapter(ha, x4, adapter.ln1.weight, adapter.ln1.bias, adapter.ln2.weight, adapter.ln2.bias, ud, pd, 0.7)
         z = adapter.ln2(adapter.dropout(adapter.activate(adapter.ln1(ha))))
         return torch.add(x4, z, alpha=0.7)
 

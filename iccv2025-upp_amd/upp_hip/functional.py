@@ -272,3 +272,36 @@ def prop_pool(X, i1, u=None, keep=1.0):
 
 def prop_interp(X, lc, i2, idx8, w8):
     return _PropInterp.apply(X, lc, i2, idx8, w8)
+
+
+# ------------------------------------------------------------------ bottleneck adapter
+class _Adapter(Function):
+    """out = x + scale * (W2 . dropout(gelu(W1 . ha + b1)) + b2); see upp_adapter_fwd."""
+
+    @staticmethod
+    def forward(ctx, ha, x, W1, b1, W2, b2, u, p, scale):
+        ha, x = ha.contiguous(), x.contiguous()
+        out, s1 = ops.adapter_fwd(ha, x, W1, b1, W2, b2, u, p, scale)
+        ctx.save_for_backward(ha, s1, W1, W2, u)
+        ctx.meta = (p, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        ha, s1, W1, W2, u = ctx.saved_tensors
+        p, scale = ctx.meta
+        g_out = g_out.contiguous()
+        g_ha, part = ops.adapter_bwd(g_out, ha, s1, W1, W2, u, p, scale)
+        need = ctx.needs_input_grad
+        gW1 = gb1 = gW2 = gb2 = None
+        if need[2] or need[3] or need[4] or need[5]:
+            H, D = W1.shape
+            tot = part.sum(dim=0)                      # fixed workgroup order: deterministic
+            gW1, gW2 = tot[:H * D].view(H, D), tot[H * D:2 * H * D].view(D, H)
+            gb1, gb2 = tot[2 * H * D:2 * H * D + H], tot[2 * H * D + H:]
+        return (g_ha if need[0] else None, g_out if need[1] else None, gW1 if need[2] else None, gb1 if need[3] else None,
+                gW2 if need[4] else None, gb2 if need[5] else None, None, None, None)
+
+
+def adapter(ha, x, W1, b1, W2, b2, u=None, p=0.0, scale=0.7):
+    return _Adapter.apply(ha, x, W1, b1, W2, b2, u, float(p), float(scale))

@@ -306,3 +306,28 @@ def adamw_flat(p, g, m, v, n, split, state, scratch, lr, beta1, beta2, eps, weig
         _need(t, name, torch.float32)
     _call(p.device, "upp_adamw_flat", _abi.ptr(p), _abi.ptr(g), _abi.ptr(m), _abi.ptr(v), int(n), int(split), _abi.ptr(state),
           _abi.ptr(scratch), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), float(max_norm))
+
+
+# ------------------------------------------------------------------ bottleneck adapter
+def adapter_fwd(ha, x, W1, b1, W2, b2, u, p, scale):
+    D = ha.shape[-1]
+    R = ha.numel() // D
+    H = W1.shape[0]
+    out = torch.empty_like(x)
+    s1 = torch.empty((R, H), dtype=torch.float32, device=ha.device)
+    _call(ha.device, "upp_adapter_fwd", _abi.ptr(ha), _abi.ptr(x), _abi.ptr(W1), _abi.ptr(b1), _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(u),
+          float(p), float(scale), _abi.ptr(out), _abi.ptr(s1), R, D, H)
+    return out, s1
+
+
+def adapter_bwd(g_out, ha, s1, W1, W2, u, p, scale):
+    D = ha.shape[-1]
+    R = ha.numel() // D
+    H = W1.shape[0]
+    g_ha = torch.empty_like(ha)
+    n = int(_abi.load().upp_adapter_part_floats(R, D))
+    nblk = (R + 31) // 32
+    part = torch.empty((nblk, n // nblk), dtype=torch.float32, device=ha.device)
+    _call(ha.device, "upp_adapter_bwd", _abi.ptr(g_out), _abi.ptr(ha), _abi.ptr(s1), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(u),
+          float(p), float(scale), _abi.ptr(g_ha), _abi.ptr(part), R, D, H)
+    return g_ha, part

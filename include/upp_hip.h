@@ -223,6 +223,21 @@ long long upp_adamw_scratch_floats(void);
 int upp_adamw_flat(float *p, float *g, float *m, float *v, long long n, long long split, float *state, float *scratch,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, void *stream);
 
+/* ---- bottleneck adapter --------------------------------------------------------------------
+ * Replaces Adapter.forward after its LayerNorm and the residual that applies it (reference
+ * models/Point_MAE_pretask_dev.py:96-104 and :312-320):
+ *   out = x + scale * ( W2 . dropout_p(gelu(W1 . ha + b1)) + b2 )        scale = 0.7, exact (erf) GELU
+ *   ha, x, out (R, D); W1 (H, D), b1 (H), W2 (D, H), b2 (D); s1 (R, H) = W1 . ha + b1 is saved for backward;
+ *   u (R, H) uniforms in [0,1) select the dropout mask (kept iff u >= p, scaled by 1/(1-p)); NULL = no dropout.
+ * Backward: g_ha (R, D) and, per workgroup of 32 rows, partial sums [dW1 (H,D) | dW2 (D,H) | db1 (H) | db2 (D)] in
+ * `part` (upp_adapter_part_floats(R, D) floats; the caller sums the workgroups).  The gradient w.r.t. x is g_out.
+ * Limits: D == 384, H == 32. */
+long long upp_adapter_part_floats(int R, int D);
+int upp_adapter_fwd(const float *ha, const float *x, const float *W1, const float *b1, const float *W2, const float *b2,
+                    const float *u, float p, float scale, float *out, float *s1, int R, int D, int H, void *stream);
+int upp_adapter_bwd(const float *g_out, const float *ha, const float *s1, const float *W1, const float *W2, const float *u,
+                    float p, float scale, float *g_ha, float *part, int R, int D, int H, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

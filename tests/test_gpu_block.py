@@ -195,3 +195,27 @@ def test_flat_adamw_matches_torch_clip_and_adamw():
         for p, q in zip(nd + d, rnd + rd):
             close(p, q, rtol=2e-5, atol_scale=2e-6)
     assert opt.state[0].item() == 5
+
+
+@pytest.mark.parametrize("R", [2400, 2080, 1120, 45])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_adapter_kernel_forward_backward(R, p):
+    torch.manual_seed(R)
+    D, H = 384, 32
+    dev = 'cuda'
+    ha = torch.randn(R, D, device=dev, requires_grad=True)
+    x = torch.randn(R, D, device=dev, requires_grad=True)
+    W1 = (torch.randn(H, D, device=dev) / D ** 0.5).requires_grad_(True)
+    b1 = (0.1 * torch.randn(H, device=dev)).requires_grad_(True)
+    W2 = (torch.randn(D, H, device=dev) / H ** 0.5).requires_grad_(True)
+    b2 = (0.1 * torch.randn(D, device=dev)).requires_grad_(True)
+    u = torch.rand(R, H, device=dev) if p > 0 else None
+    w = torch.randn(R, D, device=dev)
+    out = HF.adapter(ha, x, W1, b1, W2, b2, u, p, 0.7)
+    grads = torch.autograd.grad((out * w).sum(), [ha, x, W1, b1, W2, b2])
+    mask = ((u >= p).float() / (1 - p)) if p > 0 else 1.0
+    ref = x + 0.7 * (torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(ha, W1, b1)) * mask, W2, b2))
+    rgrads = torch.autograd.grad((ref * w).sum(), [ha, x, W1, b1, W2, b2])
+    close(out, ref, rtol=1e-5, atol_scale=2e-6)
+    for g, r in zip(grads, rgrads):
+        close(g, r, rtol=5e-5, atol_scale=1e-5)
