@@ -298,3 +298,28 @@ def test_patch_embed_mfma_chain_matches_library_path(B, G, n, training):
     # a trainable encoder must take the differentiable path
     enc.first_conv[0].weight.requires_grad_(True)
     assert not enc._fusable(x)
+
+
+def test_batched_cropping_equals_the_per_sample_loop():
+    """utils.misc.seprate_point_cloud (one argsort + two batched FPS launches) vs the reference's per-sample recipe
+    (misc.py:205-256: argsort, slice, single-cloud FPS per sample) with the oracle's FPS, for the same viewpoints."""
+    from utils import misc
+    B, n, crop, keep = 4, 8192, 2048, 1024
+    x = clouds(B, n, "ball", 77)
+    cen = np.random.default_rng(3).standard_normal((B, 1, 3)).astype(np.float32)
+    cen /= np.linalg.norm(cen, axis=-1, keepdims=True)
+    xd, cd = dev(x), dev(cen)
+    got_in, got_crop = misc.seprate_point_cloud(xd, n, crop, sample_points=keep, centers=cd)
+    assert got_in.shape == (B, keep, 3) and got_crop.shape == (B, keep, 3)
+    for b in range(B):                                   # the reference's loop body, one sample at a time
+        d = torch.norm(cd[b:b + 1] - xd[b:b + 1], p=2, dim=-1)
+        order = torch.argsort(d, dim=-1, descending=False)[0].cpu().numpy()
+        kept, cut = x[b][order[crop:]], x[b][order[:crop]]
+        np.testing.assert_array_equal(got_in[b].cpu().numpy(), kept[O.fps(kept[None], keep)[0]])
+        np.testing.assert_array_equal(got_crop[b].cpu().numpy(), cut[O.fps(cut[None], keep)[0]])
+    batch = misc.noisy_train_batch(xd, npoints=1024)
+    assert batch.shape == (B, 1096, 3) and torch.isfinite(batch).all()
+    full, none = misc.seprate_point_cloud(xd, n, n)
+    assert none is None and full.shape == (B, n, 3)
+    padded, _ = misc.seprate_point_cloud(xd, n, crop, padding_zeros=True, incomplete_shape=False, centers=cd)
+    assert padded.shape == (B, n, 3) and int((padded.abs().sum(-1) == 0).sum()) >= B * crop
