@@ -1,0 +1,170 @@
+"""Point_MAE -- the masked-autoencoder pre-training model (reference models/Point_MAE_cp.py:239-465,
+cfgs/pretrain.yaml): group -> patch embed -> 12 plain blocks on the visible 40 % -> 4-block decoder with mask tokens
+-> per-group point regression, trained with Chamfer-L2 between (B*M, 32, 3) rebuilt and ground-truth groups.
+
+This is the "Point-MAE fwd+bwd ending in Chamfer" stage list of the north star; it reuses every gfx950 kernel of the
+UPP path (FPS, kNN+group, MFMA patch embed when frozen, fused block glue, attention) plus upp_chamfer_fwd/bwd.
+Same registry name, constructor contract and state-dict keys as the reference (its Block has no BatchNorm / adapters).
+Masking is drawn on the device (the reference shuffles numpy arrays on the host per sample); `mask=` overrides it.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from upp_hip import functional as HF
+from .build import MODELS
+from .upp_layers import Block, Encoder, Group, OPS, trunc_normal_
+
+OPS.setdefault("chamfer", HF.ChamferFunction.apply)     # (xyz1, xyz2) -> (dist1, dist2); tests may inject the oracle
+
+
+class PlainBlock(Block):
+    """x + drop_path(attn(norm1 x)); x + drop_path(mlp(norm2 x))  (reference models/Point_MAE_cp.py:166-184)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        del self.bnorm                                   # the pre-training block has no BatchNorm
+
+    def forward(self, x, **kw):
+        x = self._residual(x, self.attn(self.norm1(x)))
+        return self._residual(x, self.mlp(self.norm2(x)))
+
+    def forward_fused(self, x, pos, **kw):
+        return super().forward_fused(x, pos, path='plain')
+
+
+class _Stack(nn.Module):
+    def __init__(self, embed_dim, depth, num_heads, drop_path_rate):
+        super().__init__()
+        self.blocks = nn.ModuleList([PlainBlock(dim=embed_dim, num_heads=num_heads, drop_path=drop_path_rate[i]) for i in range(depth)])
+
+    def run(self, x, pos):
+        for block in self.blocks:
+            x = block.forward_fused(x, pos) if block.fusable(x) else block(x + pos)
+        return x
+
+
+class TransformerEncoder(_Stack):
+    def forward(self, x, pos):
+        return self.run(x, pos)
+
+
+class TransformerDecoder(_Stack):
+    def __init__(self, embed_dim=384, depth=4, num_heads=6, drop_path_rate=None):
+        super().__init__(embed_dim, depth, num_heads, drop_path_rate)
+        self.norm = nn.LayerNorm(embed_dim)
+        self.head = nn.Identity()
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, x, pos, return_token_num):
+        return self.head(self.norm(self.run(x, pos)[:, -return_token_num:]))
+
+
+def _mlp2(i, h, o):
+    return nn.Sequential(nn.Linear(i, h), nn.GELU(), nn.Linear(h, o))
+
+
+class MaskTransformer(nn.Module):
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        tc = config.transformer_config
+        self.config = config
+        self.mask_ratio, self.trans_dim, self.depth = tc.mask_ratio, tc.trans_dim, tc.depth
+        self.mask_type = tc.mask_type
+        self.encoder = Encoder(encoder_channel=tc.encoder_dims)
+        self.pos_embed = _mlp2(3, 128, self.trans_dim)
+        dpr = [x.item() for x in torch.linspace(0, tc.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder(self.trans_dim, self.depth, tc.num_heads, dpr)
+        self.norm = nn.LayerNorm(self.trans_dim)
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Conv1d)):
+                trunc_normal_(m.weight, std=.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def random_mask(self, center, noaug=False):
+        """(B,G) bool, exactly int(mask_ratio*G) True per row ('rand': uniformly random; 'block': the nearest centres of a
+        random centre -- reference :277-329), drawn on the device."""
+        B, G, _ = center.shape
+        n = int(self.mask_ratio * G)
+        if noaug or n == 0:
+            return torch.zeros(B, G, dtype=torch.bool, device=center.device)
+        if self.mask_type == 'rand':
+            order = torch.rand(B, G, device=center.device).argsort(dim=1)
+        else:
+            pick = torch.randint(0, G, (B, 1, 1), device=center.device)
+            anchor = torch.gather(center, 1, pick.expand(-1, -1, 3))
+            order = torch.norm(anchor - center, p=2, dim=-1).argsort(dim=1)
+        mask = torch.zeros(B, G, dtype=torch.bool, device=center.device)
+        return mask.scatter_(1, order[:, :n], True)
+
+    def forward(self, neighborhood, center, noaug=False, eval=False, mask=None):
+        B, G, _ = center.shape
+        if mask is None:
+            mask = torch.zeros(B, G, dtype=torch.bool, device=center.device) if eval else self.random_mask(center, noaug)
+        tokens = self.encoder(neighborhood)
+        # visible positions first (ascending), masked ones after (ascending): the order boolean indexing would give,
+        # without its host sync (shapes stay static for HIP-graph capture)
+        order = torch.argsort(mask.int(), dim=1, stable=True)
+        n_vis = G - int(mask[0].sum()) if mask.any() else G
+        vis = order[:, :n_vis]
+        x_vis = torch.gather(tokens, 1, vis.unsqueeze(-1).expand(-1, -1, tokens.shape[-1]))
+        c_vis = torch.gather(center, 1, vis.unsqueeze(-1).expand(-1, -1, 3))
+        x_vis = self.norm(self.blocks(x_vis, self.pos_embed(c_vis)))
+        return x_vis, mask, order, n_vis
+
+
+@MODELS.register_module()
+class Point_MAE(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        tc = config.transformer_config
+        self.trans_dim = tc.trans_dim
+        self.MAE_encoder = MaskTransformer(config)
+        self.group_size, self.num_group = config.group_size, config.num_group
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, self.trans_dim))
+        self.decoder_pos_embed = _mlp2(3, 128, self.trans_dim)
+        dpr = [x.item() for x in torch.linspace(0, tc.drop_path_rate, tc.decoder_depth)]
+        self.MAE_decoder = TransformerDecoder(self.trans_dim, tc.decoder_depth, tc.decoder_num_heads, dpr)
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.increase_dim = nn.Sequential(nn.Conv1d(self.trans_dim, 3 * self.group_size, 1))
+        trunc_normal_(self.mask_token, std=.02)
+        self.loss = config.loss
+        if self.loss not in ('cdl1', 'cdl2'):
+            raise NotImplementedError(self.loss)
+
+    def loss_func(self, a, b):
+        d1, d2 = OPS["chamfer"](a, b)
+        if self.loss == 'cdl2':
+            return torch.mean(d1) + torch.mean(d2)                        # ChamferDistanceL2
+        return (torch.mean(torch.sqrt(d1)) + torch.mean(torch.sqrt(d2))) / 2   # ChamferDistanceL1
+
+    def forward(self, pts, vis=False, eval=False, label=None, mask=None, **kwargs):
+        neighborhood, center = self.group_divider(pts)
+        if eval:
+            return self.MAE_encoder(neighborhood, center, eval=True)[0].max(dim=1)[0]
+        x_vis, mask, order, n_vis = self.MAE_encoder(neighborhood, center, mask=mask)
+        B, _, C = x_vis.shape
+        c_sorted = torch.gather(center, 1, order.unsqueeze(-1).expand(-1, -1, 3))        # visible centres, then masked
+        pos_full = self.decoder_pos_embed(c_sorted)
+        N = order.shape[1] - n_vis
+        x_full = torch.cat([x_vis, self.mask_token.expand(B, N, -1)], dim=1)
+        x_rec = self.MAE_decoder(x_full, pos_full, N)
+        head = self.increase_dim[0]
+        rebuild = F.linear(x_rec, head.weight.squeeze(-1), head.bias).reshape(B * N, -1, 3)
+        m_idx = order[:, n_vis:]
+        gt = torch.gather(neighborhood, 1, m_idx.view(B, N, 1, 1).expand(-1, -1, self.group_size, 3)).reshape(B * N, -1, 3)
+        if vis:
+            v_idx = order[:, :n_vis]
+            vis_pts = torch.gather(neighborhood, 1, v_idx.view(B, n_vis, 1, 1).expand(-1, -1, self.group_size, 3))
+            full_vis = (vis_pts + c_sorted[:, :n_vis].unsqueeze(2)).reshape(B * n_vis, -1, 3)
+            full_rebuild = rebuild + c_sorted[:, n_vis:].reshape(B * N, 1, 3)
+            full = torch.cat([full_vis, full_rebuild], dim=0)
+            full_center = torch.cat([c_sorted[:, n_vis:].reshape(-1, 3), c_sorted[:, :n_vis].reshape(-1, 3)], dim=0)
+            return full.reshape(-1, 3).unsqueeze(0), full_vis.reshape(-1, 3).unsqueeze(0), full_center
+        return self.loss_func(rebuild.contiguous(), gt.contiguous())

@@ -9,6 +9,7 @@ Fixtures (all eval mode, key-seeded weights from tests/_seeded.py):
                    PEFT-trainable tensors (+ L2 norm of every trainable gradient)
   upp_seg.npz      Point_MAE_unify_seg (unify_shapenetpart_seg.yaml): log-probabilities of a noisy (2,1624,3) cloud
                    at 2048 label points (first 256 points + per-point sums / argmax of all) and of a clean run, NLL loss
+  point_mae.npz    Point_MAE (pretrain.yaml): Chamfer-L2 loss and gradient norms for a fixed random mask
   upp_modules.npz  per-module input/output pairs: Encoder, Attention, Block (downstream path
                    with prompt propagation incl. the index-stride behaviour), TransformerDecoder,
                    RectifyPrompter, propagate, Group index outputs
@@ -123,7 +124,29 @@ def main():
                         logp_clean_head=logp_clean[:, :256].numpy(), loss=loss.numpy(),
                         n_params=np.array(sum(p.numel() for p in seg.parameters())), n_keys=np.array(len(seg.state_dict())))
     print("seg logp", tuple(logp.shape), "loss", loss.item(), "params", sum(p.numel() for p in seg.parameters()))
-    for f in ("upp_model.npz", "upp_modules.npz", "upp_seg.npz"):
+    # ---------------- Point-MAE pre-training model (Chamfer-L2 loss), eval-mode layers, fixed numpy mask
+    mae = R.MODELS.build(ref_shim.model_cfg('pretrain'))
+    _seeded.fill(mae).eval()
+    mpts = _seeded.unit_ball_clouds(2, 1024, seed=21)
+    np.random.seed(5)
+    state = np.random.get_state()
+    with torch.no_grad():
+        nb_, cen_ = mae.group_divider(mpts)
+        used_mask = mae.MAE_encoder._mask_center_rand(cen_)
+    np.random.set_state(state)                    # the forward below redraws the same mask
+    for p_ in mae.parameters():
+        p_.requires_grad_(True)
+    mloss = mae(mpts)
+    mloss.backward()
+    mg = {n: p_.grad for n, p_ in mae.named_parameters() if p_.grad is not None}
+    feat = mae(mpts, eval=True) if False else None   # eval path needs .cuda() in the reference; not exercised
+    mnames = sorted(mg)
+    np.savez_compressed(os.path.join(out_dir, "point_mae.npz"), mask=used_mask.numpy(), loss=mloss.detach().numpy(),
+                        grad_names=np.array(mnames), grad_norms=np.array([mg[n].norm().item() for n in mnames]),
+                        g_mask_token=mg['mask_token'].numpy(), g_increase_bias=mg['increase_dim.0.bias'].numpy(),
+                        n_params=np.array(sum(p_.numel() for p_ in mae.parameters())), n_keys=np.array(len(mae.state_dict())))
+    print("point_mae loss", mloss.item(), "params", sum(p_.numel() for p_ in mae.parameters()), "masked", int(used_mask[0].sum()))
+    for f in ("upp_model.npz", "upp_modules.npz", "upp_seg.npz", "point_mae.npz"):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
 
 

@@ -180,4 +180,18 @@ def torch_ops():
         nb = torch.gather(xyz, 1, idx.reshape(B, G * K, 1).expand(-1, -1, 3)).reshape(B, G, K, 3)
         return nb - center.unsqueeze(2), idx
 
-    return {"fps_gather": fps_gather, "knn_group": knn_group}
+    class _Chamfer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a, b):
+            d1, d2, i1, i2 = chamfer_fwd(a.detach().numpy(), b.detach().numpy())
+            ctx.save_for_backward(a, b, torch.from_numpy(i1), torch.from_numpy(i2))
+            return torch.from_numpy(d1), torch.from_numpy(d2)
+
+        @staticmethod
+        def backward(ctx, g1, g2):
+            a, b, i1, i2 = ctx.saved_tensors
+            ga, gb = chamfer_bwd(a.detach().numpy(), b.detach().numpy(), i1.numpy(), i2.numpy(),
+                                 g1.contiguous().numpy(), g2.contiguous().numpy())
+            return torch.from_numpy(ga), torch.from_numpy(gb)
+
+    return {"fps_gather": fps_gather, "knn_group": knn_group, "chamfer": _Chamfer.apply}

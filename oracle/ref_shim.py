@@ -96,7 +96,14 @@ def load():
     _mod('timm.scheduler', CosineLRScheduler=object)
     _mod('ipdb'); _mod('termcolor', colored=lambda s, *a, **k: s)
     _mod('easydict', EasyDict=EasyDict)
-    _mod('pytorch3d'); _mod('pytorch3d.ops'); _mod('chamfer'); _mod('emd_cuda')
+    def _ch_fwd(a, b):
+        return [torch.from_numpy(t) for t in O.chamfer_fwd(a.detach().numpy(), b.detach().numpy())]
+
+    def _ch_bwd(a, b, i1, i2, g1, g2):
+        return [torch.from_numpy(t) for t in O.chamfer_bwd(a.detach().numpy(), b.detach().numpy(), i1.numpy(), i2.numpy(),
+                                                           g1.contiguous().numpy(), g2.contiguous().numpy())]
+
+    _mod('pytorch3d'); _mod('pytorch3d.ops'); _mod('chamfer', forward=_ch_fwd, backward=_ch_bwd); _mod('emd_cuda')
     _mod('knn_cuda', KNN=KNN)
     p2u = _mod('pointnet2_ops.pointnet2_utils', furthest_point_sample=furthest_point_sample,
                gather_operation=gather_operation)
@@ -118,8 +125,10 @@ def load():
     dev.Group, dev.propagate, dev.pooling = uni.Group, uni.propagate, pooling
     torch.cuda.empty_cache = lambda: None          # called unconditionally at Point_MAE_unify_segment.py:590
     seg = importlib.import_module('models.Point_MAE_unify_segment')
+    nn.Module.cuda = lambda self, *a, **k: self     # Point_MAE_cp.py:409 moves its (parameter-less) loss module to cuda
+    cp = importlib.import_module('models.Point_MAE_cp')
     from models.build import MODELS
-    _loaded = types.SimpleNamespace(uni=uni, dev=dev, seg=seg, MODELS=MODELS, EasyDict=EasyDict, pooling=pooling)
+    _loaded = types.SimpleNamespace(uni=uni, dev=dev, seg=seg, cp=cp, MODELS=MODELS, EasyDict=EasyDict, pooling=pooling)
     return _loaded
 
 

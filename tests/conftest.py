@@ -30,6 +30,7 @@ def oracle_ops(monkeypatch):
     ops = oracle.torch_ops()
     monkeypatch.setitem(upp_layers.OPS, "fps_gather", ops["fps_gather"])
     monkeypatch.setitem(upp_layers.OPS, "knn_group", ops["knn_group"])
+    monkeypatch.setitem(upp_layers.OPS, "chamfer", ops["chamfer"])
     monkeypatch.setattr(HF, "fps_gather", ops["fps_gather"])  # utils.misc.fps resolves through HF
     return ops
 
@@ -37,4 +38,4 @@ def oracle_ops(monkeypatch):
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
-    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("upp_model", "upp_modules", "upp_seg")}
+    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("upp_model", "upp_modules", "upp_seg", "point_mae")}

@@ -1,0 +1,76 @@
+"""Point_MAE pre-training model (Point-MAE fwd+bwd ending in Chamfer-L2) against the fixture produced by
+the reference's models/Point_MAE_cp.Point_MAE with the same random mask."""
+import numpy as np
+import pytest
+import torch
+
+import _seeded
+from models import build_model_from_cfg, MODELS
+from utils.config import builtin_cfg
+
+
+@pytest.fixture(scope="module")
+def mae():
+    m = build_model_from_cfg(builtin_cfg('pretrain').model)
+    return _seeded.fill(m).eval()
+
+
+def _run(model, golden, dev, rtol):
+    g = golden['point_mae']
+    pts = _seeded.unit_ball_clouds(2, 1024, seed=21).to(dev)
+    for p in model.parameters():
+        p.requires_grad_(True); p.grad = None
+    loss = model(pts, mask=torch.from_numpy(g['mask']).to(dev))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=rtol)
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert sorted(grads) == list(g['grad_names'])
+    norms = np.array([grads[n].norm().item() for n in g['grad_names']])
+    np.testing.assert_allclose(norms, g['grad_norms'], rtol=20 * rtol, atol=1e-7)
+    np.testing.assert_allclose(grads['mask_token'].cpu().numpy(), g['g_mask_token'], rtol=20 * rtol, atol=1e-6)
+    np.testing.assert_allclose(grads['increase_dim.0.bias'].cpu().numpy(), g['g_increase_bias'], rtol=20 * rtol, atol=1e-7)
+    for p in model.parameters():
+        p.grad = None
+
+
+def test_schema_and_mask_statistics(mae, golden):
+    g = golden['point_mae']
+    assert sum(p.numel() for p in mae.parameters()) == int(g['n_params']) == 29_006_432
+    assert len(mae.state_dict()) == int(g['n_keys'])
+    sd = mae.state_dict()
+    assert 'MAE_encoder.blocks.blocks.0.attn.qkv.weight' in sd and 'MAE_decoder.blocks.3.mlp.fc2.bias' in sd
+    assert not any('bnorm' in k or 'adapter' in k for k in sd)
+    assert sd['increase_dim.0.weight'].shape == (96, 384, 1) and MODELS.get('Point_MAE') is type(mae)
+    center = torch.randn(5, 64, 3)
+    for kind in ('rand', 'block'):
+        mae.MAE_encoder.mask_type = kind
+        m = mae.MAE_encoder.random_mask(center)
+        assert m.dtype == torch.bool and (m.sum(1) == 38).all()
+    mae.MAE_encoder.mask_type = 'rand'
+    assert not mae.MAE_encoder.random_mask(center, noaug=True).any()
+
+
+def test_loss_and_gradients_match_reference(mae, oracle_ops, golden):
+    _run(mae, golden, 'cpu', 1e-5)
+
+
+@pytest.mark.gpu
+def test_point_mae_on_gpu_matches_fixture_and_trains(mae, golden):
+    m = mae.cuda()
+    try:
+        _run(m, golden, 'cuda', 1e-4)
+        m.train()
+        pts = _seeded.unit_ball_clouds(8, 1024, seed=2).cuda()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss = m(pts)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        assert all(np.isfinite(losses))
+        feat = m.eval()(pts, eval=True)
+        assert feat.shape == (8, 384)
+    finally:
+        mae.eval().cpu()
