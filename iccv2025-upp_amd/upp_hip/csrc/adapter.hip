@@ -113,6 +113,30 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float *__restric
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lk = lane >> 5;
     const int row0 = blockIdx.x * kRows;
+    // Every global load of the kernel is issued here, before the first wait: the three W2 blocks and the x rows /
+    // biases of this wave's output tiles, b1 and the dropout uniforms of this thread's four S1 elements.
+    constexpr int NT = D / 32 / 4;                   // output column tiles per wave
+    float4 w2v[NT][4];
+    float xv[NT][16], b2v[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const int n0 = (wave + 4 * tt) * 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) w2v[tt][it] = *reinterpret_cast<const float4 *>(W2 + (size_t)n0 * kH + (lane + it * 64) * 4);
+        b2v[tt] = b2[n0 + lr];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + trow(r, lk);
+            xv[tt][r] = row < R ? x[(size_t)row * D + n0 + lr] : 0.0f;
+        }
+    }
+    float b1v[4], uv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = threadIdx.x + q * 256, i = e >> 5, j = e & 31;
+        b1v[q] = b1[j];
+        uv[q] = (u && row0 + i < R) ? u[(size_t)(row0 + i) * kH + j] : 1.0f;
+    }
     stage_tile<D>(Hs, ha, row0, R);
     stage_tile<D>(W1s, W1, 0, kH);
     __syncthreads();
@@ -125,32 +149,38 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float *__restric
         for (int r = 0; r < 16; ++r) Part[(wave * kRows + trow(r, lk)) * kLG + lr] = acc[r];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < kRows * kH; e += 256) {
-        const int i = e >> 5, j = e & 31;
-        const float s = ((Part[(0 * kRows + i) * kLG + j] + Part[(1 * kRows + i) * kLG + j]) +
-                         (Part[(2 * kRows + i) * kLG + j] + Part[(3 * kRows + i) * kLG + j])) + b1[j];
-        const size_t gi = (size_t)(row0 + i) * kH + j;
-        float g = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = threadIdx.x + q * 256, i = e >> 5, j = e & 31;
+        const float sv = ((Part[(0 * kRows + i) * kLG + j] + Part[(1 * kRows + i) * kLG + j]) +
+                          (Part[(2 * kRows + i) * kLG + j] + Part[(3 * kRows + i) * kLG + j])) + b1v[q];
+        float gq = 0.0f;
         if (row0 + i < R) {
-            s1_out[gi] = s;
-            g = gelu_f(s) * drop_factor(u, gi, p);
+            s1_out[(size_t)(row0 + i) * kH + j] = sv;
+            gq = gelu_f(sv) * (u ? (uv[q] >= p ? 1.0f / (1.0f - p) : 0.0f) : 1.0f);
         }
-        Gs[i * kLG + j] = g;
+        Gs[i * kLG + j] = gq;
     }
     __syncthreads();
     float *W2t = Part + wave * kRows * kLG;          // Part is free after the reduction above
-    for (int t = wave; t < D / 32; t += 4) {         // out tile columns [32t, 32t+32)
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {                // out tile columns [n0, n0+32)
+        const int n0 = (wave + 4 * tt) * 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {             // this wave's W2 block -> its LDS tile [n][j] (row stride 33)
+            const int e = (lane + it * 64) * 4;
+            float *d = W2t + (e >> 5) * kLG + (e & 31);
+            d[0] = w2v[tt][it].x; d[1] = w2v[tt][it].y; d[2] = w2v[tt][it].z; d[3] = w2v[tt][it].w;
+        }
+        __builtin_amdgcn_wave_barrier();
         f32x16 acc; zero16(acc);
-        stage_w2_tile(W2t, W2, t * 32, lane);
         const float *grow = Gs + lr * kLG + lk;
         const float *wrow = W2t + lr * kLG + lk;                       // B[k][n] = W2[n][k]
         mfma_chain<kH / 2>(acc, [&](int q) { return grow[2 * q]; }, [&](int q) { return wrow[2 * q]; });
-        const int n = t * 32 + lr;
-        const float bias = b2[n];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + trow(r, lk);
-            if (row < R) out[(size_t)row * D + n] = x[(size_t)row * D + n] + scale * (acc[r] + bias);
+            if (row < R) out[(size_t)row * D + n0 + lr] = xv[tt][r] + scale * (acc[r] + b2v[tt]);
         }
         __builtin_amdgcn_wave_barrier();             // the tile is rewritten in the next iteration
     }
@@ -174,6 +204,14 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float *__restric
     const int row0 = blockIdx.x * kRows;
     float *pw1 = part + (size_t)blockIdx.x * (2 * kH * D + kH + D);
     float *pw2 = pw1 + kH * D, *pb1 = pw2 + D * kH, *pb2 = pb1 + kH;
+    float s1v[4], uv[4];                             // loads for the element-wise stage, issued before the first wait
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = threadIdx.x + q * 256, i = e >> 5, j = e & 31;
+        const bool ok = row0 + i < R;
+        s1v[q] = ok ? s1[(size_t)(row0 + i) * kH + j] : 0.0f;
+        uv[q] = (u && ok) ? u[(size_t)(row0 + i) * kH + j] : 1.0f;
+    }
     stage_tile<D>(Zs, g_out, row0, R, scale);
     stage_tile<D>(Hs, ha, row0, R);
     __syncthreads();
@@ -186,16 +224,16 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float *__restric
         for (int r = 0; r < 16; ++r) Part[(wave * kRows + trow(r, lk)) * kLG + lr] = acc[r];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < kRows * kH; e += 256) {
-        const int i = e >> 5, j = e & 31;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = threadIdx.x + q * 256, i = e >> 5, j = e & 31;
         const float gd = (Part[(0 * kRows + i) * kLG + j] + Part[(1 * kRows + i) * kLG + j]) +
                          (Part[(2 * kRows + i) * kLG + j] + Part[(3 * kRows + i) * kLG + j]);
         float ga = 0.0f, d = 0.0f;
         if (row0 + i < R) {
-            const size_t gi = (size_t)(row0 + i) * kH + j;
-            const float s = s1[gi], f = drop_factor(u, gi, p);
-            ga = gd * f * gelu_grad(s);
-            d = gelu_f(s) * f;
+            const float f = u ? (uv[q] >= p ? 1.0f / (1.0f - p) : 0.0f) : 1.0f;
+            ga = gd * f * gelu_grad(s1v[q]);
+            d = gelu_f(s1v[q]) * f;
         }
         GAs[i * kLG + j] = ga;
         Ds[i * kLG + j] = d;
