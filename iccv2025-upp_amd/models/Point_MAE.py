@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from upp_hip import functional as HF
 from .build import MODELS
+from . import upp_layers as L
 from .upp_layers import Block, Encoder, Group, OPS, trunc_normal_
 
 OPS.setdefault("chamfer", HF.ChamferFunction.apply)     # (xyz1, xyz2) -> (dist1, dist2); tests may inject the oracle
@@ -145,6 +146,7 @@ class Point_MAE(nn.Module):
         return (torch.mean(torch.sqrt(d1)) + torch.mean(torch.sqrt(d2))) / 2   # ChamferDistanceL1
 
     def forward(self, pts, vis=False, eval=False, label=None, mask=None, **kwargs):
+        L.UNIFORMS.begin(pts.device, self.training)
         neighborhood, center = self.group_divider(pts)
         if eval:
             return self.MAE_encoder(neighborhood, center, eval=True)[0].max(dim=1)[0]

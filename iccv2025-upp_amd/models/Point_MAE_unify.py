@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from utils import misc
 from .build import MODELS
+from . import upp_layers as L
 from .upp_layers import (  # noqa: F401  (re-exported: the reference's sibling modules import these from here)
     Block, Encoder, Group, RectifyPrompter, TransformerDecoder, TransformerEncoder,
     pooling, propagate, trunc_normal_,
@@ -163,6 +164,7 @@ class Point_MAE_unify(PromptedBackbone):
         return loss, acc * 100
 
     def forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
+        L.UNIFORMS.begin(pts.device, self.training)
         if denoise:
             pts = self._rectify(pts, point_num)
         if completion_prompt:

@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .build import MODELS
+from . import upp_layers as L
 from .Point_MAE_unify import PromptedBackbone
 from .upp_layers import Group, PointNetFeaturePropagation, PositionalEmbedding, _bn_rows, _pointwise_bn_relu
 
@@ -61,6 +62,7 @@ class Point_MAE_unify_seg(PromptedBackbone):
         return F.log_softmax(h, dim=-1).view(B, N, -1)
 
     def forward(self, pts, cls_label, label_points=None, completion_prompt=True, denoise=True, point_num=1024, **kwargs):
+        L.UNIFORMS.begin(pts.device, self.training)
         if denoise:
             pts = self._rectify(pts, point_num)
         if completion_prompt:

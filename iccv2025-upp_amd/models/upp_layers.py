@@ -23,6 +23,35 @@ OPS = {
 
 
 # --------------------------------------------------------------------------- small helpers
+class UniformBank:
+    """One U[0,1) draw per model forward, sliced by the fused blocks' drop-path / dropout sites.
+
+    A training step of the classification model asks for ~50 small uniform tensors; as separate
+    torch.rand launches they cost ~5 us each on MI355X.  `begin()` (called at the top of a model
+    forward) draws as many values as the previous forward consumed; `take()` hands out views and
+    falls back to a direct draw while the demand is still unknown (first forward) or grew."""
+
+    def __init__(self):
+        self.buf, self.pos, self.asked, self.need = None, 0, 0, 0
+
+    def begin(self, device, training):
+        self.need = max(self.need, self.asked)
+        self.pos = self.asked = 0
+        self.buf = torch.rand(self.need, device=device) if (training and self.need) else None
+
+    def take(self, shape, device):
+        n = math.prod(shape)
+        self.asked += n
+        if self.buf is not None and self.buf.device == device and self.pos + n <= self.buf.numel():
+            out = self.buf[self.pos:self.pos + n].view(shape)
+            self.pos += n
+            return out
+        return torch.rand(shape, device=device)
+
+
+UNIFORMS = UniformBank()
+
+
 class DropPath(nn.Module):
     """timm 0.4.5 DropPath: per-sample stochastic depth, identity in eval mode."""
 
@@ -354,7 +383,7 @@ class Block(nn.Module):
         i1a, i2a, idx8, w8 = entry
         u, keep = None, 1.0
         if isinstance(self.drop_path, DropPath) and self.training and self.drop_path.drop_prob > 0:
-            u = torch.rand(B * G2, device=x.device)
+            u = UNIFORMS.take((B * G2,), x.device)
             keep = 1.0 - self.drop_path.drop_prob
         pooled = HF.prop_pool(x, i1a, u, keep)
         if self.training and self.bnorm.track_running_stats:
@@ -381,7 +410,7 @@ class Block(nn.Module):
         u = None
         keep = 1.0
         if isinstance(self.drop_path, DropPath) and self.training and self.drop_path.drop_prob > 0:
-            u = torch.rand(2, B, device=x.device)
+            u = UNIFORMS.take((2, B), x.device)
             keep = 1.0 - self.drop_path.drop_prob
         n1, n2 = self.norm1, self.norm2
         xa, h1 = HF.rowln(x, add=pos, prompts=prompts, mode=ins, P=P, gamma=n1.weight, beta=n1.bias, eps=n1.eps)
@@ -406,7 +435,7 @@ class Block(nn.Module):
         x4, ha = HF.rowln(x2, y=m, u=u2, keep=keep, mode=rem, P=P, gamma=ln.weight, beta=ln.bias, eps=ln.eps)
         if D == 384 and adapter.ln1.weight.shape[0] == 32 and isinstance(adapter.activate, nn.GELU):
             pd = adapter.dropout.p if self.training else 0.0
-            ud = torch.rand(x4.shape[0] * x4.shape[1], 32, device=x.device) if pd > 0 else None
+            ud = UNIFORMS.take((x4.shape[0] * x4.shape[1], 32), x.device) if pd > 0 else None
             return HF.adapter(ha, x4, adapter.ln1.weight, adapter.ln1.bias, adapter.ln2.weight, adapter.ln2.bias, ud, pd, 0.7)
         z = adapter.ln2(adapter.dropout(adapter.activate(adapter.ln1(ha))))
         return torch.add(x4, z, alpha=0.7)

@@ -56,36 +56,52 @@ __device__ __forceinline__ float dp_scale(const float *u, float keep, int b) {
     return u ? floorf(keep + u[b]) / keep : 1.0f;
 }
 
+// Loads of a row kernel are issued in one batch on clamped column indices (no divergent branch around a load):
+// a load inside `if (c < D)` followed by its use costs one full memory round trip per element slot.
 __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     if (row >= a.B * a.Lout) return;
     const int b = row / a.Lout, t = row - b * a.Lout;
     const int src = row_src(t, a.mode, a.P);
     const int D = a.D;
-    float v[kMaxE];
     const float *xs = src >= 0 ? a.x + ((size_t)b * a.Lin + src) * D : a.prompts + (size_t)(-src - 1) * D;
-    const float *ad = (src >= 0 && a.add) ? a.add + ((size_t)b * a.Lin + src) * D : nullptr;
-    const float *ys = (src >= 0 && a.y) ? a.y + ((size_t)b * a.Lin + src) * D : nullptr;
-    const float sc = ys ? dp_scale(a.u, a.keep, b) : 0.0f;
+    const bool has_ad = src >= 0 && a.add, has_y = src >= 0 && a.y, has_ln = a.gamma != nullptr;
+    const float *ad = has_ad ? a.add + ((size_t)b * a.Lin + src) * D : xs;
+    const float *ys = has_y ? a.y + ((size_t)b * a.Lin + src) * D : xs;
+    const float *gm = has_ln ? a.gamma : xs, *bt = has_ln ? a.beta : xs;
+    int cc[kMaxE];
+    float xv[kMaxE], av[kMaxE], yv[kMaxE], gv[kMaxE], bv[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { cc[e] = min(lane + 64 * e, D - 1); xv[e] = xs[cc[e]]; }
+    if (has_ad) {
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) av[e] = ad[cc[e]];
+    }
+    if (has_y) {
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) yv[e] = ys[cc[e]];
+    }
+    if (has_ln) {
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) { gv[e] = gm[cc[e]]; bv[e] = bt[cc[e]]; }
+    }
+    const float sc = has_y ? dp_scale(a.u, a.keep, b) : 0.0f;
+    float v[kMaxE];
     float s = 0.0f;
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) {
-        const int c = lane + 64 * e;
-        float val = 0.0f;
-        if (c < D) {
-            val = xs[c];
-            if (ad) val += ad[c];
-            if (ys) val = __builtin_fmaf(ys[c], sc, val);
-        }
-        v[e] = val;
-        s += val;
+        float val = xv[e];
+        if (has_ad) val += av[e];
+        if (has_y) val = __builtin_fmaf(yv[e], sc, val);
+        v[e] = lane + 64 * e < D ? val : 0.0f;
+        s += v[e];
     }
     if (a.xo) {
 #pragma unroll
         for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) a.xo[(size_t)row * D + c] = v[e]; }
     }
-    if (!a.gamma) return;
+    if (!has_ln) return;
     const float mean = wave_sum(s) / (float)D;
     float q = 0.0f;
 #pragma unroll
@@ -94,7 +110,7 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) {
         const int c = lane + 64 * e;
-        if (c < D) a.h[(size_t)row * D + c] = __builtin_fmaf((v[e] - mean) * rstd, a.gamma[c], a.beta[c]);
+        if (c < D) a.h[(size_t)row * D + c] = __builtin_fmaf((v[e] - mean) * rstd, gv[e], bv[e]);
     }
     if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
 }
@@ -114,23 +130,42 @@ struct RowLnBwdArgs {
 
 __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     if (row >= a.B * a.Lout) return;
     const int b = row / a.Lout, t = row - b * a.Lout;
     const int src = row_src(t, a.mode, a.P);
     const int D = a.D;
-    float d[kMaxE];
+    const bool has_gxo = a.g_xo != nullptr, has_ln = a.g_h != nullptr;
+    // one batch of loads (clamped columns), then the arithmetic
+    int cc[kMaxE];
+    float d[kMaxE], gh[kMaxE], gm[kMaxE], xo[kMaxE];
 #pragma unroll
-    for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; d[e] = (a.g_xo && c < D) ? a.g_xo[(size_t)row * D + c] : 0.0f; }
-    if (a.g_h) {
+    for (int e = 0; e < kMaxE; ++e) cc[e] = min(lane + 64 * e, D - 1);
+    if (has_gxo) {
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) d[e] = a.g_xo[(size_t)row * D + cc[e]];
+    }
+    float mean = 0.0f, rstd = 0.0f;
+    if (has_ln) {
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) { gh[e] = a.g_h[(size_t)row * D + cc[e]]; gm[e] = a.gamma[cc[e]]; xo[e] = a.xo[(size_t)row * D + cc[e]]; }
+        mean = a.mean[row]; rstd = a.rstd[row];
+    }
+    float *gx = nullptr;
+    if (src >= 0) { if (a.g_x) gx = a.g_x + ((size_t)b * a.Lin + src) * D; }
+    else if (a.g_prompt) gx = a.g_prompt + ((size_t)b * a.P + (-src - 1)) * D;
+    float *gy = (src >= 0 && a.g_y) ? a.g_y + ((size_t)b * a.Lin + src) * D : nullptr;
+    const float sc = gy ? dp_scale(a.u, a.keep, b) : 0.0f;
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) d[e] = (has_gxo && lane + 64 * e < D) ? d[e] : 0.0f;
+    if (has_ln) {
         // dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat)),  dy = g_h * gamma
-        const float mean = a.mean[row], rstd = a.rstd[row];
         float dy[kMaxE], xh[kMaxE], s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int e = 0; e < kMaxE; ++e) {
-            const int c = lane + 64 * e;
-            dy[e] = c < D ? a.g_h[(size_t)row * D + c] * a.gamma[c] : 0.0f;
-            xh[e] = c < D ? (a.xo[(size_t)row * D + c] - mean) * rstd : 0.0f;
+            const bool ok = lane + 64 * e < D;
+            dy[e] = ok ? gh[e] * gm[e] : 0.0f;
+            xh[e] = ok ? (xo[e] - mean) * rstd : 0.0f;
             s1 += dy[e];
             s2 = __builtin_fmaf(dy[e], xh[e], s2);
         }
@@ -139,11 +174,6 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < kMaxE; ++e) d[e] += rstd * (dy[e] - s1 - xh[e] * s2);
     }
-    float *gx = nullptr;
-    if (src >= 0) { if (a.g_x) gx = a.g_x + ((size_t)b * a.Lin + src) * D; }
-    else if (a.g_prompt) gx = a.g_prompt + ((size_t)b * a.P + (-src - 1)) * D;
-    float *gy = (src >= 0 && a.g_y) ? a.g_y + ((size_t)b * a.Lin + src) * D : nullptr;
-    const float sc = gy ? dp_scale(a.u, a.keep, b) : 0.0f;
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) {
         const int c = lane + 64 * e;
