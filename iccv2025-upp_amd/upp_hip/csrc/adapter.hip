@@ -212,14 +212,28 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float *__restric
         s1v[q] = ok ? s1[(size_t)(row0 + i) * kH + j] : 0.0f;
         uv[q] = (u && ok) ? u[(size_t)(row0 + i) * kH + j] : 1.0f;
     }
+    // weight operands of the two products that read W2 / W1, held in registers from the start (an operand fetched
+    // from global memory inside an MFMA chain is one exposed round trip per chunk)
+    constexpr int NT = D / 32 / 4;
+    float w2r[KW / 2], w1r[NT][kH / 2];
+    {
+        const float *wcol = W2 + (size_t)(wave * KW + lk) * kH + lr;
+#pragma unroll
+        for (int q = 0; q < KW / 2; ++q) w2r[q] = wcol[(size_t)2 * q * kH];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const float *wrow = W1 + (size_t)lk * D + (wave + 4 * tt) * 32 + lr;
+#pragma unroll
+            for (int q = 0; q < kH / 2; ++q) w1r[tt][q] = wrow[(size_t)2 * q * D];
+        }
+    }
     stage_tile<D>(Zs, g_out, row0, R, scale);
     stage_tile<D>(Hs, ha, row0, R);
     __syncthreads();
     {   // gd partial = gz . W2 over n in [wave*KW, (wave+1)*KW):  A[i][k=n] = gz[i][n], B[k=n][j] = W2[n][j]
         f32x16 acc; zero16(acc);
         const float *zrow = Zs + lr * LDH + wave * KW + lk;
-        const float *wcol = W2 + (size_t)(wave * KW + lk) * kH + lr;
-        mfma_chain<KW / 2>(acc, [&](int q) { return zrow[2 * q]; }, [&](int q) { return wcol[(size_t)2 * q * kH]; });
+        mfma_chain<KW / 2>(acc, [&](int q) { return zrow[2 * q]; }, [&](int q) { return w2r[q]; });
 #pragma unroll
         for (int r = 0; r < 16; ++r) Part[(wave * kRows + trow(r, lk)) * kLG + lr] = acc[r];
     }
@@ -245,13 +259,13 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float *__restric
         if (c < kH) { for (int i = 0; i < kRows; ++i) sacc += GAs[i * kLG + c]; pb1[c] = sacc; }
         else { const int n = c - kH; for (int i = 0; i < kRows; ++i) sacc += Zs[i * LDH + n]; pb2[n] = sacc; }
     }
-    for (int t = wave; t < D / 32; t += 4) {
-        const int n0 = t * 32;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const int n0 = (wave + 4 * tt) * 32;
         {   // g_ha[i][n] = sum_j ga[i][j] W1[j][n]
             f32x16 acc; zero16(acc);
             const float *arow = GAs + lr * kLG + lk;
-            const float *wrow = W1 + (size_t)lk * D + n0 + lr;
-            mfma_chain<kH / 2>(acc, [&](int q) { return arow[2 * q]; }, [&](int q) { return wrow[(size_t)2 * q * D]; });
+            mfma_chain<kH / 2>(acc, [&](int q) { return arow[2 * q]; }, [&](int q) { return w1r[tt][q]; });
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + trow(r, lk);

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void prop_pool_fwd_kernel(const float *__restr
                                                             const float *__restrict__ u, float keep, float *__restrict__ pooled,
                                                             uint8_t *__restrict__ amax, int groups, int D) {
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     if (g >= groups) return;
     const float f = 1.0f + (u ? floorf(keep + u[g]) / keep : 1.0f);   // x + drop_path(x): factor 1 + s
     float mx[kMaxE], sm[kMaxE];
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void prop_pool_fwd_kernel(const float *__restr
 #pragma unroll
     for (int k = 0; k < kNb; ++k)
 #pragma unroll
-        for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; val[k][e] = c < D ? X[(size_t)rows8[k] * D + c] : 0.0f; }
+        for (int e = 0; e < kMaxE; ++e) val[k][e] = X[(size_t)rows8[k] * D + min(lane + 64 * e, D - 1)];   // clamped: no branch
 #pragma unroll
     for (int k = 0; k < kNb; ++k)
 #pragma unroll
@@ -117,17 +117,17 @@ __global__ __launch_bounds__(256) void prop_pool_bwd_kernel(const float *__restr
                 g[t] = hit / kNb; k[t] = hit - g[t] * kNb;
                 f[t] = live ? 1.0f + (u ? floorf(keep + u[g[t]]) / keep : 1.0f) : 0.0f;
             }
+            float gp[kMaxE][4]; int am[kMaxE][4];
 #pragma unroll
             for (int e = 0; e < kMaxE; ++e) {
-                const int c = lane + 64 * e;
-                if (c < D) {
-                    float gp[4]; int am[4];
+                const int c = min(lane + 64 * e, D - 1);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) { gp[t] = g_pooled[(size_t)g[t] * D + c]; am[t] = amax[(size_t)g[t] * D + c]; }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[e] += gp[t] * f[t] * (0.125f + (am[t] == k[t] ? 1.0f : 0.0f));
-                }
+                for (int t = 0; t < 4; ++t) { gp[e][t] = g_pooled[(size_t)g[t] * D + c]; am[e][t] = amax[(size_t)g[t] * D + c]; }
             }
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[e] += gp[e][t] * f[t] * (0.125f + (am[e][t] == k[t] ? 1.0f : 0.0f));
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -142,13 +142,14 @@ __global__ __launch_bounds__(256) void prop_interp_fwd_kernel(const float *__res
                                                               const float *__restrict__ w8, float *__restrict__ out, int B, int Lp,
                                                               int T, int G2, int D) {
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     if (r >= B * Lp) return;
     const int b = r / Lp, t = r - b * Lp;
     const int i = t - (Lp - T);
-    float acc[kMaxE];
+    int cc[kMaxE];
+    float xv[kMaxE], acc[kMaxE];
 #pragma unroll
-    for (int e = 0; e < kMaxE; ++e) acc[e] = 0.0f;
+    for (int e = 0; e < kMaxE; ++e) { cc[e] = min(lane + 64 * e, D - 1); xv[e] = X[(size_t)r * D + cc[e]]; acc[e] = 0.0f; }
     if (i >= 0) {
         // three dependent hops (idx8 -> i2 -> X row): each hop's loads are issued for all 8 neighbours at once
         int j[kNb], cr[kNb];
@@ -158,21 +159,23 @@ __global__ __launch_bounds__(256) void prop_interp_fwd_kernel(const float *__res
 #pragma unroll
         for (int k = 0; k < kNb; ++k) cr[k] = i2[b * G2 + j[k]];
 #pragma unroll
-        for (int e = 0; e < kMaxE; ++e) {
-            const int c = lane + 64 * e;
-            if (c < D) {
-                float lv[kNb], cv[kNb];
+        for (int h = 0; h < kMaxE; h += 4) {          // 4 column slots x 8 neighbours x 2 arrays = 64 loads in flight
+            float lv[4][kNb], cv[4][kNb];
 #pragma unroll
-                for (int k = 0; k < kNb; ++k) { lv[k] = lc[((size_t)b * G2 + j[k]) * D + c]; cv[k] = X[(size_t)cr[k] * D + c]; }
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int k = 0; k < kNb; ++k) acc[e] += (lv[k] + 0.3f * cv[k]) * w[k];
-            }
+                for (int k = 0; k < kNb; ++k) { lv[e][k] = lc[((size_t)b * G2 + j[k]) * D + cc[h + e]]; cv[e][k] = X[(size_t)cr[k] * D + cc[h + e]]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < kNb; ++k) acc[h + e] += (lv[e][k] + 0.3f * cv[e][k]) * w[k];
+            if (64 * (h + 4) >= D) break;             // wave-uniform: no live column beyond
         }
     }
 #pragma unroll
     for (int e = 0; e < kMaxE; ++e) {
         const int c = lane + 64 * e;
-        if (c < D) out[(size_t)r * D + c] = X[(size_t)r * D + c] + (i >= 0 ? 0.3f * acc[e] : 0.0f);
+        if (c < D) out[(size_t)r * D + c] = xv[e] + (i >= 0 ? 0.3f * acc[e] : 0.0f);
     }
 }
 
@@ -190,7 +193,13 @@ __global__ __launch_bounds__(256) void prop_interp_bwd_c2_kernel(const float *__
     int *hits = lds_i + 2 * n + wave * kHitCap;
     const int gj0 = blockIdx.x * 4;
     const int b = gj0 / G2;
-    for (int i = threadIdx.x; i < n; i += 256) { list[i] = idx8[(size_t)b * n + i]; wl[i] = w8[(size_t)b * n + i]; }
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 4) {     // 8 independent loads in flight per thread
+        int32_t ti[4]; float tw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = min(i0 + q * 256, n - 1); ti[q] = idx8[(size_t)b * n + i]; tw[q] = w8[(size_t)b * n + i]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (i0 + q * 256 < n) { list[i0 + q * 256] = ti[q]; wl[i0 + q * 256] = tw[q]; }
+    }
     __syncthreads();
     const int gj = gj0 + wave;
     if (gj >= B * G2) return;
@@ -201,27 +210,27 @@ __global__ __launch_bounds__(256) void prop_interp_bwd_c2_kernel(const float *__
     int q0 = 0;
     while (q0 < n) {
         const int cnt = collect_hits(list, n, j, hits, kHitCap, lane, q0);
-        for (int h0 = 0; h0 < cnt; h0 += 4) {
-            const float *grow[4];
-            float w[4];
+        for (int h0 = 0; h0 < cnt; h0 += 8) {                // 8 token rows (x kMaxE column slots) in flight
+            const float *grow[8];
+            float w[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 8; ++t) {
                 const bool live = h0 + t < cnt;
                 const int hit = hits[live ? h0 + t : h0];
                 w[t] = live ? wl[hit] : 0.0f;
                 grow[t] = g_out + ((size_t)b * Lp + (Lp - T) + hit / kNb) * D;
             }
+            float gv[kMaxE][8];
 #pragma unroll
             for (int e = 0; e < kMaxE; ++e) {
-                const int c = lane + 64 * e;
-                if (c < D) {
-                    float gv[4];
+                const int c = min(lane + 64 * e, D - 1);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) gv[t] = grow[t][c];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[e] += gv[t] * w[t];
-                }
+                for (int t = 0; t < 8; ++t) gv[e][t] = grow[t][c];
             }
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[e] += gv[e][t] * w[t];
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -234,19 +243,27 @@ __global__ __launch_bounds__(256) void prop_interp_bwd_x_kernel(const float *__r
                                                                 const int32_t *__restrict__ i2, float *__restrict__ g_X, int rows,
                                                                 int groups, int D) {
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     if (r >= rows) return;
+    int cc[kMaxE];
     float acc[kMaxE];
 #pragma unroll
-    for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; acc[e] = c < D ? g_out[(size_t)r * D + c] : 0.0f; }
-    for (int base = 0; base < groups; base += 64) {
-        const int q = base + lane;
-        unsigned long long mask = __ballot(q < groups && i2[q] == r);
-        while (mask) {
-            const int m = base + __builtin_ctzll(mask);
-            mask &= mask - 1;
+    for (int e = 0; e < kMaxE; ++e) { cc[e] = min(lane + 64 * e, D - 1); acc[e] = g_out[(size_t)r * D + cc[e]]; }
+    // the whole index list is compared first (independent loads), then the matching rows are added in ascending order
+    for (int base = 0; base < groups; base += 64 * 8) {
+        int v[8];
 #pragma unroll
-            for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) acc[e] += 0.3f * g_c2[(size_t)m * D + c]; }
+        for (int q = 0; q < 8; ++q) { const int m = base + q * 64 + lane; v[q] = i2[min(m, groups - 1)]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m0 = base + q * 64;
+            unsigned long long mask = __ballot(m0 + lane < groups && v[q] == r);
+            while (mask) {
+                const int m = m0 + __builtin_ctzll(mask);
+                mask &= mask - 1;
+#pragma unroll
+                for (int e = 0; e < kMaxE; ++e) acc[e] += 0.3f * g_c2[(size_t)m * D + cc[e]];
+            }
         }
     }
 #pragma unroll
