@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (debug)")
+    ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM solutions (see upp_hip/gemm_tuning.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,6 +221,9 @@ def main():
     torch.cuda.set_device(device)
     from upp_hip import _abi
     _abi.load()                                           # fail loudly if the HIP library is missing
+    if not args.no_gemm_tuning:
+        from upp_hip import gemm_tuning
+        gemm_tuning.enable()                              # best hipBLASLt / rocBLAS solution per Linear shape (same f32 math)
 
     tr = Trainer(device, args.batch, distributed, use_graph=not args.no_graph)
     for _ in range(args.warmup):

@@ -146,7 +146,13 @@ class Point_MAE(nn.Module):
         return (torch.mean(torch.sqrt(d1)) + torch.mean(torch.sqrt(d2))) / 2   # ChamferDistanceL1
 
     def forward(self, pts, vis=False, eval=False, label=None, mask=None, **kwargs):
-        L.UNIFORMS.begin(pts.device, self.training)
+        L.begin_forward(pts.device, self.training)
+        try:
+            return self._forward(pts, vis=vis, eval=eval, label=label, mask=mask, **kwargs)
+        finally:
+            L.end_forward()
+
+    def _forward(self, pts, vis=False, eval=False, label=None, mask=None, **kwargs):
         neighborhood, center = self.group_divider(pts)
         if eval:
             return self.MAE_encoder(neighborhood, center, eval=True)[0].max(dim=1)[0]

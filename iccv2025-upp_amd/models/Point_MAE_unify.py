@@ -164,7 +164,13 @@ class Point_MAE_unify(PromptedBackbone):
         return loss, acc * 100
 
     def forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
-        L.UNIFORMS.begin(pts.device, self.training)
+        L.begin_forward(pts.device, self.training)
+        try:
+            return self._forward(pts, label=label, completion_prompt=completion_prompt, denoise=denoise, point_num=point_num, **kwargs)
+        finally:
+            L.end_forward()
+
+    def _forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
         if denoise:
             pts = self._rectify(pts, point_num)
         if completion_prompt:

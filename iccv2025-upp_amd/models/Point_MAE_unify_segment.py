@@ -43,7 +43,7 @@ class Point_MAE_unify_seg(PromptedBackbone):
         x = cls_label.reshape(cls_label.shape[0], 16).float()
         for conv, bn, act in ((c1, b1, a1), (c2, b2, a2)):
             if self.training and bn.track_running_stats:
-                bn.num_batches_tracked.add_(1)
+                L.bump_counter(bn.num_batches_tracked)
             x = act(_bn_rows(F.linear(x, conv.weight.squeeze(-1), conv.bias), bn, self.training))
         return x
 
@@ -55,14 +55,20 @@ class Point_MAE_unify_seg(PromptedBackbone):
         per_sample = F.linear(global_feat, w1[:, C:], c1.bias)                       # (B,512), once per sample
         h = F.linear(point_feat.reshape(B * N, C), w1[:, :C]).view(B, N, -1) + per_sample.unsqueeze(1)
         if self.training and bn1.track_running_stats:
-            bn1.num_batches_tracked.add_(1)
+            L.bump_counter(bn1.num_batches_tracked)
         h = drop(F.relu(_bn_rows(h.view(B * N, -1), bn1, self.training)))
         h = _pointwise_bn_relu(h, c2, bn2, self.training)
         h = F.linear(h, c3.weight.squeeze(-1), c3.bias)
         return F.log_softmax(h, dim=-1).view(B, N, -1)
 
     def forward(self, pts, cls_label, label_points=None, completion_prompt=True, denoise=True, point_num=1024, **kwargs):
-        L.UNIFORMS.begin(pts.device, self.training)
+        L.begin_forward(pts.device, self.training)
+        try:
+            return self._forward(pts, cls_label, label_points=label_points, completion_prompt=completion_prompt, denoise=denoise, point_num=point_num, **kwargs)
+        finally:
+            L.end_forward()
+
+    def _forward(self, pts, cls_label, label_points=None, completion_prompt=True, denoise=True, point_num=1024, **kwargs):
         if denoise:
             pts = self._rectify(pts, point_num)
         if completion_prompt:

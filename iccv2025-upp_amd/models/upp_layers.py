@@ -51,6 +51,31 @@ class UniformBank:
 
 UNIFORMS = UniformBank()
 
+# BatchNorm `num_batches_tracked` counters touched during one model forward: bumped together by ONE multi-tensor
+# launch at the end of the forward instead of one tiny kernel per BatchNorm call.
+_pending_counters = None
+
+
+def bump_counter(t):
+    if _pending_counters is None:
+        t.add_(1)
+    else:
+        _pending_counters.append(t)
+
+
+def begin_forward(device, training):
+    """Called at the top of a model forward: draws the forward's uniforms, opens the counter list."""
+    global _pending_counters
+    UNIFORMS.begin(device, training)
+    _pending_counters = []
+
+
+def end_forward():
+    global _pending_counters
+    pending, _pending_counters = _pending_counters, None
+    if pending:
+        torch._foreach_add_(pending, 1)
+
 
 class DropPath(nn.Module):
     """timm 0.4.5 DropPath: per-sample stochastic depth, identity in eval mode."""
@@ -90,9 +115,13 @@ def index_points(points, idx):
     return points[batch.expand_as(idx), idx, :]
 
 
-def _inverse_distance_interp(xyz1, xyz2, points2, k, eps):
-    """k nearest of xyz2 for each xyz1 point (full sort, as the reference), 1/(d+eps) weights."""
+def _inverse_distance_interp(xyz1, xyz2, points2, k, eps, out=None, col0=0):
+    """k nearest of xyz2 for each xyz1 point (full sort, as the reference), 1/(d+eps) weights.
+    `out`/`col0`: optional (B,N,W) buffer whose columns [col0, col0+C) receive the result (fused path only)."""
     dists, idx = square_distance(xyz1, xyz2).sort(dim=-1)
+    if points2.is_cuda and k <= 16 and points2.shape[-1] <= 256 and _no_grad_needed(xyz1, xyz2, points2):
+        return HF.interp(dists, idx, points2, min(k, dists.shape[-1]), eps, out, col0)
+    assert out is None
     dists, idx = dists[:, :, :k], idx[:, :, :k]
     recip = 1.0 / (dists + eps)
     weight = recip / torch.sum(recip, dim=2, keepdim=True)
@@ -143,20 +172,28 @@ class Group(nn.Module):
 
 
 # --------------------------------------------------------------------------- patch embedding
-def _bn_rows(x, bn, training):
+def _no_grad_needed(*tensors):
+    """True when no autograd graph has to be recorded for an op on these tensors (frozen branch / no_grad)."""
+    return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
+
+
+def _bn_rows(x, bn, training, relu=False):
     """BatchNorm1d of a channels-last (rows, C) matrix: identical statistics to BatchNorm1d on
     the reference's (BG, C, n) layout (both reduce over every position of every group)."""
-    return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                        training, 0.0 if bn.momentum is None else bn.momentum, bn.eps)
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and _no_grad_needed(x, bn.weight, bn.bias):
+        return HF.bn_rows(x, bn, training, relu)       # 3 launches instead of torch's 5-6 (frozen prompter branches)
+    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                     training, 0.0 if bn.momentum is None else bn.momentum, bn.eps)
+    return F.relu(y) if relu else y
 
 
 def _pointwise_bn_relu(x, conv, bn, training):
     """relu(bn(conv1x1(x))) on a channels-last (rows, C_in) matrix: a 1x1 Conv1d/Conv2d is a GEMM and
     BatchNorm over (batch, positions) is BatchNorm over rows -- no NCHW permutes, no MIOpen conv."""
     if training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
+        bump_counter(bn.num_batches_tracked)
     w = conv.weight.view(conv.weight.shape[0], -1)
-    return F.relu(_bn_rows(F.linear(x, w, conv.bias), bn, training))
+    return _bn_rows(F.linear(x, w, conv.bias), bn, training, relu=True)
 
 
 class Encoder(nn.Module):
@@ -193,8 +230,8 @@ class Encoder(nn.Module):
             from upp_hip import ops
             bn1, bn3 = self.first_conv[1], self.second_conv[1]
             if self.training:
-                bn1.num_batches_tracked.add_(1)
-                bn3.num_batches_tracked.add_(1)
+                bump_counter(bn1.num_batches_tracked)
+                bump_counter(bn3.num_batches_tracked)
             return ops.patch_embed_fwd(point_groups.contiguous(), self, self.training)
         return self._forward_torch(point_groups)
 
@@ -206,8 +243,8 @@ class Encoder(nn.Module):
         x = point_groups.reshape(bs * g * n, 3)
         h = F.linear(x, c1.weight.squeeze(-1), c1.bias)
         if self.training and bn1.track_running_stats:
-            bn1.num_batches_tracked.add_(1)
-            bn3.num_batches_tracked.add_(1)
+            bump_counter(bn1.num_batches_tracked)
+            bump_counter(bn3.num_batches_tracked)
         h = F.relu(_bn_rows(h, bn1, self.training))
         f = F.linear(h, c2.weight.squeeze(-1), c2.bias)                    # (BGn, 256)
         fg = f.view(bs * g, n, 256).max(dim=1)[0]                           # (BG, 256)
@@ -375,21 +412,24 @@ class Block(nn.Module):
                     G = Lp - off      # the reference indexes the cls-stripped tokens as a flat (B*G)-row matrix
                     i1a = torch.div(i1, G, rounding_mode='floor') * Lp + off + i1 % G
                     i2a = torch.div(i2, G, rounding_mode='floor') * Lp + off + i2 % G
-                entry = (i1a.reshape(-1).int().contiguous(), i2a.reshape(-1).int().contiguous(), idx8.int().contiguous(), w8)
+                entry = HF.PropIndex(i1a.reshape(-1).int().contiguous(), i2a.reshape(-1).int().contiguous(), idx8.int().contiguous(), w8,
+                                     rows=B * Lp)
             if cache is not None:
                 cache[key] = entry
         else:
             entry = cache[key]
-        i1a, i2a, idx8, w8 = entry
         u, keep = None, 1.0
         if isinstance(self.drop_path, DropPath) and self.training and self.drop_path.drop_prob > 0:
             u = UNIFORMS.take((B * G2,), x.device)
             keep = 1.0 - self.drop_path.drop_prob
-        pooled = HF.prop_pool(x, i1a, u, keep)
-        if self.training and self.bnorm.track_running_stats:
-            self.bnorm.num_batches_tracked.add_(1)
-        lc = _bn_rows(pooled, self.bnorm, self.training).view(B, G2, D)
-        return HF.prop_interp(x, lc, i2a, idx8, w8)
+        bn = self.bnorm
+        if self.training and bn.track_running_stats:
+            bump_counter(bn.num_batches_tracked)
+        if bn.affine and (bn.track_running_stats or self.training) and B * Lp <= 15360:
+            return HF.propagate(x, bn, entry, u, keep, self.training)
+        pooled = HF.prop_pool(x, entry.i1, u, keep)
+        lc = _bn_rows(pooled, bn, self.training).view(B, G2, D)
+        return HF.prop_interp(x, lc, entry.i2, entry.idx8, entry.w8)
 
     def fusable(self, x):
         return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 512 and self.attn.fusable(x)
@@ -539,7 +579,10 @@ class PositionalEmbedding(nn.Module):
         self.freq_bands = (2 ** torch.linspace(0, N_freqs - 1, N_freqs) if logscale
                            else torch.linspace(1, 2 ** (N_freqs - 1), N_freqs)).tolist()
 
-    def forward(self, x):
+    def forward(self, x, out=None, col0=0):
+        if x.is_cuda and x.dtype == torch.float32 and len(self.freq_bands) <= 8 and _no_grad_needed(x):
+            return HF.posenc(x, self.freq_bands, out, col0)    # one launch; may write a column window of `out`
+        assert out is None
         out = [x]
         for freq in self.freq_bands:
             out += [torch.sin(freq * x), torch.cos(freq * x)]
@@ -586,13 +629,19 @@ class PointNetFeaturePropagation(nn.Module):
             self.mlp_bns.append(nn.BatchNorm1d(out_channel))
             last = out_channel
 
-    def forward(self, xyz1, xyz2, points1, points2):
+    def forward(self, xyz1, xyz2, points1, points2, cat_buffer=None):
+        """cat_buffer: optional (B,N,C1+C2) buffer whose first C1 columns already hold points1 (fused path)."""
         N = xyz1.shape[1]
-        if xyz2.shape[1] == 1:
-            interp = points2.repeat(1, N, 1)
+        if cat_buffer is not None:
+            _inverse_distance_interp(xyz1, xyz2, points2, self.interpolate_neighbors, 1e-4, out=cat_buffer,
+                                     col0=cat_buffer.shape[-1] - points2.shape[-1])
+            x = cat_buffer
         else:
-            interp = _inverse_distance_interp(xyz1, xyz2, points2, self.interpolate_neighbors, 1e-4)
-        x = interp if points1 is None else torch.cat([points1, interp], dim=-1)
+            if xyz2.shape[1] == 1:
+                interp = points2.repeat(1, N, 1)
+            else:
+                interp = _inverse_distance_interp(xyz1, xyz2, points2, self.interpolate_neighbors, 1e-4)
+            x = interp if points1 is None else torch.cat([points1, interp], dim=-1)
         B = x.shape[0]
         x = x.reshape(B * N, -1)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
@@ -629,6 +678,15 @@ class RectifyPrompter(nn.Module):
         center2, center2_feature = self.abstraction(center1, center1_feature)
         shape_feature = center2_feature.reshape(B, -1)
         center1_feature = self.propagation2(center1, center2, None, center2_feature)
-        feature = self.propagation1(x, center1, self.position_embedding(x), center1_feature)
+        pe = self.position_embedding
+        if (x.is_cuda and x.dtype == torch.float32 and len(pe.freq_bands) <= 8 and center1.shape[1] > 1
+                and self.propagation1.interpolate_neighbors <= 16 and _no_grad_needed(x, center1, center1_feature)):
+            # embedding and interpolation write the two halves of one buffer (the reference's torch.cat)
+            C1, C2 = 3 * (2 * len(pe.freq_bands) + 1), center1_feature.shape[-1]
+            buf = x.new_empty(x.shape[0], x.shape[1], C1 + C2)
+            pe(x, out=buf, col0=0)
+            feature = self.propagation1(x, center1, None, center1_feature, cat_buffer=buf)
+        else:
+            feature = self.propagation1(x, center1, pe(x), center1_feature)
         noise_score = self.score_head(feature) * self.score_factor
         return (noise_score, shape_feature) if require_shape_feature else noise_score

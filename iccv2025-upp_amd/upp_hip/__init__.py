@@ -13,7 +13,7 @@ emd_cuda, utils, models) mirror the import surface of the reference so that
 from . import _abi  # noqa: F401
 from .functional import (  # noqa: F401
     furthest_point_sample, gather_operation, fps_gather, knn_query, knn_group, group_points,
-    ChamferFunction, EarthMoverDistanceFunction, rowln, attention, prop_pool, prop_interp, adapter,
+    ChamferFunction, EarthMoverDistanceFunction, rowln, attention, prop_pool, prop_interp, adapter, PropIndex, propagate,
 )
 
 __all__ = ["furthest_point_sample", "gather_operation", "fps_gather", "knn_query", "knn_group",

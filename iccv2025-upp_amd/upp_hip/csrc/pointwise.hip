@@ -1,0 +1,253 @@
+// pointwise.hip -- the small row operators of the frozen prompter branches, for gfx950.
+//
+// The rectify prompter (reference models/Point_MAE_pretask_dev.py:386-517) is a PointNet++-style network on a few
+// tens of thousands of rows with 3..64 channels.  In the reference every layer is a chain of tiny element-wise /
+// reduction kernels (BatchNorm statistics, update, transform, ReLU; reciprocal, sum, divide, gather, multiply,
+// reduce; sin / cos per frequency; concatenations).  At these sizes each of them costs one launch (~5 us on MI355X)
+// and nothing else, so the chains are folded into three operators:
+//   upp_bn_rows_fwd : BatchNorm over the rows of a channels-last matrix (+ optional ReLU), batch statistics via
+//                     per-slab (sum, M2) partials -> one finalize workgroup per 64 channels -> apply   [3 launches]
+//   upp_interp_fwd  : inverse-distance interpolation from the k nearest of a sorted neighbour table   [1 launch]
+//   upp_posenc_fwd  : (x, sin(f x), cos(f x))_f positional embedding                                  [1 launch]
+// interp / posenc write into a column window of a wider row-major buffer, so the reference's torch.cat is free.
+#include "common.h"
+
+namespace {
+
+constexpr int kBnWaves = 16;
+
+// ---- BatchNorm over rows ----------------------------------------------------------------------------------------
+// Partial statistics of one slab of `per` rows: part[(slab*2+0)*C + c] = sum_r x[r][c],
+// part[(slab*2+1)*C + c] = M2 = sum_r (x[r][c] - slab mean)^2, computed from sums shifted by the slab's first row
+// (shifted-data algorithm: no cancellation when |mean| >> std).  Thread (rl, col): col = tid % Cp, rl = tid / Cp.
+__global__ __launch_bounds__(256) void bn_rows_partial_kernel(const float *__restrict__ x, int R, int C, int Cp, int per,
+                                                              float *__restrict__ part) {
+    __shared__ float s1[256], s2[256];
+    const int tid = threadIdx.x;
+    const int col = blockIdx.y * 256 + tid % Cp, rl = tid / Cp, RL = 256 / Cp;
+    const int r0 = blockIdx.x * per, r1 = min(R, r0 + per);
+    const int cc = min(col, C - 1);
+    const float shift = x[(size_t)r0 * C + cc];
+    float a1 = 0.0f, a2 = 0.0f;
+    for (int rb = r0 + rl; rb < r1; rb += RL * 8) {         // 8 independent row loads in flight
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = x[(size_t)min(rb + t * RL, r1 - 1) * C + cc];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (rb + t * RL < r1) { const float d = v[t] - shift; a1 += d; a2 = __builtin_fmaf(d, d, a2); }
+    }
+    s1[tid] = a1; s2[tid] = a2;
+    __syncthreads();
+    if (rl == 0 && col < C) {
+        for (int q = 1; q < RL; ++q) { a1 += s1[q * Cp + tid]; a2 += s2[q * Cp + tid]; }   // fixed order
+        const float n = (float)(r1 - r0);
+        part[((size_t)blockIdx.x * 2 + 0) * C + col] = __builtin_fmaf(shift, n, a1);
+        part[((size_t)blockIdx.x * 2 + 1) * C + col] = a2 - a1 * a1 / n;
+    }
+}
+
+// mean / rstd from the slab partials (training) or the running statistics (eval); running statistics updated in
+// training mode.  grid = ceil(C / 64), 16 waves; lane = column; wave w merges slabs w, w+16, ... (Chan et al., f64);
+// the 16 wave results are merged in wave order.
+__global__ __launch_bounds__(64 * kBnWaves) void bn_finalize_rows_kernel(const float *__restrict__ part, int slabs, int per, int rows,
+                                                                         int C, int training, float momentum, float eps,
+                                                                         float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                                         float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+    __shared__ double shn[kBnWaves][64], shm[kBnWaves][64], shq[kBnWaves][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int cc = min(c, C - 1);
+    if (!training) {
+        if (wave == 0 && c < C) { mean_out[c] = running_mean[c]; rstd_out[c] = 1.0f / sqrtf(running_var[c] + eps); }
+        return;
+    }
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int w0 = wave; w0 < slabs; w0 += kBnWaves * 16) {
+        float ps[16], pq[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int w = min(w0 + kBnWaves * t, slabs - 1);
+            ps[t] = part[((size_t)w * 2 + 0) * C + cc]; pq[t] = part[((size_t)w * 2 + 1) * C + cc];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int w = w0 + kBnWaves * t;
+            if (w < slabs) {
+                const double nb = (double)min(per, rows - w * per), mb = (double)ps[t] / nb;
+                const double tot = n + nb, delta = mb - mean;
+                mean += delta * nb / tot;
+                m2 += (double)pq[t] + delta * delta * n * nb / tot;
+                n = tot;
+            }
+        }
+    }
+    shn[wave][lane] = n; shm[wave][lane] = mean; shq[wave][lane] = m2;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+        for (int w = 1; w < kBnWaves; ++w) {
+            const double nb = shn[w][lane];
+            if (nb > 0.0) {
+                const double tot = n + nb, delta = shm[w][lane] - mean;
+                mean += delta * nb / tot;
+                m2 += shq[w][lane] + delta * delta * n * nb / tot;
+                n = tot;
+            }
+        }
+        const float var = (float)(m2 / n);
+        mean_out[c] = (float)mean;
+        rstd_out[c] = 1.0f / sqrtf(var + eps);
+        if (running_mean) {
+            const float unbiased = (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    }
+}
+
+// y = ((x - mean) * rstd) * gamma + beta, optionally max(., 0); 4 consecutive elements per thread
+__global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int relu, float *__restrict__ y,
+                                                            long long total, int C) {
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= total) return;
+    float v[4];
+    int c[4];
+    if ((C & 3) == 0) {
+        const float4 t = *reinterpret_cast<const float4 *>(x + i0);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        const int cb = (int)(i0 % C);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = cb + q;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const long long i = min(i0 + q, total - 1); v[q] = x[i]; c[q] = (int)(i % C); }
+    }
+    float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mu[q] = mean[c[q]]; rs[q] = rstd[c[q]]; ga[q] = gamma ? gamma[c[q]] : 1.0f; be[q] = beta ? beta[c[q]] : 0.0f; }
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        o[q] = ((v[q] - mu[q]) * rs[q]) * ga[q] + be[q];
+        if (relu) o[q] = fmaxf(o[q], 0.0f);
+    }
+    if ((C & 3) == 0) *reinterpret_cast<float4 *>(y + i0) = make_float4(o[0], o[1], o[2], o[3]);
+    else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (i0 + q < total) y[i0 + q] = o[q];
+    }
+}
+
+// ---- inverse-distance interpolation ----------------------------------------------------------------------------------
+// out[row][col0 + c] = sum_{j<k} w_j * feat[b][idx[row][j]][c],  w_j = (1/(d_j+eps)) / sum_j (1/(d_j+eps)),
+// (d, idx) = the first k entries of row `row` of a neighbour table sorted by distance (row stride ld_tab).
+// PointNetFeaturePropagation.forward, reference models/Point_MAE_pretask_dev.py:443-462.
+constexpr int kInterpK = 16;
+__global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ dist, const int64_t *__restrict__ idx, int ld_tab,
+                                                     const float *__restrict__ feat, int S, int C, int Cp, int k, float eps,
+                                                     float *__restrict__ out, int ld_out, int col0, int rows, int N) {
+    const int tid = threadIdx.x;
+    const int col = tid % Cp, rl = tid / Cp, RL = 256 / Cp;
+    const int row = blockIdx.x * RL + rl;
+    if (row >= rows) return;
+    const int b = row / N;
+    const int cc = min(col, C - 1);
+    float d[kInterpK];
+    int id[kInterpK];
+#pragma unroll
+    for (int j = 0; j < kInterpK; ++j) {
+        const int jj = min(j, k - 1);
+        d[j] = dist[(size_t)row * ld_tab + jj];
+        id[j] = (int)idx[(size_t)row * ld_tab + jj];
+    }
+    float f[kInterpK];
+#pragma unroll
+    for (int j = 0; j < kInterpK; ++j) f[j] = feat[((size_t)b * S + id[j]) * C + cc];
+    float w[kInterpK], norm = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kInterpK; ++j) { w[j] = j < k ? 1.0f / (d[j] + eps) : 0.0f; norm += w[j]; }
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kInterpK; ++j) acc += f[j] * (w[j] / norm);
+    if (col < C) out[(size_t)row * ld_out + col0 + col] = acc;
+}
+
+// ---- positional embedding ---------------------------------------------------------------------------------------
+// out[row][col0 + ...] = (x, sin(f0 x), cos(f0 x), sin(f1 x), cos(f1 x), ...) for x (rows, 3)
+// (reference models/Point_MAE_pretask_dev.py:22-52).  One thread per (row, coordinate).
+struct Freqs { float f[8]; };
+__global__ __launch_bounds__(256) void posenc_kernel(const float *__restrict__ x, Freqs fr, int F, float *__restrict__ out, int ld_out,
+                                                     int col0, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long row = i / 3;
+    const int c = (int)(i - row * 3);
+    const float v = x[i];
+    float *o = out + (size_t)row * ld_out + col0 + c;
+    o[0] = v;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < F) { const float a = fr.f[q] * v; o[3 + 6 * q] = sinf(a); o[6 + 6 * q] = cosf(a); }
+}
+
+int bn_per(int R) { int per = (R + 255) / 256; return per < 8 ? 8 : per; }
+int pow2_at_least(int c) { int p = 4; while (p < c && p < 256) p <<= 1; return p; }
+
+}  // namespace
+
+// shared with prop.hip: finalize of (sum, M2) slab partials
+int upp_bn_finalize_launch(const float *part, int slabs, int per, int rows, int C, int training, float momentum, float eps,
+                           float *running_mean, float *running_var, float *mean, float *rstd, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3((C + 63) / 64), dim3(64 * kBnWaves), 0, st, part, slabs, per, rows, C, training, momentum,
+                       eps, running_mean, running_var, mean, rstd);
+    return 0;
+}
+
+extern "C" long long upp_bn_rows_part_floats(int R, int C) {
+    if (R < 1 || C < 1) return 0;
+    const int per = bn_per(R);
+    return (long long)((R + per - 1) / per) * 2 * C;
+}
+
+extern "C" int upp_bn_rows_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                               float momentum, float eps, int training, int relu, float *part, float *mean, float *rstd, float *y,
+                               int R, int C, void *stream) {
+    if (!x || !mean || !rstd || !y || R < 1 || C < 1) return UPP_E_BADARG;
+    if (training && !part) return UPP_E_BADARG;
+    if (!training && (!running_mean || !running_var)) return UPP_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int per = bn_per(R), slabs = (R + per - 1) / per;
+    if (training) {
+        const int Cp = pow2_at_least(C);
+        hipLaunchKernelGGL(bn_rows_partial_kernel, dim3(slabs, (C + 255) / 256), dim3(256), 0, st, x, R, C, Cp, per, part);
+    }
+    upp_bn_finalize_launch(part, slabs, per, R, C, training, momentum, eps, running_mean, running_var, mean, rstd, st);
+    const long long total = (long long)R * C;
+    hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y,
+                       total, C);
+    return upp_launch_status();
+}
+
+extern "C" int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, float *out, int ld_out, int col0,
+                              int B, int N, int S, int C, int k, float eps, void *stream) {
+    if (!dist || !idx || !feat || !out || B < 1 || N < 1 || S < 1 || C < 1 || k < 1 || ld_tab < k || ld_out < col0 + C || col0 < 0)
+        return UPP_E_BADARG;
+    if (k > kInterpK || k > S || C > 256) return UPP_E_RANGE;
+    const int Cp = pow2_at_least(C), RL = 256 / Cp, rows = B * N;
+    hipLaunchKernelGGL(interp_kernel, dim3((rows + RL - 1) / RL), dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S, C, Cp, k, eps,
+                       out, ld_out, col0, rows, N);
+    return upp_launch_status();
+}
+
+extern "C" int upp_posenc_fwd(const float *x, const float *freqs, int F, float *out, int ld_out, int col0, long long rows, void *stream) {
+    if (!x || !out || rows < 1 || F < 0 || (F > 0 && !freqs) || col0 < 0 || ld_out < col0 + 3 * (2 * F + 1)) return UPP_E_BADARG;
+    if (F > 8) return UPP_E_RANGE;
+    Freqs fr;
+    for (int q = 0; q < 8; ++q) fr.f[q] = q < F ? freqs[q] : 0.0f;       // freqs is a HOST array (a handful of scalars)
+    const long long total = rows * 3;
+    hipLaunchKernelGGL(posenc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, fr, F, out, ld_out, col0, total);
+    return upp_launch_status();
+}

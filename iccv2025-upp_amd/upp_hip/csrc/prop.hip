@@ -17,6 +17,9 @@
 // backward scatter-adds are done as deterministic "scan the index list for my row" gathers, no atomics.
 #include "common.h"
 
+int upp_bn_finalize_launch(const float *part, int slabs, int per, int rows, int C, int training, float momentum, float eps,
+                           float *running_mean, float *running_var, float *mean, float *rstd, hipStream_t st);   // pointwise.hip
+
 namespace {
 
 constexpr int kMaxE = 8;   // D <= 512
@@ -272,6 +275,348 @@ __global__ __launch_bounds__(256) void prop_interp_bwd_x_kernel(const float *__r
 
 inline dim3 rows_grid(long long rows) { return dim3((unsigned)((rows + 3) / 4)); }
 
+// ---------------------------------------------------------------------------------------------
+// Fused propagation step (pool -> BatchNorm1d -> interpolate) with inverted index lists.
+//
+// The index lists (i1, i2, idx8) depend only on the centres, so they are the same for every block of a forward:
+// the host inverts each list ONCE per forward into a CSR (csr_build_kernel) and the backward kernels walk
+// "the entries that reference my row" directly instead of scanning the whole list in every block.
+// BatchNorm runs inside the step: pool emits per-workgroup (sum, M2) column partials, a one-workgroup-per-64-columns
+// kernel (pointwise.hip) combines them (Chan's update, f64) into mean / rstd and updates the running statistics, and interpolate
+// normalises the pooled rows as it gathers them.  Backward mirrors it: the c2 kernel emits the column partials of
+// sum(g_lc) and sum(g_lc * xhat), a finalize kernel reduces them to g_beta / g_gamma, and ONE row kernel produces the
+// whole g_X (identity path + i2 scatter + BatchNorm-backward + pool-backward), so autograd adds nothing on top.
+
+// Stable CSR of an index list: perm[start[r] .. start[r+1]) = the positions q (ascending) whose key equals r, where
+// key(q) = (q / seg_len) * seg_rows + keys[q]  (seg_rows = 0: keys are absolute).  Keys outside [0, rows) are skipped.
+// One workgroup of 1024 threads; counts and cursors live in LDS.
+constexpr int kCsrThreads = 1024;
+__global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(const int32_t *__restrict__ keys, int n, int seg_len, int seg_rows,
+                                                                int rows, int32_t *__restrict__ start, int32_t *__restrict__ perm) {
+    extern __shared__ int32_t lds_i[];
+    int32_t *cnt = lds_i;                   // [rows]
+    int32_t *scan = lds_i + rows;           // [kCsrThreads]
+    const int tid = threadIdx.x;
+    for (int r = tid; r < rows; r += kCsrThreads) cnt[r] = 0;
+    __syncthreads();
+    auto key_of = [&](int q, int raw) { const int k = (q / seg_len) * seg_rows + raw; return (k >= 0 && k < rows) ? k : -1; };
+    for (int q0 = tid; q0 < n; q0 += kCsrThreads * 8) {          // 8 independent loads in flight per thread
+        int raw[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) raw[t] = keys[min(q0 + t * kCsrThreads, n - 1)];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int q = q0 + t * kCsrThreads;
+            const int k = q < n ? key_of(q, raw[t]) : -1;
+            if (k >= 0) atomicAdd(&cnt[k], 1);
+        }
+    }
+    __syncthreads();
+    const int per = (rows + kCsrThreads - 1) / kCsrThreads;      // thread t owns rows [t*per, (t+1)*per)
+    const int lo = min(rows, tid * per), hi = min(rows, lo + per);
+    int sum = 0;
+    for (int r = lo; r < hi; ++r) sum += cnt[r];
+    scan[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < kCsrThreads; off <<= 1) {             // inclusive Hillis-Steele scan
+        const int v = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    const int first = scan[tid] - sum;
+    {
+        int base = first;
+        for (int r = lo; r < hi; ++r) { const int c = cnt[r]; start[r] = base; cnt[r] = base; base += c; }
+    }
+    if (tid == kCsrThreads - 1) start[rows] = scan[tid];
+    __syncthreads();
+    for (int q0 = tid; q0 < n; q0 += kCsrThreads * 8) {
+        int raw[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) raw[t] = keys[min(q0 + t * kCsrThreads, n - 1)];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int q = q0 + t * kCsrThreads;
+            const int k = q < n ? key_of(q, raw[t]) : -1;
+            if (k >= 0) perm[atomicAdd(&cnt[k], 1)] = q;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    {   // the atomics filled each segment in arbitrary order: insertion-sort it (segments are short) -> stable CSR
+        int base = first;
+        for (int r = lo; r < hi; ++r) {
+            const int end = cnt[r];
+            for (int a = base + 1; a < end; ++a) {
+                const int v = perm[a];
+                int bpos = a - 1;
+                while (bpos >= base && perm[bpos] > v) { perm[bpos + 1] = perm[bpos]; --bpos; }
+                perm[bpos + 1] = v;
+            }
+            base = end;
+        }
+    }
+}
+
+// pool forward + BatchNorm column partials.  part[(wg*2+0)*D + c] = sum of the workgroup's (<= 4) pooled values of
+// column c, part[(wg*2+1)*D + c] = their M2 about the workgroup mean.
+__global__ __launch_bounds__(256) void prop_pool_stats_kernel(const float *__restrict__ X, const int32_t *__restrict__ i1,
+                                                              const float *__restrict__ u, float keep, float *__restrict__ pooled,
+                                                              uint8_t *__restrict__ amax, float *__restrict__ part, int groups, int D) {
+    __shared__ float sh[4][64 * kMaxE];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * 4 + wave;
+    if (g < groups) {
+        const float f = 1.0f + (u ? floorf(keep + u[g]) / keep : 1.0f);
+        int rows8[kNb];
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) rows8[k] = i1[g * kNb + k];
+        float val[kNb][kMaxE];
+#pragma unroll
+        for (int k = 0; k < kNb; ++k)
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) val[k][e] = X[(size_t)rows8[k] * D + min(lane + 64 * e, D - 1)];
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) {
+            float mx = -__builtin_inff(), sm = 0.0f;
+            int am = 0;
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) {
+                const float v = val[k][e] * f;
+                if (v > mx) { mx = v; am = k; }
+                sm += v;
+            }
+            const int c = lane + 64 * e;
+            const float pv = mx + sm * 0.125f;
+            if (c < D) { pooled[(size_t)g * D + c] = pv; amax[(size_t)g * D + c] = (uint8_t)am; sh[wave][c] = pv; }
+        }
+    }
+    __syncthreads();
+    const int nw = min(4, groups - (int)blockIdx.x * 4);
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float sum = 0.0f;
+        for (int w = 0; w < nw; ++w) sum += sh[w][c];
+        const float mean = sum / (float)nw;
+        float m2 = 0.0f;
+        for (int w = 0; w < nw; ++w) { const float dv = sh[w][c] - mean; m2 = __builtin_fmaf(dv, dv, m2); }
+        part[((size_t)blockIdx.x * 2 + 0) * D + c] = sum;
+        part[((size_t)blockIdx.x * 2 + 1) * D + c] = m2;
+    }
+}
+
+// interpolate forward reading the PRE-BatchNorm pooled rows: lc = ((pooled - mean) * rstd) * gamma + beta on the fly
+__global__ __launch_bounds__(256) void prop_interp_bn_fwd_kernel(const float *__restrict__ X, const float *__restrict__ pooled,
+                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                 const int32_t *__restrict__ i2, const int32_t *__restrict__ idx8,
+                                                                 const float *__restrict__ w8, float *__restrict__ out, int B, int Lp,
+                                                                 int T, int G2, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (r >= B * Lp) return;
+    const int b = r / Lp, t = r - b * Lp;
+    const int i = t - (Lp - T);
+    int cc[kMaxE];
+    float xv[kMaxE], acc[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { cc[e] = min(lane + 64 * e, D - 1); xv[e] = X[(size_t)r * D + cc[e]]; acc[e] = 0.0f; }
+    if (i >= 0) {
+        int j[kNb], cr[kNb];
+        float w[kNb];
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) { j[k] = idx8[((size_t)b * T + i) * kNb + k]; w[k] = w8[((size_t)b * T + i) * kNb + k]; }
+        float mu[kMaxE], rs[kMaxE], ga[kMaxE], be[kMaxE];
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) { mu[e] = mean[cc[e]]; rs[e] = rstd[cc[e]]; ga[e] = gamma[cc[e]]; be[e] = beta[cc[e]]; }
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) cr[k] = i2[b * G2 + j[k]];
+#pragma unroll
+        for (int h = 0; h < kMaxE; h += 4) {
+            float lv[4][kNb], cv[4][kNb];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < kNb; ++k) { lv[e][k] = pooled[((size_t)b * G2 + j[k]) * D + cc[h + e]]; cv[e][k] = X[(size_t)cr[k] * D + cc[h + e]]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < kNb; ++k) {
+                    const float lcv = ((lv[e][k] - mu[h + e]) * rs[h + e]) * ga[h + e] + be[h + e];
+                    acc[h + e] += (lcv + 0.3f * cv[e][k]) * w[k];
+                }
+            if (64 * (h + 4) >= D) break;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int c = lane + 64 * e;
+        if (c < D) out[(size_t)r * D + c] = xv[e] + (i >= 0 ? 0.3f * acc[e] : 0.0f);
+    }
+}
+
+// g_c2[gj] = 0.3 * sum over the CSR entries q of row gj of w8[q] * g_out[token row of q]; plus the BatchNorm-backward
+// column partials of the workgroup's 4 rows: part[(wg*2+0)*D+c] = sum g_c2, part[(wg*2+1)*D+c] = sum g_c2 * xhat.
+__global__ __launch_bounds__(256) void prop_c2_csr_kernel(const float *__restrict__ g_out, const int32_t *__restrict__ start8,
+                                                          const int32_t *__restrict__ perm8, const float *__restrict__ w8,
+                                                          const float *__restrict__ pooled, const float *__restrict__ mean,
+                                                          const float *__restrict__ rstd, float *__restrict__ g_c2,
+                                                          float *__restrict__ part, int B, int Lp, int T, int G2, int D) {
+    __shared__ float sh[2][4][64 * kMaxE];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gj = blockIdx.x * 4 + wave;
+    const int groups = B * G2;
+    if (gj < groups) {
+        int cc[kMaxE];
+        float acc[kMaxE], pv[kMaxE], mu[kMaxE], rs[kMaxE];
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) {
+            cc[e] = min(lane + 64 * e, D - 1); acc[e] = 0.0f;
+            pv[e] = pooled[(size_t)gj * D + cc[e]]; mu[e] = mean[cc[e]]; rs[e] = rstd[cc[e]];
+        }
+        const int s = start8[gj], eend = start8[gj + 1];
+        for (int h0 = s; h0 < eend; h0 += 8) {                // 8 token rows x kMaxE column slots in flight
+            int q[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) q[t] = perm8[min(h0 + t, eend - 1)];
+            float w[8];
+            const float *grow[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int tok = q[t] / kNb;                   // b * T + i
+                const int bb = tok / T, ii = tok - bb * T;
+                w[t] = w8[q[t]];
+                grow[t] = g_out + ((size_t)bb * Lp + (Lp - T) + ii) * D;
+            }
+            float gv[kMaxE][8];
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) gv[e][t] = grow[t][cc[e]];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float wt = h0 + t < eend ? w[t] : 0.0f;
+#pragma unroll
+                for (int e = 0; e < kMaxE; ++e) acc[e] += gv[e][t] * wt;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) {
+            const int c = lane + 64 * e;
+            if (c < D) {
+                const float gl = 0.3f * acc[e];
+                g_c2[(size_t)gj * D + c] = gl;
+                sh[0][wave][c] = gl;
+                sh[1][wave][c] = gl * ((pv[e] - mu[e]) * rs[e]);
+            }
+        }
+    }
+    __syncthreads();
+    const int nw = min(4, groups - (int)blockIdx.x * 4);
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float s0 = 0.0f, s1 = 0.0f;
+        for (int w = 0; w < nw; ++w) { s0 += sh[0][w][c]; s1 += sh[1][w][c]; }
+        part[((size_t)blockIdx.x * 2 + 0) * D + c] = s0;
+        part[((size_t)blockIdx.x * 2 + 1) * D + c] = s1;
+    }
+}
+
+// g_beta[c] = sum of the "sum g_lc" partials, g_gamma[c] = sum of the "sum g_lc * xhat" partials (fixed order)
+__global__ __launch_bounds__(256) void prop_bn_grad_kernel(const float *__restrict__ part, int wgs, int D, float *__restrict__ g_gamma,
+                                                           float *__restrict__ g_beta) {
+    __shared__ float sb[4][64], sg[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int cc = min(c, D - 1);
+    float ab = 0.0f, ag = 0.0f;
+    for (int w0 = wave; w0 < wgs; w0 += 4 * 8) {
+        float pb[8], pg[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int w = min(w0 + 4 * t, wgs - 1);
+            pb[t] = part[((size_t)w * 2 + 0) * D + cc]; pg[t] = part[((size_t)w * 2 + 1) * D + cc];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) if (w0 + 4 * t < wgs) { ab += pb[t]; ag += pg[t]; }
+    }
+    sb[wave][lane] = ab; sg[wave][lane] = ag;
+    __syncthreads();
+    if (wave == 0 && c < D) {
+        g_beta[c] = (sb[0][lane] + sb[1][lane]) + (sb[2][lane] + sb[3][lane]);
+        g_gamma[c] = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
+    }
+}
+
+// The whole g_X of the step, one wavefront per row r of X:
+//   g_X[r] = g_out[r] + 0.3 * sum_{m: i2[m] == r} g_c2[m]
+//          + sum_{(g,k): i1[g][k] == r} (1 + s_g) * g_pooled[g] * (1/8 + [amax[g] == k])
+//   g_pooled[g] = gamma * rstd * (g_c2[g] - g_beta/n - xhat[g] * g_gamma/n)      (training; eval: gamma * rstd * g_c2[g])
+__global__ __launch_bounds__(256) void prop_x_csr_kernel(const float *__restrict__ g_out, const float *__restrict__ g_c2,
+                                                         const float *__restrict__ pooled, const uint8_t *__restrict__ amax,
+                                                         const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                         const float *__restrict__ gamma, const float *__restrict__ g_gamma,
+                                                         const float *__restrict__ g_beta, const float *__restrict__ u, float keep,
+                                                         const int32_t *__restrict__ start1, const int32_t *__restrict__ perm1,
+                                                         const int32_t *__restrict__ start2, const int32_t *__restrict__ perm2,
+                                                         float *__restrict__ g_X, int rows, int groups, int D, int training) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int s1 = start1[r], e1 = start1[r + 1], s2 = start2[r], e2 = start2[r + 1];
+    int cc[kMaxE];
+    float acc[kMaxE], mu[kMaxE], rs[kMaxE], ga[kMaxE], c1[kMaxE], c2[kMaxE];
+    const float inv_n = 1.0f / (float)groups;
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        cc[e] = min(lane + 64 * e, D - 1);
+        acc[e] = g_out[(size_t)r * D + cc[e]];
+        mu[e] = mean[cc[e]]; rs[e] = rstd[cc[e]]; ga[e] = gamma[cc[e]];
+        c1[e] = 0.0f; c2[e] = 0.0f;
+    }
+    if (training) {                                            // one uniform branch around the whole batch of loads
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) { c1[e] = g_beta[cc[e]]; c2[e] = g_gamma[cc[e]]; }
+    }
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { c1[e] *= inv_n; c2[e] *= inv_n; }
+    for (int h0 = s2; h0 < e2; h0 += 2) {                     // level-2 centres whose own token is this row (usually <= 1)
+        const int m0 = perm2[h0], m1 = perm2[min(h0 + 1, e2 - 1)];
+        float a0[kMaxE], a1[kMaxE];
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) { a0[e] = g_c2[(size_t)m0 * D + cc[e]]; a1[e] = g_c2[(size_t)m1 * D + cc[e]]; }
+        const float f1 = h0 + 1 < e2 ? 0.3f : 0.0f;
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) { acc[e] += 0.3f * a0[e]; acc[e] += f1 * a1[e]; }
+    }
+    for (int h0 = s1; h0 < e1; h0 += 4) {                     // groups that list this row as a neighbour
+        int g[4], k[4];
+        float f[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int q = perm1[min(h0 + t, e1 - 1)]; g[t] = q / kNb; k[t] = q - g[t] * kNb; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f[t] = h0 + t < e1 ? 1.0f + (u ? floorf(keep + u[g[t]]) / keep : 1.0f) : 0.0f;
+        float gl[kMaxE][4], pv[kMaxE][4];
+        int am[kMaxE][4];
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const size_t o = (size_t)g[t] * D + cc[e];
+                gl[e][t] = g_c2[o]; pv[e][t] = pooled[o]; am[e][t] = amax[o];
+            }
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float xh = (pv[e][t] - mu[e]) * rs[e];
+                const float gp = (ga[e] * rs[e]) * (gl[e][t] - c1[e] - xh * c2[e]);
+                acc[e] += gp * f[t] * (0.125f + (am[e][t] == k[t] ? 1.0f : 0.0f));
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) g_X[(size_t)r * D + c] = acc[e]; }
+}
+
 }  // namespace
 
 extern "C" int upp_prop_pool_fwd(const float *X, const int32_t *i1, const float *u, float keep, float *pooled, uint8_t *amax,
@@ -309,5 +654,56 @@ extern "C" int upp_prop_interp_bwd(const float *g_out, const int32_t *i2, const 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(prop_interp_bwd_c2_kernel, rows_grid((long long)B * G2), dim3(256), lds, st, g_out, idx8, w8, g_c2, B, Lp, T, G2, D);
     hipLaunchKernelGGL(prop_interp_bwd_x_kernel, rows_grid((long long)B * Lp), dim3(256), 0, st, g_out, g_c2, i2, g_X, B * Lp, B * G2, D);
+    return upp_launch_status();
+}
+
+extern "C" int upp_csr_build(const int32_t *keys, int n, int seg_len, int seg_rows, int rows, int32_t *start, int32_t *perm,
+                             void *stream) {
+    if (!keys || !start || !perm || n < 1 || rows < 1 || seg_len < 1 || seg_rows < 0) return UPP_E_BADARG;
+    const size_t lds = ((size_t)rows + kCsrThreads) * sizeof(int32_t);
+    if (lds > 64 * 1024) return UPP_E_RANGE;    // counts of every row live in LDS (rows <= 15360)
+    hipLaunchKernelGGL(csr_build_kernel, dim3(1), dim3(kCsrThreads), lds, (hipStream_t)stream, keys, n, seg_len, seg_rows, rows, start, perm);
+    return upp_launch_status();
+}
+
+extern "C" long long upp_prop_part_floats(int groups, int D) {
+    if (groups < 1 || D < 1) return 0;
+    return (long long)((groups + 3) / 4) * 2 * D;
+}
+
+extern "C" int upp_prop_fwd(const float *X, const int32_t *i1, const float *u, float keep, const int32_t *i2, const int32_t *idx8,
+                            const float *w8, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                            float momentum, float eps, int training, float *pooled, uint8_t *amax, float *part, float *mean,
+                            float *rstd, float *out, int B, int Lp, int T, int G2, int D, void *stream) {
+    if (!X || !i1 || !i2 || !idx8 || !w8 || !gamma || !beta || !pooled || !amax || !part || !mean || !rstd || !out) return UPP_E_BADARG;
+    if (B < 1 || Lp < T || T < 1 || G2 < 1 || D < 1) return UPP_E_BADARG;
+    if (!training && (!running_mean || !running_var)) return UPP_E_BADARG;
+    if (D > 64 * kMaxE) return UPP_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = B * G2, wgs = (groups + 3) / 4;
+    hipLaunchKernelGGL(prop_pool_stats_kernel, dim3(wgs), dim3(256), 0, st, X, i1, u, keep, pooled, amax, part, groups, D);
+    upp_bn_finalize_launch(part, wgs, 4, groups, D, training, momentum, eps, running_mean, running_var, mean, rstd, st);
+    hipLaunchKernelGGL(prop_interp_bn_fwd_kernel, rows_grid((long long)B * Lp), dim3(256), 0, st, X, pooled, mean, rstd, gamma, beta, i2,
+                       idx8, w8, out, B, Lp, T, G2, D);
+    return upp_launch_status();
+}
+
+extern "C" int upp_prop_bwd(const float *g_out, const float *pooled, const uint8_t *amax, const float *mean, const float *rstd,
+                            const float *gamma, const float *u, float keep, const float *w8, const int32_t *start1,
+                            const int32_t *perm1, const int32_t *start2, const int32_t *perm2, const int32_t *start8,
+                            const int32_t *perm8, int training, float *g_c2, float *part, float *g_gamma, float *g_beta, float *g_X,
+                            int B, int Lp, int T, int G2, int D, void *stream) {
+    if (!g_out || !pooled || !amax || !mean || !rstd || !gamma || !w8 || !start1 || !perm1 || !start2 || !perm2 || !start8 || !perm8 ||
+        !g_c2 || !part || !g_gamma || !g_beta || !g_X)
+        return UPP_E_BADARG;
+    if (B < 1 || Lp < T || T < 1 || G2 < 1 || D < 1) return UPP_E_BADARG;
+    if (D > 64 * kMaxE) return UPP_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = B * G2, wgs = (groups + 3) / 4;
+    hipLaunchKernelGGL(prop_c2_csr_kernel, dim3(wgs), dim3(256), 0, st, g_out, start8, perm8, w8, pooled, mean, rstd, g_c2, part, B, Lp, T,
+                       G2, D);
+    hipLaunchKernelGGL(prop_bn_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, st, part, wgs, D, g_gamma, g_beta);
+    hipLaunchKernelGGL(prop_x_csr_kernel, rows_grid((long long)B * Lp), dim3(256), 0, st, g_out, g_c2, pooled, amax, mean, rstd, gamma,
+                       g_gamma, g_beta, u, keep, start1, perm1, start2, perm2, g_X, B * Lp, groups, D, training);
     return upp_launch_status();
 }

@@ -274,6 +274,68 @@ def prop_interp(X, lc, i2, idx8, w8):
     return _PropInterp.apply(X, lc, i2, idx8, w8)
 
 
+class PropIndex:
+    """Index lists of the propagation step for one forward (they depend only on the centres): absolute neighbour rows
+    i1 (groups*8), level-2 centre rows i2 (groups), interpolation neighbours idx8 / weights w8 (B,T,8), and their inverses
+    (CSR) for the backward kernels.  Built once per forward and shared by every block."""
+
+    def __init__(self, i1, i2, idx8, w8, rows):
+        B, T = idx8.shape[0], idx8.shape[1]
+        groups = i2.numel()
+        self.i1, self.i2, self.idx8, self.w8 = i1, i2, idx8, w8
+        self.B, self.T, self.G2, self.rows = B, T, groups // B, rows
+        self.csr1 = ops.csr_build(i1, rows)
+        self.csr2 = ops.csr_build(i2, rows)
+        self.csr8 = ops.csr_build(idx8.view(-1), groups, seg_len=T * 8, seg_rows=groups // B)
+
+
+class _Propagate(Function):
+    """Fused pool -> BatchNorm1d -> interpolate of one block (upp_prop_fwd / upp_prop_bwd)."""
+
+    @staticmethod
+    def forward(ctx, X, gamma, beta, index, u, keep, running_mean, running_var, momentum, eps, training):
+        X = X.contiguous()
+        B, Lp, D = X.shape
+        out, pooled, amax, mean, rstd = ops.prop_fwd(X, index.i1, u, keep, index.i2, index.idx8, index.w8, gamma, beta, running_mean,
+                                                     running_var, momentum, eps, training, B, Lp, index.T, index.G2)
+        ctx.save_for_backward(pooled, amax, mean, rstd, gamma, u)
+        ctx.meta = (index, keep, training, B, Lp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pooled, amax, mean, rstd, gamma, u = ctx.saved_tensors
+        index, keep, training, B, Lp = ctx.meta
+        g_X, g_gamma, g_beta = ops.prop_bwd(g.contiguous(), pooled, amax, mean, rstd, gamma, u, keep, index.w8, index.csr1, index.csr2,
+                                            index.csr8, training, B, Lp, index.T, index.G2)
+        return (g_X, g_gamma, g_beta) + (None,) * 8
+
+
+def propagate(X, bn, index, u=None, keep=1.0, training=True):
+    """X (B,L',D) -> X with its last T rows += 0.3 * interp(bn(pool(X)) + 0.3 * X[i2]); bn: nn.BatchNorm1d (affine)."""
+    use_batch = training or bn.running_mean is None
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    return _Propagate.apply(X, bn.weight, bn.bias, index, u, float(keep), bn.running_mean, bn.running_var, momentum, bn.eps, use_batch)
+
+
+# ------------------------------------------------------------------ forward-only row operators (frozen prompter branches)
+def bn_rows(x, bn, training, relu=False):
+    """BatchNorm(+ReLU) over the rows of a channels-last (R,C) matrix; no autograd (frozen branches only)."""
+    use_batch = training or bn.running_mean is None
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    return ops.bn_rows_fwd(x.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, use_batch, relu)
+
+
+def interp(dists, idx, feat, k, eps, out=None, col0=0):
+    """Inverse-distance interpolation from the k nearest of a sorted neighbour table; no autograd."""
+    return ops.interp_fwd(dists, idx, feat.contiguous(), k, eps, out, col0)
+
+
+def posenc(x, freqs, out=None, col0=0):
+    """(x, sin(f x), cos(f x))_f positional embedding of (...,3) coordinates; no autograd."""
+    return ops.posenc_fwd(x.contiguous(), freqs, out, col0)
+
+
 # ------------------------------------------------------------------ bottleneck adapter
 class _Adapter(Function):
     """out = x + scale * (W2 . dropout(gelu(W1 . ha + b1)) + b2); see upp_adapter_fwd."""

@@ -300,6 +300,94 @@ def prop_interp_bwd(g_out, i2, idx8, w8, B, Lp, T, G2):
     return g_c2, g_X
 
 
+def csr_build(keys, rows, seg_len=None, seg_rows=0):
+    """Stable inverse of an int32 index list -> (start (rows+1), perm (n)); see upp_csr_build."""
+    _need(keys, "keys", torch.int32)
+    n = keys.numel()
+    start = torch.empty(rows + 1, dtype=torch.int32, device=keys.device)
+    perm = torch.empty(n, dtype=torch.int32, device=keys.device)
+    _call(keys.device, "upp_csr_build", _abi.ptr(keys), n, int(seg_len or n), int(seg_rows), int(rows), _abi.ptr(start), _abi.ptr(perm))
+    return start, perm
+
+
+def prop_fwd(X, i1, u, keep, i2, idx8, w8, gamma, beta, running_mean, running_var, momentum, eps, training, B, Lp, T, G2):
+    D = X.shape[-1]
+    groups = B * G2
+    dev = X.device
+    pooled = torch.empty((groups, D), dtype=torch.float32, device=dev)
+    amax = torch.empty((groups, D), dtype=torch.uint8, device=dev)
+    part = torch.empty(_abi.load().upp_prop_part_floats(groups, D), dtype=torch.float32, device=dev)
+    mean = torch.empty(D, dtype=torch.float32, device=dev)
+    rstd = torch.empty(D, dtype=torch.float32, device=dev)
+    out = torch.empty_like(X)
+    _call(dev, "upp_prop_fwd", _abi.ptr(X), _abi.ptr(i1), _abi.ptr(u), float(keep), _abi.ptr(i2), _abi.ptr(idx8), _abi.ptr(w8),
+          _abi.ptr(gamma), _abi.ptr(beta), _abi.ptr(running_mean), _abi.ptr(running_var), float(momentum), float(eps), int(bool(training)),
+          _abi.ptr(pooled), _abi.ptr(amax), _abi.ptr(part), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(out), B, Lp, T, G2, D)
+    return out, pooled, amax, mean, rstd
+
+
+def prop_bwd(g_out, pooled, amax, mean, rstd, gamma, u, keep, w8, csr1, csr2, csr8, training, B, Lp, T, G2):
+    D = g_out.shape[-1]
+    groups = B * G2
+    dev = g_out.device
+    g_c2 = torch.empty((groups, D), dtype=torch.float32, device=dev)
+    part = torch.empty(_abi.load().upp_prop_part_floats(groups, D), dtype=torch.float32, device=dev)
+    g_gamma = torch.empty(D, dtype=torch.float32, device=dev)
+    g_beta = torch.empty(D, dtype=torch.float32, device=dev)
+    g_X = torch.empty_like(g_out)
+    _call(dev, "upp_prop_bwd", _abi.ptr(g_out), _abi.ptr(pooled), _abi.ptr(amax), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma), _abi.ptr(u),
+          float(keep), _abi.ptr(w8), _abi.ptr(csr1[0]), _abi.ptr(csr1[1]), _abi.ptr(csr2[0]), _abi.ptr(csr2[1]), _abi.ptr(csr8[0]),
+          _abi.ptr(csr8[1]), int(bool(training)), _abi.ptr(g_c2), _abi.ptr(part), _abi.ptr(g_gamma), _abi.ptr(g_beta), _abi.ptr(g_X),
+          B, Lp, T, G2, D)
+    return g_X, g_gamma, g_beta
+
+
+# ------------------------------------------------------------------ row operators of the frozen prompter branches
+def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
+    _need(x, "x", torch.float32, ndim=2)
+    R, C = x.shape
+    dev = x.device
+    part = torch.empty(_abi.load().upp_bn_rows_part_floats(R, C), dtype=torch.float32, device=dev) if training else None
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    rstd = torch.empty(C, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    _call(dev, "upp_bn_rows_fwd", _abi.ptr(x), _abi.ptr(gamma), _abi.ptr(beta), _abi.ptr(running_mean), _abi.ptr(running_var),
+          float(momentum), float(eps), int(bool(training)), int(bool(relu)), _abi.ptr(part), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(y), R, C)
+    return y
+
+
+def interp_fwd(dist, idx, feat, k, eps, out=None, col0=0):
+    """dist / idx: (B,N,S') views whose last dim is contiguous (a sorted neighbour table); feat (B,S,C)."""
+    _need(feat, "feat", torch.float32, ndim=3)
+    B, S, C = feat.shape
+    N = dist.shape[1]
+    for t, name, dt in ((dist, "dist", torch.float32), (idx, "idx", torch.int64)):
+        if not t.is_cuda or t.dtype != dt or t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != N * t.stride(1):
+            raise RuntimeError(f"{name} must be a HIP {dt} (B,N,S') table with contiguous rows")
+    if dist.stride(1) != idx.stride(1) or dist.shape[:2] != idx.shape[:2] or dist.shape[0] != B:
+        raise RuntimeError("dist / idx must share shape and row stride")
+    if out is None:
+        out = torch.empty((B, N, C), dtype=torch.float32, device=feat.device)
+    _need(out, "out", torch.float32, ndim=3)
+    _call(feat.device, "upp_interp_fwd", _abi.ptr(dist), _abi.ptr(idx), dist.stride(1), _abi.ptr(feat), _abi.ptr(out), out.shape[-1], int(col0),
+          B, N, S, C, int(k), float(eps))
+    return out
+
+
+def posenc_fwd(x, freqs, out=None, col0=0):
+    _need(x, "x", torch.float32, last=3)
+    F = len(freqs)
+    rows = x.numel() // 3
+    width = 3 * (2 * F + 1)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (width,), dtype=torch.float32, device=x.device)
+    _need(out, "out", torch.float32)
+    import ctypes
+    arr = (ctypes.c_float * max(F, 1))(*[float(f) for f in freqs])
+    _call(x.device, "upp_posenc_fwd", _abi.ptr(x), arr, F, _abi.ptr(out), out.shape[-1], int(col0), rows)
+    return out
+
+
 # ------------------------------------------------------------------ optimizer tail
 def adamw_flat(p, g, m, v, n, split, state, scratch, lr, beta1, beta2, eps, weight_decay, max_norm):
     for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (state, "state"), (scratch, "scratch")):

@@ -211,6 +211,54 @@ int upp_prop_interp_fwd(const float *X, const float *lc, const int32_t *i2, cons
 int upp_prop_interp_bwd(const float *g_out, const int32_t *i2, const int32_t *idx8, const float *w8, float *g_c2,
                         float *g_X, int B, int Lp, int T, int G2, int D, void *stream);
 
+/* ---- fused propagation step: pool -> BatchNorm1d(bnorm) -> interpolate, CSR-driven backward ----
+ * Same mathematics as upp_prop_pool_fwd -> BatchNorm1d over the B*G2 pooled rows (Block.bnorm, reference
+ * models/Point_MAE_pretask_dev.py:275-303 + SURVEY D.3) -> upp_prop_interp_fwd, as 3 launches forward and 3 backward.
+ *   upp_csr_build : stable inverse of an index list.  key(q) = (q / seg_len) * seg_rows + keys[q] (seg_rows = 0: absolute
+ *                   keys); start (rows+1), perm (n): perm[start[r] .. start[r+1]) = ascending positions q with key(q) == r.
+ *                   Keys outside [0, rows) are skipped.  rows <= 15360.  The three lists of a forward are inverted once:
+ *                   csr1 = (i1; n = groups*8; rows = B*L'), csr2 = (i2; n = groups; rows = B*L'),
+ *                   csr8 = (idx8; n = B*T*8, seg_len = T*8, seg_rows = G2; rows = groups).
+ *   upp_prop_fwd  : pooled (groups, D) pre-BatchNorm rows, amax (groups, D) uint8, mean / rstd (D) batch statistics (training)
+ *                   or running statistics (training == 0), out (B*L', D).  training != 0 updates running_mean / running_var
+ *                   (momentum; unbiased variance) when they are non-NULL.  part: upp_prop_part_floats(groups, D) floats.
+ *   upp_prop_bwd  : g_X (B*L', D) complete input gradient (identity + i2 scatter + BatchNorm/pool backward), g_gamma / g_beta (D)
+ *                   BatchNorm parameter gradients; g_c2 (groups, D) and part are scratch.
+ * Column partials are combined in a fixed order (Chan's update in f64 for the variance): deterministic. */
+int upp_csr_build(const int32_t *keys, int n, int seg_len, int seg_rows, int rows, int32_t *start, int32_t *perm, void *stream);
+long long upp_prop_part_floats(int groups, int D);
+int upp_prop_fwd(const float *X, const int32_t *i1, const float *u, float keep, const int32_t *i2, const int32_t *idx8,
+                 const float *w8, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                 float momentum, float eps, int training, float *pooled, uint8_t *amax, float *part, float *mean,
+                 float *rstd, float *out, int B, int Lp, int T, int G2, int D, void *stream);
+int upp_prop_bwd(const float *g_out, const float *pooled, const uint8_t *amax, const float *mean, const float *rstd,
+                 const float *gamma, const float *u, float keep, const float *w8, const int32_t *start1,
+                 const int32_t *perm1, const int32_t *start2, const int32_t *perm2, const int32_t *start8,
+                 const int32_t *perm8, int training, float *g_c2, float *part, float *g_gamma, float *g_beta, float *g_X,
+                 int B, int Lp, int T, int G2, int D, void *stream);
+
+/* ---- row operators of the frozen prompter branches (forward only) ---------------------------------
+ * Replace the element-wise / reduction chains of the reference's rectify prompter
+ * (models/Point_MAE_pretask_dev.py:22-52 PositionalEmbedding, :386-473 set abstraction / feature propagation):
+ *   upp_bn_rows_fwd : y (R,C) = BatchNorm over the R rows of the channels-last matrix x (== BatchNorm1d/2d on the
+ *                     reference's (B,C,N[,k]) layout), optional ReLU.  training != 0: batch statistics, running
+ *                     statistics updated (momentum, unbiased variance) when non-NULL; training == 0: running
+ *                     statistics.  gamma / beta may be NULL (1 / 0).  mean, rstd (C) are outputs; part:
+ *                     upp_bn_rows_part_floats(R, C) floats of scratch.  Deterministic (fixed combination order).
+ *   upp_interp_fwd  : out[b*N+n][col0 .. col0+C) = sum_{j<k} w_j feat[b][idx[b,n,j]],  w_j = (1/(d_j+eps)) / sum_j(1/(d_j+eps)),
+ *                     where (dist, idx) (B*N rows, row stride ld_tab, idx int64) is a neighbour table sorted by distance
+ *                     (torch.sort of square_distance, as the reference computes it); feat (B,S,C); k <= 16, C <= 256.
+ *   upp_posenc_fwd  : out[row][col0 ..) = (x, sin(f_0 x), cos(f_0 x), ..., sin(f_{F-1} x), cos(f_{F-1} x)), x (rows,3);
+ *                     freqs is a HOST array of F <= 8 frequencies.
+ * interp / posenc write a column window of a row-major buffer with row stride ld_out (the reference's torch.cat). */
+long long upp_bn_rows_part_floats(int R, int C);
+int upp_bn_rows_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                    float momentum, float eps, int training, int relu, float *part, float *mean, float *rstd, float *y,
+                    int R, int C, void *stream);
+int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, float *out, int ld_out, int col0,
+                   int B, int N, int S, int C, int k, float eps, void *stream);
+int upp_posenc_fwd(const float *x, const float *freqs, int F, float *out, int ld_out, int col0, long long rows, void *stream);
+
 /* ---- training step tail: gradient clipping + AdamW on flat buffers ------------------------
  * Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.AdamW.step() of the reference loop
  * (tools/runner_module.py:202-207; parameter groups of tools/builder.py:40-55) for parameters that live in one

@@ -219,3 +219,79 @@ def test_adapter_kernel_forward_backward(R, p):
     close(out, ref, rtol=1e-5, atol_scale=2e-6)
     for g, r in zip(grads, rgrads):
         close(g, r, rtol=5e-5, atol_scale=1e-5)
+
+
+# ------------------------------------------------------------------ fused propagation step (CSR + in-kernel BatchNorm)
+@pytest.mark.parametrize("n,rows,seg", [(8192, 2400, None), (1024, 2400, None), (16384, 1024, (512, 32)), (5, 3, None), (4096, 15360, None)])
+def test_csr_build_is_the_stable_inverse(n, rows, seg):
+    from upp_hip import ops
+    rng = np.random.default_rng(n + rows)
+    if seg is None:
+        keys = rng.integers(0, rows, n).astype(np.int32)
+        keys[rng.integers(0, n, max(1, n // 50))] = rows + 7          # out-of-range keys are skipped
+        keys[0] = -1
+        absolute = keys.astype(np.int64)
+        start, perm = ops.csr_build(torch.from_numpy(keys).cuda(), rows)
+    else:
+        seg_len, seg_rows = seg
+        keys = rng.integers(0, seg_rows, n).astype(np.int32)
+        absolute = (np.arange(n) // seg_len) * seg_rows + keys
+        start, perm = ops.csr_build(torch.from_numpy(keys).cuda(), rows, seg_len=seg_len, seg_rows=seg_rows)
+    valid = np.nonzero((absolute >= 0) & (absolute < rows))[0]
+    order = valid[np.argsort(absolute[valid], kind='stable')]
+    counts = np.bincount(absolute[valid], minlength=rows)
+    want_start = np.concatenate([[0], np.cumsum(counts)])
+    assert np.array_equal(start.cpu().numpy(), want_start)
+    assert np.array_equal(perm.cpu().numpy()[:len(order)], order)
+
+
+@pytest.mark.parametrize("training,drop", [(True, 0.1), (True, 0.0), (False, 0.0)])
+@pytest.mark.parametrize("B,Lp,off", [(32, 75, 1), (3, 74, 0)])
+def test_fused_propagation_matches_pool_batchnorm_interp(B, Lp, off, training, drop):
+    torch.manual_seed(B + Lp)
+    T, G2, D = 64, 32, 384
+    dev = 'cuda'
+    X = torch.randn(B, Lp, D, device=dev) * 0.7 + 0.3
+    rows = B * Lp
+    base = (torch.arange(B, device=dev) * Lp + off + (Lp - off - T)).view(B, 1)
+    i1 = (base + torch.randint(0, T, (B, G2 * 8), device=dev)).reshape(-1).int().contiguous()
+    i2 = (base + torch.stack([torch.randperm(T, device=dev)[:G2] for _ in range(B)])).reshape(-1).int().contiguous()
+    i1[:16] = i1[0]                                                   # a heavily referenced row
+    idx8 = torch.randint(0, G2, (B, T, 8), device=dev).int().contiguous()
+    w8 = torch.rand(B, T, 8, device=dev)
+    w8 = (w8 / w8.sum(-1, keepdim=True)).contiguous()
+    u = torch.rand(B * G2, device=dev) if drop > 0 else None
+    keep = 1.0 - drop
+    index = HF.PropIndex(i1, i2, idx8, w8, rows)
+    wgt = torch.linspace(-1, 1, X.numel(), device=dev).view_as(X)
+    results = []
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm1d(D).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, D)); bn.bias.copy_(torch.linspace(-0.2, 0.2, D))
+            bn.running_mean.copy_(torch.linspace(-0.1, 0.4, D)); bn.running_var.copy_(torch.linspace(0.6, 1.7, D))
+        xi = X.clone().requires_grad_(True)
+        if fused:
+            out = HF.propagate(xi, bn, index, u, keep, training)
+        else:
+            pooled = HF.prop_pool(xi, i1, u, keep)
+            lc = F.batch_norm(pooled, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
+            out = HF.prop_interp(xi, lc.view(B, G2, D), i2, idx8, w8)
+        grads = torch.autograd.grad((out * wgt).sum(), [xi, bn.weight, bn.bias])
+        results.append((out.detach(), grads, bn.running_mean.clone(), bn.running_var.clone()))
+    (o1, g1, rm1, rv1), (o2, g2, rm2, rv2) = results
+    close(o1, o2, rtol=1e-5, atol_scale=3e-6)
+    close(rm1, rm2, rtol=1e-5, atol_scale=1e-6)
+    close(rv1, rv2, rtol=1e-5, atol_scale=1e-6)
+    for a, b in zip(g1, g2):
+        close(a, b, rtol=3e-5, atol_scale=1e-5)
+    # deterministic: a second fused run is bit-identical
+    bn = torch.nn.BatchNorm1d(D).to(dev)
+    xi = X.clone().requires_grad_(True)
+    a = HF.propagate(xi, bn, index, u, keep, training)
+    ga = torch.autograd.grad((a * wgt).sum(), [xi])[0]
+    bn = torch.nn.BatchNorm1d(D).to(dev)
+    xj = X.clone().requires_grad_(True)
+    b = HF.propagate(xj, bn, index, u, keep, training)
+    gb = torch.autograd.grad((b * wgt).sum(), [xj])[0]
+    assert torch.equal(a, b) and torch.equal(ga, gb)

@@ -1,0 +1,113 @@
+"""Row operators of the frozen prompter branches (csrc/pointwise.hip) against the torch ops they replace."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from models import upp_layers
+from upp_hip import functional as HF
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-5, atol_scale=2e-6):
+    a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_scale * max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("R,C", [(35072, 32), (35072, 64), (16384, 12), (1024, 64), (32, 256), (7, 3), (2400, 384), (1000, 300), (5, 512)])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_rows_matches_torch_batch_norm(R, C, training, relu):
+    torch.manual_seed(R + C)
+    x = (torch.randn(R, C, device='cuda') * torch.linspace(0.2, 3.0, C, device='cuda') + torch.linspace(-8.0, 5.0, C, device='cuda'))
+    outs = []
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm1d(C).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+            bn.running_mean.copy_(torch.linspace(-1, 1, C)); bn.running_var.copy_(torch.linspace(0.5, 2, C))
+            if fused:
+                y = HF.bn_rows(x, bn, training, relu)
+            else:
+                y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
+                y = F.relu(y) if relu else y
+        outs.append((y, bn.running_mean.clone(), bn.running_var.clone()))
+    # column offsets of up to 40 sigma: an unshifted sum-of-squares variance would lose most digits here
+    close(outs[0][0], outs[1][0], rtol=2e-5, atol_scale=5e-6)
+    close(outs[0][1], outs[1][1], rtol=1e-5, atol_scale=1e-6)
+    close(outs[0][2], outs[1][2], rtol=2e-5, atol_scale=1e-6)
+    with torch.no_grad():
+        bn2 = torch.nn.BatchNorm1d(C).cuda()
+        assert torch.equal(HF.bn_rows(x, bn2, training, relu), HF.bn_rows(x, torch.nn.BatchNorm1d(C).cuda(), training, relu))   # deterministic
+
+
+@pytest.mark.parametrize("B,N,S,C,k", [(32, 1096, 64, 32, 16), (32, 64, 32, 12, 16), (2, 50, 5, 7, 16), (3, 33, 40, 256, 3), (1, 1, 16, 1, 1)])
+def test_interp_matches_reference_formula(B, N, S, C, k):
+    g = torch.Generator(device='cuda').manual_seed(B * N + C)
+    xyz1 = torch.rand(B, N, 3, device='cuda', generator=g)
+    xyz2 = torch.rand(B, S, 3, device='cuda', generator=g)
+    if S >= 4 and N >= 4:
+        xyz2[:, :4] = xyz1[:, :4]                                         # coincident points: d ~ 0 (+- rounding)
+    feat = torch.randn(B, S, C, device='cuda', generator=g)
+    dists, idx = upp_layers.square_distance(xyz1, xyz2).sort(dim=-1)
+    kk = min(k, S)
+    d, i = dists[:, :, :kk], idx[:, :, :kk]
+    recip = 1.0 / (d + 1e-4)
+    w = recip / recip.sum(dim=2, keepdim=True)
+    want = torch.sum(upp_layers.index_points(feat, i) * w.unsqueeze(-1), dim=2)
+    got = HF.interp(dists, idx, feat, kk, 1e-4)
+    close(got, want, rtol=1e-5, atol_scale=2e-6)
+    wide = torch.full((B, N, C + 5), 7.0, device='cuda')
+    HF.interp(dists, idx, feat, kk, 1e-4, out=wide, col0=5)
+    assert torch.equal(wide[:, :, 5:], got) and bool((wide[:, :, :5] == 7.0).all())
+    # and through the layer helper (the fused path is the one taken for HIP tensors without grad)
+    close(upp_layers._inverse_distance_interp(xyz1, xyz2, feat, k, 1e-4), want, rtol=1e-5, atol_scale=2e-6)
+
+
+@pytest.mark.parametrize("rows,F_", [((32, 1096), 4), ((5,), 8), ((2, 3, 7), 1), ((4, 4), 0)])
+def test_posenc_matches_sin_cos_concat(rows, F_):
+    x = (torch.rand(*rows, 3, device='cuda') - 0.5) * 2.5
+    pe = upp_layers.PositionalEmbedding(max(F_, 1))
+    freqs = pe.freq_bands[:F_]
+    want = torch.cat([x] + [f(freq * x) for freq in freqs for f in (torch.sin, torch.cos)], -1)
+    got = HF.posenc(x, freqs)
+    assert got.shape == want.shape
+    close(got, want, rtol=1e-6, atol_scale=1e-7)
+    wide = torch.zeros(*rows, want.shape[-1] + 9, device='cuda')
+    HF.posenc(x, freqs, out=wide, col0=0)
+    assert torch.equal(wide[..., :want.shape[-1]], got) and bool((wide[..., want.shape[-1]:] == 0).all())
+    if F_ >= 1:
+        close(pe(x), torch.cat([x] + [f(freq * x) for freq in pe.freq_bands for f in (torch.sin, torch.cos)], -1), rtol=1e-6, atol_scale=1e-7)
+
+
+def test_rectify_prompter_fused_path_equals_torch_path():
+    from models import build_model_from_cfg
+    from utils.config import builtin_cfg
+    import _seeded
+    m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    rp = m.rectify_prompter
+    pts = _seeded.noisy_clouds(4, 1024, seed=5).cuda()
+    with torch.no_grad():
+        _, center = m.group_divider(pts)
+    c32 = center[:, :32].contiguous()
+    tok = torch.randn(4, 32, 384, device='cuda')
+    for training in (False, True):
+        rp.train(training)
+        state = {k: v.clone() for k, v in rp.state_dict().items()}
+        torch.manual_seed(0)
+        fused = rp(pts, c32, tok)                                  # nothing requires grad -> fused operators
+        stats_fused = {k: v.clone() for k, v in rp.state_dict().items()}
+        rp.load_state_dict(state)
+        torch.manual_seed(0)
+        tok_g = tok.clone().requires_grad_(True)                   # an input that requires grad forces the torch ops
+        plain = rp(pts, c32, tok_g)
+        if not training:                                           # (train mode draws a dropout mask: statistics only)
+            close(fused, plain, rtol=1e-4, atol_scale=2e-5)
+        for k in state:
+            if 'running' in k:
+                close(stats_fused[k], rp.state_dict()[k], rtol=1e-4, atol_scale=1e-5)
+            elif 'num_batches' in k:
+                assert int(stats_fused[k]) == int(rp.state_dict()[k])
