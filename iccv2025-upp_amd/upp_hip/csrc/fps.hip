@@ -38,13 +38,16 @@ template <int S, int W, bool USE_LDS>
 __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ xyz, int32_t *__restrict__ idx,
                                                      float *__restrict__ centers, FpsGeom g) {
     constexpr int L = 64 * W;
-    extern __shared__ float lds[];  // 2*W*2 words of wave records, then a [3*N] copy of the cloud
+    extern __shared__ float lds[];  // 2*W*2 words of wave records, a [3*N] copy of the cloud, then the M winners
     const int N = g.N, M = g.M;
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const float *p = xyz + (size_t)b * N * 3;
     uint32_t *rec = reinterpret_cast<uint32_t *>(lds);
     float *cloud = lds + 4 * W;
+    // Winners are collected in LDS and written out coalesced after the last round: a global store per round would
+    // sit in front of every barrier (s_waitcnt vmcnt(0)) and put a memory round trip on the critical path.
+    int *won = reinterpret_cast<int *>(cloud + 3 * N);
     // Coordinates of a point: from the LDS copy (N <= 8192) or, for larger
     // clouds that do not fit LDS, straight from global memory (L2-resident).
     auto coord = [&](int k, int c) -> float { return USE_LDS ? cloud[k * 3 + c] : p[k * 3 + c]; };
@@ -77,10 +80,13 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
 
     float x1 = coord(0, 0), y1 = coord(0, 1), z1 = coord(0, 2);
     if (tid == 0) {
-        idx[(size_t)b * M] = 0;
-        if (centers) {
-            float *c = centers + (size_t)b * M * 3;
-            c[0] = x1; c[1] = y1; c[2] = z1;
+        if (USE_LDS) won[0] = 0;
+        else {
+            idx[(size_t)b * M] = 0;
+            if (centers) {
+                float *c = centers + (size_t)b * M * 3;
+                c[0] = x1; c[1] = y1; c[2] = z1;
+            }
         }
     }
     const int lane = tid & 63, wave = tid >> 6;
@@ -121,12 +127,21 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
         const int old = (m == 0u) ? 0 : (int)(kmin & 0x7FFFu);
         x1 = coord(old, 0); y1 = coord(old, 1); z1 = coord(old, 2);
         if (tid == 0) {
-            idx[(size_t)b * M + j] = old;
-            if (centers) {
-                float *c = centers + ((size_t)b * M + j) * 3;
-                c[0] = x1; c[1] = y1; c[2] = z1;
+            if (USE_LDS) won[j] = old;
+            else {
+                idx[(size_t)b * M + j] = old;
+                if (centers) {
+                    float *c = centers + ((size_t)b * M + j) * 3;
+                    c[0] = x1; c[1] = y1; c[2] = z1;
+                }
             }
         }
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (int j = tid; j < M; j += L) idx[(size_t)b * M + j] = won[j];
+        if (centers)
+            for (int e = tid; e < 3 * M; e += L) centers[(size_t)b * M * 3 + e] = cloud[won[e / 3] * 3 + (e % 3)];
     }
 }
 
@@ -141,17 +156,17 @@ int fps_block_size(int n) {
     return t;
 }
 
-constexpr int kFpsLdsMaxN = 8192;  // 96 KiB cloud copy
+constexpr int kFpsLdsBytes = 160 * 1024 - 256;  // cloud copy + winner list + wave records must fit the CU's LDS
 
 template <int S, int W>
 int launch(const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom &g, hipStream_t st) {
-    if (g.N <= kFpsLdsMaxN) {
-        const size_t lds_bytes = (size_t)(4 * W + 3 * g.N) * 4;
+    const size_t lds_bytes = (size_t)(4 * W + 3 * g.N + g.M) * 4;
+    if (lds_bytes <= (size_t)kFpsLdsBytes) {
         if (lds_bytes > 64 * 1024) {
             static bool raised = false;  // one attribute call per instantiation
             if (!raised) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fps_kernel<S, W, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (4 * W + 3 * kFpsLdsMaxN) * 4);
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kFpsLdsBytes);
                 if (e != hipSuccess) return (int)e;
                 raised = true;
             }

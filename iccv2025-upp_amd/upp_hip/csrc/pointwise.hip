@@ -48,13 +48,14 @@ __global__ __launch_bounds__(256) void bn_rows_partial_kernel(const float *__res
 }
 
 // mean / rstd from the slab partials (training) or the running statistics (eval); running statistics updated in
-// training mode.  grid = ceil(C / 64), 16 waves; lane = column; wave w merges slabs w, w+16, ... (Chan et al., f64);
-// the 16 wave results are merged in wave order.
+// training mode.  grid = ceil(C / 64), 16 waves; lane = column; wave w owns slabs w, w+16, ...
+// Two passes over the (register-resident) partials, both in f64 and in a fixed order:
+//   mean = sum_i S_i / rows;   M2 = sum_i [ M2_i + n_i (S_i / n_i - mean)^2 ]       (Chan et al., all slabs at once)
 __global__ __launch_bounds__(64 * kBnWaves) void bn_finalize_rows_kernel(const float *__restrict__ part, int slabs, int per, int rows,
                                                                          int C, int training, float momentum, float eps,
                                                                          float *__restrict__ running_mean, float *__restrict__ running_var,
                                                                          float *__restrict__ mean_out, float *__restrict__ rstd_out) {
-    __shared__ double shn[kBnWaves][64], shm[kBnWaves][64], shq[kBnWaves][64];
+    __shared__ double sh[kBnWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int cc = min(c, C - 1);
@@ -62,39 +63,54 @@ __global__ __launch_bounds__(64 * kBnWaves) void bn_finalize_rows_kernel(const f
         if (wave == 0 && c < C) { mean_out[c] = running_mean[c]; rstd_out[c] = 1.0f / sqrtf(running_var[c] + eps); }
         return;
     }
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int w0 = wave; w0 < slabs; w0 += kBnWaves * 16) {
-        float ps[16], pq[16];
+    constexpr int T = 16;                                   // slabs held in registers per wave and sweep
+    const bool one_sweep = slabs <= kBnWaves * T;
+    float ps[T], pq[T];
+    double s = 0.0;
+    for (int w0 = wave; w0 < slabs; w0 += kBnWaves * T) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < T; ++t) {
             const int w = min(w0 + kBnWaves * t, slabs - 1);
             ps[t] = part[((size_t)w * 2 + 0) * C + cc]; pq[t] = part[((size_t)w * 2 + 1) * C + cc];
         }
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < T; ++t) if (w0 + kBnWaves * t < slabs) s += (double)ps[t];
+    }
+    sh[wave][lane] = s;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBnWaves; ++w) tot += sh[w][lane];
+    const double mean = tot / (double)rows;
+    __syncthreads();
+    const double inv_per = 1.0 / (double)per;
+    double q = 0.0;
+    for (int w0 = wave; w0 < slabs; w0 += kBnWaves * T) {
+        if (!one_sweep) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int w = min(w0 + kBnWaves * t, slabs - 1);
+                ps[t] = part[((size_t)w * 2 + 0) * C + cc]; pq[t] = part[((size_t)w * 2 + 1) * C + cc];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
             const int w = w0 + kBnWaves * t;
             if (w < slabs) {
-                const double nb = (double)min(per, rows - w * per), mb = (double)ps[t] / nb;
-                const double tot = n + nb, delta = mb - mean;
-                mean += delta * nb / tot;
-                m2 += (double)pq[t] + delta * delta * n * nb / tot;
-                n = tot;
+                const int nb = min(per, rows - w * per);
+                const double mb = nb == per ? (double)ps[t] * inv_per : (double)ps[t] / (double)nb;
+                const double d = mb - mean;
+                q += (double)pq[t] + (double)nb * d * d;
             }
         }
     }
-    shn[wave][lane] = n; shm[wave][lane] = mean; shq[wave][lane] = m2;
+    sh[wave][lane] = q;
     __syncthreads();
     if (wave == 0 && c < C) {
+        double m2 = 0.0;
 #pragma unroll
-        for (int w = 1; w < kBnWaves; ++w) {
-            const double nb = shn[w][lane];
-            if (nb > 0.0) {
-                const double tot = n + nb, delta = shm[w][lane] - mean;
-                mean += delta * nb / tot;
-                m2 += shq[w][lane] + delta * delta * n * nb / tot;
-                n = tot;
-            }
-        }
+        for (int w = 0; w < kBnWaves; ++w) m2 += sh[w][lane];
+        const double n = (double)rows;
         const float var = (float)(m2 / n);
         mean_out[c] = (float)mean;
         rstd_out[c] = 1.0f / sqrtf(var + eps);
