@@ -122,7 +122,7 @@ struct RowLnBwdArgs {
     const float *mean, *rstd, *gamma;
     int mode;
     const float *u; float keep;
-    float *g_x;            // (B, Lin, D): rows referenced by the table are written (caller zero-fills if not all are)
+    float *g_x;            // (B, Lin, D): every row is written (zeros for the prompt rows a strip map drops)
     float *g_prompt;       // (B, P, D) per-sample gradient of the prompt rows, or null
     float *g_y;            // (B, Lin, D) gradient of the residual branch (same rows as g_x), or null
     int B, Lin, Lout, D, P;
@@ -130,11 +130,33 @@ struct RowLnBwdArgs {
 
 __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
-    if (row >= a.B * a.Lout) return;
-    const int b = row / a.Lout, t = row - b * a.Lout;
-    const int src = row_src(t, a.mode, a.P);
+    const int it = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const int D = a.D;
+    // Insert / identity maps are walked by OUTPUT row; strip maps by INPUT row, so that the prompt rows the forward
+    // dropped get their zero gradient here (no separate fill launch).
+    const bool by_input = a.mode == 3 || a.mode == 4;
+    const int Lg = by_input ? a.Lin : a.Lout;
+    if (it >= a.B * Lg) return;
+    const int b = it / Lg, t = it - b * Lg;
+    int src, t_out;
+    if (by_input) {
+        src = t;
+        t_out = a.mode == 3 ? (t == 0 ? 0 : (t <= a.P ? -1 : t - a.P)) : (t < a.P ? -1 : t - a.P);
+        if (t_out < 0) {
+            float *zx = a.g_x ? a.g_x + ((size_t)b * a.Lin + t) * D : nullptr;
+            float *zy = a.g_y ? a.g_y + ((size_t)b * a.Lin + t) * D : nullptr;
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) {
+                const int c = lane + 64 * e;
+                if (c < D) { if (zx) zx[c] = 0.0f; if (zy) zy[c] = 0.0f; }
+            }
+            return;
+        }
+    } else {
+        t_out = t;
+        src = row_src(t, a.mode, a.P);
+    }
+    const int row = b * a.Lout + t_out;
     const bool has_gxo = a.g_xo != nullptr, has_ln = a.g_h != nullptr;
     // one batch of loads (clamped columns), then the arithmetic
     int cc[kMaxE];
@@ -432,7 +454,8 @@ extern "C" int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *x
     if (B == 0) return 0;
     if (mode < 0 || mode > 4 || P < 0) return UPP_E_BADARG;
     RowLnBwdArgs a{g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, g_x, g_prompt, g_y, B, Lin, Lout, D, P};
-    hipLaunchKernelGGL(rowln_bwd_kernel, dim3((B * Lout + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    const int Lg = (mode == 3 || mode == 4) ? Lin : Lout;      // strip maps are walked by input row (see the kernel)
+    hipLaunchKernelGGL(rowln_bwd_kernel, dim3((B * Lg + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return upp_launch_status();
 }
 

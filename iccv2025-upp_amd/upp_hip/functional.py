@@ -187,13 +187,14 @@ class _RowLN(Function):
             return (None,) * 11
         strip = mode in (ROW_STRIP_CLS, ROW_STRIP) and P > 0
         g_x, g_p, g_y = ops.rowln_bwd(g_xo, g_hc, xo, mean, rstd, gamma, mode, u, ctx.keep, B, Lin, Lout, D, P,
-                                      need_x=need[0] or (has_add and need[1]), zero_x=strip,
+                                      need_x=need[0] or (has_add and need[1]),
                                       need_prompt=has_prompts and need[2], need_y=has_y and need[3])
-        g_gamma = g_beta = None
+        g_gamma = g_beta = g_prompts = None
         if has_ln and g_hc is not None and (need[4] or need[5]):
             g_gamma, g_beta = ops.ln_param_grad(g_hc, xo, mean, rstd)
-        return (g_x if need[0] else None, g_x if (has_add and need[1]) else None,
-                g_p.sum(dim=0) if g_p is not None else None, g_y,
+        if g_p is not None:
+            g_prompts = g_p.sum(dim=0)
+        return (g_x if need[0] else None, g_x if (has_add and need[1]) else None, g_prompts, g_y,
                 g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None)
 
 

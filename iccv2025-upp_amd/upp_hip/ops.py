@@ -232,11 +232,11 @@ def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want
     return xo, h, mean, rstd
 
 
-def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, P, need_x, zero_x, need_prompt, need_y):
+def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, P, need_x, need_prompt, need_y):
     dev = (g_xo if g_xo is not None else g_h).device
-    g_x = (torch.zeros if zero_x else torch.empty)((B, Lin, D), dtype=torch.float32, device=dev) if need_x else None
+    g_x = torch.empty((B, Lin, D), dtype=torch.float32, device=dev) if need_x else None      # the kernel writes every row
     g_p = torch.empty((B, P, D), dtype=torch.float32, device=dev) if (need_prompt and P > 0 and mode in (1, 2)) else None
-    g_y = (torch.zeros if zero_x else torch.empty)((B, Lin, D), dtype=torch.float32, device=dev) if need_y else None
+    g_y = torch.empty((B, Lin, D), dtype=torch.float32, device=dev) if need_y else None
     _call(dev, "upp_rowln_bwd", _abi.ptr(g_xo), _abi.ptr(g_h), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma),
           int(mode), _abi.ptr(u), float(keep), _abi.ptr(g_x), _abi.ptr(g_p), _abi.ptr(g_y), B, Lin, Lout, D, P)
     return g_x, g_p, g_y

@@ -164,8 +164,8 @@ int upp_patch_embed_fwd(const float *pts, int R, int n,
  *                 (+ floor(keep + u[b]) / keep * y[b, s])  if y (row-aligned with x; u NULL: factor 1)
  *   xo (B,Lout,D) = those rows (optional);  h = LayerNorm(rows) * gamma + beta, mean / rstd (B,Lout) saved
  *   (gamma NULL: no LayerNorm, only xo).
- * Backward: d = g_xo + LayerNormBackward(g_h); written to g_x[b, s] (caller zero-fills g_x for the strip modes,
- * whose prompt rows receive nothing), g_prompt (B,P,D) (caller sums over B), g_y[b, s] = factor * d.
+ * Backward: d = g_xo + LayerNormBackward(g_h); written to g_x[b, s] (every row of g_x / g_y is written: the prompt
+ * rows a strip mode drops get zeros), g_prompt (B,P,D) (caller sums over B), g_y[b, s] = factor * d.
  * upp_ln_param_grad: per-chunk partial sums of d_gamma / d_beta, part (2, chunks, D).
  * Limits: D <= 512. */
 int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y,
