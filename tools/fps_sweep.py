@@ -13,5 +13,5 @@ def bench(N, M, W, B=32, it=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / it * 1e3
 for N, M in ((1228, 1024), (1024, 256), (1024, 64), (1096, 64), (1024, 128)):
-    print(N, M, ' '.join('W=%d: %.1f us' % (W, bench(N, M, W)) for W in (0, 2, 4, 8)))
+    print(N, M, ' '.join('W=%d: %.1f us' % (W, bench(N, M, W)) for W in (0, 1, 2, 4, 8)))
 lib.upp_fps_set_waves(0)
