@@ -191,9 +191,10 @@ class _RowLN(Function):
                                       need_prompt=has_prompts and need[2], need_y=has_y and need[3])
         g_gamma = g_beta = g_prompts = None
         if has_ln and g_hc is not None and (need[4] or need[5]):
-            g_gamma, g_beta = ops.ln_param_grad(g_hc, xo, mean, rstd)
+            part = ops.ln_param_grad(g_hc, xo, mean, rstd)
+            g_gamma, g_beta = _DEFERRED.sum0(part[0]), _DEFERRED.sum0(part[1])
         if g_p is not None:
-            g_prompts = g_p.sum(dim=0)
+            g_prompts = _DEFERRED.sum0(g_p)
         return (g_x if need[0] else None, g_x if (has_add and need[1]) else None, g_prompts, g_y,
                 g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None)
 
@@ -225,6 +226,48 @@ class _Attention(Function):
 
 def attention(qkv, num_heads, scale):
     return _Attention.apply(qkv, int(num_heads), float(scale))
+
+
+# ------------------------------------------------------------------ deferred parameter-gradient sums
+class _DeferredSums:
+    """Parameter gradients that are sums of partial results (adapter weights, LayerNorm gamma/beta, prompts) are not read
+    by anything inside a backward pass.  Inside `with deferred_sums():` (TrainStep) their reductions are queued and run
+    as ONE upp_batched_sum launch when the block exits -- the returned tensors are filled only then, so the scope must
+    cover the whole backward() and end before the gradients are consumed.  Outside a scope every sum runs at once."""
+
+    def __init__(self):
+        self.depth = 0
+        self.jobs = []
+
+    def sum0(self, part):
+        if self.depth == 0 or not part.is_cuda:
+            return part.sum(dim=0)
+        part = part.contiguous()
+        out = torch.empty(part.shape[1:], dtype=part.dtype, device=part.device)
+        self.jobs.append((part, out))
+        return out
+
+    def flush(self):
+        jobs, self.jobs = self.jobs, []
+        ops.batched_sum(jobs)
+
+
+_DEFERRED = _DeferredSums()
+
+
+class deferred_sums:
+    def __enter__(self):
+        _DEFERRED.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        _DEFERRED.depth -= 1
+        if _DEFERRED.depth == 0:
+            if exc[0] is None:
+                _DEFERRED.flush()
+            else:
+                _DEFERRED.jobs = []
+        return False
 
 
 # ------------------------------------------------------------------ prompt propagation
@@ -359,7 +402,7 @@ class _Adapter(Function):
         gW1 = gb1 = gW2 = gb2 = None
         if need[2] or need[3] or need[4] or need[5]:
             H, D = W1.shape
-            tot = part.sum(dim=0)                      # fixed workgroup order: deterministic
+            tot = _DEFERRED.sum0(part)                 # fixed workgroup order: deterministic
             gW1, gW2 = tot[:H * D].view(H, D), tot[H * D:2 * H * D].view(D, H)
             gb1, gb2 = tot[2 * H * D:2 * H * D + H], tot[2 * H * D + H:]
         return (g_ha if need[0] else None, g_out if need[1] else None, gW1 if need[2] else None, gb1 if need[3] else None,

@@ -247,8 +247,7 @@ def ln_param_grad(g_h, xo, mean, rstd, chunks=32):
     D = g_h.shape[-1]
     part = torch.empty((2, chunks, D), dtype=torch.float32, device=g_h.device)
     _call(g_h.device, "upp_ln_param_grad", _abi.ptr(g_h), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(part), rows, D, chunks)
-    s = part.sum(dim=1)
-    return s[0], s[1]
+    return part          # (2, chunks, D): [0] d_gamma partials, [1] d_beta partials; the caller sums over the chunks
 
 
 def attn_fwd(qkv, B, L, H, scale):
@@ -389,6 +388,24 @@ def posenc_fwd(x, freqs, out=None, col0=0):
 
 
 # ------------------------------------------------------------------ optimizer tail
+def batched_sum(jobs):
+    """jobs: list of (src (n, ...) contiguous f32, dst (...) contiguous f32): dst = src.sum(0), all in one launch."""
+    if not jobs:
+        return
+    import ctypes
+    k = len(jobs)
+    src = (ctypes.c_void_p * k)(*[j[0].data_ptr() for j in jobs])
+    dst = (ctypes.c_void_p * k)(*[j[1].data_ptr() for j in jobs])
+    n = (ctypes.c_int * k)(*[j[0].shape[0] for j in jobs])
+    ln = (ctypes.c_int * k)(*[j[1].numel() for j in jobs])
+    for s_, d_ in jobs:
+        _need(s_, "src", torch.float32)
+        _need(d_, "dst", torch.float32)
+        if s_.numel() != s_.shape[0] * d_.numel():
+            raise RuntimeError("batched_sum: dst must have the shape of one row of src")
+    _call(jobs[0][0].device, "upp_batched_sum", src, dst, n, ln, k)
+
+
 def adamw_flat(p, g, m, v, n, split, state, scratch, lr, beta1, beta2, eps, weight_decay, max_norm):
     for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (state, "state"), (scratch, "scratch")):
         _need(t, name, torch.float32)

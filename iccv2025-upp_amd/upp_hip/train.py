@@ -14,6 +14,8 @@ import torch.distributed as dist
 
 from utils.dist_utils import FlatGradAllReduce
 
+from . import functional as HF
+
 PEFT_STAGE1 = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'bnorm', 'cls_pos', 'cls_token',
                'cls_head_finetune']  # reference tools/runner_module.py:62-66
 
@@ -109,7 +111,8 @@ class TrainStep:
             p.grad = None              # let autograd write fresh gradients: no per-parameter accumulate kernels
         logits = self.model(self.pts, **self.kw)
         loss, acc = self.model.get_loss_acc(logits, self.labels)
-        loss.backward()
+        with HF.deferred_sums():       # the partial-sum reductions of all parameter gradients: one launch after the pass
+            loss.backward()
         got = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None]
         torch._foreach_copy_([v for v, _ in got], [g for _, g in got])   # one multi-tensor copy into the flat buffer
         for p, v in zip(self.trainable, self.flat.views):

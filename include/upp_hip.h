@@ -268,6 +268,10 @@ int upp_posenc_fwd(const float *x, const float *freqs, int F, float *out, int ld
  * g is overwritten with the clipped gradient (as clip_grad_norm_ does).  max_norm <= 0 disables clipping.
  * scratch: upp_adamw_scratch_floats() floats. */
 long long upp_adamw_scratch_floats(void);
+/* upp_batched_sum: dst_j (len_j) = sum over the n_j rows of src_j (n_j, len_j), for `jobs` independent jobs in one launch
+ * (rows added in ascending order).  src / dst / n / len are HOST arrays; the pointers in them are device pointers.
+ * Used for the parameter-gradient partials of a backward pass (see upp_adapter_bwd, upp_ln_param_grad, upp_rowln_bwd). */
+int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, int jobs, void *stream);
 int upp_adamw_flat(float *p, float *g, float *m, float *v, long long n, long long split, float *state, float *scratch,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, void *stream);
 

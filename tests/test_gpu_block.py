@@ -295,3 +295,34 @@ def test_fused_propagation_matches_pool_batchnorm_interp(B, Lp, off, training, d
     b = HF.propagate(xj, bn, index, u, keep, training)
     gb = torch.autograd.grad((b * wgt).sum(), [xj])[0]
     assert torch.equal(a, b) and torch.equal(ga, gb)
+
+
+def test_batched_sum_and_deferred_scope():
+    from upp_hip import ops
+    g = torch.Generator(device='cuda').manual_seed(1)
+    shapes = [(75, 24992), (32, 384), (32, 10, 384), (1, 5), (33, 1), (17, 300)] * 13      # 78 jobs -> two launches
+    jobs = [(torch.randn(*s, device='cuda', generator=g), torch.empty(s[1:], device='cuda')) for s in shapes]
+    ops.batched_sum(jobs)
+    for src, dst in jobs:
+        ref = src[0].clone()
+        for i in range(1, src.shape[0]):
+            ref += src[i]                         # ascending row order, as the kernel
+        assert torch.equal(dst, ref)
+    # the deferred scope returns the same gradients as immediate sums
+    torch.manual_seed(0)
+    x = torch.randn(32, 75, 384, device='cuda')
+    ln = torch.nn.LayerNorm(384).cuda()
+    prompts = torch.randn(10, 384, device='cuda', requires_grad=True)
+    outs = []
+    for deferred in (False, True):
+        xi = x[:, :65].clone().requires_grad_(True)
+        xo, h = HF.rowln(xi, prompts=prompts, mode=HF.ROW_INSERT_CLS, P=10, gamma=ln.weight, beta=ln.bias, eps=ln.eps)
+        loss = (h * torch.linspace(-1, 1, h.numel(), device='cuda').view_as(h)).sum() + xo.square().sum()
+        if deferred:
+            with HF.deferred_sums():
+                gr = torch.autograd.grad(loss, [xi, prompts, ln.weight, ln.bias])
+        else:
+            gr = torch.autograd.grad(loss, [xi, prompts, ln.weight, ln.bias])
+        outs.append(gr)
+    for a, b in zip(*outs):      # same partials, summed sequentially (kernel) vs torch's tree order: f32 reassociation only
+        close(a, b, rtol=1e-4, atol_scale=2e-4)
