@@ -62,15 +62,16 @@ __global__ __launch_bounds__(256) void adamw_update_kernel(float *__restrict__ p
     }
 }
 
-// Column sums of many small partial-result matrices in ONE launch: job j reduces src_j (n_j, len_j) over its first
-// dimension into dst_j (len_j), rows added in ascending order (deterministic).  The parameter-gradient partials of a
+// Column sums of many small partial-result matrices in ONE launch: job j reduces the n_j rows (row stride ld_j) of
+// src_j over its first dimension into dst_j (len_j), rows added in ascending order (deterministic); dst is overwritten
+// or accumulated into.  The parameter-gradient partials of a
 // backward pass (adapter weight partials per workgroup, LayerNorm gamma/beta partials per chunk, per-sample prompt
 // gradients) are summed here, after the pass, instead of by ~3 tiny reduce launches per transformer block.
 constexpr int kMaxSumJobs = 64;
 struct SumJobs {
     const float *src[kMaxSumJobs];
     float *dst[kMaxSumJobs];
-    int n[kMaxSumJobs], len[kMaxSumJobs];
+    int n[kMaxSumJobs], len[kMaxSumJobs], ld[kMaxSumJobs], acc[kMaxSumJobs];
     int wg0[kMaxSumJobs + 1];                  // first workgroup of each job (256 columns per workgroup)
     int jobs;
 };
@@ -78,31 +79,33 @@ __global__ __launch_bounds__(256) void batched_sum_kernel(SumJobs t) {
     int j = 0;
     while (j + 1 < t.jobs && (int)blockIdx.x >= t.wg0[j + 1]) ++j;             // wave-uniform scan of <= 64 entries
     const int c = ((int)blockIdx.x - t.wg0[j]) * 256 + threadIdx.x;
-    const int len = t.len[j], n = t.n[j];
+    const int len = t.len[j], n = t.n[j], ld = t.ld[j];
     if (c >= len) return;
     const float *src = t.src[j] + c;
     float acc = 0.0f;
     for (int i0 = 0; i0 < n; i0 += 16) {                                       // 16 independent loads in flight
         float v[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = src[(size_t)min(i0 + q, n - 1) * len];
+        for (int q = 0; q < 16; ++q) v[q] = src[(size_t)min(i0 + q, n - 1) * ld];
 #pragma unroll
         for (int q = 0; q < 16; ++q) if (i0 + q < n) acc += v[q];
     }
-    t.dst[j][c] = acc;
+    t.dst[j][c] = t.acc[j] ? t.dst[j][c] + acc : acc;
 }
 
 }  // namespace
 
-extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, int jobs, void *stream) {
-    if (jobs < 0 || (jobs > 0 && (!src || !dst || !n || !len))) return UPP_E_BADARG;
+extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, const int *ld,
+                               const int *accumulate, int jobs, void *stream) {
+    if (jobs < 0 || (jobs > 0 && (!src || !dst || !n || !len || !ld || !accumulate))) return UPP_E_BADARG;
     for (int j0 = 0; j0 < jobs; j0 += kMaxSumJobs) {
         SumJobs t;
         t.jobs = jobs - j0 < kMaxSumJobs ? jobs - j0 : kMaxSumJobs;
         int wg = 0;
         for (int j = 0; j < t.jobs; ++j) {
-            if (!src[j0 + j] || !dst[j0 + j] || n[j0 + j] < 1 || len[j0 + j] < 1) return UPP_E_BADARG;
+            if (!src[j0 + j] || !dst[j0 + j] || n[j0 + j] < 1 || len[j0 + j] < 1 || ld[j0 + j] < len[j0 + j]) return UPP_E_BADARG;
             t.src[j] = src[j0 + j]; t.dst[j] = dst[j0 + j]; t.n[j] = n[j0 + j]; t.len[j] = len[j0 + j];
+            t.ld[j] = ld[j0 + j]; t.acc[j] = accumulate[j0 + j];
             t.wg0[j] = wg;
             wg += (len[j0 + j] + 255) / 256;
         }

@@ -171,6 +171,7 @@ class _RowLN(Function):
         ctx.dims = (B, Lin, Lout, D, P, mode)
         ctx.keep = keep
         ctx.has = (add is not None, prompts is not None, y is not None, gamma is not None)
+        ctx.param_ptrs = tuple(t.data_ptr() if t is not None else 0 for t in (prompts, gamma, beta))
         if gamma is None:
             return xo, xo.new_empty(0)
         return xo, h
@@ -190,11 +191,15 @@ class _RowLN(Function):
                                       need_x=need[0] or (has_add and need[1]),
                                       need_prompt=has_prompts and need[2], need_y=has_y and need[3])
         g_gamma = g_beta = g_prompts = None
+        p_prompts, p_gamma, p_beta = ctx.param_ptrs
         if has_ln and g_hc is not None and (need[4] or need[5]):
-            part = ops.ln_param_grad(g_hc, xo, mean, rstd)
-            g_gamma, g_beta = _DEFERRED.sum0(part[0]), _DEFERRED.sum0(part[1])
+            part = ops.ln_param_grad(g_hc, xo, mean, rstd)               # (2, chunks, D)
+            _, g_gamma = _DEFERRED.reduce(p_gamma, part[0], 0, D)
+            _, g_beta = _DEFERRED.reduce(p_beta, part[1], 0, D)
         if g_p is not None:
-            g_prompts = _DEFERRED.sum0(g_p)
+            _, g_prompts = _DEFERRED.reduce(p_prompts, g_p.view(B, P * D), 0, P * D)
+            if g_prompts is not None:
+                g_prompts = g_prompts.view(P, D)
         return (g_x if need[0] else None, g_x if (has_add and need[1]) else None, g_prompts, g_y,
                 g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None)
 
@@ -231,21 +236,26 @@ def attention(qkv, num_heads, scale):
 # ------------------------------------------------------------------ deferred parameter-gradient sums
 class _DeferredSums:
     """Parameter gradients that are sums of partial results (adapter weights, LayerNorm gamma/beta, prompts) are not read
-    by anything inside a backward pass.  Inside `with deferred_sums():` (TrainStep) their reductions are queued and run
-    as ONE upp_batched_sum launch when the block exits -- the returned tensors are filled only then, so the scope must
-    cover the whole backward() and end before the gradients are consumed.  Outside a scope every sum runs at once."""
+    by anything inside a backward pass.  Inside `with deferred_sums(targets):` (TrainStep) their reductions are queued
+    and run as ONE upp_batched_sum launch when the scope exits, ACCUMULATING straight into the gradient buffers the
+    caller registered (targets: {parameter data_ptr: zero-initialised f32 buffer of the parameter's shape}); autograd is
+    handed None for those parameters, so nothing depends on how it would have stored a returned tensor.  Parameters
+    without a registered buffer, and everything outside a scope, are summed at once and returned as usual."""
 
     def __init__(self):
-        self.depth = 0
+        self.targets = None
         self.jobs = []
+        self.routed = set()
 
-    def sum0(self, part):
-        if self.depth == 0 or not part.is_cuda:
-            return part.sum(dim=0)
-        part = part.contiguous()
-        out = torch.empty(part.shape[1:], dtype=part.dtype, device=part.device)
-        self.jobs.append((part, out))
-        return out
+    def reduce(self, ptr, part, offset, length):
+        """Sum columns [offset, offset+length) of the 2-D partial matrix `part` over its rows.
+        -> (routed, tensor-or-None): routed sums appear in the registered buffer at scope exit."""
+        dst = self.targets.get(ptr) if (self.targets is not None and part.is_cuda) else None
+        if dst is None or dst.numel() != length:
+            return False, part[:, offset:offset + length].sum(dim=0)
+        self.jobs.append((part, offset, part.shape[0], length, part.stride(0), dst, True))
+        self.routed.add(ptr)
+        return True, None
 
     def flush(self):
         jobs, self.jobs = self.jobs, []
@@ -256,17 +266,26 @@ _DEFERRED = _DeferredSums()
 
 
 class deferred_sums:
+    """Scope of one backward pass whose parameter-gradient partial sums are batched (see _DeferredSums)."""
+
+    def __init__(self, targets):
+        self.targets = targets
+        self.routed = set()      # after exit: data_ptrs of the parameters whose buffers received sums
+
     def __enter__(self):
-        _DEFERRED.depth += 1
+        if _DEFERRED.targets is not None:
+            raise RuntimeError("deferred_sums scopes do not nest")
+        _DEFERRED.targets = self.targets
+        _DEFERRED.routed = set()
         return self
 
     def __exit__(self, *exc):
-        _DEFERRED.depth -= 1
-        if _DEFERRED.depth == 0:
-            if exc[0] is None:
-                _DEFERRED.flush()
-            else:
-                _DEFERRED.jobs = []
+        _DEFERRED.targets = None
+        self.routed = _DEFERRED.routed
+        if exc[0] is None:
+            _DEFERRED.flush()
+        else:
+            _DEFERRED.jobs = []
         return False
 
 
@@ -390,6 +409,7 @@ class _Adapter(Function):
         out, s1 = ops.adapter_fwd(ha, x, W1, b1, W2, b2, u, p, scale)
         ctx.save_for_backward(ha, s1, W1, W2, u)
         ctx.meta = (p, scale)
+        ctx.param_ptrs = (W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr())
         return out
 
     @staticmethod
@@ -402,9 +422,14 @@ class _Adapter(Function):
         gW1 = gb1 = gW2 = gb2 = None
         if need[2] or need[3] or need[4] or need[5]:
             H, D = W1.shape
-            tot = _DEFERRED.sum0(part)                 # fixed workgroup order: deterministic
-            gW1, gW2 = tot[:H * D].view(H, D), tot[H * D:2 * H * D].view(D, H)
-            gb1, gb2 = tot[2 * H * D:2 * H * D + H], tot[2 * H * D + H:]
+            pW1, pb1, pW2, pb2 = ctx.param_ptrs
+            # part (workgroups, [dW1 | dW2 | db1 | db2]); rows are summed in workgroup order: deterministic
+            _, gW1 = _DEFERRED.reduce(pW1, part, 0, H * D)
+            _, gW2 = _DEFERRED.reduce(pW2, part, H * D, H * D)
+            _, gb1 = _DEFERRED.reduce(pb1, part, 2 * H * D, H)
+            _, gb2 = _DEFERRED.reduce(pb2, part, 2 * H * D + H, D)
+            gW1 = gW1.view(H, D) if gW1 is not None else None
+            gW2 = gW2.view(D, H) if gW2 is not None else None
         return (g_ha if need[0] else None, g_out if need[1] else None, gW1 if need[2] else None, gb1 if need[3] else None,
                 gW2 if need[4] else None, gb2 if need[5] else None, None, None, None)
 

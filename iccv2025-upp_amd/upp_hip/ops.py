@@ -389,21 +389,25 @@ def posenc_fwd(x, freqs, out=None, col0=0):
 
 # ------------------------------------------------------------------ optimizer tail
 def batched_sum(jobs):
-    """jobs: list of (src (n, ...) contiguous f32, dst (...) contiguous f32): dst = src.sum(0), all in one launch."""
+    """jobs: list of (part 2-D f32, column offset, rows n, length, row stride, dst f32 (length elems), accumulate):
+    dst (+)= sum over the n rows of part[:, offset:offset+length], every job in one launch (upp_batched_sum)."""
     if not jobs:
         return
     import ctypes
     k = len(jobs)
-    src = (ctypes.c_void_p * k)(*[j[0].data_ptr() for j in jobs])
-    dst = (ctypes.c_void_p * k)(*[j[1].data_ptr() for j in jobs])
-    n = (ctypes.c_int * k)(*[j[0].shape[0] for j in jobs])
-    ln = (ctypes.c_int * k)(*[j[1].numel() for j in jobs])
-    for s_, d_ in jobs:
-        _need(s_, "src", torch.float32)
-        _need(d_, "dst", torch.float32)
-        if s_.numel() != s_.shape[0] * d_.numel():
-            raise RuntimeError("batched_sum: dst must have the shape of one row of src")
-    _call(jobs[0][0].device, "upp_batched_sum", src, dst, n, ln, k)
+    for part, off, n, length, ld, dst, acc in jobs:
+        _need(dst, "dst", torch.float32)
+        if not part.is_cuda or part.dtype != torch.float32 or part.dim() != 2 or part.stride(1) != 1 or part.stride(0) != ld:
+            raise RuntimeError("batched_sum: part must be a HIP f32 matrix with contiguous rows")
+        if n != part.shape[0] or off < 0 or off + length > part.shape[1] or dst.numel() != length:
+            raise RuntimeError("batched_sum: job geometry does not match its tensors")
+    src = (ctypes.c_void_p * k)(*[j[0].data_ptr() + 4 * j[1] for j in jobs])
+    dst = (ctypes.c_void_p * k)(*[j[5].data_ptr() for j in jobs])
+    n = (ctypes.c_int * k)(*[j[2] for j in jobs])
+    ln = (ctypes.c_int * k)(*[j[3] for j in jobs])
+    ld = (ctypes.c_int * k)(*[j[4] for j in jobs])
+    acc = (ctypes.c_int * k)(*[int(bool(j[6])) for j in jobs])
+    _call(jobs[0][0].device, "upp_batched_sum", src, dst, n, ln, ld, acc, k)
 
 
 def adamw_flat(p, g, m, v, n, split, state, scratch, lr, beta1, beta2, eps, weight_decay, max_norm):

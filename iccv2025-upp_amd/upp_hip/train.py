@@ -103,6 +103,8 @@ class TrainStep:
         self.labels = torch.zeros(batch_shape[0], dtype=torch.long, device=self.device)
         self.loss = torch.zeros((), device=self.device)
         self._g_fb = self._g_opt = None
+        self._grad_targets = ({p.data_ptr(): v for p, v in zip(self.trainable, self.flat.views)}
+                              if self.device.type == 'cuda' else None)
 
     # -- the two halves of a step ------------------------------------------------------------
     def _forward_backward(self):
@@ -111,10 +113,14 @@ class TrainStep:
             p.grad = None              # let autograd write fresh gradients: no per-parameter accumulate kernels
         logits = self.model(self.pts, **self.kw)
         loss, acc = self.model.get_loss_acc(logits, self.labels)
-        with HF.deferred_sums():       # the partial-sum reductions of all parameter gradients: one launch after the pass
+        # partial-sum reductions of parameter gradients: one launch after the pass, straight into the (zeroed) flat buffer
+        with HF.deferred_sums(self._grad_targets) as scope:
             loss.backward()
-        got = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None]
+        got = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None and p.data_ptr() not in scope.routed]
         torch._foreach_copy_([v for v, _ in got], [g for _, g in got])   # one multi-tensor copy into the flat buffer
+        both = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None and p.data_ptr() in scope.routed]
+        if both:                       # a parameter with a routed sum AND an autograd gradient: add the latter
+            torch._foreach_add_([v for v, _ in both], [g for _, g in both])
         for p, v in zip(self.trainable, self.flat.views):
             p.grad = v
         self.flat.scalars[0].copy_(loss.detach())

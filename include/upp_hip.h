@@ -268,10 +268,13 @@ int upp_posenc_fwd(const float *x, const float *freqs, int F, float *out, int ld
  * g is overwritten with the clipped gradient (as clip_grad_norm_ does).  max_norm <= 0 disables clipping.
  * scratch: upp_adamw_scratch_floats() floats. */
 long long upp_adamw_scratch_floats(void);
-/* upp_batched_sum: dst_j (len_j) = sum over the n_j rows of src_j (n_j, len_j), for `jobs` independent jobs in one launch
- * (rows added in ascending order).  src / dst / n / len are HOST arrays; the pointers in them are device pointers.
- * Used for the parameter-gradient partials of a backward pass (see upp_adapter_bwd, upp_ln_param_grad, upp_rowln_bwd). */
-int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, int jobs, void *stream);
+/* upp_batched_sum: for `jobs` independent jobs in one launch, dst_j[c] (+)= sum_{i < n_j} src_j[i * ld_j + c], c < len_j
+ * (rows added in ascending order; accumulate_j != 0 adds to dst_j, else overwrites).  src / dst / n / len / ld /
+ * accumulate are HOST arrays; the pointers in src / dst are device pointers.  Used for the parameter-gradient partials of
+ * a backward pass (upp_adapter_bwd partials per workgroup, upp_ln_param_grad partials per chunk, upp_rowln_bwd per-sample
+ * prompt gradients), summed straight into the flat gradient buffer after the pass. */
+int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, const int *ld,
+                    const int *accumulate, int jobs, void *stream);
 int upp_adamw_flat(float *p, float *g, float *m, float *v, long long n, long long split, float *state, float *scratch,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, void *stream);
 

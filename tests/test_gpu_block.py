@@ -300,29 +300,80 @@ def test_fused_propagation_matches_pool_batchnorm_interp(B, Lp, off, training, d
 def test_batched_sum_and_deferred_scope():
     from upp_hip import ops
     g = torch.Generator(device='cuda').manual_seed(1)
-    shapes = [(75, 24992), (32, 384), (32, 10, 384), (1, 5), (33, 1), (17, 300)] * 13      # 78 jobs -> two launches
-    jobs = [(torch.randn(*s, device='cuda', generator=g), torch.empty(s[1:], device='cuda')) for s in shapes]
+    shapes = [(75, 24992), (32, 384), (32, 3840), (1, 5), (33, 1), (17, 300)] * 13      # 78 jobs -> two launches
+    jobs = []
+    for n, width in shapes:
+        part = torch.randn(n, width, device='cuda', generator=g)
+        off = 0 if width < 10 else 3
+        length = width - off - (0 if width < 10 else 2)
+        acc = len(jobs) % 2 == 1
+        dst = torch.full((length,), 2.0 if acc else float('nan'), device='cuda')
+        jobs.append((part, off, n, length, part.stride(0), dst, acc))
     ops.batched_sum(jobs)
-    for src, dst in jobs:
-        ref = src[0].clone()
-        for i in range(1, src.shape[0]):
-            ref += src[i]                         # ascending row order, as the kernel
-        assert torch.equal(dst, ref)
-    # the deferred scope returns the same gradients as immediate sums
+    for part, off, n, length, ld, dst, acc in jobs:
+        ref = part[0, off:off + length].clone()
+        for i in range(1, n):
+            ref += part[i, off:off + length]          # ascending row order, as the kernel
+        assert torch.equal(dst, ref + 2.0 if acc else ref)
+    # a deferred scope accumulates the same parameter gradients into the registered buffers
     torch.manual_seed(0)
-    x = torch.randn(32, 75, 384, device='cuda')
+    x = torch.randn(32, 65, 384, device='cuda')
     ln = torch.nn.LayerNorm(384).cuda()
     prompts = torch.randn(10, 384, device='cuda', requires_grad=True)
-    outs = []
-    for deferred in (False, True):
-        xi = x[:, :65].clone().requires_grad_(True)
+    wgt = None
+    def loss_of(xi):
         xo, h = HF.rowln(xi, prompts=prompts, mode=HF.ROW_INSERT_CLS, P=10, gamma=ln.weight, beta=ln.bias, eps=ln.eps)
-        loss = (h * torch.linspace(-1, 1, h.numel(), device='cuda').view_as(h)).sum() + xo.square().sum()
-        if deferred:
-            with HF.deferred_sums():
-                gr = torch.autograd.grad(loss, [xi, prompts, ln.weight, ln.bias])
+        return (h * torch.linspace(-1, 1, h.numel(), device='cuda').view_as(h)).sum() + xo.square().sum()
+    params = [prompts, ln.weight, ln.bias]
+    xi = x.clone().requires_grad_(True)
+    want = torch.autograd.grad(loss_of(xi), [xi] + params)
+    targets = {p.data_ptr(): torch.zeros_like(p) for p in params}
+    xi = x.clone().requires_grad_(True)
+    with HF.deferred_sums(targets) as scope:
+        got = torch.autograd.grad(loss_of(xi), [xi] + params, allow_unused=True)
+    assert got[1] is None and got[2] is None and got[3] is None and scope.routed == set(targets)
+    close(got[0], want[0], rtol=1e-6, atol_scale=1e-6)
+    for p_, w in zip(params, want[1:]):      # same partials, summed sequentially (kernel) vs torch's tree order: f32 reassociation
+        close(targets[p_.data_ptr()], w, rtol=1e-4, atol_scale=2e-4)
+
+
+def test_train_step_flat_gradients_equal_plain_autograd():
+    """TrainStep (deferred sums, flat buffer, HIP graph) against loss.backward() on the same weights and batch."""
+    from upp_hip.train import TrainStep, freeze_for_peft
+    m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda().eval()
+    freeze_for_peft(m)
+    pts = _seeded.noisy_clouds(4, 1024, seed=9).cuda()
+    labels = torch.tensor([1, 5, 9, 30], device='cuda')
+    kw = dict(completion_prompt=True, denoise=True, point_num=1024)
+
+    def reference():
+        for p in m.parameters():
+            p.grad = None
+        loss, _ = m.get_loss_acc(m(pts, **kw), labels)
+        loss.backward()
+        out = {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+        for p in m.parameters():
+            p.grad = None
+        return out
+
+    names = {id(p): n for n, p in m.named_parameters()}
+    for use_graph in (False, True):
+        ts = TrainStep(m, tuple(pts.shape), use_graph=use_graph)
+        ts.pts.copy_(pts); ts.labels.copy_(labels)
+        if use_graph:
+            ts._capture()                      # warm-up steps move the weights: take the reference afterwards
+        want = reference()
+        if use_graph:
+            ts._g_fb.replay()
         else:
-            gr = torch.autograd.grad(loss, [xi, prompts, ln.weight, ln.bias])
-        outs.append(gr)
-    for a, b in zip(*outs):      # same partials, summed sequentially (kernel) vs torch's tree order: f32 reassociation only
-        close(a, b, rtol=1e-4, atol_scale=2e-4)
+            ts._forward_backward()
+        torch.cuda.synchronize()
+        checked = 0
+        for p, v in zip(ts.trainable, ts.flat.views):
+            n = names[id(p)]
+            if n in want:
+                close(v, want[n], rtol=2e-4, atol_scale=2e-4)
+                checked += 1
+            else:
+                assert float(v.abs().max()) == 0.0
+        assert checked > 100
