@@ -27,7 +27,9 @@ class PromptedBackbone(nn.Module):
     transformer, the rectify (denoising) prompter and the completion prompter with its MAE decoder
     (reference models/Point_MAE_unify.py:392-474,541-610 == models/Point_MAE_unify_segment.py:330-408,482-561)."""
 
-    def _build_backbone(self, config):
+    def _build_backbone(self, config, vis_base=64):
+        """vis_base: the group count the visible/masked split is derived from -- hard-wired 64 in the unify models
+        (reference Point_MAE_unify.py:404), `num_group` in the pre-task model (Point_MAE_pretask_dev.py:533)."""
         self.config = config
         tc = config.transformer_config
         self.trans_dim = tc.trans_dim
@@ -38,9 +40,10 @@ class PromptedBackbone(nn.Module):
         self.drop_path_rate = tc.drop_path_rate
         self.group_size = config.group_size
         self.num_group = config.num_group
-        self.vis_num = 64 - int(self.mask_ratio * 64)   # hard-wired to 64, not num_group (reference :404)
+        self.vis_num = vis_base - int(self.mask_ratio * vis_base)
+        self.n_masked = int(vis_base - self.vis_num)
         self.vis_short = 16
-        self.cls_dim = config.cls_dim
+        self.cls_dim = config.get('cls_dim') if hasattr(config, 'get') else getattr(config, 'cls_dim', None)
         D = self.trans_dim
 
         self.encoder = Encoder(encoder_channel=self.encoder_dims)
@@ -49,7 +52,7 @@ class PromptedBackbone(nn.Module):
                                          num_heads=self.num_heads, **self.config.prompter_config)
         self.norm = nn.LayerNorm(D)
         self.shape_pred = _mlp2(D, D // 2, self.vis_short)
-        self.coarse_pred = _mlp2(self.vis_short * self.vis_num, D, 3 * int(64 - self.vis_num))
+        self.coarse_pred = _mlp2(self.vis_short * self.vis_num, D, 3 * self.n_masked)
         self.predict_token_generator = _mlp2(D, 128, D)
         self.mask_token = nn.Parameter(torch.zeros(1, 1, D))
         self.decoder_pos_embed = _mlp2(3, 128, D)
@@ -107,17 +110,27 @@ class PromptedBackbone(nn.Module):
     def _complete(self, pts, point_num):
         """Completion prompter (reference :572-610): predict 32 missing centres and 32x32 points
         around them, append a quarter of them and re-sample to point_num."""
-        B = pts.shape[0]
         grouper = Group(num_group=self.vis_num, group_size=16)
         neighborhood, vis_center = grouper(pts)
-        x_vis = self.encoder(neighborhood).reshape(B, -1, self.trans_dim)
+        _, rebuild = self._reconstruct(self.encoder(neighborhood), vis_center)
+        sampled, _ = misc.fps(rebuild, point_num // 4)
+        pts = torch.cat([pts, sampled], dim=1).contiguous()
+        if pts.shape[1] > point_num:
+            pts = misc.fps(pts, point_num)[0]
+        return pts
+
+    def _reconstruct(self, tokens, vis_center):
+        """Visible tokens -> (predicted centres of the missing groups (B,n_masked,3), rebuilt points (B,n_masked*group_size,3))
+        through the pretask path of the backbone and the MAE decoder (reference :584-606, pretask_dev.py:713-737)."""
+        B = tokens.shape[0]
+        x_vis = tokens.reshape(B, -1, self.trans_dim)
         pos = self.pos_embed(vis_center)
         x_vis = self.blocks(x_vis, pos, path='pretask', pretask_adapter=True, pretask_prompts=True,
                             pretask_depth=self.config.prompter_config['pretask_depth'])
         x_vis = self.norm(x_vis)
         pos_vis = self.decoder_pos_embed(vis_center).reshape(B, -1, self.trans_dim)
         shape_feature = self.shape_pred(x_vis).reshape(B, self.vis_short * self.vis_num)
-        predict_center = self.coarse_pred(shape_feature).reshape(B, int(64 - self.vis_num), 3)
+        predict_center = self.coarse_pred(shape_feature).reshape(B, self.n_masked, 3)
         predict_token = self.predict_token_generator(x_vis)
         pos_mask = self.decoder_pos_embed(predict_center).reshape(B, -1, self.trans_dim)
         N = pos_mask.shape[1]
@@ -128,12 +141,7 @@ class PromptedBackbone(nn.Module):
         M = x_rec.shape[1]
         head = self.dense_pred[0]                                  # Conv1d(D, 3*group_size, 1) == a per-token Linear
         rel = F.linear(x_rec, head.weight.squeeze(-1), head.bias).reshape(B, M, -1, 3)
-        rebuild = (rel + predict_center.unsqueeze(-2)).reshape(B, -1, 3)
-        sampled, _ = misc.fps(rebuild, point_num // 4)
-        pts = torch.cat([pts, sampled], dim=1).contiguous()
-        if pts.shape[1] > point_num:
-            pts = misc.fps(pts, point_num)[0]
-        return pts
+        return predict_center, (rel + predict_center.unsqueeze(-2)).reshape(B, -1, 3)
 
 
 @MODELS.register_module()

@@ -10,6 +10,9 @@ Fixtures (all eval mode, key-seeded weights from tests/_seeded.py):
   upp_seg.npz      Point_MAE_unify_seg (unify_shapenetpart_seg.yaml): log-probabilities of a noisy (2,1624,3) cloud
                    at 2048 label points (first 256 points + per-point sums / argmax of all) and of a clean run, NLL loss
   point_mae.npz    Point_MAE (pretrain.yaml): Chamfer-L2 loss and gradient norms for a fixed random mask
+  pretask.npz      Point_MAE_pretask_dev (pretask.yaml) in TRAIN mode with every dropout / drop-path probability set to 0:
+                   predicted centres, rebuilt points, noise loss, recall, the three Chamfer-L1 terms of the pre-task recipe
+                   (tools/runner_pretask.py:220-225) and the gradient norm of every parameter
   upp_modules.npz  per-module input/output pairs: Encoder, Attention, Block (downstream path
                    with prompt propagation incl. the index-stride behaviour), TransformerDecoder,
                    RectifyPrompter, propagate, Group index outputs
@@ -32,10 +35,56 @@ PEFT_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 
              'cls_head_finetune']  # reference tools/runner_module.py:62-66
 
 
+def deterministic_train_mode(model):
+    """train() with all stochastic layers neutralised (shared by the fixture generator and the tests)."""
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, 'drop_prob'):
+            m.drop_prob = 0.0
+    return model
+
+
+def pretask_inputs():
+    gt = _seeded.unit_ball_clouds(2, 1280, seed=31)
+    partial, cropping = gt[:, :1024].contiguous(), gt[:, 1024:].contiguous()
+    noise = _seeded.noisy_clouds(2, 1024, seed=32)[:, 1024:1076].contiguous()      # 52 outlier points
+    return gt, partial, cropping, torch.cat([partial, noise], dim=1).contiguous()
+
+
+def gen_pretask(R, out_dir):
+    model = R.MODELS.build(ref_shim.model_cfg('pretask'))
+    deterministic_train_mode(_seeded.fill(model))
+    gt, partial, cropping, points = pretask_inputs()
+    from extensions.chamfer_dist import ChamferDistanceL1
+    cd = ChamferDistanceL1()
+    center, rebuild, noise_loss, recall = model(points, point_num=1024, train_with_gaussian=True, predict_center_num=16)
+    coarse, crop_dense, dense = cd(center, cropping), cd(rebuild, cropping), cd(torch.cat([partial, rebuild], dim=1), gt)
+    loss = coarse + crop_dense + dense + noise_loss
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    names = sorted(grads)
+    model.eval()
+    with torch.no_grad():
+        center_eval, rebuild_eval = model(partial, point_num=1024, train_with_gaussian=False)
+    np.savez_compressed(os.path.join(out_dir, "pretask.npz"), center=center.detach().numpy(), rebuild=rebuild.detach().numpy(),
+                        noise_loss=noise_loss.detach().numpy(), recall=recall.numpy(), coarse=coarse.detach().numpy(),
+                        crop_dense=crop_dense.detach().numpy(), dense=dense.detach().numpy(), loss=loss.detach().numpy(),
+                        grad_names=np.array(names), grad_norms=np.array([grads[n].norm().item() for n in names]),
+                        center_eval=center_eval.numpy(), rebuild_eval_head=rebuild_eval[:, :128].numpy(),
+                        n_params=np.array(sum(p.numel() for p in model.parameters())), n_keys=np.array(len(model.state_dict())))
+    print("pretask loss", loss.item(), "noise", noise_loss.item(), "recall", recall.item(), "params", sum(p.numel() for p in model.parameters()),
+          "keys", len(model.state_dict()), "grads", len(names))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_shim.load()
+    if sys.argv[1:] == ['pretask']:
+        gen_pretask(R, os.path.join(ROOT, "tests", "golden"))
+        return
     cfg = ref_shim.model_cfg()
     model = R.MODELS.build(cfg)
     _seeded.fill(model).eval()
@@ -146,7 +195,8 @@ def main():
                         g_mask_token=mg['mask_token'].numpy(), g_increase_bias=mg['increase_dim.0.bias'].numpy(),
                         n_params=np.array(sum(p_.numel() for p_ in mae.parameters())), n_keys=np.array(len(mae.state_dict())))
     print("point_mae loss", mloss.item(), "params", sum(p_.numel() for p_ in mae.parameters()), "masked", int(used_mask[0].sum()))
-    for f in ("upp_model.npz", "upp_modules.npz", "upp_seg.npz", "point_mae.npz"):
+    gen_pretask(R, out_dir)
+    for f in ("upp_model.npz", "upp_modules.npz", "upp_seg.npz", "point_mae.npz", "pretask.npz"):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
 
 

@@ -103,7 +103,15 @@ def load():
         return [torch.from_numpy(t) for t in O.chamfer_bwd(a.detach().numpy(), b.detach().numpy(), i1.numpy(), i2.numpy(),
                                                            g1.contiguous().numpy(), g2.contiguous().numpy())]
 
-    _mod('pytorch3d'); _mod('pytorch3d.ops'); _mod('chamfer', forward=_ch_fwd, backward=_ch_bwd); _mod('emd_cuda')
+    def knn_points(p1, p2, K=1, return_nn=False, **_):
+        """pytorch3d.ops.knn_points restated on the oracle kNN: K nearest p2 points of every p1 point, ascending distance."""
+        d, i = O.knn(p2.detach().numpy(), p1.detach().numpy(), K)            # (B, n1, K) distances (sqrt) and indices
+        i = torch.from_numpy(i)
+        nn_pts = torch.gather(p2.unsqueeze(1).expand(-1, p1.shape[1], -1, -1), 2, i.unsqueeze(-1).expand(-1, -1, -1, 3)) if return_nn else None
+        return torch.from_numpy(d) ** 2, i, nn_pts
+
+    p3 = _mod('pytorch3d.ops', knn_points=knn_points)
+    _mod('pytorch3d', ops=p3); _mod('chamfer', forward=_ch_fwd, backward=_ch_bwd); _mod('emd_cuda')
     _mod('knn_cuda', KNN=KNN)
     p2u = _mod('pointnet2_ops.pointnet2_utils', furthest_point_sample=furthest_point_sample,
                gather_operation=gather_operation)
