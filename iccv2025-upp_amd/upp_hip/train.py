@@ -69,6 +69,8 @@ class FlatAdamW:
                 view.copy_(q)
                 q.data = view                      # the model now reads its trainable weights from the flat buffer
                 off += q.numel()
+        self._shapes = [tuple(q.shape) for q in params]
+        self._n_no_decay = len(no_decay)
         self.g = flat_grad
         self.m = torch.zeros(self.n, device=dev)
         self.v = torch.zeros(self.n, device=dev)
@@ -79,6 +81,45 @@ class FlatAdamW:
     def step(self):
         lr, b1, b2, eps, wd, mn = self.hyper
         self._ops.adamw_flat(self.p, self.g, self.m, self.v, self.n, self.split, self.state, self.scratch, lr, b1, b2, eps, wd, mn)
+
+    # -- checkpoint contract: the state_dict layout of torch.optim.AdamW with the two groups of make_adamw, so a
+    #    checkpoint written by the reference loop (tools/builder.py:131-140) resumes here and vice versa
+    def state_dict(self):
+        lr, b1, b2, eps, wd, _ = self.hyper
+        step = self.state[0].detach().cpu().clone()
+        state, off = {}, 0
+        for i, shp in enumerate(self._shapes):
+            n = int(torch.tensor(shp).prod()) if shp else 1
+            state[i] = {'step': step.clone(), 'exp_avg': self.m[off:off + n].view(shp).clone(),
+                        'exp_avg_sq': self.v[off:off + n].view(shp).clone()}
+            off += n
+        k = self._n_no_decay
+        common = dict(lr=lr, betas=(b1, b2), eps=eps, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                      differentiable=False, fused=None)
+        groups = [dict(common, weight_decay=0., params=list(range(k))),
+                  dict(common, weight_decay=wd, params=list(range(k, len(self._shapes))))]
+        return {'state': state, 'param_groups': groups}
+
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        order = [i for g in groups for i in g['params']]
+        if len(order) != len(self._shapes):
+            raise ValueError("optimizer state has %d parameters, expected %d" % (len(order), len(self._shapes)))
+        off, step = 0, 0.0
+        with torch.no_grad():
+            for i, shp in zip(order, self._shapes):
+                n = int(torch.tensor(shp).prod()) if shp else 1
+                st = sd['state'].get(i)
+                if st is not None:
+                    if tuple(st['exp_avg'].shape) != shp:
+                        raise ValueError("optimizer state %d has shape %s, expected %s" % (i, tuple(st['exp_avg'].shape), shp))
+                    self.m[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                    self.v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                    step = max(step, float(st['step']))
+                off += n
+            self.state[0] = step
+        g0 = groups[0]
+        self.hyper = (g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'], groups[-1]['weight_decay'], self.hyper[5])
 
 
 class TrainStep:
