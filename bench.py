@@ -10,8 +10,10 @@ run on the hand-written gfx950 kernels through the C ABI; inputs are resident in
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant hand-written kernel, timed live
-with HIP events on the launch stream), `stages` (stand-alone FPS+kNN+Group timings and GB/s),
-`cpu_baseline` (same step on the host cores with the CPU oracle, bounded sample).
+with HIP events on the launch stream),
+`kernels` (stand-alone timings of the hand-written kernels against their rooflines; `traffic` = HBM bytes per call from
+the committed rocprofv3 --pmc passes, profiles/r01_pmc_kernels.json), `cpu_baseline` (same step on the host cores with
+the CPU oracle, bounded sample).
 """
 import argparse
 import json
@@ -109,11 +111,16 @@ def stage_report(device, B):
     from upp_hip import functional as HF, ops
     pmc = _pmc_traffic()
 
-    def traffic(prefix):
-        for k, v in pmc.items():
-            if k.startswith(prefix):
-                return v
-        return None
+    def traffic(keys):
+        """HBM bytes per call: sum over the kernels of the call (key prefix, or (prefix, launches per call))."""
+        total = 0.0
+        for key in (keys if isinstance(keys, (list, tuple)) else [keys]):
+            prefix, times = key if isinstance(key, tuple) else (key, 1)
+            hit = [v for k, v in pmc.items() if k.startswith(prefix)]
+            if not hit:
+                return None
+            total += times * hit[0]
+        return total
 
     def hbm(name, ms, nbytes, pmc_key=None, note=None):
         gbs = nbytes / ms / 1e6
@@ -132,7 +139,7 @@ def stage_report(device, B):
     out = {}
     t = time_kernel(lambda: ops.fps(x1228, 1024, want_centers=True), iters=5)
     out["fps_1228_1024"] = hbm("fps_kernel<8,4> (B,1228)->1024", t, B * (1228 * 12 + 1024 * 16), "fps_kernel<8, 4",
-                               "1023 dependent arg-max rounds per cloud: latency-bound by construction (0.57 us/round)")
+                               "1023 dependent arg-max rounds per cloud: latency-bound by construction (%.2f us/round)" % (t * 1e3 / 1023))
     t = time_kernel(lambda: ops.fps(x, 64, want_centers=True))
     out["fps_1024_64"] = hbm("fps_kernel<4,4> (B,1024)->64", t, B * (1024 * 12 + 64 * 16), "fps_kernel<4, 4")
     t = time_kernel(lambda: ops.knn(x, cen, 32, want_dist=False, want_neigh=True))
@@ -161,6 +168,51 @@ def stage_report(device, B):
     ctx, lse = ops.attn_fwd(qkv, B, 75, 6, 0.125)
     t = time_kernel(lambda: ops.attn_bwd(qkv, ctx, ctx, lse, B, 75, 6, 0.125))
     out["attn_bwd"] = mfma("attn_bwd_mfma_kernel L=75 H=6", t, 10.0 * B * 6 * 75 * 75 * 64)
+    # fused propagation step of a block (pool -> BatchNorm -> interpolate), forward and backward
+    Lp, T, G2, D = 75, 64, 32, 384
+    X = torch.randn(B, Lp, D, device=device)
+    base = (torch.arange(B, device=device) * Lp + (Lp - T)).view(B, 1)
+    i1 = (base + torch.randint(0, T, (B, G2 * 8), device=device)).reshape(-1).int().contiguous()
+    i2 = (base + torch.stack([torch.randperm(T, device=device)[:G2] for _ in range(B)])).reshape(-1).int().contiguous()
+    idx8 = torch.randint(0, G2, (B, T, 8), device=device).int().contiguous()
+    w8 = torch.softmax(torch.randn(B, T, 8, device=device), -1).contiguous()
+    index = HF.PropIndex(i1, i2, idx8, w8, B * Lp)
+    gam, bet = torch.ones(D, device=device), torch.zeros(D, device=device)
+    rm, rv = torch.zeros(D, device=device), torch.ones(D, device=device)
+    t = time_kernel(lambda: ops.prop_fwd(X, i1, None, 1.0, i2, idx8, w8, gam, bet, rm, rv, 0.1, 1e-5, True, B, Lp, T, G2))
+    rows_b = B * Lp * D * 4
+    out["prop_fwd"] = hbm("upp_prop_fwd: pool+stats | BN finalize | interpolate (3 launches)", t,
+                          rows_b * 2 + B * G2 * 8 * D * 4 + B * G2 * D * 5 + B * T * 8 * D * 8,
+                          ["prop_pool_stats_kernel", "bn_finalize_rows_kernel", "prop_interp_bn_fwd_kernel"])
+    _, pooled, amax, mean, rstd = ops.prop_fwd(X, i1, None, 1.0, i2, idx8, w8, gam, bet, rm, rv, 0.1, 1e-5, True, B, Lp, T, G2)
+    t = time_kernel(lambda: ops.prop_bwd(X, pooled, amax, mean, rstd, gam, None, 1.0, w8, index.csr1, index.csr2, index.csr8, True,
+                                         B, Lp, T, G2))
+    out["prop_bwd"] = hbm("upp_prop_bwd: c2 (CSR) | BN grads | g_X (CSR) (3 launches)", t,
+                          rows_b * 2 + B * T * 8 * D * 4 + B * G2 * D * 4 * 3 + B * G2 * 8 * D * 9,
+                          ["prop_c2_csr_kernel", "prop_bn_grad_kernel", "prop_x_csr_kernel"])
+    # bottleneck adapter, forward and backward (MFMA; tiny FLOP count -- the bound is the launch + staging latency)
+    R = B * Lp
+    ha, xa = torch.randn(R, D, device=device), torch.randn(R, D, device=device)
+    W1, bb1 = torch.randn(32, D, device=device) * 0.05, torch.zeros(32, device=device)
+    W2, bb2 = torch.randn(D, 32, device=device) * 0.05, torch.zeros(D, device=device)
+    ud = torch.rand(R, 32, device=device)
+    t = time_kernel(lambda: ops.adapter_fwd(ha, xa, W1, bb1, W2, bb2, ud, 0.1, 0.7))
+    out["adapter_fwd"] = hbm("adapter_fwd_kernel<384> (2400 rows)", t, R * D * 4 * 3 + R * 32 * 8 + 2 * 32 * D * 4, "adapter_fwd_kernel")
+    _, s1 = ops.adapter_fwd(ha, xa, W1, bb1, W2, bb2, ud, 0.1, 0.7)
+    t = time_kernel(lambda: ops.adapter_bwd(xa, ha, s1, W1, W2, ud, 0.1, 0.7))
+    out["adapter_bwd"] = hbm("adapter_bwd_kernel<384> (2400 rows, weight partials per workgroup)", t,
+                             R * D * 4 * 3 + R * 32 * 8 + ((R + 31) // 32) * (2 * 32 * D + 32 + D) * 4, "adapter_bwd_kernel")
+    # Chamfer / EMD stand-alone (BASELINE configs: two independent (32,1024,3) clouds)
+    ca, cb = _seeded.unit_ball_clouds(B, 1024, seed=5).to(device), _seeded.unit_ball_clouds(B, 1024, seed=6).to(device)
+    t = time_kernel(lambda: ops.chamfer_fwd(ca, cb))
+    out["chamfer_fwd"] = hbm("chamfer_dir_kernel x2 (B,1024)x(B,1024)", t, B * 40960, [("chamfer_dir_kernel", 2)],
+                             "VALU-bound: 2*n*m*8 flop = %.1f TFLOP/s f32 VALU" % (B * 2 * 1024 * 1024 * 8 / t / 1e9))
+    d1, d2, ix1, ix2 = ops.chamfer_fwd(ca, cb)
+    t = time_kernel(lambda: ops.chamfer_bwd(ca, cb, ix1, ix2, d1, d2))
+    out["chamfer_bwd"] = hbm("chamfer_grad_kernel (B,1024)x(B,1024)", t, B * 65536, "chamfer_grad_kernel")
+    t = time_kernel(lambda: ops.emd_approxmatch(ca, cb), iters=3)
+    out["emd_approxmatch"] = hbm("upp_emd_approxmatch (22 launches; match (B,1024,1024) written once)", t, B * (1024 * 1024 * 4 + 24576),
+                                 None, "exp-bound: 30 passes x n x m exp evaluations")
     return out
 
 

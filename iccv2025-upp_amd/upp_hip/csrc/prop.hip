@@ -291,11 +291,15 @@ inline dim3 rows_grid(long long rows) { return dim3((unsigned)((rows + 3) / 4));
 // key(q) = (q / seg_len) * seg_rows + keys[q]  (seg_rows = 0: keys are absolute).  Keys outside [0, rows) are skipped.
 // One workgroup of 1024 threads; counts and cursors live in LDS.
 constexpr int kCsrThreads = 1024;
+template <bool PERM_IN_LDS>
 __global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(const int32_t *__restrict__ keys, int n, int seg_len, int seg_rows,
-                                                                int rows, int32_t *__restrict__ start, int32_t *__restrict__ perm) {
+                                                                int rows, int32_t *__restrict__ start, int32_t *__restrict__ perm_out) {
     extern __shared__ int32_t lds_i[];
     int32_t *cnt = lds_i;                   // [rows]
     int32_t *scan = lds_i + rows;           // [kCsrThreads]
+    // the permutation is filled by atomics and then sorted per row: in LDS when it fits (an insertion sort on global
+    // memory is a chain of ~1 us round trips), written out coalesced at the end
+    int32_t *perm = PERM_IN_LDS ? scan + kCsrThreads : perm_out;
     const int tid = threadIdx.x;
     for (int r = tid; r < rows; r += kCsrThreads) cnt[r] = 0;
     __syncthreads();
@@ -356,6 +360,11 @@ __global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(const int32_t *_
             }
             base = end;
         }
+    }
+    if (PERM_IN_LDS) {
+        __syncthreads();
+        const int total = scan[kCsrThreads - 1];      // inclusive scan of the row counts: number of valid entries
+        for (int q = tid; q < total; q += kCsrThreads) perm_out[q] = perm[q];
     }
 }
 
@@ -662,7 +671,21 @@ extern "C" int upp_csr_build(const int32_t *keys, int n, int seg_len, int seg_ro
     if (!keys || !start || !perm || n < 1 || rows < 1 || seg_len < 1 || seg_rows < 0) return UPP_E_BADARG;
     const size_t lds = ((size_t)rows + kCsrThreads) * sizeof(int32_t);
     if (lds > 64 * 1024) return UPP_E_RANGE;    // counts of every row live in LDS (rows <= 15360)
-    hipLaunchKernelGGL(csr_build_kernel, dim3(1), dim3(kCsrThreads), lds, (hipStream_t)stream, keys, n, seg_len, seg_rows, rows, start, perm);
+    const size_t lds_perm = lds + (size_t)n * sizeof(int32_t);
+    if (lds_perm <= 150 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(csr_build_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) return (int)e;
+            raised = true;
+        }
+        hipLaunchKernelGGL(csr_build_kernel<true>, dim3(1), dim3(kCsrThreads), lds_perm, (hipStream_t)stream, keys, n, seg_len, seg_rows, rows,
+                           start, perm);
+    } else {
+        hipLaunchKernelGGL(csr_build_kernel<false>, dim3(1), dim3(kCsrThreads), lds, (hipStream_t)stream, keys, n, seg_len, seg_rows, rows,
+                           start, perm);
+    }
     return upp_launch_status();
 }
 

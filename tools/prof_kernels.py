@@ -27,7 +27,38 @@ pos = torch.randn(B, 65, 384, device='cuda')
 prm = torch.randn(10, 384, device='cuda')
 g1, b1 = torch.ones(384, device='cuda'), torch.zeros(384, device='cuda')
 qkv = torch.randn(B, 75, 1152, device='cuda', requires_grad=True)
+# fused propagation step, adapter, frozen-branch row operators, Chamfer / EMD at the headline shapes
+Lp, T, G2, D = 75, 64, 32, 384
+X = torch.randn(B, Lp, D, device='cuda', requires_grad=True)
+base = (torch.arange(B, device='cuda') * Lp + (Lp - T)).view(B, 1)
+i1 = (base + torch.randint(0, T, (B, G2 * 8), device='cuda')).reshape(-1).int().contiguous()
+i2 = (base + torch.stack([torch.randperm(T, device='cuda')[:G2] for _ in range(B)])).reshape(-1).int().contiguous()
+idx8 = torch.randint(0, G2, (B, T, 8), device='cuda').int().contiguous()
+w8 = torch.softmax(torch.randn(B, T, 8, device='cuda'), -1).contiguous()
+bn = torch.nn.BatchNorm1d(D).cuda()
+ha = torch.randn(B * Lp, D, device='cuda', requires_grad=True)
+xa_ = torch.randn(B * Lp, D, device='cuda', requires_grad=True)
+W1 = (torch.randn(32, D, device='cuda') * 0.05).requires_grad_(True); bb1 = torch.zeros(32, device='cuda', requires_grad=True)
+W2 = (torch.randn(D, 32, device='cuda') * 0.05).requires_grad_(True); bb2 = torch.zeros(D, device='cuda', requires_grad=True)
+ud = torch.rand(B * Lp, 32, device='cuda')
+rows = torch.randn(B * 1096, 32, device='cuda')
+bn32 = torch.nn.BatchNorm1d(32).cuda()
+xyz1, xyz2 = torch.rand(B, 1096, 3, device='cuda'), torch.rand(B, 64, 3, device='cuda')
+feat = torch.randn(B, 64, 32, device='cuda')
+ca, cb = _seeded.unit_ball_clouds(B, 1024, seed=5).cuda().requires_grad_(True), _seeded.unit_ball_clouds(B, 1024, seed=6).cuda()
+from models import upp_layers  # noqa: E402
 for _ in range(5):
+    index = HF.PropIndex(i1, i2, idx8, w8, B * Lp)
+    HF.propagate(X, bn, index, None, 1.0, True).sum().backward()
+    HF.adapter(ha, xa_, W1, bb1, W2, bb2, ud, 0.1, 0.7).sum().backward()
+    with torch.no_grad():
+        HF.bn_rows(rows, bn32, True, relu=True)
+        d_, i_ = upp_layers.square_distance(xyz1, xyz2).sort(dim=-1)
+        HF.interp(d_, i_, feat, 16, 1e-4)
+        HF.posenc(xyz1, [1.0, 2.0, 4.0, 8.0])
+    d1, d2 = HF.ChamferFunction.apply(ca, cb)
+    (d1.mean() + d2.mean()).backward()
+    HF.EarthMoverDistanceFunction.apply(ca.detach(), cb).sum()
     idx, cen = ops.fps(x, 64, want_centers=True)
     _, _, nb = ops.knn(x, cen, 32, want_dist=False, want_neigh=True)
     ops.fps(x1228, 1024, want_centers=True)
