@@ -56,6 +56,10 @@ __device__ __forceinline__ void mfma_tile(f32x16 &acc, const float *a, int lda, 
     else if (K == 64) mfma_tile_k<TA, TB, 64>(acc, a, lda, b, ldb, lr, lk);
     else mfma_tile_k<TA, TB, 96>(acc, a, lda, b, ldb, lr, lk);
 }
+// exp(x) for x <= 0 as v_exp_f32(x * log2 e): relative error ~ |x| * 6e-8 (the product's rounding), i.e. < 2e-6 for every
+// term that matters in a softmax (x > -30); libm's expf costs ~40 VALU instructions per element and made the softmax
+// the longest phase of the forward kernel.
+__device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ void zero(f32x16 &a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = 0.0f;
@@ -112,17 +116,36 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float *__restr
         for (int r = 0; r < 16; ++r) Ss[(it * 32 + tile_row(r, lk)) * kLS + jt * 32 + lr] = acc[r] * scale;
     }
     __syncthreads();
-    for (int i = wave; i < L; i += 4) {                 // row softmax, lane = key (2 slots cover 96 columns... 64+32)
-        float *row = Ss + i * kLS;
-        const float s0 = lane < L ? row[lane] : -__builtin_inff();
-        const float s1 = lane + 64 < L ? row[lane + 64] : -__builtin_inff();
-        const float mx = wave_max_f32(fmaxf(s0, s1));
-        const float e0 = lane < L ? expf(s0 - mx) : 0.0f, e1 = lane + 64 < L ? expf(s1 - mx) : 0.0f;
-        const float sum = wave_sum_f32(e0 + e1);
-        const float inv = 1.0f / sum;
-        row[lane] = e0 * inv;
-        if (lane + 64 < kLP) row[lane + 64] = e1 * inv;
-        if (lane == 0) lse[((size_t)b * H + hh) * L + i] = mx + logf(sum);
+    // row softmax, lane = key (2 slots cover the 96 columns).  A wave takes FOUR rows per iteration: the reductions
+    // are latency chains (DPP + readlane), four independent ones interleave in the pipeline.
+    for (int i0 = wave * 4; i0 < L; i0 += 16) {
+        float s0[4], s1[4], mx[4], e0[4], e1[4], sum[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float *row = Ss + min(i0 + q, L - 1) * kLS;
+            s0[q] = lane < L ? row[lane] : -__builtin_inff();
+            s1[q] = lane + 64 < L ? row[lane + 64] : -__builtin_inff();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mx[q] = wave_max_f32(fmaxf(s0[q], s1[q]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            e0[q] = lane < L ? exp_neg(s0[q] - mx[q]) : 0.0f;
+            e1[q] = lane + 64 < L ? exp_neg(s1[q] - mx[q]) : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum[q] = wave_sum_f32(e0[q] + e1[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q;
+            if (i < L) {
+                float *row = Ss + i * kLS;
+                const float inv = 1.0f / sum[q];
+                row[lane] = e0[q] * inv;
+                if (lane + 64 < kLP) row[lane + 64] = e1[q] * inv;
+                if (lane == 0) lse[((size_t)b * H + hh) * L + i] = mx[q] + logf(sum[q]);
+            }
+        }
     }
     for (int i = L + wave; i < nt * 32; i += 4) {       // padded query rows contribute nothing
         Ss[i * kLS + lane] = 0.0f;
@@ -173,9 +196,13 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float *__restr
             ls[t] = (ok && lane == 0) ? lse[((size_t)b * H + hh) * L + i] : 0.0f;
         }
 #pragma unroll
-        for (int t = 0; t < RW; ++t) {
-            const float d = wave_sum_f32(g[t] * o[t]);
-            if (lane == 0) { delta[wave + 4 * t] = d; lses[wave + 4 * t] = ls[t]; }
+        for (int t0 = 0; t0 < RW; t0 += 4) {            // four independent reduction chains at a time
+            float d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[q] = wave_sum_f32(g[t0 + q] * o[t0 + q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (lane == 0) { delta[wave + 4 * (t0 + q)] = d[q]; lses[wave + 4 * (t0 + q)] = ls[t0 + q]; }
         }
     }
     __syncthreads();
@@ -189,12 +216,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float *__restr
         mfma_tile<false, true>(s, Qs + it * 32 * kLD, kLD, Ks + jt * 32 * kLD, kLD, 64, lr, lk);
         mfma_tile<false, true>(dp, Gs + it * 32 * kLD, kLD, Vs + jt * 32 * kLD, kLD, 64, lr, lk);
         const int j = jt * 32 + lr;
+        float lr_[16], dr_[16];                           // the 16 rows' lse / delta: one batch of LDS reads (rows < kLP always)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int i = it * 32 + tile_row(r, lk); lr_[r] = lses[i]; dr_[r] = delta[i]; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = it * 32 + tile_row(r, lk);
-            const float p = (i < L && j < L) ? expf(s[r] * scale - lses[i]) : 0.0f;
+            const float p = (i < L && j < L) ? exp_neg(s[r] * scale - lr_[r]) : 0.0f;
             s[r] = p;
-            dp[r] = p * (dp[r] - delta[i]) * scale;
+            dp[r] = p * (dp[r] - dr_[r]) * scale;
         }
         // static register indexing of the per-wave tile store
         if (nown == 0) { pt[0] = s; dst[0] = dp; } else if (nown == 1) { pt[1] = s; dst[1] = dp; } else { pt[2] = s; dst[2] = dp; }
