@@ -49,6 +49,50 @@ __device__ __forceinline__ void mfma_tile_k(f32x16 &acc, const float *a, int lda
         }
     }
 }
+// NB output tiles that share their A operand: acc[n] += A . B_n.  The NB accumulator chains are independent, so their
+// MFMAs interleave in the matrix pipe (a single chain issues a dependent MFMA only every ~2x its pass count: measured
+// 2.1-2.5x the MFMA-bound time for one-accumulator tiles), and A is read from LDS once for all NB tiles.
+template <bool TA, bool TB, int K, int NB>
+__device__ __forceinline__ void mfma_tiles_k(f32x16 (&acc)[NB], const float *a, int lda, const float *const (&b)[NB], int ldb, int lr, int lk) {
+    constexpr int CH = 8, NCH = K / 2 / CH;
+    static_assert(K % (2 * CH) == 0, "K must be a multiple of 16");
+    float av[CH], bv[NB][CH];
+    auto fetch = [&](int c, float (&x)[CH], float (&y)[NB][CH]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int k0 = (c * CH + i) * 2;
+            x[i] = TA ? a[(k0 + lk) * lda + lr] : a[lr * lda + k0 + lk];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) y[n][i] = TB ? b[n][lr * ldb + k0 + lk] : b[n][(k0 + lk) * ldb + lr];
+        }
+    };
+    fetch(0, av, bv);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float an[CH], bn[NB][CH];
+        if (c + 1 < NCH) fetch(c + 1, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[n][i], acc[n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                av[i] = an[i];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) bv[n][i] = bn[n][i];
+            }
+        }
+    }
+}
+template <bool TA, bool TB, int NB>
+__device__ __forceinline__ void mfma_tiles(f32x16 (&acc)[NB], const float *a, int lda, const float *const (&b)[NB], int ldb, int K, int lr, int lk) {
+    if (K == 32) mfma_tiles_k<TA, TB, 32, NB>(acc, a, lda, b, ldb, lr, lk);
+    else if (K == 64) mfma_tiles_k<TA, TB, 64, NB>(acc, a, lda, b, ldb, lr, lk);
+    else mfma_tiles_k<TA, TB, 96, NB>(acc, a, lda, b, ldb, lr, lk);
+}
 // K is a compile-time constant so that the operand loop unrolls fully and the LDS reads run ahead of the MFMAs
 template <bool TA, bool TB>
 __device__ __forceinline__ void mfma_tile(f32x16 &acc, const float *a, int lda, const float *b, int ldb, int K, int lr, int lk) {
@@ -152,15 +196,17 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float *__restr
         if (lane + 64 < kLP) Ss[i * kLS + lane + 64] = 0.0f;
     }
     __syncthreads();
-    for (int t = wave; t < nt * 2; t += 4) {            // O = P V
-        const int it = t >> 1, dt = t & 1;
-        f32x16 acc; zero(acc);
-        mfma_tile<false, false>(acc, Ss + it * 32 * kLS, kLS, Vs + dt * 32, kLD, nt * 32, lr, lk);
+    for (int it = wave; it < nt; it += 4) {             // O = P V: a wave owns a 32-row block, both 32-column halves at once
+        f32x16 acc[2]; zero(acc[0]); zero(acc[1]);
+        const float *const vb[2] = {Vs, Vs + 32};
+        mfma_tiles<false, false, 2>(acc, Ss + it * 32 * kLS, kLS, vb, kLD, nt * 32, lr, lk);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = it * 32 + tile_row(r, lk);
-            if (i < L) ctx[((size_t)b * L + i) * (H * 64) + hh * 64 + dt * 32 + lr] = acc[r];
-        }
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = it * 32 + tile_row(r, lk);
+                if (i < L) ctx[((size_t)b * L + i) * (H * 64) + hh * 64 + dt * 32 + lr] = acc[dt][r];
+            }
     }
 }
 
