@@ -188,9 +188,13 @@ class Point_MAE_unify(PromptedBackbone):
         tokens = self.encoder(neighborhood)
         B = tokens.size(0)
         x = torch.cat((self.cls_token.expand(B, -1, -1), tokens), dim=1)
-        pos = torch.cat((self.cls_pos.expand(B, -1, -1), self.pos_embed(center)), dim=1)
+        pos_tokens = self.pos_embed(center)
+        pos = torch.cat((self.cls_pos.expand(B, -1, -1), pos_tokens), dim=1)
 
         propagation = self._level2(center)
+        if torch.is_grad_enabled() and self.cls_pos.requires_grad and not pos_tokens.requires_grad:
+            # only row 0 of `pos` is trainable (PEFT): let the fused blocks route its gradient (see TransformerEncoder)
+            propagation['cls_pos_param'] = self.cls_pos
         x = self.blocks(x, pos, path='downstream', downstream_adapter=True, downstream_prompts=True,
                         classification=True, **propagation)
         x = self.norm(x)

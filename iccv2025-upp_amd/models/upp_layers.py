@@ -453,7 +453,8 @@ class Block(nn.Module):
             u = UNIFORMS.take((2, B), x.device)
             keep = 1.0 - self.drop_path.drop_prob
         n1, n2 = self.norm1, self.norm2
-        xa, h1 = HF.rowln(x, add=pos, prompts=prompts, mode=ins, P=P, gamma=n1.weight, beta=n1.bias, eps=n1.eps)
+        xa, h1 = HF.rowln(x, add=pos, prompts=prompts, mode=ins, P=P, gamma=n1.weight, beta=n1.bias, eps=n1.eps,
+                          cls_add=kw.get('_cls_pos'))
         y = self.attn(h1)
         x2, h2 = HF.rowln(xa, y=y, u=None if u is None else u[0], keep=keep, gamma=n2.weight, beta=n2.bias, eps=n2.eps)
         m = self.mlp(h2)
@@ -533,6 +534,13 @@ class TransformerEncoder(nn.Module):
             depth = kwargs['rectify_depth']
         if 'center1' in kwargs:
             kwargs['_prop_cache'] = {}      # per-forward scratch shared by the blocks (see Block._propagate_fused)
+        cls_pos = kwargs.pop('cls_pos_param', None)
+        if cls_pos is not None and all(b.fusable(x) for b in self.blocks[:depth]):
+            # `pos` is re-added in front of every block, so autograd would sum its (B,L,D) gradient once per block although
+            # only the cls row is trainable.  Detach it; every block's row kernel reduces the cls row of its input
+            # gradient into cls_pos instead (deferred with the other parameter-gradient sums under TrainStep).
+            pos = pos.detach()
+            kwargs['_cls_pos'] = cls_pos
         features = []                       # outputs of blocks 3, 7, 11 for the segmentation head
         for idx, block in enumerate(self.blocks[:depth]):   # (reference models/Point_MAE_unify_segment.py:223-234)
             x = block.forward_fused(x, pos, **kwargs) if block.fusable(x) else block(x + pos, **kwargs)

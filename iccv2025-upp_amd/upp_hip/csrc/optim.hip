@@ -63,34 +63,41 @@ __global__ __launch_bounds__(256) void adamw_update_kernel(float *__restrict__ p
 }
 
 // Column sums of many small partial-result matrices in ONE launch: job j reduces the n_j rows (row stride ld_j) of
-// src_j over its first dimension into dst_j (len_j), rows added in ascending order (deterministic); dst is overwritten
-// or accumulated into.  The parameter-gradient partials of a
-// backward pass (adapter weight partials per workgroup, LayerNorm gamma/beta partials per chunk, per-sample prompt
-// gradients) are summed here, after the pass, instead of by ~3 tiny reduce launches per transformer block.
+// src_j into dst_j (len_j), rows added in ascending order; dst is overwritten or accumulated into.  Jobs that share a
+// destination form a GROUP served by the same workgroups, one job after the other in submission order -- so several
+// partial matrices (e.g. the cls-position gradient of 12 blocks) can target one buffer without a race, and the
+// result is deterministic.  The parameter-gradient partials of a backward pass (adapter weight partials per workgroup,
+// LayerNorm gamma/beta partials per chunk, per-sample prompt gradients) are summed here, after the pass, instead of by
+// ~3 tiny reduce launches per transformer block.
 constexpr int kMaxSumJobs = 64;
 struct SumJobs {
     const float *src[kMaxSumJobs];
-    float *dst[kMaxSumJobs];
-    int n[kMaxSumJobs], len[kMaxSumJobs], ld[kMaxSumJobs], acc[kMaxSumJobs];
-    int wg0[kMaxSumJobs + 1];                  // first workgroup of each job (256 columns per workgroup)
-    int jobs;
+    int n[kMaxSumJobs], ld[kMaxSumJobs];
+    float *dst[kMaxSumJobs];                   // per group
+    int len[kMaxSumJobs], acc[kMaxSumJobs];    // per group
+    int first[kMaxSumJobs + 1];                // per group: its jobs are [first[g], first[g+1])
+    int wg0[kMaxSumJobs + 1];                  // per group: first workgroup (256 columns per workgroup)
+    int groups;
 };
 __global__ __launch_bounds__(256) void batched_sum_kernel(SumJobs t) {
-    int j = 0;
-    while (j + 1 < t.jobs && (int)blockIdx.x >= t.wg0[j + 1]) ++j;             // wave-uniform scan of <= 64 entries
-    const int c = ((int)blockIdx.x - t.wg0[j]) * 256 + threadIdx.x;
-    const int len = t.len[j], n = t.n[j], ld = t.ld[j];
+    int g = 0;
+    while (g + 1 < t.groups && (int)blockIdx.x >= t.wg0[g + 1]) ++g;          // wave-uniform scan of <= 64 entries
+    const int c = ((int)blockIdx.x - t.wg0[g]) * 256 + threadIdx.x;
+    const int len = t.len[g];
     if (c >= len) return;
-    const float *src = t.src[j] + c;
-    float acc = 0.0f;
-    for (int i0 = 0; i0 < n; i0 += 16) {                                       // 16 independent loads in flight
-        float v[16];
+    float acc = t.acc[g] ? t.dst[g][c] : 0.0f;
+    for (int j = t.first[g]; j < t.first[g + 1]; ++j) {
+        const float *src = t.src[j] + c;
+        const int n = t.n[j], ld = t.ld[j];
+        for (int i0 = 0; i0 < n; i0 += 16) {                                   // 16 independent loads in flight
+            float v[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = src[(size_t)min(i0 + q, n - 1) * ld];
+            for (int q = 0; q < 16; ++q) v[q] = src[(size_t)min(i0 + q, n - 1) * ld];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) if (i0 + q < n) acc += v[q];
+            for (int q = 0; q < 16; ++q) if (i0 + q < n) acc += v[q];
+        }
     }
-    t.dst[j][c] = t.acc[j] ? t.dst[j][c] + acc : acc;
+    t.dst[g][c] = acc;
 }
 
 }  // namespace
@@ -98,19 +105,40 @@ __global__ __launch_bounds__(256) void batched_sum_kernel(SumJobs t) {
 extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, const int *ld,
                                const int *accumulate, int jobs, void *stream) {
     if (jobs < 0 || (jobs > 0 && (!src || !dst || !n || !len || !ld || !accumulate))) return UPP_E_BADARG;
-    for (int j0 = 0; j0 < jobs; j0 += kMaxSumJobs) {
+    for (int j = 0; j < jobs; ++j)
+        if (!src[j] || !dst[j] || n[j] < 1 || len[j] < 1 || ld[j] < len[j]) return UPP_E_BADARG;
+    // group the jobs by destination (first-seen order; submission order inside a group), then launch in batches
+    int order[4096], gstart[4096 + 1];
+    if (jobs > 4096) return UPP_E_RANGE;
+    int ngroups = 0, filled = 0;
+    bool taken[4096];
+    for (int j = 0; j < jobs; ++j) taken[j] = false;
+    for (int j = 0; j < jobs; ++j) {
+        if (taken[j]) continue;
+        gstart[ngroups++] = filled;
+        for (int k = j; k < jobs; ++k)
+            if (!taken[k] && dst[k] == dst[j]) {
+                if (len[k] != len[j] || accumulate[k] != accumulate[j]) return UPP_E_BADARG;   // one destination, one shape
+                taken[k] = true; order[filled++] = k;
+            }
+    }
+    gstart[ngroups] = filled;
+    int g0 = 0;
+    while (g0 < ngroups) {
         SumJobs t;
-        t.jobs = jobs - j0 < kMaxSumJobs ? jobs - j0 : kMaxSumJobs;
-        int wg = 0;
-        for (int j = 0; j < t.jobs; ++j) {
-            if (!src[j0 + j] || !dst[j0 + j] || n[j0 + j] < 1 || len[j0 + j] < 1 || ld[j0 + j] < len[j0 + j]) return UPP_E_BADARG;
-            t.src[j] = src[j0 + j]; t.dst[j] = dst[j0 + j]; t.n[j] = n[j0 + j]; t.len[j] = len[j0 + j];
-            t.ld[j] = ld[j0 + j]; t.acc[j] = accumulate[j0 + j];
-            t.wg0[j] = wg;
-            wg += (len[j0 + j] + 255) / 256;
+        int g = 0, nj = 0, wg = 0;
+        while (g0 + g < ngroups && g < kMaxSumJobs && nj + (gstart[g0 + g + 1] - gstart[g0 + g]) <= kMaxSumJobs) {
+            const int lo = gstart[g0 + g], hi = gstart[g0 + g + 1], head = order[lo];
+            t.first[g] = nj;
+            for (int q = lo; q < hi; ++q) { const int k = order[q]; t.src[nj] = src[k]; t.n[nj] = n[k]; t.ld[nj] = ld[k]; ++nj; }
+            t.dst[g] = dst[head]; t.len[g] = len[head]; t.acc[g] = accumulate[head]; t.wg0[g] = wg;
+            wg += (len[head] + 255) / 256;
+            ++g;
         }
-        t.wg0[t.jobs] = wg;
+        if (g == 0) return UPP_E_RANGE;                  // a single destination with more than 64 partial matrices
+        t.first[g] = nj; t.wg0[g] = wg; t.groups = g;
         hipLaunchKernelGGL(batched_sum_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
+        g0 += g;
     }
     return upp_launch_status();
 }

@@ -160,7 +160,7 @@ class _RowLN(Function):
     One kernel forward, one backward (+ one for trainable LayerNorm parameters).  See upp_rowln_fwd."""
 
     @staticmethod
-    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps):
+    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps, cls_add=None):
         x = x.contiguous()
         B, Lin, D = x.shape
         Lout = Lin + P if mode in (ROW_INSERT_CLS, ROW_INSERT) else (Lin - P if mode in (ROW_STRIP_CLS, ROW_STRIP) else Lin)
@@ -171,7 +171,8 @@ class _RowLN(Function):
         ctx.dims = (B, Lin, Lout, D, P, mode)
         ctx.keep = keep
         ctx.has = (add is not None, prompts is not None, y is not None, gamma is not None)
-        ctx.param_ptrs = tuple(t.data_ptr() if t is not None else 0 for t in (prompts, gamma, beta))
+        ctx.param_ptrs = tuple(t.data_ptr() if t is not None else 0 for t in (prompts, gamma, beta, cls_add))
+        ctx.cls_shape = tuple(cls_add.shape) if cls_add is not None else None
         if gamma is None:
             return xo, xo.new_empty(0)
         return xo, h
@@ -185,13 +186,19 @@ class _RowLN(Function):
         g_xo = g_xo.contiguous() if g_xo is not None else None
         g_hc = g_h.contiguous() if (has_ln and g_h is not None) else None
         if g_xo is None and g_hc is None:
-            return (None,) * 11
+            return (None,) * 12
         strip = mode in (ROW_STRIP_CLS, ROW_STRIP) and P > 0
+        need_cls = ctx.cls_shape is not None and len(need) > 11 and need[11]
         g_x, g_p, g_y = ops.rowln_bwd(g_xo, g_hc, xo, mean, rstd, gamma, mode, u, ctx.keep, B, Lin, Lout, D, P,
-                                      need_x=need[0] or (has_add and need[1]),
+                                      need_x=need[0] or (has_add and need[1]) or need_cls,
                                       need_prompt=has_prompts and need[2], need_y=has_y and need[3])
         g_gamma = g_beta = g_prompts = None
-        p_prompts, p_gamma, p_beta = ctx.param_ptrs
+        p_prompts, p_gamma, p_beta, p_cls = ctx.param_ptrs
+        g_cls = None
+        if need_cls:     # `add` holds a trainable row 0 (the cls position) whose gradient is the batch sum of g_x[:, 0]
+            _, g_cls = _DEFERRED.reduce(p_cls, g_x.view(B, Lin * D), 0, D)
+            if g_cls is not None:
+                g_cls = g_cls.view(ctx.cls_shape)
         if has_ln and g_hc is not None and (need[4] or need[5]):
             part = ops.ln_param_grad(g_hc, xo, mean, rstd)               # (2, chunks, D)
             _, g_gamma = _DEFERRED.reduce(p_gamma, part[0], 0, D)
@@ -201,12 +208,16 @@ class _RowLN(Function):
             if g_prompts is not None:
                 g_prompts = g_prompts.view(P, D)
         return (g_x if need[0] else None, g_x if (has_add and need[1]) else None, g_prompts, g_y,
-                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None)
+                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None, g_cls)
 
 
-def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDENTITY, P=0, u=None, keep=1.0, eps=1e-5):
-    """-> (rows (B,Lout,D), LayerNorm(rows) or None).  mode / P: see ROW_* and upp_rowln_fwd."""
-    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps))
+def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDENTITY, P=0, u=None, keep=1.0, eps=1e-5, cls_add=None):
+    """-> (rows (B,Lout,D), LayerNorm(rows) or None).  mode / P: see ROW_* and upp_rowln_fwd.
+    cls_add: optional (1,1,D) parameter that `add` (passed detached) carries in its row 0 for every sample; its gradient
+    (batch sum of the row-0 input gradient) is produced here instead of through a (B,L,D) gradient of `add`."""
+    if cls_add is not None and (add is None or add.requires_grad or mode not in (ROW_IDENTITY, ROW_INSERT_CLS)):
+        raise ValueError("cls_add needs a detached `add` and a row map that keeps source row 0 in place")
+    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps), cls_add)
     return xo, (h if gamma is not None else None)
 
 

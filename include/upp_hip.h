@@ -269,7 +269,8 @@ int upp_posenc_fwd(const float *x, const float *freqs, int F, float *out, int ld
  * scratch: upp_adamw_scratch_floats() floats. */
 long long upp_adamw_scratch_floats(void);
 /* upp_batched_sum: for `jobs` independent jobs in one launch, dst_j[c] (+)= sum_{i < n_j} src_j[i * ld_j + c], c < len_j
- * (rows added in ascending order; accumulate_j != 0 adds to dst_j, else overwrites).  src / dst / n / len / ld /
+ * (rows added in ascending order; accumulate_j != 0 adds to dst_j, else overwrites; jobs that name the same dst are
+ * applied one after the other in submission order by the same workgroups: race-free and deterministic).  src / dst / n / len / ld /
  * accumulate are HOST arrays; the pointers in src / dst are device pointers.  Used for the parameter-gradient partials of
  * a backward pass (upp_adapter_bwd partials per workgroup, upp_ln_param_grad partials per chunk, upp_rowln_bwd per-sample
  * prompt gradients), summed straight into the flat gradient buffer after the pass. */

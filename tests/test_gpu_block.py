@@ -311,10 +311,19 @@ def test_batched_sum_and_deferred_scope():
         jobs.append((part, off, n, length, part.stride(0), dst, acc))
     ops.batched_sum(jobs)
     for part, off, n, length, ld, dst, acc in jobs:
-        ref = part[0, off:off + length].clone()
-        for i in range(1, n):
-            ref += part[i, off:off + length]          # ascending row order, as the kernel
-        assert torch.equal(dst, ref + 2.0 if acc else ref)
+        ref = torch.full((length,), 2.0 if acc else 0.0, device='cuda')
+        for i in range(n):
+            ref += part[i, off:off + length]          # destination first, then ascending row order, as the kernel
+        assert torch.equal(dst, ref)
+    # many partial matrices into ONE destination (what the cls-position gradient of 12 blocks does)
+    shared = torch.zeros(384, device='cuda')
+    parts = [torch.randn(32, 65 * 384, device='cuda', generator=g) for _ in range(12)]
+    ops.batched_sum([(p_, 0, 32, 384, p_.stride(0), shared, True) for p_ in parts])
+    ref = torch.zeros(384, device='cuda')
+    for p_ in parts:
+        for i in range(32):
+            ref += p_[i, :384]
+    assert torch.equal(shared, ref)
     # a deferred scope accumulates the same parameter gradients into the registered buffers
     torch.manual_seed(0)
     x = torch.randn(32, 65, 384, device='cuda')
