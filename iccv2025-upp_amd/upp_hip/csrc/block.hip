@@ -125,83 +125,105 @@ struct RowLnBwdArgs {
     float *g_x;            // (B, Lin, D): every row is written (zeros for the prompt rows a strip map drops)
     float *g_prompt;       // (B, P, D) per-sample gradient of the prompt rows, or null
     float *g_y;            // (B, Lin, D) gradient of the residual branch (same rows as g_x), or null
+    float *ln_part;        // (workgroups, 2, D) partial d_gamma / d_beta per workgroup of 4 rows, or null
     int B, Lin, Lout, D, P;
 };
 
 __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int it = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    __shared__ float lnp[2][4][64 * kMaxE];   // per-wave LayerNorm parameter-gradient contributions (only used with ln_part)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int it = blockIdx.x * 4 + wave;   // wave-uniform
     const int D = a.D;
     // Insert / identity maps are walked by OUTPUT row; strip maps by INPUT row, so that the prompt rows the forward
     // dropped get their zero gradient here (no separate fill launch).
     const bool by_input = a.mode == 3 || a.mode == 4;
     const int Lg = by_input ? a.Lin : a.Lout;
-    if (it >= a.B * Lg) return;
-    const int b = it / Lg, t = it - b * Lg;
-    int src, t_out;
-    if (by_input) {
-        src = t;
-        t_out = a.mode == 3 ? (t == 0 ? 0 : (t <= a.P ? -1 : t - a.P)) : (t < a.P ? -1 : t - a.P);
-        if (t_out < 0) {
-            float *zx = a.g_x ? a.g_x + ((size_t)b * a.Lin + t) * D : nullptr;
-            float *zy = a.g_y ? a.g_y + ((size_t)b * a.Lin + t) * D : nullptr;
+    bool live = it < a.B * Lg;
+    const int b = live ? it / Lg : 0, t = live ? it - b * Lg : 0;
+    int src = 0, t_out = 0;
+    if (live) {
+        if (by_input) {
+            src = t;
+            t_out = a.mode == 3 ? (t == 0 ? 0 : (t <= a.P ? -1 : t - a.P)) : (t < a.P ? -1 : t - a.P);
+            if (t_out < 0) {
+                float *zx = a.g_x ? a.g_x + ((size_t)b * a.Lin + t) * D : nullptr;
+                float *zy = a.g_y ? a.g_y + ((size_t)b * a.Lin + t) * D : nullptr;
+#pragma unroll
+                for (int e = 0; e < kMaxE; ++e) {
+                    const int c = lane + 64 * e;
+                    if (c < D) { if (zx) zx[c] = 0.0f; if (zy) zy[c] = 0.0f; }
+                }
+                live = false;
+            }
+        } else {
+            t_out = t;
+            src = row_src(t, a.mode, a.P);
+        }
+    }
+    float pgam[kMaxE], pbet[kMaxE];         // this row's g_h * xhat and g_h (LayerNorm parameter gradients)
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) { pgam[e] = 0.0f; pbet[e] = 0.0f; }
+    if (live) {
+        const int row = b * a.Lout + t_out;
+        const bool has_gxo = a.g_xo != nullptr, has_ln = a.g_h != nullptr;
+        // one batch of loads (clamped columns), then the arithmetic
+        int cc[kMaxE];
+        float d[kMaxE], gh[kMaxE], gm[kMaxE], xo[kMaxE];
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) cc[e] = min(lane + 64 * e, D - 1);
+        if (has_gxo) {
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) d[e] = a.g_xo[(size_t)row * D + cc[e]];
+        }
+        float mean = 0.0f, rstd = 0.0f;
+        if (has_ln) {
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) { gh[e] = a.g_h[(size_t)row * D + cc[e]]; gm[e] = a.gamma[cc[e]]; xo[e] = a.xo[(size_t)row * D + cc[e]]; }
+            mean = a.mean[row]; rstd = a.rstd[row];
+        }
+        float *gx = nullptr;
+        if (src >= 0) { if (a.g_x) gx = a.g_x + ((size_t)b * a.Lin + src) * D; }
+        else if (a.g_prompt) gx = a.g_prompt + ((size_t)b * a.P + (-src - 1)) * D;
+        float *gy = (src >= 0 && a.g_y) ? a.g_y + ((size_t)b * a.Lin + src) * D : nullptr;
+        const float sc = gy ? dp_scale(a.u, a.keep, b) : 0.0f;
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) d[e] = (has_gxo && lane + 64 * e < D) ? d[e] : 0.0f;
+        if (has_ln) {
+            // dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat)),  dy = g_h * gamma
+            float dy[kMaxE], xh[kMaxE], s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
             for (int e = 0; e < kMaxE; ++e) {
-                const int c = lane + 64 * e;
-                if (c < D) { if (zx) zx[c] = 0.0f; if (zy) zy[c] = 0.0f; }
+                const bool ok = lane + 64 * e < D;
+                dy[e] = ok ? gh[e] * gm[e] : 0.0f;
+                xh[e] = ok ? (xo[e] - mean) * rstd : 0.0f;
+                pgam[e] = ok ? gh[e] * xh[e] : 0.0f;
+                pbet[e] = ok ? gh[e] : 0.0f;
+                s1 += dy[e];
+                s2 = __builtin_fmaf(dy[e], xh[e], s2);
             }
-            return;
+            s1 = wave_sum(s1) / (float)D;
+            s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) d[e] += rstd * (dy[e] - s1 - xh[e] * s2);
         }
-    } else {
-        t_out = t;
-        src = row_src(t, a.mode, a.P);
-    }
-    const int row = b * a.Lout + t_out;
-    const bool has_gxo = a.g_xo != nullptr, has_ln = a.g_h != nullptr;
-    // one batch of loads (clamped columns), then the arithmetic
-    int cc[kMaxE];
-    float d[kMaxE], gh[kMaxE], gm[kMaxE], xo[kMaxE];
-#pragma unroll
-    for (int e = 0; e < kMaxE; ++e) cc[e] = min(lane + 64 * e, D - 1);
-    if (has_gxo) {
-#pragma unroll
-        for (int e = 0; e < kMaxE; ++e) d[e] = a.g_xo[(size_t)row * D + cc[e]];
-    }
-    float mean = 0.0f, rstd = 0.0f;
-    if (has_ln) {
-#pragma unroll
-        for (int e = 0; e < kMaxE; ++e) { gh[e] = a.g_h[(size_t)row * D + cc[e]]; gm[e] = a.gamma[cc[e]]; xo[e] = a.xo[(size_t)row * D + cc[e]]; }
-        mean = a.mean[row]; rstd = a.rstd[row];
-    }
-    float *gx = nullptr;
-    if (src >= 0) { if (a.g_x) gx = a.g_x + ((size_t)b * a.Lin + src) * D; }
-    else if (a.g_prompt) gx = a.g_prompt + ((size_t)b * a.P + (-src - 1)) * D;
-    float *gy = (src >= 0 && a.g_y) ? a.g_y + ((size_t)b * a.Lin + src) * D : nullptr;
-    const float sc = gy ? dp_scale(a.u, a.keep, b) : 0.0f;
-#pragma unroll
-    for (int e = 0; e < kMaxE; ++e) d[e] = (has_gxo && lane + 64 * e < D) ? d[e] : 0.0f;
-    if (has_ln) {
-        // dx = rstd * (dy - mean(dy) - xhat * mean(dy * xhat)),  dy = g_h * gamma
-        float dy[kMaxE], xh[kMaxE], s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int e = 0; e < kMaxE; ++e) {
-            const bool ok = lane + 64 * e < D;
-            dy[e] = ok ? gh[e] * gm[e] : 0.0f;
-            xh[e] = ok ? (xo[e] - mean) * rstd : 0.0f;
-            s1 += dy[e];
-            s2 = __builtin_fmaf(dy[e], xh[e], s2);
+            const int c = lane + 64 * e;
+            if (c < D) {
+                if (gx) gx[c] = d[e];
+                if (gy) gy[c] = d[e] * sc;
+            }
         }
-        s1 = wave_sum(s1) / (float)D;
-        s2 = wave_sum(s2) / (float)D;
-#pragma unroll
-        for (int e = 0; e < kMaxE; ++e) d[e] += rstd * (dy[e] - s1 - xh[e] * s2);
     }
+    if (a.ln_part) {
+        // LayerNorm parameter gradients: the workgroup's 4 rows are summed in wave order into one partial row pair;
+        // the caller sums the partials over the workgroups (upp_batched_sum): deterministic, no extra pass over g_h / xo.
 #pragma unroll
-    for (int e = 0; e < kMaxE; ++e) {
-        const int c = lane + 64 * e;
-        if (c < D) {
-            if (gx) gx[c] = d[e];
-            if (gy) gy[c] = d[e] * sc;
+        for (int e = 0; e < kMaxE; ++e) { lnp[0][wave][lane + 64 * e] = pgam[e]; lnp[1][wave][lane + 64 * e] = pbet[e]; }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) {
+            a.ln_part[((size_t)blockIdx.x * 2 + 0) * D + c] = (lnp[0][0][c] + lnp[0][1][c]) + (lnp[0][2][c] + lnp[0][3][c]);
+            a.ln_part[((size_t)blockIdx.x * 2 + 1) * D + c] = (lnp[1][0][c] + lnp[1][1][c]) + (lnp[1][2][c] + lnp[1][3][c]);
         }
     }
 }
@@ -445,15 +467,22 @@ extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prom
     return upp_launch_status();
 }
 
+extern "C" long long upp_rowln_part_floats(int B, int Lin, int Lout, int D, int mode) {
+    if (B < 1 || Lin < 1 || Lout < 1 || D < 1) return 0;
+    const int Lg = (mode == 3 || mode == 4) ? Lin : Lout;
+    return (long long)((B * Lg + 3) / 4) * 2 * D;
+}
+
 extern "C" int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
                              const float *gamma, int mode, const float *u, float keep, float *g_x, float *g_prompt,
-                             float *g_y, int B, int Lin, int Lout, int D, int P, void *stream) {
+                             float *g_y, float *ln_part, int B, int Lin, int Lout, int D, int P, void *stream) {
     if ((!g_xo && !g_h) || B < 0 || Lin < 1 || Lout < 1 || D < 1) return UPP_E_BADARG;
     if (g_h && (!xo || !mean || !rstd || !gamma)) return UPP_E_BADARG;
     if (D > 64 * kMaxE) return UPP_E_RANGE;
     if (B == 0) return 0;
     if (mode < 0 || mode > 4 || P < 0) return UPP_E_BADARG;
-    RowLnBwdArgs a{g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, g_x, g_prompt, g_y, B, Lin, Lout, D, P};
+    if (ln_part && !g_h) return UPP_E_BADARG;
+    RowLnBwdArgs a{g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, g_x, g_prompt, g_y, ln_part, B, Lin, Lout, D, P};
     const int Lg = (mode == 3 || mode == 4) ? Lin : Lout;      // strip maps are walked by input row (see the kernel)
     hipLaunchKernelGGL(rowln_bwd_kernel, dim3((B * Lg + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return upp_launch_status();

@@ -189,9 +189,10 @@ class _RowLN(Function):
             return (None,) * 12
         strip = mode in (ROW_STRIP_CLS, ROW_STRIP) and P > 0
         need_cls = ctx.cls_shape is not None and len(need) > 11 and need[11]
-        g_x, g_p, g_y = ops.rowln_bwd(g_xo, g_hc, xo, mean, rstd, gamma, mode, u, ctx.keep, B, Lin, Lout, D, P,
-                                      need_x=need[0] or (has_add and need[1]) or need_cls,
-                                      need_prompt=has_prompts and need[2], need_y=has_y and need[3])
+        need_ln = has_ln and g_hc is not None and (need[4] or need[5])
+        g_x, g_p, g_y, ln_part = ops.rowln_bwd(g_xo, g_hc, xo, mean, rstd, gamma, mode, u, ctx.keep, B, Lin, Lout, D, P,
+                                               need_x=need[0] or (has_add and need[1]) or need_cls,
+                                               need_prompt=has_prompts and need[2], need_y=has_y and need[3], need_ln_part=need_ln)
         g_gamma = g_beta = g_prompts = None
         p_prompts, p_gamma, p_beta, p_cls = ctx.param_ptrs
         g_cls = None
@@ -199,10 +200,9 @@ class _RowLN(Function):
             _, g_cls = _DEFERRED.reduce(p_cls, g_x.view(B, Lin * D), 0, D)
             if g_cls is not None:
                 g_cls = g_cls.view(ctx.cls_shape)
-        if has_ln and g_hc is not None and (need[4] or need[5]):
-            part = ops.ln_param_grad(g_hc, xo, mean, rstd)               # (2, chunks, D)
-            _, g_gamma = _DEFERRED.reduce(p_gamma, part[0], 0, D)
-            _, g_beta = _DEFERRED.reduce(p_beta, part[1], 0, D)
+        if need_ln:      # per-workgroup partials [d_gamma | d_beta] written by the same backward pass
+            _, g_gamma = _DEFERRED.reduce(p_gamma, ln_part, 0, D)
+            _, g_beta = _DEFERRED.reduce(p_beta, ln_part, D, D)
         if g_p is not None:
             _, g_prompts = _DEFERRED.reduce(p_prompts, g_p.view(B, P * D), 0, P * D)
             if g_prompts is not None:

@@ -232,14 +232,18 @@ def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want
     return xo, h, mean, rstd
 
 
-def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, P, need_x, need_prompt, need_y):
+def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, P, need_x, need_prompt, need_y, need_ln_part=False):
     dev = (g_xo if g_xo is not None else g_h).device
     g_x = torch.empty((B, Lin, D), dtype=torch.float32, device=dev) if need_x else None      # the kernel writes every row
     g_p = torch.empty((B, P, D), dtype=torch.float32, device=dev) if (need_prompt and P > 0 and mode in (1, 2)) else None
     g_y = torch.empty((B, Lin, D), dtype=torch.float32, device=dev) if need_y else None
+    part = None
+    if need_ln_part and g_h is not None:
+        n = int(_abi.load().upp_rowln_part_floats(B, Lin, Lout, D, int(mode)))
+        part = torch.empty((n // (2 * D), 2 * D), dtype=torch.float32, device=dev)     # per workgroup: [d_gamma | d_beta]
     _call(dev, "upp_rowln_bwd", _abi.ptr(g_xo), _abi.ptr(g_h), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma),
-          int(mode), _abi.ptr(u), float(keep), _abi.ptr(g_x), _abi.ptr(g_p), _abi.ptr(g_y), B, Lin, Lout, D, P)
-    return g_x, g_p, g_y
+          int(mode), _abi.ptr(u), float(keep), _abi.ptr(g_x), _abi.ptr(g_p), _abi.ptr(g_y), _abi.ptr(part), B, Lin, Lout, D, P)
+    return g_x, g_p, g_y, part
 
 
 def ln_param_grad(g_h, xo, mean, rstd, chunks=32):

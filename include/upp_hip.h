@@ -166,14 +166,18 @@ int upp_patch_embed_fwd(const float *pts, int R, int n,
  *   (gamma NULL: no LayerNorm, only xo).
  * Backward: d = g_xo + LayerNormBackward(g_h); written to g_x[b, s] (every row of g_x / g_y is written: the prompt
  * rows a strip mode drops get zeros), g_prompt (B,P,D) (caller sums over B), g_y[b, s] = factor * d.
- * upp_ln_param_grad: per-chunk partial sums of d_gamma / d_beta, part (2, chunks, D).
+ * ln_part (optional, upp_rowln_part_floats floats): per-workgroup partials (workgroups, 2, D) of d_gamma = sum g_h * xhat and
+ * d_beta = sum g_h, produced by the same pass; the caller sums them over the workgroups (upp_batched_sum).
+ * upp_ln_param_grad: the same partial sums as a stand-alone pass, part (2, chunks, D).
  * Limits: D <= 512. */
 int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y,
                   const float *u, float keep, const float *gamma, const float *beta, float eps,
                   float *xo, float *h, float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream);
+long long upp_rowln_part_floats(int B, int Lin, int Lout, int D, int mode);
 int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
                   const float *gamma, int mode, const float *u, float keep,
-                  float *g_x, float *g_prompt, float *g_y, int B, int Lin, int Lout, int D, int P, void *stream);
+                  float *g_x, float *g_prompt, float *g_y, float *ln_part,
+                  int B, int Lin, int Lout, int D, int P, void *stream);
 int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, const float *rstd, float *part,
                       int rows, int D, int chunks, void *stream);
 
