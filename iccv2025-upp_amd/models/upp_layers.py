@@ -128,6 +128,23 @@ def _inverse_distance_interp(xyz1, xyz2, points2, k, eps, out=None, col0=0):
     return torch.sum(index_points(points2, idx) * weight.unsqueeze(-1), dim=2)
 
 
+def _prop_lists_torch(c1, c2, i1, i2, gather_idx, B, Lp, off):
+    """Index lists of the fused propagation step with the reference's torch ops (what upp_prop_index computes in one
+    launch): absolute rows for the neighbour / centre indices and the 8 nearest level-2 centres with their weights."""
+    dists, idx = square_distance(c1, c2).sort(dim=-1)
+    d8, idx8 = dists[:, :, :8], idx[:, :, :8]
+    recip = 1.0 / (d8 + 1e-3)
+    w8 = (recip / torch.sum(recip, dim=2, keepdim=True)).contiguous()
+    if gather_idx:
+        base = (torch.arange(B, device=c1.device) * Lp + off).view(B, 1)
+        i1a, i2a = base + i1.reshape(B, -1), base + i2.reshape(B, -1)
+    else:
+        G = Lp - off      # the reference indexes the cls-stripped tokens as a flat (B*G)-row matrix
+        i1a = torch.div(i1, G, rounding_mode='floor') * Lp + off + i1 % G
+        i2a = torch.div(i2, G, rounding_mode='floor') * Lp + off + i2 % G
+    return i1a.reshape(-1).int().contiguous(), i2a.reshape(-1).int().contiguous(), idx8.int().contiguous(), w8
+
+
 def propagate(xyz1, xyz2, points1, points2, de_neighbors=64, dist_e=1e-8):
     """points1 + 0.3 * inverse-distance interpolation of points2  (models/Point_MAE_unify.py:22-48)."""
     return points1 + 0.3 * _inverse_distance_interp(xyz1, xyz2, points2, de_neighbors, dist_e)
@@ -142,6 +159,19 @@ def pooling(x, transform):
 
 
 # --------------------------------------------------------------------------- grouping
+_OFFSETS = {}
+
+
+def _batch_offsets(B, N, device):
+    """(B,1,1) int64 tensor b*N, built once per (B, N, device): a constant, not two launches per grouping call."""
+    key = (B, N, str(device))
+    if key not in _OFFSETS:
+        if len(_OFFSETS) > 64:
+            _OFFSETS.clear()
+        _OFFSETS[key] = torch.arange(B, device=device).view(-1, 1, 1) * N
+    return _OFFSETS[key]
+
+
 class Group(nn.Module):
     """FPS centres + kNN neighbourhoods, centred  (models/Point_MAE_unify.py:51-92).
 
@@ -163,7 +193,7 @@ class Group(nn.Module):
             return neighborhood, center
         if not gather_idx:
             # flat indices into a (B*N, C) view, as the reference hands them on (:73-79)
-            base = torch.arange(B, device=xyz.device).view(-1, 1, 1) * N
+            base = _batch_offsets(B, N, xyz.device)
             idx = (idx + base).view(-1)
             center_idx = (center_idx + base.view(-1, 1)).view(-1)
         else:
@@ -399,21 +429,14 @@ class Block(nn.Module):
         cache = kw.get('_prop_cache')
         key = (Lp, off)
         if cache is None or key not in cache:
+            i1, i2 = kw['center1_idx'], kw['center2_idx']
             with torch.no_grad():
-                dists, idx = square_distance(c1, c2).sort(dim=-1)
-                d8, idx8 = dists[:, :, :8], idx[:, :, :8]
-                recip = 1.0 / (d8 + 1e-3)
-                w8 = (recip / torch.sum(recip, dim=2, keepdim=True)).contiguous()
-                i1, i2 = kw['center1_idx'], kw['center2_idx']
-                if kw.get('gather_idx'):
-                    base = (torch.arange(B, device=x.device) * Lp + off).view(B, 1)
-                    i1a, i2a = base + i1.reshape(B, -1), base + i2.reshape(B, -1)
+                if G2 <= 64 and i1.dtype == torch.int64 and i2.dtype == torch.int64:
+                    lists = HF.ops.prop_index(c1.contiguous(), c2.contiguous(), i1.contiguous(), i2.contiguous(),
+                                              bool(kw.get('gather_idx')), Lp, off, 1e-3)      # the four lists in one launch
                 else:
-                    G = Lp - off      # the reference indexes the cls-stripped tokens as a flat (B*G)-row matrix
-                    i1a = torch.div(i1, G, rounding_mode='floor') * Lp + off + i1 % G
-                    i2a = torch.div(i2, G, rounding_mode='floor') * Lp + off + i2 % G
-                entry = HF.PropIndex(i1a.reshape(-1).int().contiguous(), i2a.reshape(-1).int().contiguous(), idx8.int().contiguous(), w8,
-                                     rows=B * Lp)
+                    lists = _prop_lists_torch(c1, c2, i1, i2, bool(kw.get('gather_idx')), B, Lp, off)
+                entry = HF.PropIndex(*lists, rows=B * Lp)
             if cache is not None:
                 cache[key] = entry
         else:

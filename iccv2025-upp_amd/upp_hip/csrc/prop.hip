@@ -626,7 +626,85 @@ __global__ __launch_bounds__(256) void prop_x_csr_kernel(const float *__restrict
     for (int e = 0; e < kMaxE; ++e) { const int c = lane + 64 * e; if (c < D) g_X[(size_t)r * D + c] = acc[e]; }
 }
 
+// Index lists of the propagation step for one forward, in ONE launch (the reference spends ~30 small torch kernels on
+// them: index arithmetic, square_distance, a full sort, the weight normalisation):
+//   i1a / i2a : absolute rows of the (B*L') token matrix for the level-1 neighbour lists / level-2 centres, from the
+//               reference's index tensors (flat with batch offsets b*T when gather_idx == 0 -- re-interpreted in the
+//               (B*G)-row view G = L' - off exactly as models/Point_MAE_pretask_dev.py:291-292 does -- or per-sample);
+//   idx8 / w8 : for every level-1 centre its 8 nearest level-2 centres by  d = |a|^2 + |b|^2 - 2 a.b  (the reference's
+//               square_distance form, models/modules.py:13-32), ascending (d, index), w = (1/(d+eps)) / sum.
+// One wavefront per (sample, level-1 centre); lane = level-2 centre (G2 <= 64).
+__global__ __launch_bounds__(256) void prop_index_kernel(const float *__restrict__ c1, const float *__restrict__ c2,
+                                                         const int64_t *__restrict__ i1, const int64_t *__restrict__ i2, int gather_idx,
+                                                         int B, int T, int G2, int Lp, int off, float eps,
+                                                         int32_t *__restrict__ i1a, int32_t *__restrict__ i2a,
+                                                         int32_t *__restrict__ idx8, float *__restrict__ w8) {
+    const int lane = threadIdx.x & 63;
+    const int wg = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {   // integer part: every wave converts 64 consecutive entries of [i1 | i2]
+        const int n1 = B * G2 * kNb, n2 = B * G2;
+        const int e = wg * 64 + lane;
+        if (e < n1 + n2) {
+            const bool first = e < n1;
+            const long long v = first ? i1[e] : i2[e - n1];
+            long long r;
+            if (gather_idx) {
+                const int bsmp = first ? e / (G2 * kNb) : (e - n1) / G2;
+                r = (long long)bsmp * Lp + off + v;
+            } else {
+                const int G = Lp - off;
+                r = (v / G) * Lp + off + v % G;
+            }
+            if (first) i1a[e] = (int32_t)r; else i2a[e - n1] = (int32_t)r;
+        }
+    }
+    if (wg >= B * T) return;
+    const int b = wg / T;
+    const float *a = c1 + (size_t)wg * 3;
+    const float ax = a[0], ay = a[1], az = a[2];
+    const int j = min(lane, G2 - 1);
+    const float *q = c2 + ((size_t)b * G2 + j) * 3;
+    const float bx = q[0], by = q[1], bz = q[2];
+    // dist = -2 * (a . b); dist += |a|^2; dist += |b|^2   (operation order of the reference formula)
+    float d = -2.0f * __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
+    d += (ax * ax + ay * ay) + az * az;
+    d += (bx * bx + by * by) + bz * bz;
+    const uint32_t bits = __float_as_uint(d);
+    uint32_t img = lane < G2 ? ((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u)) : 0xFFFFFFFFu;   // order-preserving image
+    float dk[kNb];
+    int jk[kNb];
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) {
+        const uint32_t m = wave_min_u32(img);
+        const int win = __builtin_ctzll(__ballot(img == m));          // lowest index among equal distances
+        jk[k] = win;
+        dk[k] = __uint_as_float((m & 0x80000000u) ? (m & 0x7FFFFFFFu) : ~m);
+        if (lane == win) img = 0xFFFFFFFFu;
+    }
+    float rc[kNb], sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) { rc[k] = 1.0f / (dk[k] + eps); sum += rc[k]; }
+    if (lane < kNb) {
+        float wv = 0.0f; int jv = 0;
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) if (lane == k) { wv = rc[k] / sum; jv = jk[k]; }
+        idx8[(size_t)wg * kNb + lane] = jv;
+        w8[(size_t)wg * kNb + lane] = wv;
+    }
+}
+
 }  // namespace
+
+extern "C" int upp_prop_index(const float *c1, const float *c2, const int64_t *i1, const int64_t *i2, int gather_idx, int B, int T,
+                              int G2, int Lp, int off, float eps, int32_t *i1a, int32_t *i2a, int32_t *idx8, float *w8, void *stream) {
+    if (!c1 || !c2 || !i1 || !i2 || !i1a || !i2a || !idx8 || !w8 || B < 1 || T < 1 || G2 < kNb || Lp < 1 || off < 0 || off >= Lp)
+        return UPP_E_BADARG;
+    if (G2 > 64) return UPP_E_RANGE;
+    const long long waves_idx = ((long long)B * G2 * (kNb + 1) + 63) / 64, waves = waves_idx > (long long)B * T ? waves_idx : (long long)B * T;
+    hipLaunchKernelGGL(prop_index_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, c1, c2, i1, i2, gather_idx, B, T,
+                       G2, Lp, off, eps, i1a, i2a, idx8, w8);
+    return upp_launch_status();
+}
 
 extern "C" int upp_prop_pool_fwd(const float *X, const int32_t *i1, const float *u, float keep, float *pooled, uint8_t *amax,
                                  int groups, int D, void *stream) {

@@ -313,6 +313,26 @@ def csr_build(keys, rows, seg_len=None, seg_rows=0):
     return start, perm
 
 
+def prop_index(c1, c2, i1, i2, gather_idx, Lp, off, eps):
+    """-> (i1a, i2a int32 absolute rows, idx8 int32 (B,T,8), w8 f32 (B,T,8)); see upp_prop_index."""
+    _need(c1, "center1", torch.float32, 3, 3)
+    _need(c2, "center2", torch.float32, 3, 3)
+    _need(i1, "center1_idx", torch.int64)
+    _need(i2, "center2_idx", torch.int64)
+    B, T, _ = c1.shape
+    G2 = c2.shape[1]
+    if i1.numel() != B * G2 * 8 or i2.numel() != B * G2:
+        raise RuntimeError("prop_index: index tensors do not match the centre shapes")
+    dev = c1.device
+    i1a = torch.empty(B * G2 * 8, dtype=torch.int32, device=dev)
+    i2a = torch.empty(B * G2, dtype=torch.int32, device=dev)
+    idx8 = torch.empty((B, T, 8), dtype=torch.int32, device=dev)
+    w8 = torch.empty((B, T, 8), dtype=torch.float32, device=dev)
+    _call(dev, "upp_prop_index", _abi.ptr(c1), _abi.ptr(c2), _abi.ptr(i1), _abi.ptr(i2), int(bool(gather_idx)), B, T, G2, int(Lp), int(off),
+          float(eps), _abi.ptr(i1a), _abi.ptr(i2a), _abi.ptr(idx8), _abi.ptr(w8))
+    return i1a, i2a, idx8, w8
+
+
 def prop_fwd(X, i1, u, keep, i2, idx8, w8, gamma, beta, running_mean, running_var, momentum, eps, training, B, Lp, T, G2):
     D = X.shape[-1]
     groups = B * G2

@@ -230,6 +230,14 @@ int upp_prop_interp_bwd(const float *g_out, const int32_t *i2, const int32_t *id
  *                   BatchNorm parameter gradients; g_c2 (groups, D) and part are scratch.
  * Column partials are combined in a fixed order (Chan's update in f64 for the variance): deterministic. */
 int upp_csr_build(const int32_t *keys, int n, int seg_len, int seg_rows, int rows, int32_t *start, int32_t *perm, void *stream);
+/* upp_prop_index: the four index lists of upp_prop_fwd for one forward in one launch.  c1 (B,T,3) level-1 centres, c2 (B,G2,3)
+ * level-2 centres; i1 (B*G2*8) / i2 (B*G2) int64 as Group hands them on (reference models/Point_MAE_unify.py:73-79: flat with
+ * batch offsets when gather_idx == 0, per-sample otherwise); L' rows per sample, `off` leading rows (cls) excluded.
+ * -> i1a, i2a absolute rows (the stride-T-into-stride-(L'-off) re-interpretation of Point_MAE_pretask_dev.py:291-292 when
+ * gather_idx == 0); idx8 / w8 (B,T,8): 8 nearest level-2 centres by the reference's square_distance form, ascending
+ * (distance, index), weights (1/(d+eps)) / sum (propagate, models/Point_MAE_unify.py:22-48).  G2 <= 64. */
+int upp_prop_index(const float *c1, const float *c2, const int64_t *i1, const int64_t *i2, int gather_idx, int B, int T, int G2,
+                   int Lp, int off, float eps, int32_t *i1a, int32_t *i2a, int32_t *idx8, float *w8, void *stream);
 long long upp_prop_part_floats(int groups, int D);
 int upp_prop_fwd(const float *X, const int32_t *i1, const float *u, float keep, const int32_t *i2, const int32_t *idx8,
                  const float *w8, const float *gamma, const float *beta, float *running_mean, float *running_var,

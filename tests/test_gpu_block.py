@@ -386,3 +386,26 @@ def test_train_step_flat_gradients_equal_plain_autograd():
             else:
                 assert float(v.abs().max()) == 0.0
         assert checked > 100
+
+
+@pytest.mark.parametrize("gather_idx", [False, True])
+@pytest.mark.parametrize("B,Lp,off,G2", [(32, 75, 1, 32), (3, 74, 0, 32), (2, 139, 1, 64)])
+def test_prop_index_kernel_matches_the_torch_formulation(B, Lp, off, G2, gather_idx):
+    from upp_hip import ops
+    T = 2 * G2
+    pts = _seeded.unit_ball_clouds(B, 1024, seed=B + Lp).cuda()
+    with torch.no_grad():
+        _, c1 = upp_layers.Group(T, 8)(pts)
+        _, c2, i1, i2 = upp_layers.Group(G2, 8)(c1.contiguous(), require_index=True, gather_idx=gather_idx)
+        want = upp_layers._prop_lists_torch(c1, c2, i1, i2, gather_idx, B, Lp, off)
+    got = ops.prop_index(c1.contiguous(), c2.contiguous(), i1.contiguous(), i2.contiguous(), gather_idx, Lp, off, 1e-3)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # neighbour sets: identical wherever the 8th and 9th distances are separated by more than rounding noise
+    d = upp_layers.square_distance(c1, c2).sort(dim=-1)[0]
+    clear = (d[:, :, 8] - d[:, :, 7]) > 1e-6
+    same = (got[2].long().sort(dim=-1)[0] == want[2].long().sort(dim=-1)[0]).all(-1)
+    assert bool(same[clear].all()) and float(clear.float().mean()) > 0.95
+    order_ok = (got[2] == want[2]).all(-1) | ~clear
+    rows = order_ok & ((d[:, :, 1:8] - d[:, :, 0:7]).min(-1)[0] > 1e-6)
+    close(got[3][rows], want[3][rows], rtol=2e-4, atol_scale=1e-6)
+    close(got[3].sum(-1), torch.ones_like(got[3].sum(-1)), rtol=1e-6, atol_scale=1e-6)
