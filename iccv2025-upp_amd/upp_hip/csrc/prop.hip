@@ -300,6 +300,7 @@ __global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(const int32_t *_
     // the permutation is filled by atomics and then sorted per row: in LDS when it fits (an insertion sort on global
     // memory is a chain of ~1 us round trips), written out coalesced at the end
     int32_t *perm = PERM_IN_LDS ? scan + kCsrThreads : perm_out;
+    int32_t *prow = perm + n;               // PERM_IN_LDS: the row of every filled slot
     const int tid = threadIdx.x;
     for (int r = tid; r < rows; r += kCsrThreads) cnt[r] = 0;
     __syncthreads();
@@ -343,12 +344,30 @@ __global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(const int32_t *_
         for (int t = 0; t < 8; ++t) {
             const int q = q0 + t * kCsrThreads;
             const int k = q < n ? key_of(q, raw[t]) : -1;
-            if (k >= 0) perm[atomicAdd(&cnt[k], 1)] = q;
+            if (k >= 0) {
+                const int pos = atomicAdd(&cnt[k], 1);
+                perm[pos] = q;
+                if (PERM_IN_LDS) prow[pos] = k;
+            }
         }
     }
     __threadfence_block();
     __syncthreads();
-    {   // the atomics filled each segment in arbitrary order: insertion-sort it (segments are short) -> stable CSR
+    if (PERM_IN_LDS) {
+        // The atomics filled each row's segment in arbitrary order.  Rank sort, one thread per ENTRY: its final slot is
+        // segment start + the number of smaller positions in its segment -- independent LDS reads (no dependent
+        // read-modify-write chain as in an insertion sort) and balanced over the threads whatever the segment lengths.
+        const int total = scan[kCsrThreads - 1];      // inclusive scan of the row counts: number of valid entries
+        for (int p = tid; p < total; p += kCsrThreads) {
+            const int v = perm[p], k = prow[p];
+            const int e = cnt[k], sgm = k > 0 ? cnt[k - 1] : 0;   // after the fill cnt[k] is the END of row k
+            int rank = 0;
+            for (int bq = sgm; bq < e; ++bq) rank += perm[bq] < v ? 1 : 0;
+            perm_out[sgm + rank] = v;
+        }
+        return;
+    }
+    {   // global-memory variant (lists too long for LDS): insertion sort per row
         int base = first;
         for (int r = lo; r < hi; ++r) {
             const int end = cnt[r];
@@ -360,11 +379,6 @@ __global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(const int32_t *_
             }
             base = end;
         }
-    }
-    if (PERM_IN_LDS) {
-        __syncthreads();
-        const int total = scan[kCsrThreads - 1];      // inclusive scan of the row counts: number of valid entries
-        for (int q = tid; q < total; q += kCsrThreads) perm_out[q] = perm[q];
     }
 }
 
@@ -749,7 +763,7 @@ extern "C" int upp_csr_build(const int32_t *keys, int n, int seg_len, int seg_ro
     if (!keys || !start || !perm || n < 1 || rows < 1 || seg_len < 1 || seg_rows < 0) return UPP_E_BADARG;
     const size_t lds = ((size_t)rows + kCsrThreads) * sizeof(int32_t);
     if (lds > 64 * 1024) return UPP_E_RANGE;    // counts of every row live in LDS (rows <= 15360)
-    const size_t lds_perm = lds + (size_t)n * sizeof(int32_t);
+    const size_t lds_perm = lds + (size_t)2 * n * sizeof(int32_t);      // + permutation and its row ids
     if (lds_perm <= 150 * 1024) {
         static bool raised = false;
         if (!raised) {
