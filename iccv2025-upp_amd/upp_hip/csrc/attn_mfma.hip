@@ -2,7 +2,7 @@
 // Same contract as attn_fwd / attn_bwd in block.hip (which remain the general path for longer sequences); see
 // include/upp_hip.h upp_attn_fwd / upp_attn_bwd and reference models/Point_MAE_pretask_dev.py:186-193.
 //
-// One workgroup (4 waves) per (sample, head).  Q, K, V (and dO) are staged once in LDS (rows padded to 65 floats so
+// One workgroup (8 waves) per (sample, head).  Q, K, V (and dO) are staged once in LDS (rows padded to 65 floats so
 // that both the row-major and the transposed one-dword-per-lane MFMA operand reads are bank-conflict free), every
 // product is a set of 32x32 output tiles of v_mfma_f32_32x32x2_f32 dealt round-robin to the waves:
 //   forward : S = Q K^T (9 tiles) -> row softmax in LDS -> O = P V (6 tiles)
@@ -17,6 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kLP = 96;          // padded sequence length
 constexpr int kLD = 65;          // row stride of the (L x 64) operand tiles
 constexpr int kLS = 97;          // row stride of the (L x L) score buffer
+constexpr int kNW = 8;           // waves per workgroup: two per SIMD -- a lone wave issues MFMAs at about half the pipe rate
 
 // acc(32x32) += A(32 x K) . B(K x 32).  Element A(i,k): TA ? a[k*lda + i] : a[i*lda + k];  B(k,j): TB ? b[j*ldb + k] : b[k*ldb + j]
 template <bool TA, bool TB, int K>
@@ -115,13 +116,13 @@ __device__ __forceinline__ int tile_row(int r, int lk) { return (r & 3) + 8 * (r
 // (6 float4 per thread and array) instead of load -> wait -> write per iteration.
 template <int NARR>
 __device__ __forceinline__ void stage_rows(float *const (&dst)[NARR], const float *const (&src)[NARR], const size_t (&rs)[NARR], int L) {
-    constexpr int IT = kLP * 16 / 256;
+    constexpr int IT = kLP * 16 / (64 * kNW);
     float4 v[NARR][IT];
 #pragma unroll
     for (int a = 0; a < NARR; ++a)
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int i = threadIdx.x + it * 256;
+            const int i = threadIdx.x + it * 64 * kNW;
             const int r = i >> 4, c = (i & 15) * 4;
             v[a][it] = r < L ? *reinterpret_cast<const float4 *>(src[a] + (size_t)r * rs[a] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -129,13 +130,13 @@ __device__ __forceinline__ void stage_rows(float *const (&dst)[NARR], const floa
     for (int a = 0; a < NARR; ++a)
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int i = threadIdx.x + it * 256;
+            const int i = threadIdx.x + it * 64 * kNW;
             float *d = dst[a] + (i >> 4) * kLD + (i & 15) * 4;
             d[0] = v[a][it].x; d[1] = v[a][it].y; d[2] = v[a][it].z; d[3] = v[a][it].w;
         }
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
+__global__ __launch_bounds__(64 * kNW) void attn_fwd_mfma_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
                                                             float *__restrict__ lse, int L, int H, float scale) {
     extern __shared__ float sm[];
     float *Qs = sm, *Ks = Qs + kLP * kLD, *Vs = Ks + kLP * kLD, *Ss = Vs + kLP * kLD;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float *__restr
     }
     __syncthreads();
     const int nt = (L + 31) / 32;                       // tiles along the sequence
-    for (int t = wave; t < nt * nt; t += 4) {           // S = Q K^T, scaled
+    for (int t = wave; t < nt * nt; t += kNW) {         // S = Q K^T, scaled
         const int it = t / nt, jt = t - it * nt;
         f32x16 acc; zero(acc);
         mfma_tile<false, true>(acc, Qs + it * 32 * kLD, kLD, Ks + jt * 32 * kLD, kLD, 64, lr, lk);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float *__restr
     __syncthreads();
     // row softmax, lane = key (2 slots cover the 96 columns).  A wave takes FOUR rows per iteration: the reductions
     // are latency chains (DPP + readlane), four independent ones interleave in the pipeline.
-    for (int i0 = wave * 4; i0 < L; i0 += 16) {
+    for (int i0 = wave * 4; i0 < L; i0 += 4 * kNW) {
         float s0[4], s1[4], mx[4], e0[4], e1[4], sum[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -191,26 +192,24 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const float *__restr
             }
         }
     }
-    for (int i = L + wave; i < nt * 32; i += 4) {       // padded query rows contribute nothing
+    for (int i = L + wave; i < nt * 32; i += kNW) {     // padded query rows contribute nothing
         Ss[i * kLS + lane] = 0.0f;
         if (lane + 64 < kLP) Ss[i * kLS + lane + 64] = 0.0f;
     }
     __syncthreads();
-    for (int it = wave; it < nt; it += 4) {             // O = P V: a wave owns a 32-row block, both 32-column halves at once
-        f32x16 acc[2]; zero(acc[0]); zero(acc[1]);
-        const float *const vb[2] = {Vs, Vs + 32};
-        mfma_tiles<false, false, 2>(acc, Ss + it * 32 * kLS, kLS, vb, kLD, nt * 32, lr, lk);
+    for (int t = wave; t < nt * 2; t += kNW) {          // O = P V
+        const int it = t >> 1, dt = t & 1;
+        f32x16 acc; zero(acc);
+        mfma_tile<false, false>(acc, Ss + it * 32 * kLS, kLS, Vs + dt * 32, kLD, nt * 32, lr, lk);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = it * 32 + tile_row(r, lk);
-                if (i < L) ctx[((size_t)b * L + i) * (H * 64) + hh * 64 + dt * 32 + lr] = acc[dt][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int i = it * 32 + tile_row(r, lk);
+            if (i < L) ctx[((size_t)b * L + i) * (H * 64) + hh * 64 + dt * 32 + lr] = acc[r];
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float *__restrict__ qkv, const float *__restrict__ ctx,
+__global__ __launch_bounds__(64 * kNW) void attn_bwd_mfma_kernel(const float *__restrict__ qkv, const float *__restrict__ ctx,
                                                             const float *__restrict__ d_ctx, const float *__restrict__ lse,
                                                             float *__restrict__ d_qkv, int L, int H, float scale) {
     extern __shared__ float sm[];
@@ -230,12 +229,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float *__restr
         const size_t strides[4] = {rs, rs, rs, cs};
         stage_rows<4>(dst, src, strides, L);
     }
-    {   // delta_i = dO_i . O_i ; lse_i  -- 24 rows per wave, all loads first
-        constexpr int RW = kLP / 4;
+    {   // delta_i = dO_i . O_i ; lse_i  -- kLP / kNW rows per wave, all loads first
+        constexpr int RW = kLP / kNW;
         float g[RW], o[RW], ls[RW];
 #pragma unroll
         for (int t = 0; t < RW; ++t) {
-            const int i = wave + 4 * t;
+            const int i = wave + kNW * t;
             const bool ok = i < L;
             g[t] = ok ? gbase[(size_t)i * cs + lane] : 0.0f;
             o[t] = ok ? obase[(size_t)i * cs + lane] : 0.0f;
@@ -248,15 +247,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float *__restr
             for (int q = 0; q < 4; ++q) d[q] = wave_sum_f32(g[t0 + q] * o[t0 + q]);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (lane == 0) { delta[wave + 4 * (t0 + q)] = d[q]; lses[wave + 4 * (t0 + q)] = ls[t0 + q]; }
+                if (lane == 0) { delta[wave + kNW * (t0 + q)] = d[q]; lses[wave + kNW * (t0 + q)] = ls[t0 + q]; }
         }
     }
     __syncthreads();
     const int nt = (L + 31) / 32;
-    // phase 1: P and dS tiles in registers (a wave owns at most 3 of the <= 9 tiles)
-    f32x16 pt[3], dst[3];
+    // phase 1: P and dS tiles in registers (a wave owns at most 2 of the <= 9 tiles)
+    f32x16 pt[2], dst[2];
     int nown = 0;
-    for (int t = wave; t < nt * nt; t += 4, ++nown) {
+    for (int t = wave; t < nt * nt; t += kNW, ++nown) {
         const int it = t / nt, jt = t - it * nt;
         f32x16 s, dp; zero(s); zero(dp);
         mfma_tile<false, true>(s, Qs + it * 32 * kLD, kLD, Ks + jt * 32 * kLD, kLD, 64, lr, lk);
@@ -273,18 +272,18 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float *__restr
             dp[r] = p * (dp[r] - dr_[r]) * scale;
         }
         // static register indexing of the per-wave tile store
-        if (nown == 0) { pt[0] = s; dst[0] = dp; } else if (nown == 1) { pt[1] = s; dst[1] = dp; } else { pt[2] = s; dst[2] = dp; }
+        if (nown == 0) { pt[0] = s; dst[0] = dp; } else { pt[1] = s; dst[1] = dp; }
     }
     // phase 2: P -> LDS, dV = P^T dO
     nown = 0;
-    for (int t = wave; t < nt * nt; t += 4, ++nown) {
+    for (int t = wave; t < nt * nt; t += kNW, ++nown) {
         const int it = t / nt, jt = t - it * nt;
-        const f32x16 v = nown == 0 ? pt[0] : (nown == 1 ? pt[1] : pt[2]);
+        const f32x16 v = nown == 0 ? pt[0] : pt[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) Ss[(it * 32 + tile_row(r, lk)) * kLS + jt * 32 + lr] = v[r];
     }
     __syncthreads();
-    for (int t = wave; t < nt * 2; t += 4) {
+    for (int t = wave; t < nt * 2; t += kNW) {
         const int jt = t >> 1, dt = t & 1;
         f32x16 acc; zero(acc);
         mfma_tile<true, false>(acc, Ss + jt * 32, kLS, Gs + dt * 32, kLD, nt * 32, lr, lk);
@@ -297,14 +296,14 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float *__restr
     __syncthreads();
     // phase 3: dS -> LDS, dK = dS^T Q, dQ = dS K
     nown = 0;
-    for (int t = wave; t < nt * nt; t += 4, ++nown) {
+    for (int t = wave; t < nt * nt; t += kNW, ++nown) {
         const int it = t / nt, jt = t - it * nt;
-        const f32x16 v = nown == 0 ? dst[0] : (nown == 1 ? dst[1] : dst[2]);
+        const f32x16 v = nown == 0 ? dst[0] : dst[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) Ss[(it * 32 + tile_row(r, lk)) * kLS + jt * 32 + lr] = v[r];
     }
     __syncthreads();
-    for (int t = wave; t < nt * 4; t += 4) {
+    for (int t = wave; t < nt * 4; t += kNW) {
         const int which = t / (nt * 2), u = t - which * nt * 2;   // 0: dK tiles, 1: dQ tiles
         const int rt = u >> 1, dt = u & 1;
         f32x16 acc; zero(acc);
@@ -331,7 +330,7 @@ int upp_attn_fwd_mfma(const float *qkv, float *ctx, float *lse, int B, int L, in
         if (e != hipSuccess) return (int)e;
         raised = true;
     }
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), kFwdLds, st, qkv, ctx, lse, L, H, scale);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(64 * kNW), kFwdLds, st, qkv, ctx, lse, L, H, scale);
     return upp_launch_status();
 }
 
@@ -343,6 +342,6 @@ int upp_attn_bwd_mfma(const float *qkv, const float *ctx, const float *d_ctx, co
         if (e != hipSuccess) return (int)e;
         raised = true;
     }
-    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), kBwdLds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(64 * kNW), kBwdLds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
     return upp_launch_status();
 }
