@@ -17,7 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kLP = 96;          // padded sequence length
 constexpr int kLD = 65;          // row stride of the (L x 64) operand tiles
 constexpr int kLS = 97;          // row stride of the (L x L) score buffer
-constexpr int kNW = 8;           // waves per workgroup: two per SIMD -- a lone wave issues MFMAs at about half the pipe rate
+constexpr int kNW = 8;           // waves per workgroup (backward): two per SIMD -- a lone wave issues MFMAs at about half the pipe rate
+constexpr int kFW = 16;          // forward: 80 VGPRs leave room for four waves per SIMD
 
 // acc(32x32) += A(32 x K) . B(K x 32).  Element A(i,k): TA ? a[k*lda + i] : a[i*lda + k];  B(k,j): TB ? b[j*ldb + k] : b[k*ldb + j]
 template <bool TA, bool TB, int K>
@@ -114,15 +115,15 @@ __device__ __forceinline__ int tile_row(int r, int lk) { return (r & 3) + 8 * (r
 // Stage rows [0, L) x 64 of NARR sources (row stride rs floats each) into dst[a][kLP][kLD], zero rows >= L.
 // A dependent global load costs ~1 us here, so ALL loads of all arrays are issued before the first LDS write
 // (6 float4 per thread and array) instead of load -> wait -> write per iteration.
-template <int NARR>
+template <int NARR, int NW>
 __device__ __forceinline__ void stage_rows(float *const (&dst)[NARR], const float *const (&src)[NARR], const size_t (&rs)[NARR], int L) {
-    constexpr int IT = kLP * 16 / (64 * kNW);
+    constexpr int IT = (kLP * 16 + 64 * NW - 1) / (64 * NW);
     float4 v[NARR][IT];
 #pragma unroll
     for (int a = 0; a < NARR; ++a)
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int i = threadIdx.x + it * 64 * kNW;
+            const int i = threadIdx.x + it * 64 * NW;
             const int r = i >> 4, c = (i & 15) * 4;
             v[a][it] = r < L ? *reinterpret_cast<const float4 *>(src[a] + (size_t)r * rs[a] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -130,13 +131,15 @@ __device__ __forceinline__ void stage_rows(float *const (&dst)[NARR], const floa
     for (int a = 0; a < NARR; ++a)
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int i = threadIdx.x + it * 64 * kNW;
-            float *d = dst[a] + (i >> 4) * kLD + (i & 15) * 4;
-            d[0] = v[a][it].x; d[1] = v[a][it].y; d[2] = v[a][it].z; d[3] = v[a][it].w;
+            const int i = threadIdx.x + it * 64 * NW;
+            if (i < kLP * 16) {
+                float *d = dst[a] + (i >> 4) * kLD + (i & 15) * 4;
+                d[0] = v[a][it].x; d[1] = v[a][it].y; d[2] = v[a][it].z; d[3] = v[a][it].w;
+            }
         }
 }
 
-__global__ __launch_bounds__(64 * kNW) void attn_fwd_mfma_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
+__global__ __launch_bounds__(64 * kFW) void attn_fwd_mfma_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
                                                             float *__restrict__ lse, int L, int H, float scale) {
     extern __shared__ float sm[];
     float *Qs = sm, *Ks = Qs + kLP * kLD, *Vs = Ks + kLP * kLD, *Ss = Vs + kLP * kLD;
@@ -149,11 +152,11 @@ __global__ __launch_bounds__(64 * kNW) void attn_fwd_mfma_kernel(const float *__
         float *const dst[3] = {Qs, Ks, Vs};
         const float *const src[3] = {base, base + H * 64, base + 2 * H * 64};
         const size_t strides[3] = {rs, rs, rs};
-        stage_rows<3>(dst, src, strides, L);
+        stage_rows<3, kFW>(dst, src, strides, L);
     }
     __syncthreads();
     const int nt = (L + 31) / 32;                       // tiles along the sequence
-    for (int t = wave; t < nt * nt; t += kNW) {         // S = Q K^T, scaled
+    for (int t = wave; t < nt * nt; t += kFW) {         // S = Q K^T, scaled
         const int it = t / nt, jt = t - it * nt;
         f32x16 acc; zero(acc);
         mfma_tile<false, true>(acc, Qs + it * 32 * kLD, kLD, Ks + jt * 32 * kLD, kLD, 64, lr, lk);
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(64 * kNW) void attn_fwd_mfma_kernel(const float *__
     __syncthreads();
     // row softmax, lane = key (2 slots cover the 96 columns).  A wave takes FOUR rows per iteration: the reductions
     // are latency chains (DPP + readlane), four independent ones interleave in the pipeline.
-    for (int i0 = wave * 4; i0 < L; i0 += 4 * kNW) {
+    for (int i0 = wave * 4; i0 < L; i0 += 4 * kFW) {
         float s0[4], s1[4], mx[4], e0[4], e1[4], sum[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -192,12 +195,12 @@ __global__ __launch_bounds__(64 * kNW) void attn_fwd_mfma_kernel(const float *__
             }
         }
     }
-    for (int i = L + wave; i < nt * 32; i += kNW) {     // padded query rows contribute nothing
+    for (int i = L + wave; i < nt * 32; i += kFW) {     // padded query rows contribute nothing
         Ss[i * kLS + lane] = 0.0f;
         if (lane + 64 < kLP) Ss[i * kLS + lane + 64] = 0.0f;
     }
     __syncthreads();
-    for (int t = wave; t < nt * 2; t += kNW) {          // O = P V
+    for (int t = wave; t < nt * 2; t += kFW) {          // O = P V
         const int it = t >> 1, dt = t & 1;
         f32x16 acc; zero(acc);
         mfma_tile<false, false>(acc, Ss + it * 32 * kLS, kLS, Vs + dt * 32, kLD, nt * 32, lr, lk);
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_mfma_kernel(const float *__
         float *const dst[4] = {Qs, Ks, Vs, Gs};
         const float *const src[4] = {base, base + H * 64, base + 2 * H * 64, gbase};
         const size_t strides[4] = {rs, rs, rs, cs};
-        stage_rows<4>(dst, src, strides, L);
+        stage_rows<4, kNW>(dst, src, strides, L);
     }
     {   // delta_i = dO_i . O_i ; lse_i  -- kLP / kNW rows per wave, all loads first
         constexpr int RW = kLP / kNW;
@@ -330,7 +333,7 @@ int upp_attn_fwd_mfma(const float *qkv, float *ctx, float *lse, int B, int L, in
         if (e != hipSuccess) return (int)e;
         raised = true;
     }
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(64 * kNW), kFwdLds, st, qkv, ctx, lse, L, H, scale);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(64 * kFW), kFwdLds, st, qkv, ctx, lse, L, H, scale);
     return upp_launch_status();
 }
 
