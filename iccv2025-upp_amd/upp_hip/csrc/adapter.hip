@@ -21,6 +21,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kH = 32;      // bottleneck width
 constexpr int kRows = 32;   // token rows per workgroup
 constexpr int kLG = 33;     // row stride of the 32x32 LDS tiles
+constexpr int kAW = 8;      // waves per workgroup: two per SIMD (a lone wave issues MFMAs at about half the pipe rate)
+constexpr int kAT = 64 * kAW;
 
 __device__ __forceinline__ int trow(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 __device__ __forceinline__ void zero16(f32x16 &a) {
@@ -68,17 +70,18 @@ __device__ __forceinline__ void mfma_chain(f32x16 &acc, FA fa, FB fb) {
 // stage `kRows` rows x D of src (row stride D; rows >= R zero) into dst with row stride D+1; all loads first
 template <int D>
 __device__ __forceinline__ void stage_tile(float *dst, const float *src, int row0, int R, float mul = 1.0f) {
-    constexpr int IT = kRows * D / 4 / 256;
+    constexpr int IT = kRows * D / 4 / kAT;
+    static_assert(kRows * D / 4 % kAT == 0, "tile must divide over the workgroup");
     float4 v[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int i = threadIdx.x + it * 256;
+        const int i = threadIdx.x + it * kAT;
         const int r = i / (D / 4), c = (i % (D / 4)) * 4;
         v[it] = row0 + r < R ? *reinterpret_cast<const float4 *>(src + (size_t)(row0 + r) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int i = threadIdx.x + it * 256;
+        const int i = threadIdx.x + it * kAT;
         float *d = dst + (i / (D / 4)) * (D + 1) + (i % (D / 4)) * 4;
         d[0] = v[it].x * mul; d[1] = v[it].y * mul; d[2] = v[it].z * mul; d[3] = v[it].w * mul;
     }
@@ -99,28 +102,28 @@ __device__ __forceinline__ void stage_w2_tile(float *dst, const float *W2, int n
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void adapter_fwd_kernel(const float *__restrict__ ha, const float *__restrict__ x,
+__global__ __launch_bounds__(kAT) void adapter_fwd_kernel(const float *__restrict__ ha, const float *__restrict__ x,
                                                           const float *__restrict__ W1, const float *__restrict__ b1,
                                                           const float *__restrict__ W2, const float *__restrict__ b2,
                                                           const float *__restrict__ u, float p, float scale,
                                                           float *__restrict__ out, float *__restrict__ s1_out, int R) {
-    constexpr int LDH = D + 1, KW = D / 4;          // K range per wave in the split-K product
+    constexpr int LDH = D + 1, KW = D / kAW;        // K range per wave in the split-K product
     extern __shared__ float sm[];
     float *Hs = sm;                                  // [32][D+1]  ha tile
     float *W1s = Hs + kRows * LDH;                   // [32][D+1]  W1
-    float *Part = W1s + kH * LDH;                    // [4][32][33] split-K partials, later the per-wave W2 tiles
-    float *Gs = Part + 4 * kRows * kLG;              // [32][33]   dropout(gelu(S1))
+    float *Part = W1s + kH * LDH;                    // [kAW][32][33] split-K partials, later the per-wave W2 tiles
+    float *Gs = Part + kAW * kRows * kLG;            // [32][33]   dropout(gelu(S1))
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lk = lane >> 5;
     const int row0 = blockIdx.x * kRows;
     // Every global load of the kernel is issued here, before the first wait: the three W2 blocks and the x rows /
     // biases of this wave's output tiles, b1 and the dropout uniforms of this thread's four S1 elements.
-    constexpr int NT = D / 32 / 4;                   // output column tiles per wave
+    constexpr int NTILES = D / 32, NT = (NTILES + kAW - 1) / kAW;   // output column tiles, and per wave (tile = wave + kAW * tt)
     float4 w2v[NT][4];
     float xv[NT][16], b2v[NT];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
-        const int n0 = (wave + 4 * tt) * 32;
+        const int n0 = min(wave + kAW * tt, NTILES - 1) * 32;        // waves past the last tile load a clamped tile and skip it below
 #pragma unroll
         for (int it = 0; it < 4; ++it) w2v[tt][it] = *reinterpret_cast<const float4 *>(W2 + (size_t)n0 * kH + (lane + it * 64) * 4);
         b2v[tt] = b2[n0 + lr];
@@ -130,10 +133,11 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float *__restric
             xv[tt][r] = row < R ? x[(size_t)row * D + n0 + lr] : 0.0f;
         }
     }
-    float b1v[4], uv[4];
+    constexpr int EQ = kRows * kH / kAT;            // S1 elements per thread
+    float b1v[EQ], uv[EQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = threadIdx.x + q * 256, i = e >> 5, j = e & 31;
+    for (int q = 0; q < EQ; ++q) {
+        const int e = threadIdx.x + q * kAT, i = e >> 5, j = e & 31;
         b1v[q] = b1[j];
         uv[q] = (u && row0 + i < R) ? u[(size_t)(row0 + i) * kH + j] : 1.0f;
     }
@@ -150,10 +154,12 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float *__restric
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = threadIdx.x + q * 256, i = e >> 5, j = e & 31;
-        const float sv = ((Part[(0 * kRows + i) * kLG + j] + Part[(1 * kRows + i) * kLG + j]) +
-                          (Part[(2 * kRows + i) * kLG + j] + Part[(3 * kRows + i) * kLG + j])) + b1v[q];
+    for (int q = 0; q < EQ; ++q) {
+        const int e = threadIdx.x + q * kAT, i = e >> 5, j = e & 31;
+        float sv = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kAW; w += 2) sv += Part[(w * kRows + i) * kLG + j] + Part[((w + 1) * kRows + i) * kLG + j];   // fixed order
+        sv += b1v[q];
         float gq = 0.0f;
         if (row0 + i < R) {
             s1_out[(size_t)(row0 + i) * kH + j] = sv;
@@ -165,7 +171,8 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float *__restric
     float *W2t = Part + wave * kRows * kLG;          // Part is free after the reduction above
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {                // out tile columns [n0, n0+32)
-        const int n0 = (wave + 4 * tt) * 32;
+        if (wave + kAW * tt >= NTILES) break;        // wave-uniform
+        const int n0 = (wave + kAW * tt) * 32;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {             // this wave's W2 block -> its LDS tile [n][j] (row stride 33)
             const int e = (lane + it * 64) * 4;
@@ -188,33 +195,34 @@ __global__ __launch_bounds__(256) void adapter_fwd_kernel(const float *__restric
 
 // backward.  part layout per workgroup b: dW1 [32][D] | dW2 [D][32] | db1 [32] | db2 [D]
 template <int D>
-__global__ __launch_bounds__(256) void adapter_bwd_kernel(const float *__restrict__ g_out, const float *__restrict__ ha,
+__global__ __launch_bounds__(kAT) void adapter_bwd_kernel(const float *__restrict__ g_out, const float *__restrict__ ha,
                                                           const float *__restrict__ s1, const float *__restrict__ W1,
                                                           const float *__restrict__ W2, const float *__restrict__ u, float p,
                                                           float scale, float *__restrict__ g_ha, float *__restrict__ part, int R) {
-    constexpr int LDH = D + 1, KW = D / 4;
+    constexpr int LDH = D + 1, KW = D / kAW;
     extern __shared__ float sm[];
     float *Zs = sm;                                  // [32][D+1]  gz = scale * g_out
     float *Hs = Zs + kRows * LDH;                    // [32][D+1]  ha
-    float *Part = Hs + kRows * LDH;                  // [4][32][33]
-    float *GAs = Part + 4 * kRows * kLG;             // [32][33]   g_a1
+    float *Part = Hs + kRows * LDH;                  // [kAW][32][33]
+    float *GAs = Part + kAW * kRows * kLG;           // [32][33]   g_a1
     float *Ds = GAs + kRows * kLG;                   // [32][33]   d = dropout(gelu(S1))
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lk = lane >> 5;
     const int row0 = blockIdx.x * kRows;
     float *pw1 = part + (size_t)blockIdx.x * (2 * kH * D + kH + D);
     float *pw2 = pw1 + kH * D, *pb1 = pw2 + D * kH, *pb2 = pb1 + kH;
-    float s1v[4], uv[4];                             // loads for the element-wise stage, issued before the first wait
+    constexpr int EQ = kRows * kH / kAT;
+    float s1v[EQ], uv[EQ];                           // loads for the element-wise stage, issued before the first wait
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = threadIdx.x + q * 256, i = e >> 5, j = e & 31;
+    for (int q = 0; q < EQ; ++q) {
+        const int e = threadIdx.x + q * kAT, i = e >> 5, j = e & 31;
         const bool ok = row0 + i < R;
         s1v[q] = ok ? s1[(size_t)(row0 + i) * kH + j] : 0.0f;
         uv[q] = (u && ok) ? u[(size_t)(row0 + i) * kH + j] : 1.0f;
     }
     // weight operands of the two products that read W2 / W1, held in registers from the start (an operand fetched
     // from global memory inside an MFMA chain is one exposed round trip per chunk)
-    constexpr int NT = D / 32 / 4;
+    constexpr int NTILES = D / 32, NT = (NTILES + kAW - 1) / kAW;
     float w2r[KW / 2], w1r[NT][kH / 2];
     {
         const float *wcol = W2 + (size_t)(wave * KW + lk) * kH + lr;
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float *__restric
         for (int q = 0; q < KW / 2; ++q) w2r[q] = wcol[(size_t)2 * q * kH];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            const float *wrow = W1 + (size_t)lk * D + (wave + 4 * tt) * 32 + lr;
+            const float *wrow = W1 + (size_t)lk * D + min(wave + kAW * tt, NTILES - 1) * 32 + lr;
 #pragma unroll
             for (int q = 0; q < kH / 2; ++q) w1r[tt][q] = wrow[(size_t)2 * q * D];
         }
@@ -239,10 +247,11 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float *__restric
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = threadIdx.x + q * 256, i = e >> 5, j = e & 31;
-        const float gd = (Part[(0 * kRows + i) * kLG + j] + Part[(1 * kRows + i) * kLG + j]) +
-                         (Part[(2 * kRows + i) * kLG + j] + Part[(3 * kRows + i) * kLG + j]);
+    for (int q = 0; q < EQ; ++q) {
+        const int e = threadIdx.x + q * kAT, i = e >> 5, j = e & 31;
+        float gd = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kAW; w += 2) gd += Part[(w * kRows + i) * kLG + j] + Part[((w + 1) * kRows + i) * kLG + j];   // fixed order
         float ga = 0.0f, d = 0.0f;
         if (row0 + i < R) {
             const float f = u ? (uv[q] >= p ? 1.0f / (1.0f - p) : 0.0f) : 1.0f;
@@ -254,14 +263,15 @@ __global__ __launch_bounds__(256) void adapter_bwd_kernel(const float *__restric
     }
     __syncthreads();
     // bias partials: db1[j] = sum_i ga[i][j], db2[n] = sum_i gz[i][n]   (row order: deterministic)
-    for (int c = threadIdx.x; c < kH + D; c += 256) {
+    for (int c = threadIdx.x; c < kH + D; c += kAT) {
         float sacc = 0.0f;
         if (c < kH) { for (int i = 0; i < kRows; ++i) sacc += GAs[i * kLG + c]; pb1[c] = sacc; }
         else { const int n = c - kH; for (int i = 0; i < kRows; ++i) sacc += Zs[i * LDH + n]; pb2[n] = sacc; }
     }
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
-        const int n0 = (wave + 4 * tt) * 32;
+        if (wave + kAW * tt >= NTILES) break;        // wave-uniform
+        const int n0 = (wave + kAW * tt) * 32;
         {   // g_ha[i][n] = sum_j ga[i][j] W1[j][n]
             f32x16 acc; zero16(acc);
             const float *arow = GAs + lr * kLG + lk;
@@ -311,10 +321,10 @@ extern "C" int upp_adapter_fwd(const float *ha, const float *x, const float *W1,
                                const float *u, float p, float scale, float *out, float *s1, int R, int D, int H, void *stream) {
     if (!ha || !x || !W1 || !b1 || !W2 || !b2 || !out || !s1 || R < 1) return UPP_E_BADARG;
     if (D != 384 || H != kH) return UPP_E_RANGE;
-    const size_t lds = ((size_t)(kRows + kH) * (D + 1) + 5 * kRows * kLG) * sizeof(float);
+    const size_t lds = ((size_t)(kRows + kH) * (D + 1) + (kAW + 1) * kRows * kLG) * sizeof(float);
     static bool raised = false;
     if (!raised) { int rc = raise_lds(adapter_fwd_kernel<384>, lds); if (rc) return rc; raised = true; }
-    hipLaunchKernelGGL((adapter_fwd_kernel<384>), dim3((R + kRows - 1) / kRows), dim3(256), lds, (hipStream_t)stream, ha, x, W1, b1, W2,
+    hipLaunchKernelGGL((adapter_fwd_kernel<384>), dim3((R + kRows - 1) / kRows), dim3(kAT), lds, (hipStream_t)stream, ha, x, W1, b1, W2,
                        b2, u, p, scale, out, s1, R);
     return upp_launch_status();
 }
@@ -323,10 +333,10 @@ extern "C" int upp_adapter_bwd(const float *g_out, const float *ha, const float 
                                float p, float scale, float *g_ha, float *part, int R, int D, int H, void *stream) {
     if (!g_out || !ha || !s1 || !W1 || !W2 || !g_ha || !part || R < 1) return UPP_E_BADARG;
     if (D != 384 || H != kH) return UPP_E_RANGE;
-    const size_t lds = ((size_t)2 * kRows * (D + 1) + 6 * kRows * kLG) * sizeof(float);
+    const size_t lds = ((size_t)2 * kRows * (D + 1) + (kAW + 2) * kRows * kLG) * sizeof(float);
     static bool raised = false;
     if (!raised) { int rc = raise_lds(adapter_bwd_kernel<384>, lds); if (rc) return rc; raised = true; }
-    hipLaunchKernelGGL((adapter_bwd_kernel<384>), dim3((R + kRows - 1) / kRows), dim3(256), lds, (hipStream_t)stream, g_out, ha, s1, W1,
+    hipLaunchKernelGGL((adapter_bwd_kernel<384>), dim3((R + kRows - 1) / kRows), dim3(kAT), lds, (hipStream_t)stream, g_out, ha, s1, W1,
                        W2, u, p, scale, g_ha, part, R);
     return upp_launch_status();
 }
