@@ -262,9 +262,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int C, double count, c
     if (MODE == 0 && training) {
         double s = 0.0, q = 0.0;
         if (live)
-            for (int i = ty; i < slabs; i += 16) {
-                s += (double)stat_part[(size_t)i * C + c];
-                q += (double)stat_part[((size_t)slabs + i) * C + c];
+            for (int i0 = ty; i0 < slabs; i0 += 16 * 8) {       // 16 independent loads in flight (a dependent load is ~1 us)
+                float ps[8], pq[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int i = min(i0 + 16 * t, slabs - 1);
+                    ps[t] = stat_part[(size_t)i * C + c];
+                    pq[t] = stat_part[((size_t)slabs + i) * C + c];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) if (i0 + 16 * t < slabs) { s += (double)ps[t]; q += (double)pq[t]; }
             }
         rs[ty][tx] = s; rq[ty][tx] = q;
         __syncthreads();
