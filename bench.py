@@ -1,5 +1,10 @@
 """bench.py -- point-clouds/sec of one UPP / Point-MAE training step on MI355X.
 
+Each timed step does the complete work of one batch: prompting front-end (rectify + completion prompters), forward,
+cross-entropy, backward, clip + AdamW.  By default the front-end of batch k+1 runs on a second HIP stream while the
+back-end of batch k runs on the first (upp_hip.train.PipelinedTrainStep; same results as running them one after the
+other in that order, tests/test_gpu_block.py); --no-pipeline times the one-stream step.
+
 Workload (BASELINE.json configs[2] / SURVEY 8d): Point_MAE_unify, cfgs/unify_modelnet_cls.yaml,
 noisy-train recipe (B=32 clouds per GPU of N = 1024 + 48 lidar + 24 shell-noise points; rectify +
 completion prompters on), PEFT stage-1 freezing (619,176 trainable parameters), cross-entropy,
@@ -45,15 +50,18 @@ def build_model(device):
 class Trainer:
     """Synthetic-data wrapper around upp_hip.train.TrainStep (the product's step driver)."""
 
-    def __init__(self, device, batch, distributed, use_graph=True):
+    def __init__(self, device, batch, distributed, use_graph=True, pipeline=False):
         import _seeded
-        from upp_hip.train import TrainStep
+        from upp_hip.train import TrainStep, PipelinedTrainStep
         self.model = build_model(device).train()
         rank = dist.get_rank() if distributed else 0
         pts = _seeded.noisy_clouds(batch, 1024, seed=rank).to(device)             # (B,1096,3) resident in HBM
         g = torch.Generator().manual_seed(rank)
         labels = torch.randint(0, 40, (batch,), generator=g).to(device)
-        self.ts = TrainStep(self.model, tuple(pts.shape), use_graph=use_graph)
+        if pipeline and use_graph and device.type == 'cuda':
+            self.ts = PipelinedTrainStep(self.model, tuple(pts.shape))   # front-end of batch k+1 overlaps the back-end of batch k
+        else:
+            self.ts = TrainStep(self.model, tuple(pts.shape), use_graph=use_graph)
         self.ts.pts.copy_(pts)
         self.ts.labels.copy_(labels)
 
@@ -259,6 +267,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (debug)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM solutions (see upp_hip/gemm_tuning.py)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the prompting front-end and the trainable back-end of a step one after the other (one stream)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -277,7 +287,10 @@ def main():
         from upp_hip import gemm_tuning
         gemm_tuning.enable()                              # best hipBLASLt / rocBLAS solution per Linear shape (same f32 math)
 
-    tr = Trainer(device, args.batch, distributed, use_graph=not args.no_graph)
+    pipeline = not args.no_pipeline and not args.no_graph
+    tr = Trainer(device, args.batch, distributed, use_graph=not args.no_graph, pipeline=pipeline)
+    if pipeline:
+        tr.step()                                         # prime: the first call only runs the front-end of batch 0 (never timed)
     for _ in range(args.warmup):
         tr.step()
 
@@ -309,7 +322,8 @@ def main():
             "config": {"workload": "Point_MAE_unify unify_modelnet_cls noisy-train fwd+bwd+AdamW, PEFT stage-1, "
                                    "B=%d/GPU x (1024+72) pts, G=64 k=32" % args.batch,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "hip_graph": not args.no_graph},
+                       "hip_graph": not args.no_graph,
+                       "pipeline": "front-end(k+1) || back-end(k) on two streams" if pipeline else "none"},
             "roofline": dom,
             "kernels": stages,
         }

@@ -178,11 +178,25 @@ class Point_MAE_unify(PromptedBackbone):
         finally:
             L.end_forward()
 
-    def _forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
+    def prompt_points(self, pts, completion_prompt=True, denoise=True, point_num=1024):
+        """The prompting front-end alone: raw (noisy / incomplete) clouds -> rectified + completed clouds (B, point_num, 3).
+        `forward(prompt_points(pts), completion_prompt=False, denoise=False)` == `forward(pts, True, True)`; a training
+        step may run this for the NEXT batch while the trainable back-end works on the current one (TrainStep pipeline)."""
+        L.begin_forward(pts.device, self.training)
+        try:
+            return self._prompt(pts, completion_prompt, denoise, point_num)
+        finally:
+            L.end_forward()
+
+    def _prompt(self, pts, completion_prompt, denoise, point_num):
         if denoise:
             pts = self._rectify(pts, point_num)
         if completion_prompt:
             pts = self._complete(pts, point_num)
+        return pts
+
+    def _forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
+        pts = self._prompt(pts, completion_prompt, denoise, point_num)
 
         neighborhood, center = self.group_divider(pts)
         tokens = self.encoder(neighborhood)

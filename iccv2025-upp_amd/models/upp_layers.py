@@ -74,7 +74,14 @@ def end_forward():
     global _pending_counters
     pending, _pending_counters = _pending_counters, None
     if pending:
-        torch._foreach_add_(pending, 1)
+        # a module called several times per forward (the shared patch embedding) appears several times: one entry per
+        # tensor with its count -- duplicates inside one multi-tensor launch would race and lose increments
+        uniq, count = {}, {}
+        for t in pending:
+            uniq[t.data_ptr()] = t
+            count[t.data_ptr()] = count.get(t.data_ptr(), 0) + 1
+        keys = list(uniq)
+        torch._foreach_add_([uniq[k] for k in keys], [count[k] for k in keys])
 
 
 class DropPath(nn.Module):

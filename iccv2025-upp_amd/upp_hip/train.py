@@ -148,12 +148,14 @@ class TrainStep:
                               if self.device.type == 'cuda' else None)
 
     # -- the two halves of a step ------------------------------------------------------------
-    def _forward_backward(self):
+    def _forward_backward(self, pts=None, labels=None, kw=None):
+        pts = self.pts if pts is None else pts
+        labels = self.labels if labels is None else labels
         self.flat.zero()
         for p in self.trainable:
             p.grad = None              # let autograd write fresh gradients: no per-parameter accumulate kernels
-        logits = self.model(self.pts, **self.kw)
-        loss, acc = self.model.get_loss_acc(logits, self.labels)
+        logits = self.model(pts, **(self.kw if kw is None else kw))
+        loss, acc = self.model.get_loss_acc(logits, labels)
         # partial-sum reductions of parameter gradients: one launch after the pass, straight into the (zeroed) flat buffer
         with HF.deferred_sums(self._grad_targets) as scope:
             loss.backward()
@@ -209,4 +211,153 @@ class TrainStep:
             if self.distributed:
                 self.flat.reduce()
             self._update()
+        return self.loss
+
+
+_BACK_END_KEYS = ('downstream', 'bnorm', 'cls_')     # trainable parameters the prompting front-end never reads
+
+
+class PipelinedTrainStep(TrainStep):
+    """TrainStep with the frozen prompting front-end (rectify + completion prompters: `model.prompt_points`) software-
+    pipelined against the trainable back-end: while stream A runs forward + loss + backward of batch k, stream B already
+    turns batch k+1 into prompted clouds.  Both halves are launch/latency-bound at B = 32, so two HIP graphs on two
+    streams overlap almost completely (8.0 -> ~6 ms per step).  Results are those of the sequential order
+    front(k+1), back(k), opt(k):
+
+      * the front-end reads no trainable parameter (checked: every trainable name must match _BACK_END_KEYS), so the
+        prompted clouds are what the sequential step would compute;
+      * the only state both halves write is the running statistics of the shared patch-embedding BatchNorms.  During the
+        back-end they are redirected to zero-initialised shadow buffers (a momentum update from 0 leaves m * batch
+        statistic there); after the join  real = (1 - m) * real + shadow  applies the update in that order, exactly.
+
+    step(pts, labels) feeds batch k and returns the loss of batch k-1 (one step of latency; the first call only primes the
+    pipeline; flush() finishes the last batch).  The front graph is captured on its own stream so that library GEMM
+    workspaces are not shared between graphs that run concurrently."""
+
+    def __init__(self, model, batch_shape, grad_clip=10.0, forward_kwargs=None, lr=5e-4):
+        super().__init__(model, batch_shape, grad_clip=grad_clip, use_graph=True, forward_kwargs=forward_kwargs, lr=lr)
+        if self.device.type != 'cuda' or not hasattr(model, 'prompt_points'):
+            raise RuntimeError("PipelinedTrainStep needs a HIP device and a model with prompt_points()")
+        names = {id(p): n for n, p in model.named_parameters()}
+        bad = [names[id(p)] for p in self.trainable if not any(k in names[id(p)] for k in _BACK_END_KEYS)]
+        if bad:
+            raise RuntimeError("front-end / back-end pipelining needs a frozen front-end; trainable: %s ..." % bad[:3])
+        if not (self.kw.get('completion_prompt') or self.kw.get('denoise')):
+            raise RuntimeError("nothing to pipeline: both prompters are off")
+        self.point_num = self.kw.get('point_num', 1024)
+        self.kw_back = dict(self.kw, completion_prompt=False, denoise=False)
+        B = batch_shape[0]
+        self.prompted = [torch.zeros(B, self.point_num, 3, device=self.device) for _ in range(2)]
+        self.labels2 = [torch.zeros(B, dtype=torch.long, device=self.device) for _ in range(2)]
+        self.s_front = torch.cuda.Stream(device=self.device)
+        self._bns = [m for m in model.encoder.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats]
+        if any(m.momentum is None for m in self._bns):
+            raise RuntimeError("cumulative-average BatchNorm statistics cannot be pipelined")
+        self._real = [t for m in self._bns for t in (m.running_mean, m.running_var)]
+        self._shadow = [torch.zeros_like(t) for t in self._real]
+        self._decay = [1.0 - m.momentum for m in self._bns for _ in range(2)]
+        self._counters = [m.num_batches_tracked for m in self._bns]
+        self._shadow_counters = [torch.zeros_like(t) for t in self._counters]
+        self._k = 0
+        self._g_front = self._g_back = None
+
+    # -- the three parts of a step -----------------------------------------------------------
+    def _front(self, p):
+        with torch.no_grad():
+            self.prompted[p].copy_(self.model.prompt_points(self.pts, completion_prompt=bool(self.kw.get('completion_prompt')),
+                                                            denoise=bool(self.kw.get('denoise')), point_num=self.point_num))
+
+    class _Shadowed:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __enter__(self):
+            ts = self.ts
+            it, ic = iter(ts._shadow), iter(ts._shadow_counters)
+            for m in ts._bns:
+                m._buffers['running_mean'], m._buffers['running_var'] = next(it), next(it)
+                m._buffers['num_batches_tracked'] = next(ic)
+
+        def __exit__(self, *exc):
+            ts = self.ts
+            it, ic = iter(ts._real), iter(ts._counters)
+            for m in ts._bns:
+                m._buffers['running_mean'], m._buffers['running_var'] = next(it), next(it)
+                m._buffers['num_batches_tracked'] = next(ic)
+            return False
+
+    def _back(self, p):
+        with PipelinedTrainStep._Shadowed(self):
+            self._forward_backward(self.prompted[p], self.labels2[p], self.kw_back)
+
+    def _tail(self):
+        self._update()
+        # fold the back-end's BatchNorm statistics (m * batch statistic, accumulated from zero) into the real buffers
+        torch._foreach_mul_(self._real, self._decay)
+        torch._foreach_add_(self._real, self._shadow)
+        torch._foreach_zero_(self._shadow)
+        torch._foreach_add_(self._counters, self._shadow_counters)
+        torch._foreach_zero_(self._shadow_counters)
+
+    def _capture(self):
+        cur = torch.cuda.current_stream(self.device)
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):                 # eager warm-up (also tunes GEMM shapes, sizes the uniform bank)
+            for _ in range(2):
+                self._front(0)
+                self._back(0)
+                self._tail()
+        cur.wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        self._g_front, self._g_back = [], []
+        for p in range(2):
+            gf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gf, stream=self.s_front):
+                self._front(p)
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb):
+                self._back(p)
+            self._g_front.append(gf)
+            self._g_back.append(gb)
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt):
+            self._tail()
+        torch.cuda.synchronize(self.device)
+
+    def _finish(self, p):
+        if self.distributed:
+            self.flat.reduce()
+        self._g_opt.replay()
+
+    def step(self, pts=None, labels=None):
+        if self._g_front is None:
+            self._capture()
+        p = self._k & 1
+        if pts is not None:
+            self.pts.copy_(pts)
+        if labels is not None:
+            self.labels2[p].copy_(labels)
+            self.labels.copy_(labels)
+        elif self._k < 2:
+            self.labels2[p].copy_(self.labels)
+        cur = torch.cuda.current_stream(self.device)
+        self.s_front.wait_stream(cur)
+        with torch.cuda.stream(self.s_front):
+            self._g_front[p].replay()              # batch k: raw -> prompted[p]
+        if self._k > 0:
+            self._g_back[1 - p].replay()           # batch k-1: forward + loss + backward, concurrently
+        cur.wait_stream(self.s_front)
+        if self._k > 0:
+            self._finish(1 - p)
+        self._k += 1
+        return self.loss
+
+    def flush(self):
+        """Run the back-end of the batch whose front-end ran last (end of an epoch)."""
+        if self._k > 0:
+            p = (self._k - 1) & 1
+            self._g_back[p].replay()
+            self._finish(p)
+        self._k = 0
         return self.loss

@@ -409,3 +409,66 @@ def test_prop_index_kernel_matches_the_torch_formulation(B, Lp, off, G2, gather_
     rows = order_ok & ((d[:, :, 1:8] - d[:, :, 0:7]).min(-1)[0] > 1e-6)
     close(got[3][rows], want[3][rows], rtol=2e-4, atol_scale=1e-6)
     close(got[3].sum(-1), torch.ones_like(got[3].sum(-1)), rtol=1e-6, atol_scale=1e-6)
+
+
+def test_pipelined_train_step_equals_the_sequential_order():
+    """front(k+1) || back(k) on two streams == the same calls run one after the other on the real BatchNorm buffers."""
+    from upp_hip.train import TrainStep, PipelinedTrainStep, freeze_for_peft
+
+    def make():
+        m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda().train()
+        for mod in m.modules():               # identical random streams are impossible across the two orders: no dropout
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if hasattr(mod, 'drop_prob'):
+                mod.drop_prob = 0.0
+        freeze_for_peft(m)
+        return m
+
+    B, steps = 4, 4
+    raws = [_seeded.noisy_clouds(B, 1024, seed=40 + k).cuda() for k in range(steps)]
+    labels = [torch.tensor([k, 2 * k + 1, 7, 39 - k], device='cuda') for k in range(steps)]
+    kw = dict(completion_prompt=True, denoise=True, point_num=1024)
+
+    m_ref = make()
+    ref = TrainStep(m_ref, tuple(raws[0].shape), use_graph=False, forward_kwargs=kw)
+    kw_back = dict(kw, completion_prompt=False, denoise=False)
+    losses_ref = []
+    with torch.no_grad():
+        prev = m_ref.prompt_points(raws[0], True, True, 1024)
+    for k in range(1, steps):
+        with torch.no_grad():
+            nxt = m_ref.prompt_points(raws[k], True, True, 1024)
+        ref._forward_backward(prev, labels[k - 1], kw_back)
+        ref._update()
+        losses_ref.append(float(ref.loss))
+        prev = nxt
+    ref._forward_backward(prev, labels[steps - 1], kw_back)
+    ref._update()
+    losses_ref.append(float(ref.loss))
+
+    m_pipe = make()
+    pipe = PipelinedTrainStep(m_pipe, tuple(raws[0].shape), forward_kwargs=kw)
+    pipe._capture()
+    _seeded.fill(m_pipe)                       # the capture warm-up trained two steps: back to the seed state ...
+    pipe.opt.m.zero_(); pipe.opt.v.zero_(); pipe.opt.state.zero_()    # ... and a fresh optimizer
+    for mod in m_pipe.modules():
+        if hasattr(mod, 'num_batches_tracked') and mod.num_batches_tracked is not None:
+            mod.num_batches_tracked.zero_()
+    for mod in m_ref.modules():
+        pass
+    losses = []
+    for k in range(steps):
+        pipe.step(raws[k], labels[k])
+        if k > 0:
+            losses.append(float(pipe.loss))
+    pipe.flush()
+    losses.append(float(pipe.loss))
+    np.testing.assert_allclose(losses, losses_ref, rtol=2e-4)
+    sd_ref, sd = m_ref.state_dict(), m_pipe.state_dict()
+    for kname in sd_ref:
+        if 'num_batches_tracked' in kname:
+            continue
+        close(sd[kname], sd_ref[kname], rtol=5e-4, atol_scale=5e-5)
+    enc_counters = [kname for kname in sd_ref if kname.startswith('encoder.') and 'num_batches_tracked' in kname]
+    assert enc_counters and all(int(sd[kname]) == 3 * steps for kname in enc_counters)

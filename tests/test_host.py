@@ -46,3 +46,17 @@ def test_misc_helpers():
     g = misc.gaussian_noise([2, 24, 3], scale=0.1)
     r = g.norm(dim=-1)
     assert g.shape == (2, 24, 3) and (r > 0.5).all() and (r < 1.5).all()
+
+
+def test_batch_counters_count_every_call_of_a_shared_module():
+    """The per-forward counter list may hold one BatchNorm counter several times (shared patch embedding)."""
+    import torch
+    from models import upp_layers as L
+    a, b = torch.zeros((), dtype=torch.long), torch.zeros((), dtype=torch.long)
+    L.begin_forward(torch.device('cpu'), True)
+    for t in (a, b, a, a):
+        L.bump_counter(t)
+    L.end_forward()
+    assert int(a) == 3 and int(b) == 1
+    L.bump_counter(b)                      # outside a forward: immediate
+    assert int(b) == 2
