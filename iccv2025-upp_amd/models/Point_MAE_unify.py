@@ -180,11 +180,29 @@ class Point_MAE_unify(PromptedBackbone):
 
     def prompt_points(self, pts, completion_prompt=True, denoise=True, point_num=1024):
         """The prompting front-end alone: raw (noisy / incomplete) clouds -> rectified + completed clouds (B, point_num, 3).
-        `forward(prompt_points(pts), completion_prompt=False, denoise=False)` == `forward(pts, True, True)`; a training
-        step may run this for the NEXT batch while the trainable back-end works on the current one (TrainStep pipeline)."""
+        `forward(prompt_points(pts), completion_prompt=False, denoise=False)` == `forward(pts, True, True)`."""
         L.begin_forward(pts.device, self.training)
         try:
             return self._prompt(pts, completion_prompt, denoise, point_num)
+        finally:
+            L.end_forward()
+
+    def prompt_tokens(self, pts, completion_prompt=True, denoise=True, point_num=1024):
+        """Everything of the forward that reads no PEFT-trainable parameter: the prompting front-end, the grouping of the
+        prompted cloud and its patch embedding -> (tokens (B,G,C), centres (B,G,3)).  `forward_tokens(*prompt_tokens(pts))`
+        == `forward(pts, True, True)`; a training step may run this for the NEXT batch while the trainable back-end works
+        on the current one (upp_hip.train.PipelinedTrainStep)."""
+        L.begin_forward(pts.device, self.training)
+        try:
+            return self._embed(self._prompt(pts, completion_prompt, denoise, point_num))
+        finally:
+            L.end_forward()
+
+    def forward_tokens(self, tokens, center):
+        """The trainable back-end: prompted tokens + centres -> logits."""
+        L.begin_forward(tokens.device, self.training)
+        try:
+            return self._head(tokens, center)
         finally:
             L.end_forward()
 
@@ -195,11 +213,11 @@ class Point_MAE_unify(PromptedBackbone):
             pts = self._complete(pts, point_num)
         return pts
 
-    def _forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
-        pts = self._prompt(pts, completion_prompt, denoise, point_num)
-
+    def _embed(self, pts):
         neighborhood, center = self.group_divider(pts)
-        tokens = self.encoder(neighborhood)
+        return self.encoder(neighborhood), center
+
+    def _head(self, tokens, center):
         B = tokens.size(0)
         x = torch.cat((self.cls_token.expand(B, -1, -1), tokens), dim=1)
         pos_tokens = self.pos_embed(center)
@@ -213,3 +231,6 @@ class Point_MAE_unify(PromptedBackbone):
                         classification=True, **propagation)
         x = self.norm(x)
         return self.cls_head_finetune(torch.cat([x[:, 0], x[:, 1:].max(1)[0]], dim=-1))
+
+    def _forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
+        return self._head(*self._embed(self._prompt(pts, completion_prompt, denoise, point_num)))

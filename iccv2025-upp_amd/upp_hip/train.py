@@ -154,7 +154,7 @@ class TrainStep:
         self.flat.zero()
         for p in self.trainable:
             p.grad = None              # let autograd write fresh gradients: no per-parameter accumulate kernels
-        logits = self.model(pts, **(self.kw if kw is None else kw))
+        logits = self.model.forward_tokens(*pts) if isinstance(pts, tuple) else self.model(pts, **(self.kw if kw is None else kw))
         loss, acc = self.model.get_loss_acc(logits, labels)
         # partial-sum reductions of parameter gradients: one launch after the pass, straight into the (zeroed) flat buffer
         with HF.deferred_sums(self._grad_targets) as scope:
@@ -218,17 +218,20 @@ _BACK_END_KEYS = ('downstream', 'bnorm', 'cls_')     # trainable parameters the 
 
 
 class PipelinedTrainStep(TrainStep):
-    """TrainStep with the frozen prompting front-end (rectify + completion prompters: `model.prompt_points`) software-
-    pipelined against the trainable back-end: while stream A runs forward + loss + backward of batch k, stream B already
+    """TrainStep with everything that reads no trainable parameter (rectify + completion prompters, grouping and patch
+    embedding of the prompted cloud: `model.prompt_tokens`) software-pipelined against the trainable back-end
+    (`model.forward_tokens`): while stream A runs forward + loss + backward of batch k, stream B already
     turns batch k+1 into prompted clouds.  Both halves are launch/latency-bound at B = 32, so two HIP graphs on two
     streams overlap almost completely (8.0 -> ~6 ms per step).  Results are those of the sequential order
     front(k+1), back(k), opt(k):
 
       * the front-end reads no trainable parameter (checked: every trainable name must match _BACK_END_KEYS), so the
         prompted clouds are what the sequential step would compute;
-      * the only state both halves write is the running statistics of the shared patch-embedding BatchNorms.  During the
-        back-end they are redirected to zero-initialised shadow buffers (a momentum update from 0 leaves m * batch
-        statistic there); after the join  real = (1 - m) * real + shadow  applies the update in that order, exactly.
+      * state both halves could write: the running statistics of the patch-embedding BatchNorms.  `prompt_tokens` covers
+        every call of the patch embedding, so the back-end does not touch them; should a model's back-end do so, they are
+        redirected to zero-initialised shadow buffers during the back-end (a momentum update from 0 leaves m * batch
+        statistic there) and  real = (1 - m) * real + shadow  applies the update after the join, in that order, exactly
+        (the warm-up detects whether this merge is needed).
 
     step(pts, labels) feeds batch k and returns the loss of batch k-1 (one step of latency; the first call only primes the
     pipeline; flush() finishes the last batch).  The front graph is captured on its own stream so that library GEMM
@@ -236,8 +239,8 @@ class PipelinedTrainStep(TrainStep):
 
     def __init__(self, model, batch_shape, grad_clip=10.0, forward_kwargs=None, lr=5e-4):
         super().__init__(model, batch_shape, grad_clip=grad_clip, use_graph=True, forward_kwargs=forward_kwargs, lr=lr)
-        if self.device.type != 'cuda' or not hasattr(model, 'prompt_points'):
-            raise RuntimeError("PipelinedTrainStep needs a HIP device and a model with prompt_points()")
+        if self.device.type != 'cuda' or not hasattr(model, 'prompt_tokens'):
+            raise RuntimeError("PipelinedTrainStep needs a HIP device and a model with prompt_tokens() / forward_tokens()")
         names = {id(p): n for n, p in model.named_parameters()}
         bad = [names[id(p)] for p in self.trainable if not any(k in names[id(p)] for k in _BACK_END_KEYS)]
         if bad:
@@ -247,7 +250,13 @@ class PipelinedTrainStep(TrainStep):
         self.point_num = self.kw.get('point_num', 1024)
         self.kw_back = dict(self.kw, completion_prompt=False, denoise=False)
         B = batch_shape[0]
-        self.prompted = [torch.zeros(B, self.point_num, 3, device=self.device) for _ in range(2)]
+        with torch.no_grad():       # shapes of the hand-over buffers: tokens (B,G,C) and centres (B,G,3)
+            was = model.training
+            tok, cen = model.eval().prompt_tokens(torch.zeros(1, batch_shape[1], 3, device=self.device).uniform_(-1, 1),
+                                                  completion_prompt=False, denoise=False, point_num=self.point_num)
+            model.train(was)
+        self.tokens = [torch.zeros((B,) + tuple(tok.shape[1:]), device=self.device) for _ in range(2)]
+        self.centers = [torch.zeros((B,) + tuple(cen.shape[1:]), device=self.device) for _ in range(2)]
         self.labels2 = [torch.zeros(B, dtype=torch.long, device=self.device) for _ in range(2)]
         self.s_front = torch.cuda.Stream(device=self.device)
         self._bns = [m for m in model.encoder.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats]
@@ -259,13 +268,16 @@ class PipelinedTrainStep(TrainStep):
         self._counters = [m.num_batches_tracked for m in self._bns]
         self._shadow_counters = [torch.zeros_like(t) for t in self._counters]
         self._k = 0
+        self._merge = True
         self._g_front = self._g_back = None
 
     # -- the three parts of a step -----------------------------------------------------------
     def _front(self, p):
         with torch.no_grad():
-            self.prompted[p].copy_(self.model.prompt_points(self.pts, completion_prompt=bool(self.kw.get('completion_prompt')),
-                                                            denoise=bool(self.kw.get('denoise')), point_num=self.point_num))
+            tok, cen = self.model.prompt_tokens(self.pts, completion_prompt=bool(self.kw.get('completion_prompt')),
+                                                denoise=bool(self.kw.get('denoise')), point_num=self.point_num)
+            self.tokens[p].copy_(tok)
+            self.centers[p].copy_(cen)
 
     class _Shadowed:
         def __init__(self, ts):
@@ -287,11 +299,13 @@ class PipelinedTrainStep(TrainStep):
             return False
 
     def _back(self, p):
-        with PipelinedTrainStep._Shadowed(self):
-            self._forward_backward(self.prompted[p], self.labels2[p], self.kw_back)
+        with PipelinedTrainStep._Shadowed(self):       # (the back-end no longer runs the patch embedding: kept as a guard)
+            self._forward_backward((self.tokens[p], self.centers[p]), self.labels2[p])
 
     def _tail(self):
         self._update()
+        if not self._merge:
+            return
         # fold the back-end's BatchNorm statistics (m * batch statistic, accumulated from zero) into the real buffers
         torch._foreach_mul_(self._real, self._decay)
         torch._foreach_add_(self._real, self._shadow)
@@ -304,9 +318,13 @@ class PipelinedTrainStep(TrainStep):
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(cur)
         with torch.cuda.stream(s):                 # eager warm-up (also tunes GEMM shapes, sizes the uniform bank)
-            for _ in range(2):
+            for it in range(2):
                 self._front(0)
                 self._back(0)
+                if it == 0:
+                    # does the back-end touch the BatchNorms it shares with the front-end at all?  (With prompt_tokens
+                    # covering the patch embedding it does not; the shadow merge then must not decay the real buffers.)
+                    self._merge = any(int(c) != 0 for c in self._shadow_counters)
                 self._tail()
         cur.wait_stream(s)
         torch.cuda.synchronize(self.device)

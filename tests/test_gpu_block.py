@@ -435,10 +435,10 @@ def test_pipelined_train_step_equals_the_sequential_order():
     kw_back = dict(kw, completion_prompt=False, denoise=False)
     losses_ref = []
     with torch.no_grad():
-        prev = m_ref.prompt_points(raws[0], True, True, 1024)
+        prev = m_ref.prompt_tokens(raws[0], True, True, 1024)
     for k in range(1, steps):
         with torch.no_grad():
-            nxt = m_ref.prompt_points(raws[k], True, True, 1024)
+            nxt = m_ref.prompt_tokens(raws[k], True, True, 1024)
         ref._forward_backward(prev, labels[k - 1], kw_back)
         ref._update()
         losses_ref.append(float(ref.loss))
@@ -472,3 +472,60 @@ def test_pipelined_train_step_equals_the_sequential_order():
         close(sd[kname], sd_ref[kname], rtol=5e-4, atol_scale=5e-5)
     enc_counters = [kname for kname in sd_ref if kname.startswith('encoder.') and 'num_batches_tracked' in kname]
     assert enc_counters and all(int(sd[kname]) == 3 * steps for kname in enc_counters)
+
+
+def test_pipelined_step_merges_batchnorm_statistics_shared_by_both_halves():
+    """A back-end that updates a BatchNorm the front-end also updates: shadow buffers + merge == the sequential order."""
+    import copy
+    import torch.nn as nn
+    from upp_hip.train import PipelinedTrainStep
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = nn.Sequential(nn.Linear(3, 8), nn.BatchNorm1d(8))
+            self.cls_head = nn.Linear(8, 4)
+            for p in self.encoder.parameters():
+                p.requires_grad_(False)
+
+        def prompt_tokens(self, pts, completion_prompt=True, denoise=True, point_num=16):
+            B, N, _ = pts.shape
+            return self.encoder(pts.reshape(-1, 3)).view(B, N, 8), pts[:, :1].contiguous()
+
+        def forward_tokens(self, tok, cen):
+            y = self.encoder[1](tok.reshape(-1, 8) * 2.0 + cen.mean()).view_as(tok)      # the shared BatchNorm again
+            return self.cls_head(y.mean(1))
+
+        def forward(self, pts, **kw):
+            return self.forward_tokens(*self.prompt_tokens(pts))
+
+        def get_loss_acc(self, ret, gt):
+            return nn.functional.cross_entropy(ret, gt), (ret.argmax(-1) == gt).float().mean() * 100
+
+    torch.manual_seed(0)
+    base = Toy().cuda().train()
+    steps, B = 5, 6
+    raws = [torch.randn(B, 16, 3, device='cuda') * (1 + 0.3 * k) + 0.2 * k for k in range(steps)]
+    labels = [torch.randint(0, 4, (B,), device='cuda') for _ in range(steps)]
+    # sequential order front(0), [front(k), back(k-1), sgd-free: gradients only], back(last) on the real buffers
+    ref = copy.deepcopy(base)
+    with torch.no_grad():
+        prev = ref.prompt_tokens(raws[0])
+    for k in range(1, steps):
+        with torch.no_grad():
+            nxt = ref.prompt_tokens(raws[k])
+        ref.forward_tokens(*prev)
+        prev = nxt
+    ref.forward_tokens(*prev)
+    pipe_model = copy.deepcopy(base)
+    ts = PipelinedTrainStep(pipe_model, (B, 16, 3), forward_kwargs=dict(completion_prompt=True, denoise=True, point_num=16), lr=0.0)
+    ts._capture()
+    assert ts._merge
+    pipe_model.load_state_dict(base.state_dict())         # undo the capture warm-up (lr = 0: only the statistics moved)
+    for k in range(steps):
+        ts.step(raws[k], labels[k])
+    ts.flush()
+    bn_ref, bn = ref.encoder[1], pipe_model.encoder[1]
+    close(bn.running_mean, bn_ref.running_mean, rtol=1e-5, atol_scale=1e-6)
+    close(bn.running_var, bn_ref.running_var, rtol=1e-5, atol_scale=1e-6)
+    assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked) == 2 * steps
