@@ -12,6 +12,7 @@ import torch.nn.functional as F
 from utils import misc
 from .build import MODELS
 from . import upp_layers as L
+from upp_hip import functional as HF
 from .upp_layers import (  # noqa: F401  (re-exported: the reference's sibling modules import these from here)
     Block, Encoder, Group, RectifyPrompter, TransformerDecoder, TransformerEncoder,
     pooling, propagate, trunc_normal_,
@@ -188,23 +189,38 @@ class Point_MAE_unify(PromptedBackbone):
             L.end_forward()
 
     def prompt_tokens(self, pts, completion_prompt=True, denoise=True, point_num=1024):
-        """Everything of the forward that reads no PEFT-trainable parameter: the prompting front-end, the grouping of the
-        prompted cloud and its patch embedding -> (tokens (B,G,C), centres (B,G,3)).  `forward_tokens(*prompt_tokens(pts))`
-        == `forward(pts, True, True)`; a training step may run this for the NEXT batch while the trainable back-end works
-        on the current one (upp_hip.train.PipelinedTrainStep)."""
+        """Everything of the forward that reads no PEFT-trainable parameter: the prompting front-end, grouping and patch
+        embedding of the prompted cloud, positional embedding of the centres, the level-2 grouping and the index lists of
+        the propagation step -> a flat tuple of tensors `state` (tokens (B,G,C), centres (B,G,3), ...).
+        `forward_tokens(*prompt_tokens(pts))` == `forward(pts, True, True)`; a training step may run this for the NEXT batch
+        while the trainable back-end works on the current one (upp_hip.train.PipelinedTrainStep)."""
         L.begin_forward(pts.device, self.training)
         try:
-            return self._embed(self._prompt(pts, completion_prompt, denoise, point_num))
+            return self._front_state(self._prompt(pts, completion_prompt, denoise, point_num))
         finally:
             L.end_forward()
 
-    def forward_tokens(self, tokens, center):
-        """The trainable back-end: prompted tokens + centres -> logits."""
+    def forward_tokens(self, tokens, center, *rest):
+        """The trainable back-end: the state produced by prompt_tokens -> logits."""
         L.begin_forward(tokens.device, self.training)
         try:
-            return self._head(tokens, center)
+            return self._head(tokens, center, rest)
         finally:
             L.end_forward()
+
+    def _front_state(self, pts):
+        tokens, center = self._embed(pts)
+        state = (tokens, center, self.pos_embed(center))
+        lvl2 = self._level2(center)
+        if lvl2:
+            state += (lvl2['center2'], lvl2['center1_idx'], lvl2['center2_idx'])
+            prompts = getattr(self.blocks.blocks[0], 'downstream_prompts', None)
+            if tokens.is_cuda and prompts is not None and lvl2['center2'].shape[1] <= 64:
+                B, Lp = tokens.shape[0], 1 + tokens.shape[1] + prompts.shape[0]      # [cls | prompts | tokens] rows per sample
+                entry = L.build_prop_index(center, lvl2['center2'], lvl2['center1_idx'], lvl2['center2_idx'],
+                                           bool(self.config.gather_idx), B, Lp, 1)
+                state += entry.tensors()
+        return state
 
     def _prompt(self, pts, completion_prompt, denoise, point_num):
         if denoise:
@@ -217,13 +233,21 @@ class Point_MAE_unify(PromptedBackbone):
         neighborhood, center = self.group_divider(pts)
         return self.encoder(neighborhood), center
 
-    def _head(self, tokens, center):
+    def _head(self, tokens, center, rest=()):
         B = tokens.size(0)
         x = torch.cat((self.cls_token.expand(B, -1, -1), tokens), dim=1)
-        pos_tokens = self.pos_embed(center)
+        pos_tokens = rest[0] if len(rest) > 0 else self.pos_embed(center)
         pos = torch.cat((self.cls_pos.expand(B, -1, -1), pos_tokens), dim=1)
 
-        propagation = self._level2(center)
+        if len(rest) >= 4:         # level-2 grouping handed over by prompt_tokens
+            propagation = dict(center1=center, center1_idx=rest[2], center2=rest[1], center2_idx=rest[3],
+                               gather_idx=self.config.gather_idx, prompt_propagation_after=self.config.prompt_propagation_after)
+            if len(rest) >= 14:    # ... and the propagation index lists for the [cls | prompts | tokens] layout
+                prompts = self.blocks.blocks[0].downstream_prompts
+                Lp = 1 + tokens.shape[1] + prompts.shape[0]
+                propagation['_prop_entry'] = ((B, Lp, 1), HF.PropIndex.from_tensors(rest[4:14], rows=B * Lp))
+        else:
+            propagation = self._level2(center)
         if torch.is_grad_enabled() and self.cls_pos.requires_grad and not pos_tokens.requires_grad:
             # only row 0 of `pos` is trainable (PEFT): let the fused blocks route its gradient (see TransformerEncoder)
             propagation['cls_pos_param'] = self.cls_pos

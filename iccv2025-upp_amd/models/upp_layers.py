@@ -152,6 +152,17 @@ def _prop_lists_torch(c1, c2, i1, i2, gather_idx, B, Lp, off):
     return i1a.reshape(-1).int().contiguous(), i2a.reshape(-1).int().contiguous(), idx8.int().contiguous(), w8
 
 
+def build_prop_index(c1, c2, i1, i2, gather_idx, B, Lp, off):
+    """HF.PropIndex of the fused propagation step for a (B, Lp)-row token matrix with `off` leading rows per sample."""
+    G2 = c2.shape[1]
+    with torch.no_grad():
+        if G2 <= 64 and i1.dtype == torch.int64 and i2.dtype == torch.int64:
+            lists = HF.ops.prop_index(c1.contiguous(), c2.contiguous(), i1.contiguous(), i2.contiguous(), gather_idx, Lp, off, 1e-3)
+        else:
+            lists = _prop_lists_torch(c1, c2, i1, i2, gather_idx, B, Lp, off)
+        return HF.PropIndex(*lists, rows=B * Lp)
+
+
 def propagate(xyz1, xyz2, points1, points2, de_neighbors=64, dist_e=1e-8):
     """points1 + 0.3 * inverse-distance interpolation of points2  (models/Point_MAE_unify.py:22-48)."""
     return points1 + 0.3 * _inverse_distance_interp(xyz1, xyz2, points2, de_neighbors, dist_e)
@@ -435,15 +446,11 @@ class Block(nn.Module):
         T, G2 = c1.shape[1], c2.shape[1]
         cache = kw.get('_prop_cache')
         key = (Lp, off)
-        if cache is None or key not in cache:
-            i1, i2 = kw['center1_idx'], kw['center2_idx']
-            with torch.no_grad():
-                if G2 <= 64 and i1.dtype == torch.int64 and i2.dtype == torch.int64:
-                    lists = HF.ops.prop_index(c1.contiguous(), c2.contiguous(), i1.contiguous(), i2.contiguous(),
-                                              bool(kw.get('gather_idx')), Lp, off, 1e-3)      # the four lists in one launch
-                else:
-                    lists = _prop_lists_torch(c1, c2, i1, i2, bool(kw.get('gather_idx')), B, Lp, off)
-                entry = HF.PropIndex(*lists, rows=B * Lp)
+        pre = kw.get('_prop_entry')        # built ahead of time (pipelined front-end) for exactly this token layout?
+        if pre is not None and pre[0] == (B, Lp, off):
+            entry = pre[1]
+        elif cache is None or key not in cache:
+            entry = build_prop_index(c1, c2, kw['center1_idx'], kw['center2_idx'], bool(kw.get('gather_idx')), B, Lp, off)
             if cache is not None:
                 cache[key] = entry
         else:

@@ -353,14 +353,25 @@ class PropIndex:
     i1 (groups*8), level-2 centre rows i2 (groups), interpolation neighbours idx8 / weights w8 (B,T,8), and their inverses
     (CSR) for the backward kernels.  Built once per forward and shared by every block."""
 
-    def __init__(self, i1, i2, idx8, w8, rows):
+    def __init__(self, i1, i2, idx8, w8, rows, csr=None):
         B, T = idx8.shape[0], idx8.shape[1]
         groups = i2.numel()
         self.i1, self.i2, self.idx8, self.w8 = i1, i2, idx8, w8
         self.B, self.T, self.G2, self.rows = B, T, groups // B, rows
-        self.csr1 = ops.csr_build(i1, rows)
-        self.csr2 = ops.csr_build(i2, rows)
-        self.csr8 = ops.csr_build(idx8.view(-1), groups, seg_len=T * 8, seg_rows=groups // B)
+        if csr is None:
+            self.csr1 = ops.csr_build(i1, rows)
+            self.csr2 = ops.csr_build(i2, rows)
+            self.csr8 = ops.csr_build(idx8.view(-1), groups, seg_len=T * 8, seg_rows=groups // B)
+        else:
+            self.csr1, self.csr2, self.csr8 = csr
+
+    def tensors(self):
+        """The ten tensors of the index (for handing it from one HIP graph to another through static buffers)."""
+        return (self.i1, self.i2, self.idx8, self.w8) + self.csr1 + self.csr2 + self.csr8
+
+    @classmethod
+    def from_tensors(cls, t, rows):
+        return cls(t[0], t[1], t[2], t[3], rows, csr=((t[4], t[5]), (t[6], t[7]), (t[8], t[9])))
 
 
 class _Propagate(Function):

@@ -250,13 +250,12 @@ class PipelinedTrainStep(TrainStep):
         self.point_num = self.kw.get('point_num', 1024)
         self.kw_back = dict(self.kw, completion_prompt=False, denoise=False)
         B = batch_shape[0]
-        with torch.no_grad():       # shapes of the hand-over buffers: tokens (B,G,C) and centres (B,G,3)
+        with torch.no_grad():       # shapes / dtypes of the hand-over state: one run of the front-end on a random batch
             was = model.training
-            tok, cen = model.eval().prompt_tokens(torch.zeros(1, batch_shape[1], 3, device=self.device).uniform_(-1, 1),
-                                                  completion_prompt=False, denoise=False, point_num=self.point_num)
+            probe = model.eval().prompt_tokens(torch.zeros(batch_shape, device=self.device).uniform_(-1, 1),
+                                               completion_prompt=False, denoise=False, point_num=self.point_num)
             model.train(was)
-        self.tokens = [torch.zeros((B,) + tuple(tok.shape[1:]), device=self.device) for _ in range(2)]
-        self.centers = [torch.zeros((B,) + tuple(cen.shape[1:]), device=self.device) for _ in range(2)]
+        self.state = [[torch.zeros_like(t) for t in probe] for _ in range(2)]
         self.labels2 = [torch.zeros(B, dtype=torch.long, device=self.device) for _ in range(2)]
         self.s_front = torch.cuda.Stream(device=self.device)
         self._bns = [m for m in model.encoder.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats]
@@ -274,10 +273,9 @@ class PipelinedTrainStep(TrainStep):
     # -- the three parts of a step -----------------------------------------------------------
     def _front(self, p):
         with torch.no_grad():
-            tok, cen = self.model.prompt_tokens(self.pts, completion_prompt=bool(self.kw.get('completion_prompt')),
-                                                denoise=bool(self.kw.get('denoise')), point_num=self.point_num)
-            self.tokens[p].copy_(tok)
-            self.centers[p].copy_(cen)
+            state = self.model.prompt_tokens(self.pts, completion_prompt=bool(self.kw.get('completion_prompt')),
+                                             denoise=bool(self.kw.get('denoise')), point_num=self.point_num)
+            torch._foreach_copy_(self.state[p], list(state))      # hand-over buffers of this parity (per-dtype launches)
 
     class _Shadowed:
         def __init__(self, ts):
@@ -300,7 +298,7 @@ class PipelinedTrainStep(TrainStep):
 
     def _back(self, p):
         with PipelinedTrainStep._Shadowed(self):       # (the back-end no longer runs the patch embedding: kept as a guard)
-            self._forward_backward((self.tokens[p], self.centers[p]), self.labels2[p])
+            self._forward_backward(tuple(self.state[p]), self.labels2[p])
 
     def _tail(self):
         self._update()
