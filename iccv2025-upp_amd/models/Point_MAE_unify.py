@@ -168,6 +168,9 @@ class Point_MAE_unify(PromptedBackbone):
         self.loss_ce = nn.CrossEntropyLoss()
 
     def get_loss_acc(self, ret, gt):
+        if ret.is_cuda and ret.dtype == torch.float32 and ret.dim() == 2 and ret.shape[1] <= 512 and type(self.loss_ce) is nn.CrossEntropyLoss \
+                and self.loss_ce.weight is None and self.loss_ce.label_smoothing == 0.0 and self.loss_ce.reduction == 'mean':
+            return HF.cross_entropy_acc(ret, gt.long())        # loss, accuracy and d loss / d logits: one launch
         loss = self.loss_ce(ret, gt.long())
         acc = (ret.argmax(-1) == gt).sum() / float(gt.size(0))
         return loss, acc * 100
@@ -253,8 +256,13 @@ class Point_MAE_unify(PromptedBackbone):
             propagation['cls_pos_param'] = self.cls_pos
         x = self.blocks(x, pos, path='downstream', downstream_adapter=True, downstream_prompts=True,
                         classification=True, **propagation)
-        x = self.norm(x)
-        return self.cls_head_finetune(torch.cat([x[:, 0], x[:, 1:].max(1)[0]], dim=-1))
+        if (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 512 and x.shape[1] >= 2 and isinstance(self.norm, nn.LayerNorm)
+                and not (torch.is_grad_enabled() and (self.norm.weight.requires_grad or self.norm.bias.requires_grad))):
+            feat = HF.cls_pool(x, self.norm)                   # final LayerNorm + [cls | max over tokens]: one launch each way
+        else:
+            x = self.norm(x)
+            feat = torch.cat([x[:, 0], x[:, 1:].max(1)[0]], dim=-1)
+        return self.cls_head_finetune(feat)
 
     def _forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
         return self._head(*self._embed(self._prompt(pts, completion_prompt, denoise, point_num)))

@@ -421,6 +421,49 @@ def posenc(x, freqs, out=None, col0=0):
     return ops.posenc_fwd(x.contiguous(), freqs, out, col0)
 
 
+# ------------------------------------------------------------------ classification tail
+class _ClsPool(Function):
+    """feat = [LN(x)[:, 0] | max over rows 1.. of LN(x)]  (upp_cls_pool_fwd / bwd); LayerNorm parameters get no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        feat, amax, mean, rstd = ops.cls_pool_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, mean, rstd, gamma, amax)
+        return feat
+
+    @staticmethod
+    def backward(ctx, g_feat):
+        x, mean, rstd, gamma, amax = ctx.saved_tensors
+        return ops.cls_pool_bwd(g_feat.contiguous(), x, mean, rstd, gamma, amax), None, None, None
+
+
+def cls_pool(x, norm):
+    """torch.cat([norm(x)[:, 0], norm(x)[:, 1:].max(1)[0]], -1) for a frozen nn.LayerNorm `norm`."""
+    return _ClsPool.apply(x, norm.weight, norm.bias, float(norm.eps))
+
+
+class _CrossEntropyAcc(Function):
+    """(mean cross-entropy, top-1 accuracy * 100) of logits (B,C) against int64 labels in one launch (upp_ce_acc)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        out2, dlogits = ops.ce_acc(logits.contiguous(), labels.contiguous())
+        ctx.save_for_backward(dlogits)
+        loss, acc = out2[0], out2[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_acc):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g_loss, None
+
+
+def cross_entropy_acc(logits, labels):
+    return _CrossEntropyAcc.apply(logits, labels)
+
+
 # ------------------------------------------------------------------ bottleneck adapter
 class _Adapter(Function):
     """out = x + scale * (W2 . dropout(gelu(W1 . ha + b1)) + b2); see upp_adapter_fwd."""

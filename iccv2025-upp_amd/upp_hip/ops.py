@@ -411,6 +411,39 @@ def posenc_fwd(x, freqs, out=None, col0=0):
     return out
 
 
+# ------------------------------------------------------------------ classification tail
+def cls_pool_fwd(x, gamma, beta, eps):
+    _need(x, "x", torch.float32, ndim=3)
+    B, L, D = x.shape
+    dev = x.device
+    feat = torch.empty((B, 2 * D), dtype=torch.float32, device=dev)
+    amax = torch.empty((B, D), dtype=torch.int32, device=dev)
+    mean = torch.empty(B * L, dtype=torch.float32, device=dev)
+    rstd = torch.empty(B * L, dtype=torch.float32, device=dev)
+    _call(dev, "upp_cls_pool_fwd", _abi.ptr(x), _abi.ptr(gamma), _abi.ptr(beta), float(eps), _abi.ptr(feat), _abi.ptr(amax), _abi.ptr(mean),
+          _abi.ptr(rstd), B, L, D)
+    return feat, amax, mean, rstd
+
+
+def cls_pool_bwd(g_feat, x, mean, rstd, gamma, amax):
+    _need(g_feat, "g_feat", torch.float32, ndim=2)
+    B, L, D = x.shape
+    g_x = torch.empty_like(x)
+    _call(x.device, "upp_cls_pool_bwd", _abi.ptr(g_feat), _abi.ptr(x), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma), _abi.ptr(amax),
+          _abi.ptr(g_x), B, L, D)
+    return g_x
+
+
+def ce_acc(logits, labels):
+    _need(logits, "logits", torch.float32, ndim=2)
+    _need(labels, "labels", torch.int64, ndim=1)
+    B, C = logits.shape
+    out2 = torch.empty(2, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    _call(logits.device, "upp_ce_acc", _abi.ptr(logits), _abi.ptr(labels), _abi.ptr(out2), _abi.ptr(dlogits), B, C)
+    return out2, dlogits
+
+
 # ------------------------------------------------------------------ optimizer tail
 def batched_sum(jobs):
     """jobs: list of (part 2-D f32, column offset, rows n, length, row stride, dst f32 (length elems), accumulate):

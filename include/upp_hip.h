@@ -271,6 +271,19 @@ int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab, const floa
                    int B, int N, int S, int C, int k, float eps, void *stream);
 int upp_posenc_fwd(const float *x, const float *freqs, int F, float *out, int ld_out, int col0, long long rows, void *stream);
 
+/* ---- classification tail (reference models/Point_MAE_unify.py:650-655 and get_loss_acc :499-503) ----------------
+ *   upp_cls_pool_fwd : h = LayerNorm(x) (B,L,D) with gamma / beta / eps (self.norm); feat (B,2D) = [h[:,0] | max over rows 1..L-1 of h]
+ *                      (first maximum); amax (B,D) int32 = the arg-max row; mean / rstd (B*L) saved.  h itself is not stored.
+ *   upp_cls_pool_bwd : g_x (B,L,D) from g_feat (B,2D) (dense: every row is written).  gamma / beta gradients are not
+ *                      produced (self.norm is frozen under PEFT; the caller falls back to torch ops otherwise).
+ *   upp_ce_acc       : out2[0] = mean cross-entropy of logits (B,C) against labels (B) int64, out2[1] = top-1 accuracy * 100,
+ *                      dlogits (B,C) = (softmax - onehot) / B.  C <= 512.  Deterministic. */
+int upp_cls_pool_fwd(const float *x, const float *gamma, const float *beta, float eps, float *feat, int32_t *amax, float *mean,
+                     float *rstd, int B, int L, int D, void *stream);
+int upp_cls_pool_bwd(const float *g_feat, const float *x, const float *mean, const float *rstd, const float *gamma,
+                     const int32_t *amax, float *g_x, int B, int L, int D, void *stream);
+int upp_ce_acc(const float *logits, const int64_t *labels, float *out2, float *dlogits, int B, int C, void *stream);
+
 /* ---- training step tail: gradient clipping + AdamW on flat buffers ------------------------
  * Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.AdamW.step() of the reference loop
  * (tools/runner_module.py:202-207; parameter groups of tools/builder.py:40-55) for parameters that live in one

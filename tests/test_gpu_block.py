@@ -529,3 +529,44 @@ def test_pipelined_step_merges_batchnorm_statistics_shared_by_both_halves():
     close(bn.running_mean, bn_ref.running_mean, rtol=1e-5, atol_scale=1e-6)
     close(bn.running_var, bn_ref.running_var, rtol=1e-5, atol_scale=1e-6)
     assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked) == 2 * steps
+
+
+@pytest.mark.parametrize("B,L,D", [(32, 65, 384), (3, 2, 384), (5, 130, 96), (2, 40, 500)])
+def test_cls_pool_matches_layernorm_max_concat(B, L, D):
+    torch.manual_seed(B + L)
+    x = torch.randn(B, L, D, device='cuda') * 1.3 + 0.2
+    ln = torch.nn.LayerNorm(D).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.linspace(0.5, 1.5, D)); ln.bias.copy_(torch.linspace(-0.3, 0.3, D))
+    for p_ in ln.parameters():
+        p_.requires_grad_(False)
+    w = torch.linspace(-1, 1, B * 2 * D, device='cuda').view(B, 2 * D)
+    outs = []
+    for fused in (True, False):
+        xi = x.clone().requires_grad_(True)
+        if fused:
+            feat = HF.cls_pool(xi, ln)
+        else:
+            h = ln(xi)
+            feat = torch.cat([h[:, 0], h[:, 1:].max(1)[0]], dim=-1)
+        outs.append((feat.detach(), torch.autograd.grad((feat * w).sum(), xi)[0]))
+    close(outs[0][0], outs[1][0], rtol=1e-5, atol_scale=2e-6)
+    close(outs[0][1], outs[1][1], rtol=2e-5, atol_scale=5e-6)
+
+
+@pytest.mark.parametrize("B,C", [(32, 40), (4, 40), (7, 3), (64, 500), (1, 16)])
+def test_cross_entropy_acc_matches_torch(B, C):
+    torch.manual_seed(B * C)
+    logits = (torch.randn(B, C, device='cuda') * 3).requires_grad_(True)
+    labels = torch.randint(0, C, (B,), device='cuda')
+    with torch.no_grad():
+        logits[0, labels[0]] += 20.0                      # at least one correct prediction
+    loss, acc = HF.cross_entropy_acc(logits, labels)
+    (g,) = torch.autograd.grad(loss * 1.7, logits)
+    ref_logits = logits.detach().clone().requires_grad_(True)
+    ref = F.cross_entropy(ref_logits, labels)
+    (rg,) = torch.autograd.grad(ref * 1.7, ref_logits)
+    close(loss, ref, rtol=1e-6, atol_scale=1e-6)
+    close(g, rg, rtol=1e-5, atol_scale=1e-5)      # softmax - 1 at a confidently correct label is pure cancellation noise
+    want_acc = (logits.argmax(-1) == labels).sum() / float(B) * 100
+    assert abs(float(acc) - float(want_acc)) < 1e-4 and not acc.requires_grad
