@@ -262,7 +262,28 @@ class Point_MAE_unify(PromptedBackbone):
         else:
             x = self.norm(x)
             feat = torch.cat([x[:, 0], x[:, 1:].max(1)[0]], dim=-1)
-        return self.cls_head_finetune(feat)
+        return self._cls_head(feat)
+
+    def _cls_head(self, feat):
+        """cls_head_finetune; on the HIP path every [BatchNorm1d, ReLU, Dropout] run after a Linear is one launch each way."""
+        layers = list(self.cls_head_finetune)
+        if not (feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 2):
+            return self.cls_head_finetune(feat)
+        x, i = feat, 0
+        while i < len(layers):
+            if (i + 2 < len(layers) and isinstance(layers[i], nn.BatchNorm1d) and isinstance(layers[i + 1], nn.ReLU)
+                    and isinstance(layers[i + 2], nn.Dropout) and layers[i].affine):
+                bn, drop = layers[i], layers[i + 2]
+                p = drop.p if self.training else 0.0
+                u = L.UNIFORMS.take(tuple(x.shape), x.device) if p > 0 else None
+                if self.training and bn.track_running_stats:
+                    L.bump_counter(bn.num_batches_tracked)
+                x = HF.bn_relu_drop(x, bn, u, p, self.training)
+                i += 3
+            else:
+                x = layers[i](x)
+                i += 1
+        return x
 
     def _forward(self, pts, label=None, completion_prompt=False, denoise=False, point_num=1024, **kwargs):
         return self._head(*self._embed(self._prompt(pts, completion_prompt, denoise, point_num)))

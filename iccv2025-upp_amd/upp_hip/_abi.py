@@ -48,6 +48,8 @@ SIGNATURES = {
     "upp_cls_pool_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 4 + [_c_i] * 3 + [_c_f]),
     "upp_cls_pool_bwd": (_c_i, [_c_f] * 7 + [_c_i] * 3 + [_c_f]),
     "upp_ce_acc": (_c_i, [_c_f] * 4 + [_c_i] * 2 + [_c_f]),
+    "upp_bn_relu_drop_fwd": (_c_i, [_c_f] * 5 + [ctypes.c_float] * 2 + [_c_i] + [_c_f] + [ctypes.c_float] + [_c_f] * 3 + [_c_i] * 2 + [_c_f]),
+    "upp_bn_relu_drop_bwd": (_c_i, [_c_f] * 6 + [_c_i] + [_c_f] + [ctypes.c_float] + [_c_f] * 3 + [_c_i] * 2 + [_c_f]),
     "upp_csr_build": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f] * 3),
     "upp_prop_index": (_c_i, [_c_f] * 4 + [_c_i] * 6 + [ctypes.c_float] + [_c_f] * 5),
     "upp_bn_rows_part_floats": (ctypes.c_longlong, [_c_i] * 2),

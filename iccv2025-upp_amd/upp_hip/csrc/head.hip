@@ -190,7 +190,106 @@ __global__ __launch_bounds__(1024) void ce_acc_kernel(const float *__restrict__ 
     }
 }
 
+// BatchNorm1d (batch statistics over the R rows) + ReLU + Dropout of a small (R, C) matrix, one workgroup per 64 columns:
+// lane = column, the 4 waves stride the rows; two passes over the column (mean, then M2 about it) from registers/L2.
+// Forward saves mean / rstd; the dropout mask is (u >= p) from caller-supplied uniforms, kept values scaled by 1/(1-p).
+constexpr int kBW = 4;
+__global__ __launch_bounds__(64 * kBW) void bn_relu_drop_fwd_kernel(const float *__restrict__ z, const float *__restrict__ gamma,
+                                                                    const float *__restrict__ beta, float *__restrict__ running_mean,
+                                                                    float *__restrict__ running_var, float momentum, float eps,
+                                                                    int training, const float *__restrict__ u, float p,
+                                                                    float *__restrict__ a, float *__restrict__ mean_out,
+                                                                    float *__restrict__ rstd_out, int R, int C) {
+    __shared__ float red[kBW][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int cc = min(c, C - 1);
+    float mean, rstd;
+    if (training) {
+        float s = 0.0f;
+        for (int r = wave; r < R; r += kBW) s += z[(size_t)r * C + cc];
+        red[wave][lane] = s;
+        __syncthreads();
+        mean = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)R;
+        __syncthreads();
+        float q = 0.0f;
+        for (int r = wave; r < R; r += kBW) { const float d = z[(size_t)r * C + cc] - mean; q = __builtin_fmaf(d, d, q); }
+        red[wave][lane] = q;
+        __syncthreads();
+        const float m2 = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        rstd = 1.0f / sqrtf(m2 / (float)R + eps);
+        if (wave == 0 && c < C && running_mean) {
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (m2 / (float)(R > 1 ? R - 1 : 1));
+        }
+    } else {
+        mean = running_mean[cc];
+        rstd = 1.0f / sqrtf(running_var[cc] + eps);
+    }
+    if (wave == 0 && c < C) { mean_out[c] = mean; rstd_out[c] = rstd; }
+    const float g = gamma[cc], bt = beta[cc], keep = 1.0f / (1.0f - p);
+    if (c < C)
+        for (int r = wave; r < R; r += kBW) {
+            float v = fmaxf(((z[(size_t)r * C + c] - mean) * rstd) * g + bt, 0.0f);
+            if (u) v = u[(size_t)r * C + c] >= p ? v * keep : 0.0f;
+            a[(size_t)r * C + c] = v;
+        }
+}
+
+// backward of the above (training statistics): g_z, g_gamma, g_beta from g_a; ReLU / dropout masks are recomputed.
+__global__ __launch_bounds__(64 * kBW) void bn_relu_drop_bwd_kernel(const float *__restrict__ g_a, const float *__restrict__ z,
+                                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                    const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                                    int training, const float *__restrict__ u, float p,
+                                                                    float *__restrict__ g_z, float *__restrict__ g_gamma,
+                                                                    float *__restrict__ g_beta, int R, int C) {
+    __shared__ float r1[kBW][64], r2[kBW][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int cc = min(c, C - 1);
+    const float mean = mean_in[cc], rstd = rstd_in[cc], g = gamma[cc], bt = beta[cc], keep = 1.0f / (1.0f - p);
+    auto dy_of = [&](int r, float &xh) {          // gradient w.r.t. the BatchNorm output of element (r, c)
+        xh = (z[(size_t)r * C + cc] - mean) * rstd;
+        float d = g_a[(size_t)r * C + cc];
+        if (u) d = u[(size_t)r * C + cc] >= p ? d * keep : 0.0f;
+        return (xh * g + bt) > 0.0f ? d : 0.0f;
+    };
+    float sb = 0.0f, sg = 0.0f;
+    for (int r = wave; r < R; r += kBW) { float xh; const float d = dy_of(r, xh); sb += d; sg = __builtin_fmaf(d, xh, sg); }
+    r1[wave][lane] = sb; r2[wave][lane] = sg;
+    __syncthreads();
+    sb = (r1[0][lane] + r1[1][lane]) + (r1[2][lane] + r1[3][lane]);
+    sg = (r2[0][lane] + r2[1][lane]) + (r2[2][lane] + r2[3][lane]);
+    if (wave == 0 && c < C) { g_beta[c] = sb; g_gamma[c] = sg; }
+    if (c < C)
+        for (int r = wave; r < R; r += kBW) {
+            float xh;
+            const float d = dy_of(r, xh);
+            g_z[(size_t)r * C + c] = training ? g * rstd * (d - sb / (float)R - xh * sg / (float)R) : g * rstd * d;
+        }
+}
+
 }  // namespace
+
+extern "C" int upp_bn_relu_drop_fwd(const float *z, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                    float momentum, float eps, int training, const float *u, float p, float *a, float *mean,
+                                    float *rstd, int R, int C, void *stream) {
+    if (!z || !gamma || !beta || !a || !mean || !rstd || R < 1 || C < 1 || p < 0.0f || p >= 1.0f) return UPP_E_BADARG;
+    if (!training && (!running_mean || !running_var)) return UPP_E_BADARG;
+    hipLaunchKernelGGL(bn_relu_drop_fwd_kernel, dim3((C + 63) / 64), dim3(64 * kBW), 0, (hipStream_t)stream, z, gamma, beta, running_mean,
+                       running_var, momentum, eps, training, u, p, a, mean, rstd, R, C);
+    return upp_launch_status();
+}
+
+extern "C" int upp_bn_relu_drop_bwd(const float *g_a, const float *z, const float *gamma, const float *beta, const float *mean,
+                                    const float *rstd, int training, const float *u, float p, float *g_z, float *g_gamma,
+                                    float *g_beta, int R, int C, void *stream) {
+    if (!g_a || !z || !gamma || !beta || !mean || !rstd || !g_z || !g_gamma || !g_beta || R < 1 || C < 1 || p < 0.0f || p >= 1.0f)
+        return UPP_E_BADARG;
+    hipLaunchKernelGGL(bn_relu_drop_bwd_kernel, dim3((C + 63) / 64), dim3(64 * kBW), 0, (hipStream_t)stream, g_a, z, gamma, beta, mean, rstd,
+                       training, u, p, g_z, g_gamma, g_beta, R, C);
+    return upp_launch_status();
+}
 
 extern "C" int upp_cls_pool_fwd(const float *x, const float *gamma, const float *beta, float eps, float *feat, int32_t *amax, float *mean,
                                 float *rstd, int B, int L, int D, void *stream) {

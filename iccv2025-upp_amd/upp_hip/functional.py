@@ -460,6 +460,32 @@ class _CrossEntropyAcc(Function):
         return dlogits * g_loss, None
 
 
+class _BnReluDrop(Function):
+    """Dropout(ReLU(BatchNorm1d(z))) of a few-row matrix in one launch each way (upp_bn_relu_drop_fwd / bwd)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps, training, u, p):
+        z = z.contiguous()
+        a, mean, rstd = ops.bn_relu_drop_fwd(z, gamma, beta, running_mean, running_var, momentum, eps, training, u, p)
+        ctx.save_for_backward(z, gamma, beta, mean, rstd, u)
+        ctx.meta = (training, p)
+        return a
+
+    @staticmethod
+    def backward(ctx, g_a):
+        z, gamma, beta, mean, rstd, u = ctx.saved_tensors
+        training, p = ctx.meta
+        g_z, g_gamma, g_beta = ops.bn_relu_drop_bwd(g_a.contiguous(), z, gamma, beta, mean, rstd, training, u, p)
+        return (g_z, g_gamma, g_beta) + (None,) * 7
+
+
+def bn_relu_drop(z, bn, u=None, p=0.0, training=True):
+    """dropout_p(relu(bn(z))) for a (rows, C) matrix with few rows; u: uniforms (rows, C) when p > 0 in training."""
+    use_batch = training or bn.running_mean is None
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    return _BnReluDrop.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, use_batch, u, float(p))
+
+
 def cross_entropy_acc(logits, labels):
     return _CrossEntropyAcc.apply(logits, labels)
 

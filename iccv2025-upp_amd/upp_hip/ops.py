@@ -444,6 +444,27 @@ def ce_acc(logits, labels):
     return out2, dlogits
 
 
+def bn_relu_drop_fwd(z, gamma, beta, running_mean, running_var, momentum, eps, training, u, p):
+    _need(z, "z", torch.float32, ndim=2)
+    R, C = z.shape
+    a = torch.empty_like(z)
+    mean = torch.empty(C, dtype=torch.float32, device=z.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=z.device)
+    _call(z.device, "upp_bn_relu_drop_fwd", _abi.ptr(z), _abi.ptr(gamma), _abi.ptr(beta), _abi.ptr(running_mean), _abi.ptr(running_var),
+          float(momentum), float(eps), int(bool(training)), _abi.ptr(u), float(p), _abi.ptr(a), _abi.ptr(mean), _abi.ptr(rstd), R, C)
+    return a, mean, rstd
+
+
+def bn_relu_drop_bwd(g_a, z, gamma, beta, mean, rstd, training, u, p):
+    R, C = z.shape
+    g_z = torch.empty_like(z)
+    g_gamma = torch.empty(C, dtype=torch.float32, device=z.device)
+    g_beta = torch.empty(C, dtype=torch.float32, device=z.device)
+    _call(z.device, "upp_bn_relu_drop_bwd", _abi.ptr(g_a), _abi.ptr(z), _abi.ptr(gamma), _abi.ptr(beta), _abi.ptr(mean), _abi.ptr(rstd),
+          int(bool(training)), _abi.ptr(u), float(p), _abi.ptr(g_z), _abi.ptr(g_gamma), _abi.ptr(g_beta), R, C)
+    return g_z, g_gamma, g_beta
+
+
 # ------------------------------------------------------------------ optimizer tail
 def batched_sum(jobs):
     """jobs: list of (part 2-D f32, column offset, rows n, length, row stride, dst f32 (length elems), accumulate):

@@ -283,6 +283,17 @@ int upp_cls_pool_fwd(const float *x, const float *gamma, const float *beta, floa
 int upp_cls_pool_bwd(const float *g_feat, const float *x, const float *mean, const float *rstd, const float *gamma,
                      const int32_t *amax, float *g_x, int B, int L, int D, void *stream);
 int upp_ce_acc(const float *logits, const int64_t *labels, float *out2, float *dlogits, int B, int C, void *stream);
+/*   upp_bn_relu_drop_fwd / bwd : BatchNorm1d + ReLU + Dropout of a (R, C) matrix with few rows (the Linear outputs of
+ *                      cls_head_finetune, R = batch size), one launch each way.  training != 0: batch statistics (mean / rstd
+ *                      outputs, running statistics updated with momentum / unbiased variance when non-NULL); else running
+ *                      statistics.  u (R,C) uniforms or NULL (no dropout): kept where u >= p, scaled by 1/(1-p).
+ *                      Backward recomputes the ReLU / dropout masks from z and u; g_gamma / g_beta (C) are complete sums. */
+int upp_bn_relu_drop_fwd(const float *z, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                         float momentum, float eps, int training, const float *u, float p, float *a, float *mean, float *rstd,
+                         int R, int C, void *stream);
+int upp_bn_relu_drop_bwd(const float *g_a, const float *z, const float *gamma, const float *beta, const float *mean,
+                         const float *rstd, int training, const float *u, float p, float *g_z, float *g_gamma, float *g_beta,
+                         int R, int C, void *stream);
 
 /* ---- training step tail: gradient clipping + AdamW on flat buffers ------------------------
  * Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.AdamW.step() of the reference loop

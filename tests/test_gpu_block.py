@@ -570,3 +570,32 @@ def test_cross_entropy_acc_matches_torch(B, C):
     close(g, rg, rtol=1e-5, atol_scale=1e-5)      # softmax - 1 at a confidently correct label is pure cancellation noise
     want_acc = (logits.argmax(-1) == labels).sum() / float(B) * 100
     assert abs(float(acc) - float(want_acc)) < 1e-4 and not acc.requires_grad
+
+
+@pytest.mark.parametrize("R,C", [(32, 256), (4, 256), (7, 40), (130, 100)])
+@pytest.mark.parametrize("training,p", [(True, 0.5), (True, 0.0), (False, 0.0)])
+def test_bn_relu_drop_matches_torch_ops(R, C, training, p):
+    torch.manual_seed(R * C)
+    z = torch.randn(R, C, device='cuda') * 1.5 + 0.3
+    u = torch.rand(R, C, device='cuda') if p > 0 else None
+    w = torch.linspace(-1, 1, R * C, device='cuda').view(R, C)
+    outs = []
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm1d(C).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.2, C)); bn.running_var.copy_(torch.linspace(0.6, 1.5, C))
+        zi = z.clone().requires_grad_(True)
+        if fused:
+            a = HF.bn_relu_drop(zi, bn, u, p, training)
+        else:
+            a = F.relu(F.batch_norm(zi, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps))
+            if p > 0:
+                a = a * (u >= p).float() / (1.0 - p)
+        grads = torch.autograd.grad((a * w).sum(), [zi, bn.weight, bn.bias])
+        outs.append((a.detach(), grads, bn.running_mean.clone(), bn.running_var.clone()))
+    close(outs[0][0], outs[1][0], rtol=1e-5, atol_scale=2e-6)
+    close(outs[0][2], outs[1][2], rtol=1e-5, atol_scale=1e-6)
+    close(outs[0][3], outs[1][3], rtol=1e-5, atol_scale=1e-6)
+    for a_, b_ in zip(outs[0][1], outs[1][1]):
+        close(a_, b_, rtol=3e-5, atol_scale=1e-5)
