@@ -31,7 +31,10 @@ def back():
     for p in params: p.grad = None
     loss, _ = model.get_loss_acc(model.forward_tokens(*state), labels)
     loss.backward()
-streams = [torch.cuda.Stream() for _ in range(3)]
+import os
+lo, hi = (0, -1) if os.environ.get('PRIO') else (0, 0)
+streams = [torch.cuda.Stream(priority=lo), torch.cuda.Stream(priority=lo), torch.cuda.Stream(priority=hi)]
+print('priorities', [s.priority for s in streams], flush=True)
 for s, fn in ((streams[0], f12), (streams[2], back)):
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
