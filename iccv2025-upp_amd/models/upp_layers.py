@@ -184,9 +184,12 @@ def _batch_offsets(B, N, device):
     """(B,1,1) int64 tensor b*N, built once per (B, N, device): a constant, not two launches per grouping call."""
     key = (B, N, str(device))
     if key not in _OFFSETS:
+        fresh = torch.arange(B, device=device).view(-1, 1, 1) * N
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return fresh        # memory of a graph's private pool, filled only on replay: never cache it
         if len(_OFFSETS) > 64:
             _OFFSETS.clear()
-        _OFFSETS[key] = torch.arange(B, device=device).view(-1, 1, 1) * N
+        _OFFSETS[key] = fresh
     return _OFFSETS[key]
 
 
