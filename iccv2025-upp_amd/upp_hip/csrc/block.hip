@@ -30,7 +30,8 @@ struct RowLnArgs {
     const float *add;      // (B, Lin, D) added to x rows (positional embedding) or null
     const float *prompts;  // (P, D) rows selected by negative row_src values, or null
     int mode, P;           // row map (see row_src): 0 identity, 1/2 insert P prompts (with/without cls), 3/4 strip them
-    const float *y;        // (B, Lin, D) residual branch, row-aligned with x: added as scale_b * y, or null
+    const float *y;        // (B, Lin, D) residual branch, row-aligned with x: added as scale_b * (y + ybias), or null
+    const float *ybias;    // (D) bias of the Linear that produced y (its GEMM then runs bias-free), or null
     const float *u;        // (B) uniforms for stochastic depth (scale_b = floor(keep+u)/keep), or null (scale 1)
     float keep;
     const float *gamma, *beta;  // LayerNorm affine (null gamma: no LayerNorm, only xo is produced)
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
     const int src = row_src(t, a.mode, a.P);
     const int D = a.D;
     const float *xs = src >= 0 ? a.x + ((size_t)b * a.Lin + src) * D : a.prompts + (size_t)(-src - 1) * D;
-    const bool has_ad = src >= 0 && a.add, has_y = src >= 0 && a.y, has_ln = a.gamma != nullptr;
+    const bool has_ad = src >= 0 && a.add, has_y = src >= 0 && a.y, has_ln = a.gamma != nullptr, has_yb = has_y && a.ybias;
     const float *ad = has_ad ? a.add + ((size_t)b * a.Lin + src) * D : xs;
     const float *ys = has_y ? a.y + ((size_t)b * a.Lin + src) * D : xs;
     const float *gm = has_ln ? a.gamma : xs, *bt = has_ln ? a.beta : xs;
@@ -81,6 +82,13 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
     if (has_y) {
 #pragma unroll
         for (int e = 0; e < kMaxE; ++e) yv[e] = ys[cc[e]];
+    }
+    if (has_yb) {
+        float yb[kMaxE];
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) yb[e] = a.ybias[cc[e]];
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) yv[e] += yb[e];
     }
     if (has_ln) {
 #pragma unroll
@@ -440,6 +448,32 @@ __global__ __launch_bounds__(64 * kAW) void attn_bwd_kernel(const float *__restr
     }
 }
 
+// h = GELU(z + b) (erf form) of a Linear's bias-free GEMM output z (rows, C), and its backward g_z = g_h * GELU'(z + b).
+// The GEMM runs without its bias epilogue (the bias-free library kernels are 1.5-3 us faster at these shapes) and the
+// bias costs nothing here.  C % 4 == 0.
+__device__ __forceinline__ float gelu_val(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_der(float v) {
+    return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v);
+}
+__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const float *__restrict__ z, const float *__restrict__ b,
+                                                            float *__restrict__ h, long long total4, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const float4 v = reinterpret_cast<const float4 *>(z)[i];
+    const float4 bb = *reinterpret_cast<const float4 *>(b + (int)((i * 4) % C));
+    reinterpret_cast<float4 *>(h)[i] = make_float4(gelu_val(v.x + bb.x), gelu_val(v.y + bb.y), gelu_val(v.z + bb.z), gelu_val(v.w + bb.w));
+}
+__global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const float *__restrict__ g_h, const float *__restrict__ z,
+                                                            const float *__restrict__ b, float *__restrict__ g_z, long long total4, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const float4 g = reinterpret_cast<const float4 *>(g_h)[i];
+    const float4 v = reinterpret_cast<const float4 *>(z)[i];
+    const float4 bb = *reinterpret_cast<const float4 *>(b + (int)((i * 4) % C));
+    reinterpret_cast<float4 *>(g_z)[i] = make_float4(g.x * gelu_der(v.x + bb.x), g.y * gelu_der(v.y + bb.y), g.z * gelu_der(v.z + bb.z),
+                                                     g.w * gelu_der(v.w + bb.w));
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) {
@@ -452,7 +486,7 @@ int set_lds(K kernel, size_t bytes) {
 }  // namespace
 
 extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y,
-                             const float *u, float keep, const float *gamma, const float *beta, float eps, float *xo, float *h,
+                             const float *ybias, const float *u, float keep, const float *gamma, const float *beta, float eps, float *xo, float *h,
                              float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream) {
     if (!x || B < 0 || Lin < 1 || Lout < 1 || D < 1) return UPP_E_BADARG;
     if (gamma && (!beta || !h || !mean || !rstd)) return UPP_E_BADARG;
@@ -462,7 +496,8 @@ extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prom
     if (mode < 0 || mode > 4 || P < 0 || ((mode == 1 || mode == 2) && (Lout != Lin + P || (P > 0 && !prompts))) ||
         ((mode == 3 || mode == 4) && Lout != Lin - P) || (mode == 0 && Lout != Lin))
         return UPP_E_BADARG;
-    RowLnArgs a{x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, xo, h, mean, rstd, B, Lin, Lout, D};
+    if (ybias && !y) return UPP_E_BADARG;
+    RowLnArgs a{x, add, prompts, mode, P, y, ybias, u, keep, gamma, beta, eps, xo, h, mean, rstd, B, Lin, Lout, D};
     hipLaunchKernelGGL(rowln_fwd_kernel, dim3((B * Lout + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return upp_launch_status();
 }
@@ -534,4 +569,21 @@ extern "C" int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_c
     else if (L <= 128) { rc = set_lds(attn_bwd_kernel<2, 128>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<2, 128>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
     else { rc = set_lds(attn_bwd_kernel<3, 144>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<3, 144>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
     return rc ? rc : upp_launch_status();
+}
+
+extern "C" int upp_bias_gelu_fwd(const float *z, const float *bias, float *h, long long rows, int C, void *stream) {
+    if (!z || !bias || !h || rows < 1 || C < 4) return UPP_E_BADARG;
+    if (C % 4 != 0) return UPP_E_RANGE;
+    const long long total4 = rows * C / 4;
+    hipLaunchKernelGGL(bias_gelu_fwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, bias, h, total4, C);
+    return upp_launch_status();
+}
+
+extern "C" int upp_bias_gelu_bwd(const float *g_h, const float *z, const float *bias, float *g_z, long long rows, int C, void *stream) {
+    if (!g_h || !z || !bias || !g_z || rows < 1 || C < 4) return UPP_E_BADARG;
+    if (C % 4 != 0) return UPP_E_RANGE;
+    const long long total4 = rows * C / 4;
+    hipLaunchKernelGGL(bias_gelu_bwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_h, z, bias, g_z, total4,
+                       C);
+    return upp_launch_status();
 }

@@ -160,13 +160,13 @@ class _RowLN(Function):
     One kernel forward, one backward (+ one for trainable LayerNorm parameters).  See upp_rowln_fwd."""
 
     @staticmethod
-    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps, cls_add=None):
+    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps, cls_add=None, ybias=None):
         x = x.contiguous()
         B, Lin, D = x.shape
         Lout = Lin + P if mode in (ROW_INSERT_CLS, ROW_INSERT) else (Lin - P if mode in (ROW_STRIP_CLS, ROW_STRIP) else Lin)
         add_c = add.contiguous() if add is not None else None
         y_c = y.contiguous() if y is not None else None
-        xo, h, mean, rstd = ops.rowln_fwd(x, add_c, prompts, mode, P, y_c, u, keep, gamma, beta, eps, Lout)
+        xo, h, mean, rstd = ops.rowln_fwd(x, add_c, prompts, mode, P, y_c, u, keep, gamma, beta, eps, Lout, ybias=ybias)
         ctx.save_for_backward(xo, mean, rstd, gamma, u)
         ctx.dims = (B, Lin, Lout, D, P, mode)
         ctx.keep = keep
@@ -186,7 +186,7 @@ class _RowLN(Function):
         g_xo = g_xo.contiguous() if g_xo is not None else None
         g_hc = g_h.contiguous() if (has_ln and g_h is not None) else None
         if g_xo is None and g_hc is None:
-            return (None,) * 12
+            return (None,) * 13
         strip = mode in (ROW_STRIP_CLS, ROW_STRIP) and P > 0
         need_cls = ctx.cls_shape is not None and len(need) > 11 and need[11]
         need_ln = has_ln and g_hc is not None and (need[4] or need[5])
@@ -208,16 +208,20 @@ class _RowLN(Function):
             if g_prompts is not None:
                 g_prompts = g_prompts.view(P, D)
         return (g_x if need[0] else None, g_x if (has_add and need[1]) else None, g_prompts, g_y,
-                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None, g_cls)
+                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None, g_cls, None)
 
 
-def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDENTITY, P=0, u=None, keep=1.0, eps=1e-5, cls_add=None):
+def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDENTITY, P=0, u=None, keep=1.0, eps=1e-5, cls_add=None,
+          ybias=None):
     """-> (rows (B,Lout,D), LayerNorm(rows) or None).  mode / P: see ROW_* and upp_rowln_fwd.
+    ybias: optional (D) frozen bias added to y (the Linear that produced y then runs its GEMM bias-free).
     cls_add: optional (1,1,D) parameter that `add` (passed detached) carries in its row 0 for every sample; its gradient
     (batch sum of the row-0 input gradient) is produced here instead of through a (B,L,D) gradient of `add`."""
     if cls_add is not None and (add is None or add.requires_grad or mode not in (ROW_IDENTITY, ROW_INSERT_CLS)):
         raise ValueError("cls_add needs a detached `add` and a row map that keeps source row 0 in place")
-    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps), cls_add)
+    if ybias is not None and (y is None or (torch.is_grad_enabled() and ybias.requires_grad)):
+        raise ValueError("ybias is the frozen bias of the Linear that produced y")
+    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps), cls_add, ybias)
     return xo, (h if gamma is not None else None)
 
 
@@ -488,6 +492,25 @@ def bn_relu_drop(z, bn, u=None, p=0.0, training=True):
 
 def cross_entropy_acc(logits, labels):
     return _CrossEntropyAcc.apply(logits, labels)
+
+
+class _BiasGelu(Function):
+    """GELU(z + bias) for a frozen bias (upp_bias_gelu_fwd / bwd)."""
+
+    @staticmethod
+    def forward(ctx, z, bias):
+        z = z.contiguous()
+        ctx.save_for_backward(z, bias)
+        return ops.bias_gelu_fwd(z, bias)
+
+    @staticmethod
+    def backward(ctx, g_h):
+        z, bias = ctx.saved_tensors
+        return ops.bias_gelu_bwd(g_h.contiguous(), z, bias), None
+
+
+def bias_gelu(z, bias):
+    return _BiasGelu.apply(z, bias)
 
 
 # ------------------------------------------------------------------ bottleneck adapter

@@ -216,7 +216,7 @@ def patch_embed_fwd(point_groups, enc, training):
 
 
 # ------------------------------------------------------------------ Transformer block glue
-def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want_xo=True):
+def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want_xo=True, ybias=None):
     B, Lin, D = x.shape
     dev = x.device
     xo = torch.empty((B, Lout, D), dtype=torch.float32, device=dev) if want_xo else None
@@ -226,7 +226,7 @@ def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want
         rstd = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     else:
         h = mean = rstd = None
-    _call(dev, "upp_rowln_fwd", _abi.ptr(x), _abi.ptr(add), _abi.ptr(prompts), int(mode), int(P), _abi.ptr(y), _abi.ptr(u),
+    _call(dev, "upp_rowln_fwd", _abi.ptr(x), _abi.ptr(add), _abi.ptr(prompts), int(mode), int(P), _abi.ptr(y), _abi.ptr(ybias), _abi.ptr(u),
           float(keep), _abi.ptr(gamma), _abi.ptr(beta), float(eps), _abi.ptr(xo), _abi.ptr(h), _abi.ptr(mean), _abi.ptr(rstd),
           B, Lin, Lout, D)
     return xo, h, mean, rstd
@@ -244,6 +244,20 @@ def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, 
     _call(dev, "upp_rowln_bwd", _abi.ptr(g_xo), _abi.ptr(g_h), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma),
           int(mode), _abi.ptr(u), float(keep), _abi.ptr(g_x), _abi.ptr(g_p), _abi.ptr(g_y), _abi.ptr(part), B, Lin, Lout, D, P)
     return g_x, g_p, g_y, part
+
+
+def bias_gelu_fwd(z, bias):
+    _need(z, "z", torch.float32)
+    _need(bias, "bias", torch.float32, ndim=1, last=z.shape[-1])
+    h = torch.empty_like(z)
+    _call(z.device, "upp_bias_gelu_fwd", _abi.ptr(z), _abi.ptr(bias), _abi.ptr(h), z.numel() // z.shape[-1], z.shape[-1])
+    return h
+
+
+def bias_gelu_bwd(g_h, z, bias):
+    g_z = torch.empty_like(z)
+    _call(z.device, "upp_bias_gelu_bwd", _abi.ptr(g_h), _abi.ptr(z), _abi.ptr(bias), _abi.ptr(g_z), z.numel() // z.shape[-1], z.shape[-1])
+    return g_z
 
 
 def ln_param_grad(g_h, xo, mean, rstd, chunks=32):

@@ -161,7 +161,8 @@ int upp_patch_embed_fwd(const float *pts, int R, int n,
  *                3 strip the P prompts after the cls row | 4 strip P leading prompts
  *   out row (b,t) = x[b, s] (+ add[b, s])                  if s is a token row
  *                 = prompts[p]                             if s selects prompt p (modes 1, 2)
- *                 (+ floor(keep + u[b]) / keep * y[b, s])  if y (row-aligned with x; u NULL: factor 1)
+ *                 (+ floor(keep + u[b]) / keep * (y[b, s] + ybias))  if y (row-aligned with x; u NULL: factor 1; ybias (D)
+ *                    NULL or the bias of the Linear whose bias-free GEMM produced y)
  *   xo (B,Lout,D) = those rows (optional);  h = LayerNorm(rows) * gamma + beta, mean / rstd (B,Lout) saved
  *   (gamma NULL: no LayerNorm, only xo).
  * Backward: d = g_xo + LayerNormBackward(g_h); written to g_x[b, s] (every row of g_x / g_y is written: the prompt
@@ -170,7 +171,7 @@ int upp_patch_embed_fwd(const float *pts, int R, int n,
  * d_beta = sum g_h, produced by the same pass; the caller sums them over the workgroups (upp_batched_sum).
  * upp_ln_param_grad: the same partial sums as a stand-alone pass, part (2, chunks, D).
  * Limits: D <= 512. */
-int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y,
+int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y, const float *ybias,
                   const float *u, float keep, const float *gamma, const float *beta, float eps,
                   float *xo, float *h, float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream);
 long long upp_rowln_part_floats(int B, int Lin, int Lout, int D, int mode);
@@ -178,6 +179,10 @@ int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const fl
                   const float *gamma, int mode, const float *u, float keep,
                   float *g_x, float *g_prompt, float *g_y, float *ln_part,
                   int B, int Lin, int Lout, int D, int P, void *stream);
+/* upp_bias_gelu_fwd / bwd: h = GELU(z + bias) (erf form) for the bias-free GEMM output z (rows, C) of Mlp.fc1, and
+ * g_z = g_h * GELU'(z + bias).  C % 4 == 0. */
+int upp_bias_gelu_fwd(const float *z, const float *bias, float *h, long long rows, int C, void *stream);
+int upp_bias_gelu_bwd(const float *g_h, const float *z, const float *bias, float *g_z, long long rows, int C, void *stream);
 int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, const float *rstd, float *part,
                       int rows, int D, int chunks, void *stream);
 

@@ -599,3 +599,34 @@ def test_bn_relu_drop_matches_torch_ops(R, C, training, p):
     close(outs[0][3], outs[1][3], rtol=1e-5, atol_scale=1e-6)
     for a_, b_ in zip(outs[0][1], outs[1][1]):
         close(a_, b_, rtol=3e-5, atol_scale=1e-5)
+
+
+def test_rowln_ybias_and_bias_gelu_match_the_biased_ops():
+    torch.manual_seed(5)
+    B, L, D = 8, 75, 384
+    x = torch.randn(B, L, D, device='cuda'); y = torch.randn(B, L, D, device='cuda'); bias = torch.randn(D, device='cuda') * 0.3
+    u = torch.rand(B, device='cuda')
+    g1, b1 = torch.rand(D, device='cuda') + 0.5, torch.randn(D, device='cuda') * 0.1
+    outs = []
+    for fused in (True, False):
+        xi, yi = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        if fused:
+            xo, h = HF.rowln(xi, y=yi, ybias=bias, u=u, keep=0.9, gamma=g1, beta=b1)
+        else:
+            xo, h = HF.rowln(xi, y=yi + bias, u=u, keep=0.9, gamma=g1, beta=b1)
+        grads = torch.autograd.grad((h * torch.linspace(-1, 1, h.numel(), device='cuda').view_as(h)).sum() + xo.sum(), [xi, yi])
+        outs.append((xo.detach(), h.detach(), grads))
+    close(outs[0][0], outs[1][0], rtol=1e-6, atol_scale=1e-6)
+    close(outs[0][1], outs[1][1], rtol=1e-5, atol_scale=2e-6)
+    for a, b in zip(outs[0][2], outs[1][2]):
+        close(a, b, rtol=1e-5, atol_scale=2e-6)
+    z = (torch.randn(2400, 1536, device='cuda') * 1.5).requires_grad_(True)
+    bz = torch.randn(1536, device='cuda') * 0.5
+    w = torch.linspace(-1, 1, z.numel(), device='cuda').view_as(z)
+    got = HF.bias_gelu(z, bz)
+    (gg,) = torch.autograd.grad((got * w).sum(), z)
+    zr = z.detach().clone().requires_grad_(True)
+    ref = F.gelu(zr + bz)
+    (gr,) = torch.autograd.grad((ref * w).sum(), zr)
+    close(got, ref, rtol=1e-6, atol_scale=1e-6)
+    close(gg, gr, rtol=1e-5, atol_scale=1e-6)
