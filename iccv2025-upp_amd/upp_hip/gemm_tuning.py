@@ -26,7 +26,8 @@ def enable(tune_missing=True, results_file=_TUNED):
     tun = torch.cuda.tunable
     tun.enable(True)
     # TunableOp dumps its table at exit: keep that out of the working directory
-    tun.set_filename(os.path.join(tempfile.gettempdir(), "upp_tunableop_%d.csv" % os.getpid()))
+    # (UPP_GEMM_TUNING_OUT=<file> keeps it: that is how tuned/gemm_gfx950.csv is refreshed)
+    tun.set_filename(os.environ.get("UPP_GEMM_TUNING_OUT") or os.path.join(tempfile.gettempdir(), "upp_tunableop_%d.csv" % os.getpid()))
     tun.tuning_enable(bool(tune_missing))
     if results_file and os.path.isfile(results_file):
         try:
