@@ -69,6 +69,77 @@ class Trainer:
         return self.ts.step()
 
 
+PRETASK_PEFT = ['rectify_adapter', 'downstream_adapter', 'pretask_adapter', 'rectify_prompts', 'downstream_prompts',
+                'pretask_prompts', 'coarse_pred', 'increase_dim', 'mask_token', 'dense_pred', 'rectify_prompter', 'shape_pred',
+                'predict_token_generator', 'mask_prompter', 'mask_token_generator']   # reference tools/runner_pretask.py:112-117
+SEG_PEFT = ['downstream_adapter', 'downstream_prompts', 'bnorm', 'label_conv', 'propagation_0', 'seg_head']
+
+
+class RecipeTrainer:
+    """The other training recipes of the reference on the same step driver (secondary workloads, `--workload`):
+      pretask  : Point_MAE_pretask_dev + three Chamfer-L1 terms + noise loss (tools/runner_pretask.py:157-247)
+      pretrain : Point_MAE masked auto-encoding, Chamfer-L2 on the masked groups (tools/runner_pretrain.py:115-148; 8f-3)
+      seg      : Point_MAE_unify_seg part segmentation, N=2048 label points (BASELINE.json configs[4])"""
+
+    def __init__(self, kind, device, batch, use_graph=True):
+        import _seeded
+        from models import build_model_from_cfg
+        from utils.config import builtin_cfg
+        from utils import misc
+        from upp_hip.train import TrainStep, freeze_for_peft
+        torch.manual_seed(0)
+        g = torch.Generator(device=device).manual_seed(0)
+        B = batch
+        if kind == 'pretask':
+            from models.Point_MAE_pretask_dev import pretask_losses
+            model = build_model_from_cfg(builtin_cfg('pretask').model).to(device).train()
+            freeze_for_peft(model, PRETASK_PEFT)
+            gt = _seeded.unit_ball_clouds(B, 8192, seed=1).to(device)
+            partial, cropping = misc.seprate_point_cloud(gt, 8192, 2048, sample_points=1024, incomplete_shape=True, generator=g)
+            noise = [misc.gaussian_noise([B, 20, 3], loc=0., scale=0.2, shell_radius=0.8, device=device, generator=g),
+                     misc.lidar_noise(partial, 32, low=1.2, scale=1.5, generator=g)]
+            points = torch.cat([partial] + noise, dim=1).contiguous()
+            inputs = [gt, partial, cropping, points]
+
+            def loss_fn(m, gt, partial, cropping, points):
+                total, terms = pretask_losses(m, gt, partial, cropping, points, point_num=1024)
+                return total, terms['recall']
+            self.workload = ("Point_MAE_pretask_dev pretask recipe fwd+bwd+AdamW: gt (B,8192,3), partial (B,1024,3)+52 noise pts, "
+                             "3 Chamfer-L1 terms incl. (B,2048)x(B,8192), B=%d/GPU" % B)
+        elif kind == 'pretrain':
+            model = build_model_from_cfg(builtin_cfg('pretrain').model).to(device).train()
+            inputs = [_seeded.unit_ball_clouds(B, 1024, seed=1).to(device)]
+
+            def loss_fn(m, pts):
+                loss = m(pts)
+                return loss, loss.detach()
+            self.workload = "Point_MAE pretrain fwd+bwd+AdamW (mask ratio 0.6, Chamfer-L2 on (B*38,32,3)), all parameters trainable, B=%d/GPU" % B
+        elif kind == 'seg':
+            model = build_model_from_cfg(builtin_cfg('unify_shapenetpart_seg').model).to(device).train()
+            freeze_for_peft(model, SEG_PEFT)
+            pts = _seeded.noisy_clouds(B, 1536, seed=1)
+            pts = torch.cat([pts, pts[:, :1624 - pts.shape[1]] * 1.01], dim=1)[:, :1624].contiguous().to(device)
+            lpts = _seeded.unit_ball_clouds(B, 2048, seed=2).to(device)
+            onehot = torch.zeros(B, 16, device=device)
+            onehot[torch.arange(B), torch.arange(B) % 16] = 1
+            target = torch.randint(0, 50, (B * 2048,), device=device, generator=g)
+            inputs = [pts, onehot, lpts, target]
+
+            def loss_fn(m, pts, onehot, lpts, target):
+                logp = m(pts, onehot, label_points=lpts, completion_prompt=True, denoise=True, point_num=1536)
+                loss = m.get_loss(logp.reshape(-1, 50), target)
+                return loss, loss.detach()
+            self.workload = ("Point_MAE_unify_seg unify_shapenetpart_seg noisy-train fwd+bwd+AdamW, PEFT, pts (B,1624,3), "
+                             "2048 label points, B=%d/GPU" % B)
+        else:
+            raise ValueError(kind)
+        self.model = model
+        self.ts = TrainStep(model, tuple(inputs[0].shape), use_graph=use_graph, loss_fn=loss_fn, inputs=inputs)
+
+    def step(self):
+        return self.ts.step()
+
+
 def time_kernel(fn, iters=20, warm=3):
     """Average device time (ms) of one fn() call: `iters` calls are captured into a HIP graph and the replay is
     timed with HIP events on the launch stream, so the figure is kernel time, not Python / launch overhead
@@ -264,6 +335,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--workload", default="cls", choices=["cls", "pretask", "pretrain", "seg"],
+                    help="cls = the headline workload (default); the others are secondary recipes, see RecipeTrainer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (debug)")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM solutions (see upp_hip/gemm_tuning.py)")
@@ -287,8 +360,11 @@ def main():
         from upp_hip import gemm_tuning
         gemm_tuning.enable()                              # best hipBLASLt / rocBLAS solution per Linear shape (same f32 math)
 
-    pipeline = not args.no_pipeline and not args.no_graph
-    tr = Trainer(device, args.batch, distributed, use_graph=not args.no_graph, pipeline=pipeline)
+    pipeline = not args.no_pipeline and not args.no_graph and args.workload == "cls"
+    if args.workload == "cls":
+        tr = Trainer(device, args.batch, distributed, use_graph=not args.no_graph, pipeline=pipeline)
+    else:
+        tr = RecipeTrainer(args.workload, device, args.batch, use_graph=not args.no_graph)
     if pipeline:
         tr.step()                                         # prime: the first call only runs the front-end of batch 0 (never timed)
     for _ in range(args.warmup):
@@ -310,7 +386,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    if rank == 0:
+    if rank == 0 and args.workload != "cls":
+        # secondary recipe: throughput only (the kernels are the ones the headline run reports rooflines for)
+        print(json.dumps({
+            "metric": "point-clouds/sec fwd+bwd, secondary recipe '%s'" % args.workload,
+            "value": args.batch * world * args.steps / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": tr.workload, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "hip_graph": not args.no_graph, "pipeline": "none"}}))
+    elif rank == 0:
         clouds = args.batch * world * args.steps
         stages = stage_report(device, args.batch)
         dom = dict(stages["fps_1228_1024"])               # the single longest hand-written launch of the step

@@ -105,13 +105,15 @@ class MaskTransformer(nn.Module):
 
     def forward(self, neighborhood, center, noaug=False, eval=False, mask=None):
         B, G, _ = center.shape
+        n_masked = None                     # known without a host sync when the mask is drawn here
         if mask is None:
+            n_masked = 0 if (eval or noaug) else int(self.mask_ratio * G)
             mask = torch.zeros(B, G, dtype=torch.bool, device=center.device) if eval else self.random_mask(center, noaug)
         tokens = self.encoder(neighborhood)
         # visible positions first (ascending), masked ones after (ascending): the order boolean indexing would give,
         # without its host sync (shapes stay static for HIP-graph capture)
         order = torch.argsort(mask.int(), dim=1, stable=True)
-        n_vis = G - int(mask[0].sum()) if mask.any() else G
+        n_vis = G - (int(mask[0].sum()) if n_masked is None else n_masked)
         vis = order[:, :n_vis]
         x_vis = torch.gather(tokens, 1, vis.unsqueeze(-1).expand(-1, -1, tokens.shape[-1]))
         c_vis = torch.gather(center, 1, vis.unsqueeze(-1).expand(-1, -1, 3))

@@ -124,9 +124,14 @@ class FlatAdamW:
 
 class TrainStep:
     """step(pts, labels) -> loss (device tensor).  With use_graph=True the inputs are copied into
-    static buffers and the captured graphs are replayed."""
+    static buffers and the captured graphs are replayed.
 
-    def __init__(self, model, batch_shape, grad_clip=10.0, use_graph=True, forward_kwargs=None, lr=5e-4):
+    Other recipes than the classification one (pre-task Chamfer training, Point-MAE pre-training, part segmentation)
+    pass `loss_fn(model, *inputs) -> (loss, metric)` and `inputs` (example tensors fixing shapes and dtypes); they are
+    driven with step_inputs(*tensors)."""
+
+    def __init__(self, model, batch_shape, grad_clip=10.0, use_graph=True, forward_kwargs=None, lr=5e-4, loss_fn=None,
+                 inputs=None):
         self.model = model
         self.device = next(model.parameters()).device
         self.grad_clip = grad_clip
@@ -143,6 +148,8 @@ class TrainStep:
         self.pts = torch.zeros(batch_shape, device=self.device)
         self.labels = torch.zeros(batch_shape[0], dtype=torch.long, device=self.device)
         self.loss = torch.zeros((), device=self.device)
+        self.loss_fn = loss_fn
+        self.inputs = [t.detach().clone().to(self.device) for t in (inputs or [])]
         self._g_fb = self._g_opt = None
         self._grad_targets = ({p.data_ptr(): v for p, v in zip(self.trainable, self.flat.views)}
                               if self.device.type == 'cuda' else None)
@@ -154,8 +161,11 @@ class TrainStep:
         self.flat.zero()
         for p in self.trainable:
             p.grad = None              # let autograd write fresh gradients: no per-parameter accumulate kernels
-        logits = self.model.forward_tokens(*pts) if isinstance(pts, tuple) else self.model(pts, **(self.kw if kw is None else kw))
-        loss, acc = self.model.get_loss_acc(logits, labels)
+        if self.loss_fn is not None:
+            loss, acc = self.loss_fn(self.model, *self.inputs)
+        else:
+            logits = self.model.forward_tokens(*pts) if isinstance(pts, tuple) else self.model(pts, **(self.kw if kw is None else kw))
+            loss, acc = self.model.get_loss_acc(logits, labels)
         # partial-sum reductions of parameter gradients: one launch after the pass, straight into the (zeroed) flat buffer
         with HF.deferred_sums(self._grad_targets) as scope:
             loss.backward()
@@ -212,6 +222,12 @@ class TrainStep:
                 self.flat.reduce()
             self._update()
         return self.loss
+
+    def step_inputs(self, *tensors):
+        """One step of a `loss_fn` recipe on new input tensors (copied into the static buffers)."""
+        for dst, src in zip(self.inputs, tensors):
+            dst.copy_(src)
+        return self.step()
 
 
 _BACK_END_KEYS = ('downstream', 'bnorm', 'cls_')     # trainable parameters the prompting front-end never reads

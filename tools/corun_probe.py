@@ -1,0 +1,127 @@
+"""Probe: what kind of co-running work slows the trainable back-end graph?  Back-end graph on stream B against synthetic
+loads on stream F (each a graph of ~5 ms): latency-bound FPS, a storm of tiny kernels, the patch-embed MFMA chain,
+row kernels, library GEMMs.  Prints back-end finish time alone and beside each load."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'iccv2025-upp_amd'); sys.path.insert(0, 'oracle')
+import bench, _seeded
+from models.upp_layers import Encoder
+from upp_hip import gemm_tuning, ops, functional as HF
+
+gemm_tuning.enable()
+dev = torch.device('cuda', 0)
+model = bench.build_model(dev).train()
+raw = _seeded.noisy_clouds(32, 1024, seed=0).to(dev)
+labels = torch.randint(0, 40, (32,), device=dev)
+params = [p for p in model.parameters() if p.requires_grad]
+with torch.no_grad():
+    state = [t.clone() for t in model.prompt_tokens(raw, completion_prompt=True, denoise=True, point_num=1024)]
+
+
+def back():
+    for p in params:
+        p.grad = None
+    loss, _ = model.get_loss_acc(model.forward_tokens(*state), labels)
+    loss.backward()
+
+
+x1228 = _seeded.unit_ball_clouds(32, 1228, seed=8).to(dev)
+x1024 = _seeded.unit_ball_clouds(32, 1024, seed=7).to(dev)
+_, cen = ops.fps(x1024, 64, want_centers=True)
+_, _, nb = ops.knn(x1024, cen, 32, want_dist=False, want_neigh=True)
+enc = Encoder(384).to(dev).train()
+for p in enc.parameters():
+    p.requires_grad_(False)
+tiny = torch.zeros(256, device=dev)
+tok = torch.randn(32, 65, 384, device=dev); pos = torch.randn(32, 65, 384, device=dev); prm = torch.randn(10, 384, device=dev)
+g1, b1 = torch.ones(384, device=dev), torch.zeros(384, device=dev)
+a = torch.randn(2400, 384, device=dev); w = torch.randn(1536, 384, device=dev)
+big = torch.randn(64 << 20, device=dev); big2 = torch.empty_like(big)
+
+
+def load_fps():
+    for _ in range(11):
+        ops.fps(x1228, 1024, want_centers=True)
+
+
+def load_tiny():
+    for _ in range(900):
+        tiny.add_(1.0)
+
+
+def load_mfma():
+    with torch.no_grad():
+        for _ in range(10):
+            enc(nb)
+
+
+def load_rows():
+    with torch.no_grad():
+        for _ in range(800):
+            HF.rowln(tok, add=pos, prompts=prm, mode=HF.ROW_INSERT_CLS, P=10, gamma=g1, beta=b1)
+
+
+def load_gemm():
+    for _ in range(180):
+        torch.nn.functional.linear(a, w)
+
+
+def load_copy():
+    for _ in range(40):
+        big2.copy_(big)
+
+
+sB, sF = torch.cuda.Stream(), torch.cuda.Stream()
+loads = [('fps x11 (32 WGs, latency)', load_fps), ('900 tiny kernels', load_tiny), ('patch-embed chain x10', load_mfma),
+         ('rowln x800', load_rows), ('fc1 GEMM x180', load_gemm), ('256 MB copies x40 (HBM)', load_copy)]
+for s, fns in ((sB, [back]), (sF, [f for _, f in loads])):
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for fn in fns:
+            fn(); fn()
+    torch.cuda.current_stream().wait_stream(s)
+torch.cuda.synchronize(); print('warm', flush=True)
+gb = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gb, stream=sB):
+    back()
+torch.cuda.synchronize()
+cur = torch.cuda.current_stream()
+
+
+def measure(gf):
+    ef, eb, e0 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    ff = fb = 0.0
+    n = 10
+    for it in range(n + 2):
+        torch.cuda.synchronize()
+        e0.record(cur)
+        sF.wait_stream(cur); sB.wait_stream(cur)
+        if gf is not None:
+            with torch.cuda.stream(sF):
+                gf.replay(); ef.record(sF)
+        with torch.cuda.stream(sB):
+            gb.replay(); eb.record(sB)
+        cur.wait_stream(sF); cur.wait_stream(sB)
+        torch.cuda.synchronize()
+        if it >= 2:
+            fb += e0.elapsed_time(eb)
+            ff += e0.elapsed_time(ef) if gf is not None else 0.0
+    return ff / n, fb / n
+
+
+print('back-end alone: %.2f ms' % measure(None)[1], flush=True)
+for name, fn in loads:
+    gf = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gf, stream=sF):
+        fn()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sF):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            gf.replay()
+        torch.cuda.synchronize(); alone = (time.perf_counter() - t0) / 5 * 1e3
+    ff, fb = measure(gf)
+    print('%-28s load alone %.2f ms | together: load done %.2f, back-end done %.2f ms' % (name, alone, ff, fb), flush=True)
