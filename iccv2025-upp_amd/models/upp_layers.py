@@ -236,8 +236,11 @@ def _no_grad_needed(*tensors):
 def _bn_rows(x, bn, training, relu=False):
     """BatchNorm1d of a channels-last (rows, C) matrix: identical statistics to BatchNorm1d on
     the reference's (BG, C, n) layout (both reduce over every position of every group)."""
-    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and _no_grad_needed(x, bn.weight, bn.bias):
-        return HF.bn_rows(x, bn, training, relu)       # 3 launches instead of torch's 5-6 (frozen prompter branches)
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+        if _no_grad_needed(x, bn.weight, bn.bias):
+            return HF.bn_rows(x, bn, training, relu)   # 3 launches instead of torch's 5-6 (frozen prompter branches)
+        if (training or bn.running_mean is None) and bn.momentum is not None:
+            return HF.bn_rows_train(x, bn, relu)       # trainable heads: batch statistics, own backward (3 + 3 launches)
     y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                      training, 0.0 if bn.momentum is None else bn.momentum, bn.eps)
     return F.relu(y) if relu else y
@@ -301,13 +304,13 @@ class Encoder(nn.Module):
         if self.training and bn1.track_running_stats:
             bump_counter(bn1.num_batches_tracked)
             bump_counter(bn3.num_batches_tracked)
-        h = F.relu(_bn_rows(h, bn1, self.training))
+        h = _bn_rows(h, bn1, self.training, relu=True)
         f = F.linear(h, c2.weight.squeeze(-1), c2.bias)                    # (BGn, 256)
         fg = f.view(bs * g, n, 256).max(dim=1)[0]                           # (BG, 256)
         w3 = c3.weight.squeeze(-1)                                          # (512, 512): [global | local]
         hg = F.linear(fg, w3[:, :256], c3.bias)                             # (BG, 512) once per group
         h = F.linear(f, w3[:, 256:]).view(bs * g, n, 512) + hg.unsqueeze(1)
-        h = F.relu(_bn_rows(h.view(bs * g * n, 512), bn3, self.training))
+        h = _bn_rows(h.view(bs * g * n, 512), bn3, self.training, relu=True)
         out = F.linear(h, c4.weight.squeeze(-1), c4.bias)                   # (BGn, C)
         return out.view(bs * g, n, self.encoder_channel).max(dim=1)[0].view(bs, g, self.encoder_channel)
 

@@ -157,6 +157,115 @@ __global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float *__restr
     }
 }
 
+// ---- backward of BatchNorm(+ReLU) over rows (trainable heads: batch statistics) --------------------------------------
+// With xh = (x - mean) * rstd, o = xh * gamma + beta, gm = g * [o > 0] (ReLU folded in; gm = g without it):
+//   g_beta = sum_r gm,  g_gamma = sum_r gm * xh,  g_x = gamma * rstd * (gm - (g_beta + xh * g_gamma) / R).
+// Same three-launch shape as the forward: per-slab column partials -> one finalize workgroup per 64 channels -> apply.
+// The ReLU mask is recomputed from x with the forward's exact expression, so no activation is saved.
+__global__ __launch_bounds__(256) void bn_rows_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                                  const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                  const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
+                                                                  int R, int C, int Cp, int per, float *__restrict__ part) {
+    __shared__ float s1[256], s2[256];
+    const int tid = threadIdx.x;
+    const int col = blockIdx.y * 256 + tid % Cp, rl = tid / Cp, RL = 256 / Cp;
+    const int r0 = blockIdx.x * per, r1 = min(R, r0 + per);
+    const int cc = min(col, C - 1);
+    const float mu = mean[cc], rs = rstd[cc], ga = gamma ? gamma[cc] : 1.0f, be = beta ? beta[cc] : 0.0f;
+    float a1 = 0.0f, a2 = 0.0f;
+    for (int rb = r0 + rl; rb < r1; rb += RL * 8) {         // 2 x 8 independent row loads in flight
+        float xv[8], gv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const size_t o = (size_t)min(rb + t * RL, r1 - 1) * C + cc;
+            xv[t] = x[o]; gv[t] = g[o];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (rb + t * RL < r1) {
+                const float xh = (xv[t] - mu) * rs;
+                const float gm = (relu && !(xh * ga + be > 0.0f)) ? 0.0f : gv[t];
+                a1 += gm; a2 = __builtin_fmaf(gm, xh, a2);
+            }
+    }
+    s1[tid] = a1; s2[tid] = a2;
+    __syncthreads();
+    if (rl == 0 && col < C) {
+        for (int q = 1; q < RL; ++q) { a1 += s1[q * Cp + tid]; a2 += s2[q * Cp + tid]; }   // fixed order
+        part[((size_t)blockIdx.x * 2 + 0) * C + col] = a1;
+        part[((size_t)blockIdx.x * 2 + 1) * C + col] = a2;
+    }
+}
+
+// g_beta / g_gamma = column sums of the slab partials, f64, fixed order.  grid = ceil(C / 64), 16 waves.
+__global__ __launch_bounds__(64 * kBnWaves) void bn_rows_bwd_finalize_kernel(const float *__restrict__ part, int slabs, int C,
+                                                                             float *__restrict__ g_gamma, float *__restrict__ g_beta) {
+    __shared__ double sh[2][kBnWaves][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int cc = min(c, C - 1);
+    constexpr int T = 16;
+    double b = 0.0, gq = 0.0;
+    for (int w0 = wave; w0 < slabs; w0 += kBnWaves * T) {
+        float pb[T], pg[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int w = min(w0 + kBnWaves * t, slabs - 1);
+            pb[t] = part[((size_t)w * 2 + 0) * C + cc]; pg[t] = part[((size_t)w * 2 + 1) * C + cc];
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) if (w0 + kBnWaves * t < slabs) { b += (double)pb[t]; gq += (double)pg[t]; }
+    }
+    sh[0][wave][lane] = b; sh[1][wave][lane] = gq;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        double tb = 0.0, tg = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBnWaves; ++w) { tb += sh[0][w][lane]; tg += sh[1][w][lane]; }
+        g_beta[c] = (float)tb; g_gamma[c] = (float)tg;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                                const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                const float *__restrict__ g_gamma, const float *__restrict__ g_beta, int relu,
+                                                                float inv_rows, float *__restrict__ g_x, long long total, int C) {
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= total) return;
+    float xv[4], gv[4];
+    int c[4];
+    if ((C & 3) == 0) {
+        const float4 t = *reinterpret_cast<const float4 *>(x + i0), u = *reinterpret_cast<const float4 *>(g + i0);
+        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+        gv[0] = u.x; gv[1] = u.y; gv[2] = u.z; gv[3] = u.w;
+        const int cb = (int)(i0 % C);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = cb + q;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const long long i = min(i0 + q, total - 1); xv[q] = x[i]; gv[q] = g[i]; c[q] = (int)(i % C); }
+    }
+    float mu[4], rs[4], ga[4], be[4], gg[4], gb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        mu[q] = mean[c[q]]; rs[q] = rstd[c[q]]; ga[q] = gamma ? gamma[c[q]] : 1.0f; be[q] = beta ? beta[c[q]] : 0.0f;
+        gg[q] = g_gamma[c[q]]; gb[q] = g_beta[c[q]];
+    }
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float xh = (xv[q] - mu[q]) * rs[q];
+        const float gm = (relu && !(xh * ga[q] + be[q] > 0.0f)) ? 0.0f : gv[q];
+        o[q] = (ga[q] * rs[q]) * (gm - (gb[q] + xh * gg[q]) * inv_rows);
+    }
+    if ((C & 3) == 0) *reinterpret_cast<float4 *>(g_x + i0) = make_float4(o[0], o[1], o[2], o[3]);
+    else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (i0 + q < total) g_x[i0 + q] = o[q];
+    }
+}
+
 // ---- inverse-distance interpolation ----------------------------------------------------------------------------------
 // out[row][col0 + c] = sum_{j<k} w_j * feat[b][idx[row][j]][c],  w_j = (1/(d_j+eps)) / sum_j (1/(d_j+eps)),
 // (d, idx) = the first k entries of row `row` of a neighbour table sorted by distance (row stride ld_tab).
@@ -244,6 +353,22 @@ extern "C" int upp_bn_rows_fwd(const float *x, const float *gamma, const float *
     const long long total = (long long)R * C;
     hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y,
                        total, C);
+    return upp_launch_status();
+}
+
+extern "C" int upp_bn_rows_bwd(const float *x, const float *g, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                               int relu, float *part, float *g_gamma, float *g_beta, float *g_x, int R, int C, void *stream) {
+    if (!x || !g || !mean || !rstd || !part || !g_gamma || !g_beta || R < 1 || C < 1) return UPP_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int per = bn_per(R), slabs = (R + per - 1) / per, Cp = pow2_at_least(C);
+    hipLaunchKernelGGL(bn_rows_bwd_partial_kernel, dim3(slabs, (C + 255) / 256), dim3(256), 0, st, x, g, mean, rstd, gamma, beta, relu, R, C, Cp,
+                       per, part);
+    hipLaunchKernelGGL(bn_rows_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64 * kBnWaves), 0, st, part, slabs, C, g_gamma, g_beta);
+    if (g_x) {
+        const long long total = (long long)R * C;
+        hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, g, mean, rstd, gamma, beta,
+                           g_gamma, g_beta, relu, 1.0f / (float)R, g_x, total, C);
+    }
     return upp_launch_status();
 }
 

@@ -415,6 +415,32 @@ def bn_rows(x, bn, training, relu=False):
     return ops.bn_rows_fwd(x.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, use_batch, relu)
 
 
+class _BnRowsTrain(Function):
+    """Training-mode BatchNorm(+ReLU) over rows with its backward (upp_bn_rows_fwd / upp_bn_rows_bwd): the trainable
+    BatchNorm1d layers of the per-point heads.  The running statistics are updated in place by the forward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        x = x.contiguous()
+        y, mean, rstd = ops.bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, True, relu, want_stats=True)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        g_x, g_gamma, g_beta = ops.bn_rows_bwd(x, g.contiguous(), mean, rstd, gamma, beta, ctx.relu, want_gx=ctx.needs_input_grad[0])
+        return (g_x, g_gamma if ctx.needs_input_grad[1] else None, g_beta if ctx.needs_input_grad[2] else None,
+                None, None, None, None, None)
+
+
+def bn_rows_train(x, bn, relu=False):
+    """Differentiable training-mode BatchNorm(+ReLU) over the rows of a channels-last (R,C) matrix."""
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    return _BnRowsTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
+
+
 def interp(dists, idx, feat, k, eps, out=None, col0=0):
     """Inverse-distance interpolation from the k nearest of a sorted neighbour table; no autograd."""
     return ops.interp_fwd(dists, idx, feat.contiguous(), k, eps, out, col0)

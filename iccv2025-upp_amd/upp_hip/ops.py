@@ -380,7 +380,7 @@ def prop_bwd(g_out, pooled, amax, mean, rstd, gamma, u, keep, w8, csr1, csr2, cs
 
 
 # ------------------------------------------------------------------ row operators of the frozen prompter branches
-def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu):
+def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, want_stats=False):
     _need(x, "x", torch.float32, ndim=2)
     R, C = x.shape
     dev = x.device
@@ -390,7 +390,26 @@ def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, traini
     y = torch.empty_like(x)
     _call(dev, "upp_bn_rows_fwd", _abi.ptr(x), _abi.ptr(gamma), _abi.ptr(beta), _abi.ptr(running_mean), _abi.ptr(running_var),
           float(momentum), float(eps), int(bool(training)), int(bool(relu)), _abi.ptr(part), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(y), R, C)
-    return y
+    return (y, mean, rstd) if want_stats else y
+
+
+def bn_rows_bwd(x, g, mean, rstd, gamma, beta, relu, want_gx=True):
+    """Backward of the training-mode bn_rows_fwd: -> (g_x or None, g_gamma, g_beta)."""
+    _need(x, "x", torch.float32, ndim=2)
+    _need(g, "g", torch.float32, ndim=2)
+    R, C = x.shape
+    dev = x.device
+    _need(mean, "mean", torch.float32, ndim=1, last=C)
+    _need(rstd, "rstd", torch.float32, ndim=1, last=C)
+    if g.shape != x.shape or any(t is not None and (t.shape != (C,) or t.dtype != torch.float32 or not t.is_cuda) for t in (gamma, beta)):
+        raise RuntimeError("bn_rows_bwd: g must match x, gamma / beta must be (C,) f32 HIP tensors")
+    part = torch.empty(_abi.load().upp_bn_rows_part_floats(R, C), dtype=torch.float32, device=dev)
+    g_gamma = torch.empty(C, dtype=torch.float32, device=dev)
+    g_beta = torch.empty(C, dtype=torch.float32, device=dev)
+    g_x = torch.empty_like(x) if want_gx else None
+    _call(dev, "upp_bn_rows_bwd", _abi.ptr(x), _abi.ptr(g), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma), _abi.ptr(beta), int(bool(relu)),
+          _abi.ptr(part), _abi.ptr(g_gamma), _abi.ptr(g_beta), _abi.ptr(g_x), R, C)
+    return g_x, g_gamma, g_beta
 
 
 def interp_fwd(dist, idx, feat, k, eps, out=None, col0=0):

@@ -254,7 +254,7 @@ int upp_prop_bwd(const float *g_out, const float *pooled, const uint8_t *amax, c
                  const int32_t *perm8, int training, float *g_c2, float *part, float *g_gamma, float *g_beta, float *g_X,
                  int B, int Lp, int T, int G2, int D, void *stream);
 
-/* ---- row operators of the frozen prompter branches (forward only) ---------------------------------
+/* ---- row operators of the prompter branches and the per-point heads ---------------------------------
  * Replace the element-wise / reduction chains of the reference's rectify prompter
  * (models/Point_MAE_pretask_dev.py:22-52 PositionalEmbedding, :386-473 set abstraction / feature propagation):
  *   upp_bn_rows_fwd : y (R,C) = BatchNorm over the R rows of the channels-last matrix x (== BatchNorm1d/2d on the
@@ -262,6 +262,11 @@ int upp_prop_bwd(const float *g_out, const float *pooled, const uint8_t *amax, c
  *                     statistics updated (momentum, unbiased variance) when non-NULL; training == 0: running
  *                     statistics.  gamma / beta may be NULL (1 / 0).  mean, rstd (C) are outputs; part:
  *                     upp_bn_rows_part_floats(R, C) floats of scratch.  Deterministic (fixed combination order).
+ *   upp_bn_rows_bwd : backward of the training-mode form (batch statistics), for the trainable BatchNorm1d layers of the
+ *                     per-point heads (models/Point_MAE_unify_segment.py seg_head / propagation_0, the patch embedding in
+ *                     pre-training): x, g (R,C), mean / rstd from the forward; with xh = (x-mean)*rstd and
+ *                     gm = g * [xh*gamma+beta > 0] (relu != 0; gm = g otherwise):  g_beta = sum gm, g_gamma = sum gm*xh,
+ *                     g_x = gamma*rstd*(gm - (g_beta + xh*g_gamma)/R).  g_x may be NULL (parameter gradients only).
  *   upp_interp_fwd  : out[b*N+n][col0 .. col0+C) = sum_{j<k} w_j feat[b][idx[b,n,j]],  w_j = (1/(d_j+eps)) / sum_j(1/(d_j+eps)),
  *                     where (dist, idx) (B*N rows, row stride ld_tab, idx int64) is a neighbour table sorted by distance
  *                     (torch.sort of square_distance, as the reference computes it); feat (B,S,C); k <= 16, C <= 256.
@@ -272,6 +277,8 @@ long long upp_bn_rows_part_floats(int R, int C);
 int upp_bn_rows_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
                     float momentum, float eps, int training, int relu, float *part, float *mean, float *rstd, float *y,
                     int R, int C, void *stream);
+int upp_bn_rows_bwd(const float *x, const float *g, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                    int relu, float *part, float *g_gamma, float *g_beta, float *g_x, int R, int C, void *stream);
 int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, float *out, int ld_out, int col0,
                    int B, int N, int S, int C, int k, float eps, void *stream);
 int upp_posenc_fwd(const float *x, const float *freqs, int F, float *out, int ld_out, int col0, long long rows, void *stream);

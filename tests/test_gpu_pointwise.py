@@ -42,6 +42,44 @@ def test_bn_rows_matches_torch_batch_norm(R, C, training, relu):
         assert torch.equal(HF.bn_rows(x, bn2, training, relu), HF.bn_rows(x, torch.nn.BatchNorm1d(C).cuda(), training, relu))   # deterministic
 
 
+@pytest.mark.parametrize("R,C", [(65536, 512), (16384, 1536), (4096, 128), (1000, 300), (32, 64), (7, 3), (2400, 384)])
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("x_grad", [True, False])
+def test_bn_rows_train_backward_matches_torch(R, C, relu, x_grad):
+    """upp_bn_rows_fwd + upp_bn_rows_bwd (trainable per-point heads) against torch's batch_norm autograd."""
+    torch.manual_seed(R + C)
+    x0 = (torch.randn(R, C, device='cuda') * torch.linspace(0.2, 3.0, C, device='cuda') + torch.linspace(-4.0, 3.0, C, device='cuda'))
+    gy = torch.randn(R, C, device='cuda') * torch.linspace(0.5, 2.0, C, device='cuda')
+    res = []
+    mask = None
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm1d(C).cuda().train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+        x = x0.clone().requires_grad_(x_grad)
+        if fused:
+            y = upp_layers._bn_rows(x, bn, True, relu=relu)
+            assert type(y.grad_fn).__name__ == '_BnRowsTrainBackward'
+            y.backward(gy)
+            mask = (y > 0).float() if relu else None
+        else:
+            # the ReLU gate of the handful of outputs within rounding of 0 depends on the evaluation order of the affine
+            # transform: take the gate from the fused forward, so the comparison is about the BatchNorm backward
+            y_lin = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+            y = F.relu(y_lin) if relu else y_lin
+            y_lin.backward(gy * mask if relu else gy)
+        res.append((y, x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+    (y, gx, gg, gb, rm, rv), (y_t, gx_t, gg_t, gb_t, rm_t, rv_t) = res
+    close(y, y_t, rtol=2e-5, atol_scale=5e-6)
+    close(rm, rm_t, rtol=1e-5, atol_scale=1e-6); close(rv, rv_t, rtol=2e-5, atol_scale=1e-6)
+    close(gb, gb_t, rtol=2e-5, atol_scale=2e-5)          # sums of R terms of either sign: absolute error ~ sqrt(R) * eps * |g|
+    close(gg, gg_t, rtol=2e-5, atol_scale=2e-5)
+    if x_grad:
+        close(gx, gx_t, rtol=5e-5, atol_scale=1e-5)
+    else:
+        assert gx is None
+
+
 @pytest.mark.parametrize("B,N,S,C,k", [(32, 1096, 64, 32, 16), (32, 64, 32, 12, 16), (2, 50, 5, 7, 16), (3, 33, 40, 256, 3), (1, 1, 16, 1, 1)])
 def test_interp_matches_reference_formula(B, N, S, C, k):
     g = torch.Generator(device='cuda').manual_seed(B * N + C)
