@@ -126,8 +126,11 @@ def _inverse_distance_interp(xyz1, xyz2, points2, k, eps, out=None, col0=0):
     """k nearest of xyz2 for each xyz1 point (full sort, as the reference), 1/(d+eps) weights.
     `out`/`col0`: optional (B,N,W) buffer whose columns [col0, col0+C) receive the result (fused path only)."""
     dists, idx = square_distance(xyz1, xyz2).sort(dim=-1)
-    if points2.is_cuda and k <= 16 and points2.shape[-1] <= 256 and _no_grad_needed(xyz1, xyz2, points2):
-        return HF.interp(dists, idx, points2, min(k, dists.shape[-1]), eps, out, col0)
+    if points2.is_cuda and points2.dtype == torch.float32 and k <= 16:
+        if _no_grad_needed(xyz1, xyz2, points2):
+            return HF.interp(dists, idx, points2, min(k, dists.shape[-1]), eps, out, col0)
+        if out is None and _no_grad_needed(xyz1, xyz2) and xyz1.shape[1] <= 4096:     # trainable features, constant geometry
+            return HF.interp_train(dists, idx, points2, min(k, dists.shape[-1]), eps)
     assert out is None
     dists, idx = dists[:, :, :k], idx[:, :, :k]
     recip = 1.0 / (dists + eps)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "upp_bn_rows_fwd": (_c_i, [_c_f] * 5 + [ctypes.c_float] * 2 + [_c_i] * 2 + [_c_f] * 4 + [_c_i] * 2 + [_c_f]),
     "upp_bn_rows_bwd": (_c_i, [_c_f] * 6 + [_c_i] + [_c_f] * 4 + [_c_i] * 2 + [_c_f]),
     "upp_interp_fwd": (_c_i, [_c_f] * 2 + [_c_i] + [_c_f] * 2 + [_c_i] * 7 + [ctypes.c_float] + [_c_f]),
+    "upp_interp_bwd": (_c_i, [_c_f] * 2 + [_c_i] + [_c_f] + [_c_i] * 2 + [_c_f] + [_c_i] * 5 + [ctypes.c_float] + [_c_f]),
     "upp_posenc_fwd": (_c_i, [_c_f, ctypes.POINTER(ctypes.c_float), _c_i, _c_f, _c_i, _c_i, ctypes.c_longlong, _c_f]),
     "upp_prop_part_floats": (ctypes.c_longlong, [_c_i] * 2),
     "upp_prop_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 7 + [ctypes.c_float] * 2 + [_c_i] + [_c_f] * 6 + [_c_i] * 5 + [_c_f]),

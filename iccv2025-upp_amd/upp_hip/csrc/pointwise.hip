@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ d
                                                      const float *__restrict__ feat, int S, int C, int Cp, int k, float eps,
                                                      float *__restrict__ out, int ld_out, int col0, int rows, int N) {
     const int tid = threadIdx.x;
-    const int col = tid % Cp, rl = tid / Cp, RL = 256 / Cp;
+    const int col = blockIdx.y * 256 + tid % Cp, rl = tid / Cp, RL = 256 / Cp;
     const int row = blockIdx.x * RL + rl;
     if (row >= rows) return;
     const int b = row / N;
@@ -298,6 +298,69 @@ __global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ d
 #pragma unroll
     for (int j = 0; j < kInterpK; ++j) acc += f[j] * (w[j] / norm);
     if (col < C) out[(size_t)row * ld_out + col0 + col] = acc;
+}
+
+// Backward of the interpolation w.r.t. the features (the neighbour table is constant):
+//   g_feat[b][s][c] = sum over the (row, j) with idx[row][j] == s of  w_j(row) * g_out[row][col0 + c].
+// One workgroup per (sample, source row s): it scans the sample's N*k table entries in order, compacts the hits
+// (row, weight) into LDS with ballots (ascending entry order -> deterministic sums, no atomics), then accumulates the
+// referenced gradient rows; entries are split over 256/Cp thread groups whose partial sums are combined in a fixed order.
+constexpr int kInterpMaxRows = 4096;
+__global__ __launch_bounds__(256) void interp_bwd_kernel(const float *__restrict__ dist, const int64_t *__restrict__ idx, int ld_tab,
+                                                         const float *__restrict__ g_out, int ld_g, int col0, int S, int C, int Cp, int k,
+                                                         float eps, int N, float *__restrict__ g_feat) {
+    __shared__ int l_row[kInterpMaxRows];
+    __shared__ float l_w[kInterpMaxRows];
+    __shared__ int wave_cnt[4];
+    __shared__ float red[256];
+    const int b = blockIdx.x / S, s = blockIdx.x - b * S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t base = (size_t)b * N;
+    const int E = N * k;
+    int count = 0;
+    for (int e0 = 0; e0 < E; e0 += 256) {
+        const int e = e0 + tid;
+        bool hit = false;
+        int row = 0, j = 0;
+        if (e < E) { row = e / k; j = e - row * k; hit = idx[(base + row) * ld_tab + j] == (int64_t)s; }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = count;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (hit) {
+            const float *dr = dist + (base + row) * ld_tab;
+            float norm = 0.0f, mine = 0.0f;
+            for (int q = 0; q < k; ++q) { const float r = 1.0f / (dr[q] + eps); norm += r; if (q == j) mine = r; }
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            l_row[pos] = row; l_w[pos] = mine / norm;
+        }
+        count += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    const int cq = tid % Cp, part = tid / Cp, RL = 256 / Cp;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + cq, cc = min(c, C - 1);
+        float acc = 0.0f;
+        for (int i = part; i < count; i += RL * 4) {
+            float v[4], w[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ii = min(i + t * RL, count - 1);
+                w[t] = i + t * RL < count ? l_w[ii] : 0.0f;
+                v[t] = g_out[(base + l_row[ii]) * ld_g + col0 + cc];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_fmaf(w[t], v[t], acc);
+        }
+        if (RL > 1) {
+            red[tid] = acc;
+            __syncthreads();
+            if (part == 0) for (int q = 1; q < RL; ++q) acc += red[q * Cp + cq];
+            __syncthreads();
+        }
+        if (part == 0 && c < C) g_feat[((size_t)b * S + s) * C + c] = acc;
+    }
 }
 
 // ---- positional embedding ---------------------------------------------------------------------------------------
@@ -376,10 +439,20 @@ extern "C" int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab,
                               int B, int N, int S, int C, int k, float eps, void *stream) {
     if (!dist || !idx || !feat || !out || B < 1 || N < 1 || S < 1 || C < 1 || k < 1 || ld_tab < k || ld_out < col0 + C || col0 < 0)
         return UPP_E_BADARG;
-    if (k > kInterpK || k > S || C > 256) return UPP_E_RANGE;
+    if (k > kInterpK || k > S) return UPP_E_RANGE;
     const int Cp = pow2_at_least(C), RL = 256 / Cp, rows = B * N;
-    hipLaunchKernelGGL(interp_kernel, dim3((rows + RL - 1) / RL), dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S, C, Cp, k, eps,
-                       out, ld_out, col0, rows, N);
+    hipLaunchKernelGGL(interp_kernel, dim3((rows + RL - 1) / RL, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S,
+                       C, Cp, k, eps, out, ld_out, col0, rows, N);
+    return upp_launch_status();
+}
+
+extern "C" int upp_interp_bwd(const float *dist, const int64_t *idx, int ld_tab, const float *g_out, int ld_g, int col0, float *g_feat,
+                              int B, int N, int S, int C, int k, float eps, void *stream) {
+    if (!dist || !idx || !g_out || !g_feat || B < 1 || N < 1 || S < 1 || C < 1 || k < 1 || ld_tab < k || ld_g < col0 + C || col0 < 0)
+        return UPP_E_BADARG;
+    if (k > kInterpK || k > S || N > kInterpMaxRows || (long long)B * S > 0x7fffffffLL) return UPP_E_RANGE;
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, g_out, ld_g, col0, S, C,
+                       pow2_at_least(C), k, eps, N, g_feat);
     return upp_launch_status();
 }
 

@@ -446,6 +446,28 @@ def interp(dists, idx, feat, k, eps, out=None, col0=0):
     return ops.interp_fwd(dists, idx, feat.contiguous(), k, eps, out, col0)
 
 
+class _InterpTrain(Function):
+    """Inverse-distance interpolation with a gradient for the features (upp_interp_fwd / upp_interp_bwd); the sorted
+    neighbour table (dists, idx) is a constant of the graph."""
+
+    @staticmethod
+    def forward(ctx, dists, idx, feat, k, eps):
+        feat = feat.contiguous()
+        ctx.save_for_backward(dists, idx)
+        ctx.S, ctx.k, ctx.eps = feat.shape[1], k, eps
+        return ops.interp_fwd(dists, idx, feat, k, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        dists, idx = ctx.saved_tensors
+        return None, None, ops.interp_bwd(dists, idx, g.contiguous(), ctx.S, ctx.k, ctx.eps), None, None
+
+
+def interp_train(dists, idx, feat, k, eps):
+    """Differentiable (w.r.t. feat) inverse-distance interpolation from the k nearest of a sorted neighbour table."""
+    return _InterpTrain.apply(dists, idx, feat, k, eps)
+
+
 def posenc(x, freqs, out=None, col0=0):
     """(x, sin(f x), cos(f x))_f positional embedding of (...,3) coordinates; no autograd."""
     return ops.posenc_fwd(x.contiguous(), freqs, out, col0)

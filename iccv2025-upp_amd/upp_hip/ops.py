@@ -430,6 +430,21 @@ def interp_fwd(dist, idx, feat, k, eps, out=None, col0=0):
     return out
 
 
+def interp_bwd(dist, idx, g_out, S, k, eps):
+    """Gradient of interp_fwd w.r.t. feat: g_out (B,N,C) -> (B,S,C); dist / idx as in interp_fwd."""
+    _need(g_out, "g_out", torch.float32, ndim=3)
+    B, N, C = g_out.shape
+    for t, name, dt in ((dist, "dist", torch.float32), (idx, "idx", torch.int64)):
+        if not t.is_cuda or t.dtype != dt or t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != N * t.stride(1):
+            raise RuntimeError(f"{name} must be a HIP {dt} (B,N,S') table with contiguous rows")
+    if dist.stride(1) != idx.stride(1) or dist.shape[:2] != idx.shape[:2] or tuple(dist.shape[:2]) != (B, N):
+        raise RuntimeError("dist / idx must share shape and row stride and match g_out")
+    g_feat = torch.empty((B, S, C), dtype=torch.float32, device=g_out.device)
+    _call(g_out.device, "upp_interp_bwd", _abi.ptr(dist), _abi.ptr(idx), dist.stride(1), _abi.ptr(g_out), C, 0, _abi.ptr(g_feat),
+          B, N, int(S), C, int(k), float(eps))
+    return g_feat
+
+
 def posenc_fwd(x, freqs, out=None, col0=0):
     _need(x, "x", torch.float32, last=3)
     F = len(freqs)

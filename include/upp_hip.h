@@ -269,7 +269,9 @@ int upp_prop_bwd(const float *g_out, const float *pooled, const uint8_t *amax, c
  *                     g_x = gamma*rstd*(gm - (g_beta + xh*g_gamma)/R).  g_x may be NULL (parameter gradients only).
  *   upp_interp_fwd  : out[b*N+n][col0 .. col0+C) = sum_{j<k} w_j feat[b][idx[b,n,j]],  w_j = (1/(d_j+eps)) / sum_j(1/(d_j+eps)),
  *                     where (dist, idx) (B*N rows, row stride ld_tab, idx int64) is a neighbour table sorted by distance
- *                     (torch.sort of square_distance, as the reference computes it); feat (B,S,C); k <= 16, C <= 256.
+ *                     (torch.sort of square_distance, as the reference computes it); feat (B,S,C); k <= 16.
+ *   upp_interp_bwd  : g_feat (B,S,C) = gradient of the above w.r.t. feat for g_out (B*N rows, row stride ld_g, columns
+ *                     [col0, col0+C)); the neighbour table is a constant.  Deterministic (no atomics).  N <= 4096.
  *   upp_posenc_fwd  : out[row][col0 ..) = (x, sin(f_0 x), cos(f_0 x), ..., sin(f_{F-1} x), cos(f_{F-1} x)), x (rows,3);
  *                     freqs is a HOST array of F <= 8 frequencies.
  * interp / posenc write a column window of a row-major buffer with row stride ld_out (the reference's torch.cat). */
@@ -280,6 +282,8 @@ int upp_bn_rows_fwd(const float *x, const float *gamma, const float *beta, float
 int upp_bn_rows_bwd(const float *x, const float *g, const float *mean, const float *rstd, const float *gamma, const float *beta,
                     int relu, float *part, float *g_gamma, float *g_beta, float *g_x, int R, int C, void *stream);
 int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, float *out, int ld_out, int col0,
+                   int B, int N, int S, int C, int k, float eps, void *stream);
+int upp_interp_bwd(const float *dist, const int64_t *idx, int ld_tab, const float *g_out, int ld_g, int col0, float *g_feat,
                    int B, int N, int S, int C, int k, float eps, void *stream);
 int upp_posenc_fwd(const float *x, const float *freqs, int F, float *out, int ld_out, int col0, long long rows, void *stream);
 

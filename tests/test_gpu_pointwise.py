@@ -149,3 +149,33 @@ def test_rectify_prompter_fused_path_equals_torch_path():
                 close(stats_fused[k], rp.state_dict()[k], rtol=1e-4, atol_scale=1e-5)
             elif 'num_batches' in k:
                 assert int(stats_fused[k]) == int(rp.state_dict()[k])
+
+
+@pytest.mark.parametrize("B,N,S,C,k", [(8, 2048, 128, 1152, 3), (4, 1076, 32, 32, 16), (2, 32, 32, 12, 16), (3, 33, 40, 300, 3), (1, 1, 16, 1, 1),
+                                       (2, 4096, 5, 7, 5)])
+def test_interp_train_forward_and_feature_gradient(B, N, S, C, k):
+    """upp_interp_fwd / upp_interp_bwd (trainable features, constant geometry) against the reference's torch formula."""
+    g = torch.Generator(device='cuda').manual_seed(B * N + C)
+    xyz1 = torch.rand(B, N, 3, device='cuda', generator=g)
+    xyz2 = torch.rand(B, S, 3, device='cuda', generator=g)
+    feat0 = torch.randn(B, S, C, device='cuda', generator=g)
+    gy = torch.randn(B, N, C, device='cuda', generator=g)
+    outs = []
+    for fused in (True, False):
+        feat = feat0.clone().requires_grad_(True)
+        if fused:
+            y = upp_layers._inverse_distance_interp(xyz1, xyz2, feat, k, 1e-4)
+            assert type(y.grad_fn).__name__ == '_InterpTrainBackward'
+        else:
+            dists, idx = upp_layers.square_distance(xyz1, xyz2).sort(dim=-1)
+            d, i = dists[:, :, :k], idx[:, :, :k]
+            recip = 1.0 / (d + 1e-4)
+            w = recip / recip.sum(dim=2, keepdim=True)
+            y = torch.sum(upp_layers.index_points(feat, i) * w.unsqueeze(-1), dim=2)
+        y.backward(gy)
+        outs.append((y, feat.grad))
+    close(outs[0][0], outs[1][0], rtol=1e-5, atol_scale=2e-6)
+    close(outs[0][1], outs[1][1], rtol=2e-5, atol_scale=5e-6)
+    feat = feat0.clone().requires_grad_(True)
+    upp_layers._inverse_distance_interp(xyz1, xyz2, feat, k, 1e-4).backward(gy)
+    assert torch.equal(feat.grad, outs[0][1])                           # deterministic
