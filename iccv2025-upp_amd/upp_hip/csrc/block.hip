@@ -534,6 +534,9 @@ extern "C" int upp_ln_param_grad(const float *g_h, const float *xo, const float 
 int upp_attn_fwd_mfma(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st);
 int upp_attn_bwd_mfma(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
                       float scale, hipStream_t st);
+int upp_attn_fwd_long(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st);
+int upp_attn_bwd_long(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
+                      float scale, hipStream_t st);
 static int g_attn_mfma = 1;   // tuning hook: 0 forces the VALU kernels
 extern "C" int upp_attn_set_mfma(int on) { g_attn_mfma = on ? 1 : 0; return 0; }
 
@@ -543,6 +546,7 @@ extern "C" int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (g_attn_mfma && L <= 96) return upp_attn_fwd_mfma(qkv, ctx, lse, B, L, H, scale, st);
+    if (g_attn_mfma && L <= 160) return upp_attn_fwd_long(qkv, ctx, lse, B, L, H, scale, st);
     const int ns = (L + 63) / 64;
     const size_t lds = ((size_t)L * 64 + (size_t)kAW * 2 * ns * 64) * sizeof(float);
     dim3 grid(B * H), block(64 * kAW);
@@ -556,10 +560,11 @@ extern "C" int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int
 extern "C" int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L,
                             int H, int head_dim, float scale, void *stream) {
     if (!qkv || !ctx || !d_ctx || !lse || !d_qkv || B < 0 || L < 1 || H < 1) return UPP_E_BADARG;
-    if (head_dim != 64 || L > 144) return UPP_E_RANGE;
+    if (head_dim != 64 || L > 160 || (!g_attn_mfma && L > 144)) return UPP_E_RANGE;
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (g_attn_mfma && L <= 96) return upp_attn_bwd_mfma(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
+    if (g_attn_mfma && L <= 160) return upp_attn_bwd_long(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
     const int ns = (L + 63) / 64;
     const size_t lds = ((size_t)2 * L * 65 + (size_t)kAW * 2 * ns * 64 + (size_t)2 * kAW * kAW * 64) * sizeof(float);
     dim3 grid(B * H), block(64 * kAW);

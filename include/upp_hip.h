@@ -193,7 +193,7 @@ int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, cons
  *   ctx (B,L,H*64): softmax(q k^T * scale) v, already in the layout of (:193) `.transpose(1,2).reshape(B,N,C)`
  *   lse (B,H,L): log-sum-exp of the scaled scores (saved for backward)
  *   d_qkv (B,L,3,H,64) from d_ctx (B,L,H*64)
- * Limits: head_dim == 64; L <= 192 forward, L <= 144 backward. */
+ * Limits: head_dim == 64; L <= 192 forward, L <= 160 backward (FP32 MFMA kernels for L <= 96 and L <= 160). */
 int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, void *stream);
 int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv,
                  int B, int L, int H, int head_dim, float scale, void *stream);

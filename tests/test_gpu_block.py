@@ -19,10 +19,12 @@ def close(a, b, rtol=1e-5, atol_scale=2e-6):
 
 
 @pytest.mark.parametrize("mfma", [1, 0])
-@pytest.mark.parametrize("L", [1, 31, 35, 64, 65, 75, 96, 97, 129])
+@pytest.mark.parametrize("L", [1, 31, 35, 64, 65, 75, 96, 97, 128, 129, 139, 144, 159, 160])
 def test_attention_core_forward_backward(L, mfma):
     from upp_hip import _abi
-    _abi.load().upp_attn_set_mfma(mfma)     # MFMA kernels serve L <= 96; 0 forces the general VALU kernels
+    if not mfma and L > 144:
+        pytest.skip("the VALU backward serves L <= 144")
+    _abi.load().upp_attn_set_mfma(mfma)     # MFMA kernels: L <= 96 (attn_mfma.hip), L <= 160 (attn_long.hip); 0 forces the VALU kernels
     try:
         _attention_case(L)
     finally:
