@@ -217,7 +217,7 @@ def stage_report(device, B):
     x1228 = _seeded.unit_ball_clouds(B, 1228, seed=8).to(device)
     out = {}
     t = time_kernel(lambda: ops.fps(x1228, 1024, want_centers=True), iters=5)
-    out["fps_1228_1024"] = hbm("fps_kernel<8,4> (B,1228)->1024", t, B * (1228 * 12 + 1024 * 16), "fps_kernel<8, 4",
+    out["fps_1228_1024"] = hbm("fps_kernel<6,4> (B,1228)->1024", t, B * (1228 * 12 + 1024 * 16), "fps_kernel<6, 4",
                                "1023 dependent arg-max rounds per cloud: latency-bound by construction (%.2f us/round)" % (t * 1e3 / 1023))
     t = time_kernel(lambda: ops.fps(x, 64, want_centers=True))
     out["fps_1024_64"] = hbm("fps_kernel<4,4> (B,1024)->64", t, B * (1024 * 12 + 64 * 16), "fps_kernel<4, 4")

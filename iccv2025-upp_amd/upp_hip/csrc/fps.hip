@@ -197,9 +197,12 @@ template <int W>
 int dispatch_s(int slots, const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom &g, hipStream_t st) {
     if (slots <= 2) return launch<2, W>(xyz, idx, centers, B, g, st);
     if (slots <= 4) return launch<4, W>(xyz, idx, centers, B, g, st);
+    if (slots <= 6) return launch<6, W>(xyz, idx, centers, B, g, st);
     if (slots <= 8) return launch<8, W>(xyz, idx, centers, B, g, st);
+    if (slots <= 10) return launch<10, W>(xyz, idx, centers, B, g, st);
     if (slots <= 12) return launch<12, W>(xyz, idx, centers, B, g, st);
     if (slots <= 16) return launch<16, W>(xyz, idx, centers, B, g, st);
+    if (slots <= 20) return launch<20, W>(xyz, idx, centers, B, g, st);
     if (slots <= 24) return launch<24, W>(xyz, idx, centers, B, g, st);
     if (slots <= 32) return launch<32, W>(xyz, idx, centers, B, g, st);
     if (slots <= 64) return launch<64, W>(xyz, idx, centers, B, g, st);
