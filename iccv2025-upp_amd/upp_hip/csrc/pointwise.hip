@@ -271,6 +271,9 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
 // (d, idx) = the first k entries of row `row` of a neighbour table sorted by distance (row stride ld_tab).
 // PointNetFeaturePropagation.forward, reference models/Point_MAE_pretask_dev.py:443-462.
 constexpr int kInterpK = 16;
+// KK = compile-time bound of the neighbour count (k <= KK): the gathers are unrolled KK deep, so a 3-neighbour
+// interpolation must not pay for 16.
+template <int KK>
 __global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ dist, const int64_t *__restrict__ idx, int ld_tab,
                                                      const float *__restrict__ feat, int S, int C, int Cp, int k, float eps,
                                                      float *__restrict__ out, int ld_out, int col0, int rows, int N) {
@@ -280,23 +283,23 @@ __global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ d
     if (row >= rows) return;
     const int b = row / N;
     const int cc = min(col, C - 1);
-    float d[kInterpK];
-    int id[kInterpK];
+    float d[KK];
+    int id[KK];
 #pragma unroll
-    for (int j = 0; j < kInterpK; ++j) {
+    for (int j = 0; j < KK; ++j) {
         const int jj = min(j, k - 1);
         d[j] = dist[(size_t)row * ld_tab + jj];
         id[j] = (int)idx[(size_t)row * ld_tab + jj];
     }
-    float f[kInterpK];
+    float f[KK];
 #pragma unroll
-    for (int j = 0; j < kInterpK; ++j) f[j] = feat[((size_t)b * S + id[j]) * C + cc];
-    float w[kInterpK], norm = 0.0f;
+    for (int j = 0; j < KK; ++j) f[j] = feat[((size_t)b * S + id[j]) * C + cc];
+    float w[KK], norm = 0.0f;
 #pragma unroll
-    for (int j = 0; j < kInterpK; ++j) { w[j] = j < k ? 1.0f / (d[j] + eps) : 0.0f; norm += w[j]; }
+    for (int j = 0; j < KK; ++j) { w[j] = j < k ? 1.0f / (d[j] + eps) : 0.0f; norm += w[j]; }
     float acc = 0.0f;
 #pragma unroll
-    for (int j = 0; j < kInterpK; ++j) acc += f[j] * (w[j] / norm);
+    for (int j = 0; j < KK; ++j) acc += f[j] * (w[j] / norm);
     if (col < C) out[(size_t)row * ld_out + col0 + col] = acc;
 }
 
@@ -441,8 +444,10 @@ extern "C" int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab,
         return UPP_E_BADARG;
     if (k > kInterpK || k > S) return UPP_E_RANGE;
     const int Cp = pow2_at_least(C), RL = 256 / Cp, rows = B * N;
-    hipLaunchKernelGGL(interp_kernel, dim3((rows + RL - 1) / RL, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S,
-                       C, Cp, k, eps, out, ld_out, col0, rows, N);
+    const dim3 grid((rows + RL - 1) / RL, (C + 255) / 256);
+    if (k <= 4) hipLaunchKernelGGL(interp_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S, C, Cp, k, eps, out, ld_out, col0, rows, N);
+    else if (k <= 8) hipLaunchKernelGGL(interp_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S, C, Cp, k, eps, out, ld_out, col0, rows, N);
+    else hipLaunchKernelGGL(interp_kernel<kInterpK>, grid, dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S, C, Cp, k, eps, out, ld_out, col0, rows, N);
     return upp_launch_status();
 }
 
