@@ -125,7 +125,12 @@ def index_points(points, idx):
 def _inverse_distance_interp(xyz1, xyz2, points2, k, eps, out=None, col0=0):
     """k nearest of xyz2 for each xyz1 point (full sort, as the reference), 1/(d+eps) weights.
     `out`/`col0`: optional (B,N,W) buffer whose columns [col0, col0+C) receive the result (fused path only)."""
-    dists, idx = square_distance(xyz1, xyz2).sort(dim=-1)
+    S = xyz2.shape[1]
+    if (xyz1.is_cuda and xyz1.dtype == torch.float32 and xyz2.dtype == torch.float32 and S <= 256 and min(k, S) <= 16
+            and xyz1.shape[-1] == 3 and _no_grad_needed(xyz1, xyz2)):
+        dists, idx = HF.sqdist_topk(xyz1, xyz2, min(k, S))       # one launch for matmul + 5 element-wise passes + full sort
+    else:
+        dists, idx = square_distance(xyz1, xyz2).sort(dim=-1)
     if points2.is_cuda and points2.dtype == torch.float32 and k <= 16:
         if _no_grad_needed(xyz1, xyz2, points2):
             return HF.interp(dists, idx, points2, min(k, dists.shape[-1]), eps, out, col0)

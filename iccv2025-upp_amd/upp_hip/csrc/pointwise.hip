@@ -266,6 +266,60 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
     }
 }
 
+// ---- k nearest source points per query, in the reference's square_distance form ----------------------------------
+// dist[row][0..k) / idx[row][0..k) = the k smallest  d = |a|^2 + |b|^2 - 2 a.b  over the S source points of the query's
+// cloud, ascending (d, index) -- what `square_distance(xyz1, xyz2).sort(dim=-1)` followed by `[:, :, :k]` yields in the
+// reference (models/modules.py:13-32, models/Point_MAE_unify.py:22-48, Point_MAE_pretask_dev.py:443-449), without the
+// (B,N,S) matrix, its matmul, five element-wise passes and the full sort.  d is evaluated in the operation order of the
+// reference formula (dist = -2 a.b; dist += |a|^2; dist += |b|^2).  One wavefront per query; lane l holds the
+// candidates l, l+64, ... (SL per lane); k selection rounds of one wave-wide u32 min on an order-preserving image.
+template <int SL>
+__global__ __launch_bounds__(256) void sqdist_topk_kernel(const float *__restrict__ q, const float *__restrict__ src, int N, int S, int k,
+                                                          float *__restrict__ dist, int64_t *__restrict__ idx, long long rows) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long b = row / N;
+    const float *a = q + row * 3;
+    const float ax = a[0], ay = a[1], az = a[2];
+    float bx[SL], by[SL], bz[SL];
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+        const int j = min(lane + 64 * sl, S - 1);
+        const float *p = src + (b * S + j) * 3;
+        bx[sl] = p[0]; by[sl] = p[1]; bz[sl] = p[2];
+    }
+    const float aa = (ax * ax + ay * ay) + az * az;
+    uint32_t img[SL];
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+        float d = -2.0f * __builtin_fmaf(az, bz[sl], __builtin_fmaf(ay, by[sl], ax * bx[sl]));
+        d += aa;
+        d += (bx[sl] * bx[sl] + by[sl] * by[sl]) + bz[sl] * bz[sl];
+        const uint32_t bits = __float_as_uint(d);
+        img[sl] = lane + 64 * sl < S ? ((bits & 0x80000000u) ? ~bits : (bits | 0x80000000u)) : 0xFFFFFFFFu;
+    }
+    float myd = 0.0f;
+    int myj = 0;
+    for (int r = 0; r < k; ++r) {
+        uint32_t lm = img[0];
+#pragma unroll
+        for (int sl = 1; sl < SL; ++sl) lm = min(lm, img[sl]);
+        const uint32_t m = wave_min_u32(lm);
+        int wsl = 0, wl = 0;
+        bool found = false;
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) {              // lowest index among equal distances: lowest slot, then lowest lane
+            const unsigned long long mask = __ballot(img[sl] == m);
+            if (!found && mask) { found = true; wsl = sl; wl = __builtin_ctzll(mask); }
+        }
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) if (sl == wsl && lane == wl) img[sl] = 0xFFFFFFFFu;
+        if (lane == r) { myd = __uint_as_float((m & 0x80000000u) ? (m & 0x7FFFFFFFu) : ~m); myj = wl + 64 * wsl; }
+    }
+    if (lane < k) { dist[row * k + lane] = myd; idx[row * k + lane] = (int64_t)myj; }
+}
+
 // ---- inverse-distance interpolation ----------------------------------------------------------------------------------
 // out[row][col0 + c] = sum_{j<k} w_j * feat[b][idx[row][j]][c],  w_j = (1/(d_j+eps)) / sum_j (1/(d_j+eps)),
 // (d, idx) = the first k entries of row `row` of a neighbour table sorted by distance (row stride ld_tab).
@@ -435,6 +489,18 @@ extern "C" int upp_bn_rows_bwd(const float *x, const float *g, const float *mean
         hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, g, mean, rstd, gamma, beta,
                            g_gamma, g_beta, relu, 1.0f / (float)R, g_x, total, C);
     }
+    return upp_launch_status();
+}
+
+extern "C" int upp_sqdist_topk(const float *q, const float *src, float *dist, int64_t *idx, int B, int N, int S, int k, void *stream) {
+    if (!q || !src || !dist || !idx || B < 1 || N < 1 || S < 1 || k < 1) return UPP_E_BADARG;
+    if (S > 256 || k > S || k > 64) return UPP_E_RANGE;
+    const long long rows = (long long)B * N;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (S <= 64) hipLaunchKernelGGL(sqdist_topk_kernel<1>, grid, dim3(256), 0, st, q, src, N, S, k, dist, idx, rows);
+    else if (S <= 128) hipLaunchKernelGGL(sqdist_topk_kernel<2>, grid, dim3(256), 0, st, q, src, N, S, k, dist, idx, rows);
+    else hipLaunchKernelGGL(sqdist_topk_kernel<4>, grid, dim3(256), 0, st, q, src, N, S, k, dist, idx, rows);
     return upp_launch_status();
 }
 

@@ -441,6 +441,11 @@ def bn_rows_train(x, bn, relu=False):
     return _BnRowsTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
 
 
+def sqdist_topk(xyz1, xyz2, k):
+    """The k nearest xyz2 points of every xyz1 point (reference square_distance form), ascending; no autograd."""
+    return ops.sqdist_topk(xyz1.contiguous(), xyz2.contiguous(), k)
+
+
 def interp(dists, idx, feat, k, eps, out=None, col0=0):
     """Inverse-distance interpolation from the k nearest of a sorted neighbour table; no autograd."""
     return ops.interp_fwd(dists, idx, feat.contiguous(), k, eps, out, col0)

@@ -412,6 +412,21 @@ def bn_rows_bwd(x, g, mean, rstd, gamma, beta, relu, want_gx=True):
     return g_x, g_gamma, g_beta
 
 
+def sqdist_topk(q, src, k):
+    """q (B,N,3), src (B,S,3) -> (dist (B,N,k) f32, idx (B,N,k) int64): k nearest by the reference's square_distance form."""
+    _need(q, "q", torch.float32, ndim=3, last=3)
+    _need(src, "src", torch.float32, ndim=3, last=3)
+    _same_device(q, src)
+    B, N, _ = q.shape
+    S = src.shape[1]
+    if src.shape[0] != B:
+        raise RuntimeError("q / src batch sizes differ")
+    dist = torch.empty((B, N, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, N, k), dtype=torch.int64, device=q.device)
+    _call(q.device, "upp_sqdist_topk", _abi.ptr(q), _abi.ptr(src), _abi.ptr(dist), _abi.ptr(idx), B, N, S, int(k))
+    return dist, idx
+
+
 def interp_fwd(dist, idx, feat, k, eps, out=None, col0=0):
     """dist / idx: (B,N,S') views whose last dim is contiguous (a sorted neighbour table); feat (B,S,C)."""
     _need(feat, "feat", torch.float32, ndim=3)

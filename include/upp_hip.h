@@ -267,6 +267,9 @@ int upp_prop_bwd(const float *g_out, const float *pooled, const uint8_t *amax, c
  *                     pre-training): x, g (R,C), mean / rstd from the forward; with xh = (x-mean)*rstd and
  *                     gm = g * [xh*gamma+beta > 0] (relu != 0; gm = g otherwise):  g_beta = sum gm, g_gamma = sum gm*xh,
  *                     g_x = gamma*rstd*(gm - (g_beta + xh*g_gamma)/R).  g_x may be NULL (parameter gradients only).
+ *   upp_sqdist_topk : dist / idx (B,N,k) = the k nearest of the S points src[b] for every query q[b,n], by the reference's
+ *                     square_distance form d = |a|^2 + |b|^2 - 2 a.b (models/modules.py:13-32), ascending (d, index):
+ *                     `square_distance(q, src).sort(dim=-1)` cut to k columns.  S <= 256, k <= min(S, 64).
  *   upp_interp_fwd  : out[b*N+n][col0 .. col0+C) = sum_{j<k} w_j feat[b][idx[b,n,j]],  w_j = (1/(d_j+eps)) / sum_j(1/(d_j+eps)),
  *                     where (dist, idx) (B*N rows, row stride ld_tab, idx int64) is a neighbour table sorted by distance
  *                     (torch.sort of square_distance, as the reference computes it); feat (B,S,C); k <= 16.
@@ -281,6 +284,7 @@ int upp_bn_rows_fwd(const float *x, const float *gamma, const float *beta, float
                     int R, int C, void *stream);
 int upp_bn_rows_bwd(const float *x, const float *g, const float *mean, const float *rstd, const float *gamma, const float *beta,
                     int relu, float *part, float *g_gamma, float *g_beta, float *g_x, int R, int C, void *stream);
+int upp_sqdist_topk(const float *q, const float *src, float *dist, int64_t *idx, int B, int N, int S, int k, void *stream);
 int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, float *out, int ld_out, int col0,
                    int B, int N, int S, int C, int k, float eps, void *stream);
 int upp_interp_bwd(const float *dist, const int64_t *idx, int ld_tab, const float *g_out, int ld_g, int col0, float *g_feat,
