@@ -301,6 +301,25 @@ __global__ __launch_bounds__(256) void sqdist_topk_kernel(const float *__restric
     }
     float myd = 0.0f;
     int myj = 0;
+    if (SL == 1 && k > 4) {
+        // one candidate per lane and many neighbours wanted: a bitonic sort of the 64 (distance image, index) keys across the
+        // lanes (21 compare-exchange stages) is ~3x fewer instructions than k rounds of wave-min + ballot
+        unsigned long long key = ((unsigned long long)img[0] << 32) | (unsigned)lane;
+#pragma unroll
+        for (int k2 = 2; k2 <= 64; k2 <<= 1)
+#pragma unroll
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                const unsigned long long other = __shfl_xor(key, j);
+                const bool take_min = ((lane & k2) == 0) == ((lane & j) == 0);
+                key = take_min ? (other < key ? other : key) : (other > key ? other : key);
+            }
+        const uint32_t m = (uint32_t)(key >> 32);
+        if (lane < k) {
+            dist[row * k + lane] = __uint_as_float((m & 0x80000000u) ? (m & 0x7FFFFFFFu) : ~m);
+            idx[row * k + lane] = (int64_t)(key & 63u);
+        }
+        return;
+    }
     for (int r = 0; r < k; ++r) {
         uint32_t lm = img[0];
 #pragma unroll
