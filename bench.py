@@ -14,8 +14,8 @@ run on the hand-written gfx950 kernels through the C ABI; inputs are resident in
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant hand-written kernel, timed live
-with HIP events on the launch stream),
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant hand-written kernel family of the step by GPU time:
+the patch-embed FP32-MFMA chain behind upp_patch_embed_fwd, timed live with HIP events on the launch stream),
 `kernels` (stand-alone timings of the hand-written kernels against their rooflines; `traffic` = HBM bytes per call from
 the committed rocprofv3 --pmc passes, profiles/r01_pmc_kernels.json), `cpu_baseline` (same step on the host cores with
 the CPU oracle, bounded sample).
@@ -234,6 +234,8 @@ def stage_report(device, B):
     flops = 2.0 * R * (128 * 256 + 256 * 512 + 512 * 384) + 2.0 * (R / 32) * 256 * 512 + 2.0 * R * 3 * 128
     out["patch_embed_chain"] = mfma("upp_patch_embed_fwd: 4 gemm_f32_kernel launches + BN finalize (R=%d)" % R, t, flops,
                                     "whole 7-launch chain; the three big GEMMs alone run at 82/99/106 TFLOP/s (profiles/)")
+    out["patch_embed_chain"]["traffic"] = traffic(["gemm_f32_kernel<2, 21>", "gemm_f32_kernel<0, 14>", "gemm_f32_kernel<0, 5>",
+                                                   "gemm_f32_kernel<1, 17>", "bn_finalize_kernel<0>", "bn_finalize_kernel<1>"])
     tok = torch.randn(B, 65, 384, device=device)
     pos = torch.randn(B, 65, 384, device=device)
     prm = torch.randn(10, 384, device=device)
@@ -398,7 +400,9 @@ def main():
     elif rank == 0:
         clouds = args.batch * world * args.steps
         stages = stage_report(device, args.batch)
-        dom = dict(stages["fps_1228_1024"])               # the single longest hand-written launch of the step
+        # dominant hand-written kernel family of the step by GPU time: the patch-embed MFMA chain (0.82 ms of the 7.7 ms of
+        # kernel time per step; row kernels 0.70, FPS 0.62, attention 0.61 -- DESIGN.md section 5); FPS / kNN are in `kernels`
+        dom = dict(stages["patch_embed_chain"])
         line = {
             "metric": "point-clouds/sec fwd+bwd, UPP/Point-MAE N=1024 G=64 k=32",
             "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
