@@ -382,52 +382,67 @@ __global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ d
 // (row, weight) into LDS with ballots (ascending entry order -> deterministic sums, no atomics), then accumulates the
 // referenced gradient rows; entries are split over 256/Cp thread groups whose partial sums are combined in a fixed order.
 constexpr int kInterpMaxRows = 4096;
+constexpr int kInterpSeg = kInterpMaxRows / 4 + 72;   // hits of one wave's quarter of the entries: at most one per row
 __global__ __launch_bounds__(256) void interp_bwd_kernel(const float *__restrict__ dist, const int64_t *__restrict__ idx, int ld_tab,
                                                          const float *__restrict__ g_out, int ld_g, int col0, int S, int C, int Cp, int k,
                                                          float eps, int N, float *__restrict__ g_feat) {
-    __shared__ int l_row[kInterpMaxRows];
-    __shared__ float l_w[kInterpMaxRows];
-    __shared__ int wave_cnt[4];
+    __shared__ int l_row[4][kInterpSeg];
+    __shared__ float l_w[4][kInterpSeg];
+    __shared__ int cnt[4];
     __shared__ float red[256];
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t base = (size_t)b * N;
     const int E = N * k;
-    int count = 0;
-    for (int e0 = 0; e0 < E; e0 += 256) {
-        const int e = e0 + tid;
-        bool hit = false;
-        int row = 0, j = 0;
-        if (e < E) { row = e / k; j = e - row * k; hit = idx[(base + row) * ld_tab + j] == (int64_t)s; }
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = count;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        if (hit) {
-            const float *dr = dist + (base + row) * ld_tab;
-            float norm = 0.0f, mine = 0.0f;
-            for (int q = 0; q < k; ++q) { const float r = 1.0f / (dr[q] + eps); norm += r; if (q == j) mine = r; }
-            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-            l_row[pos] = row; l_w[pos] = mine / norm;
+    {   // scan: wave w owns the contiguous entry range [w * per, (w+1) * per) and compacts its hits into its own LDS
+        // segment with ballots -- no workgroup barrier inside the loop; four 64-entry chunks of loads in flight
+        const int per = (((E + 3) >> 2) + 63) & ~63;
+        const int e_lo = wave * per, e_hi = min(E, e_lo + per);
+        int c = 0;
+        for (int e0 = e_lo; e0 < e_hi; e0 += 256) {
+            int row[4], j[4];
+            long long id[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = e0 + 64 * t + lane;
+                row[t] = e / k; j[t] = e - row[t] * k;
+                id[t] = e < e_hi ? idx[(base + row[t]) * ld_tab + j[t]] : -1;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool hit = id[t] == (long long)s;
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const float *dr = dist + (base + row[t]) * ld_tab;
+                    float norm = 0.0f, mine = 0.0f;
+                    for (int q = 0; q < k; ++q) { const float r = 1.0f / (dr[q] + eps); norm += r; if (q == j[t]) mine = r; }
+                    const int pos = c + __popcll(m & ((1ull << lane) - 1ull));
+                    l_row[wave][pos] = row[t]; l_w[wave][pos] = mine / norm;
+                }
+                c += __popcll(m);
+            }
         }
-        count += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
+        if (lane == 0) cnt[wave] = c;
     }
+    __syncthreads();
+    const int p1 = cnt[0], p2 = p1 + cnt[1], p3 = p2 + cnt[2], count = p3 + cnt[3];
+    // entry i of the concatenated list (segments in wave order = ascending entry order)
+    auto seg_of = [&](int i, int &w, int &o) { w = (i >= p1) + (i >= p2) + (i >= p3); o = i - (w == 0 ? 0 : (w == 1 ? p1 : (w == 2 ? p2 : p3))); };
     const int cq = tid % Cp, part = tid / Cp, RL = 256 / Cp;
     for (int c0 = 0; c0 < C; c0 += 256) {
         const int c = c0 + cq, cc = min(c, C - 1);
         float acc = 0.0f;
-        for (int i = part; i < count; i += RL * 4) {
-            float v[4], w[4];
+        for (int i = part; i < count; i += RL * 8) {
+            float v[8], w[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int ii = min(i + t * RL, count - 1);
-                w[t] = i + t * RL < count ? l_w[ii] : 0.0f;
-                v[t] = g_out[(base + l_row[ii]) * ld_g + col0 + cc];
+            for (int t = 0; t < 8; ++t) {
+                int sw, so;
+                seg_of(min(i + t * RL, count - 1), sw, so);
+                w[t] = i + t * RL < count ? l_w[sw][so] : 0.0f;
+                v[t] = g_out[(base + l_row[sw][so]) * ld_g + col0 + cc];
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc = __builtin_fmaf(w[t], v[t], acc);
+            for (int t = 0; t < 8; ++t) acc = __builtin_fmaf(w[t], v[t], acc);
         }
         if (RL > 1) {
             red[tid] = acc;
