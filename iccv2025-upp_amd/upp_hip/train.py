@@ -285,6 +285,9 @@ class PipelinedTrainStep(TrainStep):
         self._k = 0
         self._merge = True
         self._g_front = self._g_back = None
+        self._ev_front = [torch.cuda.Event() for _ in range(2)]
+        self._ev_back = [torch.cuda.Event() for _ in range(2)]
+        self._ev_input = torch.cuda.Event()
 
     # -- the three parts of a step -----------------------------------------------------------
     def _front(self, p):
@@ -366,30 +369,59 @@ class PipelinedTrainStep(TrainStep):
         if self._g_front is None:
             self._capture()
         p = self._k & 1
+        cur = torch.cuda.current_stream(self.device)
+        if self._merge:
+            # the two halves share BatchNorm state that the tail folds: keep the strict fork / join per step
+            if pts is not None:
+                self.pts.copy_(pts)
+            self._set_labels(p, labels)
+            self.s_front.wait_stream(cur)
+            with torch.cuda.stream(self.s_front):
+                self._g_front[p].replay()              # batch k: raw -> prompted[p]
+            if self._k > 0:
+                self._g_back[1 - p].replay()           # batch k-1: forward + loss + backward, concurrently
+            cur.wait_stream(self.s_front)
+            if self._k > 0:
+                self._finish(1 - p)
+            self._k += 1
+            return self.loss
+        # Loose coupling: the only edges are the data ones.  front(k) waits for its input copy and for back(k-2), the last
+        # reader of the hand-over buffers of this parity; back(k-1) waits for front(k-1).  The front-end of the next batch
+        # therefore also runs beside the gradient all-reduce and the optimizer of the previous one (nothing they touch is
+        # read by the front-end: checked at construction and by the warm-up), not only beside its back-end.
+        if self._k > 0:
+            cur.wait_event(self._ev_front[1 - p])      # front(k-1) done: its state is complete, and self.pts is free again
         if pts is not None:
             self.pts.copy_(pts)
+        self._set_labels(p, labels)
+        self._ev_input.record(cur)
+        self.s_front.wait_event(self._ev_input)
+        if self._k > 1:
+            self.s_front.wait_event(self._ev_back[p])  # back(k-2) has read state[p]
+        with torch.cuda.stream(self.s_front):
+            self._g_front[p].replay()                  # batch k: raw -> prompted[p]
+            self._ev_front[p].record(self.s_front)
+        if self._k > 0:
+            self._g_back[1 - p].replay()               # batch k-1: forward + loss + backward
+            self._ev_back[1 - p].record(cur)
+            self._finish(1 - p)
+        self._k += 1
+        return self.loss
+
+    def _set_labels(self, p, labels):
         if labels is not None:
             self.labels2[p].copy_(labels)
             self.labels.copy_(labels)
         elif self._k < 2:
             self.labels2[p].copy_(self.labels)
-        cur = torch.cuda.current_stream(self.device)
-        self.s_front.wait_stream(cur)
-        with torch.cuda.stream(self.s_front):
-            self._g_front[p].replay()              # batch k: raw -> prompted[p]
-        if self._k > 0:
-            self._g_back[1 - p].replay()           # batch k-1: forward + loss + backward, concurrently
-        cur.wait_stream(self.s_front)
-        if self._k > 0:
-            self._finish(1 - p)
-        self._k += 1
-        return self.loss
 
     def flush(self):
         """Run the back-end of the batch whose front-end ran last (end of an epoch)."""
         if self._k > 0:
             p = (self._k - 1) & 1
+            torch.cuda.current_stream(self.device).wait_stream(self.s_front)
             self._g_back[p].replay()
             self._finish(p)
+            self.s_front.wait_stream(torch.cuda.current_stream(self.device))
         self._k = 0
         return self.loss
