@@ -226,3 +226,33 @@ def test_sqdist_topk_matches_sorted_square_distance(B, N, S, k):
     a, bb = HF.interp(d, i, feat, k, 1e-4), HF.interp(td, ti, feat, k, 1e-4)
     if clear.any():      # (rows whose k-th neighbour is one of the duplicates may keep either copy: torch.sort is not stable)
         close(a[clear], bb[clear], rtol=2e-4, atol_scale=2e-4)
+
+
+@pytest.mark.parametrize("B,N,S,Cin,mlp,k", [(2, 512, 64, 96, [128, 64], 3), (3, 2048, 128, 1152, [1536, 1024], 3)])
+def test_feature_propagation_commuted_first_layer_equals_the_concat_formulation(B, N, S, Cin, mlp, k):
+    """W.[p1 | interp(x)] + b == W_p.p1 + interp(W_x.x + b): outputs, running statistics and gradients (trainable layer, as
+    in the part-segmentation head) of the commuted form are as close to an f64 evaluation of the reference formulation as
+    the f32 concat formulation is (ReLU gates that flip under rounding make both differ from f64 by the same amount)."""
+    torch.manual_seed(5)
+    dev = 'cuda'
+    xyz1 = torch.rand(B, N, 3, device=dev) * 2 - 1
+    xyz2 = torch.rand(B, S, 3, device=dev) * 2 - 1
+    feat = torch.randn(B, S, Cin, device=dev)
+    g_out = torch.randn(B, N, mlp[-1], device=dev)
+    ref = upp_layers.PointNetFeaturePropagation(Cin + 3, mlp, interpolate_neighbors=k).to(dev).train()
+    res = {}
+    for name, commute, dt in (("f64", False, torch.float64), ("concat", False, torch.float32), ("commuted", True, torch.float32)):
+        m = upp_layers.PointNetFeaturePropagation(Cin + 3, mlp, interpolate_neighbors=k).to(dev).train()
+        m.load_state_dict(ref.state_dict())
+        m = m.to(dt)
+        m.commute_first_layer = commute
+        x = feat.to(dt).clone().requires_grad_(True)
+        out = m(xyz1.to(dt), xyz2.to(dt), xyz1.to(dt), x)
+        (out * g_out.to(dt)).sum().backward()
+        res[name] = [t.detach().double() for t in (out, x.grad, m.mlp_convs[0].weight.grad, m.mlp_bns[0].bias.grad, m.mlp_bns[0].weight.grad,
+                                                   m.mlp_convs[1].weight.grad, m.mlp_bns[0].running_mean, m.mlp_bns[0].running_var)]
+    for r, a, b in zip(res["f64"], res["concat"], res["commuted"]):
+        scale = r.abs().max().item()
+        ea, eb = (a - r).abs(), (b - r).abs()
+        assert eb.max().item() <= 4.0 * ea.max().item() + 1e-5 * scale, (eb.max().item(), ea.max().item(), scale)
+        assert eb.mean().item() <= 3.0 * ea.mean().item() + 1e-6 * scale, (eb.mean().item(), ea.mean().item(), scale)
