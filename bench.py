@@ -79,7 +79,8 @@ class RecipeTrainer:
     """The other training recipes of the reference on the same step driver (secondary workloads, `--workload`):
       pretask  : Point_MAE_pretask_dev + three Chamfer-L1 terms + noise loss (tools/runner_pretask.py:157-247)
       pretrain : Point_MAE masked auto-encoding, Chamfer-L2 on the masked groups (tools/runner_pretrain.py:115-148; 8f-3)
-      seg      : Point_MAE_unify_seg part segmentation, N=2048 label points (BASELINE.json configs[4])"""
+      seg      : Point_MAE_unify_seg part segmentation, N=2048 label points (BASELINE.json configs[4])
+      cls_aux  : the headline step + an auxiliary Chamfer-L1 + EMD reconstruction term (BASELINE.json configs[2] wording)"""
 
     def __init__(self, kind, device, batch, use_graph=True):
         import _seeded
@@ -106,6 +107,27 @@ class RecipeTrainer:
                 return total, terms['recall']
             self.workload = ("Point_MAE_pretask_dev pretask recipe fwd+bwd+AdamW: gt (B,8192,3), partial (B,1024,3)+52 noise pts, "
                              "3 Chamfer-L1 terms incl. (B,2048)x(B,8192), B=%d/GPU" % B)
+        elif kind == 'cls_aux':
+            # BASELINE.json configs[2] names "Chamfer+EMD HIP" next to the classification step, whose own loss is cross-entropy
+            # only: the headline step plus an auxiliary reconstruction term on the tensor the completion prompter
+            # already produces -- ChamferDistanceL1(rebuild_points, gt) as in tools/runner_pretask.py:222 and emd()(rebuild_points,
+            # gt) -- forward and backward (the prompter is frozen in PEFT stage 1, so the gradient stops at rebuild_points).
+            from extensions.chamfer_dist import ChamferDistanceL1
+            from emd import emd
+            model = build_model(device).train()
+            pts = _seeded.noisy_clouds(B, 1024, seed=0).to(device)
+            gt = _seeded.unit_ball_clouds(B, 1024, seed=0).to(device)       # the clean clouds the noisy batch was made from
+            labels = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(0)).to(device)
+            inputs = [pts, labels, gt]
+            cd_l1, emd_loss = ChamferDistanceL1(), emd()
+
+            def loss_fn(m, pts, labels, gt):
+                logits = m(pts, completion_prompt=True, denoise=True, point_num=1024)
+                ce, acc = m.get_loss_acc(logits, labels)
+                rebuild = m.aux['rebuild_points'].detach().requires_grad_(True)
+                return ce + cd_l1(rebuild, gt) + emd_loss(rebuild, gt), acc
+            self.workload = ("Point_MAE_unify cls noisy-train step + auxiliary ChamferDistanceL1 + EMD on rebuild_points (B,1024,3) vs "
+                             "gt (B,1024,3), fwd+bwd+AdamW, B=%d/GPU" % B)
         elif kind == 'pretrain':
             model = build_model_from_cfg(builtin_cfg('pretrain').model).to(device).train()
             inputs = [_seeded.unit_ball_clouds(B, 1024, seed=1).to(device)]
@@ -337,7 +359,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
-    ap.add_argument("--workload", default="cls", choices=["cls", "pretask", "pretrain", "seg"],
+    ap.add_argument("--workload", default="cls", choices=["cls", "cls_aux", "pretask", "pretrain", "seg"],
                     help="cls = the headline workload (default); the others are secondary recipes, see RecipeTrainer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (debug)")

@@ -32,6 +32,7 @@ class PromptedBackbone(nn.Module):
         """vis_base: the group count the visible/masked split is derived from -- hard-wired 64 in the unify models
         (reference Point_MAE_unify.py:404), `num_group` in the pre-task model (Point_MAE_pretask_dev.py:533)."""
         self.config = config
+        self.aux = {}     # by-products of the last forward (not state): 'rebuild_points' of the completion prompter
         tc = config.transformer_config
         self.trans_dim = tc.trans_dim
         self.mask_ratio = tc.mask_ratio
@@ -114,6 +115,7 @@ class PromptedBackbone(nn.Module):
         grouper = Group(num_group=self.vis_num, group_size=16)
         neighborhood, vis_center = grouper(pts)
         _, rebuild = self._reconstruct(self.encoder(neighborhood), vis_center)
+        self.aux['rebuild_points'] = rebuild          # (B, n_masked * group_size, 3): what a reconstruction loss would look at
         sampled, _ = misc.fps(rebuild, point_num // 4)
         pts = torch.cat([pts, sampled], dim=1).contiguous()
         if pts.shape[1] > point_num:

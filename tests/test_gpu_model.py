@@ -58,3 +58,24 @@ def test_train_step_gradients_match_fixture(model, golden):
     for p in model.parameters():
         p.requires_grad_(True)
         p.grad = None
+
+
+def test_auxiliary_reconstruction_losses_on_the_completion_prompters_points(model):
+    """bench.py --workload cls_aux: Chamfer-L1 + EMD on the rebuilt points of the completion prompter, forward and
+    backward (gradient w.r.t. rebuild_points), next to the classification forward."""
+    from extensions.chamfer_dist import ChamferDistanceL1
+    from emd import emd
+    import oracle as O
+    B = 2
+    with torch.no_grad():
+        model(_seeded.noisy_clouds(B, 1024, 0).cuda(), completion_prompt=True, denoise=True, point_num=1024)
+    rb = model.aux['rebuild_points']
+    assert tuple(rb.shape) == (B, 1024, 3)
+    gt = _seeded.unit_ball_clouds(B, 1024, 0).cuda()
+    x = rb.detach().clone().requires_grad_(True)
+    cd = ChamferDistanceL1()(x, gt)
+    em = emd()(x, gt)
+    (cd + em).backward()
+    assert torch.isfinite(x.grad).all() and x.grad.abs().sum().item() > 0
+    d1, d2, _, _ = O.chamfer_fwd(rb.cpu().numpy(), gt.cpu().numpy())
+    np.testing.assert_allclose(cd.item(), (np.sqrt(d1).mean() + np.sqrt(d2).mean()) / 2, rtol=1e-5)
