@@ -82,15 +82,16 @@ class RecipeTrainer:
       seg      : Point_MAE_unify_seg part segmentation, N=2048 label points (BASELINE.json configs[4])
       cls_aux  : the headline step + an auxiliary Chamfer-L1 + EMD reconstruction term (BASELINE.json configs[2] wording)"""
 
-    def __init__(self, kind, device, batch, use_graph=True):
+    def __init__(self, kind, device, batch, use_graph=True, pipeline=False):
         import _seeded
         from models import build_model_from_cfg
         from utils.config import builtin_cfg
         from utils import misc
-        from upp_hip.train import TrainStep, freeze_for_peft
+        from upp_hip.train import TrainStep, PipelinedTrainStep, freeze_for_peft
         torch.manual_seed(0)
         g = torch.Generator(device=device).manual_seed(0)
         B = batch
+        pipe = None        # (front_fn, back_fn, extras, forward_kwargs, back_end_keys) of the front-end / back-end pipelined step
         if kind == 'pretask':
             from models.Point_MAE_pretask_dev import pretask_losses
             model = build_model_from_cfg(builtin_cfg('pretask').model).to(device).train()
@@ -126,6 +127,13 @@ class RecipeTrainer:
                 ce, acc = m.get_loss_acc(logits, labels)
                 rebuild = m.aux['rebuild_points'].detach().requires_grad_(True)
                 return ce + cd_l1(rebuild, gt) + emd_loss(rebuild, gt), acc
+
+            def back_fn(m, state, labels, gt):
+                ce, acc = m.get_loss_acc(m.forward_tokens(*state[:-1]), labels)
+                rebuild = state[-1].detach().requires_grad_(True)
+                return ce + cd_l1(rebuild, gt) + emd_loss(rebuild, gt), acc
+            pipe = (lambda m, x: tuple(m.prompt_tokens(x, True, True, 1024)) + (m.aux['rebuild_points'],), back_fn, [labels, gt],
+                    dict(completion_prompt=True, denoise=True, point_num=1024), None)
             self.workload = ("Point_MAE_unify cls noisy-train step + auxiliary ChamferDistanceL1 + EMD on rebuild_points (B,1024,3) vs "
                              "gt (B,1024,3), fwd+bwd+AdamW, B=%d/GPU" % B)
         elif kind == 'pretrain':
@@ -151,12 +159,25 @@ class RecipeTrainer:
                 logp = m(pts, onehot, label_points=lpts, completion_prompt=True, denoise=True, point_num=1536)
                 loss = m.get_loss(logp.reshape(-1, 50), target)
                 return loss, loss.detach()
+
+            def back_fn(m, state, onehot, lpts, target):
+                loss = m.get_loss(m.forward_tokens(state, onehot, lpts).reshape(-1, 50), target)
+                return loss, loss.detach()
+            pipe = (lambda m, x: m.prompt_tokens(x, True, True, 1536), back_fn, [onehot, lpts, target],
+                    dict(completion_prompt=True, denoise=True, point_num=1536), SEG_PEFT)
             self.workload = ("Point_MAE_unify_seg unify_shapenetpart_seg noisy-train fwd+bwd+AdamW, PEFT, pts (B,1624,3), "
                              "2048 label points, B=%d/GPU" % B)
         else:
             raise ValueError(kind)
         self.model = model
-        self.ts = TrainStep(model, tuple(inputs[0].shape), use_graph=use_graph, loss_fn=loss_fn, inputs=inputs)
+        self.pipelined = bool(pipeline and use_graph and pipe is not None)
+        if self.pipelined:
+            front_fn, back_fn, extras, kw, keys = pipe
+            more = {} if keys is None else {"back_end_keys": tuple(keys)}
+            self.ts = PipelinedTrainStep(model, tuple(inputs[0].shape), forward_kwargs=kw, front_fn=front_fn, back_fn=back_fn, extras=extras, **more)
+            self.ts.pts.copy_(inputs[0])
+        else:
+            self.ts = TrainStep(model, tuple(inputs[0].shape), use_graph=use_graph, loss_fn=loss_fn, inputs=inputs)
 
     def step(self):
         return self.ts.step()
@@ -384,11 +405,12 @@ def main():
         from upp_hip import gemm_tuning
         gemm_tuning.enable()                              # best hipBLASLt / rocBLAS solution per Linear shape (same f32 math)
 
-    pipeline = not args.no_pipeline and not args.no_graph and args.workload == "cls"
+    pipeline = not args.no_pipeline and not args.no_graph and args.workload in ("cls", "cls_aux", "seg")
     if args.workload == "cls":
         tr = Trainer(device, args.batch, distributed, use_graph=not args.no_graph, pipeline=pipeline)
     else:
-        tr = RecipeTrainer(args.workload, device, args.batch, use_graph=not args.no_graph)
+        tr = RecipeTrainer(args.workload, device, args.batch, use_graph=not args.no_graph, pipeline=pipeline)
+        pipeline = tr.pipelined
     if pipeline:
         tr.step()                                         # prime: the first call only runs the front-end of batch 0 (never timed)
     for _ in range(args.warmup):
@@ -418,7 +440,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": tr.workload, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "hip_graph": not args.no_graph, "pipeline": "none"}}))
+                       "hip_graph": not args.no_graph,
+                       "pipeline": "front-end(k+1) || back-end(k) on two streams" if pipeline else "none"}}))
     elif rank == 0:
         clouds = args.batch * world * args.steps
         stages = stage_report(device, args.batch)

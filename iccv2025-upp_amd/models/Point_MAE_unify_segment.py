@@ -69,20 +69,48 @@ class Point_MAE_unify_seg(PromptedBackbone):
             L.end_forward()
 
     def _forward(self, pts, cls_label, label_points=None, completion_prompt=True, denoise=True, point_num=1024, **kwargs):
+        return self._back(self._front(pts, completion_prompt, denoise, point_num), cls_label, label_points)
+
+    # -- front-end / back-end split (upp_hip.train.PipelinedTrainStep): the front-end reads no PEFT-trainable parameter ----
+    def _front(self, pts, completion_prompt, denoise, point_num):
+        """Prompting front-end, grouping and patch embedding of the prompted cloud, positional embedding and the level-2
+        grouping -> (prompted pts, tokens, centres, pos[, centre2, centre1_idx, centre2_idx])."""
         if denoise:
             pts = self._rectify(pts, point_num)
         if completion_prompt:
             pts = self._complete(pts, point_num)
-        B = pts.shape[0]
         neighborhood, center = self.group_divider(pts)
-        tokens = self.encoder(neighborhood)
-        pos = self.pos_embed(center)
+        state = (pts, self.encoder(neighborhood), center, self.pos_embed(center))
+        lvl2 = self._level2(center)
+        if lvl2:
+            state += (lvl2['center2'], lvl2['center1_idx'], lvl2['center2_idx'])
+        return state
+
+    def _back(self, state, cls_label, label_points=None):
+        pts, tokens, center, pos = state[:4]
+        propagation = {}
+        if len(state) >= 7:
+            propagation = dict(center1=center, center1_idx=state[5], center2=state[4], center2_idx=state[6],
+                               gather_idx=self.config.gather_idx, prompt_propagation_after=self.config.prompt_propagation_after)
         pc = self.config.prompter_config
         feats = self.blocks(tokens, pos, path='downstream', downstream_adapter=pc.downstream_adapter,
-                            downstream_prompts=pc.downstream_prompts, classification=False, feature_list=True,
-                            **self._level2(center))
+                            downstream_prompts=pc.downstream_prompts, classification=False, feature_list=True, **propagation)
         x = torch.cat(feats, dim=-1)                                                  # (B,G,1152)
         global_feat = torch.cat((torch.max(x, 1)[0], torch.mean(x, 1), self._label_feature(cls_label)), -1)   # (B,2432)
         target = label_points if label_points is not None else pts
         f0 = self.propagation_0(target, center, target, x)                            # (B,N,1024)
         return self._head(f0, global_feat)
+
+    def prompt_tokens(self, pts, completion_prompt=True, denoise=True, point_num=1024):
+        L.begin_forward(pts.device, self.training)
+        try:
+            return self._front(pts, completion_prompt, denoise, point_num)
+        finally:
+            L.end_forward()
+
+    def forward_tokens(self, state, cls_label, label_points=None):
+        L.begin_forward(state[1].device, self.training)
+        try:
+            return self._back(tuple(state), cls_label, label_points)
+        finally:
+            L.end_forward()

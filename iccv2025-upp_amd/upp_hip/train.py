@@ -253,14 +253,23 @@ class PipelinedTrainStep(TrainStep):
     pipeline; flush() finishes the last batch).  The front graph is captured on its own stream so that library GEMM
     workspaces are not shared between graphs that run concurrently."""
 
-    def __init__(self, model, batch_shape, grad_clip=10.0, forward_kwargs=None, lr=5e-4):
+    def __init__(self, model, batch_shape, grad_clip=10.0, forward_kwargs=None, lr=5e-4, front_fn=None, back_fn=None, extras=None,
+                 back_end_keys=_BACK_END_KEYS):
+        """Other recipes than the classification one: front_fn(model, pts) -> tuple of tensors (the hand-over state; default
+        model.prompt_tokens), back_fn(model, state, *extras) -> (loss, metric) (default: cross-entropy of
+        model.forward_tokens(*state) against extras[0] = labels), extras = example tensors of the per-batch inputs the
+        back-end needs besides the state (labels, targets, ...; one static copy per pipeline slot);
+        back_end_keys = substrings every trainable parameter name must contain one of (the front-end must be frozen)."""
         super().__init__(model, batch_shape, grad_clip=grad_clip, use_graph=True, forward_kwargs=forward_kwargs, lr=lr)
-        if self.device.type != 'cuda' or not hasattr(model, 'prompt_tokens'):
+        if self.device.type != 'cuda' or not (hasattr(model, 'prompt_tokens') or front_fn is not None):
             raise RuntimeError("PipelinedTrainStep needs a HIP device and a model with prompt_tokens() / forward_tokens()")
         names = {id(p): n for n, p in model.named_parameters()}
-        bad = [names[id(p)] for p in self.trainable if not any(k in names[id(p)] for k in _BACK_END_KEYS)]
+        bad = [names[id(p)] for p in self.trainable if not any(k in names[id(p)] for k in back_end_keys)]
         if bad:
             raise RuntimeError("front-end / back-end pipelining needs a frozen front-end; trainable: %s ..." % bad[:3])
+        self.front_fn, self.back_fn = front_fn, back_fn
+        if back_fn is not None and extras is None:
+            raise RuntimeError("back_fn needs extras (example tensors of its per-batch inputs; may be an empty list)")
         if not (self.kw.get('completion_prompt') or self.kw.get('denoise')):
             raise RuntimeError("nothing to pipeline: both prompters are off")
         self.point_num = self.kw.get('point_num', 1024)
@@ -268,11 +277,15 @@ class PipelinedTrainStep(TrainStep):
         B = batch_shape[0]
         with torch.no_grad():       # shapes / dtypes of the hand-over state: one run of the front-end on a random batch
             was = model.training
-            probe = model.eval().prompt_tokens(torch.zeros(batch_shape, device=self.device).uniform_(-1, 1),
-                                               completion_prompt=False, denoise=False, point_num=self.point_num)
+            x0 = torch.zeros(batch_shape, device=self.device).uniform_(-1, 1)
+            if front_fn is not None:
+                probe = front_fn(model.eval(), x0)
+            else:
+                probe = model.eval().prompt_tokens(x0, completion_prompt=False, denoise=False, point_num=self.point_num)
             model.train(was)
         self.state = [[torch.zeros_like(t) for t in probe] for _ in range(2)]
         self.labels2 = [torch.zeros(B, dtype=torch.long, device=self.device) for _ in range(2)]
+        self.extras2 = [[t.detach().clone().to(self.device) for t in (extras or [])] for _ in range(2)]
         self.s_front = torch.cuda.Stream(device=self.device)
         self._bns = [m for m in model.encoder.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats]
         if any(m.momentum is None for m in self._bns):
@@ -292,8 +305,11 @@ class PipelinedTrainStep(TrainStep):
     # -- the three parts of a step -----------------------------------------------------------
     def _front(self, p):
         with torch.no_grad():
-            state = self.model.prompt_tokens(self.pts, completion_prompt=bool(self.kw.get('completion_prompt')),
-                                             denoise=bool(self.kw.get('denoise')), point_num=self.point_num)
+            if self.front_fn is not None:
+                state = self.front_fn(self.model, self.pts)
+            else:
+                state = self.model.prompt_tokens(self.pts, completion_prompt=bool(self.kw.get('completion_prompt')),
+                                                 denoise=bool(self.kw.get('denoise')), point_num=self.point_num)
             torch._foreach_copy_(self.state[p], list(state))      # hand-over buffers of this parity (per-dtype launches)
 
     class _Shadowed:
@@ -317,7 +333,15 @@ class PipelinedTrainStep(TrainStep):
 
     def _back(self, p):
         with PipelinedTrainStep._Shadowed(self):       # (the back-end no longer runs the patch embedding: kept as a guard)
-            self._forward_backward(tuple(self.state[p]), self.labels2[p])
+            if self.back_fn is not None:
+                self.loss_fn = lambda m: self.back_fn(m, tuple(self.state[p]), *self.extras2[p])
+                self.inputs = []
+                try:
+                    self._forward_backward()
+                finally:
+                    self.loss_fn = None
+            else:
+                self._forward_backward(tuple(self.state[p]), self.labels2[p])
 
     def _tail(self):
         self._update()
@@ -365,7 +389,8 @@ class PipelinedTrainStep(TrainStep):
             self.flat.reduce()
         self._g_opt.replay()
 
-    def step(self, pts=None, labels=None):
+    def step(self, pts=None, labels=None, extras=None):
+        """Feed batch k (pts, and labels or -- for a back_fn recipe -- its extras) and run the back-end of batch k-1."""
         if self._g_front is None:
             self._capture()
         p = self._k & 1
@@ -374,7 +399,7 @@ class PipelinedTrainStep(TrainStep):
             # the two halves share BatchNorm state that the tail folds: keep the strict fork / join per step
             if pts is not None:
                 self.pts.copy_(pts)
-            self._set_labels(p, labels)
+            self._set_labels(p, labels, extras)
             self.s_front.wait_stream(cur)
             with torch.cuda.stream(self.s_front):
                 self._g_front[p].replay()              # batch k: raw -> prompted[p]
@@ -393,7 +418,7 @@ class PipelinedTrainStep(TrainStep):
             cur.wait_event(self._ev_front[1 - p])      # front(k-1) done: its state is complete, and self.pts is free again
         if pts is not None:
             self.pts.copy_(pts)
-        self._set_labels(p, labels)
+        self._set_labels(p, labels, extras)
         self._ev_input.record(cur)
         self.s_front.wait_event(self._ev_input)
         if self._k > 1:
@@ -408,7 +433,10 @@ class PipelinedTrainStep(TrainStep):
         self._k += 1
         return self.loss
 
-    def _set_labels(self, p, labels):
+    def _set_labels(self, p, labels, extras=None):
+        if extras is not None:            # (without: the slot keeps what it holds -- the construction-time examples at first)
+            for dst, src in zip(self.extras2[p], extras):
+                dst.copy_(src)
         if labels is not None:
             self.labels2[p].copy_(labels)
             self.labels.copy_(labels)
