@@ -73,9 +73,6 @@ class FlatGradAllReduce:
         """SUM over ranks then divide by world size; no-op without a process group."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        if average and dist.get_backend() == "nccl":
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)      # RCCL averages in the collective: no extra launch
-            return
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         if average:
             self.flat /= dist.get_world_size()
