@@ -18,6 +18,9 @@ from .upp_layers import Group, PointNetFeaturePropagation, PositionalEmbedding, 
 
 class get_loss(nn.Module):
     def forward(self, pred, target):
+        if pred.is_cuda and pred.dim() == 2:
+            # F.nll_loss reduces 65,536 rows in a single workgroup on this stack (0.1 ms); gather + mean is the same number
+            return -pred.gather(1, target.view(-1, 1)).mean()
         return F.nll_loss(pred, target)
 
 

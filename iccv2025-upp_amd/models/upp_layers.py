@@ -740,9 +740,16 @@ class PointNetFeaturePropagation(nn.Module):
         w = conv.weight.view(conv.weight.shape[0], -1)
         C1 = 0 if points1 is None else points1.shape[-1]
         z = F.linear(points2, w[:, C1:], conv.bias)                                         # (B,S,C_out)
-        y = _inverse_distance_interp(xyz1, xyz2, z, self.interpolate_neighbors, 1e-4).reshape(B * N, -1)
-        if C1:
-            y = torch.addmm(y, points1.reshape(B * N, C1), w[:, :C1].t())
+        S, k, Co = xyz2.shape[1], self.interpolate_neighbors, w.shape[0]
+        if (C1 == 3 and z.dtype == torch.float32 and S <= 256 and k <= min(4, S) and Co >= 256 and Co % 4 == 0 and N <= 4096
+                and xyz1.shape[-1] == 3 and _no_grad_needed(xyz1, xyz2, points1)):
+            # one launch: neighbour search; one launch: interpolation of the C_out-wide rows + the rank-3 xyz term
+            dists, idx = HF.sqdist_topk(xyz1, xyz2, k)
+            y = HF.interp_affine_train(dists, idx, z, points1, w[:, :C1].t(), k, 1e-4).reshape(B * N, -1)
+        else:
+            y = _inverse_distance_interp(xyz1, xyz2, z, k, 1e-4).reshape(B * N, -1)
+            if C1:
+                y = torch.addmm(y, points1.reshape(B * N, C1), w[:, :C1].t())
         if self.training and bn.track_running_stats:
             bump_counter(bn.num_batches_tracked)
         x = _bn_rows(y, bn, self.training, relu=True)

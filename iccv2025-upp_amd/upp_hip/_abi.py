@@ -59,6 +59,7 @@ SIGNATURES = {
     "upp_bn_rows_bwd": (_c_i, [_c_f] * 6 + [_c_i] + [_c_f] * 4 + [_c_i] * 2 + [_c_f]),
     "upp_sqdist_topk": (_c_i, [_c_f] * 4 + [_c_i] * 4 + [_c_f]),
     "upp_interp_fwd": (_c_i, [_c_f] * 2 + [_c_i] + [_c_f] * 2 + [_c_i] * 7 + [ctypes.c_float] + [_c_f]),
+    "upp_interp_affine_fwd": (_c_i, [_c_f] * 2 + [_c_i] + [_c_f] * 4 + [_c_i] * 5 + [ctypes.c_float] + [_c_f]),
     "upp_interp_bwd": (_c_i, [_c_f] * 2 + [_c_i] + [_c_f] + [_c_i] * 2 + [_c_f] + [_c_i] * 5 + [ctypes.c_float] + [_c_f]),
     "upp_posenc_fwd": (_c_i, [_c_f, ctypes.POINTER(ctypes.c_float), _c_i, _c_f, _c_i, _c_i, ctypes.c_longlong, _c_f]),
     "upp_prop_part_floats": (ctypes.c_longlong, [_c_i] * 2),

@@ -376,6 +376,64 @@ __global__ __launch_bounds__(256) void interp_kernel(const float *__restrict__ d
     if (col < C) out[(size_t)row * ld_out + col0 + col] = acc;
 }
 
+// Wide rows (C >= 256, C % 4 == 0, k <= 4): one wave per target row walks the row in 1 KB pieces (a float4 per lane), so the
+// k table entries are read once per row instead of once per 256 columns and every gather is a contiguous kilobyte.
+// Optional affine term (the part-segmentation head's commuted first layer, upp_layers._forward_commuted):
+//   out[row][c] += x[row][0] * wt[0][c] + x[row][1] * wt[1][c] + x[row][2] * wt[2][c],   x (rows,3), wt (3,C).
+// Same weights and summation order over the neighbours as interp_kernel.
+__global__ __launch_bounds__(256) void interp_wide_kernel(const float *__restrict__ dist, const int64_t *__restrict__ idx, int ld_tab,
+                                                          const float *__restrict__ feat, int S, int C, int k, float eps,
+                                                          const float *__restrict__ x3, const float *__restrict__ wt,
+                                                          float *__restrict__ out, int ld_out, int col0, int rows, int N) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / N;
+    float d[4];
+    int id[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int jj = min(j, k - 1);
+        d[j] = dist[(size_t)row * ld_tab + jj];
+        id[j] = (int)idx[(size_t)row * ld_tab + jj];
+    }
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    if (x3) { px = x3[(size_t)row * 3 + 0]; py = x3[(size_t)row * 3 + 1]; pz = x3[(size_t)row * 3 + 2]; }
+    float w[4], norm = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { w[j] = j < k ? 1.0f / (d[j] + eps) : 0.0f; norm += w[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = w[j] / norm;
+    const float *f0 = feat + ((size_t)b * S + id[0]) * C, *f1 = feat + ((size_t)b * S + id[1]) * C;
+    const float *f2 = feat + ((size_t)b * S + id[2]) * C, *f3 = feat + ((size_t)b * S + id[3]) * C;
+    float *o = out + (size_t)row * ld_out + col0;
+    for (int c0 = 0; c0 < C; c0 += 512) {          // two pieces per trip: 8 + 6 independent loads in flight
+        const int ca = c0 + lane * 4, cb = ca + 256;
+        const int la = min(ca, C - 4), lb = min(cb, C - 4);
+        const float4 a0 = *reinterpret_cast<const float4 *>(f0 + la), a1 = *reinterpret_cast<const float4 *>(f1 + la);
+        const float4 a2 = *reinterpret_cast<const float4 *>(f2 + la), a3 = *reinterpret_cast<const float4 *>(f3 + la);
+        const float4 b0 = *reinterpret_cast<const float4 *>(f0 + lb), b1 = *reinterpret_cast<const float4 *>(f1 + lb);
+        const float4 b2 = *reinterpret_cast<const float4 *>(f2 + lb), b3 = *reinterpret_cast<const float4 *>(f3 + lb);
+        float4 ra, rb;
+#define UPP_MIX(r, v0, v1, v2, v3, m)  r.m = v0.m * w[0]; r.m += v1.m * w[1]; r.m += v2.m * w[2]; r.m += v3.m * w[3];
+        UPP_MIX(ra, a0, a1, a2, a3, x) UPP_MIX(ra, a0, a1, a2, a3, y) UPP_MIX(ra, a0, a1, a2, a3, z) UPP_MIX(ra, a0, a1, a2, a3, w)
+        UPP_MIX(rb, b0, b1, b2, b3, x) UPP_MIX(rb, b0, b1, b2, b3, y) UPP_MIX(rb, b0, b1, b2, b3, z) UPP_MIX(rb, b0, b1, b2, b3, w)
+#undef UPP_MIX
+        if (x3) {
+            const float4 ua = *reinterpret_cast<const float4 *>(wt + la), va = *reinterpret_cast<const float4 *>(wt + C + la);
+            const float4 ta = *reinterpret_cast<const float4 *>(wt + 2 * (size_t)C + la);
+            const float4 ub = *reinterpret_cast<const float4 *>(wt + lb), vb = *reinterpret_cast<const float4 *>(wt + C + lb);
+            const float4 tb = *reinterpret_cast<const float4 *>(wt + 2 * (size_t)C + lb);
+#define UPP_AFF(r, u, v, t, m)  r.m += (px * u.m + py * v.m) + pz * t.m;
+            UPP_AFF(ra, ua, va, ta, x) UPP_AFF(ra, ua, va, ta, y) UPP_AFF(ra, ua, va, ta, z) UPP_AFF(ra, ua, va, ta, w)
+            UPP_AFF(rb, ub, vb, tb, x) UPP_AFF(rb, ub, vb, tb, y) UPP_AFF(rb, ub, vb, tb, z) UPP_AFF(rb, ub, vb, tb, w)
+#undef UPP_AFF
+        }
+        if (ca < C) *reinterpret_cast<float4 *>(o + ca) = ra;
+        if (cb < C) *reinterpret_cast<float4 *>(o + cb) = rb;
+    }
+}
+
 // Backward of the interpolation w.r.t. the features (the neighbour table is constant):
 //   g_feat[b][s][c] = sum over the (row, j) with idx[row][j] == s of  w_j(row) * g_out[row][col0 + c].
 // One workgroup per (sample, source row s): it scans the sample's N*k table entries in order, compacts the hits
@@ -544,10 +602,25 @@ extern "C" int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab,
         return UPP_E_BADARG;
     if (k > kInterpK || k > S) return UPP_E_RANGE;
     const int Cp = pow2_at_least(C), RL = 256 / Cp, rows = B * N;
+    if (k <= 4 && C >= 256 && C % 4 == 0 && ld_out % 4 == 0 && col0 % 4 == 0 && (((uintptr_t)feat | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(interp_wide_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S, C, k, eps,
+                           (const float *)nullptr, (const float *)nullptr, out, ld_out, col0, rows, N);
+        return upp_launch_status();
+    }
     const dim3 grid((rows + RL - 1) / RL, (C + 255) / 256);
     if (k <= 4) hipLaunchKernelGGL(interp_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S, C, Cp, k, eps, out, ld_out, col0, rows, N);
     else if (k <= 8) hipLaunchKernelGGL(interp_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S, C, Cp, k, eps, out, ld_out, col0, rows, N);
     else hipLaunchKernelGGL(interp_kernel<kInterpK>, grid, dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S, C, Cp, k, eps, out, ld_out, col0, rows, N);
+    return upp_launch_status();
+}
+
+extern "C" int upp_interp_affine_fwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, const float *x3, const float *wt,
+                                     float *out, int B, int N, int S, int C, int k, float eps, void *stream) {
+    if (!dist || !idx || !feat || !x3 || !wt || !out || B < 1 || N < 1 || S < 1 || C < 1 || k < 1 || ld_tab < k) return UPP_E_BADARG;
+    if (k > 4 || k > S || C < 256 || C % 4 != 0 || (((uintptr_t)feat | (uintptr_t)out | (uintptr_t)wt) & 15) != 0) return UPP_E_RANGE;
+    const int rows = B * N;
+    hipLaunchKernelGGL(interp_wide_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, feat, S, C, k, eps, x3, wt,
+                       out, C, 0, rows, N);
     return upp_launch_status();
 }
 

@@ -473,6 +473,31 @@ def interp_train(dists, idx, feat, k, eps):
     return _InterpTrain.apply(dists, idx, feat, k, eps)
 
 
+class _InterpAffine(Function):
+    """interp(feat) + x3 . wt in one launch (upp_interp_affine_fwd); gradients for feat (upp_interp_bwd) and wt (one skinny
+    GEMM); the neighbour table and x3 are constants of the graph."""
+
+    @staticmethod
+    def forward(ctx, dists, idx, feat, x3, wt, k, eps):
+        feat, x3, wt = feat.contiguous(), x3.contiguous(), wt.contiguous()
+        ctx.save_for_backward(dists, idx, x3)
+        ctx.S, ctx.k, ctx.eps = feat.shape[1], k, eps
+        return ops.interp_affine_fwd(dists, idx, feat, x3, wt, k, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        dists, idx, x3 = ctx.saved_tensors
+        g = g.contiguous()
+        g_feat = ops.interp_bwd(dists, idx, g, ctx.S, ctx.k, ctx.eps) if ctx.needs_input_grad[2] else None
+        g_wt = torch.mm(x3.reshape(-1, 3).t(), g.reshape(-1, g.shape[-1])) if ctx.needs_input_grad[4] else None
+        return None, None, g_feat, None, g_wt, None, None
+
+
+def interp_affine_train(dists, idx, feat, x3, wt, k, eps):
+    """Differentiable (w.r.t. feat and wt) interpolation + rank-3 term: (B,N,C) = interp(feat) + x3 (B,N,3) . wt (3,C)."""
+    return _InterpAffine.apply(dists, idx, feat, x3, wt, k, eps)
+
+
 def posenc(x, freqs, out=None, col0=0):
     """(x, sin(f x), cos(f x))_f positional embedding of (...,3) coordinates; no autograd."""
     return ops.posenc_fwd(x.contiguous(), freqs, out, col0)

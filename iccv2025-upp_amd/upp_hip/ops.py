@@ -445,6 +445,24 @@ def interp_fwd(dist, idx, feat, k, eps, out=None, col0=0):
     return out
 
 
+def interp_affine_fwd(dist, idx, feat, x3, wt, k, eps):
+    """interp_fwd into a dense (B,N,C) matrix plus x3 (B,N,3) . wt (3,C); k <= 4, C >= 256, C % 4 == 0."""
+    _need(feat, "feat", torch.float32, ndim=3)
+    _need(x3, "x3", torch.float32, ndim=3, last=3)
+    B, S, C = feat.shape
+    _need(wt, "wt", torch.float32, ndim=2, last=C)
+    N = dist.shape[1]
+    for t, name, dt in ((dist, "dist", torch.float32), (idx, "idx", torch.int64)):
+        if not t.is_cuda or t.dtype != dt or t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != N * t.stride(1):
+            raise RuntimeError(f"{name} must be a HIP {dt} (B,N,S') table with contiguous rows")
+    if dist.stride(1) != idx.stride(1) or dist.shape[:2] != idx.shape[:2] or dist.shape[0] != B or x3.shape[:2] != dist.shape[:2] or wt.shape[0] != 3:
+        raise RuntimeError("dist / idx / x3 / wt shapes do not match")
+    out = torch.empty((B, N, C), dtype=torch.float32, device=feat.device)
+    _call(feat.device, "upp_interp_affine_fwd", _abi.ptr(dist), _abi.ptr(idx), dist.stride(1), _abi.ptr(feat), _abi.ptr(x3), _abi.ptr(wt),
+          _abi.ptr(out), B, N, S, C, int(k), float(eps))
+    return out
+
+
 def interp_bwd(dist, idx, g_out, S, k, eps):
     """Gradient of interp_fwd w.r.t. feat: g_out (B,N,C) -> (B,S,C); dist / idx as in interp_fwd."""
     _need(g_out, "g_out", torch.float32, ndim=3)

@@ -273,6 +273,11 @@ int upp_prop_bwd(const float *g_out, const float *pooled, const uint8_t *amax, c
  *   upp_interp_fwd  : out[b*N+n][col0 .. col0+C) = sum_{j<k} w_j feat[b][idx[b,n,j]],  w_j = (1/(d_j+eps)) / sum_j(1/(d_j+eps)),
  *                     where (dist, idx) (B*N rows, row stride ld_tab, idx int64) is a neighbour table sorted by distance
  *                     (torch.sort of square_distance, as the reference computes it); feat (B,S,C); k <= 16.
+ *   upp_interp_affine_fwd : the same interpolation into a dense (B*N, C) matrix plus a rank-3 term,
+ *                     out[row][c] = sum_j w_j feat[..][c] + x3[row][0] wt[0][c] + x3[row][1] wt[1][c] + x3[row][2] wt[2][c],
+ *                     x3 (B*N,3), wt (3,C): the first 1x1 convolution of PointNetFeaturePropagation (reference
+ *                     models/Point_MAE_pretask_dev.py:463-470) commuted with the interpolation -- feat then holds
+ *                     W_x . points2 + b per source row and wt the xyz columns of the weight.  k <= 4, C >= 256, C % 4 == 0.
  *   upp_interp_bwd  : g_feat (B,S,C) = gradient of the above w.r.t. feat for g_out (B*N rows, row stride ld_g, columns
  *                     [col0, col0+C)); the neighbour table is a constant.  Deterministic (no atomics).  N <= 4096.
  *   upp_posenc_fwd  : out[row][col0 ..) = (x, sin(f_0 x), cos(f_0 x), ..., sin(f_{F-1} x), cos(f_{F-1} x)), x (rows,3);
@@ -287,6 +292,8 @@ int upp_bn_rows_bwd(const float *x, const float *g, const float *mean, const flo
 int upp_sqdist_topk(const float *q, const float *src, float *dist, int64_t *idx, int B, int N, int S, int k, void *stream);
 int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, float *out, int ld_out, int col0,
                    int B, int N, int S, int C, int k, float eps, void *stream);
+int upp_interp_affine_fwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, const float *x3, const float *wt,
+                          float *out, int B, int N, int S, int C, int k, float eps, void *stream);
 int upp_interp_bwd(const float *dist, const int64_t *idx, int ld_tab, const float *g_out, int ld_g, int col0, float *g_feat,
                    int B, int N, int S, int C, int k, float eps, void *stream);
 int upp_posenc_fwd(const float *x, const float *freqs, int F, float *out, int ld_out, int col0, long long rows, void *stream);
