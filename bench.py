@@ -392,10 +392,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank %= max(torch.cuda.device_count(), 1)       # (rehearsals with more ranks than GPUs share a device)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")           # RCCL on ROCm
+        # RCCL ("nccl") over xGMI; UPP_DIST_BACKEND=gloo only to rehearse the N > 1 code path on a one-GPU box
+        dist.init_process_group(backend=os.environ.get("UPP_DIST_BACKEND", "nccl"))
     rank = dist.get_rank() if distributed else 0
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
