@@ -16,26 +16,31 @@
 namespace {
 
 constexpr int kTile = 2048;  // points of the other cloud per LDS tile (32 KiB)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void chamfer_dir_kernel(const float *__restrict__ xyz1, const float *__restrict__ xyz2,
                                                           float *__restrict__ dist, int32_t *__restrict__ idx, int n, int m) {
-    __shared__ float4 tile[kTile];
+    // two points per 32-byte LDS record [x0 x1 y0 y1 z0 z1 - -]: the pair loop runs on packed f32 (v_pk_add / mul / fma_f32:
+    // IEEE per element, the same contracted form per pair), 3 + 3 instead of 6 + 3 VALU instructions per pair
+    __shared__ __attribute__((aligned(16))) float tile[kTile / 2][8];
     __shared__ float cd[4][64];
     __shared__ int ci[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave-uniform wave index: the pair loop's counter, its bounds and the candidate index then live in SGPRs
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     const int j = blockIdx.x * 64 + lane;
     const int jc = j < n ? j : n - 1;
     const float *a = xyz1 + ((size_t)b * n + jc) * 3;
     const float x1 = a[0], y1 = a[1], z1 = a[2];
+    const f32x2 X1 = {x1, x1}, Y1 = {y1, y1}, Z1 = {z1, z1};
     const float *other = xyz2 + (size_t)b * m * 3;
 
     float best = __builtin_inff();
     int besti = 0;
     for (int c0 = 0; c0 < m; c0 += kTile) {
-        const int len = min(kTile, m - c0);
+        const int len = min(kTile, m - c0), len2 = (len + 1) & ~1;
         __syncthreads();
-        for (int i0 = threadIdx.x; i0 < len; i0 += 256 * 4) {   // 12 independent loads in flight per thread
+        for (int i0 = threadIdx.x; i0 < len2; i0 += 256 * 4) {   // 12 independent loads in flight per thread
             float t[4][3];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -44,19 +49,33 @@ __global__ __launch_bounds__(256) void chamfer_dir_kernel(const float *__restric
                 t[q][0] = s[0]; t[q][1] = s[1]; t[q][2] = s[2];
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (i0 + q * 256 < len) tile[i0 + q * 256] = make_float4(t[q][0], t[q][1], t[q][2], 0.0f);
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * 256;
+                if (i < len2) {
+                    const bool real = i < len;            // the odd slot past the end: a point at infinity (d = inf never wins)
+                    float *r = &tile[i >> 1][i & 1];
+                    r[0] = real ? t[q][0] : __builtin_inff(); r[2] = real ? t[q][1] : __builtin_inff(); r[4] = real ? t[q][2] : __builtin_inff();
+                }
+            }
         }
         __syncthreads();
-        const int seg = (len + 3) >> 2;
-        const int k0 = wave * seg;
-        const int k1 = min(len, k0 + seg);
+        const int seg = ((((len2 >> 1) + 3) >> 2));           // pairs per wave
+        const int p0 = wave * seg;
+        const int p1 = min(len2 >> 1, p0 + seg);
 #pragma unroll 4
-        for (int k = k0; k < k1; ++k) {
-            const float4 p = tile[k];
-            const float d = sumsq3(p.x - x1, p.y - y1, p.z - z1);  // x2 = buf - x1; x2*x2 + y2*y2 + z2*z2
-            const bool lt = d < best;
-            besti = lt ? c0 + k : besti;
-            best = lt ? d : best;
+        for (int p = p0; p < p1; ++p) {
+            const float4 xy = *reinterpret_cast<const float4 *>(&tile[p][0]);
+            const float2 zz = *reinterpret_cast<const float2 *>(&tile[p][4]);
+            const f32x2 dx = f32x2{xy.x, xy.y} - X1, dy = f32x2{xy.z, xy.w} - Y1, dz = f32x2{zz.x, zz.y} - Z1;
+            f32x2 d = dy * dy;                                 // sumsq3 per element: t = dy*dy; fma(dx,dx,t); fma(dz,dz,t)
+            d = __builtin_elementwise_fma(dx, dx, d);
+            d = __builtin_elementwise_fma(dz, dz, d);
+            const bool lt0 = d[0] < best;
+            besti = lt0 ? c0 + 2 * p : besti;
+            best = lt0 ? d[0] : best;
+            const bool lt1 = d[1] < best;
+            besti = lt1 ? c0 + 2 * p + 1 : besti;
+            best = lt1 ? d[1] : best;
         }
     }
     cd[wave][lane] = best;
