@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void emd_row_kernel(const float *__restrict__ 
     __shared__ float4 tile[kT];   // x, y, z, remainR
     __shared__ float tr[kT];      // ratioR of the previous level
     __shared__ float part[2][4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
     const int b = blockIdx.y;
     const int k = blockIdx.x * 64 + lane;
     const int kc = k < n ? k : n - 1;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void emd_col_kernel(const float *__restrict__ 
                                                       int B, int n, int m, int it) {
     __shared__ float4 tile[kT];  // x, y, z, ratioL
     __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
     const int b = blockIdx.y;
     const int l = blockIdx.x * 64 + lane;
     const int lc = l < m ? l : m - 1;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void emd_match_kernel(const float *__restrict_
                                                         float *__restrict__ match, int B, int n, int m) {
     __shared__ float4 pt[kMT];
     __shared__ float rr[kLevels][kMT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
     const int b = blockIdx.z;
     const int k = blockIdx.x * 64 + lane;
     const int kc = k < n ? k : n - 1;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void emd_cost_kernel(const float *__restrict__
                                                        const float *__restrict__ match, float *__restrict__ cost, int n, int m) {
     __shared__ float4 tile[kT];
     __shared__ float part[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
     const int b = blockIdx.y;
     const int k = blockIdx.x * 64 + lane;
     const int kc = k < n ? k : n - 1;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void emd_grad1_kernel(const float *__restrict_
                                                         float *__restrict__ grad1, int n, int m) {
     __shared__ float4 tile[kT];
     __shared__ float part[3][4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
     const int b = blockIdx.y;
     const int l = blockIdx.x * 64 + lane;
     const int lc = l < n ? l : n - 1;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void emd_grad1_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void emd_grad2_kernel(const float *__restrict__ gc, const float *__restrict__ xyz1,
                                                         const float *__restrict__ xyz2, const float *__restrict__ match,
                                                         float *__restrict__ grad2, int n, int m) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
     const int b = blockIdx.y;
     const int k = blockIdx.x * 4 + wave;
     if (k >= m) return;
