@@ -337,7 +337,8 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        h = self.drop(self.act(HF.linear(x, self.fc1.weight, self.fc1.bias)))
+        return self.drop(HF.linear(h, self.fc2.weight, self.fc2.bias))
 
 
 class Attention(nn.Module):
@@ -361,7 +362,7 @@ class Attention(nn.Module):
         B, N, C = x.shape
         if self.fusable(x):
             ctx = HF.attention(self.qkv(x), self.num_heads, self.scale)
-            return self.proj_drop(self.proj(ctx))
+            return self.proj_drop(HF.linear(ctx, self.proj.weight, self.proj.bias))
         qkv = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1))

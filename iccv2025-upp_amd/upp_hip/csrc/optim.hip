@@ -100,6 +100,38 @@ __global__ __launch_bounds__(256) void batched_sum_kernel(SumJobs t) {
     t.dst[g][c] = acc;
 }
 
+// Tall jobs (more than kTallRows rows: the bias gradients of trainable Linear layers are column sums of (B L, N) output
+// gradients): 64 columns per workgroup and the four waves split the rows in 16-row chunks (wave w takes chunks w, w+4, ...);
+// the four partial sums are combined in wave order, so the result is deterministic.
+constexpr int kTallRows = 512;
+__global__ __launch_bounds__(256) void batched_sum_tall_kernel(SumJobs t) {
+    __shared__ float part[4][64];
+    int g = 0;
+    while (g + 1 < t.groups && (int)blockIdx.x >= t.wg0[g + 1]) ++g;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = ((int)blockIdx.x - t.wg0[g]) * 64 + lane;
+    const int len = t.len[g];
+    const int cc = min(c, len - 1);
+    float acc = 0.0f;
+    for (int j = t.first[g]; j < t.first[g + 1]; ++j) {
+        const float *src = t.src[j] + cc;
+        const int n = t.n[j], ld = t.ld[j];
+        for (int i0 = wave * 16; i0 < n; i0 += 64) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = src[(size_t)min(i0 + q, n - 1) * ld];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) if (i0 + q < n) acc += v[q];
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < len) {
+        const float s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        t.dst[g][c] = t.acc[g] ? t.dst[g][c] + s : s;
+    }
+}
+
 }  // namespace
 
 extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, const int *ld,
@@ -123,22 +155,38 @@ extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const
             }
     }
     gstart[ngroups] = filled;
-    int g0 = 0;
-    while (g0 < ngroups) {
-        SumJobs t;
-        int g = 0, nj = 0, wg = 0;
-        while (g0 + g < ngroups && g < kMaxSumJobs && nj + (gstart[g0 + g + 1] - gstart[g0 + g]) <= kMaxSumJobs) {
-            const int lo = gstart[g0 + g], hi = gstart[g0 + g + 1], head = order[lo];
-            t.first[g] = nj;
-            for (int q = lo; q < hi; ++q) { const int k = order[q]; t.src[nj] = src[k]; t.n[nj] = n[k]; t.ld[nj] = ld[k]; ++nj; }
-            t.dst[g] = dst[head]; t.len[g] = len[head]; t.acc[g] = accumulate[head]; t.wg0[g] = wg;
-            wg += (len[head] + 255) / 256;
-            ++g;
+    // two passes over the groups: the short ones (<= kTallRows rows per job, 256 columns per workgroup), then the tall ones
+    bool tall[4096];
+    for (int g = 0; g < ngroups; ++g) {
+        tall[g] = false;
+        for (int q = gstart[g]; q < gstart[g + 1]; ++q) tall[g] = tall[g] || n[order[q]] > kTallRows;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        const int cols = pass ? 64 : 256;
+        int g0 = 0;
+        while (g0 < ngroups) {
+            SumJobs t;
+            int g = 0, nj = 0, wg = 0, used = 0;
+            while (g0 + used < ngroups && g < kMaxSumJobs) {
+                const int gi = g0 + used;
+                if (tall[gi] != (pass == 1)) { ++used; continue; }
+                if (nj + (gstart[gi + 1] - gstart[gi]) > kMaxSumJobs) break;
+                const int lo = gstart[gi], hi = gstart[gi + 1], head = order[lo];
+                t.first[g] = nj;
+                for (int q = lo; q < hi; ++q) { const int k = order[q]; t.src[nj] = src[k]; t.n[nj] = n[k]; t.ld[nj] = ld[k]; ++nj; }
+                t.dst[g] = dst[head]; t.len[g] = len[head]; t.acc[g] = accumulate[head]; t.wg0[g] = wg;
+                wg += (len[head] + cols - 1) / cols;
+                ++g; ++used;
+            }
+            if (g == 0) {
+                if (g0 + used >= ngroups) break;             // nothing of this pass left
+                return UPP_E_RANGE;                          // a single destination with more than 64 partial matrices
+            }
+            t.first[g] = nj; t.wg0[g] = wg; t.groups = g;
+            if (pass) hipLaunchKernelGGL(batched_sum_tall_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
+            else hipLaunchKernelGGL(batched_sum_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
+            g0 += used;
         }
-        if (g == 0) return UPP_E_RANGE;                  // a single destination with more than 64 partial matrices
-        t.first[g] = nj; t.wg0[g] = wg; t.groups = g;
-        hipLaunchKernelGGL(batched_sum_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
-        g0 += g;
     }
     return upp_launch_status();
 }

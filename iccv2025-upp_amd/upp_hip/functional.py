@@ -1,5 +1,6 @@
 """Autograd Functions over upp_hip.ops with the reference operators' contracts."""
 import torch
+import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import ops
@@ -302,6 +303,40 @@ class deferred_sums:
         else:
             _DEFERRED.jobs = []
         return False
+
+
+class _LinearDeferredBias(Function):
+    """F.linear for a TRAINABLE layer whose bias gradient -- a column sum over all (B L) rows of the output gradient, one
+    ~12 us torch reduce launch per layer and step -- joins the deferred sums of the backward pass (one launch for all of
+    them); outside a deferred_sums scope it is summed at once.  Data and weight gradients are the two GEMMs autograd's
+    AddmmBackward would issue."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.bias_ptr = b.data_ptr()
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        gx = torch.mm(g2, w).view(x.shape) if ctx.needs_input_grad[0] else None
+        gw = torch.mm(g2.t(), x.reshape(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
+        gb = None
+        if ctx.needs_input_grad[2]:
+            _, gb = _DEFERRED.reduce(ctx.bias_ptr, g2, 0, g2.shape[1])
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """F.linear; a trainable bias on a HIP tensor takes the deferred column sum for its gradient."""
+    if (bias is not None and bias.requires_grad and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+            and weight.dim() == 2 and x.numel() // x.shape[-1] <= 4096):
+        return _LinearDeferredBias.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
 
 
 # ------------------------------------------------------------------ prompt propagation

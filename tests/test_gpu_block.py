@@ -702,3 +702,29 @@ def test_pipelined_step_with_a_recipe_back_end_equals_the_sequential_order():
         if 'num_batches_tracked' in kname or 'running_' in kname and kname.startswith('encoder.'):
             continue                      # (the capture warm-up ran the front-end's BatchNorms two more times)
         close(sd[kname], sd_ref[kname], rtol=1e-4, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize("rows,K,N", [(832, 384, 1536), (2048, 1536, 384), (300, 64, 40)])
+def test_linear_with_a_deferred_bias_gradient_matches_autograd(rows, K, N):
+    """HF.linear: data / weight gradients by the two GEMMs, the bias gradient by the batched column sum of the scope
+    (tall-job kernel above 512 rows), accumulated into the registered buffer -- against torch's addmm backward."""
+    torch.manual_seed(rows + N)
+    x = torch.randn(4, rows // 4, K, device='cuda', requires_grad=True)
+    w = (torch.randn(N, K, device='cuda') * 0.05).requires_grad_(True)
+    b = torch.randn(N, device='cuda', requires_grad=True)
+    g = torch.randn(4, rows // 4, N, device='cuda')
+    ref_out = torch.nn.functional.linear(x, w, b)
+    gx, gw, gb = torch.autograd.grad(ref_out, (x, w, b), g)
+    buf = torch.full((N,), 0.5, device='cuda')                     # accumulated into: starts from a known value
+    with HF.deferred_sums({b.data_ptr(): buf}) as scope:
+        out = HF.linear(x, w, b)
+        hx, hw, hb = torch.autograd.grad(out, (x, w, b), g, allow_unused=True)
+    assert hb is None and b.data_ptr() in scope.routed
+    close(out, ref_out)
+    close(hx, gx, rtol=1e-5)
+    close(hw, gw, rtol=1e-5)
+    close(buf - 0.5, gb, rtol=1e-5, atol_scale=1e-5)
+    # outside a scope: summed at once
+    out = HF.linear(x, w, b)
+    _, _, hb = torch.autograd.grad(out, (x, w, b), g)
+    close(hb, gb, rtol=1e-5, atol_scale=1e-5)
