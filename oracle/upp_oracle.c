@@ -21,10 +21,16 @@
  *        pointnet2_ops 3.0.0 (erikwijmans/Pointnet2_PyTorch, git master, unpinned;
  *                             reference README.md:73)  sampling_gpu.cu
  *        KNN_CUDA 0.2        (unlimblue/KNN_CUDA wheel; reference README.md:76)  knn.cu
- *    Their published algorithms are restated here; the reference holds no test
- *    or golden vector for them ==> "PARITY UNPINNED" for FPS / gather / kNN:
- *    anchored only on the reference call sites utils/misc.py:18-19 and
- *    models/Point_MAE_unify.py:56,69.
+ *    Their published algorithms are restated here.  The reference holds no test
+ *    or golden vector for the operators themselves, but its tree states the same
+ *    algorithms in plain numpy / torch (datasets/ModelNetDataset.py:29-49
+ *    farthest_point_sample, models/Transformer_utils.py:17-29 knn_point); their
+ *    outputs, produced here by oracle/gen_golden_ops.py, are tests/golden/ref_ops.npz
+ *    and pin the FPS index sequence and the kNN neighbour sets on clouds without
+ *    exact ties and without points inside |p|^2 <= 1e-3.  Still "PARITY UNPINNED":
+ *    the CUDA kernels' tie order, the 1e-3 skip rule of FPS, and the order inside a
+ *    KNN_CUDA neighbour list -- anchored only on upstream memory and the reference
+ *    call sites utils/misc.py:18-19 and models/Point_MAE_unify.py:56,69.
  *
  * FLOATING-POINT CONTRACTION.  The CUDA sources are compiled by nvcc with
  * -fmad=true, so  a*a + b*b + c*c  is contracted.  nvcc (NVPTX DAG combiner,

@@ -60,3 +60,12 @@ def noisy_clouds(B, N=1024, seed=0, lidar=48, gauss=24):
     gn = torch.empty(B, gauss, 3).normal_(0., 0.1, generator=g)
     gn = gn + gn / gn.norm(dim=-1, keepdim=True) * 0.9
     return torch.cat([p, lid, gn], dim=1).contiguous()
+
+
+def ref_ops_cases(fixture):
+    """(name, clouds (B,N,3) f32 tensor, M, Q, k) for every case of tests/golden/ref_ops.npz (oracle/gen_golden_ops.py)."""
+    for line in fixture["cases"]:
+        name, seed, B, N, M, Q, k = str(line).split(",")
+        seed, B, N, M, Q, k = int(seed), int(B), int(N), int(M), int(Q), int(k)
+        pts = noisy_clouds(B, 1024, seed=seed) if N == 1096 else unit_ball_clouds(B, N, seed=seed)
+        yield name, pts, M, Q, k

@@ -323,3 +323,17 @@ def test_batched_cropping_equals_the_per_sample_loop():
     assert none is None and full.shape == (B, n, 3)
     padded, _ = misc.seprate_point_cloud(xd, n, crop, padding_zeros=True, incomplete_shape=False, centers=cd)
     assert padded.shape == (B, n, 3) and int((padded.abs().sum(-1) == 0).sum()) >= B * crop
+
+
+def test_fps_and_knn_kernels_reproduce_the_references_own_numpy_and_torch_statements(golden):
+    """The HIP kernels against tests/golden/ref_ops.npz (outputs of the reference's numpy FPS and torch knn_point, see
+    oracle/gen_golden_ops.py): same FPS index sequence, same neighbour sets, neighbours in ascending distance."""
+    g = golden["ref_ops"]
+    for name, pts, M, Q, k in _seeded.ref_ops_cases(g):
+        x = pts.cuda()
+        idx, cen = ops.fps(x, M, want_centers=True)
+        np.testing.assert_array_equal(idx.cpu().numpy(), g[name + "/fps"])
+        if Q:
+            d, nb, _ = ops.knn(x, cen[:, :Q].contiguous(), k, want_dist=True, want_neigh=False)
+            np.testing.assert_array_equal(np.sort(nb.cpu().numpy(), axis=-1), g[name + "/knn"])
+            assert (d[..., 1:] >= d[..., :-1]).all()

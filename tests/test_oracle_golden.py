@@ -168,3 +168,23 @@ def test_gather_and_group_roundtrip():
     _, kidx = O.knn(xyz, out.transpose(0, 2, 1).copy(), 4)
     nb = O.group(xyz, out.transpose(0, 2, 1).copy(), kidx)
     np.testing.assert_array_equal(nb[:, :, 0], 0)     # nearest neighbour of a sampled centre is itself
+
+
+def test_fps_and_knn_reproduce_the_references_own_numpy_and_torch_statements(golden):
+    """tests/golden/ref_ops.npz holds what the reference's plain-numpy farthest_point_sample (datasets/ModelNetDataset.py:29-49,
+    start index 0) and torch knn_point (models/Transformer_utils.py:17-29) return on seeded clouds without exact ties and
+    without points inside the CUDA kernel's |p|^2 <= 1e-3 skip radius: the oracle must give the same index sequence / the
+    same neighbour sets."""
+    import _seeded
+    g = golden["ref_ops"]
+    n = 0
+    for name, pts, M, Q, k in _seeded.ref_ops_cases(g):
+        p = pts.numpy()
+        idx = O.fps(p, M)
+        np.testing.assert_array_equal(idx, g[name + "/fps"])
+        if Q:
+            centers = np.stack([p[b][idx[b, :Q]] for b in range(p.shape[0])])
+            _, nb = O.knn(p, centers, k, want_dist=False)
+            np.testing.assert_array_equal(np.sort(nb, axis=-1), g[name + "/knn"])
+        n += 1
+    assert n == 5
