@@ -187,4 +187,4 @@ def test_fps_and_knn_reproduce_the_references_own_numpy_and_torch_statements(gol
             _, nb = O.knn(p, centers, k, want_dist=False)
             np.testing.assert_array_equal(np.sort(nb, axis=-1), g[name + "/knn"])
         n += 1
-    assert n == 5
+    assert n == 6
