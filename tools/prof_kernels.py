@@ -47,7 +47,13 @@ xyz1, xyz2 = torch.rand(B, 1096, 3, device='cuda'), torch.rand(B, 64, 3, device=
 feat = torch.randn(B, 64, 32, device='cuda')
 ca, cb = _seeded.unit_ball_clouds(B, 1024, seed=5).cuda().requires_grad_(True), _seeded.unit_ball_clouds(B, 1024, seed=6).cuda()
 from models import upp_layers  # noqa: E402
+# the commuted first propagation layer of the part-segmentation head: 1536-wide rows to 65,536 label points + rank-3 term
+lp, cen128 = torch.rand(B, 2048, 3, device='cuda'), torch.rand(B, 128, 3, device='cuda')
+z1536 = torch.randn(B, 128, 1536, device='cuda', requires_grad=True)
+wt3 = torch.randn(3, 1536, device='cuda', requires_grad=True)
+dseg, iseg = HF.sqdist_topk(lp, cen128, 3)
 for _ in range(5):
+    HF.interp_affine_train(dseg, iseg, z1536, lp, wt3, 3, 1e-4).sum().backward()
     index = HF.PropIndex(i1, i2, idx8, w8, B * Lp)
     HF.propagate(X, bn, index, None, 1.0, True).sum().backward()
     HF.adapter(ha, xa_, W1, bb1, W2, bb2, ud, 0.1, 0.7).sum().backward()
