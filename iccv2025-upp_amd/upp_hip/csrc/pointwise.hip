@@ -123,16 +123,28 @@ __global__ __launch_bounds__(64 * kBnWaves) void bn_finalize_rows_kernel(const f
 }
 
 // y = ((x - mean) * rstd) * gamma + beta, optionally max(., 0); 4 consecutive elements per thread
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float *p) {
+    const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float *p, float a, float b, float c, float d) {
+    __builtin_nontemporal_store(v4f_t{a, b, c, d}, reinterpret_cast<v4f_t *>(p));
+}
+constexpr long long kStreamElems = 32ll << 20;   // 128 MB of f32: beyond this a tensor is streamed, not cached
+
 __global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, int relu, float *__restrict__ y,
-                                                            long long total, int C) {
+                                                            long long total, int C, int nt) {
+    // nt: streams larger than the last-level cache (the 65,536-row activations of the per-point heads) are read and written
+    // with non-temporal accesses -- a written-once stream that allocates in L2 costs a third of the HBM write rate
     const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= total) return;
     float v[4];
     int c[4];
     if ((C & 3) == 0) {
-        const float4 t = *reinterpret_cast<const float4 *>(x + i0);
+        const float4 t = nt ? nt_load4(x + i0) : *reinterpret_cast<const float4 *>(x + i0);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         const int cb = (int)(i0 % C);
 #pragma unroll
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float *__restr
         o[q] = ((v[q] - mu[q]) * rs[q]) * ga[q] + be[q];
         if (relu) o[q] = fmaxf(o[q], 0.0f);
     }
-    if ((C & 3) == 0) *reinterpret_cast<float4 *>(y + i0) = make_float4(o[0], o[1], o[2], o[3]);
+    if ((C & 3) == 0) { if (nt) nt_store4(y + i0, o[0], o[1], o[2], o[3]); else *reinterpret_cast<float4 *>(y + i0) = make_float4(o[0], o[1], o[2], o[3]); }
     else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (i0 + q < total) y[i0 + q] = o[q];
@@ -230,13 +242,14 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                 const float *__restrict__ g_gamma, const float *__restrict__ g_beta, int relu,
-                                                                float inv_rows, float *__restrict__ g_x, long long total, int C) {
+                                                                float inv_rows, float *__restrict__ g_x, long long total, int C, int nt) {
     const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= total) return;
     float xv[4], gv[4];
     int c[4];
     if ((C & 3) == 0) {
-        const float4 t = *reinterpret_cast<const float4 *>(x + i0), u = *reinterpret_cast<const float4 *>(g + i0);
+        const float4 t = nt ? nt_load4(x + i0) : *reinterpret_cast<const float4 *>(x + i0);
+        const float4 u = nt ? nt_load4(g + i0) : *reinterpret_cast<const float4 *>(g + i0);
         xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
         gv[0] = u.x; gv[1] = u.y; gv[2] = u.z; gv[3] = u.w;
         const int cb = (int)(i0 % C);
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
         const float gm = (relu && !(xh * ga[q] + be[q] > 0.0f)) ? 0.0f : gv[q];
         o[q] = (ga[q] * rs[q]) * (gm - (gb[q] + xh * gg[q]) * inv_rows);
     }
-    if ((C & 3) == 0) *reinterpret_cast<float4 *>(g_x + i0) = make_float4(o[0], o[1], o[2], o[3]);
+    if ((C & 3) == 0) { if (nt) nt_store4(g_x + i0, o[0], o[1], o[2], o[3]); else *reinterpret_cast<float4 *>(g_x + i0) = make_float4(o[0], o[1], o[2], o[3]); }
     else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (i0 + q < total) g_x[i0 + q] = o[q];
@@ -429,8 +442,9 @@ __global__ __launch_bounds__(256) void interp_wide_kernel(const float *__restric
             UPP_AFF(rb, ub, vb, tb, x) UPP_AFF(rb, ub, vb, tb, y) UPP_AFF(rb, ub, vb, tb, z) UPP_AFF(rb, ub, vb, tb, w)
 #undef UPP_AFF
         }
-        if (ca < C) *reinterpret_cast<float4 *>(o + ca) = ra;
-        if (cb < C) *reinterpret_cast<float4 *>(o + cb) = rb;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        if (ca < C) __builtin_nontemporal_store(v4f{ra.x, ra.y, ra.z, ra.w}, reinterpret_cast<v4f *>(o + ca));
+        if (cb < C) __builtin_nontemporal_store(v4f{rb.x, rb.y, rb.z, rb.w}, reinterpret_cast<v4f *>(o + cb));
     }
 }
 
@@ -448,7 +462,12 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float *__restrict
     __shared__ float l_w[4][kInterpSeg];
     __shared__ int cnt[4];
     __shared__ float red[256];
-    const int b = blockIdx.x / S, s = blockIdx.x - b * S;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so the S workgroups of one sample -- which read the
+    // same gradient rows, k times in total -- would sit on 8 different L2s and fetch every row from memory k times (PMC:
+    // 1.13 GB for 403 MB of gradients).  Give every XCD whole samples instead.
+    int lin = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lin = (lin & 7) * (gridDim.x >> 3) + (lin >> 3);
+    const int b = lin / S, s = lin - b * S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t base = (size_t)b * N;
     const int E = N * k;
@@ -564,7 +583,7 @@ extern "C" int upp_bn_rows_fwd(const float *x, const float *gamma, const float *
     upp_bn_finalize_launch(part, slabs, per, R, C, training, momentum, eps, running_mean, running_var, mean, rstd, st);
     const long long total = (long long)R * C;
     hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y,
-                       total, C);
+                       total, C, total >= kStreamElems ? 1 : 0);
     return upp_launch_status();
 }
 
@@ -579,7 +598,7 @@ extern "C" int upp_bn_rows_bwd(const float *x, const float *g, const float *mean
     if (g_x) {
         const long long total = (long long)R * C;
         hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, g, mean, rstd, gamma, beta,
-                           g_gamma, g_beta, relu, 1.0f / (float)R, g_x, total, C);
+                           g_gamma, g_beta, relu, 1.0f / (float)R, g_x, total, C, total >= kStreamElems ? 1 : 0);
     }
     return upp_launch_status();
 }
