@@ -36,6 +36,7 @@ SIGNATURES = {
     "upp_rowln_fwd": (_c_i, [_c_f] * 3 + [_c_i] * 2 + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 2 + [ctypes.c_float] + [_c_f] * 4
                       + [_c_i] * 4 + [_c_f]),
     "upp_bias_gelu_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_longlong, _c_i, _c_f]),
+    "upp_bias_gelu_fwd_d": (_c_i, [_c_f] * 4 + [ctypes.c_longlong, _c_i, _c_f]),
     "upp_bias_gelu_bwd": (_c_i, [_c_f] * 4 + [ctypes.c_longlong, _c_i, _c_f]),
     "upp_rowln_part_floats": (ctypes.c_longlong, [_c_i] * 5),
     "upp_rowln_bwd": (_c_i, [_c_f] * 6 + [_c_i] + [_c_f] + [ctypes.c_float] + [_c_f] * 4 + [_c_i] * 5 + [_c_f]),

@@ -463,6 +463,21 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const float *__restr
     const float4 bb = *reinterpret_cast<const float4 *>(b + (int)((i * 4) % C));
     reinterpret_cast<float4 *>(h)[i] = make_float4(gelu_val(v.x + bb.x), gelu_val(v.y + bb.y), gelu_val(v.z + bb.z), gelu_val(v.w + bb.w));
 }
+// forward that also leaves d = GELU'(z + b) behind: the backward is then one multiply per element (g_z = g_h * d) instead of
+// a second erf + exp per element (the erf is shared between the value and the derivative here)
+__global__ __launch_bounds__(256) void bias_gelu_fwd_d_kernel(const float *__restrict__ z, const float *__restrict__ b,
+                                                              float *__restrict__ h, float *__restrict__ d, long long total4, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const float4 v = reinterpret_cast<const float4 *>(z)[i];
+    const float4 bb = *reinterpret_cast<const float4 *>(b + (int)((i * 4) % C));
+    const float x[4] = {v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w};
+    float hv[4], dv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { hv[q] = gelu_val(x[q]); dv[q] = gelu_der(x[q]); }
+    reinterpret_cast<float4 *>(h)[i] = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    reinterpret_cast<float4 *>(d)[i] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+}
 __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const float *__restrict__ g_h, const float *__restrict__ z,
                                                             const float *__restrict__ b, float *__restrict__ g_z, long long total4, int C) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -581,6 +596,15 @@ extern "C" int upp_bias_gelu_fwd(const float *z, const float *bias, float *h, lo
     if (C % 4 != 0) return UPP_E_RANGE;
     const long long total4 = rows * C / 4;
     hipLaunchKernelGGL(bias_gelu_fwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, bias, h, total4, C);
+    return upp_launch_status();
+}
+
+extern "C" int upp_bias_gelu_fwd_d(const float *z, const float *bias, float *h, float *d, long long rows, int C, void *stream) {
+    if (!z || !bias || !h || !d || rows < 1 || C < 4) return UPP_E_BADARG;
+    if (C % 4 != 0) return UPP_E_RANGE;
+    const long long total4 = rows * C / 4;
+    hipLaunchKernelGGL(bias_gelu_fwd_d_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, bias, h, d, total4,
+                       C);
     return upp_launch_status();
 }
 

@@ -254,6 +254,15 @@ def bias_gelu_fwd(z, bias):
     return h
 
 
+def bias_gelu_fwd_d(z, bias):
+    """-> (GELU(z + bias), GELU'(z + bias)) in one pass."""
+    _need(z, "z", torch.float32)
+    _need(bias, "bias", torch.float32, ndim=1, last=z.shape[-1])
+    h, d = torch.empty_like(z), torch.empty_like(z)
+    _call(z.device, "upp_bias_gelu_fwd_d", _abi.ptr(z), _abi.ptr(bias), _abi.ptr(h), _abi.ptr(d), z.numel() // z.shape[-1], z.shape[-1])
+    return h, d
+
+
 def bias_gelu_bwd(g_h, z, bias):
     g_z = torch.empty_like(z)
     _call(z.device, "upp_bias_gelu_bwd", _abi.ptr(g_h), _abi.ptr(z), _abi.ptr(bias), _abi.ptr(g_z), z.numel() // z.shape[-1], z.shape[-1])

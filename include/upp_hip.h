@@ -183,6 +183,9 @@ int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const fl
  * g_z = g_h * GELU'(z + bias).  C % 4 == 0. */
 int upp_bias_gelu_fwd(const float *z, const float *bias, float *h, long long rows, int C, void *stream);
 int upp_bias_gelu_bwd(const float *g_h, const float *z, const float *bias, float *g_z, long long rows, int C, void *stream);
+/* upp_bias_gelu_fwd_d: the forward that also stores d = GELU'(z + bias) (rows, C): the backward of a training step is then
+ * g_z = g_h * d, one multiply per element. */
+int upp_bias_gelu_fwd_d(const float *z, const float *bias, float *h, float *d, long long rows, int C, void *stream);
 int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, const float *rstd, float *part,
                       int rows, int D, int chunks, void *stream);
 
