@@ -505,6 +505,40 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float *__restrict
     const int p1 = cnt[0], p2 = p1 + cnt[1], p3 = p2 + cnt[2], count = p3 + cnt[3];
     // entry i of the concatenated list (segments in wave order = ascending entry order)
     auto seg_of = [&](int i, int &w, int &o) { w = (i >= p1) + (i >= p2) + (i >= p3); o = i - (w == 0 ? 0 : (w == 1 ? p1 : (w == 2 ? p2 : p3))); };
+    if (Cp == 256 && C <= 2048) {
+        // wide rows: walk the hits ONCE, row-major (a whole gradient row = C / 256 coalesced kilobyte loads per thread group),
+        // so the k workgroups that read a row do so at about the same point of their ascending lists and share it in L2
+        // (column-chunk-major order re-read every hit row C / 256 times, each time as a separate 1 KB piece).  The sum over
+        // the hits of a column keeps its ascending order.
+        const int nch = (C + 255) >> 8;
+        float acc[8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) acc[ch] = 0.0f;
+        for (int i = 0; i < count; i += 4) {
+            float v[4][8], w[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int sw, so;
+                seg_of(min(i + t, count - 1), sw, so);
+                w[t] = i + t < count ? l_w[sw][so] : 0.0f;
+                const float *gr = g_out + (base + l_row[sw][so]) * ld_g + col0;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch)
+                    if (ch < nch) v[t][ch] = gr[min(ch * 256 + tid, C - 1)];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch)
+                    if (ch < nch) acc[ch] = __builtin_fmaf(w[t], v[t][ch], acc[ch]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const int c = ch * 256 + tid;
+            if (ch < nch && c < C) g_feat[((size_t)b * S + s) * C + c] = acc[ch];
+        }
+        return;
+    }
     const int cq = tid % Cp, part = tid / Cp, RL = 256 / Cp;
     for (int c0 = 0; c0 < C; c0 += 256) {
         const int c = c0 + cq, cc = min(c, C - 1);
