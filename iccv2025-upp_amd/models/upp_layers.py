@@ -361,7 +361,7 @@ class Attention(nn.Module):
     def forward(self, x):
         B, N, C = x.shape
         if self.fusable(x):
-            ctx = HF.attention(self.qkv(x), self.num_heads, self.scale)
+            ctx = HF.attention(HF.linear(x, self.qkv.weight, self.qkv.bias), self.num_heads, self.scale)
             return self.proj_drop(HF.linear(ctx, self.proj.weight, self.proj.bias))
         qkv = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
@@ -512,19 +512,25 @@ class Block(nn.Module):
         n1, n2 = self.norm1, self.norm2
         xa, h1 = HF.rowln(x, add=pos, prompts=prompts, mode=ins, P=P, gamma=n1.weight, beta=n1.bias, eps=n1.eps,
                           cls_add=kw.get('_cls_pos'))
-        # Frozen Linear biases ride along in the row kernels / the GELU kernel: the library GEMMs then run bias-free, which
-        # is 1.5-3 us faster per call at these shapes (and the GELU of the MLP is one of this library's kernels).
+        # The four Linear layers run on upp_linear_f32 (csrc/linear.hip).  Frozen output biases ride along in the row kernel
+        # that consumes the GEMM result (proj.bias, fc2.bias); fc1's bias, the GELU and -- for backward -- GELU' are the
+        # epilogue of the fc1 GEMM, and the fc2 data gradient multiplies by that GELU' in its own epilogue.
         attn, mlp = self.attn, self.mlp
         yb = mb = None
         if _frozen_bias(attn.proj) and attn.proj_drop.p == 0:
-            ctx = HF.attention(attn.qkv(h1), attn.num_heads, attn.scale)
-            y, yb = F.linear(ctx, attn.proj.weight), attn.proj.bias
+            ctx = HF.attention(HF.linear(h1, attn.qkv.weight, attn.qkv.bias), attn.num_heads, attn.scale)
+            y, yb = HF.linear(ctx, attn.proj.weight), attn.proj.bias
         else:
             y = attn(h1)
         x2, h2 = HF.rowln(xa, y=y, ybias=yb, u=None if u is None else u[0], keep=keep, gamma=n2.weight, beta=n2.bias, eps=n2.eps)
-        if _frozen_bias(mlp.fc1) and _frozen_bias(mlp.fc2) and isinstance(mlp.act, nn.GELU) and mlp.fc1.out_features % 4 == 0:
-            hid = HF.bias_gelu(F.linear(h2, mlp.fc1.weight), mlp.fc1.bias)
-            m, mb = F.linear(hid, mlp.fc2.weight), mlp.fc2.bias
+        fc1, fc2 = mlp.fc1, mlp.fc2
+        if (_frozen_bias(fc1) and _frozen_bias(fc2) and isinstance(mlp.act, nn.GELU) and mlp.act.approximate == 'none'
+                and HF.linear_usable(h2, fc1.weight) and fc1.out_features % 32 == 0
+                and _no_grad_needed(fc1.weight, fc2.weight)):
+            m, mb = HF.mlp_gelu(h2, fc1.weight, fc1.bias, fc2.weight), fc2.bias
+        elif _frozen_bias(fc1) and _frozen_bias(fc2) and isinstance(mlp.act, nn.GELU) and fc1.out_features % 4 == 0:
+            hid = HF.bias_gelu(HF.linear(h2, fc1.weight), fc1.bias)
+            m, mb = HF.linear(hid, fc2.weight), fc2.bias
         else:
             m = mlp(h2)
         adapter = getattr(self, f'{path}_adapter') if (path in _PATHS and kw.get(f'{path}_adapter', False)) else None

@@ -1,0 +1,302 @@
+// linear.hip -- the token-matrix Linear layers of the Transformer blocks (reference
+// models/Point_MAE_pretask_dev.py:153-169 Mlp.fc1/fc2, :172-196 Attention.qkv/proj) and their
+// data gradients as ONE exact-f32 MFMA GEMM family for gfx950:
+//
+//     C (M,N) = epilogue( A (M,K) . W (N,K)^T )            v_mfma_f32_32x32x2_f32, k-ordered fma chains
+//
+// These GEMMs have M = B*L = 1,120 ... 2,400 token rows and N, K in {384, 1152, 1536}: 420 ... 3,600 output blocks
+// of 32x32 for the chip's 1,024 SIMDs, i.e. 0.4 ... 3.5 blocks per SIMD.  At that size the decomposition decides
+// the time: every SIMD should own the same small number of blocks, and 2-4 waves must share a SIMD so that the
+// matrix pipe keeps issuing while a wave waits for operands.  Structure:
+//
+//   * ONE 32x32 output block per wave.  A workgroup owns BMB x BNB blocks and, for the narrow-N shapes, splits the
+//     contraction KS ways over wave groups: BMB*BNB*KS <= 16 waves (4 per SIMD).  The host picks (BMB, BNB, KS) per
+//     (M, N, K) so that the workgroups fit the 256 CUs in one round with the fewest blocks per SIMD (pick_config).
+//   * Operands reach the LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write): every wave-instruction
+//     fetches 8 rows x 128 contiguous bytes (whole cache lines -- fragment-shaped loads straight into VGPRs,
+//     32 lines per instruction, were measured TA-bound at ~10 B/clk/CU: 31-45 us where this kernel takes 22-27).
+//     Two stages: the DMA of k-chunk c+1 is issued right after the barrier that opens chunk c.
+//   * Both operands are K-contiguous (nn.Linear stores W as (out, in)) and a sum may run in any order, so a lane
+//     reads its MFMA operands as 16-byte granules (ds_read_b128): lane (h = lane >> 5, r = lane & 31) reads
+//     A[r][8 i + 4 h ... + 3] and four consecutive MFMAs contract k = 8 i + j of the lower lane half with
+//     8 i + 4 + j of the upper one (W alike).  The 16-byte granules of a row are XOR-swizzled with (row >> 1) & 7
+//     -- applied to the SOURCE address of the DMA, whose LDS side is lane-linear -- so that every 16-lane group
+//     of a ds_read_b128 covers all 64 banks.
+//   * K-split partial tiles are summed through the LDS in wave-group order (deterministic); every wave group
+//     finishes a quarter / half of the rows, so the epilogue (bias, exact-erf GELU and its derivative) is spread
+//     over all waves and overlaps the other waves' MFMAs.
+//   * Workgroups are renumbered so that each XCD (own L2) gets a contiguous run of tiles in row-panel order: the
+//     big operand A is fetched by about one XCD per row panel, only the small W is read by all eight.
+//   * Epilogues: bias; bias + GELU, optionally storing GELU' for the backward pass; multiply by a saved GELU'
+//     (the data gradient of fc2 then IS the gradient w.r.t. the fc1 pre-activation).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+enum { LEPI_NONE = 0, LEPI_BIAS = 1, LEPI_BIAS_GELU = 2, LEPI_BIAS_GELU_D = 3, LEPI_MUL = 4 };
+
+struct LinArgs {
+    const float *A; long long lda;
+    const float *W; long long ldw;
+    float *C; long long ldc;
+    const float *bias;            // (N) or null
+    float *aux; long long ldaux;  // LEPI_BIAS_GELU_D: out (M,N) GELU'(z); LEPI_MUL: in (M,N) factor
+    int M, N, K;
+    int tiles_n;                  // workgroup tiles along N
+    int epi;
+};
+
+// GELU(v) = v Phi(v) and GELU'(v) = Phi(v) + v phi(v) from ONE exponential: with x = |v| / sqrt 2 and t = 1 / (1 + p x),
+// erfc(x) = (a1 t + ... + a5 t^5) e^{-x^2} (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7) and phi(v) = e^{-x^2} / sqrt(2 pi).
+// ~20 VALU instructions for both against ~70 for erff + expf: the epilogue of a 16-wave workgroup is VALU time of its SIMDs.
+__device__ __forceinline__ void gelu_pair(float v, float &gelu, float &dgelu) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * x * x);
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float half_erfc = 0.5f * p * t * e;                     // 0.5 erfc(|v| / sqrt 2) = Phi(-|v|)
+    const float cdf = v < 0.0f ? half_erfc : 1.0f - half_erfc;
+    gelu = v * cdf;
+    dgelu = __builtin_fmaf(v * 0.39894228040143267794f, e, cdf);
+}
+
+template <int BMB, int BNB, int KS, int KC>
+__global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g) {
+    constexpr int NW = BMB * BNB * KS, BM = BMB * 32, BN = BNB * 32;
+    constexpr int ROWS = (BM + BN) * KS * KC;       // 128-byte row images per stage: [ks][kc][A rows | W rows]
+    constexpr int STAGE = ROWS * 128;
+    constexpr int T = ROWS / 8;                     // DMA wave-instructions per stage (8 rows each)
+    constexpr int TPW = (T + NW - 1) / NW;
+    constexpr int RED = KS > 1 ? NW * 4096 : 0;
+    constexpr int LDS_BYTES = 2 * STAGE > RED ? 2 * STAGE : RED;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];     // (the only LDS object of the kernel)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    // XCD-aware, bijective renumbering: workgroups b and b + 8 share an XCD; give every XCD a contiguous run of tiles
+    const int nwg = gridDim.x;
+    const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, rem = nwg & 7;
+    const int lin = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (orig >> 3);
+    const int by = lin / g.tiles_n, bx = lin - by * g.tiles_n;      // row-panel order
+    const int m0 = by * BM, n0 = bx * BN;
+    const int M = g.M, N = g.N;
+    const int ks = wave / (BMB * BNB), wb = wave - ks * (BMB * BNB);
+    const int bm = wb / BNB, bn = wb - bm * BNB;
+
+    // ---- DMA sources: instruction t fills row images 8t .. 8t+7; lane -> (row image 8t + lane/8, granule lane%8)
+    const float *src[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * NW;
+        const int rho = (t < T ? t : 0) * 8 + (lane >> 3);
+        const int sk = rho / (BM + BN), rr = rho - sk * (BM + BN);
+        const float *row = rr < BM ? g.A + (long long)min(m0 + rr, M - 1) * g.lda
+                                   : g.W + (long long)min(n0 + rr - BM, N - 1) * g.ldw;
+        src[q] = row + sk * 32 + 4 * ((lane & 7) ^ ((rho >> 1) & 7));
+    }
+    auto issue = [&](int stage, int c) {
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int t = wave + q * NW;
+            if (TPW * NW == T || t < T)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[q] + (long long)c * (32 * KS * KC)),
+                                                 (lds_ptr_t)(lds + stage * STAGE + t * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses: row image of lane's A row / W row, granule (2 i + h) ^ swizzle
+    const int sw = (r >> 1) & 7;
+    const int rowA = (ks * KC * (BM + BN) + bm * 32 + r) * 128, rowW = (ks * KC * (BM + BN) + BM + bn * 32 + r) * 128;
+    int offA[4], offW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { offA[i] = rowA + (((2 * i + h) ^ sw) << 4); offW[i] = rowW + (((2 * i + h) ^ sw) << 4); }
+
+    f32x16 acc;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
+
+    // The fragment reads are inline asm: to hipcc an LDS-DMA is a pending LDS write that any ds_read may alias, so it puts
+    // s_waitcnt vmcnt(0) in front of compiler-visible reads -- which would expose the latency of the DMA just issued
+    // for the NEXT chunk on every iteration.  Ordering is by hand: vmcnt(0) + barrier before a stage is read (above the
+    // DMA issue), counted lgkmcnt before each MFMA group, and every read has been consumed by an MFMA before the barrier
+    // that lets the other waves overwrite its stage.
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    unsigned adrA[4], adrW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { adrA[i] = lds0 + offA[i]; adrW[i] = lds0 + offW[i]; }
+    const int nsc = g.K / (32 * KS * KC);
+    issue(0, 0);
+    for (int c = 0; c < nsc; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk c has landed
+        __builtin_amdgcn_s_barrier();                        // ... everyone's has; and everyone is done reading the other stage
+        if (c + 1 < nsc) issue((c + 1) & 1, c + 1);
+#define UPP_LIN_STEP(N_LEFT, AV, BV)                                                     \
+        asm volatile("s_waitcnt lgkmcnt(" #N_LEFT ")" ::: "memory");                     \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[0], BV[0], acc, 0, 0, 0);          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[1], BV[1], acc, 0, 0, 0);          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[2], BV[2], acc, 0, 0, 0);          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[3], BV[3], acc, 0, 0, 0);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const unsigned so = (c & 1) * STAGE + kc * ((BM + BN) * 128);
+            f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(adrA[0] + so));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b0) : "v"(adrW[0] + so));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(adrA[1] + so));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b1) : "v"(adrW[1] + so));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(a2) : "v"(adrA[2] + so));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b2) : "v"(adrW[2] + so));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(a3) : "v"(adrA[3] + so));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b3) : "v"(adrW[3] + so));
+            UPP_LIN_STEP(6, a0, b0)
+            UPP_LIN_STEP(4, a1, b1)
+            UPP_LIN_STEP(2, a2, b2)
+            UPP_LIN_STEP(0, a3, b3)
+        }
+#undef UPP_LIN_STEP
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- K-split: partial tiles through the LDS, summed in wave-group order; group ks finishes registers [T0, T0 + TN)
+    constexpr int TN = 16 / KS;
+    const int T0 = ks * TN;
+    float outv[TN];
+    if (KS > 1) {
+        __syncthreads();                                     // all fragment reads done: the stages may be overwritten
+        float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) red[(wave * 16 + t) * 64 + lane] = acc[t];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            float s = 0.0f;
+#pragma unroll
+            for (int k2 = 0; k2 < KS; ++k2) s += red[((k2 * (BMB * BNB) + wb) * 16 + T0 + u) * 64 + lane];
+            outv[u] = s;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < TN; ++u) outv[u] = acc[u];
+    }
+
+    // ---- epilogue.  register t of a block = C[row][col]: col = lane & 31, row = (t & 3) + 8 (t >> 2) + 4 (lane >> 5)
+    const int col = n0 + bn * 32 + r;
+    if (col >= N) return;
+    const int epi = g.epi;
+    const float bias = (epi == LEPI_BIAS || epi == LEPI_BIAS_GELU || epi == LEPI_BIAS_GELU_D) ? g.bias[col] : 0.0f;
+    const int rbase = m0 + bm * 32 + 4 * h;
+    float fac[TN];
+    if (epi == LEPI_MUL) {                                   // all factor loads in flight before the first use
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const int t = T0 + u;
+            fac[u] = g.aux[(long long)min(rbase + (t & 3) + 8 * (t >> 2), M - 1) * g.ldaux + col];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int t = T0 + u;
+        const int row = rbase + (t & 3) + 8 * (t >> 2);
+        if (row >= M) continue;
+        float v = outv[u] + bias;
+        if (epi == LEPI_BIAS_GELU || epi == LEPI_BIAS_GELU_D) {
+            float gv, dv;
+            gelu_pair(v, gv, dv);
+            if (epi == LEPI_BIAS_GELU_D) g.aux[(long long)row * g.ldaux + col] = dv;
+            v = gv;
+        } else if (epi == LEPI_MUL) {
+            v *= fac[u];
+        }
+        g.C[(long long)row * g.ldc + col] = v;
+    }
+}
+
+template <int BMB, int BNB, int KS, int KC>
+int launch_linear(const LinArgs &g0, hipStream_t st) {
+    LinArgs g = g0;
+    const int tiles_m = (g.M + BMB * 32 - 1) / (BMB * 32);
+    g.tiles_n = (g.N + BNB * 32 - 1) / (BNB * 32);
+    hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC>), dim3((unsigned)(tiles_m * g.tiles_n)), dim3(BMB * BNB * KS * 64), 0, st, g);
+    return upp_launch_status();
+}
+
+struct LinConfig { int bmb, bnb, ks, kc; };
+#define UPP_LIN_CONFIGS(X) \
+    X(4, 4, 1, 1) X(4, 4, 1, 2) X(3, 4, 1, 1) X(3, 4, 1, 2) X(4, 3, 1, 1) X(4, 3, 1, 2) X(2, 4, 1, 1) X(2, 4, 1, 2) X(4, 2, 1, 1) \
+    X(2, 4, 2, 1) X(2, 3, 2, 1) X(2, 2, 1, 2) X(2, 2, 2, 1) X(2, 2, 2, 2) X(2, 2, 4, 1) X(1, 2, 4, 1) X(1, 2, 2, 2)
+#define UPP_LIN_ENTRY(a, b, c, d) {a, b, c, d},
+constexpr LinConfig kConfigs[] = {UPP_LIN_CONFIGS(UPP_LIN_ENTRY)};
+#undef UPP_LIN_ENTRY
+constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+inline int config_code(const LinConfig &c) { return c.bmb * 4096 + c.bnb * 256 + c.ks * 16 + c.kc; }
+
+// Choice of the decomposition (measured on MI355X, tools/time_linear.py): a workgroup per CU in ONE
+// round beats everything else at these sizes, so among the shapes whose workgroups fit the 256 CUs take the one with the
+// fewest MFMAs per SIMD -- ceil(waves / 4) waves per SIMD, each with 1 / KS of a block --, then the one with more waves per
+// SIMD (they cover each other's barrier and LDS latency), then the measured k-stage width, then fewer idle CUs.  Larger problems
+// (the 65,536-row layers of the segmentation head) run the 128 x 128 tile in several rounds.
+int pick_config(int M, int N, int K) {
+    const int mb = (M + 31) / 32, nb = (N + 31) / 32;
+    int best = -1;
+    long long best_cost = 0;
+    for (int i = 0; i < kNumConfigs; ++i) {
+        const LinConfig c = kConfigs[i];
+        if (K % (32 * c.ks * c.kc) != 0) continue;
+        const long long wgs = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
+        const int waves = c.bmb * c.bnb * c.ks;
+        const long long rounds = (wgs + 255) / 256;
+        const long long quarters = rounds * ((waves + 3) / 4) * (4 / c.ks);                      // quarter blocks per SIMD
+        const long long traffic = 100LL * (c.bmb + c.bnb) / (c.bmb * c.bnb);                    // staged rows per block
+        long long cost;
+        const int kc_pref = (c.bmb == 4 && c.bnb == 4) ? 2 : 1;       // 64-wide stages pay only for the 16-block tile (measured)
+        if (rounds == 1) cost = quarters * 1000000LL + (16 - waves) * 10000LL + (c.kc != kc_pref) * 1000LL + (256 - wgs);
+        else cost = 1000000000LL + quarters * 1000000LL + traffic * 1000LL + (2 - c.kc);
+        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" int upp_linear_tile(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
+    const int i = pick_config(M, N, K);
+    if (i < 0) return UPP_E_RANGE;
+    return config_code(kConfigs[i]);
+}
+
+extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias, float *C, long long ldc,
+                              float *aux, long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream) {
+    if (!A || !W || !C || M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
+    if (K % 32 != 0 || lda % 4 != 0 || ldw % 4 != 0 || lda < K || ldw < K || ldc < N) return UPP_E_RANGE;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return UPP_E_RANGE;
+    if (epilogue < LEPI_NONE || epilogue > LEPI_MUL) return UPP_E_RANGE;
+    if ((epilogue == LEPI_BIAS || epilogue == LEPI_BIAS_GELU || epilogue == LEPI_BIAS_GELU_D) && !bias) return UPP_E_BADARG;
+    if ((epilogue == LEPI_BIAS_GELU_D || epilogue == LEPI_MUL) && (!aux || ldaux < N)) return UPP_E_BADARG;
+    LinArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.bias = bias; g.aux = aux; g.ldaux = ldaux;
+    g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+    hipStream_t st = (hipStream_t)stream;
+    if (tile <= 0) {
+        const int i = pick_config(M, N, K);
+        if (i < 0) return UPP_E_RANGE;
+        tile = config_code(kConfigs[i]);
+    }
+    if (K % (32 * ((tile >> 4) & 15) * (tile & 15)) != 0) return UPP_E_RANGE;
+#define UPP_LIN_CASE(a, b, c, d) case a * 4096 + b * 256 + c * 16 + d: return launch_linear<a, b, c, d>(g, st);
+    switch (tile) {
+        UPP_LIN_CONFIGS(UPP_LIN_CASE)
+        default: return UPP_E_RANGE;
+    }
+#undef UPP_LIN_CASE
+}

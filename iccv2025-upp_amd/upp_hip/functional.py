@@ -1,4 +1,8 @@
 """Autograd Functions over upp_hip.ops with the reference operators' contracts."""
+import os
+import sys
+import weakref
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -305,17 +309,75 @@ class deferred_sums:
         return False
 
 
-class _LinearDeferredBias(Function):
-    """F.linear for a TRAINABLE layer whose bias gradient -- a column sum over all (B L) rows of the output gradient, one
-    ~12 us torch reduce launch per layer and step -- joins the deferred sums of the backward pass (one launch for all of
-    them); outside a deferred_sums scope it is summed at once.  Data and weight gradients are the two GEMMs autograd's
-    AddmmBackward would issue."""
+# ------------------------------------------------------------------ FP32-MFMA Linear (upp_linear_f32)
+_declined = set()
+
+
+def note_declined(what, why):
+    """A fused gfx950 path was not taken: say so ONCE per (site, reason) when UPP_VERBOSE is set -- the torch / library
+    path that runs instead is correct but slower, and nothing else would show it."""
+    key = (what, why)
+    if key in _declined:
+        return
+    _declined.add(key)
+    if os.environ.get("UPP_VERBOSE"):
+        print("[upp_hip] %s: fused path declined (%s); running the torch / library formulation" % (what, why), file=sys.stderr)
+
+
+class _TransposedWeights:
+    """W^T copies of FROZEN weights for the data-gradient GEMMs (dX = dY . W is upp_linear_f32(dY, W^T)).  One copy per
+    weight, made on first use (during the eager warm-up of a captured step) and REFRESHED IN PLACE when the weight's
+    version counter moved (load_state_dict) -- in place, so that HIP graphs that captured the copy's address stay valid;
+    `refresh()` re-copies every entry (call it after loading weights into a model whose step is already captured)."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, w):
+        key = (w.data_ptr(), tuple(w.shape))
+        e = self.entries.get(key)
+        if e is None or e[0]() is None:
+            if len(self.entries) > 1024:
+                self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
+            wt = w.detach().t().contiguous()
+            self.entries[key] = [weakref.ref(w), w._version, wt]
+            return wt
+        if e[1] != w._version and not torch.cuda.is_current_stream_capturing():
+            e[2].copy_(w.detach().t())
+            e[1] = w._version
+        return e[2]
+
+    def refresh(self):
+        for e in self.entries.values():
+            w = e[0]()
+            if w is not None:
+                e[2].copy_(w.detach().t())
+                e[1] = w._version
+
+
+TRANSPOSED = _TransposedWeights()
+
+
+def _wt(w):
+    """W^T (K,N) contiguous: cached for frozen weights, a fresh copy for trainable ones (they change every step)."""
+    return w.detach().t().contiguous() if w.requires_grad else TRANSPOSED.get(w)
+
+
+def linear_usable(x, weight):
+    """upp_linear_f32 serves f32 HIP operands whose contraction length is a multiple of 32."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and weight.is_contiguous()
+            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 32 == 0 and x.numel() > 0)
+
+
+class _LinearMFMA(Function):
+    """x . W^T (+ b) on upp_linear_f32, forward and data gradient.  The weight gradient of a TRAINABLE layer is a library GEMM
+    (not on the PEFT hot path: the Transformer weights are frozen there); a trainable bias takes the deferred column sum."""
 
     @staticmethod
     def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        ctx.bias_ptr = b.data_ptr()
-        return F.linear(x, w, b)
+        ctx.save_for_backward(x if w.requires_grad else None, w)
+        ctx.bias_ptr = b.data_ptr() if b is not None else 0
+        return ops.linear_f32(x, w, b, ops.LIN_BIAS if b is not None else ops.LIN_NONE)
 
     @staticmethod
     def backward(ctx, g):
@@ -323,20 +385,64 @@ class _LinearDeferredBias(Function):
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        gx = torch.mm(g2, w).view(x.shape) if ctx.needs_input_grad[0] else None
-        gw = torch.mm(g2.t(), x.reshape(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
-        gb = None
-        if ctx.needs_input_grad[2]:
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = _wt(w)
+            if wt.shape[1] % 32 == 0:
+                gx = ops.linear_f32(g2, wt).view(g.shape[:-1] + (w.shape[1],))
+            else:
+                note_declined("linear data gradient", "N = %d is not a multiple of 32" % wt.shape[1])
+                gx = torch.mm(g2, w).view(g.shape[:-1] + (w.shape[1],))
+        if ctx.needs_input_grad[1]:
+            gw = torch.mm(g2.t(), x.reshape(-1, x.shape[-1]))
+        if b_needed(ctx):
             _, gb = _DEFERRED.reduce(ctx.bias_ptr, g2, 0, g2.shape[1])
         return gx, gw, gb
 
 
+def b_needed(ctx):
+    return len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]
+
+
 def linear(x, weight, bias=None):
-    """F.linear; a trainable bias on a HIP tensor takes the deferred column sum for its gradient."""
-    if (bias is not None and bias.requires_grad and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
-            and weight.dim() == 2 and x.numel() // x.shape[-1] <= 4096):
-        return _LinearDeferredBias.apply(x, weight, bias)
-    return F.linear(x, weight, bias)
+    """F.linear on the FP32 matrix cores (upp_linear_f32) where the shapes allow; otherwise the library GEMM (said once
+    under UPP_VERBOSE)."""
+    if not linear_usable(x, weight):
+        if x.is_cuda:
+            note_declined("linear %s x %s" % (tuple(x.shape), tuple(weight.shape)), "dtype / layout / K % 32")
+        return F.linear(x, weight, bias)
+    if not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return ops.linear_f32(x, weight, bias, ops.LIN_BIAS if bias is not None else ops.LIN_NONE)
+    return _LinearMFMA.apply(x, weight, bias)
+
+
+class _MlpGelu(Function):
+    """fc2( GELU( fc1(x) + b1 ) ) without the fc2 bias, for FROZEN fc1 / fc2 (reference models/Point_MAE_pretask_dev.py:163-168):
+    two upp_linear_f32 launches forward (the first carries bias + GELU and stores GELU'), two backward (the data gradient
+    of fc2 is multiplied by the saved GELU' in its epilogue, i.e. it IS the gradient at the fc1 pre-activation).
+    The hidden activation is not kept for backward."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2):
+        hid, d = ops.linear_f32(x, w1, b1, ops.LIN_BIAS_GELU_D)
+        ctx.save_for_backward(d, w1, w2)
+        return ops.linear_f32(hid, w2)
+
+    @staticmethod
+    def backward(ctx, g):
+        d, w1, w2 = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        g_z = ops.linear_f32(g2, _wt(w2), None, ops.LIN_MUL, aux=d.view(-1, d.shape[-1]))
+        return ops.linear_f32(g_z, _wt(w1)).view(g.shape[:-1] + (w1.shape[1],)), None, None, None
+
+
+def mlp_gelu(x, w1, b1, w2):
+    """fc2(GELU(fc1(x) + b1)) (no fc2 bias) for frozen weights; both GEMMs and the activation on upp_linear_f32."""
+    if not torch.is_grad_enabled() or not x.requires_grad:
+        return ops.linear_f32(ops.linear_f32(x, w1, b1, ops.LIN_BIAS_GELU), w2)
+    return _MlpGelu.apply(x, w1, b1, w2)
 
 
 # ------------------------------------------------------------------ prompt propagation

@@ -216,6 +216,43 @@ def patch_embed_fwd(point_groups, enc, training):
 
 
 # ------------------------------------------------------------------ Transformer block glue
+LIN_NONE, LIN_BIAS, LIN_BIAS_GELU, LIN_BIAS_GELU_D, LIN_MUL = 0, 1, 2, 3, 4
+
+
+def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
+    """C (M,N) = epilogue(a (M,K) . w (N,K)^T) on the FP32 matrix cores (upp_linear_f32).
+    a: (..., K) f32 whose rows are K-contiguous with one common row stride; w: (N,K).
+    epilogue LIN_BIAS_GELU_D returns (C, GELU'); LIN_MUL multiplies by aux (M,N)."""
+    _need(w, "w", torch.float32, 2)
+    if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.float32):
+        raise RuntimeError("a must be a f32 HIP (cuda) tensor; upp_hip has no CPU path")
+    _same_device(a, w)
+    K = a.shape[-1]
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise RuntimeError(f"linear_f32: a (...,{K}) against w {tuple(w.shape)}")
+    a2 = a.reshape(-1, K)
+    if a2.stride(1) != 1 or a2.stride(0) % 4 != 0:
+        a2 = a2.contiguous()
+    M = a2.shape[0]
+    lead = tuple(a.shape[:-1])
+    if out is None:
+        out = torch.empty(lead + (N,), dtype=torch.float32, device=a.device)
+    d = None
+    if epilogue == LIN_BIAS_GELU_D:
+        d = torch.empty(lead + (N,), dtype=torch.float32, device=a.device)
+        aux = d
+    if epilogue == LIN_MUL:
+        _need(aux, "aux", torch.float32)
+        if aux.numel() != M * N:
+            raise RuntimeError("linear_f32: aux must be (M,N)")
+    if bias is not None:
+        _need(bias, "bias", torch.float32, 1, N)
+    _call(a.device, "upp_linear_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(bias), _abi.ptr(out), N,
+          _abi.ptr(aux), N, M, N, K, int(epilogue), int(tile))
+    return (out, d) if epilogue == LIN_BIAS_GELU_D else out
+
+
 def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want_xo=True, ybias=None):
     B, Lin, D = x.shape
     dev = x.device

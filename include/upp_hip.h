@@ -360,6 +360,28 @@ int upp_adapter_fwd(const float *ha, const float *x, const float *W1, const floa
 int upp_adapter_bwd(const float *g_out, const float *ha, const float *s1, const float *W1, const float *W2, const float *u,
                     float p, float scale, float *g_ha, float *part, int R, int D, int H, void *stream);
 
+/* ---- token-matrix Linear (exact f32 on the matrix cores) -------------------------------------
+ * Replaces the nn.Linear layers of the Transformer blocks and their data gradients: Attention.qkv / .proj
+ * (reference models/Point_MAE_pretask_dev.py:178,181 called :186,:194) and Mlp.fc1 / .fc2 (:158,:160 called
+ * :164-168), i.e. torch.nn.functional.linear -> cuBLAS in the reference.
+ *   C (M,N) = epilogue( A (M,K) . W (N,K)^T )       A, W, C row-major with leading dimensions lda, ldw, ldc (floats)
+ * f32 in, f32 accumulate on v_mfma_f32_32x32x2_f32: every output is a k-ordered chain of fused multiply-adds
+ * (one rounding per product), the order of k being a fixed permutation inside each group of 32.
+ * A data gradient dX = dY . W is the same call with W^T stored row-major: (A = dY, W = W^T (K,N), N <-> K).
+ *   epilogue 0: none                      1: + bias[n]
+ *            2: GELU(. + bias[n])         3: GELU(. + bias[n]), and aux (M,N; ldaux) receives GELU'(. + bias[n])
+ *            4: . * aux[m][n]   (exact erf GELU, as nn.GELU; 3 / 4 make fc1 forward / fc2 data-gradient carry the
+ *               activation and its backward, reference :165 `self.act`)
+ *   tile: 0 = chosen by the library for (M,N,K) (upp_linear_tile returns that choice); else 4096*BMB + 256*BNB + 16*KS + KC
+ *         forces workgroups of BMB x BNB blocks of 32 x 32 (one block per wave), the contraction split KS ways over wave
+ *         groups and 32*KS*KC values of k per LDS stage -- one of the compiled shapes (csrc/linear.hip UPP_LIN_CONFIGS),
+ *         anything else is UPP_E_RANGE; for measurements.
+ * Limits: K % 32 == 0 (K % (32 KS KC) == 0 for a forced tile), lda % 4 == 0, ldw % 4 == 0, A and W 16-byte aligned. */
+int upp_linear_tile(int M, int N, int K);
+int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias,
+                   float *C, long long ldc, float *aux, long long ldaux,
+                   int M, int N, int K, int epilogue, int tile, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,24 @@ def test_cpu_tensors_are_rejected_not_silently_served():
         ChamferDistanceL1()(x, x)
     with pytest.raises((RuntimeError, AssertionError)):
         emd.emd()(x, x)
+
+
+def test_linear_decomposition_choice_is_a_host_function():
+    """upp_linear_tile: one workgroup per CU in one round with the fewest MFMAs per SIMD (csrc/linear.hip pick_config)."""
+    lib = _abi.load()
+
+    def cfg(M, N, K):
+        c = lib.upp_linear_tile(M, N, K)
+        return c >> 12, (c >> 8) & 15, (c >> 4) & 15, c & 15
+
+    for M in (2400, 2080, 2048, 1120, 65536, 1):
+        for N, K in ((1152, 384), (384, 384), (1536, 384), (384, 1536), (384, 1152), (96, 384), (40, 256)):
+            bmb, bnb, ks, kc = cfg(M, N, K)
+            assert 4 <= bmb * bnb * ks <= 16 and K % (32 * ks * kc) == 0
+            wgs = -(-M // (32 * bmb)) * -(-N // (32 * bnb))
+            if M <= 2400:
+                assert wgs <= 256, (M, N, K, wgs)
+    assert cfg(2400, 1536, 384)[:3] == (4, 4, 1)           # 228 workgroups of 16 blocks: 4 per SIMD
+    assert cfg(2048, 1536, 384)[:3] == (4, 3, 1)           # 256 workgroups of 12 blocks: 3 per SIMD
+    assert cfg(2400, 384, 1536)[:3] == (2, 2, 4)           # 228 workgroups, contraction split 4 ways: 1 block per SIMD
+    assert lib.upp_linear_tile(0, 1, 32) == -1 and lib.upp_linear_tile(32, 32, 48) == -2
