@@ -15,7 +15,7 @@
 //   * Operands reach the LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write): every wave-instruction
 //     fetches 8 rows x 128 contiguous bytes (whole cache lines -- fragment-shaped loads straight into VGPRs,
 //     32 lines per instruction, were measured TA-bound at ~10 B/clk/CU: 31-45 us where this kernel takes 22-27).
-//     Two stages: the DMA of k-chunk c+1 is issued right after the barrier that opens chunk c.
+//     Two LDS stages: the DMA of k-stage c+1 is issued behind the barrier that opens k-stage c, between its MFMAs.
 //   * Both operands are K-contiguous (nn.Linear stores W as (out, in)) and a sum may run in any order, so a lane
 //     reads its MFMA operands as 16-byte granules (ds_read_b128): lane (h = lane >> 5, r = lane & 31) reads
 //     A[r][8 i + 4 h ... + 3] and four consecutive MFMAs contract k = 8 i + j of the lower lane half with
@@ -49,7 +49,21 @@ struct LinArgs {
     int M, N, K;
     int tiles_n;                  // workgroup tiles along N
     int epi;
+#ifdef UPP_LIN_STAMPS
+    unsigned long long *stamps;   // diagnostic build only (tools/micro/lin_stamps.py): [workgroup][8] clock readings
+#endif
 };
+
+#ifdef UPP_LIN_STAMPS
+unsigned long long *g_lin_stamps = nullptr;
+#define UPP_STAMP(slot)                                                                                   \
+    if (g.stamps && threadIdx.x == 0) {                                                                   \
+        g.stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();                         \
+        if ((slot) == 0 || (slot) == 3) g.stamps[(size_t)blockIdx.x * 8 + 4 + (slot) / 3] = __builtin_amdgcn_s_memrealtime(); \
+    }
+#else
+#define UPP_STAMP(slot)
+#endif
 
 // GELU(v) = v Phi(v) and GELU'(v) = Phi(v) + v phi(v) from ONE exponential: with x = |v| / sqrt 2 and t = 1 / (1 + p x),
 // erfc(x) = (a1 t + ... + a5 t^5) e^{-x^2} (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7) and phi(v) = e^{-x^2} / sqrt(2 pi).
@@ -68,6 +82,9 @@ __device__ __forceinline__ void gelu_pair(float v, float &gelu, float &dgelu) {
     dgelu = __builtin_fmaf(v * 0.39894228040143267794f, e, cdf);
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <int BMB, int BNB, int KS, int KC>
 __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g) {
     constexpr int NW = BMB * BNB * KS, BM = BMB * 32, BN = BNB * 32;
@@ -77,8 +94,10 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     constexpr int TPW = (T + NW - 1) / NW;
     constexpr int RED = KS > 1 ? NW * 4096 : 0;
     constexpr int LDS_BYTES = 2 * STAGE > RED ? 2 * STAGE : RED;
+    static_assert(LDS_BYTES <= 160 * 1024, "stages exceed the 160 KB of LDS");
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];     // (the only LDS object of the kernel)
 
+    UPP_STAMP(0)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
@@ -92,25 +111,31 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     const int ks = wave / (BMB * BNB), wb = wave - ks * (BMB * BNB);
     const int bm = wb / BNB, bn = wb - bm * BNB;
 
-    // ---- DMA sources: instruction t fills row images 8t .. 8t+7; lane -> (row image 8t + lane/8, granule lane%8)
+    // ---- DMA sources: instruction t fills row images 8t .. 8t+7; lane -> (row image 8t + lane/8, granule lane%8).
+    // Everything that depends on t only (sub-image, A or W, first row) is wave-uniform: scalar code, few VALU instructions.
     const float *src[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int t = wave + q * NW;
-        const int rho = (t < T ? t : 0) * 8 + (lane >> 3);
-        const int sk = rho / (BM + BN), rr = rho - sk * (BM + BN);
-        const float *row = rr < BM ? g.A + (long long)min(m0 + rr, M - 1) * g.lda
-                                   : g.W + (long long)min(n0 + rr - BM, N - 1) * g.ldw;
-        src[q] = row + sk * 32 + 4 * ((lane & 7) ^ ((rho >> 1) & 7));
+        const int rho0 = (t < T ? t : 0) * 8;                         // (scalar) first row image of the instruction
+        const int sk = rho0 / (BM + BN), rr0 = rho0 - sk * (BM + BN);  // (scalar) sub-image, first row in it: 8 | BM, so all 8 rows
+        const bool isA = rr0 < BM;                                     //          of an instruction are on the same side
+        const float *base = isA ? g.A : g.W;
+        const long long ld = isA ? g.lda : g.ldw;
+        const int first = isA ? m0 + rr0 : n0 + rr0 - BM, last = isA ? M - 1 : N - 1;
+        const int row = min(first + (lane >> 3), last);
+        src[q] = base + row * ld + (sk * 32 + 4 * ((lane & 7) ^ (((rho0 >> 1) + (lane >> 4)) & 7)));
     }
+    static_assert(TPW <= 6, "DMA slots of the interleaved schedule");
+    auto issue1 = [&](int q, int stage, int c) {            // q-th DMA instruction of this wave for k-stage c
+        const int t = wave + q * NW;
+        if (TPW * NW == T || t < T)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[q < TPW ? q : 0] + (long long)c * (32 * KS * KC)),
+                                             (lds_ptr_t)(lds + stage * STAGE + t * 1024), 16, 0, 0);
+    };
     auto issue = [&](int stage, int c) {
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            const int t = wave + q * NW;
-            if (TPW * NW == T || t < T)
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[q] + (long long)c * (32 * KS * KC)),
-                                                 (lds_ptr_t)(lds + stage * STAGE + t * 1024), 16, 0, 0);
-        }
+        for (int q = 0; q < TPW; ++q) issue1(q, stage, c);
     };
 
     // ---- fragment addresses: row image of lane's A row / W row, granule (2 i + h) ^ swizzle
@@ -125,48 +150,74 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
 
     // The fragment reads are inline asm: to hipcc an LDS-DMA is a pending LDS write that any ds_read may alias, so it puts
-    // s_waitcnt vmcnt(0) in front of compiler-visible reads -- which would expose the latency of the DMA just issued
-    // for the NEXT chunk on every iteration.  Ordering is by hand: vmcnt(0) + barrier before a stage is read (above the
-    // DMA issue), counted lgkmcnt before each MFMA group, and every read has been consumed by an MFMA before the barrier
-    // that lets the other waves overwrite its stage.
+    // s_waitcnt vmcnt(0) in front of compiler-visible reads -- which would expose the latency of the DMA just issued for a
+    // LATER k-stage on every iteration.  Ordering is by hand (vmcnt / lgkmcnt / barriers below).
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
     unsigned adrA[4], adrW[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { adrA[i] = lds0 + offA[i]; adrW[i] = lds0 + offW[i]; }
     const int nsc = g.K / (32 * KS * KC);
+#define UPP_READ_FRAG(F, SO)                                                          \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(F.a0) : "v"(adrA[0] + (SO)));           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(F.b0) : "v"(adrW[0] + (SO)));           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(F.a1) : "v"(adrA[1] + (SO)));           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(F.b1) : "v"(adrW[1] + (SO)));           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(F.a2) : "v"(adrA[2] + (SO)));           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(F.b2) : "v"(adrW[2] + (SO)));           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(F.a3) : "v"(adrA[3] + (SO)));           \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(F.b3) : "v"(adrW[3] + (SO)));
+#define UPP_MFMA4(AV, BV)                                                             \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[0], BV[0], acc, 0, 0, 0);           \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[1], BV[1], acc, 0, 0, 0);           \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[2], BV[2], acc, 0, 0, 0);           \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[3], BV[3], acc, 0, 0, 0);
+#define UPP_M1(AV, BV) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV, acc, 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+#define UPP_RD1(DST, ADR) asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(ADR));
+#define UPP_LGKM(N_LEFT) asm volatile("s_waitcnt lgkmcnt(" #N_LEFT ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+    struct Frag { f32x4 a0, a1, a2, a3, b0, b1, b2, b3; };
+
+    // Two LDS stages.  Iteration c: "my share of k-stage c has landed" (vmcnt) + barrier -- behind it k-stage c is complete
+    // in the LDS and every wave has finished reading the other stage, which is refilled with k-stage c + 1 while the MFMAs of
+    // k-stage c run.  The DMA instructions go BETWEEN the first MFMAs: issued as one burst behind the barrier they cost every
+    // wave of a SIMD 60-180 issue cycles each at the same moment, with the matrix pipe idle (64 x 64 tiles: 32.3 -> 29.0 us
+    // at K = 1536); the 128 x 128 tile with 64-wide k-stages measured better with the burst (its iterations are twice as long).
+    // Measured and dropped (tools/micro/lin_stamps.py): three / four stages with the DMA two / three k-stages
+    // ahead (no gain: the DMA is not late), and operands of k-stage c + 1 read into a second register set during the MFMAs
+    // of k-stage c (k-loop 82 -> 89 % MFMA duty, but the epilogue then bunches up: same launch time).
     issue(0, 0);
     for (int c = 0; c < nsc; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of chunk c has landed
-        __builtin_amdgcn_s_barrier();                        // ... everyone's has; and everyone is done reading the other stage
-        if (c + 1 < nsc) issue((c + 1) & 1, c + 1);
-#define UPP_LIN_STEP(N_LEFT, AV, BV)                                                     \
-        asm volatile("s_waitcnt lgkmcnt(" #N_LEFT ")" ::: "memory");                     \
-        __builtin_amdgcn_sched_barrier(0);                                               \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[0], BV[0], acc, 0, 0, 0);          \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[1], BV[1], acc, 0, 0, 0);          \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[2], BV[2], acc, 0, 0, 0);          \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[3], BV[3], acc, 0, 0, 0);
+        wait_vmcnt<0>();                                 // this wave's share of k-stage c has landed
+        __builtin_amdgcn_s_barrier();                    // ... everyone's has; and everyone is done reading the other stage
+        const bool fill = c + 1 < nsc;
+        const int fst = (c + 1) & 1;
+        if (KC == 2 && fill) issue(fst, c + 1);
+        if (c == 0) { UPP_STAMP(1) }
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             const unsigned so = (c & 1) * STAGE + kc * ((BM + BN) * 128);
-            f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(adrA[0] + so));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(b0) : "v"(adrW[0] + so));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(adrA[1] + so));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(b1) : "v"(adrW[1] + so));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(a2) : "v"(adrA[2] + so));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(b2) : "v"(adrW[2] + so));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(a3) : "v"(adrA[3] + so));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(b3) : "v"(adrW[3] + so));
-            UPP_LIN_STEP(6, a0, b0)
-            UPP_LIN_STEP(4, a1, b1)
-            UPP_LIN_STEP(2, a2, b2)
-            UPP_LIN_STEP(0, a3, b3)
+            Frag f;
+            UPP_READ_FRAG(f, so)
+            UPP_LGKM(6)
+            UPP_M1(f.a0[0], f.b0[0]) if (KC == 1 && fill) issue1(0, fst, c + 1);
+            UPP_M1(f.a0[1], f.b0[1]) if (KC == 1 && fill && TPW > 1) issue1(1, fst, c + 1);
+            UPP_M1(f.a0[2], f.b0[2]) if (KC == 1 && fill && TPW > 2) issue1(2, fst, c + 1);
+            UPP_M1(f.a0[3], f.b0[3]) if (KC == 1 && fill && TPW > 3) issue1(3, fst, c + 1);
+            UPP_LGKM(4)
+            UPP_M1(f.a1[0], f.b1[0]) if (KC == 1 && fill && TPW > 4) issue1(4, fst, c + 1);
+            UPP_M1(f.a1[1], f.b1[1]) if (KC == 1 && fill && TPW > 5) issue1(5, fst, c + 1);
+            UPP_M1(f.a1[2], f.b1[2]) UPP_M1(f.a1[3], f.b1[3])
+            UPP_LGKM(2) UPP_MFMA4(f.a2, f.b2)
+            UPP_LGKM(0) UPP_MFMA4(f.a3, f.b3)
         }
-#undef UPP_LIN_STEP
         __builtin_amdgcn_sched_barrier(0);
     }
+#undef UPP_READ_FRAG
+#undef UPP_MFMA4
+#undef UPP_LGKM
+#undef UPP_M1
+#undef UPP_RD1
 
+    UPP_STAMP(2)
     // ---- K-split: partial tiles through the LDS, summed in wave-group order; group ks finishes registers [T0, T0 + TN)
     constexpr int TN = 16 / KS;
     const int T0 = ks * TN;
@@ -189,36 +240,53 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
         for (int u = 0; u < TN; ++u) outv[u] = acc[u];
     }
 
-    // ---- epilogue.  register t of a block = C[row][col]: col = lane & 31, row = (t & 3) + 8 (t >> 2) + 4 (lane >> 5)
-    const int col = n0 + bn * 32 + r;
-    if (col >= N) return;
-    const int epi = g.epi;
-    const float bias = (epi == LEPI_BIAS || epi == LEPI_BIAS_GELU || epi == LEPI_BIAS_GELU_D) ? g.bias[col] : 0.0f;
-    const int rbase = m0 + bm * 32 + 4 * h;
-    float fac[TN];
-    if (epi == LEPI_MUL) {                                   // all factor loads in flight before the first use
+    // ---- epilogue.  register t of a block = C[row][col]: col = lane & 31, row = (t & 3) + 8 (t >> 2) + 4 (lane >> 5).
+    // Written for instruction COUNT: 16 waves share the CU's four issue ports, a wave's epilogue runs beside the other waves'
+    // last MFMAs, and the first version (one runtime switch and 64-bit address arithmetic per element: ~1,000 instructions
+    // per wave) took 3.8 us of the 31 us fc1 launch WITHOUT its stores.  Now: a wave-uniform block base (scalar), one 32-bit
+    // lane offset, a switch outside the element loop, and per-element guards only on edge tiles.
+    const int rb = m0 + bm * 32, cb = n0 + bn * 32;                         // (scalar) block origin
+    const bool full = rb + 32 <= M && cb + 32 <= N;                          // (scalar)
+    const int ldc = (int)g.ldc, ldx = (int)g.ldaux;
+    float *cblk = g.C + (long long)rb * g.ldc + cb;
+    float *xblk = g.aux ? g.aux + (long long)rb * g.ldaux + cb : nullptr;
+    const int row_l = 4 * h, lc = row_l * ldc + r, lx = row_l * ldx + r;     // lane offsets inside the block
+    const bool col_ok = cb + r < N;
+    const float bias = (g.epi == LEPI_BIAS || g.epi == LEPI_BIAS_GELU || g.epi == LEPI_BIAS_GELU_D) ? g.bias[min(cb + r, N - 1)] : 0.0f;
+#define UPP_ROWOF(u) (((T0 + (u)) & 3) + 8 * ((T0 + (u)) >> 2))
+#define UPP_EPI_LOOP(...)                                                                  \
+    if (full) {                                                                             \
+        _Pragma("unroll") for (int u = 0; u < TN; ++u) { const int rr = UPP_ROWOF(u); __VA_ARGS__ } \
+    } else {                                                                                \
+        _Pragma("unroll") for (int u = 0; u < TN; ++u) {                                    \
+            const int rr = UPP_ROWOF(u);                                                    \
+            if (col_ok && rb + row_l + rr < M) { __VA_ARGS__ }                                     \
+        }                                                                                   \
+    }
+    switch (g.epi) {
+        case LEPI_NONE:
+        case LEPI_BIAS:
+            UPP_EPI_LOOP(cblk[lc + rr * ldc] = outv[u] + bias;)
+            break;
+        case LEPI_BIAS_GELU:
+            UPP_EPI_LOOP(float gv, dv; gelu_pair(outv[u] + bias, gv, dv); cblk[lc + rr * ldc] = gv;)
+            break;
+        case LEPI_BIAS_GELU_D:
+            UPP_EPI_LOOP(float gv, dv; gelu_pair(outv[u] + bias, gv, dv); cblk[lc + rr * ldc] = gv; xblk[lx + rr * ldx] = dv;)
+            break;
+        default: {                                               // LEPI_MUL: all factor loads in flight before the first use
+            float fac[TN];
 #pragma unroll
-        for (int u = 0; u < TN; ++u) {
-            const int t = T0 + u;
-            fac[u] = g.aux[(long long)min(rbase + (t & 3) + 8 * (t >> 2), M - 1) * g.ldaux + col];
+            for (int u = 0; u < TN; ++u) {
+                const int rr = UPP_ROWOF(u);
+                fac[u] = (full || (col_ok && rb + row_l + rr < M)) ? xblk[lx + rr * ldx] : 0.0f;
+            }
+            UPP_EPI_LOOP(cblk[lc + rr * ldc] = outv[u] * fac[u];)
         }
     }
-#pragma unroll
-    for (int u = 0; u < TN; ++u) {
-        const int t = T0 + u;
-        const int row = rbase + (t & 3) + 8 * (t >> 2);
-        if (row >= M) continue;
-        float v = outv[u] + bias;
-        if (epi == LEPI_BIAS_GELU || epi == LEPI_BIAS_GELU_D) {
-            float gv, dv;
-            gelu_pair(v, gv, dv);
-            if (epi == LEPI_BIAS_GELU_D) g.aux[(long long)row * g.ldaux + col] = dv;
-            v = gv;
-        } else if (epi == LEPI_MUL) {
-            v *= fac[u];
-        }
-        g.C[(long long)row * g.ldc + col] = v;
-    }
+#undef UPP_EPI_LOOP
+#undef UPP_ROWOF
+    UPP_STAMP(3)
 }
 
 template <int BMB, int BNB, int KS, int KC>
@@ -231,9 +299,7 @@ int launch_linear(const LinArgs &g0, hipStream_t st) {
 }
 
 struct LinConfig { int bmb, bnb, ks, kc; };
-#define UPP_LIN_CONFIGS(X) \
-    X(4, 4, 1, 1) X(4, 4, 1, 2) X(3, 4, 1, 1) X(3, 4, 1, 2) X(4, 3, 1, 1) X(4, 3, 1, 2) X(2, 4, 1, 1) X(2, 4, 1, 2) X(4, 2, 1, 1) \
-    X(2, 4, 2, 1) X(2, 3, 2, 1) X(2, 2, 1, 2) X(2, 2, 2, 1) X(2, 2, 2, 2) X(2, 2, 4, 1) X(1, 2, 4, 1) X(1, 2, 2, 2)
+#define UPP_LIN_CONFIGS(X) X(4, 4, 1, 2) X(4, 3, 1, 1) X(3, 4, 1, 1) X(2, 4, 2, 1) X(2, 3, 2, 1) X(2, 2, 4, 1) X(1, 2, 4, 1)
 #define UPP_LIN_ENTRY(a, b, c, d) {a, b, c, d},
 constexpr LinConfig kConfigs[] = {UPP_LIN_CONFIGS(UPP_LIN_ENTRY)};
 #undef UPP_LIN_ENTRY
@@ -243,7 +309,7 @@ inline int config_code(const LinConfig &c) { return c.bmb * 4096 + c.bnb * 256 +
 // Choice of the decomposition (measured on MI355X, tools/time_linear.py): a workgroup per CU in ONE
 // round beats everything else at these sizes, so among the shapes whose workgroups fit the 256 CUs take the one with the
 // fewest MFMAs per SIMD -- ceil(waves / 4) waves per SIMD, each with 1 / KS of a block --, then the one with more waves per
-// SIMD (they cover each other's barrier and LDS latency), then the measured k-stage width, then fewer idle CUs.  Larger problems
+// SIMD (they cover each other's barrier and LDS latency), then fewer idle CUs.  Larger problems
 // (the 65,536-row layers of the segmentation head) run the 128 x 128 tile in several rounds.
 int pick_config(int M, int N, int K) {
     const int mb = (M + 31) / 32, nb = (N + 31) / 32;
@@ -258,15 +324,18 @@ int pick_config(int M, int N, int K) {
         const long long quarters = rounds * ((waves + 3) / 4) * (4 / c.ks);                      // quarter blocks per SIMD
         const long long traffic = 100LL * (c.bmb + c.bnb) / (c.bmb * c.bnb);                    // staged rows per block
         long long cost;
-        const int kc_pref = (c.bmb == 4 && c.bnb == 4) ? 2 : 1;       // 64-wide stages pay only for the 16-block tile (measured)
-        if (rounds == 1) cost = quarters * 1000000LL + (16 - waves) * 10000LL + (c.kc != kc_pref) * 1000LL + (256 - wgs);
-        else cost = 1000000000LL + quarters * 1000000LL + traffic * 1000LL + (2 - c.kc);
+        if (rounds == 1) cost = quarters * 1000000LL + (16 - waves) * 10000LL + (256 - wgs);
+        else cost = 1000000000LL + quarters * 1000000LL + traffic * 1000LL;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
     }
     return best;
 }
 
 }  // namespace
+
+#ifdef UPP_LIN_STAMPS
+extern "C" void upp_linear_set_stamps(unsigned long long *p) { g_lin_stamps = p; }
+#endif
 
 extern "C" int upp_linear_tile(int M, int N, int K) {
     if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
@@ -280,12 +349,16 @@ extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, lon
     if (!A || !W || !C || M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
     if (K % 32 != 0 || lda % 4 != 0 || ldw % 4 != 0 || lda < K || ldw < K || ldc < N) return UPP_E_RANGE;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return UPP_E_RANGE;
+    if (ldc > (1LL << 24) || ldaux > (1LL << 24)) return UPP_E_RANGE;          // 32-bit offsets inside a 32-row block
     if (epilogue < LEPI_NONE || epilogue > LEPI_MUL) return UPP_E_RANGE;
     if ((epilogue == LEPI_BIAS || epilogue == LEPI_BIAS_GELU || epilogue == LEPI_BIAS_GELU_D) && !bias) return UPP_E_BADARG;
     if ((epilogue == LEPI_BIAS_GELU_D || epilogue == LEPI_MUL) && (!aux || ldaux < N)) return UPP_E_BADARG;
     LinArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.bias = bias; g.aux = aux; g.ldaux = ldaux;
     g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+#ifdef UPP_LIN_STAMPS
+    g.stamps = g_lin_stamps;
+#endif
     hipStream_t st = (hipStream_t)stream;
     if (tile <= 0) {
         const int i = pick_config(M, N, K);
