@@ -23,11 +23,13 @@ the CPU oracle, bounded sample).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "iccv2025-upp_amd")):
+for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "iccv2025-upp_amd")):      # oracle/: the cpu_baseline leg only
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -51,7 +53,7 @@ class Trainer:
     """Synthetic-data wrapper around upp_hip.train.TrainStep (the product's step driver)."""
 
     def __init__(self, device, batch, distributed, use_graph=True, pipeline=False):
-        import _seeded
+        from utils import synthetic as _seeded
         from upp_hip.train import TrainStep, PipelinedTrainStep
         self.model = build_model(device).train()
         rank = dist.get_rank() if distributed else 0
@@ -83,7 +85,7 @@ class RecipeTrainer:
       cls_aux  : the headline step + an auxiliary Chamfer-L1 + EMD reconstruction term (BASELINE.json configs[2] wording)"""
 
     def __init__(self, kind, device, batch, use_graph=True, pipeline=False):
-        import _seeded
+        from utils import synthetic as _seeded
         from models import build_model_from_cfg
         from utils.config import builtin_cfg
         from utils import misc
@@ -228,7 +230,7 @@ def _pmc_traffic():
 def stage_report(device, B):
     """Stand-alone timings (HIP events on the launch stream) of the main hand-written kernels at the headline shapes,
     each against the roofline that bounds it.  Algorithmic bytes / flops: SURVEY 8(d) and DESIGN.md section 4."""
-    import _seeded
+    from utils import synthetic as _seeded
     from models.upp_layers import Encoder
     from upp_hip import functional as HF, ops
     pmc = _pmc_traffic()
@@ -375,6 +377,40 @@ def cpu_baseline(budget_s=20.0):
         HF.fps_gather = saved[1]
 
 
+def launch_ranks(n):
+    """N ranks of this script under torch.distributed.run (127.0.0.1 rendezvous), as a child process."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_launch(args, world):
+    """The distributed skeleton of main() without any GPU work (see --selftest-launch)."""
+    backend = os.environ.get("UPP_DIST_BACKEND", "nccl")
+    if world > 1:
+        dist.init_process_group(backend="gloo" if not torch.cuda.is_available() else backend)
+    rank = dist.get_rank() if world > 1 else 0
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert dist.get_world_size() == args.gpus
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "max_over_ranks_s": t.item(), "selftest": True}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,10 +424,22 @@ def main():
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM solutions (see upp_hip/gemm_tuning.py)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the prompting front-end and the trainable back-end of a step one after the other (one stream)")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="ranks only rendezvous, barrier and reduce a dummy time, rank 0 prints the JSON skeleton: checks the "
+                         "--gpus N launcher and the process-group plumbing on a host without a GPU (tests/test_host.py)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start N ranks (one process per GPU) as CHILDREN of this process, which has
+        # not touched the GPU, through the same launcher the driver uses, and hand their exit code on.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)"
+                         % (args.gpus, world, args.gpus))
     distributed = world > 1
+    if args.selftest_launch:
+        return selftest_launch(args, world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_rank %= max(torch.cuda.device_count(), 1)       # (rehearsals with more ranks than GPUs share a device)
     if distributed:
@@ -399,7 +447,9 @@ def main():
         torch.cuda.set_device(local_rank)
         # RCCL ("nccl") over xGMI; UPP_DIST_BACKEND=gloo only to rehearse the N > 1 code path on a one-GPU box
         dist.init_process_group(backend=os.environ.get("UPP_DIST_BACKEND", "nccl"))
+        assert dist.get_world_size() == args.gpus
     rank = dist.get_rank() if distributed else 0
+    backend = dist.get_backend() if distributed else None
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     from upp_hip import _abi
@@ -456,6 +506,7 @@ def main():
             "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": world if backend == "nccl" else 0, "dist_backend": backend,
             "config": {"workload": "Point_MAE_unify unify_modelnet_cls noisy-train fwd+bwd+AdamW, PEFT stage-1, "
                                    "B=%d/GPU x (1024+72) pts, G=64 k=32" % args.batch,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,

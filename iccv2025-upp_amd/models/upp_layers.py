@@ -31,13 +31,14 @@ class UniformBank:
     forward) draws as many values as the previous forward consumed; `take()` hands out views and
     falls back to a direct draw while the demand is still unknown (first forward) or grew."""
 
-    def __init__(self):
+    def __init__(self, generator=None):
         self.buf, self.pos, self.asked, self.need = None, 0, 0, 0
+        self.generator = generator          # None = the device's default generator
 
     def begin(self, device, training):
         self.need = max(self.need, self.asked)
         self.pos = self.asked = 0
-        self.buf = torch.rand(self.need, device=device) if (training and self.need) else None
+        self.buf = torch.rand(self.need, device=device, generator=self.generator) if (training and self.need) else None
 
     def take(self, shape, device):
         n = math.prod(shape)
@@ -46,10 +47,30 @@ class UniformBank:
             out = self.buf[self.pos:self.pos + n].view(shape)
             self.pos += n
             return out
-        return torch.rand(shape, device=device)
+        return torch.rand(shape, device=device, generator=self.generator)
 
 
 UNIFORMS = UniformBank()
+
+
+class use_rng:
+    """Scope in which the model's random draws (the uniform bank, DropPath) come from `bank` -- a UniformBank with its own
+    torch.Generator.  PipelinedTrainStep runs the front-end under one: its graphs replay on a second stream beside the
+    back-end's, and two concurrently replaying graphs that captured draws from the SAME generator race on its philox offset
+    (and a shared bank would make the front-end draw the back-end's demand)."""
+
+    def __init__(self, bank):
+        self.bank = bank
+
+    def __enter__(self):
+        global UNIFORMS
+        self.prev, UNIFORMS = UNIFORMS, self.bank
+        return self.bank
+
+    def __exit__(self, *exc):
+        global UNIFORMS
+        UNIFORMS = self.prev
+        return False
 
 # BatchNorm `num_batches_tracked` counters touched during one model forward: bumped together by ONE multi-tensor
 # launch at the end of the forward instead of one tiny kernel per BatchNorm call.
@@ -96,7 +117,7 @@ class DropPath(nn.Module):
         if self.drop_prob == 0. or not self.training:
             return None
         keep = 1.0 - self.drop_prob
-        return x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).uniform_().add_(keep).floor_().div_(keep)
+        return x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).uniform_(generator=UNIFORMS.generator).add_(keep).floor_().div_(keep)
 
     def forward(self, x):
         scale = self.sample_scale(x)

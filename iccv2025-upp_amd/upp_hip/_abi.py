@@ -19,9 +19,11 @@ SIGNATURES = {
     "upp_abi_version": (_c_i, []),
     "upp_error_string": (ctypes.c_char_p, [_c_i]),
     "upp_fps": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f]),
+    "upp_fps_ex": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_gather_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_gather_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_knn": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
+    "upp_knn_ex": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_group_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_group_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_chamfer_fwd": (_c_i, [_c_f] * 6 + [_c_i] * 3 + [_c_f]),
@@ -43,6 +45,8 @@ SIGNATURES = {
     "upp_ln_param_grad": (_c_i, [_c_f] * 5 + [_c_i] * 3 + [_c_f]),
     "upp_attn_fwd": (_c_i, [_c_f] * 3 + [_c_i] * 4 + [ctypes.c_float, _c_f]),
     "upp_attn_bwd": (_c_i, [_c_f] * 5 + [_c_i] * 4 + [ctypes.c_float, _c_f]),
+    "upp_attn_fwd_ex": (_c_i, [_c_f] * 3 + [_c_i] * 4 + [ctypes.c_float, _c_i, _c_f]),
+    "upp_attn_bwd_ex": (_c_i, [_c_f] * 5 + [_c_i] * 4 + [ctypes.c_float, _c_i, _c_f]),
     "upp_prop_pool_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 2 + [_c_i] * 2 + [_c_f]),
     "upp_prop_pool_bwd": (_c_i, [_c_f] * 4 + [ctypes.c_float] + [_c_f] + [_c_i] * 3 + [_c_f]),
     "upp_prop_interp_fwd": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f]),
@@ -75,12 +79,6 @@ SIGNATURES = {
                        + [_c_i] * 5 + [_c_f]),
     "upp_adamw_flat": (_c_i, [_c_f] * 4 + [ctypes.c_longlong] * 2 + [_c_f] * 2 + [ctypes.c_float] * 6 + [_c_f]),
 }
-# tuning hooks (not part of the reference-facing ABI)
-_EXTRA = {
-    "upp_fps_set_waves": (_c_i, [_c_i]),
-    "upp_knn_set_prefilter": (_c_i, [_c_i]),
-    "upp_attn_set_mfma": (_c_i, [_c_i]),
-}
 
 _lib = None
 
@@ -95,11 +93,10 @@ def load():
             "libupp_hip.so is not built (%s). Run `python __graft_entry__.py` or "
             "`python iccv2025-upp_amd/upp_hip/build.py`; there is no CPU fallback." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
-    for table in (SIGNATURES, _EXTRA):
-        for name, (res, args) in table.items():
-            fn = getattr(lib, name)  # AttributeError -> loud failure on a stale build
-            fn.restype = res
-            fn.argtypes = args
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> loud failure on a stale build
+        fn.restype = res
+        fn.argtypes = args
     if lib.upp_abi_version() != 1:
         raise RuntimeError("libupp_hip.so ABI version mismatch")
     _lib = lib

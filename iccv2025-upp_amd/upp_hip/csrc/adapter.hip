@@ -322,7 +322,7 @@ extern "C" int upp_adapter_fwd(const float *ha, const float *x, const float *W1,
     if (!ha || !x || !W1 || !b1 || !W2 || !b2 || !out || !s1 || R < 1) return UPP_E_BADARG;
     if (D != 384 || H != kH) return UPP_E_RANGE;
     const size_t lds = ((size_t)(kRows + kH) * (D + 1) + (kAW + 1) * kRows * kLG) * sizeof(float);
-    static bool raised = false;
+    static std::atomic<bool> raised{false};
     if (!raised) { int rc = raise_lds(adapter_fwd_kernel<384>, lds); if (rc) return rc; raised = true; }
     hipLaunchKernelGGL((adapter_fwd_kernel<384>), dim3((R + kRows - 1) / kRows), dim3(kAT), lds, (hipStream_t)stream, ha, x, W1, b1, W2,
                        b2, u, p, scale, out, s1, R);
@@ -334,7 +334,7 @@ extern "C" int upp_adapter_bwd(const float *g_out, const float *ha, const float 
     if (!g_out || !ha || !s1 || !W1 || !W2 || !g_ha || !part || R < 1) return UPP_E_BADARG;
     if (D != 384 || H != kH) return UPP_E_RANGE;
     const size_t lds = ((size_t)2 * kRows * (D + 1) + (kAW + 2) * kRows * kLG) * sizeof(float);
-    static bool raised = false;
+    static std::atomic<bool> raised{false};
     if (!raised) { int rc = raise_lds(adapter_bwd_kernel<384>, lds); if (rc) return rc; raised = true; }
     hipLaunchKernelGGL((adapter_bwd_kernel<384>), dim3((R + kRows - 1) / kRows), dim3(kAT), lds, (hipStream_t)stream, g_out, ha, s1, W1,
                        W2, u, p, scale, g_ha, part, R);

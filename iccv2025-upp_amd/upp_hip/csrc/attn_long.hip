@@ -246,7 +246,7 @@ static_assert(kBwdLongLds <= 160 * 1024, "LDS budget");
 
 // called by upp_attn_fwd / upp_attn_bwd (block.hip) for 96 < L <= 160
 int upp_attn_fwd_long(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st) {
-    static bool raised = false;
+    static std::atomic<bool> raised{false};
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLongLds);
         if (e != hipSuccess) return (int)e;
@@ -258,7 +258,7 @@ int upp_attn_fwd_long(const float *qkv, float *ctx, float *lse, int B, int L, in
 
 int upp_attn_bwd_long(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
                       float scale, hipStream_t st) {
-    static bool raised = false;
+    static std::atomic<bool> raised{false};
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLongLds);
         if (e != hipSuccess) return (int)e;

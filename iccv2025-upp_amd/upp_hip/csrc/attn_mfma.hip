@@ -233,7 +233,7 @@ constexpr size_t kBwdLds = ((size_t)4 * kLP * kLD + (size_t)kLP * kLS + 2 * kLP)
 
 // called by upp_attn_fwd / upp_attn_bwd (block.hip) for L <= 96
 int upp_attn_fwd_mfma(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st) {
-    static bool raised = false;
+    static std::atomic<bool> raised{false};
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
         if (e != hipSuccess) return (int)e;
@@ -245,7 +245,7 @@ int upp_attn_fwd_mfma(const float *qkv, float *ctx, float *lse, int B, int L, in
 
 int upp_attn_bwd_mfma(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
                       float scale, hipStream_t st) {
-    static bool raised = false;
+    static std::atomic<bool> raised{false};
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds);
         if (e != hipSuccess) return (int)e;

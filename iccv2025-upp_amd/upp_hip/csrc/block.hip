@@ -552,11 +552,10 @@ int upp_attn_bwd_mfma(const float *qkv, const float *ctx, const float *d_ctx, co
 int upp_attn_fwd_long(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st);
 int upp_attn_bwd_long(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
                       float scale, hipStream_t st);
-static int g_attn_mfma = 1;   // tuning hook: 0 forces the VALU kernels
-extern "C" int upp_attn_set_mfma(int on) { g_attn_mfma = on ? 1 : 0; return 0; }
-
-extern "C" int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, void *stream) {
-    if (!qkv || !ctx || !lse || B < 0 || L < 1 || H < 1) return UPP_E_BADARG;
+extern "C" int upp_attn_fwd_ex(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, int variant,
+                               void *stream) {
+    if (!qkv || !ctx || !lse || B < 0 || L < 1 || H < 1 || variant < 0 || variant > 1) return UPP_E_BADARG;
+    const bool g_attn_mfma = variant == 0;
     if (head_dim != 64 || L > 192) return UPP_E_RANGE;
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -572,9 +571,14 @@ extern "C" int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int
     return rc ? rc : upp_launch_status();
 }
 
-extern "C" int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L,
-                            int H, int head_dim, float scale, void *stream) {
-    if (!qkv || !ctx || !d_ctx || !lse || !d_qkv || B < 0 || L < 1 || H < 1) return UPP_E_BADARG;
+extern "C" int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, void *stream) {
+    return upp_attn_fwd_ex(qkv, ctx, lse, B, L, H, head_dim, scale, 0, stream);
+}
+
+extern "C" int upp_attn_bwd_ex(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L,
+                               int H, int head_dim, float scale, int variant, void *stream) {
+    if (!qkv || !ctx || !d_ctx || !lse || !d_qkv || B < 0 || L < 1 || H < 1 || variant < 0 || variant > 1) return UPP_E_BADARG;
+    const bool g_attn_mfma = variant == 0;
     if (head_dim != 64 || L > 160 || (!g_attn_mfma && L > 144)) return UPP_E_RANGE;
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -589,6 +593,11 @@ extern "C" int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_c
     else if (L <= 128) { rc = set_lds(attn_bwd_kernel<2, 128>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<2, 128>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
     else { rc = set_lds(attn_bwd_kernel<3, 144>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<3, 144>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
     return rc ? rc : upp_launch_status();
+}
+
+extern "C" int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L,
+                            int H, int head_dim, float scale, void *stream) {
+    return upp_attn_bwd_ex(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, head_dim, scale, 0, stream);
 }
 
 extern "C" int upp_bias_gelu_fwd(const float *z, const float *bias, float *h, long long rows, int C, void *stream) {

@@ -178,7 +178,7 @@ int launch(const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom 
     const size_t lds_bytes = (size_t)(4 * W + 3 * g.N + g.M) * 4;
     if (lds_bytes <= (size_t)kFpsLdsBytes) {
         if (lds_bytes > 64 * 1024) {
-            static bool raised = false;  // one attribute call per instantiation
+            static std::atomic<bool> raised{false};  // one attribute call per instantiation
             if (!raised) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fps_kernel<S, W, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kFpsLdsBytes);
@@ -209,18 +209,11 @@ int dispatch_s(int slots, const float *xyz, int32_t *idx, float *centers, int B,
     return UPP_E_RANGE;
 }
 
-int g_fps_waves = 0;  // 0 = heuristic; set through upp_fps_set_waves (tuning hook)
-
 }  // namespace
 
-extern "C" int upp_fps_set_waves(int w) {
-    if (w != 0 && w != 1 && w != 2 && w != 4 && w != 8) return UPP_E_BADARG;
-    g_fps_waves = w;
-    return 0;
-}
-
-extern "C" int upp_fps(const float *xyz, int32_t *idx, float *centers, int B, int N, int M, void *stream) {
+extern "C" int upp_fps_ex(const float *xyz, int32_t *idx, float *centers, int B, int N, int M, int waves, void *stream) {
     if (!xyz || !idx || B < 0 || N < 1 || M < 1) return UPP_E_BADARG;
+    if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8) return UPP_E_BADARG;
     if (N > 32768) return UPP_E_RANGE;  // 15-bit point ids, 64 slots x 512 lanes
     if (B == 0) return 0;
     FpsGeom g;
@@ -229,7 +222,7 @@ extern "C" int upp_fps(const float *xyz, int32_t *idx, float *centers, int B, in
     g.log2T = ilog2_floor(g.T);
     g.Q = (N + g.T - 1) / g.T;
     // waves per cloud: never more lanes than virtual threads
-    int W = g_fps_waves ? g_fps_waves : (N <= 128 ? 1 : (N <= 512 ? 2 : 4));
+    int W = waves ? waves : (N <= 128 ? 1 : (N <= 512 ? 2 : 4));
     while (W > 1 && 64 * W > g.T) W >>= 1;
     while (W < 8 && 64 * W < g.T && (g.T / (64 * W)) * g.Q > 64) W <<= 1;  // at most 64 slots per lane
     const int L = 64 * W;
@@ -242,4 +235,8 @@ extern "C" int upp_fps(const float *xyz, int32_t *idx, float *centers, int B, in
         case 4: return dispatch_s<4>(slots, xyz, idx, centers, B, g, st);
         default: return dispatch_s<8>(slots, xyz, idx, centers, B, g, st);
     }
+}
+
+extern "C" int upp_fps(const float *xyz, int32_t *idx, float *centers, int B, int N, int M, void *stream) {
+    return upp_fps_ex(xyz, idx, centers, B, N, M, 0, stream);
 }

@@ -117,14 +117,10 @@ __global__ __launch_bounds__(64 * kKnnWaves) void knn_kernel(const float *__rest
     }
 }
 
-int g_knn_prefilter = 1;
-
 }  // namespace
 
-extern "C" int upp_knn_set_prefilter(int on) { g_knn_prefilter = on ? 1 : 0; return 0; }
-
-extern "C" int upp_knn(const float *ref, const float *query, float *dist, int64_t *idx, float *neigh, int B, int N, int Q,
-                       int K, void *stream) {
+extern "C" int upp_knn_ex(const float *ref, const float *query, float *dist, int64_t *idx, float *neigh, int B, int N, int Q,
+                          int K, int prefilter, void *stream) {
     if (!ref || !query || !idx || B < 0 || N < 1 || Q < 0 || K < 1) return UPP_E_BADARG;
     if (K > N) return UPP_E_KGTN;
     if (K > 64) return UPP_E_RANGE;
@@ -132,9 +128,14 @@ extern "C" int upp_knn(const float *ref, const float *query, float *dist, int64_
     if (B > 65535) return UPP_E_RANGE;
     dim3 grid((Q + kKnnWaves - 1) / kKnnWaves, B);
     hipStream_t st = (hipStream_t)stream;
-    if (g_knn_prefilter)
+    if (prefilter)
         hipLaunchKernelGGL((knn_kernel<true>), grid, dim3(64 * kKnnWaves), 0, st, ref, query, dist, idx, neigh, N, Q, K);
     else
         hipLaunchKernelGGL((knn_kernel<false>), grid, dim3(64 * kKnnWaves), 0, st, ref, query, dist, idx, neigh, N, Q, K);
     return upp_launch_status();
+}
+
+extern "C" int upp_knn(const float *ref, const float *query, float *dist, int64_t *idx, float *neigh, int B, int N, int Q,
+                       int K, void *stream) {
+    return upp_knn_ex(ref, query, dist, idx, neigh, B, N, Q, K, 1, stream);
 }

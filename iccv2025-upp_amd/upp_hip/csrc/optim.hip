@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void adamw_update_kernel(float *__restrict__ p
                                                            const float *__restrict__ state, float lr, float beta1, float beta2,
                                                            float eps, float wd) {
     const float clip = state[2], bc1 = state[3], sbc2 = state[4];
+    if (lr < 0.0f) { lr = state[5]; wd = state[6]; }        // schedule-driven values live on the device (HIP-graph replays see updates)
     const float step_size = lr / bc1;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float gi = g[i] * clip;                       // the clipped gradient is what stays in the buffer

@@ -765,7 +765,7 @@ extern "C" int upp_csr_build(const int32_t *keys, int n, int seg_len, int seg_ro
     if (lds > 64 * 1024) return UPP_E_RANGE;    // counts of every row live in LDS (rows <= 15360)
     const size_t lds_perm = lds + (size_t)2 * n * sizeof(int32_t);      // + permutation and its row ids
     if (lds_perm <= 150 * 1024) {
-        static bool raised = false;
+        static std::atomic<bool> raised{false};
         if (!raised) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(csr_build_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

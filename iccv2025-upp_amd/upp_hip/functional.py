@@ -234,23 +234,24 @@ class _Attention(Function):
     """ctx = softmax(q k^T * scale) v from the packed qkv projection (B, L, 3*H*64)."""
 
     @staticmethod
-    def forward(ctx, qkv, num_heads, scale):
+    def forward(ctx, qkv, num_heads, scale, variant=0):
         qkv = qkv.contiguous()
         B, L, _ = qkv.shape
-        out, lse = ops.attn_fwd(qkv, B, L, num_heads, scale)
+        out, lse = ops.attn_fwd(qkv, B, L, num_heads, scale, variant)
         ctx.save_for_backward(qkv, out, lse)
-        ctx.meta = (B, L, num_heads, scale)
+        ctx.meta = (B, L, num_heads, scale, variant)
         return out
 
     @staticmethod
     def backward(ctx, g):
         qkv, out, lse = ctx.saved_tensors
-        B, L, H, scale = ctx.meta
-        return ops.attn_bwd(qkv, out, g.contiguous(), lse, B, L, H, scale), None, None
+        B, L, H, scale, variant = ctx.meta
+        return ops.attn_bwd(qkv, out, g.contiguous(), lse, B, L, H, scale, variant), None, None, None
 
 
-def attention(qkv, num_heads, scale):
-    return _Attention.apply(qkv, int(num_heads), float(scale))
+def attention(qkv, num_heads, scale, variant=0):
+    """variant 0: the library's kernel choice (FP32 MFMA where it applies); 1: the VALU kernels (tests / measurements)."""
+    return _Attention.apply(qkv, int(num_heads), float(scale), int(variant))
 
 
 # ------------------------------------------------------------------ deferred parameter-gradient sums

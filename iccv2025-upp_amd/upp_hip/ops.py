@@ -39,14 +39,14 @@ def _call(dev, name, *args):
 
 
 # ------------------------------------------------------------------ FPS / gather
-def fps(xyz, npoint, want_centers=False):
-    """(B,N,3) f32 -> idx (B,npoint) int32 [, centers (B,npoint,3)]."""
+def fps(xyz, npoint, want_centers=False, waves=0):
+    """(B,N,3) f32 -> idx (B,npoint) int32 [, centers (B,npoint,3)].  waves: wavefronts per cloud (0 = the library's choice)."""
     _need(xyz, "xyz", torch.float32, 3, 3)
     B, N, _ = xyz.shape
     npoint = int(npoint)
     idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     centers = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if want_centers else None
-    _call(xyz.device, "upp_fps", _abi.ptr(xyz), _abi.ptr(idx), _abi.ptr(centers), B, N, npoint)
+    _call(xyz.device, "upp_fps_ex", _abi.ptr(xyz), _abi.ptr(idx), _abi.ptr(centers), B, N, npoint, int(waves))
     return (idx, centers) if want_centers else idx
 
 
@@ -71,7 +71,7 @@ def gather_bwd(grad_out, idx, N):
 
 
 # ------------------------------------------------------------------ kNN / group
-def knn(ref, query, k, want_dist=True, want_neigh=False):
+def knn(ref, query, k, want_dist=True, want_neigh=False, prefilter=True):
     """ref (B,N,3), query (B,Q,3) -> dist (B,Q,k) f32 | None, idx (B,Q,k) int64 [, neigh (B,Q,k,3)]."""
     _need(ref, "ref", torch.float32, 3, 3)
     _need(query, "query", torch.float32, 3, 3)
@@ -84,7 +84,7 @@ def knn(ref, query, k, want_dist=True, want_neigh=False):
     idx = torch.empty((B, Q, k), dtype=torch.int64, device=ref.device)
     dist = torch.empty((B, Q, k), dtype=torch.float32, device=ref.device) if want_dist else None
     neigh = torch.empty((B, Q, k, 3), dtype=torch.float32, device=ref.device) if want_neigh else None
-    _call(ref.device, "upp_knn", _abi.ptr(ref), _abi.ptr(query), _abi.ptr(dist), _abi.ptr(idx), _abi.ptr(neigh), B, N, Q, k)
+    _call(ref.device, "upp_knn_ex", _abi.ptr(ref), _abi.ptr(query), _abi.ptr(dist), _abi.ptr(idx), _abi.ptr(neigh), B, N, Q, k, int(bool(prefilter)))
     return dist, idx, neigh
 
 
@@ -314,19 +314,19 @@ def ln_param_grad(g_h, xo, mean, rstd, chunks=32):
     return part          # (2, chunks, D): [0] d_gamma partials, [1] d_beta partials; the caller sums over the chunks
 
 
-def attn_fwd(qkv, B, L, H, scale):
+def attn_fwd(qkv, B, L, H, scale, variant=0):
     _need(qkv, "qkv", torch.float32)
     hd = qkv.numel() // (B * L * 3 * H)
     ctx = torch.empty((B, L, H * hd), dtype=torch.float32, device=qkv.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
-    _call(qkv.device, "upp_attn_fwd", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(lse), B, L, H, hd, float(scale))
+    _call(qkv.device, "upp_attn_fwd_ex", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(lse), B, L, H, hd, float(scale), int(variant))
     return ctx, lse
 
 
-def attn_bwd(qkv, ctx, d_ctx, lse, B, L, H, scale):
+def attn_bwd(qkv, ctx, d_ctx, lse, B, L, H, scale, variant=0):
     hd = qkv.numel() // (B * L * 3 * H)
     d_qkv = torch.empty_like(qkv)
-    _call(qkv.device, "upp_attn_bwd", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(d_ctx), _abi.ptr(lse), _abi.ptr(d_qkv), B, L, H, hd, float(scale))
+    _call(qkv.device, "upp_attn_bwd_ex", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(d_ctx), _abi.ptr(lse), _abi.ptr(d_qkv), B, L, H, hd, float(scale), int(variant))
     return d_qkv
 
 

@@ -74,13 +74,39 @@ class FlatAdamW:
         self.g = flat_grad
         self.m = torch.zeros(self.n, device=dev)
         self.v = torch.zeros(self.n, device=dev)
-        self.state = torch.zeros(8, device=dev)
+        self.state = torch.zeros(8, device=dev)        # [0] step ... [5] learning rate, [6] weight decay (read by the kernel)
         self.scratch = torch.empty(int(_abi.load().upp_adamw_scratch_floats()), device=dev)
         self.hyper = (lr, betas[0], betas[1], eps, weight_decay, -1.0 if max_norm is None else max_norm)
+        self._push_hyper()
+
+    def _push_hyper(self):
+        """lr and weight decay live in the device state buffer (upp_adamw_flat with lr < 0 reads them there), so a step
+        captured in a HIP graph follows set_lr() / load_state_dict() / a scheduler without being re-captured."""
+        self.state[5:7].copy_(torch.tensor([self.hyper[0], self.hyper[4]], dtype=torch.float32), non_blocking=False)
+
+    def set_lr(self, lr, weight_decay=None):
+        h = list(self.hyper)
+        h[0] = float(lr)
+        if weight_decay is not None:
+            h[4] = float(weight_decay)
+        self.hyper = tuple(h)
+        self._push_hyper()
+
+    @property
+    def param_groups(self):
+        """torch.optim-style view for schedulers that do `for g in opt.param_groups: g['lr'] = ...`; call sync_param_groups()
+        (or set_lr) afterwards to publish the values to the device."""
+        if not hasattr(self, '_groups'):
+            self._groups = [{'lr': self.hyper[0], 'weight_decay': 0.0}, {'lr': self.hyper[0], 'weight_decay': self.hyper[4]}]
+        return self._groups
+
+    def sync_param_groups(self):
+        g = self.param_groups
+        self.set_lr(g[-1]['lr'], g[-1]['weight_decay'])
 
     def step(self):
-        lr, b1, b2, eps, wd, mn = self.hyper
-        self._ops.adamw_flat(self.p, self.g, self.m, self.v, self.n, self.split, self.state, self.scratch, lr, b1, b2, eps, wd, mn)
+        _, b1, b2, eps, _, mn = self.hyper
+        self._ops.adamw_flat(self.p, self.g, self.m, self.v, self.n, self.split, self.state, self.scratch, -1.0, b1, b2, eps, 0.0, mn)
 
     # -- checkpoint contract: the state_dict layout of torch.optim.AdamW with the two groups of make_adamw, so a
     #    checkpoint written by the reference loop (tools/builder.py:131-140) resumes here and vice versa
@@ -119,7 +145,48 @@ class FlatAdamW:
                 off += n
             self.state[0] = step
         g0 = groups[0]
+        if (g0['betas'][0], g0['betas'][1], g0['eps']) != self.hyper[1:4] and getattr(self, 'captured', False):
+            raise RuntimeError("betas / eps differ from the captured optimizer step: build the TrainStep after loading the checkpoint")
         self.hyper = (g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'], groups[-1]['weight_decay'], self.hyper[5])
+        self._push_hyper()                              # lr / weight decay reach captured graphs through the device buffer
+
+
+class _TrainingState:
+    """Everything a training step mutates -- flat parameters, Adam moments and counters (or the library optimizer's state), every
+    module buffer (BatchNorm statistics and counters), parameters outside the flat buffer -- cloned, to be put back IN PLACE.
+    The graph-capture warm-up runs real steps (it has to: it sizes the uniform bank, tunes the remaining library GEMMs, fills
+    the transposed-weight cache); with this it leaves no trace: the first step() starts from exactly the state the caller
+    built -- on every rank, whatever data the ranks hold (a warm-up that applied two un-reduced updates made replicas diverge)."""
+
+    def __init__(self, model, opt, flat):
+        self.tensors = [b for b in model.buffers()] + [flat]
+        if isinstance(opt, FlatAdamW):
+            self.tensors += [opt.p, opt.m, opt.v, opt.state]
+            self.opt, self.opt_state = None, None
+        else:
+            import copy
+            self.tensors += [p for p in model.parameters() if p.requires_grad]
+            self.opt, self.opt_state = opt, copy.deepcopy(opt.state_dict())
+        with torch.no_grad():
+            self.saved = [t.detach().clone() for t in self.tensors]
+
+    def restore(self):
+        with torch.no_grad():
+            for t, s in zip(self.tensors, self.saved):
+                t.copy_(s)
+        if self.opt is not None:
+            self.opt.load_state_dict(self.opt_state)
+
+
+def broadcast_model(model, src=0):
+    """Rank `src`'s parameters and buffers to every rank (what DistributedDataParallel does when it wraps a model,
+    reference tools/runner_module.py:53-57): replicas start identical whatever seed / checkpoint each process used."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
+                dist.broadcast(t.data, src)
 
 
 class TrainStep:
@@ -145,6 +212,8 @@ class TrainStep:
         else:                                                   # host runs (gloo tests, CPU baseline): library optimizer
             self.opt = make_adamw(model, lr=lr)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if self.distributed:
+            broadcast_model(model)      # (after FlatAdamW re-pointed the trainable parameters into its flat buffer: views of it)
         self.pts = torch.zeros(batch_shape, device=self.device)
         self.labels = torch.zeros(batch_shape[0], dtype=torch.long, device=self.device)
         self.loss = torch.zeros((), device=self.device)
@@ -189,6 +258,7 @@ class TrainStep:
         self.opt.step()
 
     def _capture(self):
+        keep = _TrainingState(self.model, self.opt, self.flat.flat)     # the warm-up below must leave no trace (see _TrainingState)
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):                 # warm-up on a side stream, as graph capture requires
@@ -203,6 +273,10 @@ class TrainStep:
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt):
             self._update()
+        keep.restore()
+        if isinstance(self.opt, FlatAdamW):
+            self.opt.captured = True
+        torch.cuda.synchronize(self.device)
 
     def step(self, pts=None, labels=None):
         if pts is not None:
@@ -287,6 +361,11 @@ class PipelinedTrainStep(TrainStep):
         self.labels2 = [torch.zeros(B, dtype=torch.long, device=self.device) for _ in range(2)]
         self.extras2 = [[t.detach().clone().to(self.device) for t in (extras or [])] for _ in range(2)]
         self.s_front = torch.cuda.Stream(device=self.device)
+        from models import upp_layers as _L
+        self._L = _L
+        self._gen_front = torch.Generator(device=self.device)          # the front-end's own random stream (see upp_layers.use_rng)
+        self._gen_front.manual_seed(torch.initial_seed() + 0x5EED)
+        self._bank_front = _L.UniformBank(self._gen_front)
         self._bns = [m for m in model.encoder.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats]
         if any(m.momentum is None for m in self._bns):
             raise RuntimeError("cumulative-average BatchNorm statistics cannot be pipelined")
@@ -304,7 +383,7 @@ class PipelinedTrainStep(TrainStep):
 
     # -- the three parts of a step -----------------------------------------------------------
     def _front(self, p):
-        with torch.no_grad():
+        with torch.no_grad(), self._L.use_rng(self._bank_front):
             if self.front_fn is not None:
                 state = self.front_fn(self.model, self.pts)
             else:
@@ -356,6 +435,9 @@ class PipelinedTrainStep(TrainStep):
 
     def _capture(self):
         cur = torch.cuda.current_stream(self.device)
+        keep = _TrainingState(self.model, self.opt, self.flat.flat)     # the warm-up must leave no trace (see _TrainingState)
+        keep.tensors += self._shadow + self._shadow_counters
+        keep.saved += [t.detach().clone() for t in self._shadow + self._shadow_counters]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(cur)
         with torch.cuda.stream(s):                 # eager warm-up (also tunes GEMM shapes, sizes the uniform bank)
@@ -372,6 +454,7 @@ class PipelinedTrainStep(TrainStep):
         self._g_front, self._g_back = [], []
         for p in range(2):
             gf = torch.cuda.CUDAGraph()
+            gf.register_generator_state(self._gen_front)
             with torch.cuda.graph(gf, stream=self.s_front):
                 self._front(p)
             gb = torch.cuda.CUDAGraph()
@@ -382,6 +465,9 @@ class PipelinedTrainStep(TrainStep):
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt):
             self._tail()
+        keep.restore()
+        if isinstance(self.opt, FlatAdamW):
+            self.opt.captured = True
         torch.cuda.synchronize(self.device)
 
     def _finish(self, p):

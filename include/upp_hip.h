@@ -6,7 +6,8 @@
  * operator the reference binds through a torch C++/CUDA extension (file:line
  * of the replaced interface is cited per function).  The signatures use only
  * plain device pointers, sizes and a HIP stream (passed as void*): no torch
- * types, no allocation inside the library, no global state.  The caller owns
+ * types, no allocation inside the library, no global state (the *_ex entry
+ * points take the kernel variant of a measurement as an ARGUMENT).  The caller owns
  * every buffer (including scratch) and the library never synchronises; all
  * work is enqueued on `stream` (hipStream_t; NULL = the default stream).
  *
@@ -49,6 +50,10 @@ const char *upp_error_string(int code);
  * Limits: 1 <= M, 1 <= N <= 32768. */
 int upp_fps(const float *xyz, int32_t *idx, float *centers,
             int B, int N, int M, void *stream);
+/* the same with the number of wavefronts per cloud forced (waves in {1,2,4,8}; 0 = the
+ * library's choice = upp_fps): identical results, for measurements and tests. */
+int upp_fps_ex(const float *xyz, int32_t *idx, float *centers,
+               int B, int N, int M, int waves, void *stream);
 
 /* ---- gather_operation ---------------------------------------------------------
  * Replaces pointnet2_ops._ext.gather_points / gather_points_grad
@@ -77,6 +82,10 @@ int upp_gather_bwd(const float *grad_out, const int32_t *idx, float *grad_feat,
  * Limits: 1 <= K <= min(N, 64). */
 int upp_knn(const float *ref, const float *query, float *dist, int64_t *idx, float *neigh,
             int B, int N, int Q, int K, void *stream);
+/* the same with the k-th-smallest prefilter of the insertion sort switched off
+ * (prefilter = 0; 1 = upp_knn): identical results, for measurements and tests. */
+int upp_knn_ex(const float *ref, const float *query, float *dist, int64_t *idx, float *neigh,
+               int B, int N, int Q, int K, int prefilter, void *stream);
 
 /* ---- grouping gather (stand-alone) and its backward ----------------------------
  * Replaces the torch indexing of Group.forward (reference
@@ -200,6 +209,11 @@ int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, cons
 int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, void *stream);
 int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv,
                  int B, int L, int H, int head_dim, float scale, void *stream);
+/* the same with the kernel family chosen by the caller: variant 0 = the library's choice (the FP32-MFMA kernels where they
+ * apply), 1 = the VALU kernels (L <= 192 forward, L <= 144 backward); for measurements and tests. */
+int upp_attn_fwd_ex(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, int variant, void *stream);
+int upp_attn_bwd_ex(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv,
+                    int B, int L, int H, int head_dim, float scale, int variant, void *stream);
 
 /* ---- prompt propagation (Block.forward, reference models/Point_MAE_pretask_dev.py:275-303) ----
  * X (rows, D): the block's token matrix viewed as rows = B*L' rows [cls | prompts | T centre tokens] per sample.
@@ -332,6 +346,9 @@ int upp_bn_relu_drop_bwd(const float *g_a, const float *z, const float *gamma, c
  * [split, n) have `weight_decay`.  state (8 floats, zero-initialised once): [0] step count, [1] gradient L2 norm,
  * [2] clip coefficient min(max_norm / (norm + 1e-6), 1), [3] 1 - beta1^step, [4] sqrt(1 - beta2^step).
  * g is overwritten with the clipped gradient (as clip_grad_norm_ does).  max_norm <= 0 disables clipping.
+ * lr < 0: the learning rate and the weight decay are read from state[5] and state[6] on the device instead of the
+ * by-value arguments -- a launch captured in a HIP graph then follows a learning-rate schedule (the reference steps
+ * a CosineLRScheduler per epoch, tools/builder.py:67-75 / tools/runner_module.py:217-221) without being re-captured.
  * scratch: upp_adamw_scratch_floats() floats. */
 long long upp_adamw_scratch_floats(void);
 /* upp_batched_sum: for `jobs` independent jobs in one launch, dst_j[c] (+)= sum_{i < n_j} src_j[i * ld_j + c], c < len_j

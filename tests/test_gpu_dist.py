@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, paths):
+def _worker(rank, world, port, out_dir, paths, kind="pipelined"):
     sys.path[:0] = paths
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -34,13 +34,34 @@ def _worker(rank, world, port, out_dir, paths):
         dist_utils.init_dist('pytorch', backend='gloo')
     torch.cuda.set_device(0)
     m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda().train()
+    if kind == "rank_seeded":
+        # every rank starts from DIFFERENT trainable weights and feeds rank-specific data BEFORE the first step (= before the
+        # capture warm-up): the construction-time broadcast and the trace-free warm-up must still give identical replicas
+        torch.manual_seed(1234 + rank)
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                if 'cls_head_finetune' in n_ or 'downstream_adapter' in n_:
+                    p_.add_(0.01 * torch.randn_like(p_))
     for mod in m.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
         if hasattr(mod, 'drop_prob'):
             mod.drop_prob = 0.0
     freeze_for_peft(m)
-    ts = PipelinedTrainStep(m, (4, 1096, 3))
+    if kind == "rank_seeded":
+        from upp_hip.train import TrainStep
+        ts = TrainStep(m, (4, 1096, 3))
+        ts.pts.copy_(_seeded.noisy_clouds(4, 1024, seed=900 + rank).cuda())       # what bench.Trainer does before step()
+        ts.labels.copy_(torch.tensor([rank, 5, 6, 7], device='cuda'))
+        bn = m.blocks.blocks[0].bnorm
+        before = (bn.running_mean.clone(), bn.num_batches_tracked.clone())
+        ts._capture()
+        torch.cuda.synchronize()
+        assert float(ts.opt.state[0]) == 0.0, "the capture warm-up left optimizer steps behind"
+        assert torch.equal(bn.running_mean, before[0]) and torch.equal(bn.num_batches_tracked, before[1])
+        ts.flush = lambda: None
+    else:
+        ts = PipelinedTrainStep(m, (4, 1096, 3))
     assert ts.distributed == (world > 1)
     for k in range(4):
         pts = _seeded.noisy_clouds(4, 1024, seed=100 * rank + k).cuda()
@@ -49,8 +70,10 @@ def _worker(rank, world, port, out_dir, paths):
     ts.flush()
     torch.cuda.synchronize()
     flat = torch.cat([p.detach().reshape(-1) for p in ts.trainable]).cpu().numpy()
-    np.save(os.path.join(out_dir, "params_w%d_r%d.npy" % (world, rank)), flat)
-    np.save(os.path.join(out_dir, "loss_w%d_r%d.npy" % (world, rank)), np.array(float(ts.loss)))
+    np.save(os.path.join(out_dir, "params_%s_w%d_r%d.npy" % (kind, world, rank)), flat)
+    np.save(os.path.join(out_dir, "loss_%s_w%d_r%d.npy" % (kind, world, rank)), np.array(float(ts.loss)))
+    if kind == "rank_seeded":
+        assert float(ts.opt.state[0]) == 4.0          # four steps, not four + warm-up
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -62,7 +85,60 @@ def test_two_ranks_keep_identical_parameters(tmp_path):
     paths = [here, os.path.join(root, "iccv2025-upp_amd"), os.path.join(root, "oracle")]
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), paths), nprocs=2, join=True)
     mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), paths), nprocs=1, join=True)
-    a = np.load(tmp_path / "params_w2_r0.npy"); b = np.load(tmp_path / "params_w2_r1.npy"); solo = np.load(tmp_path / "params_w1_r0.npy")
+    a = np.load(tmp_path / "params_pipelined_w2_r0.npy"); b = np.load(tmp_path / "params_pipelined_w2_r1.npy")
+    solo = np.load(tmp_path / "params_pipelined_w1_r0.npy")
     np.testing.assert_array_equal(a, b)                       # one all-reduce per step: bit-identical replicas
     assert np.abs(a - solo).max() > 1e-6                      # ... and the other rank's batches did contribute
-    assert np.isfinite(np.load(tmp_path / "loss_w2_r0.npy")) and np.isfinite(np.load(tmp_path / "loss_w2_r1.npy"))
+    assert np.isfinite(np.load(tmp_path / "loss_pipelined_w2_r0.npy")) and np.isfinite(np.load(tmp_path / "loss_pipelined_w2_r1.npy"))
+
+
+def test_replicas_stay_identical_when_ranks_start_apart_and_feed_data_before_the_first_step(tmp_path):
+    """the capture warm-up used to apply two un-reduced optimizer steps on rank-local data and nothing
+    broadcast rank 0's weights.  Now: broadcast at construction, warm-up restored in place."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    paths = [here, os.path.join(root, "iccv2025-upp_amd"), os.path.join(root, "oracle")]
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), paths, "rank_seeded"), nprocs=2, join=True)
+    a = np.load(tmp_path / "params_rank_seeded_w2_r0.npy"); b = np.load(tmp_path / "params_rank_seeded_w2_r1.npy")
+    np.testing.assert_array_equal(a, b)
+
+
+def test_bench_gpus_2_reports_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no launcher around it) starts two ranks itself; gloo stands in for RCCL on a one-GPU box."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UPP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
+                          "--no-gemm-tuning"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["dist_backend"] == "gloo" and rec["value"] > 0
+
+
+def test_learning_rate_changes_reach_a_captured_step():
+    """lr / weight decay were by-value kernel arguments frozen into the optimizer graph."""
+    import _seeded
+    from models import build_model_from_cfg
+    from upp_hip.train import TrainStep, freeze_for_peft
+    from utils.config import builtin_cfg
+    m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda().train()
+    freeze_for_peft(m)
+    ts = TrainStep(m, (4, 1096, 3), lr=1e-3)
+    ts.pts.copy_(_seeded.noisy_clouds(4, 1024, seed=3).cuda())
+    ts.labels.copy_(torch.tensor([1, 2, 3, 4], device='cuda'))
+    ts.step()
+    assert float(ts.opt.state[0]) == 1.0
+    p0 = ts.opt.p.clone()
+    ts.opt.set_lr(0.0, weight_decay=0.0)            # after capture
+    ts.step()
+    assert torch.equal(ts.opt.p, p0), "lr = 0 must freeze the parameters of a captured step"
+    ts.opt.param_groups[-1]['lr'] = 1e-3
+    ts.opt.param_groups[0]['lr'] = 1e-3
+    ts.opt.sync_param_groups()
+    ts.step()
+    assert (ts.opt.p - p0).abs().max() > 0
+    sd = ts.opt.state_dict()
+    assert sd['param_groups'][0]['lr'] == 1e-3 and float(sd['state'][0]['step']) == 3.0

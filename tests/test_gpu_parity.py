@@ -53,14 +53,9 @@ def test_fps_indices_bit_exact(B, N, M, kind):
 
 @pytest.mark.parametrize("waves", [1, 2, 4, 8])
 def test_fps_every_wave_count_gives_the_same_answer(waves):
-    from upp_hip import _abi
     x = clouds(4, 1228, "dup", 3)
     want = O.fps(x, 300)
-    try:
-        assert _abi.load().upp_fps_set_waves(waves) == 0
-        np.testing.assert_array_equal(ops.fps(dev(x), 300).cpu().numpy(), want)
-    finally:
-        _abi.load().upp_fps_set_waves(0)
+    np.testing.assert_array_equal(ops.fps(dev(x), 300, waves=waves).cpu().numpy(), want)       # upp_fps_ex
 
 
 def test_fps_origin_skip_rule():
@@ -94,16 +89,11 @@ def test_knn_neighbour_lists_bit_exact(B, N, Q, K, kind):
 
 
 def test_knn_prefilter_on_off_identical_and_errors():
-    from upp_hip import _abi
     ref = clouds(3, 2000, "lattice", 2)
     qry = np.ascontiguousarray(ref[:, :50])
     _, wi = O.knn(ref, qry, 32)
-    try:
-        for on in (0, 1):
-            _abi.load().upp_knn_set_prefilter(on)
-            np.testing.assert_array_equal(ops.knn(dev(ref), dev(qry), 32)[1].cpu().numpy(), wi)
-    finally:
-        _abi.load().upp_knn_set_prefilter(1)
+    for on in (False, True):
+        np.testing.assert_array_equal(ops.knn(dev(ref), dev(qry), 32, prefilter=on)[1].cpu().numpy(), wi)   # upp_knn_ex
     with pytest.raises(RuntimeError, match="exceeds"):
         ops.knn(dev(ref[:, :10]), dev(qry), 11)
     with pytest.raises(RuntimeError, match="range"):

@@ -1,4 +1,6 @@
 """Host-side mirror of the reference interface: registry, config, misc helpers."""
+import os
+
 import pytest
 import torch
 
@@ -60,3 +62,25 @@ def test_batch_counters_count_every_call_of_a_shared_module():
     assert int(a) == 3 and int(b) == 1
     L.bump_counter(b)                      # outside a forward: immediate
     assert int(b) == 2
+
+
+def test_bench_gpus_flag_launches_that_many_ranks(tmp_path):
+    """`python bench.py --gpus 2` alone must start 2 ranks (torch.distributed.run child, 127.0.0.1 rendezvous), rank 0 prints ONE
+    JSON line with n_gpus == 2, and a WORLD_SIZE that contradicts --gpus is refused.  --selftest-launch keeps the GPU out of it."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, UPP_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest-launch"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and abs(rec["max_over_ranks_s"] - 0.002) < 1e-12
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                         env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr

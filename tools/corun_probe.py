@@ -7,7 +7,8 @@ import time
 import torch
 
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'iccv2025-upp_amd'); sys.path.insert(0, 'oracle')
-import bench, _seeded
+import bench
+from utils import synthetic as _seeded
 from models.upp_layers import Encoder
 from upp_hip import gemm_tuning, ops, functional as HF
 

@@ -1,7 +1,8 @@
 """Probe: 2-stage (front || back) against 3-stage (rectify || complete+embed || back) software pipelining."""
 import sys, time, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'iccv2025-upp_amd'); sys.path.insert(0, 'oracle')
-import bench, _seeded
+import bench
+from utils import synthetic as _seeded
 from models import upp_layers as L
 from upp_hip import gemm_tuning
 gemm_tuning.enable()

@@ -11,7 +11,7 @@ for p in ("oracle", "tests", "iccv2025-upp_amd"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import torch  # noqa: E402
 
-import _seeded  # noqa: E402
+from utils import synthetic as _seeded  # noqa: E402
 from models.upp_layers import Encoder  # noqa: E402
 from upp_hip import functional as HF, ops  # noqa: E402
 

@@ -7,7 +7,7 @@ for p in ("oracle", "tests", "iccv2025-upp_amd"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import torch  # noqa: E402
 
-import _seeded  # noqa: E402
+from utils import synthetic as _seeded  # noqa: E402
 from upp_hip import ops  # noqa: E402
 
 B = 32

@@ -9,7 +9,7 @@ for p in ("oracle", "tests", "iccv2025-upp_amd"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import torch  # noqa: E402
 
-import _seeded  # noqa: E402
+from utils import synthetic as _seeded  # noqa: E402
 sys.path.insert(0, ROOT)
 from bench import time_kernel  # noqa: E402
 from upp_hip import _abi, ops  # noqa: E402
@@ -23,9 +23,7 @@ def main():
         x = _seeded.unit_ball_clouds(B, N, seed=N).cuda()
         row = []
         for w in (1, 2, 4, 8):
-            lib.upp_fps_set_waves(w)
-            row.append(time_kernel(lambda: ops.fps(x, M, want_centers=True), iters=10, warm=2))
-        lib.upp_fps_set_waves(0)
+            row.append(time_kernel(lambda: ops.fps(x, M, want_centers=True, waves=w), iters=10, warm=2))
         row.append(time_kernel(lambda: ops.fps(x, M, want_centers=True), iters=10, warm=2))
         print("  N=%5d M=%5d  W1 %.4f  W2 %.4f  W4 %.4f  W8 %.4f  auto %.4f   us/iter(best) %.3f"
               % (N, M, *row, 1000 * min(row[:4]) / max(M - 1, 1)))
@@ -35,10 +33,8 @@ def main():
         q = x[:, :Q].contiguous()
         row = []
         for on in (0, 1):
-            lib.upp_knn_set_prefilter(on)
-            row.append(time_kernel(lambda: ops.knn(x, q, K, want_dist=False, want_neigh=True), iters=10, warm=2))
+            row.append(time_kernel(lambda: ops.knn(x, q, K, want_dist=False, want_neigh=True, prefilter=on), iters=10, warm=2))
         print("  N=%5d Q=%4d K=%3d  off %.4f  on %.4f" % (N, Q, K, *row))
-    lib.upp_knn_set_prefilter(1)
     a = _seeded.unit_ball_clouds(B, 1024, seed=1).cuda()
     b = _seeded.unit_ball_clouds(B, 1024, seed=2).cuda()
     t = time_kernel(lambda: ops.chamfer_fwd(a, b), iters=10)

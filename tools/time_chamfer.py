@@ -1,6 +1,7 @@
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'iccv2025-upp_amd')
-import torch, bench, _seeded
+import torch, bench
+from utils import synthetic as _seeded
 from upp_hip import ops
 for B, n, m in ((32, 1024, 1024), (32, 2048, 8192), (1216, 32, 32)):
     a = _seeded.unit_ball_clouds(B, n, 1).cuda(); b = _seeded.unit_ball_clouds(B, m, 2).cuda()

@@ -1,6 +1,7 @@
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'iccv2025-upp_amd')
-import torch, bench, _seeded
+import torch, bench
+from utils import synthetic as _seeded
 from upp_hip import ops
 a = _seeded.unit_ball_clouds(32, 1024, 1).cuda(); b = _seeded.unit_ball_clouds(32, 1024, 2).cuda()
 t = bench.time_kernel(lambda: ops.emd_approxmatch(a, b), iters=3)
