@@ -74,6 +74,8 @@ class Trainer:
 PRETASK_PEFT = ['rectify_adapter', 'downstream_adapter', 'pretask_adapter', 'rectify_prompts', 'downstream_prompts',
                 'pretask_prompts', 'coarse_pred', 'increase_dim', 'mask_token', 'dense_pred', 'rectify_prompter', 'shape_pred',
                 'predict_token_generator', 'mask_prompter', 'mask_token_generator']   # reference tools/runner_pretask.py:112-117
+STAGE2_PEFT = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'dense_pred', 'mask_token', 'rectify_prompter',
+               'shape_pred', 'coarse_pred', 'predict_token_generator', 'mask_prompter', 'mask_token_generator']   # reference tools/runner_module.py:232-238
 SEG_PEFT = ['downstream_adapter', 'downstream_prompts', 'bnorm', 'label_conv', 'propagation_0', 'seg_head']
 
 
@@ -82,7 +84,9 @@ class RecipeTrainer:
       pretask  : Point_MAE_pretask_dev + three Chamfer-L1 terms + noise loss (tools/runner_pretask.py:157-247)
       pretrain : Point_MAE masked auto-encoding, Chamfer-L2 on the masked groups (tools/runner_pretrain.py:115-148; 8f-3)
       seg      : Point_MAE_unify_seg part segmentation, N=2048 label points (BASELINE.json configs[4])
-      cls_aux  : the headline step + an auxiliary Chamfer-L1 + EMD reconstruction term (BASELINE.json configs[2] wording)"""
+      cls_aux  : the headline step + an auxiliary Chamfer-L1 + EMD reconstruction term (BASELINE.json configs[2] wording)
+      stage2   : the headline step with the SECOND-stage parameter list (tools/runner_module.py:230-244, "joint optimisation"):
+                 the prompter heads train, the gradient runs back through the whole prompting front-end"""
 
     def __init__(self, kind, device, batch, use_graph=True, pipeline=False):
         from utils import synthetic as _seeded
@@ -138,6 +142,17 @@ class RecipeTrainer:
                     dict(completion_prompt=True, denoise=True, point_num=1024), None)
             self.workload = ("Point_MAE_unify cls noisy-train step + auxiliary ChamferDistanceL1 + EMD on rebuild_points (B,1024,3) vs "
                              "gt (B,1024,3), fwd+bwd+AdamW, B=%d/GPU" % B)
+        elif kind == 'stage2':
+            model = build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model).to(device).train()
+            freeze_for_peft(model, STAGE2_PEFT)
+            pts = _seeded.noisy_clouds(B, 1024, seed=0).to(device)
+            labels = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(0)).to(device)
+            inputs = [pts, labels]
+
+            def loss_fn(m, pts, labels):
+                return m.get_loss_acc(m(pts, completion_prompt=True, denoise=True, point_num=1024), labels)
+            self.workload = ("Point_MAE_unify cls noisy-train step, stage-2 parameter list (prompter heads trainable: gradient through "
+                             "FPS gather, grouping, patch embedding, decoder, rectify prompter), fwd+bwd+AdamW, B=%d/GPU" % B)
         elif kind == 'pretrain':
             model = build_model_from_cfg(builtin_cfg('pretrain').model).to(device).train()
             inputs = [_seeded.unit_ball_clouds(B, 1024, seed=1).to(device)]
@@ -417,7 +432,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
-    ap.add_argument("--workload", default="cls", choices=["cls", "cls_aux", "pretask", "pretrain", "seg"],
+    ap.add_argument("--workload", default="cls", choices=["cls", "cls_aux", "stage2", "pretask", "pretrain", "seg"],
                     help="cls = the headline workload (default); the others are secondary recipes, see RecipeTrainer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (debug)")

@@ -560,9 +560,13 @@ class Block(nn.Module):
         u2 = None if u is None else u[1]
         if P and kw.get('prompt_propagation_after'):
             x3, _ = HF.rowln(x2, y=m, ybias=mb, u=u2, keep=keep)
-            if kw['center1_idx'].numel() == B * kw['center2'].shape[1] * 8:
+            if kw['center1_idx'].numel() == B * kw['center2'].shape[1] * 8 and _no_grad_needed(kw['center1'], kw['center2']):
                 x3 = self._propagate_fused(x3, kw)
             else:
+                # (stage 2 of the recipe: the centres carry a gradient back to the prompters, and the interpolation weights
+                # 1 / (d + eps) are functions of them -- the fused kernels treat the weights as constants of the forward)
+                if not _no_grad_needed(kw['center1'], kw['center2']):
+                    HF.note_declined("Block prompt propagation", "the level-1 / level-2 centres require a gradient")
                 x3, _ = self._propagate_prompts(x3, kw)
             m, mb, u2, x2 = None, None, None, x3
         if adapter is None:

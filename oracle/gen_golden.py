@@ -13,6 +13,8 @@ Fixtures (all eval mode, key-seeded weights from tests/_seeded.py):
   pretask.npz      Point_MAE_pretask_dev (pretask.yaml) in TRAIN mode with every dropout / drop-path probability set to 0:
                    predicted centres, rebuilt points, noise loss, recall, the three Chamfer-L1 terms of the pre-task recipe
                    (tools/runner_pretask.py:220-225) and the gradient norm of every parameter
+  upp_stage2.npz   the stage-2 ("joint optimisation", tools/runner_module.py:230-244) step: logits, loss, gradient norms of every
+                   stage-2 trainable tensor and 14 full gradient arrays (prompter heads, mask token, rectify prompter)
   upp_modules.npz  per-module input/output pairs: Encoder, Attention, Block (downstream path
                    with prompt propagation incl. the index-stride behaviour), TransformerDecoder,
                    RectifyPrompter, propagate, Group index outputs
@@ -78,12 +80,50 @@ def gen_pretask(R, out_dir):
           "keys", len(model.state_dict()), "grads", len(names))
 
 
+STAGE2_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'dense_pred', 'mask_token', 'rectify_prompter',
+               'shape_pred', 'coarse_pred', 'predict_token_generator', 'mask_prompter', 'mask_token_generator']
+# reference tools/runner_module.py:232-238 ("joint optimisation" from epoch args.joint_optimization on: the prompter heads train,
+# the classification head / bnorm / cls tokens of stage 1 are frozen again)
+STAGE2_KEEP = ['mask_token', 'dense_pred.0.weight', 'dense_pred.0.bias', 'coarse_pred.2.bias', 'coarse_pred.0.weight', 'shape_pred.0.weight',
+               'shape_pred.2.bias', 'predict_token_generator.2.weight', 'rectify_prompter.score_head.3.weight',
+               'rectify_prompter.score_head.0.bias', 'rectify_prompter.propagation1.mlp_convs.0.weight',
+               'rectify_prompter.abstraction.mlp_convs.2.weight', 'blocks.blocks.3.downstream_adapter.ln1.weight',
+               'blocks.blocks.0.downstream_prompts']
+
+
+def gen_stage2(R, out_dir):
+    """upp_stage2.npz: the noisy-train step of the SECOND stage of the recipe -- the gradient reaches the prompter heads
+    through the grouping / patch embedding of the prompted cloud, the FPS gather, rebuild_points, the frozen decoder and
+    backbone paths and the rectification offsets.  Eval-mode layers (as upp_model.npz), reference classes, key-seeded weights."""
+    model = R.MODELS.build(ref_shim.model_cfg())
+    _seeded.fill(model).eval()
+    for name, p in model.named_parameters():
+        p.requires_grad_(any(k in name for k in STAGE2_KEYS))
+    noisy = _seeded.noisy_clouds(2, 1024, seed=0)
+    labels = torch.tensor([3, 17])
+    logits = model(noisy, completion_prompt=True, denoise=True, point_num=1024)
+    loss, _ = model.get_loss_acc(logits, labels)
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    names = sorted(grads)
+    np.savez_compressed(os.path.join(out_dir, "upp_stage2.npz"), labels=labels.numpy(), logits=logits.detach().numpy(),
+                        loss=loss.detach().numpy(), grad_names=np.array(names),
+                        grad_norms=np.array([grads[n].norm().item() for n in names], dtype=np.float64),
+                        **{"grad::" + k: grads[k].numpy() for k in STAGE2_KEEP})
+    print("stage2 loss", loss.item(), "trainable tensors with a gradient", len(names), "of",
+          sum(1 for _, p in model.named_parameters() if p.requires_grad),
+          "norms", {k: float(grads[k].norm()) for k in STAGE2_KEEP[:6]})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_shim.load()
     if sys.argv[1:] == ['pretask']:
         gen_pretask(R, os.path.join(ROOT, "tests", "golden"))
+        return
+    if sys.argv[1:] == ['stage2']:
+        gen_stage2(R, os.path.join(ROOT, "tests", "golden"))
         return
     cfg = ref_shim.model_cfg()
     model = R.MODELS.build(cfg)
@@ -196,7 +236,8 @@ def main():
                         n_params=np.array(sum(p_.numel() for p_ in mae.parameters())), n_keys=np.array(len(mae.state_dict())))
     print("point_mae loss", mloss.item(), "params", sum(p_.numel() for p_ in mae.parameters()), "masked", int(used_mask[0].sum()))
     gen_pretask(R, out_dir)
-    for f in ("upp_model.npz", "upp_modules.npz", "upp_seg.npz", "point_mae.npz", "pretask.npz"):
+    gen_stage2(R, out_dir)
+    for f in ("upp_stage2.npz", "upp_model.npz", "upp_modules.npz", "upp_seg.npz", "point_mae.npz", "pretask.npz"):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
 
 

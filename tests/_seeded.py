@@ -36,7 +36,16 @@ def fill(model):
     return model
 
 
-from utils.synthetic import noisy_clouds, unit_ball_clouds  # noqa: E402,F401  (the generators live with the product: bench.py uses them)
+# The cloud generators live with the product (iccv2025-upp_amd/utils/synthetic.py: bench.py uses them).  Loaded by file path: the
+# fixture generators under oracle/ import this module next to the REFERENCE's own `utils` package.
+import importlib.util as _ilu  # noqa: E402
+import os as _os  # noqa: E402
+
+_spec = _ilu.spec_from_file_location("upp_synthetic", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
+                                                                    "iccv2025-upp_amd", "utils", "synthetic.py"))
+_syn = _ilu.module_from_spec(_spec)
+_spec.loader.exec_module(_syn)
+noisy_clouds, unit_ball_clouds = _syn.noisy_clouds, _syn.unit_ball_clouds
 
 
 def ref_ops_cases(fixture):

@@ -67,6 +67,38 @@ def test_peft_gradients_match_reference(model, oracle_ops, golden):
         p.grad = None
 
 
+STAGE2_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'dense_pred', 'mask_token', 'rectify_prompter',
+               'shape_pred', 'coarse_pred', 'predict_token_generator', 'mask_prompter', 'mask_token_generator']   # runner_module.py:232-238
+
+
+def test_stage2_joint_optimisation_gradients_match_reference(model, oracle_ops, golden):
+    """Second half of the recipe (reference tools/runner_module.py:230-244): the prompter heads train, so the gradient has to
+    travel back through grouping + patch embedding of the prompted cloud, the FPS gather, rebuild_points, the frozen decoder
+    and backbone paths and the rectification offsets."""
+    g = golden['upp_stage2']
+    for n, p in model.named_parameters():
+        p.requires_grad_(any(k in n for k in STAGE2_KEYS))
+        p.grad = None
+    logits = model(_seeded.noisy_clouds(2, 1024, 0), completion_prompt=True, denoise=True, point_num=1024)
+    loss, _ = model.get_loss_acc(logits, T(g['labels']))
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().numpy(), g['logits'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-5)
+    grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    assert sorted(grads) == list(g['grad_names']) and len(grads) == 125
+    norms = np.array([grads[n].norm().item() for n in g['grad_names']])
+    np.testing.assert_allclose(norms, g['grad_norms'], rtol=5e-4, atol=1e-7)
+    for k in g.files:
+        if k.startswith('grad::'):
+            ref = g[k]
+            # (a long f32 chain through two prompters, three encoder passes and 31 block passes, in re-associated but
+            # equivalent formulations: 1e-3 of the array's scale)
+            np.testing.assert_allclose(grads[k[6:]].numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max(), err_msg=k)
+    for p in model.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+
+
 def test_group_outputs_and_index_layout(model, oracle_ops, golden):
     m = golden['upp_modules']
     nb, center, idx, cidx = model.group_divider(T(m['group_pts']), require_index=True, gather_idx=False)
