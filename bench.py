@@ -14,11 +14,14 @@ run on the hand-written gfx950 kernels through the C ABI; inputs are resident in
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant hand-written kernel family of the step by GPU time:
-the patch-embed FP32-MFMA chain behind upp_patch_embed_fwd, timed live with HIP events on the launch stream),
-`kernels` (stand-alone timings of the hand-written kernels against their rooflines; `traffic` = HBM bytes per call from
-the committed rocprofv3 --pmc passes, profiles/r01_pmc_kernels.json), `cpu_baseline` (same step on the host cores with
-the CPU oracle, bounded sample).
+`python bench.py --gpus N` without a launcher around it starts the N ranks itself (torch.distributed.run as a child process).
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (the kernel family with the most GPU time per step: the
+upp_linear_f32 launches -- QKV / proj / fc1 / fc2 of every block pass and their data gradients -- each timed with HIP events
+on the launch stream inside one eager step; FLOPs / time against the FP32-MFMA peak), `ms_per_step_sequential` (the same step
+on one stream), `kernels` (stand-alone timings of the hand-written kernels against their rooflines; `traffic` = HBM bytes per
+call from the committed rocprofv3 --pmc passes, profiles/r0*_pmc_kernels.json), `cpu_baseline` (same step, same batch, on the
+host cores with the CPU oracle, bounded sample).  tools/make_profiles.sh regenerates profiles/r02_* with the same commands.
 """
 import argparse
 import json
@@ -233,13 +236,24 @@ MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f
 
 
 def _pmc_traffic():
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_kernels.json:
-    FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH doubled per the gfx950 note in MI355X_MICROARCH.md)."""
-    try:
-        raw = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")))
-    except Exception:
-        return {}
-    return {k: (2.0 * v["fetch_kb_raw"] + v["write_kb"]) * 1024.0 for k, v in raw.items()}
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_kernels.json, produced by
+    tools/make_profiles.sh: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH doubled per the gfx950 note in
+    MI355X_MICROARCH.md; kernels not re-profiled this round keep their profiles/r01_pmc_kernels.json entry)."""
+    out = {}
+    for name in ("r01_pmc_kernels.json", "r02_pmc_kernels.json"):
+        try:
+            raw = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        out.update({k: (2.0 * v["fetch_kb_raw"] + v["write_kb"]) * 1024.0 for k, v in raw.items()
+                    if v.get("fetch_kb_raw") is not None and v.get("write_kb") is not None})
+    return out
+
+
+# The Linear layers of one Transformer block at the headline token count (B = 32, L = 75 -> M = 2400): forward and data
+# gradients, as launched by models/upp_layers.py (label, M, N, K, epilogue).
+LINEAR_SHAPES = [("qkv", 2400, 1152, 384, 0), ("proj", 2400, 384, 384, 0), ("fc1_gelu_d", 2400, 1536, 384, 3), ("fc2", 2400, 384, 1536, 0),
+                 ("dfc2_mul", 2400, 1536, 384, 4), ("dfc1", 2400, 384, 1536, 0), ("dproj", 2400, 384, 384, 0), ("dqkv", 2400, 384, 1152, 0)]
 
 
 def stage_report(device, B):
@@ -279,6 +293,7 @@ def stage_report(device, B):
     t = time_kernel(lambda: ops.fps(x1228, 1024, want_centers=True), iters=5)
     out["fps_1228_1024"] = hbm("fps_kernel<6,4> (B,1228)->1024", t, B * (1228 * 12 + 1024 * 16), "fps_kernel<6, 4",
                                "1023 dependent arg-max rounds per cloud: latency-bound by construction (%.2f us/round)" % (t * 1e3 / 1023))
+    out["fps_1228_1024"]["rounds_per_us"] = 1023.0 / (t * 1e3)
     t = time_kernel(lambda: ops.fps(x, 64, want_centers=True))
     out["fps_1024_64"] = hbm("fps_kernel<4,4> (B,1024)->64", t, B * (1024 * 12 + 64 * 16), "fps_kernel<4, 4")
     t = time_kernel(lambda: ops.knn(x, cen, 32, want_dist=False, want_neigh=True))
@@ -354,13 +369,74 @@ def stage_report(device, B):
     out["chamfer_bwd"] = hbm("chamfer_grad_kernel (B,1024)x(B,1024)", t, B * 65536, "chamfer_grad_kernel")
     t = time_kernel(lambda: ops.emd_approxmatch(ca, cb), iters=3)
     out["emd_approxmatch"] = hbm("upp_emd_approxmatch (22 launches; match (B,1024,1024) written once)", t, B * (1024 * 1024 * 4 + 24576),
-                                 None, "exp-bound: 30 passes x n x m exp evaluations")
+                                 [("emd_row_kernel", 10), ("emd_col_kernel", 10), ("emd_match_kernel", 1), ("emd_init_kernel", 1)],
+                                 "VALU-issue + launch bound, not HBM and not the exp unit: 40 v_exp_f32 per point pair = %.2f T exp/s "
+                                 "of a ~19.7 T/s issue roof" % (B * 1024 * 1024 * 40 / t / 1e9))
+    out["emd_approxmatch"]["bound"] = "valu"
+    # the Linear layers of one block on upp_linear_f32 (csrc/linear.hip), stand-alone at M = 2400
+    gl = torch.Generator(device=device).manual_seed(11)
+    for label, M, N, K, epi in LINEAR_SHAPES:
+        a = torch.randn(M, K, device=device, generator=gl)
+        w = torch.randn(N, K, device=device, generator=gl) * K ** -0.5
+        bias = torch.randn(N, device=device, generator=gl)
+        aux = torch.randn(M, N, device=device, generator=gl) if epi == ops.LIN_MUL else None
+        res = torch.empty(M, N, device=device)
+        t = time_kernel(lambda: ops.linear_f32(a, w, bias if epi in (1, 2, 3) else None, epi, aux=aux, out=res))
+        tile = _abi_tile(M, N, K)
+        out["linear_" + label] = mfma("linear_f32_kernel<%s> %s: (%d,%d) x (%d,%d)^T, epilogue %d" % (tile, label, M, K, N, K, epi), t,
+                                      2.0 * M * N * K)
+        out["linear_" + label]["traffic"] = traffic("linear:" + label)
+        out["linear_" + label]["algorithmic_bytes"] = 4.0 * (M * K + N * K + M * N * (2 if epi in (3, 4) else 1))
     return out
 
 
-def cpu_baseline(budget_s=20.0):
+def _abi_tile(M, N, K):
+    from upp_hip import _abi
+    c = _abi.load().upp_linear_tile(M, N, K)
+    return "%d, %d, %d, %d" % (c >> 12, (c >> 8) & 15, (c >> 4) & 15, c & 15)
+
+
+def linear_family_replay(ts, device):
+    """The upp_linear_f32 launches of ONE training step: their (M, N, K, epilogue) sequence is recorded from an eager run of the
+    step driver's forward + loss + backward, then the same sequence of launches (same shapes, same order, synthetic operands)
+    is captured into a HIP graph and its replay timed with HIP events on the launch stream -- device time of the family without
+    the host, with the kernel-to-kernel boundaries of a real step (~1.2 us each) included.
+    -> (flops per step, ms per step, launches, per-shape rows)."""
+    from upp_hip import ops
+    ts._forward_backward()
+    with ops.time_linear_calls() as scope:
+        ts._forward_backward()
+    calls = [(M, N, K, e) for M, N, K, e, _ in scope.report()]
+    gl = torch.Generator(device=device).manual_seed(5)
+    bufs = {}
+    for M, N, K, e in calls:
+        if (M, N, K) not in bufs:
+            bufs[(M, N, K)] = (torch.randn(M, K, device=device, generator=gl), torch.randn(N, K, device=device, generator=gl) * K ** -0.5,
+                               torch.randn(N, device=device, generator=gl), torch.randn(M, N, device=device, generator=gl),
+                               torch.empty(M, N, device=device), torch.empty(M, N, device=device))
+
+    def launch(M, N, K, e):
+        a, w, b, x, o, d = bufs[(M, N, K)]
+        lib_aux = x if e == ops.LIN_MUL else None
+        ops.linear_f32(a, w, b if e in (1, 2, 3) else None, e, aux=lib_aux, out=o)
+
+    def run_all():
+        for c in calls:
+            launch(*c)
+    ms = time_kernel(run_all, iters=1, warm=2)
+    by = {}
+    for c in calls:
+        by[c] = by.get(c, 0) + 1
+    shapes = []
+    for (M, N, K, e), n in sorted(by.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2]):
+        t = time_kernel(lambda: launch(M, N, K, e), iters=10, warm=1)
+        shapes.append({"M": M, "N": N, "K": K, "epilogue": e, "launches_per_step": n, "ms_per_launch": t, "tflops": 2.0 * M * N * K / t / 1e9})
+    return sum(2.0 * M * N * K for M, N, K, _ in calls), ms, len(calls), shapes
+
+
+def cpu_baseline(budget_s=20.0, batch=32):
     """The same training step on the host cores: torch-CPU dense ops + the C oracle (OpenMP) for
-    FPS / kNN.  Bounded sample: B=4 clouds, as many steps as fit ~budget_s (at least 1)."""
+    FPS / kNN.  Bounded sample: the same batch (B=32 clouds), as many steps as fit ~budget_s (at least 1)."""
     import oracle
     from models import upp_layers
     from upp_hip import functional as HF
@@ -374,7 +450,7 @@ def cpu_baseline(budget_s=20.0):
         ops = oracle.torch_ops()
         upp_layers.OPS.update(ops)
         HF.fps_gather = ops["fps_gather"]
-        tr = Trainer(torch.device("cpu"), 4, False, use_graph=False)
+        tr = Trainer(torch.device("cpu"), batch, False, use_graph=False)
         tr.step()                                   # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
@@ -383,9 +459,9 @@ def cpu_baseline(budget_s=20.0):
             el = time.perf_counter() - t0
             if el > budget_s or n >= 200:
                 break
-        return {"value": 4 * n / el, "unit": "clouds/s", "cores": cores, "kind": "port",
-                "sample": "%d steps of B=4 noisy-train fwd+bwd+AdamW on torch-CPU + C oracle (OpenMP %d thr) in %.1f s"
-                          % (n, oracle.num_threads(), el)}
+        return {"value": batch * n / el, "unit": "clouds/s", "cores": cores, "kind": "port",
+                "sample": "%d steps of B=%d noisy-train fwd+bwd+AdamW on torch-CPU + C oracle (OpenMP %d thr) in %.1f s"
+                          % (n, batch, oracle.num_threads(), el)}
     finally:
         upp_layers.OPS.clear()
         upp_layers.OPS.update(saved[0])
@@ -439,6 +515,9 @@ def main():
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM solutions (see upp_hip/gemm_tuning.py)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the prompting front-end and the trainable back-end of a step one after the other (one stream)")
+    ap.add_argument("--no-stage-report", action="store_true",
+                    help="skip the stand-alone kernel timings and the in-situ Linear timing (profiling runs: the rocprofv3 trace then "
+                         "holds the step's own launches only)")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="ranks only rendezvous, barrier and reduce a dummy time, rank 0 prints the JSON skeleton: checks the "
                          "--gpus N launcher and the process-group plumbing on a host without a GPU (tests/test_host.py)")
@@ -512,10 +591,6 @@ def main():
                        "pipeline": "front-end(k+1) || back-end(k) on two streams" if pipeline else "none"}}))
     elif rank == 0:
         clouds = args.batch * world * args.steps
-        stages = stage_report(device, args.batch)
-        # dominant hand-written kernel family of the step by GPU time: the patch-embed MFMA chain (0.82 ms of the 7.7 ms of
-        # kernel time per step; row kernels 0.70, FPS 0.62, attention 0.61 -- DESIGN.md section 5); FPS / kNN are in `kernels`
-        dom = dict(stages["patch_embed_chain"])
         line = {
             "metric": "point-clouds/sec fwd+bwd, UPP/Point-MAE N=1024 G=64 k=32",
             "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -527,11 +602,40 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph,
                        "pipeline": "front-end(k+1) || back-end(k) on two streams" if pipeline else "none"},
-            "roofline": dom,
-            "kernels": stages,
         }
+        if not args.no_stage_report:
+            # one-stream step time + the dominant kernel family of the step, measured inside the step
+            seq = tr
+            if world == 1 and pipeline:
+                seq = Trainer(device, args.batch, False, use_graph=not args.no_graph, pipeline=False)
+                for _ in range(max(args.warmup, 2)):
+                    seq.step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    seq.step()
+                torch.cuda.synchronize()
+                line["ms_per_step_sequential"] = 1000.0 * (time.perf_counter() - t1) / args.steps
+            elif not pipeline:
+                line["ms_per_step_sequential"] = line["ms_per_step"]
+            flops, ms, n, shapes = linear_family_replay(seq.ts, device)
+            tf = flops / ms / 1e9
+            stages = stage_report(device, args.batch)
+            pmc_step = [stages["linear_" + lab].get("traffic") for lab, *_ in LINEAR_SHAPES]
+            line["roofline"] = {
+                "kernel": "linear_f32_kernel<*> (csrc/linear.hip): the %d upp_linear_f32 launches of one step -- QKV / proj / fc1 / fc2 of "
+                          "every Transformer block pass and their data gradients; the kernel family with the most GPU time per step" % n,
+                "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                "ms": ms, "launches": n, "algorithmic_flops": flops,
+                "traffic": None if any(v is None for v in pmc_step) else sum(pmc_step),
+                "traffic_note": "PMC bytes of the eight launches of ONE block at M = 2400 (kernels.linear_*), not of the whole step",
+                "how": "the step's launch sequence (recorded from an eager step) replayed as one HIP graph, HIP events on the launch "
+                       "stream; kernel-to-kernel boundaries included.  profiles/r02_bench_sequential_kernel_stats.csv holds the same "
+                       "launches inside the step under rocprofv3 (sum of linear_f32_kernel<*> over 14 executions of the step)",
+                "by_shape": shapes}
+            line["kernels"] = stages
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(batch=args.batch)
         print(json.dumps(line))
     if distributed:
         dist.barrier()

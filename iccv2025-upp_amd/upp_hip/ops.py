@@ -219,6 +219,25 @@ def patch_embed_fwd(point_groups, enc, training):
 LIN_NONE, LIN_BIAS, LIN_BIAS_GELU, LIN_BIAS_GELU_D, LIN_MUL = 0, 1, 2, 3, 4
 
 
+class time_linear_calls:
+    """Measurement scope (bench.py): every upp_linear_f32 launch inside it is bracketed by a pair of HIP events recorded on
+    the launch stream; `.report()` -> [(M, N, K, epilogue, ms)] after a synchronize.  Eager launches only (not under capture)."""
+    active = None
+
+    def __enter__(self):
+        self.calls = []
+        time_linear_calls.active = self
+        return self
+
+    def __exit__(self, *exc):
+        time_linear_calls.active = None
+        return False
+
+    def report(self):
+        torch.cuda.synchronize()
+        return [(M, N, K, e, a.elapsed_time(b)) for (M, N, K, e, a, b) in self.calls]
+
+
 def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
     """C (M,N) = epilogue(a (M,K) . w (N,K)^T) on the FP32 matrix cores (upp_linear_f32).
     a: (..., K) f32 whose rows are K-contiguous with one common row stride; w: (N,K).
@@ -248,8 +267,15 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
             raise RuntimeError("linear_f32: aux must be (M,N)")
     if bias is not None:
         _need(bias, "bias", torch.float32, 1, N)
+    scope = time_linear_calls.active
+    if scope is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _call(a.device, "upp_linear_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(bias), _abi.ptr(out), N,
           _abi.ptr(aux), N, M, N, K, int(epilogue), int(tile))
+    if scope is not None:
+        ev1.record()
+        scope.calls.append((M, N, K, int(epilogue), ev0, ev1))
     return (out, d) if epilogue == LIN_BIAS_GELU_D else out
 
 

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Regenerate profiles/r02_* on a GPU box (run from the repo root through gpurun):
+#     gpurun --timeout 1200 -- 'bash tools/make_profiles.sh'
+# rocprofv3 kernel traces of the headline step (one stream / pipelined), of the stand-alone kernels, two PMC passes
+# (FETCH_SIZE, WRITE_SIZE: separate runs, never combined with a trace domain), then the un-profiled bench lines.
+set -e -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r02
+rm -rf $O && mkdir -p $O
+stats() { ls $1/*/*kernel_stats.csv | head -1; }
+trace() { ls $1/*/*kernel_trace.csv | head -1; }
+# (executions of the step per trace: 2 eager warm-ups + 2 replays + 10 timed = 14)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/seq -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipeline --no-stage-report > $O/seq.log 2>&1
+cp "$(stats $O/seq)" $O/r02_bench_sequential_kernel_stats.csv
+python3 tools/phase_summary.py "$(trace $O/seq)" > $O/r02_phase_summary.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/pipe -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stage-report > $O/pipe.log 2>&1
+cp "$(stats $O/pipe)" $O/r02_bench_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kern -- python3 tools/prof_kernels.py > $O/kern.log 2>&1
+cp "$(stats $O/kern)" $O/r02_kernels_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 tools/prof_kernels.py > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 tools/prof_kernels.py > $O/write.log 2>&1
+python3 tools/pmc_summary.py "$(ls $O/fetch/*/*counter_collection.csv | head -1)" "$(ls $O/write/*/*counter_collection.csv | head -1)" "$(trace $O/kern)" > $O/r02_pmc_kernels.json
+python3 bench.py --no-cpu-baseline --no-pipeline > $O/r02_bench_sequential.json 2> $O/bench_seq.err
+python3 bench.py > $O/r02_bench.json 2> $O/bench.err
+rm -rf $O/seq $O/pipe $O/kern $O/fetch $O/write
+ls -la $O

@@ -73,5 +73,20 @@ for _ in range(5):
     xa, h = HF.rowln(tok, add=pos, prompts=prm, mode=HF.ROW_INSERT_CLS, P=10, gamma=g1, beta=b1)
     out = HF.attention(qkv, 6, 0.125)
     out.sum().backward()
+# the Linear layers of one Transformer block on upp_linear_f32 (bench.LINEAR_SHAPES), in a fixed order: tools/pmc_summary.py
+# attributes the i-th linear_f32_kernel dispatch to LINEAR_SHAPES[i % 8] (several shapes share one kernel instantiation)
+sys.path.insert(0, ROOT)
+from bench import LINEAR_SHAPES  # noqa: E402
+gl = torch.Generator(device='cuda').manual_seed(11)
+lin = []
+for label, M, N, K, epi in LINEAR_SHAPES:
+    a_ = torch.randn(M, K, device='cuda', generator=gl)
+    w_ = torch.randn(N, K, device='cuda', generator=gl) * K ** -0.5
+    b_ = torch.randn(N, device='cuda', generator=gl)
+    x_ = torch.randn(M, N, device='cuda', generator=gl) if epi == ops.LIN_MUL else None
+    lin.append((a_, w_, b_ if epi in (1, 2, 3) else None, epi, x_))
+for _ in range(6):
+    for a_, w_, b_, epi, x_ in lin:
+        ops.linear_f32(a_, w_, b_, epi, aux=x_)
 torch.cuda.synchronize()
 print("done")
