@@ -323,24 +323,41 @@ class Encoder(nn.Module):
             return ops.patch_embed_fwd(point_groups.contiguous(), self, self.training)
         return self._forward_torch(point_groups)
 
+    def _w1_k32(self):
+        """Conv1d(3,128) weight zero-padded to K = 32 (the contraction granule of upp_linear_f32); cached while frozen."""
+        w = self.first_conv[0].weight
+        if torch.is_grad_enabled() and w.requires_grad:
+            return F.pad(w.squeeze(-1), (0, 29))
+        key = (w.data_ptr(), w._version)
+        if getattr(self, '_w1p_key', None) != key and not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._w1p, self._w1p_key = F.pad(w.detach().squeeze(-1), (0, 29)).contiguous(), key
+        return self._w1p
+
     def _forward_torch(self, point_groups):
-        """Same math through library GEMMs; differentiable (used when the encoder is being trained)."""
+        """The differentiable formulation (a gradient reaches the encoder: Point-MAE pre-training trains it, stage 2 of the UPP
+        recipe differentiates THROUGH it).  On the GPU every GEMM, forward and backward, is one of this library's kernels:
+        upp_linear_f32 (outputs and data gradients; the K = 3 first layer zero-padded to the 32-wide contraction granule),
+        upp_linear_wgrad_f32 (weight gradients), the BatchNorm(+ReLU) row kernels with their backward; the two max-pools
+        and the group broadcast stay autograd ops.  Reference models/Point_MAE_unify.py:204-222."""
         bs, g, n, _ = point_groups.shape
         c1, bn1, _, c2 = self.first_conv
         c3, bn3, _, c4 = self.second_conv
         x = point_groups.reshape(bs * g * n, 3)
-        h = F.linear(x, c1.weight.squeeze(-1), c1.bias)
+        if x.is_cuda and x.dtype == torch.float32:
+            h = HF.linear(F.pad(x, (0, 29)), self._w1_k32(), c1.bias)
+        else:
+            h = F.linear(x, c1.weight.squeeze(-1), c1.bias)
         if self.training and bn1.track_running_stats:
             bump_counter(bn1.num_batches_tracked)
             bump_counter(bn3.num_batches_tracked)
         h = _bn_rows(h, bn1, self.training, relu=True)
-        f = F.linear(h, c2.weight.squeeze(-1), c2.bias)                    # (BGn, 256)
+        f = HF.linear(h, c2.weight.squeeze(-1), c2.bias)                    # (BGn, 256)
         fg = f.view(bs * g, n, 256).max(dim=1)[0]                           # (BG, 256)
         w3 = c3.weight.squeeze(-1)                                          # (512, 512): [global | local]
-        hg = F.linear(fg, w3[:, :256], c3.bias)                             # (BG, 512) once per group
-        h = F.linear(f, w3[:, 256:]).view(bs * g, n, 512) + hg.unsqueeze(1)
+        hg = HF.linear(fg, w3[:, :256], c3.bias)                            # (BG, 512) once per group (column windows: no copies)
+        h = HF.linear(f, w3[:, 256:]).view(bs * g, n, 512) + hg.unsqueeze(1)
         h = _bn_rows(h.view(bs * g * n, 512), bn3, self.training, relu=True)
-        out = F.linear(h, c4.weight.squeeze(-1), c4.bias)                   # (BGn, C)
+        out = HF.linear(h, c4.weight.squeeze(-1), c4.bias)                  # (BGn, C)
         return out.view(bs * g, n, self.encoder_channel).max(dim=1)[0].view(bs, g, self.encoder_channel)
 
 

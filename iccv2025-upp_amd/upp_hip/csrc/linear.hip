@@ -298,6 +298,121 @@ int launch_linear(const LinArgs &g0, hipStream_t st) {
     return upp_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient  dW (N,K) = G^T . X  of a trainable Linear (G = dY (M,N), X (M,K): the contraction runs over the M token /
+// point rows).  Same machine as above -- LDS-DMA staging, one 32x32 output block per wave, 16 waves -- with the operands
+// "k-major" by nature: a stage is 32 rows of G (128 columns) and of X (128 columns), each row segment 512 contiguous
+// bytes, and the MFMA operands of a lane are single dwords of one LDS row (conflict-free ds_read_b32).  The M rows are split
+// over workgroups (tiles x splits ~ 256..512 workgroups); every split writes its partial (N,K) tile, and the caller sums
+// the splits in order (upp_batched_sum: deterministic, and for a training step straight into the flat gradient buffer).
+struct WgArgs {
+    const float *G; long long ldg;
+    const float *X; long long ldx;
+    float *P;                     // (splits, N, K)
+    int M, N, K, tiles_k, rows_per_split;
+};
+
+template <int BNB, int BKB>
+__global__ __launch_bounds__(BNB *BKB * 64) void linear_wgrad_kernel(WgArgs g) {
+    constexpr int NW = BNB * BKB, BN = 32 * BNB, BK = 32 * BKB;
+    constexpr int STAGE = 32 * (BN + BK) * 4;               // 32 rows of [G tile | X tile], row-major, one after the other
+    constexpr int TG = BN / 8, T = (BN + BK) / 8;            // DMA instructions (1 KB each) per stage: first TG fill the G part
+    constexpr int TPW = (T + NW - 1) / NW;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, split = blockIdx.y;          // gridDim.y = splits
+    const int tn = tile / g.tiles_k, tk = tile - tn * g.tiles_k;
+    const int n0 = tn * BN, k0 = tk * BK;
+    const int ms = split * g.rows_per_split, me = min(g.M, ms + g.rows_per_split);
+    const int bn = wave / BKB, bk = wave - bn * BKB;
+
+    // DMA sources: instruction t covers granules 64 t .. 64 t + 63 of its part; a row of a part is BN/4 (BK/4) granules.
+    // Rows beyond M are clamped to the last row (their products are masked below); columns beyond N / K to the last granule
+    // (their outputs are not stored).
+    const float *colptr[TPW];
+    long long ldq[TPW];
+    int row0[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * NW;
+        const bool isG = (t < T ? t : 0) < TG;
+        const int tt = isG ? t : (t < T ? t : TG) - TG;
+        const int per_row = (isG ? BN : BK) / 4;
+        const int gq = tt * 64 + lane, row = gq / per_row, c4 = gq - row * per_row;
+        const int col = min((isG ? n0 : k0) + 4 * c4, (isG ? g.N : g.K) - 4);
+        colptr[q] = (isG ? g.G : g.X) + col;
+        ldq[q] = isG ? g.ldg : g.ldx;
+        row0[q] = ms + row;
+    }
+    auto issue1 = [&](int q, int stage, int c) {
+        const int t = wave + q * NW;
+        if (TPW * NW == T || t < T) {
+            const int qq = q < TPW ? q : 0;
+            const int row = min(row0[qq] + 32 * c, g.M - 1);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(colptr[qq] + row * ldq[qq]), (lds_ptr_t)(lds + stage * STAGE + t * 1024), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int stage, int c) {
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) issue1(q, stage, c);
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    const unsigned adrG = lds0 + (h * BN + bn * 32 + r) * 4, adrX = lds0 + 32 * BN * 4 + (h * BK + bk * 32 + r) * 4;
+    const int nst = (me - ms + 31) / 32;
+    if (nst > 0) issue(0, 0);
+    for (int c = 0; c < nst; ++c) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (c + 1 < nst) issue((c + 1) & 1, c + 1);
+        const unsigned so = (c & 1) * STAGE;
+        const int left = me - ms - 32 * c - h;                 // rows 2 s + h of this stage exist while 2 s < left
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = 4 * s4 + u;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(a[u]) : "v"(adrG + so + s * (2 * BN * 4)));
+                asm volatile("ds_read_b32 %0, %1" : "=v"(b[u]) : "v"(adrX + so + s * (2 * BK * 4)));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float av = 2 * (4 * s4 + u) < left ? a[u] : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u], acc, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // partial tile of this split: register t = dW[n][k], n = n0 + 32 bn + (t & 3) + 8 (t >> 2) + 4 h, k = k0 + 32 bk + (lane & 31)
+    const int kk = k0 + bk * 32 + r;
+    if (kk >= g.K) return;
+    float *out = g.P + (long long)split * g.N * g.K + kk;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int n = n0 + bn * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+        if (n < g.N) out[(long long)n * g.K] = acc[t];
+    }
+}
+
+inline void wgrad_geometry(int M, int N, int K, int &tiles_n, int &tiles_k, int &splits, int &rows_per_split) {
+    tiles_n = (N + 127) / 128; tiles_k = (K + 127) / 128;
+    const int tiles = tiles_n * tiles_k, chunks = (M + 31) / 32;
+    splits = (384 + tiles - 1) / tiles;                          // ~1.5 workgroups per CU: the splits even out the tail
+    if (splits > chunks) splits = chunks;
+    if (splits > 256) splits = 256;
+    if (splits < 1) splits = 1;
+    rows_per_split = ((chunks + splits - 1) / splits) * 32;
+    splits = (M + rows_per_split - 1) / rows_per_split;
+}
+
 struct LinConfig { int bmb, bnb, ks, kc; };
 #define UPP_LIN_CONFIGS(X) X(4, 4, 1, 2) X(4, 3, 1, 1) X(3, 4, 1, 1) X(2, 4, 2, 1) X(2, 3, 2, 1) X(2, 2, 4, 1) X(1, 2, 4, 1)
 #define UPP_LIN_ENTRY(a, b, c, d) {a, b, c, d},
@@ -372,4 +487,24 @@ extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, lon
         default: return UPP_E_RANGE;
     }
 #undef UPP_LIN_CASE
+}
+
+extern "C" int upp_linear_wgrad_splits(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
+    int tn, tk, splits, rps;
+    wgrad_geometry(M, N, K, tn, tk, splits, rps);
+    return splits;
+}
+
+extern "C" int upp_linear_wgrad_f32(const float *G, long long ldg, const float *X, long long ldx, float *partials, int M, int N, int K,
+                                    void *stream) {
+    if (!G || !X || !partials || M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
+    if (N % 4 != 0 || K % 4 != 0 || ldg % 4 != 0 || ldx % 4 != 0 || ldg < N || ldx < K) return UPP_E_RANGE;
+    if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(X)) & 15) return UPP_E_RANGE;
+    WgArgs g{};
+    int tn, splits;
+    wgrad_geometry(M, N, K, tn, g.tiles_k, splits, g.rows_per_split);
+    g.G = G; g.ldg = ldg; g.X = X; g.ldx = ldx; g.P = partials; g.M = M; g.N = N; g.K = K;
+    hipLaunchKernelGGL((linear_wgrad_kernel<4, 4>), dim3((unsigned)(tn * g.tiles_k), (unsigned)splits), dim3(1024), 0, (hipStream_t)stream, g);
+    return upp_launch_status();
 }

@@ -334,26 +334,32 @@ class _TransposedWeights:
     def __init__(self):
         self.entries = {}
 
+    @staticmethod
+    def _view_of(owner, geom):
+        return torch.as_strided(owner.detach(), geom[0], geom[1], geom[2])
+
     def get(self, w):
-        key = (w.data_ptr(), tuple(w.shape))
+        owner = w._base if w._base is not None else w        # a column window of a parameter (w3[:, 256:]) shares its version counter
+        geom = (tuple(w.shape), tuple(w.stride()), w.storage_offset())
+        key = (w.data_ptr(),) + geom
         e = self.entries.get(key)
         if e is None or e[0]() is None:
             if len(self.entries) > 1024:
                 self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
             wt = w.detach().t().contiguous()
-            self.entries[key] = [weakref.ref(w), w._version, wt]
+            self.entries[key] = [weakref.ref(owner), owner._version, wt, geom]
             return wt
-        if e[1] != w._version and not torch.cuda.is_current_stream_capturing():
+        if e[1] != owner._version and not torch.cuda.is_current_stream_capturing():
             e[2].copy_(w.detach().t())
-            e[1] = w._version
+            e[1] = owner._version
         return e[2]
 
     def refresh(self):
         for e in self.entries.values():
-            w = e[0]()
-            if w is not None:
-                e[2].copy_(w.detach().t())
-                e[1] = w._version
+            owner = e[0]()
+            if owner is not None:
+                e[2].copy_(self._view_of(owner, e[3]).t())
+                e[1] = owner._version
 
 
 TRANSPOSED = _TransposedWeights()
@@ -366,7 +372,8 @@ def _wt(w):
 
 def linear_usable(x, weight):
     """upp_linear_f32 serves f32 HIP operands whose contraction length is a multiple of 32."""
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and weight.is_contiguous()
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and weight.stride(1) == 1
+            and weight.stride(0) % 4 == 0 and weight.data_ptr() % 16 == 0
             and x.shape[-1] == weight.shape[1] and weight.shape[1] % 32 == 0 and x.numel() > 0)
 
 
@@ -395,10 +402,22 @@ class _LinearMFMA(Function):
                 note_declined("linear data gradient", "N = %d is not a multiple of 32" % wt.shape[1])
                 gx = torch.mm(g2, w).view(g.shape[:-1] + (w.shape[1],))
         if ctx.needs_input_grad[1]:
-            gw = torch.mm(g2.t(), x.reshape(-1, x.shape[-1]))
+            gw = weight_grad(g2, x.reshape(-1, x.shape[-1]), w)
         if b_needed(ctx):
             _, gb = _DEFERRED.reduce(ctx.bias_ptr, g2, 0, g2.shape[1])
         return gx, gw, gb
+
+
+def weight_grad(g2, x2, w):
+    """dW = g2^T . x2 for the trainable weight w (N,K): upp_linear_wgrad_f32 partials, summed in split order -- inside a
+    training step by the deferred batched sum, straight into w's slot of the flat gradient buffer (then None is returned)."""
+    N, K = g2.shape[1], x2.shape[1]
+    if N % 4 or K % 4 or x2.stride(1) != 1 or x2.stride(0) % 4 or g2.stride(0) % 4:
+        note_declined("linear weight gradient (%d,%d)" % (N, K), "N % 4 / K % 4 / row alignment")
+        return torch.mm(g2.t(), x2)
+    part = ops.linear_wgrad(g2, x2)
+    _, gw = _DEFERRED.reduce(w.data_ptr(), part.view(part.shape[0], N * K), 0, N * K)
+    return None if gw is None else gw.view(N, K)
 
 
 def b_needed(ctx):

@@ -242,7 +242,8 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
     """C (M,N) = epilogue(a (M,K) . w (N,K)^T) on the FP32 matrix cores (upp_linear_f32).
     a: (..., K) f32 whose rows are K-contiguous with one common row stride; w: (N,K).
     epilogue LIN_BIAS_GELU_D returns (C, GELU'); LIN_MUL multiplies by aux (M,N)."""
-    _need(w, "w", torch.float32, 2)
+    if not (isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1):
+        raise RuntimeError("w must be a 2-D f32 HIP (cuda) matrix with contiguous rows; upp_hip has no CPU path")
     if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.float32):
         raise RuntimeError("a must be a f32 HIP (cuda) tensor; upp_hip has no CPU path")
     _same_device(a, w)
@@ -277,6 +278,23 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
         ev1.record()
         scope.calls.append((M, N, K, int(epilogue), ev0, ev1))
     return (out, d) if epilogue == LIN_BIAS_GELU_D else out
+
+
+def linear_wgrad(g, x):
+    """Partial weight gradients (splits, N, K) of y = x . W^T: sum over dim 0 = g^T . x  (g (M,N), x (M,K); upp_linear_wgrad_f32).
+    The caller sums the splits (batched_sum / the deferred sums of a training step)."""
+    for t, name in ((g, "g"), (x, "x")):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise RuntimeError(f"{name} must be a 2-D f32 HIP (cuda) matrix with contiguous rows; upp_hip has no CPU path")
+    _same_device(g, x)
+    M, N = g.shape
+    K = x.shape[1]
+    if x.shape[0] != M:
+        raise RuntimeError("linear_wgrad: row counts differ")
+    splits = _abi.load().upp_linear_wgrad_splits(M, N, K)
+    part = torch.empty((splits, N, K), dtype=torch.float32, device=g.device)
+    _call(g.device, "upp_linear_wgrad_f32", _abi.ptr(g), g.stride(0), _abi.ptr(x), x.stride(0), _abi.ptr(part), M, N, K)
+    return part
 
 
 def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want_xo=True, ybias=None):

@@ -395,6 +395,13 @@ int upp_adapter_bwd(const float *g_out, const float *ha, const float *s1, const 
  *         anything else is UPP_E_RANGE; for measurements.
  * Limits: K % 32 == 0 (K % (32 KS KC) == 0 for a forced tile), lda % 4 == 0, ldw % 4 == 0, A and W 16-byte aligned. */
 int upp_linear_tile(int M, int N, int K);
+/* Weight gradient of a trainable Linear (AddmmBackward's second GEMM in the reference): dW (N,K) = G^T . X with G = dY (M,N)
+ * and X (M,K) row-major (leading dimensions ldg, ldx).  The M rows are split over upp_linear_wgrad_splits(M,N,K) groups of
+ * workgroups; `partials` (splits, N, K) receives one partial dW per split and the caller sums them in order (upp_batched_sum).
+ * Limits: N % 4 == 0, K % 4 == 0, ldg % 4 == 0, ldx % 4 == 0, G and X 16-byte aligned. */
+int upp_linear_wgrad_splits(int M, int N, int K);
+int upp_linear_wgrad_f32(const float *G, long long ldg, const float *X, long long ldx, float *partials,
+                         int M, int N, int K, void *stream);
 int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias,
                    float *C, long long ldc, float *aux, long long ldaux,
                    int M, int N, int K, int epilogue, int tile, void *stream);
