@@ -312,13 +312,19 @@ struct WgArgs {
     int M, N, K, tiles_k, rows_per_split;
 };
 
-template <int BNB, int BKB>
-__global__ __launch_bounds__(BNB *BKB * 64) void linear_wgrad_kernel(WgArgs g) {
-    constexpr int NW = BNB * BKB, BN = 32 * BNB, BK = 32 * BKB;
-    constexpr int STAGE = 32 * (BN + BK) * 4;               // 32 rows of [G tile | X tile], row-major, one after the other
-    constexpr int TG = BN / 8, T = (BN + BK) / 8;            // DMA instructions (1 KB each) per stage: first TG fill the G part
+template <int BNB, int BKB, int KS>
+__global__ __launch_bounds__(BNB *BKB *KS * 64) void linear_wgrad_kernel(WgArgs g) {
+    // KS wave groups work on KS consecutive 32-row slabs of a stage (small M: the rows are split INSIDE the workgroup and
+    // summed through the LDS, so 64 x 64 tiles give enough workgroups without partial tiles in memory)
+    constexpr int NW = BNB * BKB * KS, BN = 32 * BNB, BK = 32 * BKB;
+    constexpr int SLAB = 32 * (BN + BK) * 4;                 // 32 rows of [G tile | X tile], row-major, one after the other
+    constexpr int STAGE = KS * SLAB;
+    constexpr int TG = BN / 8, TS = (BN + BK) / 8, T = KS * TS;  // DMA instructions (1 KB each): per slab the first TG fill the G part
     constexpr int TPW = (T + NW - 1) / NW;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+    constexpr int RED = KS > 1 ? NW * 4096 : 0;
+    constexpr int LDS_BYTES = 2 * STAGE > RED ? 2 * STAGE : RED;
+    static_assert(TPW * NW == T && LDS_BYTES <= 160 * 1024, "wgrad geometry");
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
@@ -326,52 +332,50 @@ __global__ __launch_bounds__(BNB *BKB * 64) void linear_wgrad_kernel(WgArgs g) {
     const int tn = tile / g.tiles_k, tk = tile - tn * g.tiles_k;
     const int n0 = tn * BN, k0 = tk * BK;
     const int ms = split * g.rows_per_split, me = min(g.M, ms + g.rows_per_split);
-    const int bn = wave / BKB, bk = wave - bn * BKB;
+    const int ks = wave / (BNB * BKB), wb = wave - ks * (BNB * BKB);
+    const int bn = wb / BKB, bk = wb - bn * BKB;
 
-    // DMA sources: instruction t covers granules 64 t .. 64 t + 63 of its part; a row of a part is BN/4 (BK/4) granules.
-    // Rows beyond M are clamped to the last row (their products are masked below); columns beyond N / K to the last granule
-    // (their outputs are not stored).
+    // DMA sources: instruction t = slab * TS + tt covers granules 64 tt .. 64 tt + 63 of its part of that slab; a row of a part
+    // is BN/4 (BK/4) granules.  Rows beyond M are clamped to the last row (their products are masked below); columns beyond
+    // N / K to the last granule (their outputs are not stored).
     const float *colptr[TPW];
     long long ldq[TPW];
     int row0[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int t = wave + q * NW;
-        const bool isG = (t < T ? t : 0) < TG;
-        const int tt = isG ? t : (t < T ? t : TG) - TG;
+        const int slab = t / TS, ts = t - slab * TS;
+        const bool isG = ts < TG;
+        const int tt = isG ? ts : ts - TG;
         const int per_row = (isG ? BN : BK) / 4;
         const int gq = tt * 64 + lane, row = gq / per_row, c4 = gq - row * per_row;
         const int col = min((isG ? n0 : k0) + 4 * c4, (isG ? g.N : g.K) - 4);
         colptr[q] = (isG ? g.G : g.X) + col;
         ldq[q] = isG ? g.ldg : g.ldx;
-        row0[q] = ms + row;
+        row0[q] = ms + 32 * slab + row;
     }
-    auto issue1 = [&](int q, int stage, int c) {
-        const int t = wave + q * NW;
-        if (TPW * NW == T || t < T) {
-            const int qq = q < TPW ? q : 0;
-            const int row = min(row0[qq] + 32 * c, g.M - 1);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(colptr[qq] + row * ldq[qq]), (lds_ptr_t)(lds + stage * STAGE + t * 1024), 16, 0, 0);
-        }
-    };
     auto issue = [&](int stage, int c) {
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) issue1(q, stage, c);
+        for (int q = 0; q < TPW; ++q) {
+            const int t = wave + q * NW;
+            const int row = min(row0[q] + 32 * KS * c, g.M - 1);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(colptr[q] + row * ldq[q]), (lds_ptr_t)(lds + stage * STAGE + t * 1024), 16, 0, 0);
+        }
     };
 
     f32x16 acc;
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds + ks * SLAB;
     const unsigned adrG = lds0 + (h * BN + bn * 32 + r) * 4, adrX = lds0 + 32 * BN * 4 + (h * BK + bk * 32 + r) * 4;
-    const int nst = (me - ms + 31) / 32;
+    const int nst = (me - ms + 32 * KS - 1) / (32 * KS);
     if (nst > 0) issue(0, 0);
     for (int c = 0; c < nst; ++c) {
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (c + 1 < nst) issue((c + 1) & 1, c + 1);
         const unsigned so = (c & 1) * STAGE;
-        const int left = me - ms - 32 * c - h;                 // rows 2 s + h of this stage exist while 2 s < left
+        const int left = me - ms - 32 * (c * KS + ks) - h;     // rows 2 s + h of this wave group's slab exist while 2 s < left
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             float a[4], b[4];
@@ -391,22 +395,58 @@ __global__ __launch_bounds__(BNB *BKB * 64) void linear_wgrad_kernel(WgArgs g) {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // wave groups: partial blocks through the LDS, summed in group order; group ks finishes registers [T0, T0 + TN)
+    constexpr int TN = 16 / KS;
+    const int T0 = ks * TN;
+    float outv[TN];
+    if (KS > 1) {
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) red[(wave * 16 + t) * 64 + lane] = acc[t];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int k2 = 0; k2 < KS; ++k2) sum += red[((k2 * (BNB * BKB) + wb) * 16 + T0 + u) * 64 + lane];
+            outv[u] = sum;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < TN; ++u) outv[u] = acc[u];
+    }
     // partial tile of this split: register t = dW[n][k], n = n0 + 32 bn + (t & 3) + 8 (t >> 2) + 4 h, k = k0 + 32 bk + (lane & 31)
     const int kk = k0 + bk * 32 + r;
     if (kk >= g.K) return;
     float *out = g.P + (long long)split * g.N * g.K + kk;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int u = 0; u < TN; ++u) {
+        const int t = T0 + u;
         const int n = n0 + bn * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
-        if (n < g.N) out[(long long)n * g.K] = acc[t];
+        if (n < g.N) out[(long long)n * g.K] = outv[u];
     }
 }
 
+// Two shapes: 128 x 128 tiles with the rows split over workgroups (many rows: the 65,536-row layers of the patch embedding and
+// the segmentation head), and 64 x 64 tiles whose four wave groups split the rows inside the workgroup (the M <= a few
+// thousand token matrices of the Transformer blocks: enough workgroups without partial tiles; measured on the pre-training
+// step: 128 x 128 tiles with 9-11 row splits cost 28 us per launch + 1.3 ms per step of partial sums).
+inline bool wgrad_small(int M, int N, int K) { return (long long)M * 4 <= 8192LL * 4 && ((N + 63) / 64) * ((K + 63) / 64) >= 24; }
+
 inline void wgrad_geometry(int M, int N, int K, int &tiles_n, int &tiles_k, int &splits, int &rows_per_split) {
-    tiles_n = (N + 127) / 128; tiles_k = (K + 127) / 128;
-    const int tiles = tiles_n * tiles_k, chunks = (M + 31) / 32;
-    splits = (384 + tiles - 1) / tiles;                          // ~1.5 workgroups per CU: the splits even out the tail
-    if (splits > chunks) splits = chunks;
+    const int chunks = (M + 31) / 32;
+    if (wgrad_small(M, N, K)) {
+        tiles_n = (N + 63) / 64; tiles_k = (K + 63) / 64;
+        const int tiles = tiles_n * tiles_k;
+        splits = tiles >= 224 ? 1 : (287 + tiles) / tiles;        // fewer tiles than CUs: a little row splitting on top
+        if (splits > (chunks + 7) / 8) splits = (chunks + 7) / 8;
+    } else {
+        tiles_n = (N + 127) / 128; tiles_k = (K + 127) / 128;
+        const int tiles = tiles_n * tiles_k;
+        splits = (384 + tiles - 1) / tiles;                       // ~1.5 workgroups per CU: the splits even out the tail
+        if (splits > (chunks + 7) / 8) splits = (chunks + 7) / 8; // at least 8 stages of 32 rows per split
+    }
     if (splits > 256) splits = 256;
     if (splits < 1) splits = 1;
     rows_per_split = ((chunks + splits - 1) / splits) * 32;
@@ -505,6 +545,8 @@ extern "C" int upp_linear_wgrad_f32(const float *G, long long ldg, const float *
     int tn, splits;
     wgrad_geometry(M, N, K, tn, g.tiles_k, splits, g.rows_per_split);
     g.G = G; g.ldg = ldg; g.X = X; g.ldx = ldx; g.P = partials; g.M = M; g.N = N; g.K = K;
-    hipLaunchKernelGGL((linear_wgrad_kernel<4, 4>), dim3((unsigned)(tn * g.tiles_k), (unsigned)splits), dim3(1024), 0, (hipStream_t)stream, g);
+    const dim3 grid((unsigned)(tn * g.tiles_k), (unsigned)splits);
+    if (wgrad_small(M, N, K)) hipLaunchKernelGGL((linear_wgrad_kernel<2, 2, 4>), grid, dim3(1024), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((linear_wgrad_kernel<4, 4, 1>), grid, dim3(1024), 0, (hipStream_t)stream, g);
     return upp_launch_status();
 }
