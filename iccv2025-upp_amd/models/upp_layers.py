@@ -344,20 +344,20 @@ class Encoder(nn.Module):
         c3, bn3, _, c4 = self.second_conv
         x = point_groups.reshape(bs * g * n, 3)
         if x.is_cuda and x.dtype == torch.float32:
-            h = HF.linear(F.pad(x, (0, 29)), self._w1_k32(), c1.bias)
+            h = HF.linear(F.pad(x, (0, 29)), self._w1_k32(), c1.bias, own_wgrad=True)
         else:
             h = F.linear(x, c1.weight.squeeze(-1), c1.bias)
         if self.training and bn1.track_running_stats:
             bump_counter(bn1.num_batches_tracked)
             bump_counter(bn3.num_batches_tracked)
         h = _bn_rows(h, bn1, self.training, relu=True)
-        f = HF.linear(h, c2.weight.squeeze(-1), c2.bias)                    # (BGn, 256)
+        f = HF.linear(h, c2.weight.squeeze(-1), c2.bias, own_wgrad=True)                    # (BGn, 256)
         fg = f.view(bs * g, n, 256).max(dim=1)[0]                           # (BG, 256)
         w3 = c3.weight.squeeze(-1)                                          # (512, 512): [global | local]
-        hg = HF.linear(fg, w3[:, :256], c3.bias)                            # (BG, 512) once per group (column windows: no copies)
-        h = HF.linear(f, w3[:, 256:]).view(bs * g, n, 512) + hg.unsqueeze(1)
+        hg = HF.linear(fg, w3[:, :256], c3.bias, own_wgrad=True)                            # (BG, 512) once per group (column windows: no copies)
+        h = HF.linear(f, w3[:, 256:], own_wgrad=True).view(bs * g, n, 512) + hg.unsqueeze(1)
         h = _bn_rows(h.view(bs * g * n, 512), bn3, self.training, relu=True)
-        out = HF.linear(h, c4.weight.squeeze(-1), c4.bias)                  # (BGn, C)
+        out = HF.linear(h, c4.weight.squeeze(-1), c4.bias, own_wgrad=True)                  # (BGn, C)
         return out.view(bs * g, n, self.encoder_channel).max(dim=1)[0].view(bs, g, self.encoder_channel)
 
 

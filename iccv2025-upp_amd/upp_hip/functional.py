@@ -382,9 +382,10 @@ class _LinearMFMA(Function):
     (not on the PEFT hot path: the Transformer weights are frozen there); a trainable bias takes the deferred column sum."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, own_wgrad=False):
         ctx.save_for_backward(x if w.requires_grad else None, w)
         ctx.bias_ptr = b.data_ptr() if b is not None else 0
+        ctx.own_wgrad = own_wgrad
         return ops.linear_f32(x, w, b, ops.LIN_BIAS if b is not None else ops.LIN_NONE)
 
     @staticmethod
@@ -402,23 +403,23 @@ class _LinearMFMA(Function):
                 note_declined("linear data gradient", "N = %d is not a multiple of 32" % wt.shape[1])
                 gx = torch.mm(g2, w).view(g.shape[:-1] + (w.shape[1],))
         if ctx.needs_input_grad[1]:
-            gw = weight_grad(g2, x.reshape(-1, x.shape[-1]), w)
+            gw = weight_grad(g2, x.reshape(-1, x.shape[-1]), w, ctx.own_wgrad)
         if b_needed(ctx):
             _, gb = _DEFERRED.reduce(ctx.bias_ptr, g2, 0, g2.shape[1])
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 WGRAD_MIN_ROWS = int(os.environ.get("UPP_WGRAD_MIN_ROWS", "4096"))
 
 
-def weight_grad(g2, x2, w):
+def weight_grad(g2, x2, w, own=False):
     """dW = g2^T . x2 for the trainable weight w (N,K): upp_linear_wgrad_f32 partials, summed in split order -- inside a
     training step by the deferred batched sum, straight into w's slot of the flat gradient buffer (then None is returned)."""
     N, K = g2.shape[1], x2.shape[1]
     if N % 4 or K % 4 or x2.stride(1) != 1 or x2.stride(0) % 4 or g2.stride(0) % 4:
         note_declined("linear weight gradient (%d,%d)" % (N, K), "N % 4 / K % 4 / row alignment")
         return torch.mm(g2.t(), x2)
-    if g2.shape[0] < WGRAD_MIN_ROWS:
+    if g2.shape[0] < WGRAD_MIN_ROWS and not own:
         # measured (pre-training step, M = 864 / 2080 token rows, profiles/r02_workload_pretrain_*): the 64 x 64-tile variant
         # of upp_linear_wgrad_f32 takes 25 us per launch where the library's split-K solutions take ~12 us -- 65 launches per
         # step, 9.36 against 8.23 ms.  The many-row layers (patch embedding, segmentation head: M = 65,536) run on ours.
@@ -433,16 +434,17 @@ def b_needed(ctx):
     return len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]
 
 
-def linear(x, weight, bias=None):
+def linear(x, weight, bias=None, own_wgrad=False):
     """F.linear on the FP32 matrix cores (upp_linear_f32) where the shapes allow; otherwise the library GEMM (said once
-    under UPP_VERBOSE)."""
+    under UPP_VERBOSE).  own_wgrad: the weight gradient of a trainable layer on upp_linear_wgrad_f32 whatever the row count
+    (the patch embedding; default: below WGRAD_MIN_ROWS rows the library's split-K GEMM is faster and is used)."""
     if not linear_usable(x, weight):
         if x.is_cuda:
             note_declined("linear %s x %s" % (tuple(x.shape), tuple(weight.shape)), "dtype / layout / K % 32")
         return F.linear(x, weight, bias)
     if not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         return ops.linear_f32(x, weight, bias, ops.LIN_BIAS if bias is not None else ops.LIN_NONE)
-    return _LinearMFMA.apply(x, weight, bias)
+    return _LinearMFMA.apply(x, weight, bias, bool(own_wgrad))
 
 
 class _MlpGelu(Function):
