@@ -24,3 +24,11 @@ python3 bench.py --no-cpu-baseline --no-pipeline > $O/r02_bench_sequential.json 
 python3 bench.py > $O/r02_bench.json 2> $O/bench.err
 rm -rf $O/seq $O/pipe $O/kern $O/fetch $O/write
 ls -la $O
+# secondary recipes: un-profiled lines + one kernel summary for the pre-training step (8 executions: 2 eager + 1 replay + 5 timed)
+for w in cls_aux stage2 pretask pretrain seg; do python3 bench.py --workload $w --steps 10 --warmup 3 > $O/r02_workload_$w.json 2> $O/w_$w.err; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/pre -- python3 bench.py --workload pretrain --steps 5 --warmup 1 > $O/pre.log 2>&1
+cp "$(stats $O/pre)" $O/r02_workload_pretrain_kernel_stats.csv
+rm -rf $O/pre
+python3 tools/time_linear.py --tiles > $O/r02_time_linear.jsonl 2> /dev/null
+python3 tools/_fmt_linear.py $O/r02_time_linear.jsonl > $O/r02_time_linear.txt
+ls -la $O
