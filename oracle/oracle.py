@@ -47,6 +47,7 @@ def lib():
         L.oracle_emd_approxmatch.argtypes = [_f, _f, _int, _int, _int, _f]
         L.oracle_emd_matchcost.argtypes = [_f, _f, _f, _int, _int, _int, _f]
         L.oracle_emd_matchcost_grad.argtypes = [_f, _f, _f, _f, _int, _int, _int, _f, _f]
+        L.oracle_linear_f32.argtypes = [_f, _f, ctypes.c_void_p, ctypes.c_void_p, _f, _int, _int, _int, _int, _int, _int]
         L.oracle_num_threads.restype = _int
         L.oracle_set_threads.argtypes = [_int]
         _lib = L
@@ -162,6 +163,21 @@ def emd_matchcost_grad(grad_cost, xyz1, xyz2, match):
 
 
 # ---------------------------------------------------------------- torch-facing stand-ins (tests only)
+def linear_f32(a, w, bias=None, aux=None, ks=1, kc=1, epilogue=0):
+    """C = a . w^T in the summation order of upp_linear_f32 for the decomposition (KS = ks wave groups, 32 ks kc values of k per
+    stage); epilogue 0 none / 1 + bias / 4 * aux.  See oracle_linear_f32 in upp_oracle.c."""
+    a, w = _c(a), _c(w)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and K % (32 * ks * kc) == 0
+    out = np.empty((M, N), np.float32)
+    b = _c(bias) if bias is not None else None
+    x = _c(aux) if aux is not None else None
+    lib().oracle_linear_f32(a, w, None if b is None else b.ctypes.data_as(ctypes.c_void_p),
+                            None if x is None else x.ctypes.data_as(ctypes.c_void_p), out, M, N, K, ks, kc, epilogue)
+    return out
+
+
 def torch_ops():
     """Oracle-backed callables with the signatures of models.upp_layers.OPS, for running the
     model on a GPU-less host in tests.  Differentiable w.r.t. the coordinates through torch

@@ -449,6 +449,46 @@ void oracle_emd_matchcost_grad(const float *grad_cost, const float *xyz1, const 
     }
 }
 
+/* ---- Linear layers of the Transformer blocks ---------------------------------------------------
+ * Reference: nn.Linear -> F.linear (models/Point_MAE_pretask_dev.py:153-196: Mlp.fc1/fc2, Attention.qkv/proj), i.e.
+ * C = A . W^T (+ bias); the reference's GEMM library fixes no summation order.  This is the order of the product under test
+ * (upp_linear_f32, csrc/linear.hip), written as plain fmaf chains so that the kernel can be checked BIT FOR BIT:
+ *   - v_mfma_f32_32x32x2_f32 adds its two products to the accumulator as fma(a1, b1, fma(a0, b0, c)), lower lane half (k index 0)
+ *     first, one rounding per product;
+ *   - inside a group of 32 k values the kernel feeds k = 8 i + j to the lower and 8 i + 4 + j to the upper lane half for
+ *     i = 0..3, j = 0..3 (16-byte operand granules);
+ *   - the contraction is cut into stages of 32 KS KC values; wave group g of KS owns sub-chunks g KC .. g KC + KC - 1 of every
+ *     stage and keeps its own accumulator; the KS accumulators are summed in group order starting from 0.0f;
+ *   - epilogues: 0 none, 1 + bias[n], 4 * aux[m][n]  (the GELU epilogues use the hardware's v_exp_f32 / v_rcp_f32 approximations
+ *     and are checked against torch within a tolerance instead).  */
+void oracle_linear_f32(const float *A, const float *W, const float *bias, const float *aux, float *C, int M, int N, int K,
+                       int ks, int kc, int epilogue) {
+    const int stage = 32 * ks * kc, nst = K / stage;
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) {
+        for (int n = 0; n < N; ++n) {
+            const float *a = A + (size_t)m * K, *w = W + (size_t)n * K;
+            float total = 0.0f;
+            for (int g = 0; g < ks; ++g) {
+                float acc = 0.0f;
+                for (int c = 0; c < nst; ++c)
+                    for (int q = 0; q < kc; ++q) {
+                        const int k0 = c * stage + (g * kc + q) * 32;
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j) {
+                                acc = fmaf(a[k0 + 8 * i + j], w[k0 + 8 * i + j], acc);
+                                acc = fmaf(a[k0 + 8 * i + 4 + j], w[k0 + 8 * i + 4 + j], acc);
+                            }
+                    }
+                total = ks > 1 ? total + acc : acc;
+            }
+            if (epilogue == 1) total += bias[n];
+            if (epilogue == 4) total *= aux[(size_t)m * N + n];
+            C[(size_t)m * N + n] = total;
+        }
+    }
+}
+
 void oracle_set_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

@@ -188,3 +188,34 @@ def test_fps_and_knn_reproduce_the_references_own_numpy_and_torch_statements(gol
             np.testing.assert_array_equal(np.sort(nb, axis=-1), g[name + "/knn"])
         n += 1
     assert n == 6
+
+
+def test_linear_oracle_is_a_product_and_its_order_is_what_it_says():
+    """oracle.linear_f32 (the CPU restatement upp_linear_f32 is checked against bit for bit on the GPU): equals the f64 product
+    to f32 accuracy for every (KS, KC), and equals a direct numpy evaluation of the documented fmaf order."""
+    import oracle as O
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((37, 256)).astype(np.float32)
+    w = (rng.standard_normal((24, 256)) / 16).astype(np.float32)
+    b = rng.standard_normal(24).astype(np.float32)
+    exact = a.astype(np.float64) @ w.astype(np.float64).T
+    for ks, kc in ((1, 1), (1, 2), (2, 1), (4, 1), (2, 2)):
+        c = O.linear_f32(a, w, ks=ks, kc=kc)
+        np.testing.assert_allclose(c, exact, rtol=0, atol=2e-6 * np.abs(exact).max())
+        np.testing.assert_array_equal(O.linear_f32(a, w, bias=b, ks=ks, kc=kc, epilogue=1), c + b)
+    # the documented order for KS = 2, KC = 1, written out with numpy scalars (fma emulated in f64: exact for f32 operands,
+    # one rounding per product as fmaf does)
+    def fmaf(x, y, z):
+        return np.float32(np.float64(x) * np.float64(y) + np.float64(z))
+    m, n = 5, 7
+    total = np.float32(0.0)
+    for g in range(2):
+        acc = np.float32(0.0)
+        for c0 in range(0, 256, 64):
+            k0 = c0 + g * 32
+            for i in range(4):
+                for j in range(4):
+                    acc = fmaf(a[m, k0 + 8 * i + j], w[n, k0 + 8 * i + j], acc)
+                    acc = fmaf(a[m, k0 + 8 * i + 4 + j], w[n, k0 + 8 * i + 4 + j], acc)
+        total = np.float32(total + acc)
+    assert O.linear_f32(a, w, ks=2, kc=1)[m, n] == total
