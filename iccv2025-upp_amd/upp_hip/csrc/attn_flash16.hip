@@ -1,0 +1,309 @@
+// attn_flash16.hip -- attention core for L <= 96 tokens, head dim 64, on v_mfma_f32_16x16x4_f32, forward without LDS and
+// without a barrier.  Same contract as upp_attn_fwd / upp_attn_bwd (include/upp_hip.h; reference
+// models/Point_MAE_pretask_dev.py:186-193).
+//
+// The sequences of the UPP blocks are 35 / 64 / 65 / 75 tokens: on 32x32 tiles they pad to 64 / 64 / 96 / 96 (up to 1.64x the
+// MFMA work), and the round-1 kernels (attn_mfma.hip) spend most of their 13 us in phases -- stage Q, K, V through registers
+// into padded LDS rows, barrier, S tiles to LDS, barrier, row softmax from LDS, barrier, P V -- not in their ~2.4 us of MFMA.
+// Here one workgroup per (sample, head) has ceil(L/16) waves; wave w owns the 16 queries 16 w .. 16 w + 15 and ALL keys:
+//
+//   S^T tile t (16 keys x 16 queries) = K_t . Q_w^T      A = K rows, B = Q rows: both loaded straight from global memory as
+//                                                        16-byte pieces (the contraction over d may run in any order: lane
+//                                                        (i = lane & 15, g = lane >> 4) takes d = 16 m + 4 g + c for the
+//                                                        k-step (m, c), so one float4 feeds four MFMAs)
+//   softmax over the keys of a query = over the 4 accumulator registers x ceil(L/16) tiles of a lane, then over the four lane
+//                                      groups g (two __shfl_xor): in registers, no LDS round trip
+//   O_w (16 queries x 64) = P_w . V                      A = P: the accumulator register s of S^T tile t IS the A operand of
+//                                                        the k-step "keys 16 t + 4 g + s, g = 0..3" -- no lane movement, no
+//                                                        transpose; B = V rows, one dword per lane (64 contiguous bytes per key)
+//
+// A wave never waits for another wave: no __syncthreads, no LDS.  All loads of a wave (Q, K, then V) are issued before the
+// first MFMA.  Masking: keys >= L get p = 0 (their rows are clamped loads), queries >= L are computed and not stored.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float exp2_scaled(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float comp(const float4 &v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attn_fwd16_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
+                                                            float *__restrict__ lse, int L, int H, float scale) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const size_t rs = (size_t)3 * H * 64;
+    const float *qb = qkv + (size_t)b * L * rs + (size_t)hh * 64, *kb = qb + H * 64, *vb = qb + 2 * H * 64;
+    const int q0 = wave * 16;
+    if (q0 >= L) return;
+
+    // ---- operand loads: Q (B of S^T), K (A of S^T), V (B of P V); rows clamped to L - 1
+    float4 qv[4], kv[NT][4];
+    const float *qrow = qb + (size_t)min(q0 + j, L - 1) * rs + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) qv[m] = *reinterpret_cast<const float4 *>(qrow + 16 * m);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float *krow = kb + (size_t)min(16 * t + j, L - 1) * rs + 4 * g;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) kv[t][m] = *reinterpret_cast<const float4 *>(krow + 16 * m);
+    }
+    float vv[NT][4][4];                                  // [key tile][s][d tile]: V[16 t + 4 g + s][16 dt + j]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float *vrow = vb + (size_t)min(16 * t + 4 * g + s, L - 1) * rs + j;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) vv[t][s][dt] = vrow[16 * dt];
+        }
+
+    // ---- S^T tiles
+    f32x4 st[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(kv[t][m], c), comp(qv[m], c), st[t], 0, 0, 0);
+    }
+    // ---- softmax over the keys of query q0 + j: registers (4) x tiles (NT) in the lane, then the four lane groups
+    const float sl = scale * 1.4426950408889634f;        // exp(x * scale) = exp2(x * scale * log2 e)
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool live = 16 * t + 4 * g + s < L;
+            st[t][s] = live ? st[t][s] : -__builtin_inff();
+            mx = fmaxf(mx, st[t][s]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float p = exp2_scaled((st[t][s] - mx) * sl);    // masked keys: exp2(-inf) = 0
+            st[t][s] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    if (g == 0 && q0 + j < L) lse[((size_t)b * H + hh) * L + q0 + j] = mx * scale + logf(sum);
+    // ---- O = P V: register s of S^T tile t is the A operand of the k-step over keys 16 t + 4 g + s
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float p = st[t][s] * inv;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(p, vv[t][s][dt], o[dt], 0, 0, 0);
+        }
+    // o[dt][reg] = O[q0 + 4 g + reg][16 dt + j]
+    float *ob = ctx + (size_t)b * L * (H * 64) + (size_t)hh * 64 + j;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int q = q0 + 4 * g + reg;
+        if (q < L) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) ob[(size_t)q * (H * 64) + 16 * dt] = o[dt][reg];
+        }
+    }
+}
+
+// Backward, same partition.  Phase 1, wave w = query tile w, everything in registers:
+//   S^T_t = K_t Q_w^T,  dP^T_t = V_t dO_w^T   (A = K / V rows, B = Q / dO rows: float4 loads, four MFMAs each)
+//   P^T = exp(S scale - lse),  dS^T = P^T (dP^T - delta) scale,   delta_q = dO_q . O_q  (lane-local partial + two shuffles)
+//   dQ_w = dS_w K : the accumulator registers of dS^T are the A operand (as P in the forward), B = K rows (one dword per lane)
+// then P^T and dS^T go to the LDS ([key][query], the only exchange of the kernel, ONE barrier) and, phase 2, wave w = key
+// tile w computes  dV_w = P^T_w dO  and  dK_w = dS^T_w Q  with A from the LDS (16-byte reads along the queries) and B = dO / Q
+// rows from global memory: complete sums over all queries inside one wave -- no atomics, no cross-wave reduction.
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attn_bwd16_kernel(const float *__restrict__ qkv, const float *__restrict__ ctx,
+                                                            const float *__restrict__ d_ctx, const float *__restrict__ lse,
+                                                            float *__restrict__ d_qkv, int L, int H, float scale) {
+    constexpr int LP = 16 * NT, LS = LP + 4;             // padded length, LDS row stride (floats; 16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) float PT[LP * LS], DS[LP * LS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const size_t rs = (size_t)3 * H * 64, cs = (size_t)H * 64;
+    const float *qb = qkv + (size_t)b * L * rs + (size_t)hh * 64, *kb = qb + H * 64, *vb = qb + 2 * H * 64;
+    const float *gb = d_ctx + (size_t)b * L * cs + (size_t)hh * 64, *ob = ctx + (size_t)b * L * cs + (size_t)hh * 64;
+    float *dqb = d_qkv + (size_t)b * L * rs + (size_t)hh * 64, *dkb = dqb + H * 64, *dvb = dqb + 2 * H * 64;
+    const int q0 = wave * 16;                            // (every wave index < NT has q0 < LP; tiles beyond L are all-masked)
+    const float sl = scale * 1.4426950408889634f;
+
+    // ---- phase 1 -------------------------------------------------------------------------------------------------
+    {
+        const int qr = min(q0 + j, L - 1);
+        const bool qlive = q0 + j < L;
+        float4 qv[4], gv[4], ov[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            qv[m] = *reinterpret_cast<const float4 *>(qb + (size_t)qr * rs + 16 * m + 4 * g);
+            gv[m] = *reinterpret_cast<const float4 *>(gb + (size_t)qr * cs + 16 * m + 4 * g);
+            ov[m] = *reinterpret_cast<const float4 *>(ob + (size_t)qr * cs + 16 * m + 4 * g);
+        }
+        const float lse_q = lse[((size_t)b * H + hh) * L + qr] * 1.4426950408889634f;
+        float4 kv[NT][4], vv[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int kr = min(16 * t + j, L - 1);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                kv[t][m] = *reinterpret_cast<const float4 *>(kb + (size_t)kr * rs + 16 * m + 4 * g);
+                vv[t][m] = *reinterpret_cast<const float4 *>(vb + (size_t)kr * rs + 16 * m + 4 * g);
+            }
+        }
+        float delta = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            delta += gv[m].x * ov[m].x + gv[m].y * ov[m].y + gv[m].z * ov[m].z + gv[m].w * ov[m].w;
+        delta += __shfl_xor(delta, 16);
+        delta += __shfl_xor(delta, 32);
+        f32x4 st[NT], dp[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(kv[t][m], c), comp(qv[m], c), st[t], 0, 0, 0);
+                    dp[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(vv[t][m], c), comp(gv[m], c), dp[t], 0, 0, 0);
+                }
+        }
+        // K rows again as the B operand of dQ = dS K: K[16 t + 4 g + s][16 dt + j]
+        float kd[NT][4][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float *krow = kb + (size_t)min(16 * t + 4 * g + s, L - 1) * rs + j;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) kd[t][s][dt] = krow[16 * dt];
+            }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool live = qlive && 16 * t + 4 * g + s < L;
+                const float p = live ? exp2_scaled(st[t][s] * sl - lse_q) : 0.0f;
+                st[t][s] = p;
+                dp[t][s] = p * (dp[t][s] - delta) * scale;
+            }
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[t][s], kd[t][s][dt], dq[dt], 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int q = q0 + 4 * g + reg;
+            if (q < L) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dqb[(size_t)q * rs + 16 * dt + j] = dq[dt][reg];
+            }
+        }
+        // exchange: [key][query]
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                PT[(16 * t + 4 * g + s) * LS + q0 + j] = st[t][s];
+                DS[(16 * t + 4 * g + s) * LS + q0 + j] = dp[t][s];
+            }
+    }
+    __syncthreads();
+    // ---- phase 2: wave = key tile ------------------------------------------------------------------------------------
+    {
+        const int k0 = wave * 16;
+        if (k0 >= L) return;
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            // A: P^T / dS^T [key k0 + j][queries 16 u + 4 g .. + 3]; B: dO / Q [query 16 u + 4 g + s][16 dt + j]
+            const float4 pa = *reinterpret_cast<const float4 *>(&PT[(k0 + j) * LS + 16 * u + 4 * g]);
+            const float4 da = *reinterpret_cast<const float4 *>(&DS[(k0 + j) * LS + 16 * u + 4 * g]);
+            float gd[4][4], qd[4][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int qr = min(16 * u + 4 * g + s, L - 1);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    gd[s][dt] = gb[(size_t)qr * cs + 16 * dt + j];
+                    qd[s][dt] = qb[(size_t)qr * rs + 16 * dt + j];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(pa, s), gd[s][dt], dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(da, s), qd[s][dt], dk[dt], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int key = k0 + 4 * g + reg;
+            if (key < L) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dvb[(size_t)key * rs + 16 * dt + j] = dv[dt][reg];
+                    dkb[(size_t)key * rs + 16 * dt + j] = dk[dt][reg];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int upp_attn_bwd_flash16(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
+                         float scale, hipStream_t st) {
+    const int nt = (L + 15) / 16;
+    const dim3 grid(B * H);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((attn_bwd16_kernel<1>), grid, dim3(64), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
+        case 2: hipLaunchKernelGGL((attn_bwd16_kernel<2>), grid, dim3(128), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
+        case 3: hipLaunchKernelGGL((attn_bwd16_kernel<3>), grid, dim3(192), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
+        case 4: hipLaunchKernelGGL((attn_bwd16_kernel<4>), grid, dim3(256), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
+        case 5: hipLaunchKernelGGL((attn_bwd16_kernel<5>), grid, dim3(320), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
+        case 6: hipLaunchKernelGGL((attn_bwd16_kernel<6>), grid, dim3(384), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
+        default: return UPP_E_RANGE;
+    }
+    return upp_launch_status();
+}
+
+// called by upp_attn_fwd_ex (block.hip) for L <= 96, variant 0
+int upp_attn_fwd_flash16(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st) {
+    const int nt = (L + 15) / 16;
+    const dim3 grid(B * H);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((attn_fwd16_kernel<1>), grid, dim3(64), 0, st, qkv, ctx, lse, L, H, scale); break;
+        case 2: hipLaunchKernelGGL((attn_fwd16_kernel<2>), grid, dim3(128), 0, st, qkv, ctx, lse, L, H, scale); break;
+        case 3: hipLaunchKernelGGL((attn_fwd16_kernel<3>), grid, dim3(192), 0, st, qkv, ctx, lse, L, H, scale); break;
+        case 4: hipLaunchKernelGGL((attn_fwd16_kernel<4>), grid, dim3(256), 0, st, qkv, ctx, lse, L, H, scale); break;
+        case 5: hipLaunchKernelGGL((attn_fwd16_kernel<5>), grid, dim3(320), 0, st, qkv, ctx, lse, L, H, scale); break;
+        case 6: hipLaunchKernelGGL((attn_fwd16_kernel<6>), grid, dim3(384), 0, st, qkv, ctx, lse, L, H, scale); break;
+        default: return UPP_E_RANGE;
+    }
+    return upp_launch_status();
+}

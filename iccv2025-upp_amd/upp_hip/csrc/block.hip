@@ -552,13 +552,15 @@ int upp_attn_bwd_mfma(const float *qkv, const float *ctx, const float *d_ctx, co
 int upp_attn_fwd_long(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st);
 int upp_attn_bwd_long(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
                       float scale, hipStream_t st);
+int upp_attn_fwd_flash16(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st);
 extern "C" int upp_attn_fwd_ex(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, int variant,
                                void *stream) {
-    if (!qkv || !ctx || !lse || B < 0 || L < 1 || H < 1 || variant < 0 || variant > 1) return UPP_E_BADARG;
-    const bool g_attn_mfma = variant == 0;
+    if (!qkv || !ctx || !lse || B < 0 || L < 1 || H < 1 || variant < 0 || variant > 2) return UPP_E_BADARG;
+    const bool g_attn_mfma = variant != 1;
     if (head_dim != 64 || L > 192) return UPP_E_RANGE;
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (variant == 0 && L <= 96) return upp_attn_fwd_flash16(qkv, ctx, lse, B, L, H, scale, st);
     if (g_attn_mfma && L <= 96) return upp_attn_fwd_mfma(qkv, ctx, lse, B, L, H, scale, st);
     if (g_attn_mfma && L <= 160) return upp_attn_fwd_long(qkv, ctx, lse, B, L, H, scale, st);
     const int ns = (L + 63) / 64;
@@ -575,13 +577,16 @@ extern "C" int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int
     return upp_attn_fwd_ex(qkv, ctx, lse, B, L, H, head_dim, scale, 0, stream);
 }
 
+int upp_attn_bwd_flash16(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
+                         float scale, hipStream_t st);
 extern "C" int upp_attn_bwd_ex(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L,
                                int H, int head_dim, float scale, int variant, void *stream) {
-    if (!qkv || !ctx || !d_ctx || !lse || !d_qkv || B < 0 || L < 1 || H < 1 || variant < 0 || variant > 1) return UPP_E_BADARG;
-    const bool g_attn_mfma = variant == 0;
+    if (!qkv || !ctx || !d_ctx || !lse || !d_qkv || B < 0 || L < 1 || H < 1 || variant < 0 || variant > 2) return UPP_E_BADARG;
+    const bool g_attn_mfma = variant != 1;
     if (head_dim != 64 || L > 160 || (!g_attn_mfma && L > 144)) return UPP_E_RANGE;
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (variant == 0 && L <= 96) return upp_attn_bwd_flash16(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
     if (g_attn_mfma && L <= 96) return upp_attn_bwd_mfma(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
     if (g_attn_mfma && L <= 160) return upp_attn_bwd_long(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
     const int ns = (L + 63) / 64;

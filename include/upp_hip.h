@@ -209,8 +209,9 @@ int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, cons
 int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, void *stream);
 int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv,
                  int B, int L, int H, int head_dim, float scale, void *stream);
-/* the same with the kernel family chosen by the caller: variant 0 = the library's choice (the FP32-MFMA kernels where they
- * apply), 1 = the VALU kernels (L <= 192 forward, L <= 144 backward); for measurements and tests. */
+/* the same with the kernel family chosen by the caller: variant 0 = the library's choice (L <= 96: the register-resident 16x16x4
+ * MFMA kernels of attn_flash16.hip; L <= 160: attn_long.hip), 1 = the VALU kernels (L <= 192 forward, L <= 144 backward),
+ * 2 = the LDS-staged 32x32x2 MFMA kernels of attn_mfma.hip for L <= 96 (round 1's choice); for measurements and tests. */
 int upp_attn_fwd_ex(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, int variant, void *stream);
 int upp_attn_bwd_ex(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv,
                     int B, int L, int H, int head_dim, float scale, int variant, void *stream);

@@ -18,13 +18,15 @@ def close(a, b, rtol=1e-5, atol_scale=2e-6):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_scale * max(np.abs(b).max(), 1e-30))
 
 
-@pytest.mark.parametrize("mfma", [1, 0])
-@pytest.mark.parametrize("L", [1, 31, 35, 64, 65, 75, 96, 97, 128, 129, 139, 144, 159, 160])
-def test_attention_core_forward_backward(L, mfma):
-    if not mfma and L > 144:
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("L", [1, 15, 16, 17, 31, 35, 48, 64, 65, 75, 80, 81, 96, 97, 128, 129, 139, 144, 159, 160])
+def test_attention_core_forward_backward(L, variant):
+    if variant == 1 and L > 144:
         pytest.skip("the VALU backward serves L <= 144")
-    # MFMA kernels: L <= 96 (attn_mfma.hip), L <= 160 (attn_long.hip); variant 1 of upp_attn_*_ex asks for the VALU kernels
-    _attention_case(L, variant=0 if mfma else 1)
+    if variant == 2 and L > 96:
+        pytest.skip("variant 2 = attn_mfma.hip, L <= 96 (longer sequences: same kernels as variant 0)")
+    # variant 0: attn_flash16.hip (L <= 96) / attn_long.hip (L <= 160); 1: the VALU kernels; 2: attn_mfma.hip (round 1's L <= 96 path)
+    _attention_case(L, variant=variant)
 
 
 def _attention_case(L, variant=0):
