@@ -349,7 +349,7 @@ class _TransposedWeights:
             wt = w.detach().t().contiguous()
             self.entries[key] = [weakref.ref(owner), owner._version, wt, geom]
             return wt
-        if e[1] != owner._version and not torch.cuda.is_current_stream_capturing():
+        if e[1] != owner._version and not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
             e[2].copy_(w.detach().t())
             e[1] = owner._version
         return e[2]

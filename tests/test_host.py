@@ -84,3 +84,62 @@ def test_bench_gpus_flag_launches_that_many_ranks(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"],
                          env=dict(env, WORLD_SIZE="1"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def test_transposed_weight_cache_tracks_versions_views_and_refresh():
+    """functional.TRANSPOSED (W^T copies for the data-gradient GEMMs of frozen layers): one copy per weight or column window,
+    refreshed IN PLACE when the owner's version counter moves (graphs keep the address), refresh() re-copies everything."""
+    from upp_hip.functional import _TransposedWeights
+    c = _TransposedWeights()
+    w = torch.arange(12.0).view(3, 4)
+    t1 = c.get(w)
+    assert torch.equal(t1, w.t()) and t1.is_contiguous()
+    assert c.get(w) is t1                                  # cached
+    w.mul_(2.0)                                            # in-place update (load_state_dict): version moves
+    t2 = c.get(w)
+    assert t2 is t1 and torch.equal(t1, w.t())             # same storage, new contents
+    big = torch.arange(24.0).view(3, 8)
+    win = big[:, 4:]                                       # a column window of a parameter (Conv1d(512,512) split in the encoder)
+    tw = c.get(win)
+    assert torch.equal(tw, win.t()) and c.get(big[:, 4:]) is tw and c.get(big[:, :4]) is not tw
+    big.add_(1.0)
+    assert torch.equal(c.get(big[:, 4:]), big[:, 4:].t())
+    with torch.no_grad():
+        w.copy_(torch.ones(3, 4))
+    c.entries[next(iter(c.entries))][1] = w._version       # pretend nobody noticed: refresh() must still re-copy
+    c.refresh()
+    assert torch.equal(c.get(w), torch.ones(4, 3))
+
+
+def test_declined_fused_paths_are_reported_once(monkeypatch, capsys):
+    from upp_hip import functional as HF
+    monkeypatch.setenv("UPP_VERBOSE", "1")
+    HF._declined.discard(("unit-test site", "reason"))
+    HF.note_declined("unit-test site", "reason")
+    HF.note_declined("unit-test site", "reason")
+    err = capsys.readouterr().err
+    assert err.count("unit-test site") == 1 and "fused path declined" in err
+
+
+def test_capture_state_snapshot_restores_in_place():
+    """train._TrainingState: what the graph-capture warm-up uses to leave model and optimizer untouched."""
+    from upp_hip.train import _TrainingState
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    opt = torch.optim.AdamW(m.parameters(), lr=0.1)
+    flat = torch.zeros(5)
+    m(torch.randn(8, 4)).sum().backward()
+    opt.step()
+    keep = _TrainingState(m, opt, flat)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    ptrs = [p.data_ptr() for p in m.parameters()]
+    step_before = opt.state_dict()['state'][0]['step'].clone()
+    for _ in range(2):                                     # "warm-up": trains, moves BatchNorm statistics and counters
+        opt.zero_grad()
+        m(torch.randn(8, 4)).sum().backward()
+        opt.step()
+        flat += 1
+    keep.restore()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert [p.data_ptr() for p in m.parameters()] == ptrs and float(flat.abs().sum()) == 0.0
+    assert torch.equal(opt.state_dict()['state'][0]['step'], step_before)
