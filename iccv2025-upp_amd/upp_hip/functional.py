@@ -410,6 +410,7 @@ class _LinearMFMA(Function):
 
 
 WGRAD_MIN_ROWS = int(os.environ.get("UPP_WGRAD_MIN_ROWS", "4096"))
+WGRAD_FEW_ROWS = 512        # up to here one or two 32-row stages: ~8 us on ours; the un-tuned library picks 25-170 us solutions (stage-2 heads)
 
 
 def weight_grad(g2, x2, w, own=False):
@@ -419,11 +420,11 @@ def weight_grad(g2, x2, w, own=False):
     if N % 4 or K % 4 or x2.stride(1) != 1 or x2.stride(0) % 4 or g2.stride(0) % 4:
         note_declined("linear weight gradient (%d,%d)" % (N, K), "N % 4 / K % 4 / row alignment")
         return torch.mm(g2.t(), x2)
-    if g2.shape[0] < WGRAD_MIN_ROWS and not own:
+    if WGRAD_FEW_ROWS < g2.shape[0] < WGRAD_MIN_ROWS and not own:
         # measured (pre-training step, M = 864 / 2080 token rows, profiles/r02_workload_pretrain_*): the 64 x 64-tile variant
         # of upp_linear_wgrad_f32 takes 25 us per launch where the library's split-K solutions take ~12 us -- 65 launches per
         # step, 9.36 against 8.23 ms.  The many-row layers (patch embedding, segmentation head: M = 65,536) run on ours.
-        note_declined("linear weight gradient (%d,%d) over %d rows" % (N, K, g2.shape[0]), "fewer than %d rows: library GEMM" % WGRAD_MIN_ROWS)
+        note_declined("linear weight gradient (%d,%d) over %d rows" % (N, K, g2.shape[0]), "%d < rows < %d: library GEMM" % (WGRAD_FEW_ROWS, WGRAD_MIN_ROWS))
         return torch.mm(g2.t(), x2)
     part = ops.linear_wgrad(g2, x2)
     _, gw = _DEFERRED.reduce(w.data_ptr(), part.view(part.shape[0], N * K), 0, N * K)
