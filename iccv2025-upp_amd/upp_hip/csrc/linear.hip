@@ -129,9 +129,13 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     static_assert(TPW <= 6, "DMA slots of the interleaved schedule");
     auto issue1 = [&](int q, int stage, int c) {            // q-th DMA instruction of this wave for k-stage c
         const int t = wave + q * NW;
+#ifndef UPP_LIN_NO_DMA        // diagnostic build without the operand stream (the MFMAs then run on whatever the LDS holds)
         if (TPW * NW == T || t < T)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[q < TPW ? q : 0] + (long long)c * (32 * KS * KC)),
                                              (lds_ptr_t)(lds + stage * STAGE + t * 1024), 16, 0, 0);
+#else
+        (void)t; (void)stage; (void)c;
+#endif
     };
     auto issue = [&](int stage, int c) {
 #pragma unroll
@@ -166,12 +170,20 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     asm volatile("ds_read_b128 %0, %1" : "=v"(F.b2) : "v"(adrW[2] + (SO)));           \
     asm volatile("ds_read_b128 %0, %1" : "=v"(F.a3) : "v"(adrA[3] + (SO)));           \
     asm volatile("ds_read_b128 %0, %1" : "=v"(F.b3) : "v"(adrW[3] + (SO)));
+#ifdef UPP_LIN_NO_MFMA
+#define UPP_MFMA4(AV, BV) asm volatile("" ::"v"(AV), "v"(BV));
+#else
 #define UPP_MFMA4(AV, BV)                                                             \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[0], BV[0], acc, 0, 0, 0);           \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[1], BV[1], acc, 0, 0, 0);           \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[2], BV[2], acc, 0, 0, 0);           \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[3], BV[3], acc, 0, 0, 0);
+#endif
+#ifdef UPP_LIN_NO_MFMA      // diagnostic build: operands delivered and read, no matrix instructions (the values stay live)
+#define UPP_M1(AV, BV) asm volatile("" ::"v"(AV), "v"(BV)); __builtin_amdgcn_sched_barrier(0);
+#else
 #define UPP_M1(AV, BV) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV, acc, 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+#endif
 #define UPP_RD1(DST, ADR) asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(ADR));
 #define UPP_LGKM(N_LEFT) asm volatile("s_waitcnt lgkmcnt(" #N_LEFT ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
     struct Frag { f32x4 a0, a1, a2, a3, b0, b1, b2, b3; };
