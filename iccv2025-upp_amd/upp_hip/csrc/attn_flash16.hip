@@ -28,12 +28,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float exp2_scaled(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float comp(const float4 &v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
 
+// One wave per workgroup: the NT query tiles of a (sample, head) are NT independent single-wave workgroups, so that the
+// dispatcher spreads B H NT waves over the 1,024 SIMDs (five waves of one workgroup on the four SIMDs of a CU run 2:1:1:1).
+// Workgroups i and i + 8 share an XCD (and its L2): the tiles of one (sample, head) are 8 apart in the launch order.
+__device__ __forceinline__ void unit_of(int unit, int NT, int BH, int &bh, int &tile) {
+    if ((BH & 7) == 0) { const int x = unit & 7, y = unit >> 3; bh = (y / NT) * 8 + x; tile = y - (y / NT) * NT; }
+    else { bh = unit / NT; tile = unit - bh * NT; }
+}
+
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void attn_fwd16_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
-                                                            float *__restrict__ lse, int L, int H, float scale) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+__global__ __launch_bounds__(64) void attn_fwd16_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
+                                                       float *__restrict__ lse, int L, int H, float scale, int BH) {
+    const int lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    int bh, wave;
+    unit_of(blockIdx.x, NT, BH, bh, wave);
+    const int b = bh / H, hh = bh - b * H;
     const size_t rs = (size_t)3 * H * 64;
     const float *qb = qkv + (size_t)b * L * rs + (size_t)hh * 64, *kb = qb + H * 64, *vb = qb + 2 * H * 64;
     const int q0 = wave * 16;
@@ -127,6 +137,9 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd16_kernel(const float *__rest
 // then P^T and dS^T go to the LDS ([key][query], the only exchange of the kernel, ONE barrier) and, phase 2, wave w = key
 // tile w computes  dV_w = P^T_w dO  and  dK_w = dS^T_w Q  with A from the LDS (16-byte reads along the queries) and B = dO / Q
 // rows from global memory: complete sums over all queries inside one wave -- no atomics, no cross-wave reduction.
+// (Measured and dropped: the backward as 2 NT independent single-wave workgroups per (sample, head), the key-tile units
+// recomputing S and dP un-transposed instead of reading them from the LDS -- no barrier and a better spread over the SIMDs,
+// but 40 % more MFMAs and five dependent load -> MFMA rounds per key-tile wave: 24.3 us against 21.8 us at L = 75.)
 template <int NT>
 __global__ __launch_bounds__(64 * NT) void attn_bwd16_kernel(const float *__restrict__ qkv, const float *__restrict__ ctx,
                                                             const float *__restrict__ d_ctx, const float *__restrict__ lse,
@@ -274,6 +287,7 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd16_kernel(const float *__rest
     }
 }
 
+
 }  // namespace
 
 int upp_attn_bwd_flash16(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
@@ -295,14 +309,14 @@ int upp_attn_bwd_flash16(const float *qkv, const float *ctx, const float *d_ctx,
 // called by upp_attn_fwd_ex (block.hip) for L <= 96, variant 0
 int upp_attn_fwd_flash16(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st) {
     const int nt = (L + 15) / 16;
-    const dim3 grid(B * H);
+    const dim3 grid(B * H * nt);
     switch (nt) {
-        case 1: hipLaunchKernelGGL((attn_fwd16_kernel<1>), grid, dim3(64), 0, st, qkv, ctx, lse, L, H, scale); break;
-        case 2: hipLaunchKernelGGL((attn_fwd16_kernel<2>), grid, dim3(128), 0, st, qkv, ctx, lse, L, H, scale); break;
-        case 3: hipLaunchKernelGGL((attn_fwd16_kernel<3>), grid, dim3(192), 0, st, qkv, ctx, lse, L, H, scale); break;
-        case 4: hipLaunchKernelGGL((attn_fwd16_kernel<4>), grid, dim3(256), 0, st, qkv, ctx, lse, L, H, scale); break;
-        case 5: hipLaunchKernelGGL((attn_fwd16_kernel<5>), grid, dim3(320), 0, st, qkv, ctx, lse, L, H, scale); break;
-        case 6: hipLaunchKernelGGL((attn_fwd16_kernel<6>), grid, dim3(384), 0, st, qkv, ctx, lse, L, H, scale); break;
+        case 1: hipLaunchKernelGGL((attn_fwd16_kernel<1>), grid, dim3(64), 0, st, qkv, ctx, lse, L, H, scale, B * H); break;
+        case 2: hipLaunchKernelGGL((attn_fwd16_kernel<2>), grid, dim3(64), 0, st, qkv, ctx, lse, L, H, scale, B * H); break;
+        case 3: hipLaunchKernelGGL((attn_fwd16_kernel<3>), grid, dim3(64), 0, st, qkv, ctx, lse, L, H, scale, B * H); break;
+        case 4: hipLaunchKernelGGL((attn_fwd16_kernel<4>), grid, dim3(64), 0, st, qkv, ctx, lse, L, H, scale, B * H); break;
+        case 5: hipLaunchKernelGGL((attn_fwd16_kernel<5>), grid, dim3(64), 0, st, qkv, ctx, lse, L, H, scale, B * H); break;
+        case 6: hipLaunchKernelGGL((attn_fwd16_kernel<6>), grid, dim3(64), 0, st, qkv, ctx, lse, L, H, scale, B * H); break;
         default: return UPP_E_RANGE;
     }
     return upp_launch_status();
