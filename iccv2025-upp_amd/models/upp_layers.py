@@ -51,6 +51,7 @@ class UniformBank:
 
 
 UNIFORMS = UniformBank()
+FUSE_LN_ADAPTER = True     # Block.forward_fused: close the block with HF.ln_adapter (one launch) instead of HF.rowln + HF.adapter
 
 
 class use_rng:
@@ -590,6 +591,12 @@ class Block(nn.Module):
             x4, _ = HF.rowln(x2, y=m, ybias=mb, u=u2, keep=keep, mode=rem, P=P)
             return x4
         ln = adapter.layer_norm
+        if D == 384 and adapter.ln1.weight.shape[0] == 32 and isinstance(adapter.activate, nn.GELU) and FUSE_LN_ADAPTER:
+            # one launch: residual + strip + the adapter's LayerNorm + the adapter (csrc/adapter.hip ln_adapter_fwd_kernel)
+            pd = adapter.dropout.p if self.training else 0.0
+            ud = UNIFORMS.take((B * (x2.shape[1] - (P if rem != HF.ROW_IDENTITY else 0)), 32), x.device) if pd > 0 else None
+            return HF.ln_adapter(x2, m, mb, u2, keep, rem, P, ln, adapter.ln1.weight, adapter.ln1.bias, adapter.ln2.weight,
+                                 adapter.ln2.bias, ud, pd, 0.7)
         x4, ha = HF.rowln(x2, y=m, ybias=mb, u=u2, keep=keep, mode=rem, P=P, gamma=ln.weight, beta=ln.bias, eps=ln.eps)
         if D == 384 and adapter.ln1.weight.shape[0] == 32 and isinstance(adapter.activate, nn.GELU):
             pd = adapter.dropout.p if self.training else 0.0

@@ -87,6 +87,37 @@ __device__ __forceinline__ void stage_tile(float *dst, const float *src, int row
     }
 }
 
+// the same tile recomputed from the saved rows and statistics of the LayerNorm: dst = (src - mean) * rstd * gamma + beta
+// (the expression of rowln_fwd_kernel / ln_adapter_fwd_kernel: identical values)
+template <int D>
+__device__ __forceinline__ void stage_tile_ln(float *dst, const float *src, const float *mean, const float *rstd, const float *gamma,
+                                              const float *beta, int row0, int R) {
+    constexpr int IT = kRows * D / 4 / kAT;
+    float4 v[IT], gm[IT], bt[IT];
+    float mu[IT], rs[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = threadIdx.x + it * kAT;
+        const int r = i / (D / 4), c = (i % (D / 4)) * 4;
+        const bool ok = row0 + r < R;
+        v[it] = ok ? *reinterpret_cast<const float4 *>(src + (size_t)(row0 + r) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gm[it] = *reinterpret_cast<const float4 *>(gamma + c);
+        bt[it] = *reinterpret_cast<const float4 *>(beta + c);
+        mu[it] = ok ? mean[row0 + r] : 0.0f;
+        rs[it] = ok ? rstd[row0 + r] : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = threadIdx.x + it * kAT;
+        const bool ok = row0 + i / (D / 4) < R;
+        float *d = dst + (i / (D / 4)) * (D + 1) + (i % (D / 4)) * 4;
+        d[0] = ok ? __builtin_fmaf((v[it].x - mu[it]) * rs[it], gm[it].x, bt[it].x) : 0.0f;
+        d[1] = ok ? __builtin_fmaf((v[it].y - mu[it]) * rs[it], gm[it].y, bt[it].y) : 0.0f;
+        d[2] = ok ? __builtin_fmaf((v[it].z - mu[it]) * rs[it], gm[it].z, bt[it].z) : 0.0f;
+        d[3] = ok ? __builtin_fmaf((v[it].w - mu[it]) * rs[it], gm[it].w, bt[it].w) : 0.0f;
+    }
+}
+
 // one wave copies the contiguous 32x32 block W2[n0 .. n0+32][0..32) into its own LDS tile [32][33] (coalesced loads)
 __device__ __forceinline__ void stage_w2_tile(float *dst, const float *W2, int n0, int lane) {
     float4 v[4];
@@ -198,7 +229,10 @@ template <int D>
 __global__ __launch_bounds__(kAT) void adapter_bwd_kernel(const float *__restrict__ g_out, const float *__restrict__ ha,
                                                           const float *__restrict__ s1, const float *__restrict__ W1,
                                                           const float *__restrict__ W2, const float *__restrict__ u, float p,
-                                                          float scale, float *__restrict__ g_ha, float *__restrict__ part, int R) {
+                                                          float scale, float *__restrict__ g_ha, float *__restrict__ part, int R,
+                                                          const float *__restrict__ ln_mean, const float *__restrict__ ln_rstd,
+                                                          const float *__restrict__ ln_gamma, const float *__restrict__ ln_beta) {
+    // ln_mean != null: `ha` holds the un-normalised rows saved by ln_adapter_fwd_kernel; the LayerNorm output is rebuilt here
     constexpr int LDH = D + 1, KW = D / kAW;
     extern __shared__ float sm[];
     float *Zs = sm;                                  // [32][D+1]  gz = scale * g_out
@@ -236,7 +270,8 @@ __global__ __launch_bounds__(kAT) void adapter_bwd_kernel(const float *__restric
         }
     }
     stage_tile<D>(Zs, g_out, row0, R, scale);
-    stage_tile<D>(Hs, ha, row0, R);
+    if (ln_mean) stage_tile_ln<D>(Hs, ha, ln_mean, ln_rstd, ln_gamma, ln_beta, row0, R);
+    else stage_tile<D>(Hs, ha, row0, R);
     __syncthreads();
     {   // gd partial = gz . W2 over n in [wave*KW, (wave+1)*KW):  A[i][k=n] = gz[i][n], B[k=n][j] = W2[n][j]
         f32x16 acc; zero16(acc);
@@ -301,6 +336,189 @@ __global__ __launch_bounds__(kAT) void adapter_bwd_kernel(const float *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused tail of a block (round 2): the row kernel that closes the MLP residual, strips the prompts and applies the adapter's
+// LayerNorm, and the adapter itself, in ONE launch on 16-row workgroups (v_mfma_f32_16x16x4_f32):
+//     v   = x[src(t)] + dp_scale(u_b) * (y[src(t)] + ybias)          (rows of the block's output stream, saved: xo)
+//     ha  = LayerNorm(v)                                             (never written to memory; mean / rstd saved)
+//     out = v + scale * (W2 . dropout(gelu(W1 . ha + b1)) + b2)
+// The separate launches (rowln_fwd 6.0 us + adapter_fwd 11.2 us at 2,400 rows) ran 600 and 75 workgroups; the adapter's 32-row
+// workgroups left 181 CUs idle behind a chain of dependent phases.  Here 150 workgroups of 4 waves: wave w normalises rows
+// 4 w .. 4 w + 3 (lane -> columns lane + 64 e, the arithmetic of rowln_fwd_kernel: bit-identical rows and statistics), then
+// takes the k-range [96 w, 96 w + 96) of S1 = ha . W1^T (two 16 x 16 tiles) and the six column tiles 6 w .. 6 w + 5 of the
+// second product.  Operands: ha / G from LDS rows padded to stride = 4 (mod 64) floats (16-byte reads, conflict-free:
+// lane (r = lane & 15, g = lane >> 4) reads row r, floats 16 i + 4 g .. + 3, one read feeds four MFMAs -- the contraction
+// order inside a 16-block is free); W1 / W2 rows straight from L2 as 16-byte pieces in the same k order, all issued at
+// kernel entry.  The result goes back through the LDS so that the 16 x 384 tile leaves as full 1,536-byte rows.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int kFR = 16;                 // rows per workgroup
+__device__ __forceinline__ float comp4(const float4 &v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+struct LnAdapterArgs {
+    const float *x, *y, *ybias, *u;     // (B, Lin, D) stream, residual branch (or null), its frozen bias (or null), drop-path uniforms
+    float keep;
+    int mode, P;                        // row map: 0 identity, 3 / 4 strip P prompts (behind the cls token / leading)
+    const float *gamma, *beta;
+    float eps;
+    const float *W1, *b1, *W2, *b2, *ud;  // adapter; ud: (R, 32) dropout uniforms or null
+    float p, scale;
+    float *xo, *mean, *rstd, *s1, *out;
+    int B, Lin, Lout;
+};
+
+template <int D, int kFW>
+__global__ __launch_bounds__(64 * kFW) void ln_adapter_fwd_kernel(LnAdapterArgs a) {
+    constexpr int LDH = D + 4;          // 388 = 4 (mod 64): 16-byte operand reads of 16 rows cover all banks
+    constexpr int LDG = kH + 4;         // 36: same property for the 32-wide G rows
+    constexpr int E = D / 64;           // elements per lane and row
+    constexpr int KW = D / kFW;         // k-range per wave of the first product (96)
+    constexpr int NI = KW / 16;         // 16-blocks of k per wave (6)
+    constexpr int NT = D / 16 / kFW;    // output column tiles per wave (6)
+    constexpr int RW = kFR / kFW;       // rows per wave in the row phase
+    static_assert(D % 64 == 0 && KW % 16 == 0 && (D / 16) % kFW == 0, "shape");
+    __shared__ __attribute__((aligned(16))) float Hs[kFR * LDH];        // ha
+    __shared__ __attribute__((aligned(16))) float Vs[kFR * LDH];        // v, later the output tile
+    __shared__ __attribute__((aligned(16))) float Part[kFW * kFR * (kH + 1)];
+    __shared__ __attribute__((aligned(16))) float Gs[kFR * LDG];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, g = lane >> 4;
+    const int R = a.B * a.Lout;
+    const int row0 = blockIdx.x * kFR;
+
+    // ---- weight operands, issued first (they do not depend on anything this workgroup computes)
+    float4 w1v[2][NI], w2v[NT][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            w1v[t][i] = *reinterpret_cast<const float4 *>(a.W1 + (size_t)(16 * t + r) * D + wave * KW + 16 * i + 4 * g);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            w2v[t][i] = *reinterpret_cast<const float4 *>(a.W2 + (size_t)(16 * (wave * NT + t) + r) * kH + 16 * i + 4 * g);
+
+    // ---- rows: residual, prompt strip, LayerNorm (the arithmetic of rowln_fwd_kernel)
+    {
+        float gv[E], bv[E], ybv[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            gv[e] = a.gamma[lane + 64 * e];
+            bv[e] = a.beta[lane + 64 * e];
+            ybv[e] = a.ybias ? a.ybias[lane + 64 * e] : 0.0f;
+        }
+        float xv[RW][E], yv[RW][E];
+        int rowi[RW], bi[RW];
+#pragma unroll
+        for (int q = 0; q < RW; ++q) {
+            const int row = min(row0 + wave * RW + q, R - 1);
+            const int b = row / a.Lout, t = row - b * a.Lout;
+            const int src = a.mode == 3 ? (t == 0 ? 0 : t + a.P) : (a.mode == 4 ? t + a.P : t);
+            const size_t off = ((size_t)b * a.Lin + src) * D;
+            rowi[q] = row; bi[q] = b;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                xv[q][e] = a.x[off + lane + 64 * e];
+                yv[q][e] = a.y ? a.y[off + lane + 64 * e] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RW; ++q) {
+            const int rr = wave * RW + q;
+            const bool live = row0 + rr < R;
+            const float sc = a.y ? (a.u ? floorf(a.keep + a.u[bi[q]]) / a.keep : 1.0f) : 0.0f;
+            float v[E];
+            float s = 0.0f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                float val = xv[q][e];
+                if (a.y) val = __builtin_fmaf(yv[q][e] + ybv[e], sc, val);
+                v[e] = val;
+                s += val;
+            }
+            const float mean = wave_sum_f32(s) / (float)D;
+            float qq = 0.0f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const float dv = v[e] - mean; qq = __builtin_fmaf(dv, dv, qq); }
+            const float rstd = 1.0f / sqrtf(wave_sum_f32(qq) / (float)D + a.eps);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float h = __builtin_fmaf((v[e] - mean) * rstd, gv[e], bv[e]);
+                Hs[rr * LDH + lane + 64 * e] = live ? h : 0.0f;
+                Vs[rr * LDH + lane + 64 * e] = v[e];
+                if (live) a.xo[(size_t)rowi[q] * D + lane + 64 * e] = v[e];
+            }
+            if (live && lane == 0) { a.mean[rowi[q]] = mean; a.rstd[rowi[q]] = rstd; }
+        }
+    }
+    __syncthreads();
+
+    // ---- S1 partial over k in [wave KW, wave KW + KW): two 16 x 16 tiles (hidden units 0..15 | 16..31)
+    {
+        f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4 av = *reinterpret_cast<const float4 *>(&Hs[r * LDH + wave * KW + 16 * i + 4 * g]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(av, c), comp4(w1v[0][i], c), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(av, c), comp4(w1v[1][i], c), acc1, 0, 0, 0);
+            }
+        }
+        // acc[reg] = S1[row 4 g + reg][hidden 16 t + r]
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            Part[(wave * kFR + 4 * g + reg) * (kH + 1) + r] = acc0[reg];
+            Part[(wave * kFR + 4 * g + reg) * (kH + 1) + 16 + r] = acc1[reg];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kFR * kH / (64 * kFW); ++q) {
+        const int e = threadIdx.x + q * 64 * kFW, i = e >> 5, jn = e & 31;
+        float sv = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kFW; w += 2) sv += Part[(w * kFR + i) * (kH + 1) + jn] + Part[((w + 1) * kFR + i) * (kH + 1) + jn];   // fixed order
+        sv += a.b1[jn];
+        float gq = 0.0f;
+        if (row0 + i < R) {
+            a.s1[(size_t)(row0 + i) * kH + jn] = sv;
+            const float f = a.ud ? (a.ud[(size_t)(row0 + i) * kH + jn] >= a.p ? 1.0f / (1.0f - a.p) : 0.0f) : 1.0f;
+            gq = gelu_f(sv) * f;
+        }
+        Gs[i * LDG + jn] = gq;
+    }
+    __syncthreads();
+
+    // ---- out tile columns 16 (wave NT + t) .. + 15:  Z = G . W2^T, out = v + scale (Z + b2), written over v in the LDS
+    {
+        const float4 g0 = *reinterpret_cast<const float4 *>(&Gs[r * LDG + 4 * g]);
+        const float4 g1 = *reinterpret_cast<const float4 *>(&Gs[r * LDG + 16 + 4 * g]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(g0, c), comp4(w2v[t][0], c), acc, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(g1, c), comp4(w2v[t][1], c), acc, 0, 0, 0);
+            const int col = 16 * (wave * NT + t) + r;
+            const float b2 = a.b2[col];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float *d = &Vs[(4 * g + reg) * LDH + col];
+                *d = *d + a.scale * (acc[reg] + b2);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kFR * (D / 4) / (64 * kFW); ++q) {
+        const int idx = threadIdx.x + q * 64 * kFW, i = idx / (D / 4), c4 = idx - i * (D / 4);
+        if (row0 + i < R)
+            *reinterpret_cast<float4 *>(a.out + (size_t)(row0 + i) * D + 4 * c4) = *reinterpret_cast<const float4 *>(&Vs[i * LDH + 4 * c4]);
+    }
+}
+
 template <typename K>
 int raise_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) {
@@ -329,14 +547,42 @@ extern "C" int upp_adapter_fwd(const float *ha, const float *x, const float *W1,
     return upp_launch_status();
 }
 
-extern "C" int upp_adapter_bwd(const float *g_out, const float *ha, const float *s1, const float *W1, const float *W2, const float *u,
-                               float p, float scale, float *g_ha, float *part, int R, int D, int H, void *stream) {
+extern "C" int upp_ln_adapter_fwd(const float *x, const float *y, const float *ybias, const float *u, float keep, int mode, int P,
+                                  const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
+                                  const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
+                                  float *out, int B, int Lin, int Lout, int D, int H, void *stream) {
+    if (!x || !gamma || !beta || !W1 || !b1 || !W2 || !b2 || !xo || !mean || !rstd || !s1 || !out || B < 0 || Lin < 1 || Lout < 1)
+        return UPP_E_BADARG;
+    if (ybias && !y) return UPP_E_BADARG;
+    if (D != 384 || H != kH) return UPP_E_RANGE;
+    if (!(mode == 0 || mode == 3 || mode == 4) || P < 0 || (mode == 0 && Lout != Lin) || (mode != 0 && Lout != Lin - P)) return UPP_E_BADARG;
+    if (B == 0) return 0;
+    LnAdapterArgs a{x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, xo, mean, rstd, s1, out, B, Lin, Lout};
+    hipLaunchKernelGGL((ln_adapter_fwd_kernel<384, 8>), dim3((B * Lout + kFR - 1) / kFR), dim3(64 * 8), 0, (hipStream_t)stream, a);
+    return upp_launch_status();
+}
+
+static int adapter_bwd_launch(const float *g_out, const float *ha, const float *mean, const float *rstd, const float *gamma,
+                              const float *beta, const float *s1, const float *W1, const float *W2, const float *u, float p, float scale,
+                              float *g_ha, float *part, int R, int D, int H, void *stream) {
     if (!g_out || !ha || !s1 || !W1 || !W2 || !g_ha || !part || R < 1) return UPP_E_BADARG;
     if (D != 384 || H != kH) return UPP_E_RANGE;
     const size_t lds = ((size_t)2 * kRows * (D + 1) + (kAW + 2) * kRows * kLG) * sizeof(float);
     static std::atomic<bool> raised{false};
     if (!raised) { int rc = raise_lds(adapter_bwd_kernel<384>, lds); if (rc) return rc; raised = true; }
     hipLaunchKernelGGL((adapter_bwd_kernel<384>), dim3((R + kRows - 1) / kRows), dim3(kAT), lds, (hipStream_t)stream, g_out, ha, s1, W1,
-                       W2, u, p, scale, g_ha, part, R);
+                       W2, u, p, scale, g_ha, part, R, mean, rstd, gamma, beta);
     return upp_launch_status();
+}
+
+extern "C" int upp_adapter_bwd(const float *g_out, const float *ha, const float *s1, const float *W1, const float *W2, const float *u,
+                               float p, float scale, float *g_ha, float *part, int R, int D, int H, void *stream) {
+    return adapter_bwd_launch(g_out, ha, nullptr, nullptr, nullptr, nullptr, s1, W1, W2, u, p, scale, g_ha, part, R, D, H, stream);
+}
+
+extern "C" int upp_ln_adapter_bwd(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
+                                  const float *beta, const float *s1, const float *W1, const float *W2, const float *u, float p,
+                                  float scale, float *g_ha, float *part, int R, int D, int H, void *stream) {
+    if (!mean || !rstd || !gamma || !beta) return UPP_E_BADARG;
+    return adapter_bwd_launch(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, u, p, scale, g_ha, part, R, D, H, stream);
 }

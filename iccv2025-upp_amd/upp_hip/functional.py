@@ -803,5 +803,61 @@ class _Adapter(Function):
                 gW2 if need[4] else None, gb2 if need[5] else None, None, None, None)
 
 
+class _LnAdapter(Function):
+    """The tail of a block in one launch: rows = strip(x + dp_scale(u) (y + ybias)), out = rows + scale * adapter(LayerNorm(rows)).
+    Forward: upp_ln_adapter_fwd.  Backward: upp_ln_adapter_bwd (the adapter's, rebuilding the LayerNorm output from the saved
+    rows) followed by upp_rowln_bwd -- the two kernels of the unfused path, minus the stored LayerNorm output."""
+
+    @staticmethod
+    def forward(ctx, x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, pd, scale):
+        x = x.contiguous()
+        B, Lin, D = x.shape
+        Lout = Lin - P if mode in (ROW_STRIP_CLS, ROW_STRIP) else Lin
+        y_c = y.contiguous() if y is not None else None
+        out, xo, mean, rstd, s1 = ops.ln_adapter_fwd(x, y_c, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, pd, scale, Lout)
+        ctx.save_for_backward(xo, mean, rstd, gamma, beta, u, s1, W1, W2, ud)
+        ctx.dims = (B, Lin, Lout, D, P, mode)
+        ctx.meta = (keep, pd, scale, y is not None)
+        ctx.param_ptrs = (gamma.data_ptr(), beta.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        xo, mean, rstd, gamma, beta, u, s1, W1, W2, ud = ctx.saved_tensors
+        B, Lin, Lout, D, P, mode = ctx.dims
+        keep, pd, scale, has_y = ctx.meta
+        need = ctx.needs_input_grad
+        g_out = g_out.contiguous()
+        g_ha, part = ops.ln_adapter_bwd(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, pd, scale)
+        need_ln = need[7] or need[8]
+        g_x, _, g_y, ln_part = ops.rowln_bwd(g_out, g_ha, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, P,
+                                             need_x=need[0], need_prompt=False, need_y=has_y and need[1], need_ln_part=need_ln)
+        p_gamma, p_beta, pW1, pb1, pW2, pb2 = ctx.param_ptrs
+        g_gamma = g_beta = gW1 = gb1 = gW2 = gb2 = None
+        if need_ln:
+            _, g_gamma = _DEFERRED.reduce(p_gamma, ln_part, 0, D)
+            _, g_beta = _DEFERRED.reduce(p_beta, ln_part, D, D)
+        if need[10] or need[11] or need[12] or need[13]:
+            H = W1.shape[0]
+            _, gW1 = _DEFERRED.reduce(pW1, part, 0, H * D)
+            _, gW2 = _DEFERRED.reduce(pW2, part, H * D, H * D)
+            _, gb1 = _DEFERRED.reduce(pb1, part, 2 * H * D, H)
+            _, gb2 = _DEFERRED.reduce(pb2, part, 2 * H * D + H, D)
+            gW1 = gW1.view(H, D) if gW1 is not None else None
+            gW2 = gW2.view(D, H) if gW2 is not None else None
+        return (g_x if need[0] else None, g_y, None, None, None, None, None, g_gamma if need[7] else None, g_beta if need[8] else None,
+                None, gW1 if need[10] else None, gb1 if need[11] else None, gW2 if need[12] else None, gb2 if need[13] else None,
+                None, None, None)
+
+
+def ln_adapter(x, y, ybias, u, keep, mode, P, ln, W1, b1, W2, b2, ud=None, pd=0.0, scale=0.7):
+    """One launch for `rowln(x, y=y, ybias=ybias, u=u, keep=keep, mode=mode, P=P, gamma, beta)` + `adapter(ha, rows, ...)`
+    (mode: ROW_IDENTITY / ROW_STRIP_CLS / ROW_STRIP).  Limits: D == 384, 32 hidden units."""
+    if ybias is not None and (y is None or (torch.is_grad_enabled() and ybias.requires_grad)):
+        raise ValueError("ybias is the frozen bias of the Linear that produced y")
+    return _LnAdapter.apply(x, y, ybias, u, float(keep), int(mode), int(P), ln.weight, ln.bias, float(ln.eps), W1, b1, W2, b2, ud,
+                            float(pd), float(scale))
+
+
 def adapter(ha, x, W1, b1, W2, b2, u=None, p=0.0, scale=0.7):
     return _Adapter.apply(ha, x, W1, b1, W2, b2, u, float(p), float(scale))

@@ -678,6 +678,37 @@ def adapter_fwd(ha, x, W1, b1, W2, b2, u, p, scale):
     return out, s1
 
 
+def ln_adapter_fwd(x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, Lout):
+    """Residual + prompt strip + adapter LayerNorm + adapter in one launch -> (out, xo, mean, rstd, s1); upp_ln_adapter_fwd."""
+    _need(x, "x", torch.float32, ndim=3)
+    B, Lin, D = x.shape
+    H = W1.shape[0]
+    dev = x.device
+    xo = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
+    out = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
+    mean = torch.empty((B, Lout), dtype=torch.float32, device=dev)
+    rstd = torch.empty((B, Lout), dtype=torch.float32, device=dev)
+    s1 = torch.empty((B * Lout, H), dtype=torch.float32, device=dev)
+    _call(dev, "upp_ln_adapter_fwd", _abi.ptr(x), _abi.ptr(y), _abi.ptr(ybias), _abi.ptr(u), float(keep), int(mode), int(P), _abi.ptr(gamma),
+          _abi.ptr(beta), float(eps), _abi.ptr(W1), _abi.ptr(b1), _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(ud), float(p), float(scale),
+          _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(s1), _abi.ptr(out), B, Lin, Lout, D, H)
+    return out, xo, mean, rstd, s1
+
+
+def ln_adapter_bwd(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, u, p, scale):
+    """upp_adapter_bwd with the LayerNorm output rebuilt from the saved rows and statistics -> (g_ha, partials)."""
+    D = xo.shape[-1]
+    R = xo.numel() // D
+    H = W1.shape[0]
+    g_ha = torch.empty_like(xo)
+    n = int(_abi.load().upp_adapter_part_floats(R, D))
+    nblk = (R + 31) // 32
+    part = torch.empty((nblk, n // nblk), dtype=torch.float32, device=xo.device)
+    _call(xo.device, "upp_ln_adapter_bwd", _abi.ptr(g_out), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma), _abi.ptr(beta),
+          _abi.ptr(s1), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(u), float(p), float(scale), _abi.ptr(g_ha), _abi.ptr(part), R, D, H)
+    return g_ha, part
+
+
 def adapter_bwd(g_out, ha, s1, W1, W2, u, p, scale):
     D = ha.shape[-1]
     R = ha.numel() // D

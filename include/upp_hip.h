@@ -377,6 +377,22 @@ int upp_adapter_fwd(const float *ha, const float *x, const float *W1, const floa
                     const float *u, float p, float scale, float *out, float *s1, int R, int D, int H, void *stream);
 int upp_adapter_bwd(const float *g_out, const float *ha, const float *s1, const float *W1, const float *W2, const float *u,
                     float p, float scale, float *g_ha, float *part, int R, int D, int H, void *stream);
+/* upp_ln_adapter_fwd: the row operator that closes a block (residual + drop path, prompt strip, the adapter's LayerNorm:
+ * upp_rowln_fwd with mode 0 / 3 / 4 and no `add`) and upp_adapter_fwd in ONE launch on 16-row workgroups; the LayerNorm
+ * output is never written (reference models/Point_MAE_pretask_dev.py:305-320: `x = x + drop_path(mlp(norm2(x)))`, prompt
+ * removal, `x = x + adapter(x)` with Adapter.forward :96-104).
+ *   xo (B, Lout, D) = x[src(t)] + dp_scale(u_b) * (y[src(t)] + ybias)     (y, ybias, u may be NULL)
+ *   mean, rstd (B, Lout): LayerNorm statistics of xo;  s1 (B*Lout, H);  out (B, Lout, D) = adapter(LayerNorm(xo), xo)
+ *   ud (B*Lout, H): dropout uniforms of the adapter or NULL.  Rows and statistics are bit-identical to upp_rowln_fwd's.
+ * upp_ln_adapter_bwd = upp_adapter_bwd with the LayerNorm output rebuilt from (xo, mean, rstd, gamma, beta) while the tile is
+ * staged; the row operator's own backward stays upp_rowln_bwd (g_xo = g_out, g_h = g_ha). */
+int upp_ln_adapter_fwd(const float *x, const float *y, const float *ybias, const float *u, float keep, int mode, int P,
+                       const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
+                       const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
+                       float *out, int B, int Lin, int Lout, int D, int H, void *stream);
+int upp_ln_adapter_bwd(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
+                       const float *beta, const float *s1, const float *W1, const float *W2, const float *u, float p,
+                       float scale, float *g_ha, float *part, int R, int D, int H, void *stream);
 
 /* ---- token-matrix Linear (exact f32 on the matrix cores) -------------------------------------
  * Replaces the nn.Linear layers of the Transformer blocks and their data gradients: Attention.qkv / .proj

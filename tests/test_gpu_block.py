@@ -221,6 +221,42 @@ def test_adapter_kernel_forward_backward(R, p):
         close(g, r, rtol=5e-5, atol_scale=1e-5)
 
 
+@pytest.mark.parametrize("B,Lin,P,mode,pd,with_y", [(32, 75, 10, 'strip_cls', 0.1, True), (32, 74, 10, 'strip', 0.0, True), (3, 33, 0, 'identity', 0.1, True),
+                                                     (2, 21, 5, 'strip_cls', 0.0, False), (1, 16, 0, 'identity', 0.0, True), (32, 43, 10, 'strip', 0.1, True)])
+def test_block_tail_in_one_launch_equals_row_kernel_plus_adapter(B, Lin, P, mode, pd, with_y):
+    """upp_ln_adapter_fwd / _bwd (residual + strip + adapter LayerNorm + adapter, 16-row workgroups) against the two launches it
+    replaces: rows, statistics bit-identical; the output and every gradient within f32 re-association of the two small products."""
+    from upp_hip import ops
+    torch.manual_seed(B * 100 + Lin)
+    D, H, dev = 384, 32, 'cuda'
+    m = {'strip_cls': HF.ROW_STRIP_CLS, 'strip': HF.ROW_STRIP, 'identity': HF.ROW_IDENTITY}[mode]
+    Lout = Lin - P if m != HF.ROW_IDENTITY else Lin
+    mk = lambda *s, sc=1.0: (sc * torch.randn(*s, device=dev)).requires_grad_(True)
+    x, y = mk(B, Lin, D), (mk(B, Lin, D) if with_y else None)
+    yb = 0.1 * torch.randn(D, device=dev) if with_y else None
+    u = torch.rand(B, device=dev) if with_y else None
+    ln = torch.nn.LayerNorm(D).to(dev)
+    with torch.no_grad():
+        ln.weight.add_(0.1 * torch.randn(D, device=dev)); ln.bias.add_(0.1 * torch.randn(D, device=dev))
+    W1, b1, W2, b2 = mk(H, D, sc=D ** -0.5), mk(H, sc=0.1), mk(D, H, sc=H ** -0.5), mk(D, sc=0.1)
+    ud = torch.rand(B * Lout, H, device=dev) if pd > 0 else None
+    w = torch.randn(B, Lout, D, device=dev)
+    leaves = [t for t in (x, y, ln.weight, ln.bias, W1, b1, W2, b2) if t is not None]
+    out = HF.ln_adapter(x, y, yb, u, 0.9, m, P, ln, W1, b1, W2, b2, ud, pd, 0.7)
+    grads = torch.autograd.grad((out * w).sum(), leaves)
+    x4, ha = HF.rowln(x, y=y, ybias=yb, u=u, keep=0.9, mode=m, P=P, gamma=ln.weight, beta=ln.bias, eps=ln.eps)
+    ref = HF.adapter(ha, x4, W1, b1, W2, b2, ud, pd, 0.7)
+    rgrads = torch.autograd.grad((ref * w).sum(), leaves)
+    # the saved rows / statistics of the fused forward are the row kernel's, bit for bit
+    o2, xo, mean, rstd, s1 = ops.ln_adapter_fwd(x.detach(), None if y is None else y.detach(), yb, u, 0.9, m, P, ln.weight.detach(), ln.bias.detach(), ln.eps,
+                                                W1.detach(), b1.detach(), W2.detach(), b2.detach(), ud, pd, 0.7, Lout)
+    xo_r, h_r, mean_r, rstd_r = ops.rowln_fwd(x.detach(), None, None, m, P, None if y is None else y.detach(), u, 0.9, ln.weight.detach(), ln.bias.detach(), ln.eps, Lout, ybias=yb)
+    assert torch.equal(xo, xo_r) and torch.equal(mean, mean_r) and torch.equal(rstd, rstd_r) and torch.equal(o2, out.detach())
+    close(out, ref, rtol=1e-5, atol_scale=2e-6)
+    for g, r in zip(grads, rgrads):
+        close(g, r, rtol=5e-5, atol_scale=1e-5)
+
+
 # ------------------------------------------------------------------ fused propagation step (CSR + in-kernel BatchNorm)
 @pytest.mark.parametrize("n,rows,seg", [(8192, 2400, None), (1024, 2400, None), (16384, 1024, (512, 32)), (5, 3, None), (4096, 15360, None)])
 def test_csr_build_is_the_stable_inverse(n, rows, seg):

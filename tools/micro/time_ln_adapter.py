@@ -1,0 +1,18 @@
+import sys, os
+sys.path[:0]=['/root/repo','/root/repo/iccv2025-upp_amd']
+import torch
+from bench import time_kernel
+from upp_hip import ops
+import upp_hip.functional as HF
+B,Lin,P,D,H=32,85,10,384,32
+dev='cuda'
+x=torch.randn(B,Lin,D,device=dev); y=torch.randn(B,Lin,D,device=dev); yb=torch.randn(D,device=dev)
+g=torch.ones(D,device=dev); bt=torch.zeros(D,device=dev)
+W1=torch.randn(H,D,device=dev)*0.05; b1=torch.zeros(H,device=dev); W2=torch.randn(D,H,device=dev)*0.1; b2=torch.zeros(D,device=dev)
+Lout=Lin-P
+t1=time_kernel(lambda: ops.ln_adapter_fwd(x,y,yb,None,1.0,3,P,g,bt,1e-5,W1,b1,W2,b2,None,0.0,0.7,Lout))
+def two():
+    xo,h,mean,rstd=ops.rowln_fwd(x,None,None,3,P,y,None,1.0,g,bt,1e-5,Lout,ybias=yb)
+    ops.adapter_fwd(h.view(-1,D),xo.view(-1,D),W1,b1,W2,b2,None,0.0,0.7)
+t2=time_kernel(two)
+print("fused %.2f us   rowln+adapter %.2f us"%(t1*1e3,t2*1e3))
