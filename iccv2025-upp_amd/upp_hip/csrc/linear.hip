@@ -49,6 +49,7 @@ struct LinArgs {
     int M, N, K;
     int tiles_n;                  // workgroup tiles along N
     int epi;
+    int ktail;                    // K is not a multiple of the k-stage: the last stage reads zeros beyond K (K % 4 == 0)
 #ifdef UPP_LIN_STAMPS
     unsigned long long *stamps;   // diagnostic build only (tools/micro/lin_stamps.py): [workgroup][8] clock readings
 #endif
@@ -82,6 +83,8 @@ __device__ __forceinline__ void gelu_pair(float v, float &gelu, float &dgelu) {
     dgelu = __builtin_fmaf(v * 0.39894228040143267794f, e, cdf);
 }
 
+__device__ __attribute__((aligned(16))) const float g_lin_zeros[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -114,6 +117,8 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     // ---- DMA sources: instruction t fills row images 8t .. 8t+7; lane -> (row image 8t + lane/8, granule lane%8).
     // Everything that depends on t only (sub-image, A or W, first row) is wave-uniform: scalar code, few VALU instructions.
     const float *src[TPW];
+    int koff[TPW];                                                     // k of the lane's granule inside a k-stage
+    const int nsc = (g.K + 32 * KS * KC - 1) / (32 * KS * KC);
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int t = wave + q * NW;
@@ -124,15 +129,19 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
         const long long ld = isA ? g.lda : g.ldw;
         const int first = isA ? m0 + rr0 : n0 + rr0 - BM, last = isA ? M - 1 : N - 1;
         const int row = min(first + (lane >> 3), last);
-        src[q] = base + row * ld + (sk * 32 + 4 * ((lane & 7) ^ (((rho0 >> 1) + (lane >> 4)) & 7)));
+        koff[q] = sk * 32 + 4 * ((lane & 7) ^ (((rho0 >> 1) + (lane >> 4)) & 7));
+        src[q] = base + row * ld + koff[q];
     }
     static_assert(TPW <= 6, "DMA slots of the interleaved schedule");
     auto issue1 = [&](int q, int stage, int c) {            // q-th DMA instruction of this wave for k-stage c
         const int t = wave + q * NW;
 #ifndef UPP_LIN_NO_DMA        // diagnostic build without the operand stream (the MFMAs then run on whatever the LDS holds)
-        if (TPW * NW == T || t < T)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[q < TPW ? q : 0] + (long long)c * (32 * KS * KC)),
-                                             (lds_ptr_t)(lds + stage * STAGE + t * 1024), 16, 0, 0);
+        if (TPW * NW == T || t < T) {
+            const float *p = src[q < TPW ? q : 0] + (long long)c * (32 * KS * KC);
+            // (contraction lengths that are not a multiple of the k-stage: granules beyond K come from a page of zeros)
+            if (g.ktail && c == nsc - 1 && koff[q < TPW ? q : 0] + c * (32 * KS * KC) >= g.K) p = g_lin_zeros;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)p, (lds_ptr_t)(lds + stage * STAGE + t * 1024), 16, 0, 0);
+        }
 #else
         (void)t; (void)stage; (void)c;
 #endif
@@ -160,7 +169,6 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     unsigned adrA[4], adrW[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { adrA[i] = lds0 + offA[i]; adrW[i] = lds0 + offW[i]; }
-    const int nsc = g.K / (32 * KS * KC);
 #define UPP_READ_FRAG(F, SO)                                                          \
     asm volatile("ds_read_b128 %0, %1" : "=v"(F.a0) : "v"(adrA[0] + (SO)));           \
     asm volatile("ds_read_b128 %0, %1" : "=v"(F.b0) : "v"(adrW[0] + (SO)));           \
@@ -484,11 +492,11 @@ int pick_config(int M, int N, int K) {
     long long best_cost = 0;
     for (int i = 0; i < kNumConfigs; ++i) {
         const LinConfig c = kConfigs[i];
-        if (K % (32 * c.ks * c.kc) != 0) continue;
         const long long wgs = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
         const int waves = c.bmb * c.bnb * c.ks;
         const long long rounds = (wgs + 255) / 256;
-        const long long quarters = rounds * ((waves + 3) / 4) * (4 / c.ks);                      // quarter blocks per SIMD
+        const long long ksteps = (K + 32 * c.ks * c.kc - 1) / (32 * c.ks * c.kc) * c.kc;         // 32-wide k-steps per wave, padding included
+        const long long quarters = rounds * ((waves + 3) / 4) * ksteps;                          // MFMA work per SIMD (x 16 MFMAs)
         const long long traffic = 100LL * (c.bmb + c.bnb) / (c.bmb * c.bnb);                    // staged rows per block
         long long cost;
         if (rounds == 1) cost = quarters * 1000000LL + (16 - waves) * 10000LL + (256 - wgs);
@@ -506,6 +514,7 @@ extern "C" void upp_linear_set_stamps(unsigned long long *p) { g_lin_stamps = p;
 
 extern "C" int upp_linear_tile(int M, int N, int K) {
     if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
+    if (K % 4 != 0) return UPP_E_RANGE;
     const int i = pick_config(M, N, K);
     if (i < 0) return UPP_E_RANGE;
     return config_code(kConfigs[i]);
@@ -514,7 +523,7 @@ extern "C" int upp_linear_tile(int M, int N, int K) {
 extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias, float *C, long long ldc,
                               float *aux, long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream) {
     if (!A || !W || !C || M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
-    if (K % 32 != 0 || lda % 4 != 0 || ldw % 4 != 0 || lda < K || ldw < K || ldc < N) return UPP_E_RANGE;
+    if (K % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || lda < K || ldw < K || ldc < N) return UPP_E_RANGE;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return UPP_E_RANGE;
     if (ldc > (1LL << 24) || ldaux > (1LL << 24)) return UPP_E_RANGE;          // 32-bit offsets inside a 32-row block
     if (epilogue < LEPI_NONE || epilogue > LEPI_MUL) return UPP_E_RANGE;
@@ -532,7 +541,7 @@ extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, lon
         if (i < 0) return UPP_E_RANGE;
         tile = config_code(kConfigs[i]);
     }
-    if (K % (32 * ((tile >> 4) & 15) * (tile & 15)) != 0) return UPP_E_RANGE;
+    g.ktail = K % (32 * ((tile >> 4) & 15) * (tile & 15)) != 0;
 #define UPP_LIN_CASE(a, b, c, d) case a * 4096 + b * 256 + c * 16 + d: return launch_linear<a, b, c, d>(g, st);
     switch (tile) {
         UPP_LIN_CONFIGS(UPP_LIN_CASE)

@@ -371,10 +371,10 @@ def _wt(w):
 
 
 def linear_usable(x, weight):
-    """upp_linear_f32 serves f32 HIP operands whose contraction length is a multiple of 32."""
+    """upp_linear_f32 serves f32 HIP operands with 16-byte aligned rows (contraction length a multiple of 4)."""
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and weight.stride(1) == 1
             and weight.stride(0) % 4 == 0 and weight.data_ptr() % 16 == 0
-            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 32 == 0 and x.numel() > 0)
+            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 4 == 0 and x.numel() > 0)
 
 
 class _LinearMFMA(Function):
@@ -397,10 +397,10 @@ class _LinearMFMA(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wt = _wt(w)
-            if wt.shape[1] % 32 == 0:
+            if wt.shape[1] % 4 == 0 and g2.stride(0) % 4 == 0:
                 gx = ops.linear_f32(g2, wt).view(g.shape[:-1] + (w.shape[1],))
             else:
-                note_declined("linear data gradient", "N = %d is not a multiple of 32" % wt.shape[1])
+                note_declined("linear data gradient", "N = %d is not a multiple of 4" % wt.shape[1])
                 gx = torch.mm(g2, w).view(g.shape[:-1] + (w.shape[1],))
         if ctx.needs_input_grad[1]:
             gw = weight_grad(g2, x.reshape(-1, x.shape[-1]), w, ctx.own_wgrad)
@@ -441,7 +441,7 @@ def linear(x, weight, bias=None, own_wgrad=False):
     (the patch embedding; default: below WGRAD_MIN_ROWS rows the library's split-K GEMM is faster and is used)."""
     if not linear_usable(x, weight):
         if x.is_cuda:
-            note_declined("linear %s x %s" % (tuple(x.shape), tuple(weight.shape)), "dtype / layout / K % 32")
+            note_declined("linear %s x %s" % (tuple(x.shape), tuple(weight.shape)), "dtype / layout / K % 4")
         return F.linear(x, weight, bias)
     if not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         return ops.linear_f32(x, weight, bias, ops.LIN_BIAS if bias is not None else ops.LIN_NONE)

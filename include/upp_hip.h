@@ -410,7 +410,8 @@ int upp_ln_adapter_bwd(const float *g_out, const float *xo, const float *mean, c
  *         forces workgroups of BMB x BNB blocks of 32 x 32 (one block per wave), the contraction split KS ways over wave
  *         groups and 32*KS*KC values of k per LDS stage -- one of the compiled shapes (csrc/linear.hip UPP_LIN_CONFIGS),
  *         anything else is UPP_E_RANGE; for measurements.
- * Limits: K % 32 == 0 (K % (32 KS KC) == 0 for a forced tile), lda % 4 == 0, ldw % 4 == 0, A and W 16-byte aligned. */
+ * Limits: K % 4 == 0 (a k-stage holds 32 KS KC values of k; the last one reads zeros beyond K: exact), lda % 4 == 0, ldw % 4 == 0,
+ * A and W 16-byte aligned. */
 int upp_linear_tile(int M, int N, int K);
 /* Weight gradient of a trainable Linear (AddmmBackward's second GEMM in the reference): dW (N,K) = G^T . X with G = dY (M,N)
  * and X (M,K) row-major (leading dimensions ldg, ldx).  The M rows are split over upp_linear_wgrad_splits(M,N,K) groups of

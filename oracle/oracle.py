@@ -169,7 +169,12 @@ def linear_f32(a, w, bias=None, aux=None, ks=1, kc=1, epilogue=0):
     a, w = _c(a), _c(w)
     M, K = a.shape
     N = w.shape[0]
-    assert w.shape[1] == K and K % (32 * ks * kc) == 0
+    assert w.shape[1] == K and K % 4 == 0
+    stage = 32 * ks * kc
+    if K % stage:                  # the kernel's last k-stage reads zeros beyond K
+        pad = stage - K % stage
+        a, w = _c(np.pad(a, ((0, 0), (0, pad)))), _c(np.pad(w, ((0, 0), (0, pad))))
+        K += pad
     out = np.empty((M, N), np.float32)
     b = _c(bias) if bias is not None else None
     x = _c(aux) if aux is not None else None

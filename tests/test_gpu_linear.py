@@ -129,7 +129,7 @@ def test_strided_rows_and_rejections():
     w = torch.randn(96, 384, device='cuda') * 0.05
     close(ops.linear_f32(a, w), F.linear(a, w))
     with pytest.raises(RuntimeError):
-        ops.linear_f32(torch.randn(8, 100, device='cuda'), torch.randn(16, 100, device='cuda'))     # K % 32 != 0
+        ops.linear_f32(torch.randn(8, 102, device='cuda'), torch.randn(16, 102, device='cuda'))     # K % 4 != 0
     with pytest.raises(RuntimeError):
         ops.linear_f32(torch.randn(8, 64), torch.randn(16, 64))                                     # CPU tensors: no CPU path
     assert lib.upp_linear_f32(None, 0, None, 0, None, None, 0, None, 0, 1, 1, 32, 0, 0, None) == -1
@@ -242,6 +242,29 @@ def test_bit_exact_against_the_cpu_restatement_of_its_summation_order(cfg):
                                       O.linear_f32(an, wn, bias=b.cpu().numpy(), ks=ks, kc=kc, epilogue=1))
         np.testing.assert_array_equal(ops.linear_f32(a, w, None, ops.LIN_MUL, aux=x, tile=cfg).cpu().numpy(),
                                       O.linear_f32(an, wn, aux=x.cpu().numpy(), ks=ks, kc=kc, epilogue=4))
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 40, 256), (32, 256, 40), (1024, 64, 12), (2400, 384, 100), (35072, 32, 60), (75, 96, 4), (1024, 16, 192)])
+def test_contraction_lengths_that_are_not_a_multiple_of_the_k_stage(M, N, K):
+    """K % 4 == 0 is enough: the last k-stage takes its granules beyond K from a page of zeros (bit-exact against the oracle on
+    zero-padded operands, for the library's choice and for every compiled decomposition; strided operands included)."""
+    import oracle as O
+    lib = _abi.load()
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    big = torch.randn(M, K + 8, device='cuda', generator=g)
+    a = big[:, 4:4 + K]                                       # row stride K + 8, 16-byte aligned start
+    w = torch.randn(N, K, device='cuda', generator=g) * K ** -0.5
+    b = torch.randn(N, device='cuda', generator=g)
+    an, wn = a.cpu().numpy(), w.cpu().numpy()
+    close(ops.linear_f32(a, w, b, ops.LIN_BIAS), F.linear(a, w, b))
+    for cfg in [lib.upp_linear_tile(M, N, K)] + CONFIGS:
+        ks, kc = (cfg >> 4) & 15, cfg & 15
+        np.testing.assert_array_equal(ops.linear_f32(a, w, b, ops.LIN_BIAS, tile=cfg).cpu().numpy(),
+                                      O.linear_f32(an, wn, bias=b.cpu().numpy(), ks=ks, kc=kc, epilogue=1))
+    # and through autograd (data gradient: contraction over N)
+    x = a.clone().requires_grad_(True)
+    HF.linear(x, w, b).backward(torch.ones(M, N, device='cuda'))
+    close(x.grad, torch.ones(M, N, device='cuda') @ w)
 
 
 def test_block_shapes_bit_exact_against_the_oracle():
