@@ -117,7 +117,7 @@ class MaskTransformer(nn.Module):
         vis = order[:, :n_vis]
         x_vis = torch.gather(tokens, 1, vis.unsqueeze(-1).expand(-1, -1, tokens.shape[-1]))
         c_vis = torch.gather(center, 1, vis.unsqueeze(-1).expand(-1, -1, 3))
-        x_vis = self.norm(self.blocks(x_vis, self.pos_embed(c_vis)))
+        x_vis = self.norm(self.blocks(x_vis, L.mlp2(self.pos_embed, c_vis)))
         return x_vis, mask, order, n_vis
 
 
@@ -161,12 +161,12 @@ class Point_MAE(nn.Module):
         x_vis, mask, order, n_vis = self.MAE_encoder(neighborhood, center, mask=mask)
         B, _, C = x_vis.shape
         c_sorted = torch.gather(center, 1, order.unsqueeze(-1).expand(-1, -1, 3))        # visible centres, then masked
-        pos_full = self.decoder_pos_embed(c_sorted)
+        pos_full = L.mlp2(self.decoder_pos_embed, c_sorted)
         N = order.shape[1] - n_vis
         x_full = torch.cat([x_vis, self.mask_token.expand(B, N, -1)], dim=1)
         x_rec = self.MAE_decoder(x_full, pos_full, N)
         head = self.increase_dim[0]
-        rebuild = F.linear(x_rec, head.weight.squeeze(-1), head.bias).reshape(B * N, -1, 3)
+        rebuild = HF.linear(x_rec, head.weight.squeeze(-1), head.bias).reshape(B * N, -1, 3)
         m_idx = order[:, n_vis:]
         gt = torch.gather(neighborhood, 1, m_idx.view(B, N, 1, 1).expand(-1, -1, self.group_size, 3)).reshape(B * N, -1, 3)
         if vis:

@@ -43,7 +43,7 @@ class Point_MAE_pretask_dev(PromptedBackbone):
         """reference :669-702.  pts = [point_num shape points | noise points].  The rectify prompter predicts an offset per
         point; noise points are supervised with the mean offset to their 4 nearest shape points, shape points with 0."""
         P = pts.shape[1]
-        pos = self.pos_embed(vis_center)
+        pos = L.mlp2(self.pos_embed, vis_center)
         tokens = self.blocks(tokens, pos, path='rectify', rectify_adapter=True, rectify_prompts=True,
                              rectify_depth=self.config.prompter_config['rectify_depth'])
         noise, partial = pts[:, point_num:], pts[:, :point_num]

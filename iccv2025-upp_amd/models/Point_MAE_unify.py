@@ -99,7 +99,7 @@ class PromptedBackbone(nn.Module):
         grouper = Group(num_group=self.vis_num, group_size=16)
         neighborhood, vis_center = grouper(pts)
         tokens = self.encoder(neighborhood)
-        pos = self.pos_embed(vis_center)
+        pos = L.mlp2(self.pos_embed, vis_center)
         tokens = self.blocks(tokens, pos, path='rectify', rectify_adapter=True, rectify_prompts=True,
                              rectify_depth=self.config.prompter_config['rectify_depth'])
         pred_vector = self.rectify_prompter(pts, vis_center, tokens, require_shape_feature=False)
@@ -127,15 +127,15 @@ class PromptedBackbone(nn.Module):
         through the pretask path of the backbone and the MAE decoder (reference :584-606, pretask_dev.py:713-737)."""
         B = tokens.shape[0]
         x_vis = tokens.reshape(B, -1, self.trans_dim)
-        pos = self.pos_embed(vis_center)
+        pos = L.mlp2(self.pos_embed, vis_center)
         x_vis = self.blocks(x_vis, pos, path='pretask', pretask_adapter=True, pretask_prompts=True,
                             pretask_depth=self.config.prompter_config['pretask_depth'])
         x_vis = self.norm(x_vis)
-        pos_vis = self.decoder_pos_embed(vis_center).reshape(B, -1, self.trans_dim)
-        shape_feature = self.shape_pred(x_vis).reshape(B, self.vis_short * self.vis_num)
-        predict_center = self.coarse_pred(shape_feature).reshape(B, self.n_masked, 3)
-        predict_token = self.predict_token_generator(x_vis)
-        pos_mask = self.decoder_pos_embed(predict_center).reshape(B, -1, self.trans_dim)
+        pos_vis = L.mlp2(self.decoder_pos_embed, vis_center).reshape(B, -1, self.trans_dim)
+        shape_feature = L.mlp2(self.shape_pred, x_vis).reshape(B, self.vis_short * self.vis_num)
+        predict_center = L.mlp2(self.coarse_pred, shape_feature).reshape(B, self.n_masked, 3)
+        predict_token = L.mlp2(self.predict_token_generator, x_vis)
+        pos_mask = L.mlp2(self.decoder_pos_embed, predict_center).reshape(B, -1, self.trans_dim)
         N = pos_mask.shape[1]
         mask_token = propagate(predict_center, vis_center, self.mask_token.expand(B, N, -1), predict_token,
                                de_neighbors=6)
@@ -143,7 +143,7 @@ class PromptedBackbone(nn.Module):
                                  pretask_adapter=True, path='pretask')
         M = x_rec.shape[1]
         head = self.dense_pred[0]                                  # Conv1d(D, 3*group_size, 1) == a per-token Linear
-        rel = F.linear(x_rec, head.weight.squeeze(-1), head.bias).reshape(B, M, -1, 3)
+        rel = HF.linear(x_rec, head.weight.squeeze(-1), head.bias).reshape(B, M, -1, 3)
         return predict_center, (rel + predict_center.unsqueeze(-2)).reshape(B, -1, 3)
 
 
@@ -215,7 +215,7 @@ class Point_MAE_unify(PromptedBackbone):
 
     def _front_state(self, pts):
         tokens, center = self._embed(pts)
-        state = (tokens, center, self.pos_embed(center))
+        state = (tokens, center, L.mlp2(self.pos_embed, center))
         lvl2 = self._level2(center)
         if lvl2:
             state += (lvl2['center2'], lvl2['center1_idx'], lvl2['center2_idx'])
@@ -241,7 +241,7 @@ class Point_MAE_unify(PromptedBackbone):
     def _head(self, tokens, center, rest=()):
         B = tokens.size(0)
         x = torch.cat((self.cls_token.expand(B, -1, -1), tokens), dim=1)
-        pos_tokens = rest[0] if len(rest) > 0 else self.pos_embed(center)
+        pos_tokens = rest[0] if len(rest) > 0 else L.mlp2(self.pos_embed, center)
         pos = torch.cat((self.cls_pos.expand(B, -1, -1), pos_tokens), dim=1)
 
         if len(rest) >= 4:         # level-2 grouping handed over by prompt_tokens
@@ -283,7 +283,8 @@ class Point_MAE_unify(PromptedBackbone):
                 x = HF.bn_relu_drop(x, bn, u, p, self.training)
                 i += 3
             else:
-                x = layers[i](x)
+                # (the head is trainable: data and weight gradients on upp_linear_f32 / upp_linear_wgrad_f32, 32 rows)
+                x = HF.linear(x, layers[i].weight, layers[i].bias, own_wgrad=True) if isinstance(layers[i], nn.Linear) else layers[i](x)
                 i += 1
         return x
 

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 from .build import MODELS
 from . import upp_layers as L
+from upp_hip import functional as HF
 from .Point_MAE_unify import PromptedBackbone
 from .upp_layers import Group, PointNetFeaturePropagation, PositionalEmbedding, _bn_rows, _pointwise_bn_relu
 
@@ -47,7 +48,7 @@ class Point_MAE_unify_seg(PromptedBackbone):
         for conv, bn, act in ((c1, b1, a1), (c2, b2, a2)):
             if self.training and bn.track_running_stats:
                 L.bump_counter(bn.num_batches_tracked)
-            x = act(_bn_rows(F.linear(x, conv.weight.squeeze(-1), conv.bias), bn, self.training))
+            x = act(_bn_rows(HF.linear(x, conv.weight.squeeze(-1), conv.bias, own_wgrad=True), bn, self.training))
         return x
 
     def _head(self, point_feat, global_feat):
@@ -55,13 +56,13 @@ class Point_MAE_unify_seg(PromptedBackbone):
         c1, bn1, _, drop, c2, bn2, _, c3 = self.seg_head
         B, N, C = point_feat.shape
         w1 = c1.weight.squeeze(-1)
-        per_sample = F.linear(global_feat, w1[:, C:], c1.bias)                       # (B,512), once per sample
-        h = F.linear(point_feat.reshape(B * N, C), w1[:, :C]).view(B, N, -1) + per_sample.unsqueeze(1)
+        per_sample = HF.linear(global_feat, w1[:, C:], c1.bias, own_wgrad=True)                       # (B,512), once per sample
+        h = HF.linear(point_feat.reshape(B * N, C), w1[:, :C], own_wgrad=True).view(B, N, -1) + per_sample.unsqueeze(1)
         if self.training and bn1.track_running_stats:
             L.bump_counter(bn1.num_batches_tracked)
         h = drop(_bn_rows(h.view(B * N, -1), bn1, self.training, relu=True))
         h = _pointwise_bn_relu(h, c2, bn2, self.training)
-        h = F.linear(h, c3.weight.squeeze(-1), c3.bias)
+        h = HF.linear(h, c3.weight.squeeze(-1), c3.bias, own_wgrad=True)
         return F.log_softmax(h, dim=-1).view(B, N, -1)
 
     def forward(self, pts, cls_label, label_points=None, completion_prompt=True, denoise=True, point_num=1024, **kwargs):
@@ -83,7 +84,7 @@ class Point_MAE_unify_seg(PromptedBackbone):
         if completion_prompt:
             pts = self._complete(pts, point_num)
         neighborhood, center = self.group_divider(pts)
-        state = (pts, self.encoder(neighborhood), center, self.pos_embed(center))
+        state = (pts, self.encoder(neighborhood), center, L.mlp2(self.pos_embed, center))
         lvl2 = self._level2(center)
         if lvl2:
             state += (lvl2['center2'], lvl2['center1_idx'], lvl2['center2_idx'])

@@ -276,13 +276,21 @@ def _bn_rows(x, bn, training, relu=False):
     return F.relu(y) if relu else y
 
 
+def mlp2(seq, x):
+    """`Sequential(Linear, GELU, Linear)` -- the position MLPs (3 -> 128 -> D) and the prompter heads -- on HF.linear: the GELU rides
+    in the first layer's epilogue, K = 3 takes the small-K kernel (reference models/Point_MAE_pretask_dev.py:395-399, 46)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and len(seq) == 3 and isinstance(seq[1], nn.GELU) and seq[1].approximate == 'none'):
+        return seq(x)
+    return HF.linear(HF.linear(x, seq[0].weight, seq[0].bias, act='gelu'), seq[2].weight, seq[2].bias)
+
+
 def _pointwise_bn_relu(x, conv, bn, training):
     """relu(bn(conv1x1(x))) on a channels-last (rows, C_in) matrix: a 1x1 Conv1d/Conv2d is a GEMM and
     BatchNorm over (batch, positions) is BatchNorm over rows -- no NCHW permutes, no MIOpen conv."""
     if training and bn.track_running_stats:
         bump_counter(bn.num_batches_tracked)
     w = conv.weight.view(conv.weight.shape[0], -1)
-    return _bn_rows(F.linear(x, w, conv.bias), bn, training, relu=True)
+    return _bn_rows(HF.linear(x, w, conv.bias), bn, training, relu=True)
 
 
 class Encoder(nn.Module):

@@ -366,8 +366,10 @@ TRANSPOSED = _TransposedWeights()
 
 
 def _wt(w):
-    """W^T (K,N) contiguous: cached for frozen weights, a fresh copy for trainable ones (they change every step)."""
-    return w.detach().t().contiguous() if w.requires_grad else TRANSPOSED.get(w)
+    """W^T (K,N) contiguous: cached for frozen weights, a fresh upp_transpose_f32 copy for trainable ones (they change every step)."""
+    if w.requires_grad:
+        return ops.transpose(w.detach()) if (w.is_cuda and w.stride(1) == 1) else w.detach().t().contiguous()
+    return TRANSPOSED.get(w)
 
 
 def linear_usable(x, weight):
@@ -435,17 +437,43 @@ def b_needed(ctx):
     return len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]
 
 
-def linear(x, weight, bias=None, own_wgrad=False):
-    """F.linear on the FP32 matrix cores (upp_linear_f32) where the shapes allow; otherwise the library GEMM (said once
-    under UPP_VERBOSE).  own_wgrad: the weight gradient of a trainable layer on upp_linear_wgrad_f32 whatever the row count
-    (the patch embedding; default: below WGRAD_MIN_ROWS rows the library's split-K GEMM is faster and is used)."""
+_ACT_EPI = {None: (ops.LIN_BIAS, 0), 'relu': (ops.LIN_BIAS_RELU, 1), 'gelu': (ops.LIN_BIAS_GELU, 2)}
+
+
+def _act_torch(y, act):
+    return y if act is None else (F.relu(y) if act == 'relu' else F.gelu(y))
+
+
+def linear(x, weight, bias=None, own_wgrad=False, act=None):
+    """act(F.linear(x, weight, bias)) on this library's kernels: upp_linear_f32 (FP32 matrix cores) for 16-byte aligned rows and
+    K % 4 == 0, upp_linear_smallk_f32 (K <= 64, N <= 256, forward only) for the rest; otherwise the library GEMM (said once under
+    UPP_VERBOSE).  act: None / 'relu' / 'gelu' (erf) -- fused into the epilogue when nothing needs a gradient, applied by torch
+    otherwise.  own_wgrad: the weight gradient of a trainable layer on upp_linear_wgrad_f32 whatever the row count (the patch
+    embedding, the classification head; default: between WGRAD_FEW_ROWS and WGRAD_MIN_ROWS rows the library's split-K GEMM is used)."""
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))
     if not linear_usable(x, weight):
+        if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] == weight.shape[1]
+                and weight.shape[1] <= 64 and weight.shape[0] <= 256 and x.numel() > 0 and not needs_grad):
+            return ops.linear_smallk(x, weight, bias, _ACT_EPI[act][1])
         if x.is_cuda:
-            note_declined("linear %s x %s" % (tuple(x.shape), tuple(weight.shape)), "dtype / layout / K % 4")
-        return F.linear(x, weight, bias)
-    if not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
-        return ops.linear_f32(x, weight, bias, ops.LIN_BIAS if bias is not None else ops.LIN_NONE)
-    return _LinearMFMA.apply(x, weight, bias, bool(own_wgrad))
+            note_declined("linear %s x %s" % (tuple(x.shape), tuple(weight.shape)), "dtype / layout / K % 4" + (" with a gradient" if needs_grad else ""))
+        return _act_torch(F.linear(x, weight, bias), act)
+    if not needs_grad:
+        if act is not None and bias is None:
+            bias = _zero_bias(weight)
+        return ops.linear_f32(x, weight, bias, _ACT_EPI[act][0] if bias is not None else ops.LIN_NONE)
+    return _act_torch(_LinearMFMA.apply(x, weight, bias, bool(own_wgrad)), act)
+
+
+_ZERO_BIAS = {}
+
+
+def _zero_bias(weight):
+    key = (weight.device, weight.shape[0])
+    z = _ZERO_BIAS.get(key)
+    if z is None:
+        z = _ZERO_BIAS[key] = torch.zeros(weight.shape[0], dtype=torch.float32, device=weight.device)
+    return z
 
 
 class _MlpGelu(Function):

@@ -216,7 +216,7 @@ def patch_embed_fwd(point_groups, enc, training):
 
 
 # ------------------------------------------------------------------ Transformer block glue
-LIN_NONE, LIN_BIAS, LIN_BIAS_GELU, LIN_BIAS_GELU_D, LIN_MUL = 0, 1, 2, 3, 4
+LIN_NONE, LIN_BIAS, LIN_BIAS_GELU, LIN_BIAS_GELU_D, LIN_MUL, LIN_BIAS_RELU = 0, 1, 2, 3, 4, 5
 
 
 class time_linear_calls:
@@ -278,6 +278,37 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
         ev1.record()
         scope.calls.append((M, N, K, int(epilogue), ev0, ev1))
     return (out, d) if epilogue == LIN_BIAS_GELU_D else out
+
+
+def linear_smallk(x, w, bias=None, act=0):
+    """act(x (...,K) . w (N,K)^T + bias) for K <= 64, N <= 256, any alignment (upp_linear_smallk_f32); act 0 none / 1 ReLU / 2 GELU."""
+    for t_, n_ in ((x, "x"), (w, "w")):
+        if not (isinstance(t_, torch.Tensor) and t_.is_cuda and t_.dtype == torch.float32):
+            raise RuntimeError(f"{n_} must be a f32 HIP (cuda) tensor; upp_hip has no CPU path")
+    _same_device(x, w)
+    K, N = x.shape[-1], w.shape[0]
+    if w.dim() != 2 or w.shape[1] != K:
+        raise RuntimeError(f"linear_smallk: x (...,{K}) against w {tuple(w.shape)}")
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+    _call(x.device, "upp_linear_smallk_f32", _abi.ptr(x2), x2.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(bias), _abi.ptr(out), N,
+          x2.shape[0], N, K, int(act))
+    return out
+
+
+def transpose(w, out=None):
+    """W^T of a 2-D f32 matrix with contiguous rows (upp_transpose_f32); `out` (cols, rows) is overwritten in place when given."""
+    if not (isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1):
+        raise RuntimeError("transpose: a 2-D f32 HIP (cuda) matrix with contiguous rows is required (column windows are fine)")
+    rows, cols = w.shape
+    if out is None:
+        out = torch.empty((cols, rows), dtype=torch.float32, device=w.device)
+    _call(w.device, "upp_transpose_f32", _abi.ptr(w), w.stride(0), _abi.ptr(out), out.stride(0), rows, cols)
+    return out
 
 
 def linear_wgrad(g, x):

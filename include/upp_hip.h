@@ -404,6 +404,7 @@ int upp_ln_adapter_bwd(const float *g_out, const float *xo, const float *mean, c
  * A data gradient dX = dY . W is the same call with W^T stored row-major: (A = dY, W = W^T (K,N), N <-> K).
  *   epilogue 0: none                      1: + bias[n]
  *            2: GELU(. + bias[n])         3: GELU(. + bias[n]), and aux (M,N; ldaux) receives GELU'(. + bias[n])
+ *            5: ReLU(. + bias[n])
  *            4: . * aux[m][n]   (exact erf GELU, as nn.GELU; 3 / 4 make fc1 forward / fc2 data-gradient carry the
  *               activation and its backward, reference :165 `self.act`)
  *   tile: 0 = chosen by the library for (M,N,K) (upp_linear_tile returns that choice); else 4096*BMB + 256*BNB + 16*KS + KC
@@ -423,6 +424,16 @@ int upp_linear_wgrad_f32(const float *G, long long ldg, const float *X, long lon
 int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias,
                    float *C, long long ldc, float *aux, long long ldaux,
                    int M, int N, int K, int epilogue, int tile, void *stream);
+/* upp_linear_smallk_f32: y (M,N) = act(x (M,K) . W (N,K)^T + bias) for the Linear layers upp_linear_f32 does not take (K not a
+ * multiple of 4, unaligned rows): the first layer of every position MLP (K = 3; reference models/Point_MAE_unify.py pos_embed /
+ * models/Point_MAE_pretask_dev.py:395-399 `nn.Linear(3, 128), nn.GELU(), nn.Linear(128, dim)`) and the first point-wise layer of
+ * the rectify prompter's feature propagation (K = 59, :475-517).  act: 0 none, 1 ReLU, 2 GELU (erf).  VALU kernel, sums over k in
+ * ascending order.  Limits: K <= 64, N <= 256.
+ * upp_transpose_f32: dst (cols, rows; ld_dst) = src (rows, cols; ld_src)^T -- the W^T a data-gradient GEMM needs of a TRAINABLE
+ * weight (frozen ones are transposed once and cached by the caller). */
+int upp_linear_smallk_f32(const float *x, long long ldx, const float *W, long long ldw, const float *bias, float *y, long long ldy,
+                          int M, int N, int K, int act, void *stream);
+int upp_transpose_f32(const float *src, long long ld_src, float *dst, long long ld_dst, int rows, int cols, void *stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,7 @@ def lib():
         L.oracle_emd_matchcost.argtypes = [_f, _f, _f, _int, _int, _int, _f]
         L.oracle_emd_matchcost_grad.argtypes = [_f, _f, _f, _f, _int, _int, _int, _f, _f]
         L.oracle_linear_f32.argtypes = [_f, _f, ctypes.c_void_p, ctypes.c_void_p, _f, _int, _int, _int, _int, _int, _int]
+        L.oracle_linear_smallk.argtypes = [_f, _f, ctypes.c_void_p, _f, _int, _int, _int, _int]
         L.oracle_num_threads.restype = _int
         L.oracle_set_threads.argtypes = [_int]
         _lib = L
@@ -180,6 +181,17 @@ def linear_f32(a, w, bias=None, aux=None, ks=1, kc=1, epilogue=0):
     x = _c(aux) if aux is not None else None
     lib().oracle_linear_f32(a, w, None if b is None else b.ctypes.data_as(ctypes.c_void_p),
                             None if x is None else x.ctypes.data_as(ctypes.c_void_p), out, M, N, K, ks, kc, epilogue)
+    return out
+
+
+def linear_smallk(x, w, bias=None, act=0):
+    """act(x . w^T + bias) as upp_linear_smallk_f32 sums it (ascending k, fmaf); act 0 none / 1 ReLU."""
+    x, w = _c(x), _c(w)
+    M, K = x.shape
+    N = w.shape[0]
+    out = np.empty((M, N), np.float32)
+    b = _c(bias) if bias is not None else None
+    lib().oracle_linear_smallk(x, w, None if b is None else b.ctypes.data_as(ctypes.c_void_p), out, M, N, K, int(act))
     return out
 
 

@@ -489,6 +489,20 @@ void oracle_linear_f32(const float *A, const float *W, const float *bias, const 
     }
 }
 
+/* upp_linear_smallk_f32 (csrc/smallk.hip): one ascending-k fmaf chain per output, k padded to a multiple of 4 with zeros,
+ * then + bias, then act (0 none, 1 ReLU; GELU goes through erff and is compared within a tolerance instead).
+ * Stands for torch.nn.functional.linear at the reference's K = 3 / K = 59 layers (models/Point_MAE_pretask_dev.py:395-399, 475-517). */
+void oracle_linear_smallk(const float *x, const float *W, const float *bias, float *y, int M, int N, int K, int act) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; ++k) acc = fmaf(x[(size_t)m * K + k], W[(size_t)n * K + k], acc);
+            acc += bias ? bias[n] : 0.0f;
+            y[(size_t)m * N + n] = act == 1 ? (acc > 0.0f ? acc : 0.0f) : acc;
+        }
+}
+
 void oracle_set_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

@@ -267,6 +267,58 @@ def test_contraction_lengths_that_are_not_a_multiple_of_the_k_stage(M, N, K):
     close(x.grad, torch.ones(M, N, device='cuda') @ w)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(1024, 128, 3, 'gelu'), (2048, 128, 3, 'gelu'), (35072, 32, 59, None), (35072, 32, 59, 'relu'), (1024, 64, 12, 'relu'),
+                                        (7, 256, 64, None), (33, 5, 1, 'gelu'), (100, 200, 17, None)])
+def test_small_k_linear(M, N, K, act):
+    """upp_linear_smallk_f32 (K <= 64, N <= 256, any alignment) with bias and activation in the same pass; HF.linear routes there."""
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    x = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g) * K ** -0.5
+    b = torch.randn(N, device='cuda', generator=g)
+    ref = F.linear(x, w, b)
+    ref = F.relu(ref) if act == 'relu' else (F.gelu(ref) if act == 'gelu' else ref)
+    close(ops.linear_smallk(x, w, b, {None: 0, 'relu': 1, 'gelu': 2}[act]), ref)
+    with torch.no_grad():
+        close(HF.linear(x, w, b, act=act), ref)
+    if act != 'gelu':       # summation order: ascending k, one fmaf chain per output -- bit-exact against the CPU restatement
+        import oracle as O
+        np.testing.assert_array_equal(ops.linear_smallk(x, w, b, 1 if act == 'relu' else 0).cpu().numpy(),
+                                      O.linear_smallk(x.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), 1 if act == 'relu' else 0))
+
+
+@pytest.mark.parametrize("act", [None, 'relu', 'gelu'])
+def test_activation_epilogues_through_hf_linear(act):
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(1024, 384, device='cuda', generator=g)
+    w = torch.randn(192, 384, device='cuda', generator=g) * 0.05
+    b = torch.randn(192, device='cuda', generator=g)
+    ref = F.linear(x, w, b)
+    ref = F.relu(ref) if act == 'relu' else (F.gelu(ref) if act == 'gelu' else ref)
+    with torch.no_grad():
+        close(HF.linear(x, w, b, act=act), ref)
+        close(HF.linear(x, w, None, act=act), _a(F.linear(x, w), act))
+    xg = x.clone().requires_grad_(True)                      # with a gradient: the activation is torch's, the GEMMs ours
+    wg = w.clone().requires_grad_(True)
+    out = HF.linear(xg, wg, b, act=act, own_wgrad=True)
+    close(out, ref)
+    out.backward(torch.ones_like(out))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    _a(F.linear(xr, wr, b), act).backward(torch.ones_like(out))
+    close(xg.grad, xr.grad, rtol=2e-5, atol_scale=1e-5)
+    close(wg.grad, wr.grad, rtol=2e-5, atol_scale=1e-5)
+
+
+def _a(y, act):
+    return F.relu(y) if act == 'relu' else (F.gelu(y) if act == 'gelu' else y)
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(256, 768, 768), (40, 256, 256), (33, 65, 80), (1, 1, 1), (512, 256, 3456)])
+def test_transpose_kernel(rows, cols, ld):
+    big = torch.randn(rows, ld, device='cuda')
+    w = big[:, :cols]
+    assert torch.equal(ops.transpose(w), w.t().contiguous())
+
+
 def test_block_shapes_bit_exact_against_the_oracle():
     """The library's own choice of decomposition at the four Linear layers of a block (B = 32, L = 75)."""
     import oracle as O

@@ -219,3 +219,14 @@ def test_linear_oracle_is_a_product_and_its_order_is_what_it_says():
                     acc = fmaf(a[m, k0 + 8 * i + 4 + j], w[n, k0 + 8 * i + 4 + j], acc)
         total = np.float32(total + acc)
     assert O.linear_f32(a, w, ks=2, kc=1)[m, n] == total
+
+
+def test_small_k_linear_oracle_is_the_plain_f32_product():
+    import oracle as O
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((50, 59)).astype(np.float32)
+    w = rng.standard_normal((32, 59)).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    np.testing.assert_allclose(O.linear_smallk(x, w, b), ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(O.linear_smallk(x, w, b, 1), np.maximum(O.linear_smallk(x, w, b), 0))
