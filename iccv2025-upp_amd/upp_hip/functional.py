@@ -263,6 +263,8 @@ class _DeferredSums:
     handed None for those parameters, so nothing depends on how it would have stored a returned tensor.  Parameters
     without a registered buffer, and everything outside a scope, are summed at once and returned as usual."""
 
+    TALL = 4096
+
     def __init__(self):
         self.targets = None
         self.jobs = []
@@ -271,6 +273,10 @@ class _DeferredSums:
     def reduce(self, ptr, part, offset, length):
         """Sum columns [offset, offset+length) of the 2-D partial matrix `part` over its rows.
         -> (routed, tensor-or-None): routed sums appear in the registered buffer at scope exit."""
+        if part.is_cuda and part.shape[0] > self.TALL and part.dtype == torch.float32 and part.stride(1) == 1:
+            # one very tall matrix (a bias gradient over 65,536 point rows): first stage on many workgroups (a single column
+            # sum of 64-column workgroups took 0.78 ms of the pre-training step)
+            part, offset = ops.colsum_partials(part, offset, length), 0
         dst = self.targets.get(ptr) if (self.targets is not None and part.is_cuda) else None
         if dst is None or dst.numel() != length:
             return False, part[:, offset:offset + length].sum(dim=0)
@@ -477,30 +483,42 @@ def _zero_bias(weight):
 
 
 class _MlpGelu(Function):
-    """fc2( GELU( fc1(x) + b1 ) ) without the fc2 bias, for FROZEN fc1 / fc2 (reference models/Point_MAE_pretask_dev.py:163-168):
-    two upp_linear_f32 launches forward (the first carries bias + GELU and stores GELU'), two backward (the data gradient
-    of fc2 is multiplied by the saved GELU' in its epilogue, i.e. it IS the gradient at the fc1 pre-activation).
-    The hidden activation is not kept for backward."""
+    """fc2( GELU( fc1(x) + b1 ) ) without the fc2 bias (reference models/Point_MAE_pretask_dev.py:163-168):
+    two upp_linear_f32 launches forward (the first carries bias + GELU and stores GELU'), two backward for the data gradient (the
+    data gradient of fc2 is multiplied by the saved GELU' in its epilogue, i.e. it IS the gradient at the fc1 pre-activation).
+    Frozen weights (the PEFT recipe): the hidden activation is not kept.  Trainable weights (Point-MAE pre-training): it is, and
+    dW2 = g^T hid, dW1 = g_z^T x, db1 = column sum of g_z follow weight_grad / the deferred sums."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2):
         hid, d = ops.linear_f32(x, w1, b1, ops.LIN_BIAS_GELU_D)
-        ctx.save_for_backward(d, w1, w2)
+        train = w1.requires_grad or w2.requires_grad or b1.requires_grad
+        ctx.save_for_backward(d, w1, w2, x if train else None, hid if w2.requires_grad else None)
+        ctx.bias_ptr = b1.data_ptr()
         return ops.linear_f32(hid, w2)
 
     @staticmethod
     def backward(ctx, g):
-        d, w1, w2 = ctx.saved_tensors
+        d, w1, w2, x, hid = ctx.saved_tensors
+        need = ctx.needs_input_grad
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         g_z = ops.linear_f32(g2, _wt(w2), None, ops.LIN_MUL, aux=d.view(-1, d.shape[-1]))
-        return ops.linear_f32(g_z, _wt(w1)).view(g.shape[:-1] + (w1.shape[1],)), None, None, None
+        gx = ops.linear_f32(g_z, _wt(w1)).view(g.shape[:-1] + (w1.shape[1],)) if need[0] else None
+        gw1 = gb1 = gw2 = None
+        if need[1]:
+            gw1 = weight_grad(g_z, x.reshape(-1, x.shape[-1]), w1)
+        if need[2]:
+            _, gb1 = _DEFERRED.reduce(ctx.bias_ptr, g_z, 0, g_z.shape[1])
+        if need[3]:
+            gw2 = weight_grad(g2, hid.reshape(-1, hid.shape[-1]), w2)
+        return gx, gw1, gb1, gw2
 
 
 def mlp_gelu(x, w1, b1, w2):
-    """fc2(GELU(fc1(x) + b1)) (no fc2 bias) for frozen weights; both GEMMs and the activation on upp_linear_f32."""
-    if not torch.is_grad_enabled() or not x.requires_grad:
+    """fc2(GELU(fc1(x) + b1)) (no fc2 bias); both GEMMs and the activation on upp_linear_f32."""
+    if not torch.is_grad_enabled() or not (x.requires_grad or w1.requires_grad or w2.requires_grad or b1.requires_grad):
         return ops.linear_f32(ops.linear_f32(x, w1, b1, ops.LIN_BIAS_GELU), w2)
     return _MlpGelu.apply(x, w1, b1, w2)
 

@@ -280,6 +280,17 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
     return (out, d) if epilogue == LIN_BIAS_GELU_D else out
 
 
+def colsum_partials(part, offset, length, chunks=None):
+    """(chunks, length) partial column sums of columns [offset, offset + length) of the tall 2-D matrix `part` (upp_colsum_partials)."""
+    n = part.shape[0]
+    if chunks is None:
+        chunks = max(1, min(256, (n + 255) // 256))
+    dst = torch.empty((chunks, length), dtype=torch.float32, device=part.device)
+    view = part[:, offset:offset + length]
+    _call(part.device, "upp_colsum_partials", _abi.ptr(view), part.stride(0), n, length, chunks, _abi.ptr(dst))
+    return dst
+
+
 def linear_smallk(x, w, bias=None, act=0):
     """act(x (...,K) . w (N,K)^T + bias) for K <= 64, N <= 256, any alignment (upp_linear_smallk_f32); act 0 none / 1 ReLU / 2 GELU."""
     for t_, n_ in ((x, "x"), (w, "w")):

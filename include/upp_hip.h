@@ -360,6 +360,11 @@ long long upp_adamw_scratch_floats(void);
  * prompt gradients), summed straight into the flat gradient buffer after the pass. */
 int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, const int *ld,
                     const int *accumulate, int jobs, void *stream);
+/* upp_colsum_partials: dst (chunks, len)[ch][c] = sum of src[r][c] over the rows r of chunk ch (ceil(n / chunks) rows each, ascending):
+ * first stage of the column sum of one very tall matrix -- the bias gradient of a trainable Linear / 1x1 Conv1d over the 65,536
+ * point rows of the patch embedding (reference models/Point_MAE_unify.py:191-222 under autograd) -- the second stage is
+ * upp_batched_sum over the `chunks` rows. */
+int upp_colsum_partials(const float *src, long long ld, int n, int len, int chunks, float *dst, void *stream);
 int upp_adamw_flat(float *p, float *g, float *m, float *v, long long n, long long split, float *state, float *scratch,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, void *stream);
 
