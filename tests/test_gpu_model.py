@@ -26,9 +26,10 @@ def test_logits_match_reference_fixture(model, golden):
     with torch.no_grad():
         lc = model(_seeded.unit_ball_clouds(2, 1024, 0).cuda())
         ln = model(_seeded.noisy_clouds(2, 1024, 0).cuda(), completion_prompt=True, denoise=True, point_num=1024)
-    # dense ops run through rocBLAS here vs MKL in the fixture: 1e-4 abs on O(1) logits
-    np.testing.assert_allclose(lc.cpu().numpy(), g['logits_clean'], rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(ln.cpu().numpy(), g['logits_noisy'], rtol=1e-4, atol=2e-4)
+    # north_star's bar, 1e-5 on O(1) logits (f32 HIP kernels here, MKL on the CPU in the fixture; measured: 7e-7 / 1e-6 max abs,
+    # tools/micro/logit_tolerance.py)
+    np.testing.assert_allclose(lc.cpu().numpy(), g['logits_clean'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ln.cpu().numpy(), g['logits_noisy'], rtol=1e-5, atol=1e-5)
 
 
 def test_modules_match_reference_fixture(model, golden):
@@ -51,7 +52,7 @@ def test_train_step_gradients_match_fixture(model, golden):
     logits = model(_seeded.noisy_clouds(2, 1024, 0).cuda(), completion_prompt=True, denoise=True, point_num=1024)
     loss, _ = model.get_loss_acc(logits, torch.from_numpy(g['labels']).cuda())
     loss.backward()
-    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-4)
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-5)
     grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
     assert sorted(grads) == list(g['grad_names'])
     norms = np.array([grads[n].norm().item() for n in g['grad_names']])
@@ -90,7 +91,7 @@ def test_stage2_joint_optimisation_gradients_match_fixture(model, golden):
         p.requires_grad_(any(k in n for k in STAGE2_KEYS))
         p.grad = None
     logits = model(_seeded.noisy_clouds(2, 1024, 0).cuda(), completion_prompt=True, denoise=True, point_num=1024)
-    np.testing.assert_allclose(logits.detach().cpu().numpy(), g['logits'], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g['logits'], rtol=1e-5, atol=1e-5)
     loss, _ = model.get_loss_acc(logits, torch.from_numpy(g['labels']).cuda())
     loss.backward()
     _stage2_check({n: p.grad for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}, loss.item(), g)

@@ -54,7 +54,7 @@ def test_seg_log_probabilities_match_reference(seg, oracle_ops, golden):
 def test_seg_on_gpu_matches_reference_fixture(seg, golden):
     m = seg.cuda()
     try:
-        _check(m, golden, 'cuda', 1e-4, 5e-4)
+        _check(m, golden, 'cuda', 1e-5, 2e-5)
     finally:
         seg.cpu()
 
