@@ -60,9 +60,13 @@ class Trainer:
         from upp_hip.train import TrainStep, PipelinedTrainStep
         self.model = build_model(device).train()
         rank = dist.get_rank() if distributed else 0
-        pts = _seeded.noisy_clouds(batch, 1024, seed=rank).to(device)             # (B,1096,3) resident in HBM
+        # four different batches, resident in HBM before the timed region; every step is fed the next one (a device-to-device
+        # copy into the step's static input buffers, inside the timed region)
         g = torch.Generator().manual_seed(rank)
-        labels = torch.randint(0, 40, (batch,), generator=g).to(device)
+        self.batches = [(_seeded.noisy_clouds(batch, 1024, seed=4 * rank + k).to(device), torch.randint(0, 40, (batch,), generator=g).to(device))
+                        for k in range(4)]
+        self.k = 0
+        pts, labels = self.batches[0]                                              # (B,1096,3)
         if pipeline and use_graph and device.type == 'cuda':
             self.ts = PipelinedTrainStep(self.model, tuple(pts.shape))   # front-end of batch k+1 overlaps the back-end of batch k
         else:
@@ -71,7 +75,8 @@ class Trainer:
         self.ts.labels.copy_(labels)
 
     def step(self):
-        return self.ts.step()
+        self.k += 1
+        return self.ts.step(*self.batches[self.k & 3])
 
 
 PRETASK_PEFT = ['rectify_adapter', 'downstream_adapter', 'pretask_adapter', 'rectify_prompts', 'downstream_prompts',
@@ -505,8 +510,8 @@ def selftest_launch(args, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--workload", default="cls", choices=["cls", "cls_aux", "stage2", "pretask", "pretrain", "seg"],
                     help="cls = the headline workload (default); the others are secondary recipes, see RecipeTrainer")
