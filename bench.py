@@ -326,10 +326,10 @@ def stage_report(device, B):
                            B * (2 * 65 + 2 * 75) * 384 * 4, "rowln_fwd_kernel")
     qkv = torch.randn(B, 75, 1152, device=device)
     t = time_kernel(lambda: ops.attn_fwd(qkv, B, 75, 6, 0.125))
-    out["attn_fwd"] = mfma("attn_fwd_mfma_kernel L=75 H=6", t, 4.0 * B * 6 * 75 * 75 * 64)
+    out["attn_fwd"] = mfma("attn_fwd16_kernel<5> L=75 H=6 (960 single-wave workgroups, 16x16x4 tiles, no LDS)", t, 4.0 * B * 6 * 75 * 75 * 64)
     ctx, lse = ops.attn_fwd(qkv, B, 75, 6, 0.125)
     t = time_kernel(lambda: ops.attn_bwd(qkv, ctx, ctx, lse, B, 75, 6, 0.125))
-    out["attn_bwd"] = mfma("attn_bwd_mfma_kernel L=75 H=6", t, 10.0 * B * 6 * 75 * 75 * 64)
+    out["attn_bwd"] = mfma("attn_bwd16_kernel<5> L=75 H=6 (one LDS exchange)", t, 10.0 * B * 6 * 75 * 75 * 64)
     # fused propagation step of a block (pool -> BatchNorm -> interpolate), forward and backward
     Lp, T, G2, D = 75, 64, 32, 384
     X = torch.randn(B, Lp, D, device=device)
@@ -364,6 +364,12 @@ def stage_report(device, B):
     t = time_kernel(lambda: ops.adapter_bwd(xa, ha, s1, W1, W2, ud, 0.1, 0.7))
     out["adapter_bwd"] = hbm("adapter_bwd_kernel<384> (2400 rows, weight partials per workgroup)", t,
                              R * D * 4 * 3 + R * 32 * 8 + ((R + 31) // 32) * (2 * 32 * D + 32 + D) * 4, "adapter_bwd_kernel")
+    # the tail of a block in one launch: residual + prompt strip + adapter LayerNorm + adapter (85 -> 75 rows per cloud)
+    xs, ys = torch.randn(B, Lp + 10, D, device=device), torch.randn(B, Lp + 10, D, device=device)
+    lnw, lnb = torch.ones(D, device=device), torch.zeros(D, device=device)
+    t = time_kernel(lambda: ops.ln_adapter_fwd(xs, ys, bb2, None, 1.0, 3, 10, lnw, lnb, 1e-5, W1, bb1, W2, bb2, None, 0.0, 0.7, Lp))
+    out["ln_adapter_fwd"] = hbm("ln_adapter_fwd_kernel<384,8> (2400 rows out: x, y read; rows, out written)", t,
+                                R * D * 4 * 4 + R * 32 * 4 + 2 * 32 * D * 4, "ln_adapter_fwd_kernel")
     # Chamfer / EMD stand-alone (BASELINE configs: two independent (32,1024,3) clouds)
     ca, cb = _seeded.unit_ball_clouds(B, 1024, seed=5).to(device), _seeded.unit_ball_clouds(B, 1024, seed=6).to(device)
     t = time_kernel(lambda: ops.chamfer_fwd(ca, cb))

@@ -69,6 +69,10 @@ __global__ __launch_bounds__(64) void attn_fwd16_kernel(const float *__restrict_
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) vv[t][s][dt] = vrow[16 * dt];
         }
+    // (measured and dropped: V as 16-byte pieces through a private LDS tile, dword operand reads from there: 8.0 vs 7.7 us)
+
+    // (also dropped: a scheduling barrier that keeps every load in front of the first MFMA -- 8.4 us: the K rows then queue behind
+    // the 80 V loads of all 960 waves)
 
     // ---- S^T tiles
     f32x4 st[NT];
@@ -288,21 +292,236 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd16_kernel(const float *__rest
 }
 
 
+// Backward with the operand rows staged once per workgroup (round 2, second version).  In the kernel above every wave fetches its
+// B operands (K for dQ, dO for dV, Q for dK: one dword per lane and MFMA k-step) straight from global memory -- 240 dword loads per
+// wave that the compiler can only keep a handful in flight of, and five waves fetching the same K rows: the kernel was bound by
+// load latency, not by its 12 us of MFMA (measured 21.8 us at L = 75).  Here the 4 row blocks K, V, Q, dO of the (sample, head)
+// go to the LDS once (coalesced 16-byte loads, rows padded to 68 floats: the 16-byte A-operand reads of 16 rows and the dword
+// B-operand reads of 4 rows x 16 columns are both conflict-free), and every operand of every product is an LDS read.
+// Same partition and arithmetic as attn_bwd16_kernel: bit-identical results.
+template <int NT, bool SPLIT>
+__global__ __launch_bounds__(64 * NT * (SPLIT ? 2 : 1)) void attn_bwd16l_kernel(const float *__restrict__ qkv, const float *__restrict__ ctx,
+                                                             const float *__restrict__ d_ctx, const float *__restrict__ lse,
+                                                             float *__restrict__ d_qkv, int L, int H, float scale) {
+    constexpr int LP = 16 * NT, RS = 68, LS = LP + 4, NW = NT * (SPLIT ? 2 : 1);
+    constexpr int T0 = SPLIT ? (NT + 1) / 2 : NT;     // SPLIT: waves [0, NT) take key tiles [0, T0) of phase 1, waves [NT, 2 NT) the rest
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *Ks = sm, *Vs = Ks + LP * RS, *Qs = Vs + LP * RS, *Gs = Qs + LP * RS;     // [LP][68] each
+    float *PT = Gs + LP * RS, *DS = PT + LP * LS;                                   // [LP][LP + 4] each
+    float *DQ = DS + LP * LS;                                                       // (SPLIT) [NT][16][64] partial dQ of the second half
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const size_t rs = (size_t)3 * H * 64, cs = (size_t)H * 64;
+    const float *qb = qkv + (size_t)b * L * rs + (size_t)hh * 64, *kb = qb + H * 64, *vb = qb + 2 * H * 64;
+    const float *gb = d_ctx + (size_t)b * L * cs + (size_t)hh * 64, *ob = ctx + (size_t)b * L * cs + (size_t)hh * 64;
+    float *dqb = d_qkv + (size_t)b * L * rs + (size_t)hh * 64, *dkb = dqb + H * 64, *dvb = dqb + 2 * H * 64;
+    const int half = SPLIT ? wave / NT : 0, wq = wave - half * NT;
+    const int q0 = wq * 16;
+    const float sl = scale * 1.4426950408889634f;
+
+    // ---- stage K, V, Q, dO: LP rows x 16 float4 each; thread -> (row, piece); rows beyond L are clamped copies (masked later)
+    {
+        constexpr int PER = LP * 16 / (64 * NW);          // float4 per thread and array
+        float4 kv[PER], vv[PER], qv[PER], gv[PER];
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int i = threadIdx.x + it * 64 * NW, row = i >> 4, c = (i & 15) * 4;
+            const int rr = min(row, L - 1);
+            kv[it] = *reinterpret_cast<const float4 *>(kb + (size_t)rr * rs + c);
+            vv[it] = *reinterpret_cast<const float4 *>(vb + (size_t)rr * rs + c);
+            qv[it] = *reinterpret_cast<const float4 *>(qb + (size_t)rr * rs + c);
+            gv[it] = *reinterpret_cast<const float4 *>(gb + (size_t)rr * cs + c);
+        }
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int i = threadIdx.x + it * 64 * NW, row = i >> 4, c = (i & 15) * 4;
+            *reinterpret_cast<float4 *>(&Ks[row * RS + c]) = kv[it];
+            *reinterpret_cast<float4 *>(&Vs[row * RS + c]) = vv[it];
+            *reinterpret_cast<float4 *>(&Qs[row * RS + c]) = qv[it];
+            *reinterpret_cast<float4 *>(&Gs[row * RS + c]) = gv[it];
+        }
+    }
+    // delta_q = dO_q . O_q for the wave's query tile (O straight from global memory: read once)
+    const int qr = min(q0 + j, L - 1);
+    const bool qlive = q0 + j < L;
+    float4 ov[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) ov[m] = *reinterpret_cast<const float4 *>(ob + (size_t)qr * cs + 16 * m + 4 * g);
+    const float lse_q = lse[((size_t)b * H + hh) * L + qr] * 1.4426950408889634f;
+    __syncthreads();
+
+    // ---- phase 1: wave = query tile -------------------------------------------------------------------------------------
+    {
+        float4 qv[4], gv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            qv[m] = *reinterpret_cast<const float4 *>(&Qs[(q0 + j) * RS + 16 * m + 4 * g]);
+            gv[m] = *reinterpret_cast<const float4 *>(&Gs[(q0 + j) * RS + 16 * m + 4 * g]);
+        }
+        float delta = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            delta += gv[m].x * ov[m].x + gv[m].y * ov[m].y + gv[m].z * ov[m].z + gv[m].w * ov[m].w;
+        delta += __shfl_xor(delta, 16);
+        delta += __shfl_xor(delta, 32);
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < T0; ++tt) {
+            const int t = half ? T0 + tt : tt;
+            if (t >= NT) break;                            // (wave-uniform: the second half has NT - T0 tiles)
+            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 kv = *reinterpret_cast<const float4 *>(&Ks[(16 * t + j) * RS + 16 * m + 4 * g]);
+                const float4 vv = *reinterpret_cast<const float4 *>(&Vs[(16 * t + j) * RS + 16 * m + 4 * g]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    st = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(kv, c), comp(qv[m], c), st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(vv, c), comp(gv[m], c), dp, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool live = qlive && 16 * t + 4 * g + s < L;
+                const float p = live ? exp2_scaled(st[s] * sl - lse_q) : 0.0f;
+                const float ds = p * (dp[s] - delta) * scale;
+                PT[(16 * t + 4 * g + s) * LS + q0 + j] = p;
+                DS[(16 * t + 4 * g + s) * LS + q0 + j] = ds;
+                // dQ += dS K: B = K[16 t + 4 g + s][16 dt + j]
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds, Ks[(16 * t + 4 * g + s) * RS + 16 * dt + j], dq[dt], 0, 0, 0);
+            }
+        }
+        if (SPLIT) {
+            // the two halves of a query tile meet in the LDS: the second writes its partial dQ, the first adds it after the barrier
+            if (half) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) DQ[(wq * 16 + reg * 4 + dt) * 64 + lane] = dq[dt][reg];
+            }
+            __syncthreads();
+            if (!half) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int q = q0 + 4 * g + reg;
+                    if (q < L) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+                            dqb[(size_t)q * rs + 16 * dt + j] = dq[dt][reg] + DQ[(wq * 16 + reg * 4 + dt) * 64 + lane];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int q = q0 + 4 * g + reg;
+                if (q < L) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) dqb[(size_t)q * rs + 16 * dt + j] = dq[dt][reg];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- phase 2: wave = key tile -----------------------------------------------------------------------------------------
+    {
+        const int k0 = wq * 16;
+        if (k0 >= L) return;
+        if (SPLIT) {
+            // wave (key tile, which): dV = P^T dO (first NT waves) or dK = dS^T Q (the others)
+            const float *As = half ? DS : PT, *Bs = half ? Qs : Gs;
+            float *dst = half ? dkb : dvb;
+            f32x4 acc[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const float4 aa = *reinterpret_cast<const float4 *>(&As[(k0 + j) * LS + 16 * u + 4 * g]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(aa, s), Bs[(16 * u + 4 * g + s) * RS + 16 * dt + j], acc[dt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int key = k0 + 4 * g + reg;
+                if (key < L) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) dst[(size_t)key * rs + 16 * dt + j] = acc[dt][reg];
+                }
+            }
+            return;
+        }
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float4 pa = *reinterpret_cast<const float4 *>(&PT[(k0 + j) * LS + 16 * u + 4 * g]);
+            const float4 da = *reinterpret_cast<const float4 *>(&DS[(k0 + j) * LS + 16 * u + 4 * g]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(pa, s), Gs[(16 * u + 4 * g + s) * RS + 16 * dt + j], dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(da, s), Qs[(16 * u + 4 * g + s) * RS + 16 * dt + j], dk[dt], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int key = k0 + 4 * g + reg;
+            if (key < L) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dvb[(size_t)key * rs + 16 * dt + j] = dv[dt][reg];
+                    dkb[(size_t)key * rs + 16 * dt + j] = dk[dt][reg];
+                }
+            }
+        }
+    }
+}
+
+template <int NT, bool SPLIT>
+int launch_bwd16l(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H, float scale,
+                  hipStream_t st) {
+    constexpr int LP = 16 * NT;
+    constexpr size_t lds = (size_t)(4 * LP * 68 + 2 * LP * (LP + 4) + (SPLIT ? NT * 16 * 64 : 0)) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS");
+    if (lds > 64 * 1024) {
+        static std::atomic<bool> raised{false};
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd16l_kernel<NT, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((attn_bwd16l_kernel<NT, SPLIT>), dim3(B * H), dim3(64 * NT * (SPLIT ? 2 : 1)), lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
+    return upp_launch_status();
+}
+
 }  // namespace
 
 int upp_attn_bwd_flash16(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
                          float scale, hipStream_t st) {
     const int nt = (L + 15) / 16;
-    const dim3 grid(B * H);
+    // LDS-staged kernel; twice the waves where that evens out the four SIMDs (2, 3, 5 tiles: measured 7.9 -> 5.6, 9.6 -> 8.0,
+    // 19.1 -> 16.3 us; at 4 tiles the plain version is as fast: 11.1 vs 11.6 us)
     switch (nt) {
-        case 1: hipLaunchKernelGGL((attn_bwd16_kernel<1>), grid, dim3(64), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
-        case 2: hipLaunchKernelGGL((attn_bwd16_kernel<2>), grid, dim3(128), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
-        case 3: hipLaunchKernelGGL((attn_bwd16_kernel<3>), grid, dim3(192), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
-        case 4: hipLaunchKernelGGL((attn_bwd16_kernel<4>), grid, dim3(256), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
-        case 5: hipLaunchKernelGGL((attn_bwd16_kernel<5>), grid, dim3(320), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
-        case 6: hipLaunchKernelGGL((attn_bwd16_kernel<6>), grid, dim3(384), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); break;
-        default: return UPP_E_RANGE;
+        case 1: return launch_bwd16l<1, false>(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
+        case 2: return launch_bwd16l<2, true>(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
+        case 3: return launch_bwd16l<3, true>(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
+        case 4: return launch_bwd16l<4, false>(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
+        case 5: return launch_bwd16l<5, true>(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
+        default: break;                          // 81 .. 96 tokens: 181 KB of LDS -- the exchanging kernel above
     }
+    if (nt != 6) return UPP_E_RANGE;
+    hipLaunchKernelGGL((attn_bwd16_kernel<6>), dim3(B * H), dim3(384), 0, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
     return upp_launch_status();
 }
 

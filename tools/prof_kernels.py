@@ -36,6 +36,7 @@ i2 = (base + torch.stack([torch.randperm(T, device='cuda')[:G2] for _ in range(B
 idx8 = torch.randint(0, G2, (B, T, 8), device='cuda').int().contiguous()
 w8 = torch.softmax(torch.randn(B, T, 8, device='cuda'), -1).contiguous()
 bn = torch.nn.BatchNorm1d(D).cuda()
+lnA = torch.nn.LayerNorm(D).cuda()
 ha = torch.randn(B * Lp, D, device='cuda', requires_grad=True)
 xa_ = torch.randn(B * Lp, D, device='cuda', requires_grad=True)
 W1 = (torch.randn(32, D, device='cuda') * 0.05).requires_grad_(True); bb1 = torch.zeros(32, device='cuda', requires_grad=True)
@@ -57,6 +58,7 @@ for _ in range(5):
     index = HF.PropIndex(i1, i2, idx8, w8, B * Lp)
     HF.propagate(X, bn, index, None, 1.0, True).sum().backward()
     HF.adapter(ha, xa_, W1, bb1, W2, bb2, ud, 0.1, 0.7).sum().backward()
+    HF.ln_adapter(X, X, None, None, 1.0, HF.ROW_STRIP_CLS, 10, lnA, W1, bb1, W2, bb2, None, 0.0, 0.7).sum().backward()   # block tail, one launch
     with torch.no_grad():
         HF.bn_rows(rows, bn32, True, relu=True)
         d_, i_ = upp_layers.square_distance(xyz1, xyz2).sort(dim=-1)

@@ -6,7 +6,7 @@ import torch
 from bench import time_kernel
 from upp_hip import ops
 B, H = 32, 6
-for L in (35, 64, 65, 75, 96):
+for L in (27, 32, 35, 64, 65, 75, 96):
     qkv = torch.randn(B, L, 3 * H * 64, device='cuda')
     row = ["L=%d" % L]
     for v in (0, 2, 1):
