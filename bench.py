@@ -633,9 +633,17 @@ def main():
             tf = flops / ms / 1e9
             stages = stage_report(device, args.batch)
             pmc_step = [stages["linear_" + lab].get("traffic") for lab, *_ in LINEAR_SHAPES]
+            blk = [r for r in shapes if r["M"] >= 1000 and r["N"] in (384, 1152, 1536) and r["K"] in (384, 1152, 1536)]
+            blk_ms = sum(r["ms_per_launch"] * r["launches_per_step"] for r in blk)
+            blk_fl = sum(2.0 * r["M"] * r["N"] * r["K"] * r["launches_per_step"] for r in blk)
             line["roofline"] = {
-                "kernel": "linear_f32_kernel<*> (csrc/linear.hip): the %d upp_linear_f32 launches of one step -- QKV / proj / fc1 / fc2 of "
-                          "every Transformer block pass and their data gradients; the kernel family with the most GPU time per step" % n,
+                "kernel": "linear_f32_kernel<*> (csrc/linear.hip): ALL %d upp_linear_f32 launches of one step -- QKV / proj / fc1 / fc2 of "
+                          "every Transformer block pass and their data gradients (%d launches, %.1f %% of the flops), plus the heads, position "
+                          "MLPs and point-wise layers that left the library in round 2 (tiny: launch-bound); the kernel family with the most "
+                          "GPU time per step" % (n, sum(r["launches_per_step"] for r in blk), 100.0 * blk_fl / flops),
+                "block_layers": {"launches": sum(r["launches_per_step"] for r in blk), "ms": blk_ms, "achieved": blk_fl / blk_ms / 1e9,
+                                 "frac": blk_fl / blk_ms / 1e9 / MFMA_F32_PEAK_TF,
+                                 "how": "sum over by_shape rows of the Transformer-block shapes: stand-alone graph-replay time x launches"},
                 "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                 "ms": ms, "launches": n, "algorithmic_flops": flops,
                 "traffic": None if any(v is None for v in pmc_step) else sum(pmc_step),

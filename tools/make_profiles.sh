@@ -31,4 +31,7 @@ cp "$(stats $O/pre)" $O/r02_workload_pretrain_kernel_stats.csv
 rm -rf $O/pre
 python3 tools/time_linear.py --tiles > $O/r02_time_linear.jsonl 2> /dev/null
 python3 tools/_fmt_linear.py $O/r02_time_linear.jsonl > $O/r02_time_linear.txt
+python3 tools/time_attention.py 2> /dev/null | grep -v amdgpu.ids > $O/r02_time_attention.txt
+python3 tools/micro/time_ln_adapter.py 2> /dev/null | grep -v amdgpu.ids >> $O/r02_time_attention.txt
+python3 tools/glue_census.py 2> /dev/null | grep -v amdgpu.ids > $O/r02_glue_census.txt
 ls -la $O
