@@ -133,7 +133,7 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
         if constexpr (TAIL) koff[q] = ko;
         src[q] = base + row * ld + ko;
     }
-    static_assert(TPW <= 6, "DMA slots of the interleaved schedule");
+    static_assert(KC != 1 || TPW <= 6, "DMA slots of the interleaved schedule");
     auto issue1 = [&](int q, int stage, int c) {            // q-th DMA instruction of this wave for k-stage c
         const int t = wave + q * NW;
 #ifndef UPP_LIN_NO_DMA        // diagnostic build without the operand stream (the MFMAs then run on whatever the LDS holds)
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
         __builtin_amdgcn_s_barrier();                    // ... everyone's has; and everyone is done reading the other stage
         const bool fill = c + 1 < nsc;
         const int fst = (c + 1) & 1;
-        if (KC == 2 && fill) issue(fst, c + 1);
+        if (KC >= 2 && fill) issue(fst, c + 1);
         if (c == 0) { UPP_STAMP(1) }
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
