@@ -633,8 +633,9 @@ def main():
             tf = flops / ms / 1e9
             stages = stage_report(device, args.batch)
             pmc_step = [stages["linear_" + lab].get("traffic") for lab, *_ in LINEAR_SHAPES]
-            blk = [r for r in shapes if r["M"] >= 1000 and r["N"] in (384, 1152, 1536) and r["K"] in (384, 1152, 1536)]
-            blk_ms = sum(r["ms_per_launch"] * r["launches_per_step"] for r in blk)
+            # (the Transformer-block layers: token rows x {384, 1152, 1536}^2; the heads have at most B rows, the prompter layers other widths)
+            blk = [r for r in shapes if r["M"] > args.batch and r["N"] in (384, 1152, 1536) and r["K"] in (384, 1152, 1536)]
+            blk_ms = sum(r["ms_per_launch"] * r["launches_per_step"] for r in blk) or float("nan")
             blk_fl = sum(2.0 * r["M"] * r["N"] * r["K"] * r["launches_per_step"] for r in blk)
             line["roofline"] = {
                 "kernel": "linear_f32_kernel<*> (csrc/linear.hip): ALL %d upp_linear_f32 launches of one step -- QKV / proj / fc1 / fc2 of "

@@ -519,6 +519,247 @@ __global__ __launch_bounds__(64 * kFW) void ln_adapter_fwd_kernel(LnAdapterArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the fused block tail in ONE launch on 16-row workgroups (was adapter_bwd_kernel on 32-row workgroups, 75 of them,
+// 19 us, followed by rowln_bwd_kernel, 5.6 us):
+//   gd = scale (g_out . W2)                      split 8 ways over k = the 384 output columns, reduced through the LDS
+//   ga = gd * dropout' * gelu'(s1),  d = scale * dropout(gelu(s1))
+//   g_ha = ga . W1                               3 column tiles per wave, into an LDS tile
+//   dW2 += g_out^T d,  dW1 += ga^T ha            per-workgroup partials (contraction over the 16 rows: 4 k-steps per 16x16 tile)
+//   db1 += col-sum ga,  db2 += scale col-sum g_out
+//   LayerNorm backward of the adapter's LayerNorm + the residual:  d_row = g_out + rstd (dy - mean(dy) - xhat mean(dy xhat)),
+//   dy = g_ha gamma;  g_x[src row] = d_row,  g_y[src row] = dp_scale d_row;  d_gamma / d_beta partials per workgroup;
+//   the prompt rows a strip map dropped get their zero gradient from the same launch.
+// ha is rebuilt from the saved rows and statistics (the forward does not store it).  LDS tiles of g_out and ha use a row stride
+// of 400 floats (= 16 mod 64): the products over the ROWS read them column-wise (lane (r, g) -> row 4 s + g, column 16 t + r), which
+// that stride makes conflict-free; their few 16-byte row reads take a 4-way conflict instead.
+struct LnAdapterBwdArgs {
+    const float *g_out, *xo, *mean, *rstd, *gamma, *beta, *s1, *W1, *W2, *ud, *u;
+    float p, scale, keep;
+    int mode, P;
+    float *g_x, *g_y, *part, *ln_part;     // part: [workgroup][dW1 (32,D) | dW2 (D,32) | db1 (32) | db2 (D)];  ln_part: [workgroup][2][D]
+    int B, Lin, Lout;
+};
+
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void ln_adapter_bwd_kernel(LnAdapterBwdArgs a) {
+    constexpr int LDC = 400, LDR = D + 4, LDG = 48, E = D / 64, RW = kFR / NW;
+    constexpr int KW = D / NW, NI = KW / 16, NT = D / 16 / NW;     // k-range of gd per wave (48), its 16-blocks (3), column tiles per wave (3)
+    constexpr int TW = 2 * (D / 16) / NW;                          // weight-gradient tiles per wave and matrix (6)
+    static_assert(kFR % NW == 0 && KW % 16 == 0 && (D / 16) % NW == 0 && (2 * (D / 16)) % NW == 0, "shape");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *Zs = sm;                        // [16][400]  g_out
+    float *Hs = Zs + kFR * LDC;            // [16][400]  ha; later the LayerNorm parameter-gradient rows of the waves
+    float *Gh = Hs + kFR * LDC;            // [16][388]  g_ha
+    float *Part = Gh + kFR * LDR;          // [NW][16][33]
+    float *GAs = Part + NW * kFR * (kH + 1);   // [16][48]  ga
+    float *Ds = GAs + kFR * LDG;           // [16][48]  scale * dropout(gelu(s1))
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, g = lane >> 4;
+    const int R = a.B * a.Lout;
+    const int row0 = blockIdx.x * kFR;
+    const size_t psz = (size_t)2 * kH * D + kH + D;
+    float *pw1 = a.part ? a.part + (size_t)blockIdx.x * psz : nullptr;
+    float *pw2 = pw1 ? pw1 + kH * D : nullptr, *pb1 = pw1 ? pw2 + D * kH : nullptr, *pb2 = pw1 ? pb1 + kH : nullptr;
+
+    // ---- weight operands of the two products over the feature dimension, one dword per lane and k-step, all issued first
+    float w2r[2][NI][4], w1r[NT][2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w2r[t][i][c] = a.W2[(size_t)(wave * KW + 16 * i + 4 * g + c) * kH + 16 * t + r];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w1r[t][i][c] = a.W1[(size_t)(16 * i + 4 * g + c) * D + 16 * (wave * NT + t) + r];
+
+    // ---- rows: g_out and ha = LayerNorm(rows) into the LDS
+    int rowi[RW];
+    float mu[RW], rs[RW];
+    {
+        float gm[E], bt[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { gm[e] = a.gamma[lane + 64 * e]; bt[e] = a.beta[lane + 64 * e]; }
+        float gv[RW][E], xv[RW][E];
+#pragma unroll
+        for (int q = 0; q < RW; ++q) {
+            rowi[q] = min(row0 + wave * RW + q, R - 1);
+            mu[q] = a.mean[rowi[q]]; rs[q] = a.rstd[rowi[q]];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                gv[q][e] = a.g_out[(size_t)rowi[q] * D + lane + 64 * e];
+                xv[q][e] = a.xo[(size_t)rowi[q] * D + lane + 64 * e];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RW; ++q) {
+            const int rr = wave * RW + q;
+            const bool live = row0 + rr < R;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                Zs[rr * LDC + lane + 64 * e] = live ? gv[q][e] : 0.0f;
+                Hs[rr * LDC + lane + 64 * e] = live ? __builtin_fmaf((xv[q][e] - mu[q]) * rs[q], gm[e], bt[e]) : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- gd partial over the columns [wave KW, wave KW + KW): A = g_out rows, B[k = column][j] = W2[column][j]
+    {
+        f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4 av = *reinterpret_cast<const float4 *>(&Zs[r * LDC + wave * KW + 16 * i + 4 * g]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(av, c), w2r[0][i][c], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(av, c), w2r[1][i][c], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            Part[(wave * kFR + 4 * g + reg) * (kH + 1) + r] = acc0[reg];
+            Part[(wave * kFR + 4 * g + reg) * (kH + 1) + 16 + r] = acc1[reg];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kFR * kH / (64 * NW); ++q) {
+        const int e = threadIdx.x + q * 64 * NW, i = e >> 5, jn = e & 31;
+        float gd = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 2) gd += Part[(w * kFR + i) * (kH + 1) + jn] + Part[((w + 1) * kFR + i) * (kH + 1) + jn];   // fixed order
+        gd *= a.scale;
+        float ga = 0.0f, d = 0.0f;
+        if (row0 + i < R) {
+            const float sv = a.s1[(size_t)(row0 + i) * kH + jn];
+            const float f = a.ud ? (a.ud[(size_t)(row0 + i) * kH + jn] >= a.p ? 1.0f / (1.0f - a.p) : 0.0f) : 1.0f;
+            ga = gd * f * gelu_grad(sv);
+            d = gelu_f(sv) * f * a.scale;
+        }
+        GAs[i * LDG + jn] = ga;
+        Ds[i * LDG + jn] = d;
+    }
+    __syncthreads();
+
+    // ---- g_ha tiles (A = ga rows, B = W1 rows) into Gh
+    {
+        const float4 g0 = *reinterpret_cast<const float4 *>(&GAs[r * LDG + 4 * g]);
+        const float4 g1 = *reinterpret_cast<const float4 *>(&GAs[r * LDG + 16 + 4 * g]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(g0, c), w1r[t][0][c], acc, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(g1, c), w1r[t][1][c], acc, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Gh[(4 * g + reg) * LDR + 16 * (wave * NT + t) + r] = acc[reg];
+        }
+    }
+    // ---- weight-gradient partials: contraction over the 16 rows (4 k-steps); tile id -> (tn = column tile of D, tj = half of the 32)
+    if (pw1) {
+#pragma unroll
+        for (int q = 0; q < TW; ++q) {
+            const int tile = wave * TW + q, tn = tile >> 1, tj = tile & 1;
+            f32x4v acc2 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float zc = Zs[(4 * s + g) * LDC + 16 * tn + r];      // g_out[row][n]   (A of dW2, rows = n)
+                const float dc = Ds[(4 * s + g) * LDG + 16 * tj + r];      // d[row][j]       (B of dW2)
+                const float gc = GAs[(4 * s + g) * LDG + 16 * tj + r];     // ga[row][j]      (A of dW1, rows = j)
+                const float hc = Hs[(4 * s + g) * LDC + 16 * tn + r];      // ha[row][n]      (B of dW1)
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(zc, dc, acc2, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(gc, hc, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                pw2[(size_t)(16 * tn + 4 * g + reg) * kH + 16 * tj + r] = acc2[reg];     // dW2[n][j]
+                pw1[(size_t)(16 * tj + 4 * g + reg) * D + 16 * tn + r] = acc1[reg];      // dW1[j][n]
+            }
+        }
+        // bias partials: db1[j] = sum_i ga[i][j], db2[n] = scale sum_i g_out[i][n]   (row order: deterministic)
+        for (int c = threadIdx.x; c < kH + D; c += 64 * NW) {
+            float sacc = 0.0f;
+            if (c < kH) { for (int i = 0; i < kFR; ++i) sacc += GAs[i * LDG + c]; pb1[c] = sacc; }
+            else { const int n = c - kH; for (int i = 0; i < kFR; ++i) sacc += Zs[i * LDC + n]; pb2[n] = sacc * a.scale; }
+        }
+    }
+    __syncthreads();
+
+    // ---- LayerNorm backward + residual, row by row (the arithmetic of rowln_bwd_kernel); parameter-gradient rows into Hs
+    float *lnp = Hs;                                       // [NW][2][D] (ha is no longer needed)
+    {
+        float gm[E], pg[E], pb[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { gm[e] = a.gamma[lane + 64 * e]; pg[e] = 0.0f; pb[e] = 0.0f; }
+#pragma unroll
+        for (int q = 0; q < RW; ++q) {
+            const int rr = wave * RW + q;
+            if (row0 + rr >= R) continue;                  // (wave-uniform)
+            const int row = rowi[q];
+            const int b = row / a.Lout, t = row - b * a.Lout;
+            const int src = a.mode == 3 ? (t == 0 ? 0 : t + a.P) : (a.mode == 4 ? t + a.P : t);
+            float xo[E], gh[E], go[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                xo[e] = a.xo[(size_t)row * D + lane + 64 * e];
+                gh[e] = Gh[rr * LDR + lane + 64 * e];
+                go[e] = Zs[rr * LDC + lane + 64 * e];
+            }
+            float dy[E], xh[E], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                dy[e] = gh[e] * gm[e];
+                xh[e] = (xo[e] - mu[q]) * rs[q];
+                pg[e] += gh[e] * xh[e];
+                pb[e] += gh[e];
+                s1 += dy[e];
+                s2 = __builtin_fmaf(dy[e], xh[e], s2);
+            }
+            s1 = wave_sum_f32(s1) / (float)D;
+            s2 = wave_sum_f32(s2) / (float)D;
+            const float sc = a.g_y ? (a.u ? floorf(a.keep + a.u[b]) / a.keep : 1.0f) : 0.0f;
+            float *gx = a.g_x ? a.g_x + ((size_t)b * a.Lin + src) * D : nullptr;
+            float *gy = a.g_y ? a.g_y + ((size_t)b * a.Lin + src) * D : nullptr;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float dv = go[e] + rs[q] * (dy[e] - s1 - xh[e] * s2);
+                if (gx) gx[lane + 64 * e] = dv;
+                if (gy) gy[lane + 64 * e] = dv * sc;
+            }
+        }
+        if (a.ln_part) {                                   // (the barrier in front of this phase: every wave is done with ha)
+#pragma unroll
+            for (int e = 0; e < E; ++e) { lnp[(wave * 2 + 0) * D + lane + 64 * e] = pg[e]; lnp[(wave * 2 + 1) * D + lane + 64 * e] = pb[e]; }
+            __syncthreads();
+            for (int c = threadIdx.x; c < 2 * D; c += 64 * NW) {
+                const int which = c / D, col = c - which * D;
+                float sacc = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; w += 2) sacc += lnp[(w * 2 + which) * D + col] + lnp[((w + 1) * 2 + which) * D + col];   // wave order
+                a.ln_part[((size_t)blockIdx.x * 2 + which) * D + col] = sacc;
+            }
+        }
+    }
+    // ---- zero gradient for the prompt rows the forward's strip map dropped: B P rows, dealt round-robin to the workgroups
+    if (a.P > 0 && (a.mode == 3 || a.mode == 4)) {
+        const int first = a.mode == 3 ? 1 : 0;
+        for (int z = blockIdx.x; z < a.B * a.P; z += gridDim.x) {
+            const int b = z / a.P, t = first + (z - b * a.P);
+            const size_t off = ((size_t)b * a.Lin + t) * D;
+            for (int c = threadIdx.x; c < D; c += 64 * NW) {
+                if (a.g_x) a.g_x[off + c] = 0.0f;
+                if (a.g_y) a.g_y[off + c] = 0.0f;
+            }
+        }
+    }
+}
+
 template <typename K>
 int raise_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) {
@@ -578,6 +819,28 @@ static int adapter_bwd_launch(const float *g_out, const float *ha, const float *
 extern "C" int upp_adapter_bwd(const float *g_out, const float *ha, const float *s1, const float *W1, const float *W2, const float *u,
                                float p, float scale, float *g_ha, float *part, int R, int D, int H, void *stream) {
     return adapter_bwd_launch(g_out, ha, nullptr, nullptr, nullptr, nullptr, s1, W1, W2, u, p, scale, g_ha, part, R, D, H, stream);
+}
+
+extern "C" long long upp_ln_adapter_part_floats(int R, int D) {
+    if (R < 1 || D < 1) return 0;
+    return (long long)((R + kFR - 1) / kFR) * (2LL * kH * D + kH + D);
+}
+
+extern "C" int upp_ln_adapter_bwd_fused(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
+                                        const float *beta, const float *s1, const float *W1, const float *W2, const float *ud, float p,
+                                        float scale, const float *u, float keep, int mode, int P, float *g_x, float *g_y, float *part,
+                                        float *ln_part, int B, int Lin, int Lout, int D, int H, void *stream) {
+    if (!g_out || !xo || !mean || !rstd || !gamma || !beta || !s1 || !W1 || !W2 || B < 0 || Lin < 1 || Lout < 1) return UPP_E_BADARG;
+    if (D != 384 || H != kH) return UPP_E_RANGE;
+    if (!(mode == 0 || mode == 3 || mode == 4) || P < 0 || (mode == 0 && Lout != Lin) || (mode != 0 && Lout != Lin - P)) return UPP_E_BADARG;
+    if (B == 0) return 0;
+    constexpr int NW = 8;
+    const size_t lds = ((size_t)2 * kFR * 400 + kFR * (384 + 4) + NW * kFR * (kH + 1) + 2 * kFR * 48) * sizeof(float);
+    static std::atomic<bool> raised{false};
+    if (!raised) { int rc = raise_lds(ln_adapter_bwd_kernel<384, NW>, lds); if (rc) return rc; raised = true; }
+    LnAdapterBwdArgs a{g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, u, p, scale, keep, mode, P, g_x, g_y, part, ln_part, B, Lin, Lout};
+    hipLaunchKernelGGL((ln_adapter_bwd_kernel<384, NW>), dim3((B * Lout + kFR - 1) / kFR), dim3(64 * NW), lds, (hipStream_t)stream, a);
+    return upp_launch_status();
 }
 
 extern "C" int upp_ln_adapter_bwd(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,

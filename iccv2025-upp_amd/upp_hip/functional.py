@@ -849,6 +849,9 @@ class _Adapter(Function):
                 gW2 if need[4] else None, gb2 if need[5] else None, None, None, None)
 
 
+FUSE_TAIL_BACKWARD = True     # _LnAdapter.backward: one launch (upp_ln_adapter_bwd_fused) instead of adapter backward + row backward
+
+
 class _LnAdapter(Function):
     """The tail of a block in one launch: rows = strip(x + dp_scale(u) (y + ybias)), out = rows + scale * adapter(LayerNorm(rows)).
     Forward: upp_ln_adapter_fwd.  Backward: upp_ln_adapter_bwd (the adapter's, rebuilding the LayerNorm output from the saved
@@ -874,16 +877,21 @@ class _LnAdapter(Function):
         keep, pd, scale, has_y = ctx.meta
         need = ctx.needs_input_grad
         g_out = g_out.contiguous()
-        g_ha, part = ops.ln_adapter_bwd(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, pd, scale)
         need_ln = need[7] or need[8]
-        g_x, _, g_y, ln_part = ops.rowln_bwd(g_out, g_ha, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, P,
-                                             need_x=need[0], need_prompt=False, need_y=has_y and need[1], need_ln_part=need_ln)
+        need_ad = need[10] or need[11] or need[12] or need[13]
+        if FUSE_TAIL_BACKWARD:
+            g_x, g_y, part, ln_part = ops.ln_adapter_bwd_fused(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, pd, scale, u, keep, mode, P, Lin,
+                                                               need[0], has_y and need[1], need_ad, need_ln)
+        else:       # the two kernels of the unfused path (kept: tests compare the fused launch against them)
+            g_ha, part = ops.ln_adapter_bwd(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, pd, scale)
+            g_x, _, g_y, ln_part = ops.rowln_bwd(g_out, g_ha, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, P,
+                                                 need_x=need[0], need_prompt=False, need_y=has_y and need[1], need_ln_part=need_ln)
         p_gamma, p_beta, pW1, pb1, pW2, pb2 = ctx.param_ptrs
         g_gamma = g_beta = gW1 = gb1 = gW2 = gb2 = None
         if need_ln:
             _, g_gamma = _DEFERRED.reduce(p_gamma, ln_part, 0, D)
             _, g_beta = _DEFERRED.reduce(p_beta, ln_part, D, D)
-        if need[10] or need[11] or need[12] or need[13]:
+        if need_ad:
             H = W1.shape[0]
             _, gW1 = _DEFERRED.reduce(pW1, part, 0, H * D)
             _, gW2 = _DEFERRED.reduce(pW2, part, H * D, H * D)

@@ -751,6 +751,24 @@ def ln_adapter_bwd(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, u, p, scale):
     return g_ha, part
 
 
+def ln_adapter_bwd_fused(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, p, scale, u, keep, mode, P, Lin, need_x, need_y, need_adapter,
+                         need_ln):
+    """Backward of ln_adapter_fwd in one launch -> (g_x, g_y, adapter partials, LayerNorm partials); upp_ln_adapter_bwd_fused."""
+    B, Lout, D = xo.shape
+    H = W1.shape[0]
+    dev = xo.device
+    R = B * Lout
+    nwg = (R + 15) // 16
+    g_x = torch.empty((B, Lin, D), dtype=torch.float32, device=dev) if need_x else None
+    g_y = torch.empty((B, Lin, D), dtype=torch.float32, device=dev) if need_y else None
+    part = torch.empty((nwg, int(_abi.load().upp_ln_adapter_part_floats(R, D)) // nwg), dtype=torch.float32, device=dev) if need_adapter else None
+    ln_part = torch.empty((nwg, 2 * D), dtype=torch.float32, device=dev) if need_ln else None
+    _call(dev, "upp_ln_adapter_bwd_fused", _abi.ptr(g_out), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma), _abi.ptr(beta),
+          _abi.ptr(s1), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(ud), float(p), float(scale), _abi.ptr(u), float(keep), int(mode), int(P),
+          _abi.ptr(g_x), _abi.ptr(g_y), _abi.ptr(part), _abi.ptr(ln_part), B, Lin, Lout, D, H)
+    return g_x, g_y, part, ln_part
+
+
 def adapter_bwd(g_out, ha, s1, W1, W2, u, p, scale):
     D = ha.shape[-1]
     R = ha.numel() // D

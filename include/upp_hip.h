@@ -395,6 +395,16 @@ int upp_ln_adapter_fwd(const float *x, const float *y, const float *ybias, const
                        const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
                        const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
                        float *out, int B, int Lin, int Lout, int D, int H, void *stream);
+/* upp_ln_adapter_bwd_fused: the whole backward of upp_ln_adapter_fwd in one launch on 16-row workgroups -- the adapter's backward
+ * (g_ha, per-workgroup partials [dW1 (H,D) | dW2 (D,H) | db1 (H) | db2 (D)] in `part`, upp_ln_adapter_part_floats(R, D) floats, or
+ * part = NULL), the LayerNorm backward with the residual (g_x / g_y (B, Lin, D): every row is written, zeros for the prompt rows
+ * the strip map dropped; either may be NULL), and the LayerNorm parameter-gradient partials (`ln_part`: [workgroup][2][D], or NULL).
+ * Same results as upp_ln_adapter_bwd + upp_rowln_bwd up to f32 re-association of the small products. */
+long long upp_ln_adapter_part_floats(int R, int D);
+int upp_ln_adapter_bwd_fused(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
+                             const float *beta, const float *s1, const float *W1, const float *W2, const float *ud, float p,
+                             float scale, const float *u, float keep, int mode, int P, float *g_x, float *g_y, float *part,
+                             float *ln_part, int B, int Lin, int Lout, int D, int H, void *stream);
 int upp_ln_adapter_bwd(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
                        const float *beta, const float *s1, const float *W1, const float *W2, const float *u, float p,
                        float scale, float *g_ha, float *part, int R, int D, int H, void *stream);

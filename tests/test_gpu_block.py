@@ -255,6 +255,18 @@ def test_block_tail_in_one_launch_equals_row_kernel_plus_adapter(B, Lin, P, mode
     close(out, ref, rtol=1e-5, atol_scale=2e-6)
     for g, r in zip(grads, rgrads):
         close(g, r, rtol=5e-5, atol_scale=1e-5)
+    # the one-launch backward (upp_ln_adapter_bwd_fused, 16-row workgroups) against the two-launch backward of the same Function
+    HF.FUSE_TAIL_BACKWARD = False
+    try:
+        out2 = HF.ln_adapter(x, y, yb, u, 0.9, m, P, ln, W1, b1, W2, b2, ud, pd, 0.7)
+        grads2 = torch.autograd.grad((out2 * w).sum(), leaves)
+    finally:
+        HF.FUSE_TAIL_BACKWARD = True
+    for g, r in zip(grads, grads2):
+        close(g, r, rtol=2e-5, atol_scale=4e-6)
+    if m != HF.ROW_IDENTITY:      # the prompt rows the strip map dropped: exactly zero
+        rows = slice(1, 1 + P) if m == HF.ROW_STRIP_CLS else slice(0, P)
+        assert float(grads[0][:, rows].abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------ fused propagation step (CSR + in-kernel BatchNorm)
