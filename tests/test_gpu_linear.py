@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 TOKENS = [2400, 2080, 2048, 1120]                                                   # B*L of the classification step (B = 32)
 LAYERS = [("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536)]   # (name, out, in)
-CONFIGS = [0x4412, 0x4311, 0x3411, 0x2421, 0x2321, 0x2241, 0x1241]
+CONFIGS = [0x4412, 0x4311, 0x3411, 0x2421, 0x2321, 0x2241, 0x1241, 0x2221]
 
 
 def close(a, b, rtol=1e-5, atol_scale=2e-6):

@@ -24,7 +24,7 @@ SHAPES = [  # (name, M, N, K)
     ("qkv_2048", 2048, 1152, 384), ("fc1_2048", 2048, 1536, 384), ("fc2_2048", 2048, 384, 1536),
     ("qkv_1120", 1120, 1152, 384), ("proj_1120", 1120, 384, 384), ("fc1_1120", 1120, 1536, 384), ("fc2_1120", 1120, 384, 1536),
 ]
-TILES = [0x4412, 0x4311, 0x3411, 0x2421, 0x2321, 0x2241, 0x1241]
+TILES = [0x4412, 0x4311, 0x3411, 0x2421, 0x2321, 0x2241, 0x1241, 0x2221]
 
 
 def main():
