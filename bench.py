@@ -286,10 +286,11 @@ def stage_report(device, B):
                 "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": nbytes, "traffic": traffic(pmc_key) if pmc_key else None,
                 **({"note": note} if note else {})}
 
-    def mfma(name, ms, flops, note=None):
+    def mfma(name, ms, flops, note=None, pmc_key=None):
         tf = flops / ms / 1e9
         return {"kernel": name, "bound": "mfma", "ms": ms, "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": tf / MFMA_F32_PEAK_TF, "algorithmic_flops": flops, **({"note": note} if note else {})}
+                "frac": tf / MFMA_F32_PEAK_TF, "algorithmic_flops": flops, **({"traffic": traffic(pmc_key)} if pmc_key else {}),
+                **({"note": note} if note else {})}
 
     x = _seeded.unit_ball_clouds(B, 1024, seed=7).to(device)
     _, cen = ops.fps(x, 64, want_centers=True)
@@ -326,10 +327,12 @@ def stage_report(device, B):
                            B * (2 * 65 + 2 * 75) * 384 * 4, "rowln_fwd_kernel")
     qkv = torch.randn(B, 75, 1152, device=device)
     t = time_kernel(lambda: ops.attn_fwd(qkv, B, 75, 6, 0.125))
-    out["attn_fwd"] = mfma("attn_fwd16_kernel<5> L=75 H=6 (960 single-wave workgroups, 16x16x4 tiles, no LDS)", t, 4.0 * B * 6 * 75 * 75 * 64)
+    out["attn_fwd"] = mfma("attn_fwd16_kernel<5> L=75 H=6 (960 single-wave workgroups, 16x16x4 tiles, no LDS)", t, 4.0 * B * 6 * 75 * 75 * 64,
+                           pmc_key="attn_fwd16_kernel<5>")
     ctx, lse = ops.attn_fwd(qkv, B, 75, 6, 0.125)
     t = time_kernel(lambda: ops.attn_bwd(qkv, ctx, ctx, lse, B, 75, 6, 0.125))
-    out["attn_bwd"] = mfma("attn_bwd16_kernel<5> L=75 H=6 (one LDS exchange)", t, 10.0 * B * 6 * 75 * 75 * 64)
+    out["attn_bwd"] = mfma("attn_bwd16l_kernel<5, true> L=75 H=6 (operand rows staged in the LDS, 10 waves, one exchange)", t,
+                           10.0 * B * 6 * 75 * 75 * 64, pmc_key="attn_bwd16l_kernel<5")
     # fused propagation step of a block (pool -> BatchNorm -> interpolate), forward and backward
     Lp, T, G2, D = 75, 64, 32, 384
     X = torch.randn(B, Lp, D, device=device)
@@ -370,6 +373,12 @@ def stage_report(device, B):
     t = time_kernel(lambda: ops.ln_adapter_fwd(xs, ys, bb2, None, 1.0, 3, 10, lnw, lnb, 1e-5, W1, bb1, W2, bb2, None, 0.0, 0.7, Lp))
     out["ln_adapter_fwd"] = hbm("ln_adapter_fwd_kernel<384,8> (2400 rows out: x, y read; rows, out written)", t,
                                 R * D * 4 * 4 + R * 32 * 4 + 2 * 32 * D * 4, "ln_adapter_fwd_kernel")
+    go = torch.randn(B, Lp, D, device=device)
+    _, xo_, mean_, rstd_, s1_ = ops.ln_adapter_fwd(xs, ys, bb2, None, 1.0, 3, 10, lnw, lnb, 1e-5, W1, bb1, W2, bb2, None, 0.0, 0.7, Lp)
+    t = time_kernel(lambda: ops.ln_adapter_bwd_fused(go, xo_, mean_, rstd_, lnw, lnb, s1_, W1, W2, None, 0.0, 0.7, None, 1.0, 3, 10, Lp + 10,
+                                                     True, True, True, True))
+    out["ln_adapter_bwd"] = hbm("ln_adapter_bwd_kernel<384,8> (2400 rows: g_out, rows read; g_x, g_y, weight partials written)", t,
+                                R * D * 4 * 4 + R * 32 * 4 + ((R + 15) // 16) * (2 * 32 * D + 32 + 3 * D) * 4, "ln_adapter_bwd_kernel")
     # Chamfer / EMD stand-alone (BASELINE configs: two independent (32,1024,3) clouds)
     ca, cb = _seeded.unit_ball_clouds(B, 1024, seed=5).to(device), _seeded.unit_ball_clouds(B, 1024, seed=6).to(device)
     t = time_kernel(lambda: ops.chamfer_fwd(ca, cb))
