@@ -57,12 +57,12 @@ class Point_MAE_unify_seg(PromptedBackbone):
         B, N, C = point_feat.shape
         w1 = c1.weight.squeeze(-1)
         per_sample = HF.linear(global_feat, w1[:, C:], c1.bias, own_wgrad=True)                       # (B,512), once per sample
-        h = HF.linear(point_feat.reshape(B * N, C), w1[:, :C], own_wgrad=True).view(B, N, -1) + per_sample.unsqueeze(1)
+        h = HF.linear(point_feat.reshape(B * N, C), w1[:, :C]).view(B, N, -1) + per_sample.unsqueeze(1)
         if self.training and bn1.track_running_stats:
             L.bump_counter(bn1.num_batches_tracked)
         h = drop(_bn_rows(h.view(B * N, -1), bn1, self.training, relu=True))
         h = _pointwise_bn_relu(h, c2, bn2, self.training)
-        h = HF.linear(h, c3.weight.squeeze(-1), c3.bias, own_wgrad=True)
+        h = HF.linear(h, c3.weight.squeeze(-1), c3.bias)
         return F.log_softmax(h, dim=-1).view(B, N, -1)
 
     def forward(self, pts, cls_label, label_points=None, completion_prompt=True, denoise=True, point_num=1024, **kwargs):

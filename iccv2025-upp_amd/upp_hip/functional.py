@@ -417,6 +417,7 @@ class _LinearMFMA(Function):
         return gx, gw, gb, None
 
 
+LINEAR_TALL_ROWS = int(os.environ.get("UPP_LINEAR_TALL_ROWS", "16384"))     # from here on the tuned library GEMM wins by > 10 % (see linear())
 WGRAD_MIN_ROWS = int(os.environ.get("UPP_WGRAD_MIN_ROWS", "4096"))
 WGRAD_FEW_ROWS = 512        # up to here one or two 32-row stages: ~8 us on ours; the un-tuned library picks 25-170 us solutions (stage-2 heads)
 
@@ -457,6 +458,12 @@ def linear(x, weight, bias=None, own_wgrad=False, act=None):
     otherwise.  own_wgrad: the weight gradient of a trainable layer on upp_linear_wgrad_f32 whatever the row count (the patch
     embedding, the classification head; default: between WGRAD_FEW_ROWS and WGRAD_MIN_ROWS rows the library's split-K GEMM is used)."""
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))
+    if x.is_cuda and not own_wgrad and x.numel() // max(1, x.shape[-1]) >= LINEAR_TALL_ROWS and weight.shape[0] * weight.shape[1] >= 65536:
+        # measured at 65,536 rows (tools/micro/time_linear_tall.py, TunableOp-selected library solutions): upp_linear_f32 126 TFLOP/s
+        # against 145 forward and data gradient, the weight gradient 1.8x behind -- the part-segmentation head (three such
+        # layers) is 2.2 ms per step faster on the library.  own_wgrad=True (the patch embedding) keeps everything on ours.
+        note_declined("linear %s x %s" % (tuple(x.shape), tuple(weight.shape)), ">= %d rows: library GEMM (measured faster)" % LINEAR_TALL_ROWS)
+        return _act_torch(F.linear(x, weight, bias), act)
     if not linear_usable(x, weight):
         if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] == weight.shape[1]
                 and weight.shape[1] <= 64 and weight.shape[0] <= 256 and x.numel() > 0 and not needs_grad):

@@ -59,16 +59,16 @@ class FlatAdamW:
         self._ops = ops
         params = list(no_decay) + list(decay)
         dev = params[0].device
-        self.n = sum(p.numel() for p in params)
-        self.split = sum(p.numel() for p in no_decay)
-        self.p = torch.empty(self.n, device=dev)
-        off = 0
+        from utils.dist_utils import flat_offsets
+        # same layout as the gradient buffer (FlatGradAllReduce over the same list): 16-byte aligned starts, zero gaps
+        self._offsets, self.n = flat_offsets(params)
+        self.split = self._offsets[len(no_decay)] if len(decay) else self.n
+        self.p = torch.zeros(self.n, device=dev)
         with torch.no_grad():
-            for q in params:
+            for q, off in zip(params, self._offsets):
                 view = self.p[off:off + q.numel()].view_as(q)
                 view.copy_(q)
                 q.data = view                      # the model now reads its trainable weights from the flat buffer
-                off += q.numel()
         self._shapes = [tuple(q.shape) for q in params]
         self._n_no_decay = len(no_decay)
         self.g = flat_grad
@@ -113,12 +113,11 @@ class FlatAdamW:
     def state_dict(self):
         lr, b1, b2, eps, wd, _ = self.hyper
         step = self.state[0].detach().cpu().clone()
-        state, off = {}, 0
-        for i, shp in enumerate(self._shapes):
+        state = {}
+        for i, (shp, off) in enumerate(zip(self._shapes, self._offsets)):
             n = int(torch.tensor(shp).prod()) if shp else 1
             state[i] = {'step': step.clone(), 'exp_avg': self.m[off:off + n].view(shp).clone(),
                         'exp_avg_sq': self.v[off:off + n].view(shp).clone()}
-            off += n
         k = self._n_no_decay
         common = dict(lr=lr, betas=(b1, b2), eps=eps, amsgrad=False, maximize=False, foreach=None, capturable=False,
                       differentiable=False, fused=None)
@@ -131,9 +130,9 @@ class FlatAdamW:
         order = [i for g in groups for i in g['params']]
         if len(order) != len(self._shapes):
             raise ValueError("optimizer state has %d parameters, expected %d" % (len(order), len(self._shapes)))
-        off, step = 0, 0.0
+        step = 0.0
         with torch.no_grad():
-            for i, shp in zip(order, self._shapes):
+            for i, shp, off in zip(order, self._shapes, self._offsets):
                 n = int(torch.tensor(shp).prod()) if shp else 1
                 st = sd['state'].get(i)
                 if st is not None:
@@ -142,7 +141,6 @@ class FlatAdamW:
                     self.m[off:off + n].copy_(st['exp_avg'].reshape(-1))
                     self.v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
                     step = max(step, float(st['step']))
-                off += n
             self.state[0] = step
         g0 = groups[0]
         if (g0['betas'][0], g0['betas'][1], g0['eps']) != self.hyper[1:4] and getattr(self, 'captured', False):

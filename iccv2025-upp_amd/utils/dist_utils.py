@@ -40,6 +40,20 @@ def gather_tensor(tensor, args=None):
     return torch.cat(out, dim=0)
 
 
+FLAT_ALIGN = 4      # floats: every parameter (and its gradient) starts on a 16-byte boundary of the flat buffers, which is what the
+                    # matrix-core Linear kernels ask of a weight (upp_linear_f32: 16-byte aligned rows); the gaps hold zeros
+
+
+def flat_offsets(params, align=FLAT_ALIGN):
+    """-> (offsets, total): start of every parameter in a flat buffer, each rounded up to `align` elements."""
+    offs, off = [], 0
+    for p in params:
+        off = (off + align - 1) // align * align
+        offs.append(off)
+        off += p.numel()
+    return offs, (off + align - 1) // align * align
+
+
 class FlatGradAllReduce:
     """Gradient exchange for batch-parallel training: every trainable parameter's .grad is a
     view into one contiguous f32 buffer, so a step needs exactly one all-reduce (2.48 MB for
@@ -55,15 +69,14 @@ class FlatGradAllReduce:
         if not self.params:
             raise ValueError("no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
-        n = sum(p.numel() for p in self.params)
-        self.numel = n
+        self.offsets, n = flat_offsets(self.params)
+        self.numel = n                                  # gradient slots incl. alignment gaps (zeros); the scalars follow
+        self.count = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n + extra_scalars, device=dev, dtype=dt)
-        off = 0
         self.views = []
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             p.grad = self.views[-1]
-            off += p.numel()
         self.scalars = self.flat[n:]
 
     def zero(self):

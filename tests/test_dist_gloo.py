@@ -112,14 +112,15 @@ def test_flat_grad_buffer_views_survive_backward():
     for p in frozen.parameters():
         p.requires_grad_(False)
     f = FlatGradAllReduce(list(lin.parameters()) + list(frozen.parameters()))
-    assert f.numel == 15 and f.flat.numel() == 17
+    assert f.count == 15 and f.numel == 16 and f.flat.numel() == 18         # bias starts on a 16-byte boundary: 12 + 3 -> 16 slots
+    assert all(v.data_ptr() % 16 == 0 for v in f.views)
     for _ in range(2):
         f.zero()
         frozen(lin(torch.ones(2, 4))).sum().backward()
         base = f.flat.data_ptr()
         for p in lin.parameters():
             assert base <= p.grad.data_ptr() < base + f.flat.numel() * 4        # still a view of the flat buffer
-        assert f.flat[:15].abs().sum() > 0
+        assert f.flat[:15].abs().sum() > 0 and float(f.flat[15]) == 0.0
     f.reduce()   # no process group: no-op
     with pytest.raises(ValueError):
         FlatGradAllReduce(frozen.parameters())
