@@ -36,10 +36,6 @@ __device__ __forceinline__ float gelu_grad(float x) {
     const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
-__device__ __forceinline__ float drop_factor(const float *u, size_t i, float p) {
-    // torch dropout: keep with probability 1-p, scale kept values by 1/(1-p)
-    return u ? (u[i] >= p ? 1.0f / (1.0f - p) : 0.0f) : 1.0f;
-}
 
 // acc += A . B over NK k-pairs, operands supplied by functors, fetched CH pairs ahead of the MFMAs
 template <int NK, typename FA, typename FB>
@@ -116,20 +112,6 @@ __device__ __forceinline__ void stage_tile_ln(float *dst, const float *src, cons
         d[2] = ok ? __builtin_fmaf((v[it].z - mu[it]) * rs[it], gm[it].z, bt[it].z) : 0.0f;
         d[3] = ok ? __builtin_fmaf((v[it].w - mu[it]) * rs[it], gm[it].w, bt[it].w) : 0.0f;
     }
-}
-
-// one wave copies the contiguous 32x32 block W2[n0 .. n0+32][0..32) into its own LDS tile [32][33] (coalesced loads)
-__device__ __forceinline__ void stage_w2_tile(float *dst, const float *W2, int n0, int lane) {
-    float4 v[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const float4 *>(W2 + (size_t)n0 * kH + (lane + it * 64) * 4);
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int e = (lane + it * 64) * 4;
-        float *d = dst + (e >> 5) * kLG + (e & 31);
-        d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
-    }
-    __builtin_amdgcn_wave_barrier();
 }
 
 template <int D>

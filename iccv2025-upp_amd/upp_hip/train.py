@@ -12,7 +12,7 @@ tools/runner_module.py:193-212) built for MI355X:
 import torch
 import torch.distributed as dist
 
-from utils.dist_utils import FlatGradAllReduce
+from utils.dist_utils import FlatGradAllReduce, flat_offsets
 
 from . import functional as HF
 
@@ -59,7 +59,6 @@ class FlatAdamW:
         self._ops = ops
         params = list(no_decay) + list(decay)
         dev = params[0].device
-        from utils.dist_utils import flat_offsets
         # same layout as the gradient buffer (FlatGradAllReduce over the same list): 16-byte aligned starts, zero gaps
         self._offsets, self.n = flat_offsets(params)
         self.split = self._offsets[len(no_decay)] if len(decay) else self.n
