@@ -329,3 +329,18 @@ def test_block_shapes_bit_exact_against_the_oracle():
         a, w, _ = _operands(M, N, K, seed=N + K)
         np.testing.assert_array_equal(ops.linear_f32(a, w).cpu().numpy(),
                                       O.linear_f32(a.cpu().numpy(), w.cpu().numpy(), ks=(c >> 4) & 15, kc=c & 15))
+
+
+@pytest.mark.parametrize("rows,cols,off,length", [(65536, 512, 0, 512), (10000, 100, 4, 50), (4097, 64, 0, 64), (300, 40, 8, 16)])
+def test_tall_column_sums_in_two_stages(rows, cols, off, length):
+    """upp_colsum_partials (first stage of a bias gradient over very many rows) + the row sum of its partials == the column sum;
+    and the deferred-sum front door takes that route by itself above functional._DeferredSums.TALL rows."""
+    g = torch.Generator(device='cuda').manual_seed(rows + cols)
+    part = torch.randn(rows, cols, device='cuda', generator=g)
+    ref = part[:, off:off + length].double().sum(0)
+    p = ops.colsum_partials(part, off, length)
+    assert p.shape[1] == length and p.shape[0] >= 1
+    torch.testing.assert_close(p.double().sum(0), ref, rtol=1e-5, atol=1e-4 * max(1.0, float(ref.abs().max())) * 1e-1)
+    routed, t = HF._DEFERRED.reduce(0, part, off, length)          # no scope open: summed at once and returned
+    assert not routed
+    torch.testing.assert_close(t.double(), ref, rtol=1e-5, atol=1e-4 * max(1.0, float(ref.abs().max())) * 1e-1)
