@@ -268,6 +268,10 @@ def stage_report(device, B):
     from models.upp_layers import Encoder
     from upp_hip import functional as HF, ops
     pmc = _pmc_traffic()
+    try:
+        mfma_pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_mfma.json")))
+    except Exception:
+        mfma_pmc = {}
 
     def traffic(keys):
         """HBM bytes per call: sum over the kernels of the call (key prefix, or (prefix, launches per call))."""
@@ -406,6 +410,8 @@ def stage_report(device, B):
         out["linear_" + label] = mfma("linear_f32_kernel<%s> %s: (%d,%d) x (%d,%d)^T, epilogue %d" % (tile, label, M, K, N, K, epi), t,
                                       2.0 * M * N * K)
         out["linear_" + label]["traffic"] = traffic("linear:" + label)
+        if "linear:" + label in mfma_pmc:           # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch time x 2.1 GHz): profiles/r02_pmc_mfma.json
+            out["linear_" + label]["mfma_pipe_frac_pmc"] = mfma_pmc["linear:" + label].get("mfma_pipe_frac")
         out["linear_" + label]["algorithmic_bytes"] = 4.0 * (M * K + N * K + M * N * (2 if epi in (3, 4) else 1))
     return out
 

@@ -20,9 +20,11 @@ cp "$(stats $O/kern)" $O/r02_kernels_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 tools/prof_kernels.py > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 tools/prof_kernels.py > $O/write.log 2>&1
 python3 tools/pmc_summary.py "$(ls $O/fetch/*/*counter_collection.csv | head -1)" "$(ls $O/write/*/*counter_collection.csv | head -1)" "$(trace $O/kern)" > $O/r02_pmc_kernels.json
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES --output-format csv -d $O/mfma -- python3 tools/prof_kernels.py > $O/mfma.log 2>&1
+python3 tools/pmc_mfma_summary.py "$(ls $O/mfma/*/*counter_collection.csv | head -1)" "$(trace $O/kern)" > $O/r02_pmc_mfma.json
 python3 bench.py --no-cpu-baseline --no-pipeline > $O/r02_bench_sequential.json 2> $O/bench_seq.err
 python3 bench.py > $O/r02_bench.json 2> $O/bench.err
-rm -rf $O/seq $O/pipe $O/kern $O/fetch $O/write
+rm -rf $O/seq $O/pipe $O/kern $O/fetch $O/write $O/mfma
 ls -la $O
 # secondary recipes: un-profiled lines + one kernel summary for the pre-training step (8 executions: 2 eager + 1 replay + 5 timed)
 for w in cls_aux stage2 pretask pretrain seg; do python3 bench.py --workload $w --steps 10 --warmup 3 > $O/r02_workload_$w.json 2> $O/w_$w.err; done
