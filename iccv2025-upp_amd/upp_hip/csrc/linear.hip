@@ -512,12 +512,10 @@ int pick_config(int M, int N, int K) {
         else cost = 1000000000LL + quarters * 1000000LL + traffic * 1000LL;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
     }
-    // Same 64 x 64 tile, contraction split 2 ways instead of 4: the same MFMA work per SIMD (2 waves x half a block), but k-stages of
-    // 64 instead of 128 values -- at K = 384 that is 6 pipeline stages instead of 3 (the first stage's load is a third of all loads
-    // there) and a 2-way instead of a 4-way reduction: 10.2 vs 10.9 us at (2400, 384, 384); no difference at K >= 1152.
-    if (best >= 0 && kConfigs[best].bmb == 2 && kConfigs[best].bnb == 2 && kConfigs[best].ks == 4 && K <= 3 * 128 && K % 64 == 0)
-        for (int i = 0; i < kNumConfigs; ++i)
-            if (kConfigs[i].bmb == 2 && kConfigs[i].bnb == 2 && kConfigs[i].ks == 2) best = i;
+    // (2,2,2,64) -- the same 64 x 64 tile with the contraction split 2 ways, k-stages of 64 -- is compiled and can be forced, but is
+    // never chosen: stand-alone it is 3-7 % faster than (2,2,4,128) (10.1 vs 10.9 us at K = 384, 28.9 vs 30.2 at K = 1536), in the
+    // pipelined step it costs 0.28 ms (5.71 vs 5.43 ms per step, measured twice): with 64 KB of LDS instead of 128 KB a workgroup of
+    // the other stream's GEMM moves onto the same CU and the two share its matrix pipe and L2 slice instead of taking turns.
     return best;
 }
 
