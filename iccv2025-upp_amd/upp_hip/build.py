@@ -50,7 +50,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         src, obj = job
-        cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [_hipcc()] + FLAGS + os.environ.get("UPP_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]   # (extra -D switches for A/B builds)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * kFW) void ln_adapter_fwd_kernel(LnAdapterArgs 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, g = lane >> 4;
     const int R = a.B * a.Lout;
-    const int row0 = blockIdx.x * kFR;
+    const int row0 = xcd_contiguous(blockIdx.x, gridDim.x) * kFR;
 
     // ---- weight operands, issued first (they do not depend on anything this workgroup computes)
     float4 w1v[2][NI], w2v[NT][2];
@@ -539,9 +539,10 @@ __global__ __launch_bounds__(64 * NW) void ln_adapter_bwd_kernel(LnAdapterBwdArg
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 15, g = lane >> 4;
     const int R = a.B * a.Lout;
-    const int row0 = blockIdx.x * kFR;
+    const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int row0 = wg * kFR;
     const size_t psz = (size_t)2 * kH * D + kH + D;
-    float *pw1 = a.part ? a.part + (size_t)blockIdx.x * psz : nullptr;
+    float *pw1 = a.part ? a.part + (size_t)wg * psz : nullptr;
     float *pw2 = pw1 ? pw1 + kH * D : nullptr, *pb1 = pw1 ? pw2 + D * kH : nullptr, *pb2 = pw1 ? pb1 + kH : nullptr;
 
     // ---- weight operands of the two products over the feature dimension, one dword per lane and k-step, all issued first
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(64 * NW) void ln_adapter_bwd_kernel(LnAdapterBwdArg
                 float sacc = 0.0f;
 #pragma unroll
                 for (int w = 0; w < NW; w += 2) sacc += lnp[(w * 2 + which) * D + col] + lnp[((w + 1) * 2 + which) * D + col];   // wave order
-                a.ln_part[((size_t)blockIdx.x * 2 + which) * D + col] = sacc;
+                a.ln_part[((size_t)wg * 2 + which) * D + col] = sacc;
             }
         }
     }

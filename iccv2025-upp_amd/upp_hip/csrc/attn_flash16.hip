@@ -30,10 +30,12 @@ __device__ __forceinline__ float comp(const float4 &v, int c) { return c == 0 ? 
 
 // One wave per workgroup: the NT query tiles of a (sample, head) are NT independent single-wave workgroups, so that the
 // dispatcher spreads B H NT waves over the 1,024 SIMDs (five waves of one workgroup on the four SIMDs of a CU run 2:1:1:1).
-// Workgroups i and i + 8 share an XCD (and its L2): the tiles of one (sample, head) are 8 apart in the launch order.
 __device__ __forceinline__ void unit_of(int unit, int NT, int BH, int &bh, int &tile) {
-    if ((BH & 7) == 0) { const int x = unit & 7, y = unit >> 3; bh = (y / NT) * 8 + x; tile = y - (y / NT) * NT; }
-    else { bh = unit / NT; tile = unit - bh * NT; }
+    // XCD x takes the contiguous run of (sample, head) pairs [x BH/8, (x+1) BH/8) -- the token rows it owns in the other kernels of
+    // the block (common.h xcd_contiguous) -- with all NT query tiles of a pair on that XCD
+    const int lin = xcd_contiguous(unit, BH * NT);
+    bh = lin / NT;
+    tile = lin - bh * NT;
 }
 
 template <int NT>
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(64 * NT) void attn_bwd16_kernel(const float *__rest
     __shared__ __attribute__((aligned(16))) float PT[LP * LS], DS[LP * LS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const int bhx = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = bhx / H, hh = bhx - b * H;
     const size_t rs = (size_t)3 * H * 64, cs = (size_t)H * 64;
     const float *qb = qkv + (size_t)b * L * rs + (size_t)hh * 64, *kb = qb + H * 64, *vb = qb + 2 * H * 64;
     const float *gb = d_ctx + (size_t)b * L * cs + (size_t)hh * 64, *ob = ctx + (size_t)b * L * cs + (size_t)hh * 64;
@@ -311,7 +314,8 @@ __global__ __launch_bounds__(64 * NT * (SPLIT ? 2 : 1)) void attn_bwd16l_kernel(
     float *DQ = DS + LP * LS;                                                       // (SPLIT) [NT][16][64] partial dQ of the second half
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
+    const int bhx = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = bhx / H, hh = bhx - b * H;
     const size_t rs = (size_t)3 * H * 64, cs = (size_t)H * 64;
     const float *qb = qkv + (size_t)b * L * rs + (size_t)hh * 64, *kb = qb + H * 64, *vb = qb + 2 * H * 64;
     const float *gb = d_ctx + (size_t)b * L * cs + (size_t)hh * 64, *ob = ctx + (size_t)b * L * cs + (size_t)hh * 64;

@@ -61,7 +61,8 @@ __device__ __forceinline__ float dp_scale(const float *u, float keep, int b) {
 // a load inside `if (c < D)` followed by its use costs one full memory round trip per element slot.
 __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int row = wg * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     if (row >= a.B * a.Lout) return;
     const int b = row / a.Lout, t = row - b * a.Lout;
     const int src = row_src(t, a.mode, a.P);
@@ -140,7 +141,8 @@ struct RowLnBwdArgs {
 __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
     __shared__ float lnp[2][4][64 * kMaxE];   // per-wave LayerNorm parameter-gradient contributions (only used with ln_part)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int it = blockIdx.x * 4 + wave;   // wave-uniform
+    const int wg = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int it = wg * 4 + wave;   // wave-uniform
     const int D = a.D;
     // Insert / identity maps are walked by OUTPUT row; strip maps by INPUT row, so that the prompt rows the forward
     // dropped get their zero gradient here (no separate fill launch).
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
         for (int e = 0; e < kMaxE; ++e) { lnp[0][wave][lane + 64 * e] = pgam[e]; lnp[1][wave][lane + 64 * e] = pbet[e]; }
         __syncthreads();
         for (int c = threadIdx.x; c < D; c += 256) {
-            a.ln_part[((size_t)blockIdx.x * 2 + 0) * D + c] = (lnp[0][0][c] + lnp[0][1][c]) + (lnp[0][2][c] + lnp[0][3][c]);
-            a.ln_part[((size_t)blockIdx.x * 2 + 1) * D + c] = (lnp[1][0][c] + lnp[1][1][c]) + (lnp[1][2][c] + lnp[1][3][c]);
+            a.ln_part[((size_t)wg * 2 + 0) * D + c] = (lnp[0][0][c] + lnp[0][1][c]) + (lnp[0][2][c] + lnp[0][3][c]);
+            a.ln_part[((size_t)wg * 2 + 1) * D + c] = (lnp[1][0][c] + lnp[1][1][c]) + (lnp[1][2][c] + lnp[1][3][c]);
         }
     }
 }

@@ -82,6 +82,23 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return (a + b) + (c + d);
 }
 
+// XCD-aware, bijective renumbering of the workgroups of a 1-D grid: workgroups b and b + 8 share an XCD (and its L2), so XCD x gets
+// the contiguous run [x n/8, (x+1) n/8) of the work items.  Every row-wise kernel of a Transformer block uses it (row kernels,
+// block tail, attention, and the row panels of upp_linear_f32): XCD x then works on the same ~1/8 of the token rows in every
+// kernel of the block, and an activation written by one kernel is read by the next from the same L2 instead of the Infinity Cache.
+// `UPP_XCD_REMAP` = 0 at build time switches it off for A/B measurements (the mapping never changes results).
+#ifndef UPP_XCD_REMAP
+#define UPP_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int xcd_contiguous(int orig, int nwg) {
+#if UPP_XCD_REMAP
+    const int xcd = orig & 7, q8 = nwg >> 3, rem = nwg & 7;
+    return (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (orig >> 3);
+#else
+    return orig;
+#endif
+}
+
 // Cooperative global -> LDS copy of n floats by `nthreads` threads.  Each thread keeps 8 independent loads in flight
 // per round: a load -> ds_write -> next load loop pays the full ~1 us memory latency on every iteration.
 __device__ __forceinline__ void stage_floats(float *dst, const float *__restrict__ src, int n, int tid, int nthreads) {
