@@ -387,9 +387,10 @@ __global__ __launch_bounds__(kCsrThreads) void csr_build_kernel(const int32_t *_
 __global__ __launch_bounds__(256) void prop_pool_stats_kernel(const float *__restrict__ X, const int32_t *__restrict__ i1,
                                                               const float *__restrict__ u, float keep, float *__restrict__ pooled,
                                                               uint8_t *__restrict__ amax, float *__restrict__ part, int groups, int D) {
+    const int wgx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // XCD x owns a contiguous eighth of the rows / groups (common.h)
     __shared__ float sh[4][64 * kMaxE];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = blockIdx.x * 4 + wave;
+    const int g = wgx * 4 + wave;
     if (g < groups) {
         const float f = 1.0f + (u ? floorf(keep + u[g]) / keep : 1.0f);
         int rows8[kNb];
@@ -416,15 +417,15 @@ __global__ __launch_bounds__(256) void prop_pool_stats_kernel(const float *__res
         }
     }
     __syncthreads();
-    const int nw = min(4, groups - (int)blockIdx.x * 4);
+    const int nw = min(4, groups - (int)wgx * 4);
     for (int c = threadIdx.x; c < D; c += 256) {
         float sum = 0.0f;
         for (int w = 0; w < nw; ++w) sum += sh[w][c];
         const float mean = sum / (float)nw;
         float m2 = 0.0f;
         for (int w = 0; w < nw; ++w) { const float dv = sh[w][c] - mean; m2 = __builtin_fmaf(dv, dv, m2); }
-        part[((size_t)blockIdx.x * 2 + 0) * D + c] = sum;
-        part[((size_t)blockIdx.x * 2 + 1) * D + c] = m2;
+        part[((size_t)wgx * 2 + 0) * D + c] = sum;
+        part[((size_t)wgx * 2 + 1) * D + c] = m2;
     }
 }
 
@@ -435,8 +436,9 @@ __global__ __launch_bounds__(256) void prop_interp_bn_fwd_kernel(const float *__
                                                                  const int32_t *__restrict__ i2, const int32_t *__restrict__ idx8,
                                                                  const float *__restrict__ w8, float *__restrict__ out, int B, int Lp,
                                                                  int T, int G2, int D) {
+    const int wgx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // XCD x owns a contiguous eighth of the rows / groups (common.h)
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = wgx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (r >= B * Lp) return;
     const int b = r / Lp, t = r - b * Lp;
     const int i = t - (Lp - T);
@@ -485,9 +487,10 @@ __global__ __launch_bounds__(256) void prop_c2_csr_kernel(const float *__restric
                                                           const float *__restrict__ pooled, const float *__restrict__ mean,
                                                           const float *__restrict__ rstd, float *__restrict__ g_c2,
                                                           float *__restrict__ part, int B, int Lp, int T, int G2, int D) {
+    const int wgx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // XCD x owns a contiguous eighth of the rows / groups (common.h)
     __shared__ float sh[2][4][64 * kMaxE];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gj = blockIdx.x * 4 + wave;
+    const int gj = wgx * 4 + wave;
     const int groups = B * G2;
     if (gj < groups) {
         int cc[kMaxE];
@@ -535,12 +538,12 @@ __global__ __launch_bounds__(256) void prop_c2_csr_kernel(const float *__restric
         }
     }
     __syncthreads();
-    const int nw = min(4, groups - (int)blockIdx.x * 4);
+    const int nw = min(4, groups - (int)wgx * 4);
     for (int c = threadIdx.x; c < D; c += 256) {
         float s0 = 0.0f, s1 = 0.0f;
         for (int w = 0; w < nw; ++w) { s0 += sh[0][w][c]; s1 += sh[1][w][c]; }
-        part[((size_t)blockIdx.x * 2 + 0) * D + c] = s0;
-        part[((size_t)blockIdx.x * 2 + 1) * D + c] = s1;
+        part[((size_t)wgx * 2 + 0) * D + c] = s0;
+        part[((size_t)wgx * 2 + 1) * D + c] = s1;
     }
 }
 
@@ -582,8 +585,9 @@ __global__ __launch_bounds__(256) void prop_x_csr_kernel(const float *__restrict
                                                          const int32_t *__restrict__ start1, const int32_t *__restrict__ perm1,
                                                          const int32_t *__restrict__ start2, const int32_t *__restrict__ perm2,
                                                          float *__restrict__ g_X, int rows, int groups, int D, int training) {
+    const int wgx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // XCD x owns a contiguous eighth of the rows / groups (common.h)
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = wgx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (r >= rows) return;
     const int s1 = start1[r], e1 = start1[r + 1], s2 = start2[r], e2 = start2[r + 1];
     int cc[kMaxE];
