@@ -282,6 +282,10 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
 
 def colsum_partials(part, offset, length, chunks=None):
     """(chunks, length) partial column sums of columns [offset, offset + length) of the tall 2-D matrix `part` (upp_colsum_partials)."""
+    if not (isinstance(part, torch.Tensor) and part.is_cuda and part.dtype == torch.float32 and part.dim() == 2 and part.stride(1) == 1):
+        raise RuntimeError("colsum_partials: a 2-D f32 HIP (cuda) matrix with contiguous rows is required; upp_hip has no CPU path")
+    if offset < 0 or length < 1 or offset + length > part.shape[1]:
+        raise RuntimeError(f"colsum_partials: columns [{offset}, {offset + length}) outside {tuple(part.shape)}")
     n = part.shape[0]
     if chunks is None:
         chunks = max(1, min(256, (n + 255) // 256))
@@ -300,6 +304,10 @@ def linear_smallk(x, w, bias=None, act=0):
     K, N = x.shape[-1], w.shape[0]
     if w.dim() != 2 or w.shape[1] != K:
         raise RuntimeError(f"linear_smallk: x (...,{K}) against w {tuple(w.shape)}")
+    if bias is not None:
+        _need(bias, "bias", torch.float32, 1, N)
+    if K > 64 or N > 256:
+        raise RuntimeError(f"linear_smallk serves K <= 64 and N <= 256, got K = {K}, N = {N}")
     x2 = x.reshape(-1, K)
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
@@ -726,6 +734,12 @@ def ln_adapter_fwd(x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, 
     B, Lin, D = x.shape
     H = W1.shape[0]
     dev = x.device
+    for t_, n_, shp in ((gamma, "gamma", (D,)), (beta, "beta", (D,)), (W1, "W1", (H, D)), (b1, "b1", (H,)), (W2, "W2", (D, H)), (b2, "b2", (D,))):
+        _need(t_, n_, torch.float32)
+        if tuple(t_.shape) != shp:
+            raise RuntimeError(f"ln_adapter_fwd: {n_} must be {shp}, got {tuple(t_.shape)}")
+    if y is not None and tuple(y.shape) != tuple(x.shape):
+        raise RuntimeError("ln_adapter_fwd: y must have the shape of x")
     xo = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
     out = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
     mean = torch.empty((B, Lout), dtype=torch.float32, device=dev)
