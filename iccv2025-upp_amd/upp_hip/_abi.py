@@ -85,6 +85,7 @@ SIGNATURES = {
                        + [_c_i] * 5 + [_c_f]),
     "upp_linear_smallk_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_f, ctypes.c_longlong] + [_c_i] * 4 + [_c_f]),
     "upp_transpose_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_f]),
+    "upp_transpose_batched_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f]),
     "upp_linear_wgrad_splits": (_c_i, [_c_i, _c_i, _c_i]),
     "upp_linear_wgrad_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_i, _c_i, _c_f]),
     "upp_adamw_flat": (_c_i, [_c_f] * 4 + [ctypes.c_longlong] * 2 + [_c_f] * 2 + [ctypes.c_float] * 6 + [_c_f]),

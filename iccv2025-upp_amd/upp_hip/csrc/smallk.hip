@@ -84,7 +84,47 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
     }
 }
 
+// several matrices in one launch: blockIdx.z selects the matrix (grid x / y sized for the largest one)
+constexpr int kMaxTr = 96;
+struct TrJobs { const float *src[kMaxTr]; float *dst[kMaxTr]; int rows[kMaxTr], cols[kMaxTr]; };
+__global__ __launch_bounds__(256) void transpose_batched_kernel(TrJobs t) {
+    __shared__ float tile[32][33];
+    const int j = blockIdx.z, rows = t.rows[j], cols = t.cols[j];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    if (c0 >= cols || r0 >= rows) return;                              // (workgroup-uniform)
+    const float *src = t.src[j];
+    float *dst = t.dst[j];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(long long)r * cols + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(long long)c * rows + r] = tile[tx][ty + 8 * i];
+    }
+}
+
 }  // namespace
+
+extern "C" int upp_transpose_batched_f32(const float *const *src, float *const *dst, const int *rows, const int *cols, int count, void *stream) {
+    if (count < 0 || (count > 0 && (!src || !dst || !rows || !cols))) return UPP_E_BADARG;
+    for (int j0 = 0; j0 < count; j0 += kMaxTr) {
+        TrJobs t;
+        const int n = count - j0 < kMaxTr ? count - j0 : kMaxTr;
+        int mr = 1, mc = 1;
+        for (int j = 0; j < n; ++j) {
+            if (!src[j0 + j] || !dst[j0 + j] || rows[j0 + j] < 1 || cols[j0 + j] < 1) return UPP_E_BADARG;
+            t.src[j] = src[j0 + j]; t.dst[j] = dst[j0 + j]; t.rows[j] = rows[j0 + j]; t.cols[j] = cols[j0 + j];
+            mr = rows[j0 + j] > mr ? rows[j0 + j] : mr; mc = cols[j0 + j] > mc ? cols[j0 + j] : mc;
+        }
+        hipLaunchKernelGGL(transpose_batched_kernel, dim3((mc + 31) / 32, (mr + 31) / 32, n), dim3(256), 0, (hipStream_t)stream, t);
+    }
+    return upp_launch_status();
+}
 
 extern "C" int upp_linear_smallk_f32(const float *x, long long ldx, const float *W, long long ldw, const float *bias, float *y, long long ldy,
                                      int M, int N, int K, int act, void *stream) {

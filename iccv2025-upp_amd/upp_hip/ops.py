@@ -709,6 +709,25 @@ def batched_sum(jobs):
     _call(jobs[0][0].device, "upp_batched_sum", src, dst, n, ln, ld, acc, k)
 
 
+def transpose_batched(pairs):
+    """pairs: list of (src (rows, cols) contiguous f32, dst (cols, rows) contiguous f32): dst = src^T for all of them in one launch
+    (upp_transpose_batched_f32)."""
+    if not pairs:
+        return
+    import ctypes
+    k = len(pairs)
+    for src, dst in pairs:
+        _need(src, "src", torch.float32, ndim=2)
+        _need(dst, "dst", torch.float32, ndim=2)
+        if tuple(dst.shape) != (src.shape[1], src.shape[0]):
+            raise RuntimeError("transpose_batched: dst must be (cols, rows) of src")
+    srcs = (ctypes.c_void_p * k)(*[a.data_ptr() for a, _ in pairs])
+    dsts = (ctypes.c_void_p * k)(*[b.data_ptr() for _, b in pairs])
+    rows = (ctypes.c_int * k)(*[a.shape[0] for a, _ in pairs])
+    cols = (ctypes.c_int * k)(*[a.shape[1] for a, _ in pairs])
+    _call(pairs[0][0].device, "upp_transpose_batched_f32", srcs, dsts, rows, cols, k)
+
+
 def adamw_flat(p, g, m, v, n, split, state, scratch, lr, beta1, beta2, eps, weight_decay, max_norm):
     for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (state, "state"), (scratch, "scratch")):
         _need(t, name, torch.float32)

@@ -227,14 +227,22 @@ class TrainStep:
         self.flat.zero()
         for p in self.trainable:
             p.grad = None              # let autograd write fresh gradients: no per-parameter accumulate kernels
-        if self.loss_fn is not None:
-            loss, acc = self.loss_fn(self.model, *self.inputs)
-        else:
-            logits = self.model.forward_tokens(*pts) if isinstance(pts, tuple) else self.model(pts, **(self.kw if kw is None else kw))
-            loss, acc = self.model.get_loss_acc(logits, labels)
-        # partial-sum reductions of parameter gradients: one launch after the pass, straight into the (zeroed) flat buffer
-        with HF.deferred_sums(self._grad_targets) as scope:
-            loss.backward()
+        # W^T copies of the trainable weights (data-gradient GEMMs): persistent inside this driver, all refreshed by one launch here,
+        # i.e. after whatever changed the weights since the last step (optimizer, load_state_dict, a restore)
+        was = HF.TRANSPOSED.managed
+        HF.TRANSPOSED.managed = True
+        try:
+            HF.TRANSPOSED.refresh_trainable()
+            if self.loss_fn is not None:
+                loss, acc = self.loss_fn(self.model, *self.inputs)
+            else:
+                logits = self.model.forward_tokens(*pts) if isinstance(pts, tuple) else self.model(pts, **(self.kw if kw is None else kw))
+                loss, acc = self.model.get_loss_acc(logits, labels)
+            # partial-sum reductions of parameter gradients: one launch after the pass, straight into the (zeroed) flat buffer
+            with HF.deferred_sums(self._grad_targets) as scope:
+                loss.backward()
+        finally:
+            HF.TRANSPOSED.managed = was
         got = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None and p.data_ptr() not in scope.routed]
         torch._foreach_copy_([v for v, _ in got], [g for _, g in got])   # one multi-tensor copy into the flat buffer
         both = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None and p.data_ptr() in scope.routed]

@@ -449,6 +449,9 @@ int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw,
 int upp_linear_smallk_f32(const float *x, long long ldx, const float *W, long long ldw, const float *bias, float *y, long long ldy,
                           int M, int N, int K, int act, void *stream);
 int upp_transpose_f32(const float *src, long long ld_src, float *dst, long long ld_dst, int rows, int cols, void *stream);
+/* upp_transpose_batched_f32: dst_j (cols_j, rows_j) = src_j (rows_j, cols_j)^T for `count` contiguous matrices in one launch (host arrays of
+ * device pointers and sizes): the W^T copies of ALL trainable weights of a recipe, refreshed once per training step. */
+int upp_transpose_batched_f32(const float *const *src, float *const *dst, const int *rows, const int *cols, int count, void *stream);
 
 #ifdef __cplusplus
 }
