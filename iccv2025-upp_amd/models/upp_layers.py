@@ -388,8 +388,7 @@ class Mlp(nn.Module):
         if (self.drop.p == 0 and isinstance(self.act, nn.GELU) and self.act.approximate == 'none' and fc1.bias is not None
                 and HF.linear_usable(x, fc1.weight) and fc1.out_features % 4 == 0):
             # bias + GELU (+ GELU' for backward) in the fc1 epilogue, GELU' applied in the epilogue of fc2's data gradient
-            m = HF.mlp_gelu(x, fc1.weight, fc1.bias, fc2.weight)
-            return m if fc2.bias is None else m + fc2.bias
+            return HF.mlp_gelu(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
         h = self.drop(self.act(HF.linear(x, self.fc1.weight, self.fc1.bias)))
         return self.drop(HF.linear(h, self.fc2.weight, self.fc2.bias))
 

@@ -284,6 +284,16 @@ class _DeferredSums:
         self.routed.add(ptr)
         return True, None
 
+    def accumulate_mm(self, ptr, a, b):
+        """dst += a . b for a parameter whose gradient buffer is registered (the library weight-gradient GEMM writes straight into the
+        flat gradient buffer: no temporary, no copy by the step driver).  -> True when routed."""
+        dst = self.targets.get(ptr) if (self.targets is not None and a.is_cuda) else None
+        if dst is None or dst.numel() != a.shape[0] * b.shape[1]:
+            return False
+        dst.view(a.shape[0], b.shape[1]).addmm_(a, b)
+        self.routed.add(ptr)
+        return True
+
     def flush(self):
         jobs, self.jobs = self.jobs, []
         ops.batched_sum(jobs)
@@ -466,6 +476,8 @@ def weight_grad(g2, x2, w, own=False):
         # of upp_linear_wgrad_f32 takes 25 us per launch where the library's split-K solutions take ~12 us -- 65 launches per
         # step, 9.36 against 8.23 ms.  The many-row layers (patch embedding, segmentation head: M = 65,536) run on ours.
         note_declined("linear weight gradient (%d,%d) over %d rows" % (N, K, g2.shape[0]), "%d < rows < %d: library GEMM" % (WGRAD_FEW_ROWS, WGRAD_MIN_ROWS))
+        if _DEFERRED.accumulate_mm(w.data_ptr(), g2.t(), x2):
+            return None
         return torch.mm(g2.t(), x2)
     part = ops.linear_wgrad(g2, x2)
     _, gw = _DEFERRED.reduce(w.data_ptr(), part.view(part.shape[0], N * K), 0, N * K)
@@ -522,19 +534,19 @@ def _zero_bias(weight):
 
 
 class _MlpGelu(Function):
-    """fc2( GELU( fc1(x) + b1 ) ) without the fc2 bias (reference models/Point_MAE_pretask_dev.py:163-168):
+    """fc2( GELU( fc1(x) + b1 ) ) (+ b2) (reference models/Point_MAE_pretask_dev.py:163-168):
     two upp_linear_f32 launches forward (the first carries bias + GELU and stores GELU'), two backward for the data gradient (the
     data gradient of fc2 is multiplied by the saved GELU' in its epilogue, i.e. it IS the gradient at the fc1 pre-activation).
     Frozen weights (the PEFT recipe): the hidden activation is not kept.  Trainable weights (Point-MAE pre-training): it is, and
-    dW2 = g^T hid, dW1 = g_z^T x, db1 = column sum of g_z follow weight_grad / the deferred sums."""
+    dW2 = g^T hid, dW1 = g_z^T x, db1 = column sum of g_z, db2 = column sum of g follow weight_grad / the deferred sums."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2):
+    def forward(ctx, x, w1, b1, w2, b2=None):
         hid, d = ops.linear_f32(x, w1, b1, ops.LIN_BIAS_GELU_D)
         train = w1.requires_grad or w2.requires_grad or b1.requires_grad
         ctx.save_for_backward(d, w1, w2, x if train else None, hid if w2.requires_grad else None)
-        ctx.bias_ptr = b1.data_ptr()
-        return ops.linear_f32(hid, w2)
+        ctx.bias_ptrs = (b1.data_ptr(), b2.data_ptr() if b2 is not None else 0)
+        return ops.linear_f32(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE)
 
     @staticmethod
     def backward(ctx, g):
@@ -545,21 +557,24 @@ class _MlpGelu(Function):
             g2 = g2.contiguous()
         g_z = ops.linear_f32(g2, _wt(w2), None, ops.LIN_MUL, aux=d.view(-1, d.shape[-1]))
         gx = ops.linear_f32(g_z, _wt(w1)).view(g.shape[:-1] + (w1.shape[1],)) if need[0] else None
-        gw1 = gb1 = gw2 = None
+        gw1 = gb1 = gw2 = gb2 = None
         if need[1]:
             gw1 = weight_grad(g_z, x.reshape(-1, x.shape[-1]), w1)
         if need[2]:
-            _, gb1 = _DEFERRED.reduce(ctx.bias_ptr, g_z, 0, g_z.shape[1])
+            _, gb1 = _DEFERRED.reduce(ctx.bias_ptrs[0], g_z, 0, g_z.shape[1])
         if need[3]:
             gw2 = weight_grad(g2, hid.reshape(-1, hid.shape[-1]), w2)
-        return gx, gw1, gb1, gw2
+        if len(need) > 4 and need[4]:
+            _, gb2 = _DEFERRED.reduce(ctx.bias_ptrs[1], g2, 0, g2.shape[1])
+        return gx, gw1, gb1, gw2, gb2
 
 
-def mlp_gelu(x, w1, b1, w2):
-    """fc2(GELU(fc1(x) + b1)) (no fc2 bias); both GEMMs and the activation on upp_linear_f32."""
-    if not torch.is_grad_enabled() or not (x.requires_grad or w1.requires_grad or w2.requires_grad or b1.requires_grad):
-        return ops.linear_f32(ops.linear_f32(x, w1, b1, ops.LIN_BIAS_GELU), w2)
-    return _MlpGelu.apply(x, w1, b1, w2)
+def mlp_gelu(x, w1, b1, w2, b2=None):
+    """fc2(GELU(fc1(x) + b1)) (+ b2); both GEMMs and the activation on upp_linear_f32."""
+    if not torch.is_grad_enabled() or not (x.requires_grad or w1.requires_grad or w2.requires_grad or b1.requires_grad
+                                           or (b2 is not None and b2.requires_grad)):
+        return ops.linear_f32(ops.linear_f32(x, w1, b1, ops.LIN_BIAS_GELU), w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE)
+    return _MlpGelu.apply(x, w1, b1, w2, b2)
 
 
 # ------------------------------------------------------------------ prompt propagation
