@@ -818,7 +818,8 @@ class PointNetFeaturePropagation(nn.Module):
         else:
             y = _inverse_distance_interp(xyz1, xyz2, z, k, 1e-4).reshape(B * N, -1)
             if C1:
-                y = torch.addmm(y, points1.reshape(B * N, C1), w[:, :C1].t())
+                # (the concat's first C1 columns as a separate small-K product: forward, data and weight gradient on our kernels)
+                y = y + HF.linear(points1.reshape(B * N, C1), w[:, :C1]) if y.is_cuda else torch.addmm(y, points1.reshape(B * N, C1), w[:, :C1].t())
         if self.training and bn.track_running_stats:
             bump_counter(bn.num_batches_tracked)
         x = _bn_rows(y, bn, self.training, relu=True)

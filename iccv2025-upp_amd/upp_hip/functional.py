@@ -469,6 +469,10 @@ def weight_grad(g2, x2, w, own=False):
     training step by the deferred batched sum, straight into w's slot of the flat gradient buffer (then None is returned)."""
     N, K = g2.shape[1], x2.shape[1]
     if N % 4 or K % 4 or x2.stride(1) != 1 or x2.stride(0) % 4 or g2.stride(0) % 4:
+        if N * K <= 2048 and x2.stride(1) == 1 and g2.stride(1) == 1 and g2.is_cuda:
+            part = ops.linear_smallk_wgrad(g2, x2)
+            _, gw = _DEFERRED.reduce(w.data_ptr(), part.view(part.shape[0], N * K), 0, N * K)
+            return None if gw is None else gw.view(N, K)
         note_declined("linear weight gradient (%d,%d)" % (N, K), "N % 4 / K % 4 / row alignment")
         return torch.mm(g2.t(), x2)
     if WGRAD_FEW_ROWS < g2.shape[0] < WGRAD_MIN_ROWS and not own:
@@ -486,6 +490,47 @@ def weight_grad(g2, x2, w, own=False):
 
 def b_needed(ctx):
     return len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2]
+
+
+class _LinearSmallK(Function):
+    """x . W^T + b for the layers upp_linear_f32 does not take (K not a multiple of 4 or unaligned rows; K <= 64, N <= 256) WITH a
+    gradient: forward upp_linear_smallk_f32, data gradient the same kernel on W^T (contraction over N <= 64), weight gradient
+    upp_linear_smallk_wgrad_f32 partials, bias gradient a (two-stage) column sum -- all through the deferred sums of a step driver.
+    (The rectify prompter's point-wise layers in the pre-task recipe and stage 2: K = 3, 27, 59.)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x if w.requires_grad else None, w)
+        ctx.ptrs = (w.data_ptr(), b.data_ptr() if b is not None else 0)
+        return ops.linear_smallk(x, w, b, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        N, K = w.shape
+        g2 = g.reshape(-1, N)
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear_smallk(g2, w.detach().t().contiguous() if not w.requires_grad else ops.transpose(w.detach()), None, 0)
+            gx = gx.view(g.shape[:-1] + (K,))
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, K)
+            if x2.stride(1) != 1:
+                x2 = x2.contiguous()
+            part = ops.linear_smallk_wgrad(g2, x2)
+            _, gw = _DEFERRED.reduce(ctx.ptrs[0], part.view(part.shape[0], N * K), 0, N * K)
+            gw = None if gw is None else gw.view(N, K)
+        if ctx.needs_input_grad[2]:
+            _, gb = _DEFERRED.reduce(ctx.ptrs[1], g2, 0, N)
+        return gx, gw, gb
+
+
+def _smallk_with_grad(x, weight):
+    N, K = weight.shape
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] == K
+            and K <= 64 and N <= 64 and N * K <= 2048 and x.numel() > 0 and weight.stride(1) == 1)
 
 
 _ACT_EPI = {None: (ops.LIN_BIAS, 0), 'relu': (ops.LIN_BIAS_RELU, 1), 'gelu': (ops.LIN_BIAS_GELU, 2)}
@@ -512,6 +557,8 @@ def linear(x, weight, bias=None, own_wgrad=False, act=None):
         if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] == weight.shape[1]
                 and weight.shape[1] <= 64 and weight.shape[0] <= 256 and x.numel() > 0 and not needs_grad):
             return ops.linear_smallk(x, weight, bias, _ACT_EPI[act][1])
+        if needs_grad and _smallk_with_grad(x, weight):
+            return _act_torch(_LinearSmallK.apply(x, weight, bias), act)
         if x.is_cuda:
             note_declined("linear %s x %s" % (tuple(x.shape), tuple(weight.shape)), "dtype / layout / K % 4" + (" with a gradient" if needs_grad else ""))
         return _act_torch(F.linear(x, weight, bias), act)
@@ -762,7 +809,13 @@ class _InterpAffine(Function):
         dists, idx, x3 = ctx.saved_tensors
         g = g.contiguous()
         g_feat = ops.interp_bwd(dists, idx, g, ctx.S, ctx.k, ctx.eps) if ctx.needs_input_grad[2] else None
-        g_wt = torch.mm(x3.reshape(-1, 3).t(), g.reshape(-1, g.shape[-1])) if ctx.needs_input_grad[4] else None
+        g_wt = None
+        if ctx.needs_input_grad[4]:
+            g2, x2 = g.reshape(-1, g.shape[-1]), x3.reshape(-1, 3)
+            if g2.shape[1] * 3 <= 2048:           # (3, C) = x3^T g over all points: the small-K weight-gradient kernel (transposed roles)
+                g_wt = ops.linear_smallk_wgrad(g2, x2).sum(0).t()
+            else:
+                g_wt = torch.mm(x2.t(), g2)
         return None, None, g_feat, None, g_wt, None, None
 
 

@@ -319,6 +319,23 @@ def linear_smallk(x, w, bias=None, act=0):
     return out
 
 
+def linear_smallk_wgrad(g, x, chunks=None):
+    """(chunks, N, K) partial weight gradients of a small Linear: sum over dim 0 = g^T . x (g (M,N), x (M,K), N K <= 2048);
+    upp_linear_smallk_wgrad_f32."""
+    for t_, n_ in ((g, "g"), (x, "x")):
+        if not (isinstance(t_, torch.Tensor) and t_.is_cuda and t_.dtype == torch.float32 and t_.dim() == 2 and t_.stride(1) == 1):
+            raise RuntimeError(f"{n_} must be a 2-D f32 HIP (cuda) matrix with contiguous rows; upp_hip has no CPU path")
+    M, N = g.shape
+    K = x.shape[1]
+    if x.shape[0] != M or N * K > 2048:
+        raise RuntimeError(f"linear_smallk_wgrad: g {tuple(g.shape)} against x {tuple(x.shape)} (N K <= 2048)")
+    if chunks is None:
+        chunks = max(1, min(512, (M + 63) // 64))
+    part = torch.empty((chunks, N, K), dtype=torch.float32, device=g.device)
+    _call(g.device, "upp_linear_smallk_wgrad_f32", _abi.ptr(g), g.stride(0), _abi.ptr(x), x.stride(0), _abi.ptr(part), M, N, K, chunks)
+    return part
+
+
 def transpose(w, out=None):
     """W^T of a 2-D f32 matrix with contiguous rows (upp_transpose_f32); `out` (cols, rows) is overwritten in place when given."""
     if not (isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1):

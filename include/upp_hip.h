@@ -448,6 +448,11 @@ int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw,
  * weight (frozen ones are transposed once and cached by the caller). */
 int upp_linear_smallk_f32(const float *x, long long ldx, const float *W, long long ldw, const float *bias, float *y, long long ldy,
                           int M, int N, int K, int act, void *stream);
+/* upp_linear_smallk_wgrad_f32: partials (chunks, N, K)[c][n][k] = sum over the rows m of chunk c of G[m][n] * X[m][k] -- the weight gradient of
+ * a small Linear (N K <= 2048, any alignment) over many rows, rows added in ascending order; the caller sums the chunks (upp_batched_sum).
+ * (The rectify prompter's point-wise layers in the pre-task recipe: 32 x 27, 64 x 3, ... over 34,432 rows.) */
+int upp_linear_smallk_wgrad_f32(const float *G, long long ldg, const float *X, long long ldx, float *partials, int M, int N, int K,
+                                int chunks, void *stream);
 int upp_transpose_f32(const float *src, long long ld_src, float *dst, long long ld_dst, int rows, int cols, void *stream);
 /* upp_transpose_batched_f32: dst_j (cols_j, rows_j) = src_j (rows_j, cols_j)^T for `count` contiguous matrices in one launch (host arrays of
  * device pointers and sizes): the W^T copies of ALL trainable weights of a recipe, refreshed once per training step. */

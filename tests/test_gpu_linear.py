@@ -344,3 +344,25 @@ def test_tall_column_sums_in_two_stages(rows, cols, off, length):
     routed, t = HF._DEFERRED.reduce(0, part, off, length)          # no scope open: summed at once and returned
     assert not routed
     torch.testing.assert_close(t.double(), ref, rtol=1e-5, atol=1e-4 * max(1.0, float(ref.abs().max())) * 1e-1)
+
+
+@pytest.mark.parametrize("M,N,K", [(34432, 32, 27), (34432, 64, 3), (5000, 32, 59), (33, 16, 7), (70000, 40, 12)])
+def test_small_k_linear_with_gradients(M, N, K):
+    """_LinearSmallK: forward / data gradient on upp_linear_smallk_f32, weight gradient on upp_linear_smallk_wgrad_f32 (partials summed by
+    the caller), bias gradient a column sum -- against torch autograd."""
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    x = torch.randn(M, K, device='cuda', generator=g).requires_grad_(True)
+    w = (torch.randn(N, K, device='cuda', generator=g) * K ** -0.5).requires_grad_(True)
+    b = torch.randn(N, device='cuda', generator=g).requires_grad_(True)
+    go = torch.randn(M, N, device='cuda', generator=g)
+    out = HF.linear(x, w, b)
+    gx, gw, gb = torch.autograd.grad(out, [x, w, b], go)
+    xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.linear(xr, wr, br)
+    rx, rw, rb = torch.autograd.grad(ref, [xr, wr, br], go)
+    close(out, ref)
+    close(gx, rx)
+    close(gw, rw, rtol=2e-5, atol_scale=2e-5)
+    close(gb, rb, rtol=2e-5, atol_scale=2e-5)
+    part = ops.linear_smallk_wgrad(go, x.detach())
+    close(part.sum(0), rw, rtol=2e-5, atol_scale=2e-5)
