@@ -366,3 +366,41 @@ def test_small_k_linear_with_gradients(M, N, K):
     close(gb, rb, rtol=2e-5, atol_scale=2e-5)
     part = ops.linear_smallk_wgrad(go, x.detach())
     close(part.sum(0), rw, rtol=2e-5, atol_scale=2e-5)
+
+
+def test_trainable_weight_transposes_follow_the_weights_inside_a_step_driver():
+    """Inside a step driver (TRANSPOSED.managed) the W^T copy of a trainable weight is persistent and refreshed by ONE batched launch
+    (upp_transpose_batched_f32) at the start of a step: the data gradient must follow in-place weight updates; outside a driver every
+    use transposes afresh."""
+    g = torch.Generator(device='cuda').manual_seed(9)
+    ws = [(torch.randn(n, k, device='cuda', generator=g) * 0.05).requires_grad_(True) for n, k in ((96, 384), (384, 64), (40, 256))]
+    xs = [torch.randn(50, w.shape[1], device='cuda', generator=g).requires_grad_(True) for w in ws]
+
+    def grads():
+        return [torch.autograd.grad(HF.linear(x, w).sum(), x)[0] for x, w in zip(xs, ws)]
+
+    def refs():
+        return [torch.ones(50, w.shape[0], device='cuda') @ w.detach() for w in ws]
+
+    HF.TRANSPOSED.managed = True
+    try:
+        HF.TRANSPOSED.refresh_trainable()
+        for a, b in zip(grads(), refs()):
+            close(a, b)
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.5).add_(0.01)                       # what an optimizer step does, without telling anyone
+        stale = grads()                                      # (persistent copies: still the old weights -- by design)
+        assert not torch.allclose(stale[0], refs()[0], rtol=1e-3)
+        HF.TRANSPOSED.refresh_trainable()                    # what TrainStep._forward_backward does first
+        for a, b in zip(grads(), refs()):
+            close(a, b)
+    finally:
+        HF.TRANSPOSED.managed = False
+    with torch.no_grad():
+        ws[0].mul_(0.5)
+    close(grads()[0], refs()[0])                             # unmanaged: transposed at every use
+    pairs = [(w.detach(), torch.empty(w.shape[1], w.shape[0], device='cuda')) for w in ws]
+    ops.transpose_batched(pairs)
+    for src, dst in pairs:
+        assert torch.equal(dst, src.t().contiguous())
