@@ -405,7 +405,7 @@ def stage_report(device, B):
         bias = torch.randn(N, device=device, generator=gl)
         aux = torch.randn(M, N, device=device, generator=gl) if epi == ops.LIN_MUL else None
         res = torch.empty(M, N, device=device)
-        t = time_kernel(lambda: ops.linear_f32(a, w, bias if epi in (1, 2, 3) else None, epi, aux=aux, out=res))
+        t = time_kernel(lambda: ops.linear_f32(a, w, bias if epi in (1, 2, 3, 5) else None, epi, aux=aux, out=res))
         tile = _abi_tile(M, N, K)
         out["linear_" + label] = mfma("linear_f32_kernel<%s> %s: (%d,%d) x (%d,%d)^T, epilogue %d" % (tile, label, M, K, N, K, epi), t,
                                       2.0 * M * N * K)
@@ -444,7 +444,7 @@ def linear_family_replay(ts, device):
     def launch(M, N, K, e):
         a, w, b, x, o, d = bufs[(M, N, K)]
         lib_aux = x if e == ops.LIN_MUL else None
-        ops.linear_f32(a, w, b if e in (1, 2, 3) else None, e, aux=lib_aux, out=o)
+        ops.linear_f32(a, w, b if e in (1, 2, 3, 5) else None, e, aux=lib_aux, out=o)
 
     def run_all():
         for c in calls:
@@ -538,7 +538,6 @@ def main():
                     help="cls = the headline workload (default); the others are secondary recipes, see RecipeTrainer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (debug)")
-    ap.add_argument("--no-gemm-tuning", action="store_true", help="library-default GEMM solutions (see upp_hip/gemm_tuning.py)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the prompting front-end and the trainable back-end of a step one after the other (one stream)")
     ap.add_argument("--no-stage-report", action="store_true",
@@ -574,9 +573,6 @@ def main():
     torch.cuda.set_device(device)
     from upp_hip import _abi
     _abi.load()                                           # fail loudly if the HIP library is missing
-    if not args.no_gemm_tuning:
-        from upp_hip import gemm_tuning
-        gemm_tuning.enable()                              # best hipBLASLt / rocBLAS solution per Linear shape (same f32 math)
 
     pipeline = not args.no_pipeline and not args.no_graph and args.workload in ("cls", "cls_aux", "seg")
     if args.workload == "cls":

@@ -808,7 +808,7 @@ class PointNetFeaturePropagation(nn.Module):
         conv, bn = self.mlp_convs[0], self.mlp_bns[0]
         w = conv.weight.view(conv.weight.shape[0], -1)
         C1 = 0 if points1 is None else points1.shape[-1]
-        z = F.linear(points2, w[:, C1:], conv.bias)                                         # (B,S,C_out)
+        z = HF.linear(points2, w[:, C1:], conv.bias)                                        # (B,S,C_out)
         S, k, Co = xyz2.shape[1], self.interpolate_neighbors, w.shape[0]
         if (C1 == 3 and z.dtype == torch.float32 and S <= 256 and k <= min(4, S) and Co >= 256 and Co % 4 == 0 and N <= 4096
                 and xyz1.shape[-1] == 3 and _no_grad_needed(xyz1, xyz2, points1)):
@@ -867,5 +867,6 @@ class RectifyPrompter(nn.Module):
             feature = self.propagation1(x, center1, None, center1_feature, cat_buffer=buf)
         else:
             feature = self.propagation1(x, center1, pe(x), center1_feature)
-        noise_score = self.score_head(feature) * self.score_factor
+        l0, _, drop, l1 = self.score_head                                  # Linear(32, 64), ReLU, Dropout(0.2), Linear(64, 3): both on our kernels
+        noise_score = HF.linear(drop(HF.linear(feature, l0.weight, l0.bias, act='relu')), l1.weight, l1.bias) * self.score_factor
         return (noise_score, shape_feature) if require_shape_feature else noise_score

@@ -87,6 +87,10 @@ SIGNATURES = {
     "upp_linear_smallk_wgrad_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_transpose_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_f]),
     "upp_transpose_batched_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f]),
+    "upp_linear_wgrad_grouped_rows": (_c_i, [_c_i] + [ctypes.POINTER(ctypes.c_int)] * 4),
+    "upp_linear_wgrad_grouped_f32": (_c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p),
+                                            ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p)] + [ctypes.POINTER(ctypes.c_int)] * 4
+                                     + [_c_i, _c_f]),
     "upp_linear_wgrad_splits": (_c_i, [_c_i, _c_i, _c_i]),
     "upp_linear_wgrad_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_i, _c_i, _c_f]),
     "upp_adamw_flat": (_c_i, [_c_f] * 4 + [ctypes.c_longlong] * 2 + [_c_f] * 2 + [ctypes.c_float] * 6 + [_c_f]),
@@ -109,7 +113,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError -> loud failure on a stale build
         fn.restype = res
         fn.argtypes = args
-    if lib.upp_abi_version() != 1:
+    if lib.upp_abi_version() != 2:
         raise RuntimeError("libupp_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -33,60 +33,7 @@
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
-
-enum { LEPI_NONE = 0, LEPI_BIAS = 1, LEPI_BIAS_GELU = 2, LEPI_BIAS_GELU_D = 3, LEPI_MUL = 4, LEPI_BIAS_RELU = 5 };
-
-struct LinArgs {
-    const float *A; long long lda;
-    const float *W; long long ldw;
-    float *C; long long ldc;
-    const float *bias;            // (N) or null
-    float *aux; long long ldaux;  // LEPI_BIAS_GELU_D: out (M,N) GELU'(z); LEPI_MUL: in (M,N) factor
-    int M, N, K;
-    int tiles_n;                  // workgroup tiles along N
-    int epi;
-    int ktail;                    // K is not a multiple of the k-stage: the last stage reads zeros beyond K (K % 4 == 0)
-#ifdef UPP_LIN_STAMPS
-    unsigned long long *stamps;   // diagnostic build only (tools/micro/lin_stamps.py): [workgroup][8] clock readings
-#endif
-};
-
-#ifdef UPP_LIN_STAMPS
-unsigned long long *g_lin_stamps = nullptr;
-#define UPP_STAMP(slot)                                                                                   \
-    if (g.stamps && threadIdx.x == 0) {                                                                   \
-        g.stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();                         \
-        if ((slot) == 0 || (slot) == 3) g.stamps[(size_t)blockIdx.x * 8 + 4 + (slot) / 3] = __builtin_amdgcn_s_memrealtime(); \
-    }
-#else
-#define UPP_STAMP(slot)
-#endif
-
-// GELU(v) = v Phi(v) and GELU'(v) = Phi(v) + v phi(v) from ONE exponential: with x = |v| / sqrt 2 and t = 1 / (1 + p x),
-// erfc(x) = (a1 t + ... + a5 t^5) e^{-x^2} (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7) and phi(v) = e^{-x^2} / sqrt(2 pi).
-// ~20 VALU instructions for both against ~70 for erff + expf: the epilogue of a 16-wave workgroup is VALU time of its SIMDs.
-__device__ __forceinline__ void gelu_pair(float v, float &gelu, float &dgelu) {
-    const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
-    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * x * x);
-    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    p = __builtin_fmaf(p, t, 1.421413741f);
-    p = __builtin_fmaf(p, t, -0.284496736f);
-    p = __builtin_fmaf(p, t, 0.254829592f);
-    const float half_erfc = 0.5f * p * t * e;                     // 0.5 erfc(|v| / sqrt 2) = Phi(-|v|)
-    const float cdf = v < 0.0f ? half_erfc : 1.0f - half_erfc;
-    gelu = v * cdf;
-    dgelu = __builtin_fmaf(v * 0.39894228040143267794f, e, cdf);
-}
-
-__device__ __attribute__((aligned(16))) const float g_lin_zeros[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#include "linear_shared.h"
 
 template <int BMB, int BNB, int KS, int KC, bool TAIL>
 __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g) {
@@ -327,161 +274,6 @@ int launch_linear(const LinArgs &g0, hipStream_t st) {
     return upp_launch_status();
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Weight gradient  dW (N,K) = G^T . X  of a trainable Linear (G = dY (M,N), X (M,K): the contraction runs over the M token /
-// point rows).  Same machine as above -- LDS-DMA staging, one 32x32 output block per wave, 16 waves -- with the operands
-// "k-major" by nature: a stage is 32 rows of G (128 columns) and of X (128 columns), each row segment 512 contiguous
-// bytes, and the MFMA operands of a lane are single dwords of one LDS row (conflict-free ds_read_b32).  The M rows are split
-// over workgroups (tiles x splits ~ 256..512 workgroups); every split writes its partial (N,K) tile, and the caller sums
-// the splits in order (upp_batched_sum: deterministic, and for a training step straight into the flat gradient buffer).
-struct WgArgs {
-    const float *G; long long ldg;
-    const float *X; long long ldx;
-    float *P;                     // (splits, N, K)
-    int M, N, K, tiles_k, rows_per_split;
-};
-
-template <int BNB, int BKB, int KS>
-__global__ __launch_bounds__(BNB *BKB *KS * 64) void linear_wgrad_kernel(WgArgs g) {
-    // KS wave groups work on KS consecutive 32-row slabs of a stage (small M: the rows are split INSIDE the workgroup and
-    // summed through the LDS, so 64 x 64 tiles give enough workgroups without partial tiles in memory)
-    constexpr int NW = BNB * BKB * KS, BN = 32 * BNB, BK = 32 * BKB;
-    constexpr int SLAB = 32 * (BN + BK) * 4;                 // 32 rows of [G tile | X tile], row-major, one after the other
-    constexpr int STAGE = KS * SLAB;
-    constexpr int TG = BN / 8, TS = (BN + BK) / 8, T = KS * TS;  // DMA instructions (1 KB each): per slab the first TG fill the G part
-    constexpr int TPW = (T + NW - 1) / NW;
-    constexpr int RED = KS > 1 ? NW * 4096 : 0;
-    constexpr int LDS_BYTES = 2 * STAGE > RED ? 2 * STAGE : RED;
-    static_assert(TPW * NW == T && LDS_BYTES <= 160 * 1024, "wgrad geometry");
-    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x, split = blockIdx.y;          // gridDim.y = splits
-    const int tn = tile / g.tiles_k, tk = tile - tn * g.tiles_k;
-    const int n0 = tn * BN, k0 = tk * BK;
-    const int ms = split * g.rows_per_split, me = min(g.M, ms + g.rows_per_split);
-    const int ks = wave / (BNB * BKB), wb = wave - ks * (BNB * BKB);
-    const int bn = wb / BKB, bk = wb - bn * BKB;
-
-    // DMA sources: instruction t = slab * TS + tt covers granules 64 tt .. 64 tt + 63 of its part of that slab; a row of a part
-    // is BN/4 (BK/4) granules.  Rows beyond M are clamped to the last row (their products are masked below); columns beyond
-    // N / K to the last granule (their outputs are not stored).
-    const float *colptr[TPW];
-    long long ldq[TPW];
-    int row0[TPW];
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        const int t = wave + q * NW;
-        const int slab = t / TS, ts = t - slab * TS;
-        const bool isG = ts < TG;
-        const int tt = isG ? ts : ts - TG;
-        const int per_row = (isG ? BN : BK) / 4;
-        const int gq = tt * 64 + lane, row = gq / per_row, c4 = gq - row * per_row;
-        const int col = min((isG ? n0 : k0) + 4 * c4, (isG ? g.N : g.K) - 4);
-        colptr[q] = (isG ? g.G : g.X) + col;
-        ldq[q] = isG ? g.ldg : g.ldx;
-        row0[q] = ms + 32 * slab + row;
-    }
-    auto issue = [&](int stage, int c) {
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            const int t = wave + q * NW;
-            const int row = min(row0[q] + 32 * KS * c, g.M - 1);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(colptr[q] + row * ldq[q]), (lds_ptr_t)(lds + stage * STAGE + t * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds + ks * SLAB;
-    const unsigned adrG = lds0 + (h * BN + bn * 32 + r) * 4, adrX = lds0 + 32 * BN * 4 + (h * BK + bk * 32 + r) * 4;
-    const int nst = (me - ms + 32 * KS - 1) / (32 * KS);
-    if (nst > 0) issue(0, 0);
-    for (int c = 0; c < nst; ++c) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (c + 1 < nst) issue((c + 1) & 1, c + 1);
-        const unsigned so = (c & 1) * STAGE;
-        const int left = me - ms - 32 * (c * KS + ks) - h;     // rows 2 s + h of this wave group's slab exist while 2 s < left
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            float a[4], b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = 4 * s4 + u;
-                asm volatile("ds_read_b32 %0, %1" : "=v"(a[u]) : "v"(adrG + so + s * (2 * BN * 4)));
-                asm volatile("ds_read_b32 %0, %1" : "=v"(b[u]) : "v"(adrX + so + s * (2 * BK * 4)));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float av = 2 * (4 * s4 + u) < left ? a[u] : 0.0f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u], acc, 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // wave groups: partial blocks through the LDS, summed in group order; group ks finishes registers [T0, T0 + TN)
-    constexpr int TN = 16 / KS;
-    const int T0 = ks * TN;
-    float outv[TN];
-    if (KS > 1) {
-        __syncthreads();
-        float *red = reinterpret_cast<float *>(lds);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) red[(wave * 16 + t) * 64 + lane] = acc[t];
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < TN; ++u) {
-            float sum = 0.0f;
-#pragma unroll
-            for (int k2 = 0; k2 < KS; ++k2) sum += red[((k2 * (BNB * BKB) + wb) * 16 + T0 + u) * 64 + lane];
-            outv[u] = sum;
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < TN; ++u) outv[u] = acc[u];
-    }
-    // partial tile of this split: register t = dW[n][k], n = n0 + 32 bn + (t & 3) + 8 (t >> 2) + 4 h, k = k0 + 32 bk + (lane & 31)
-    const int kk = k0 + bk * 32 + r;
-    if (kk >= g.K) return;
-    float *out = g.P + (long long)split * g.N * g.K + kk;
-#pragma unroll
-    for (int u = 0; u < TN; ++u) {
-        const int t = T0 + u;
-        const int n = n0 + bn * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
-        if (n < g.N) out[(long long)n * g.K] = outv[u];
-    }
-}
-
-// Two shapes: 128 x 128 tiles with the rows split over workgroups (many rows: the 65,536-row layers of the patch embedding and
-// the segmentation head), and 64 x 64 tiles whose four wave groups split the rows inside the workgroup (the M <= a few
-// thousand token matrices of the Transformer blocks: enough workgroups without partial tiles; measured on the pre-training
-// step: 128 x 128 tiles with 9-11 row splits cost 28 us per launch + 1.3 ms per step of partial sums).
-inline bool wgrad_small(int M, int N, int K) { return (long long)M * 4 <= 8192LL * 4 && ((N + 63) / 64) * ((K + 63) / 64) >= 24; }
-
-inline void wgrad_geometry(int M, int N, int K, int &tiles_n, int &tiles_k, int &splits, int &rows_per_split) {
-    const int chunks = (M + 31) / 32;
-    if (wgrad_small(M, N, K)) {
-        tiles_n = (N + 63) / 64; tiles_k = (K + 63) / 64;
-        const int tiles = tiles_n * tiles_k;
-        splits = tiles >= 224 ? 1 : (287 + tiles) / tiles;        // fewer tiles than CUs: a little row splitting on top
-        if (splits > (chunks + 7) / 8) splits = (chunks + 7) / 8;
-    } else {
-        tiles_n = (N + 127) / 128; tiles_k = (K + 127) / 128;
-        const int tiles = tiles_n * tiles_k;
-        splits = (384 + tiles - 1) / tiles;                       // ~1.5 workgroups per CU: the splits even out the tail
-        if (splits > (chunks + 7) / 8) splits = (chunks + 7) / 8; // at least 8 stages of 32 rows per split
-    }
-    if (splits > 256) splits = 256;
-    if (splits < 1) splits = 1;
-    rows_per_split = ((chunks + splits - 1) / splits) * 32;
-    splits = (M + rows_per_split - 1) / rows_per_split;
-}
-
 struct LinConfig { int bmb, bnb, ks, kc; };
 #define UPP_LIN_CONFIGS(X) X(4, 4, 1, 2) X(4, 3, 1, 1) X(3, 4, 1, 1) X(2, 4, 2, 1) X(2, 3, 2, 1) X(2, 2, 4, 1) X(1, 2, 4, 1) X(2, 2, 2, 1)
 #define UPP_LIN_ENTRY(a, b, c, d) {a, b, c, d},
@@ -519,7 +311,20 @@ int pick_config(int M, int N, int K) {
     return best;
 }
 
+// Tall matrices (thousands of 128 x 128 tiles: the B N point rows of the segmentation head, a trainable patch embedding) go to the
+// register-tiled kernel of linear_rt.hip: 2 x 2 waves of 2 x 2 blocks, two workgroups per CU.  Measured at 65,536 x 1024 x 1536:
+// 139 TFLOP/s against 126 for the (4,4,1,64) shape above (one block per wave, one workgroup per CU, prologue and store burst of
+// every tile exposed).  Code: 0x1000000 NST + 0x100000 (4 (RM - 1) + RN - 1) + 0x10000 + 4096 WM + 256 WN + 16 + KC -- the low 16 bits
+// read like a (BMB, BNB, KS = 1, KC) code of this file, which is also the summation order (oracle_linear_f32 with ks = 1).
+constexpr int kRtTall = 0x2000000 + 0x100000 * 5 + 0x10000 + 4096 * 2 + 256 * 2 + 16 + 1;
+int pick_rt(int M, int N, int K) {
+    const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    return tiles >= 1024 && N >= 128 && K >= 32 ? kRtTall : 0;      // at least two rounds of the 512 resident workgroups
+}
+
 }  // namespace
+
+__attribute__((visibility("hidden"))) int upp_detail_linear_rt(const void *args, int code, hipStream_t st);
 
 #ifdef UPP_LIN_STAMPS
 extern "C" void upp_linear_set_stamps(unsigned long long *p) { g_lin_stamps = p; }
@@ -528,6 +333,7 @@ extern "C" void upp_linear_set_stamps(unsigned long long *p) { g_lin_stamps = p;
 extern "C" int upp_linear_tile(int M, int N, int K) {
     if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
     if (K % 4 != 0) return UPP_E_RANGE;
+    if (const int rt = pick_rt(M, N, K)) return rt;
     const int i = pick_config(M, N, K);
     if (i < 0) return UPP_E_RANGE;
     return config_code(kConfigs[i]);
@@ -549,6 +355,8 @@ extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, lon
     g.stamps = g_lin_stamps;
 #endif
     hipStream_t st = (hipStream_t)stream;
+    if (tile <= 0) tile = pick_rt(M, N, K);
+    if (tile & 0x10000) return upp_detail_linear_rt(&g, tile, st);
     if (tile <= 0) {
         const int i = pick_config(M, N, K);
         if (i < 0) return UPP_E_RANGE;
@@ -561,26 +369,4 @@ extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, lon
         default: return UPP_E_RANGE;
     }
 #undef UPP_LIN_CASE
-}
-
-extern "C" int upp_linear_wgrad_splits(int M, int N, int K) {
-    if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
-    int tn, tk, splits, rps;
-    wgrad_geometry(M, N, K, tn, tk, splits, rps);
-    return splits;
-}
-
-extern "C" int upp_linear_wgrad_f32(const float *G, long long ldg, const float *X, long long ldx, float *partials, int M, int N, int K,
-                                    void *stream) {
-    if (!G || !X || !partials || M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
-    if (N % 4 != 0 || K % 4 != 0 || ldg % 4 != 0 || ldx % 4 != 0 || ldg < N || ldx < K) return UPP_E_RANGE;
-    if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(X)) & 15) return UPP_E_RANGE;
-    WgArgs g{};
-    int tn, splits;
-    wgrad_geometry(M, N, K, tn, g.tiles_k, splits, g.rows_per_split);
-    g.G = G; g.ldg = ldg; g.X = X; g.ldx = ldx; g.P = partials; g.M = M; g.N = N; g.K = K;
-    const dim3 grid((unsigned)(tn * g.tiles_k), (unsigned)splits);
-    if (wgrad_small(M, N, K)) hipLaunchKernelGGL((linear_wgrad_kernel<2, 2, 4>), grid, dim3(1024), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL((linear_wgrad_kernel<4, 4, 1>), grid, dim3(1024), 0, (hipStream_t)stream, g);
-    return upp_launch_status();
 }

@@ -1,0 +1,60 @@
+// linear_shared.h -- types and device helpers shared by the exact-f32 MFMA Linear kernels (linear.hip: one 32x32 block per wave,
+// the token matrices of the Transformer blocks; linear_rt.hip: register-tiled waves, the tall point-row matrices and the grouped
+// weight gradients).  Included inside each file's anonymous namespace.
+#pragma once
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+enum { LEPI_NONE = 0, LEPI_BIAS = 1, LEPI_BIAS_GELU = 2, LEPI_BIAS_GELU_D = 3, LEPI_MUL = 4, LEPI_BIAS_RELU = 5 };
+
+struct LinArgs {
+    const float *A; long long lda;
+    const float *W; long long ldw;
+    float *C; long long ldc;
+    const float *bias;            // (N) or null
+    float *aux; long long ldaux;  // LEPI_BIAS_GELU_D: out (M,N) GELU'(z); LEPI_MUL: in (M,N) factor
+    int M, N, K;
+    int tiles_n;                  // workgroup tiles along N
+    int epi;
+    int ktail;                    // K is not a multiple of the k-stage: the last stage reads zeros beyond K (K % 4 == 0)
+#ifdef UPP_LIN_STAMPS
+    unsigned long long *stamps;   // diagnostic build only (tools/micro/lin_stamps.py): [workgroup][8] clock readings
+#endif
+};
+
+#ifdef UPP_LIN_STAMPS
+unsigned long long *g_lin_stamps = nullptr;
+#define UPP_STAMP(slot)                                                                                   \
+    if (g.stamps && threadIdx.x == 0) {                                                                   \
+        g.stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();                         \
+        if ((slot) == 0 || (slot) == 3) g.stamps[(size_t)blockIdx.x * 8 + 4 + (slot) / 3] = __builtin_amdgcn_s_memrealtime(); \
+    }
+#else
+#define UPP_STAMP(slot)
+#endif
+
+// GELU(v) = v Phi(v) and GELU'(v) = Phi(v) + v phi(v) from ONE exponential: with x = |v| / sqrt 2 and t = 1 / (1 + p x),
+// erfc(x) = (a1 t + ... + a5 t^5) e^{-x^2} (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7) and phi(v) = e^{-x^2} / sqrt(2 pi).
+// ~20 VALU instructions for both against ~70 for erff + expf: the epilogue of a 16-wave workgroup is VALU time of its SIMDs.
+__device__ __forceinline__ void gelu_pair(float v, float &gelu, float &dgelu) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * x * x);
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float half_erfc = 0.5f * p * t * e;                     // 0.5 erfc(|v| / sqrt 2) = Phi(-|v|)
+    const float cdf = v < 0.0f ? half_erfc : 1.0f - half_erfc;
+    gelu = v * cdf;
+    dgelu = __builtin_fmaf(v * 0.39894228040143267794f, e, cdf);
+}
+
+__device__ __attribute__((aligned(16))) const float g_lin_zeros[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+

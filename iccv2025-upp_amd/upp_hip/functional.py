@@ -268,6 +268,7 @@ class _DeferredSums:
     def __init__(self):
         self.targets = None
         self.jobs = []
+        self.wgrads = []
         self.routed = set()
 
     def reduce(self, ptr, part, offset, length):
@@ -284,18 +285,24 @@ class _DeferredSums:
         self.routed.add(ptr)
         return True, None
 
-    def accumulate_mm(self, ptr, a, b):
-        """dst += a . b for a parameter whose gradient buffer is registered (the library weight-gradient GEMM writes straight into the
-        flat gradient buffer: no temporary, no copy by the step driver).  -> True when routed."""
-        dst = self.targets.get(ptr) if (self.targets is not None and a.is_cuda) else None
-        if dst is None or dst.numel() != a.shape[0] * b.shape[1]:
+    def wgrad(self, ptr, g2, x2):
+        """Queue dW = g2^T . x2 for a parameter whose gradient buffer is registered: every weight gradient of the backward pass
+        runs in ONE grouped launch at scope exit (upp_linear_wgrad_grouped_f32; a weight gradient is read by nothing inside the
+        pass) and its partials are added to the buffer by the batched sum.  -> True when queued (autograd is handed None)."""
+        dst = self.targets.get(ptr) if (self.targets is not None and g2.is_cuda) else None
+        if dst is None or dst.numel() != g2.shape[1] * x2.shape[1]:
             return False
-        dst.view(a.shape[0], b.shape[1]).addmm_(a, b)
+        self.wgrads.append((g2, x2, dst))
         self.routed.add(ptr)
         return True
 
     def flush(self):
         jobs, self.jobs = self.jobs, []
+        wg, self.wgrads = self.wgrads, []
+        if wg:
+            for part, (_, _, dst) in zip(ops.linear_wgrad_grouped([(g, x) for g, x, _ in wg]), wg):
+                n = dst.numel()
+                jobs.append((part.view(part.shape[0], n), 0, part.shape[0], n, n, dst, True))
         ops.batched_sum(jobs)
 
 
@@ -323,6 +330,7 @@ class deferred_sums:
             _DEFERRED.flush()
         else:
             _DEFERRED.jobs = []
+            _DEFERRED.wgrads = []
         return False
 
 
@@ -459,33 +467,27 @@ class _LinearMFMA(Function):
         return gx, gw, gb, None
 
 
-LINEAR_TALL_ROWS = int(os.environ.get("UPP_LINEAR_TALL_ROWS", "16384"))     # from here on the tuned library GEMM wins by > 10 % (see linear())
-WGRAD_MIN_ROWS = int(os.environ.get("UPP_WGRAD_MIN_ROWS", "4096"))
-WGRAD_FEW_ROWS = 512        # up to here one or two 32-row stages: ~8 us on ours; the un-tuned library picks 25-170 us solutions (stage-2 heads)
-
-
 def weight_grad(g2, x2, w, own=False):
-    """dW = g2^T . x2 for the trainable weight w (N,K): upp_linear_wgrad_f32 partials, summed in split order -- inside a
-    training step by the deferred batched sum, straight into w's slot of the flat gradient buffer (then None is returned)."""
+    """dW = g2^T . x2 for the trainable weight w (N,K) on upp_linear_wgrad_grouped_f32: inside a training step the pair is queued
+    and every weight gradient of the backward pass runs in one launch at the end, its partials summed in split order straight
+    into w's slot of the flat gradient buffer (then None is returned); otherwise a group of one, summed at once."""
     N, K = g2.shape[1], x2.shape[1]
-    if N % 4 or K % 4 or x2.stride(1) != 1 or x2.stride(0) % 4 or g2.stride(0) % 4:
-        if N * K <= 2048 and x2.stride(1) == 1 and g2.stride(1) == 1 and g2.is_cuda:
+    if N % 4 or K % 4 or not g2.is_cuda:
+        if N * K <= 2048 and N + K <= 512 and x2.stride(1) == 1 and g2.stride(1) == 1 and g2.is_cuda:
             part = ops.linear_smallk_wgrad(g2, x2)
             _, gw = _DEFERRED.reduce(w.data_ptr(), part.view(part.shape[0], N * K), 0, N * K)
             return None if gw is None else gw.view(N, K)
-        note_declined("linear weight gradient (%d,%d)" % (N, K), "N % 4 / K % 4 / row alignment")
+        if g2.is_cuda:
+            note_declined("linear weight gradient (%d,%d)" % (N, K), "N % 4 / K % 4")
         return torch.mm(g2.t(), x2)
-    if WGRAD_FEW_ROWS < g2.shape[0] < WGRAD_MIN_ROWS and not own:
-        # measured (pre-training step, M = 864 / 2080 token rows, profiles/r02_workload_pretrain_*): the 64 x 64-tile variant
-        # of upp_linear_wgrad_f32 takes 25 us per launch where the library's split-K solutions take ~12 us -- 65 launches per
-        # step, 9.36 against 8.23 ms.  The many-row layers (patch embedding, segmentation head: M = 65,536) run on ours.
-        note_declined("linear weight gradient (%d,%d) over %d rows" % (N, K, g2.shape[0]), "%d < rows < %d: library GEMM" % (WGRAD_FEW_ROWS, WGRAD_MIN_ROWS))
-        if _DEFERRED.accumulate_mm(w.data_ptr(), g2.t(), x2):
-            return None
-        return torch.mm(g2.t(), x2)
+    if g2.stride(1) != 1 or g2.stride(0) % 4 or g2.data_ptr() % 16:          # (a misaligned view: one copy makes it servable)
+        g2 = g2.contiguous()
+    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    if _DEFERRED.wgrad(w.data_ptr(), g2, x2):
+        return None
     part = ops.linear_wgrad(g2, x2)
-    _, gw = _DEFERRED.reduce(w.data_ptr(), part.view(part.shape[0], N * K), 0, N * K)
-    return None if gw is None else gw.view(N, K)
+    return part.sum(dim=0) if part.shape[0] > 1 else part[0]
 
 
 def b_needed(ctx):
@@ -528,9 +530,12 @@ class _LinearSmallK(Function):
 
 
 def _smallk_with_grad(x, weight):
+    """(the data gradient contracts over N on the same kernel: N <= 64 unless the input needs none -- the 3 -> 128 first layer of a
+    trainable position MLP reads the centres)"""
     N, K = weight.shape
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] == K
-            and K <= 64 and N <= 64 and N * K <= 2048 and x.numel() > 0 and weight.stride(1) == 1)
+            and K <= 64 and (N <= 64 or (N <= 256 and not x.requires_grad)) and N * K <= 2048 and N + K <= 512 and x.numel() > 0
+            and weight.stride(1) == 1)
 
 
 _ACT_EPI = {None: (ops.LIN_BIAS, 0), 'relu': (ops.LIN_BIAS_RELU, 1), 'gelu': (ops.LIN_BIAS_GELU, 2)}
@@ -544,15 +549,20 @@ def linear(x, weight, bias=None, own_wgrad=False, act=None):
     """act(F.linear(x, weight, bias)) on this library's kernels: upp_linear_f32 (FP32 matrix cores) for 16-byte aligned rows and
     K % 4 == 0, upp_linear_smallk_f32 (K <= 64, N <= 256, forward only) for the rest; otherwise the library GEMM (said once under
     UPP_VERBOSE).  act: None / 'relu' / 'gelu' (erf) -- fused into the epilogue when nothing needs a gradient, applied by torch
-    otherwise.  own_wgrad: the weight gradient of a trainable layer on upp_linear_wgrad_f32 whatever the row count (the patch
-    embedding, the classification head; default: between WGRAD_FEW_ROWS and WGRAD_MIN_ROWS rows the library's split-K GEMM is used)."""
+    otherwise.  own_wgrad: kept for callers of round 2 (every weight gradient is ours now, whatever the row count)."""
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))
-    if x.is_cuda and not own_wgrad and x.numel() // max(1, x.shape[-1]) >= LINEAR_TALL_ROWS and weight.shape[0] * weight.shape[1] >= 65536:
-        # measured at 65,536 rows (tools/micro/time_linear_tall.py, TunableOp-selected library solutions): upp_linear_f32 126 TFLOP/s
-        # against 145 forward and data gradient, the weight gradient 1.8x behind -- the part-segmentation head (three such
-        # layers) is 2.2 ms per step faster on the library.  own_wgrad=True (the patch embedding) keeps everything on ours.
-        note_declined("linear %s x %s" % (tuple(x.shape), tuple(weight.shape)), ">= %d rows: library GEMM (measured faster)" % LINEAR_TALL_ROWS)
-        return _act_torch(F.linear(x, weight, bias), act)
+    if (x.is_cuda and weight.dim() == 2 and weight.dtype == torch.float32 and weight.shape[1] % 4 == 0 and weight.shape[1] > 64
+            and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16)):
+        # a column window of a wider weight whose rows start off a 16-byte boundary (w[:, 3:] of the (1536, 1155) first layer of the
+        # segmentation head's feature propagation): one differentiable copy makes it servable
+        weight = weight.contiguous()
+    if needs_grad and weight.dim() == 2 and weight.shape[0] % 4 and weight.shape[0] > 16 and linear_usable(x, weight):
+        # the data gradient contracts over the N outputs and the weight gradient is (N, K): both want N % 4 == 0 (the 50 part classes of
+        # the segmentation head's last layer).  Zero rows up to the next multiple of 4 -- their outputs are sliced off, their gradient
+        # rows are dropped by the pad's backward -- keep forward and both gradients on our kernels.
+        pad = -weight.shape[0] % 4
+        y = linear(x, F.pad(weight, (0, 0, 0, pad)), None if bias is None else F.pad(bias, (0, pad)), own_wgrad, act)
+        return y[..., :weight.shape[0]]
     if not linear_usable(x, weight):
         if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] == weight.shape[1]
                 and weight.shape[1] <= 64 and weight.shape[0] <= 256 and x.numel() > 0 and not needs_grad):
@@ -812,7 +822,7 @@ class _InterpAffine(Function):
         g_wt = None
         if ctx.needs_input_grad[4]:
             g2, x2 = g.reshape(-1, g.shape[-1]), x3.reshape(-1, 3)
-            if g2.shape[1] * 3 <= 2048:           # (3, C) = x3^T g over all points: the small-K weight-gradient kernel (transposed roles)
+            if g2.shape[1] * 3 <= 2048 and g2.shape[1] + 3 <= 512:           # (3, C) = x3^T g over all points: the small-K weight-gradient kernel (transposed roles)
                 g_wt = ops.linear_smallk_wgrad(g2, x2).sum(0).t()
             else:
                 g_wt = torch.mm(x2.t(), g2)

@@ -252,7 +252,7 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
     if w.shape[1] != K:
         raise RuntimeError(f"linear_f32: a (...,{K}) against w {tuple(w.shape)}")
     a2 = a.reshape(-1, K)
-    if a2.stride(1) != 1 or a2.stride(0) % 4 != 0:
+    if a2.stride(1) != 1 or a2.stride(0) % 4 != 0 or a2.data_ptr() % 16 != 0:      # (a column window with a misaligned base: one copy)
         a2 = a2.contiguous()
     M = a2.shape[0]
     lead = tuple(a.shape[:-1])
@@ -362,6 +362,35 @@ def linear_wgrad(g, x):
     part = torch.empty((splits, N, K), dtype=torch.float32, device=g.device)
     _call(g.device, "upp_linear_wgrad_f32", _abi.ptr(g), g.stride(0), _abi.ptr(x), x.stride(0), _abi.ptr(part), M, N, K)
     return part
+
+
+def linear_wgrad_grouped(pairs):
+    """pairs: list of (g (M,N), x (M,K)) -- the weight gradients of several Linear layers in ONE launch (upp_linear_wgrad_grouped_f32).
+    -> list of partial gradients (splits_p, N_p, K_p); the caller sums each over dim 0 in order (batched_sum)."""
+    if not pairs:
+        return []
+    import ctypes
+    k = len(pairs)
+    dev = pairs[0][0].device
+    for g, x in pairs:
+        for t, name in ((g, "g"), (x, "x")):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.device == dev):
+                raise RuntimeError(f"{name} must be a 2-D f32 matrix with contiguous rows on one HIP (cuda) device; upp_hip has no CPU path")
+        if x.shape[0] != g.shape[0]:
+            raise RuntimeError("linear_wgrad_grouped: row counts differ")
+    M = (ctypes.c_int * k)(*[g.shape[0] for g, _ in pairs])
+    N = (ctypes.c_int * k)(*[g.shape[1] for g, _ in pairs])
+    K = (ctypes.c_int * k)(*[x.shape[1] for _, x in pairs])
+    rows = (ctypes.c_int * k)()
+    _abi.check(_abi.load().upp_linear_wgrad_grouped_rows(k, M, N, K, rows))
+    parts = [torch.empty(((M[i] + rows[i] - 1) // rows[i], N[i], K[i]), dtype=torch.float32, device=dev) for i in range(k)]
+    G = (ctypes.c_void_p * k)(*[g.data_ptr() for g, _ in pairs])
+    X = (ctypes.c_void_p * k)(*[x.data_ptr() for _, x in pairs])
+    P = (ctypes.c_void_p * k)(*[q.data_ptr() for q in parts])
+    ldg = (ctypes.c_longlong * k)(*[g.stride(0) for g, _ in pairs])
+    ldx = (ctypes.c_longlong * k)(*[x.stride(0) for _, x in pairs])
+    _call(dev, "upp_linear_wgrad_grouped_f32", G, ldg, X, ldx, P, M, N, K, rows, k)
+    return parts
 
 
 def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want_xo=True, ybias=None):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UPP_ABI_VERSION 1
+#define UPP_ABI_VERSION 2   /* 2: grouped weight gradients, register-tiled Linear codes; the round-1 *_set_* toggles are gone */
 
 #define UPP_E_BADARG   (-1)  /* null pointer / non-positive size                   */
 #define UPP_E_RANGE    (-2)  /* size outside what the kernels support (see below)  */
@@ -425,14 +425,27 @@ int upp_ln_adapter_bwd(const float *g_out, const float *xo, const float *mean, c
  *   tile: 0 = chosen by the library for (M,N,K) (upp_linear_tile returns that choice); else 4096*BMB + 256*BNB + 16*KS + KC
  *         forces workgroups of BMB x BNB blocks of 32 x 32 (one block per wave), the contraction split KS ways over wave
  *         groups and 32*KS*KC values of k per LDS stage -- one of the compiled shapes (csrc/linear.hip UPP_LIN_CONFIGS),
- *         anything else is UPP_E_RANGE; for measurements.
+ *         anything else is UPP_E_RANGE; for measurements.  Codes with bit 16 set name the register-tiled shapes of
+ *         csrc/linear_rt.hip (tall matrices: thousands of tiles): 0x1000000 NST + 0x100000 (4 (RM-1) + RN-1) + 0x10000 + 4096 WM +
+ *         256 WN + 16 + KC = WM x WN waves of RM x RN blocks each, NST LDS stages of 32 KC values of k, no split of the
+ *         contraction (the low byte reads KS = 1, KC: the summation order).
  * Limits: K % 4 == 0 (a k-stage holds 32 KS KC values of k; the last one reads zeros beyond K: exact), lda % 4 == 0, ldw % 4 == 0,
  * A and W 16-byte aligned. */
 int upp_linear_tile(int M, int N, int K);
-/* Weight gradient of a trainable Linear (AddmmBackward's second GEMM in the reference): dW (N,K) = G^T . X with G = dY (M,N)
- * and X (M,K) row-major (leading dimensions ldg, ldx).  The M rows are split over upp_linear_wgrad_splits(M,N,K) groups of
- * workgroups; `partials` (splits, N, K) receives one partial dW per split and the caller sums them in order (upp_batched_sum).
- * Limits: N % 4 == 0, K % 4 == 0, ldg % 4 == 0, ldx % 4 == 0, G and X 16-byte aligned. */
+/* Weight gradients of trainable Linear layers (AddmmBackward's second GEMM in the reference: every nn.Linear / 1x1 Conv1d under
+ * autograd -- models/Point_MAE_cp.py:369-465 in pre-training, models/Point_MAE_unify_segment.py:420-433 for the segmentation head):
+ * dW_p (N_p,K_p) = G_p^T . X_p with G_p = dY (M_p,N_p) and X_p (M_p,K_p) row-major (leading dimensions ldg, ldx), for `count`
+ * layers in ONE launch (a weight gradient is read by nothing inside the backward pass, so a step driver issues them together when
+ * the pass is over).  The rows of problem p are cut into runs of rows[p] (a multiple of 32; upp_linear_wgrad_grouped_rows plans them
+ * for a group: equal work units, about six rounds of the resident workgroups); partials[p] (ceil(M_p / rows[p]), N_p, K_p) receives
+ * one partial dW per run -- every entry ONE ascending-row chain of fused multiply-adds -- and the caller sums the runs in order
+ * (upp_batched_sum).  All array arguments are HOST arrays; G / X / partials hold device pointers.
+ * upp_linear_wgrad_f32 / upp_linear_wgrad_splits: a group of one.
+ * Limits: N % 4 == 0, K % 4 == 0, ldg % 4 == 0, ldx % 4 == 0, G, X and partials 16-byte aligned. */
+int upp_linear_wgrad_grouped_rows(int count, const int *M, const int *N, const int *K, int *rows);
+int upp_linear_wgrad_grouped_f32(const float *const *G, const long long *ldg, const float *const *X, const long long *ldx,
+                                 float *const *partials, const int *M, const int *N, const int *K, const int *rows,
+                                 int count, void *stream);
 int upp_linear_wgrad_splits(int M, int N, int K);
 int upp_linear_wgrad_f32(const float *G, long long ldg, const float *X, long long ldx, float *partials,
                          int M, int N, int K, void *stream);

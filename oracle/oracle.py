@@ -49,6 +49,7 @@ def lib():
         L.oracle_emd_matchcost_grad.argtypes = [_f, _f, _f, _f, _int, _int, _int, _f, _f]
         L.oracle_linear_f32.argtypes = [_f, _f, ctypes.c_void_p, ctypes.c_void_p, _f, _int, _int, _int, _int, _int, _int]
         L.oracle_linear_smallk.argtypes = [_f, _f, ctypes.c_void_p, _f, _int, _int, _int, _int]
+        L.oracle_linear_wgrad.argtypes = [_f, _f, _f, _int, _int, _int, _int]
         L.oracle_num_threads.restype = _int
         L.oracle_set_threads.argtypes = [_int]
         _lib = L
@@ -181,6 +182,18 @@ def linear_f32(a, w, bias=None, aux=None, ks=1, kc=1, epilogue=0):
     x = _c(aux) if aux is not None else None
     lib().oracle_linear_f32(a, w, None if b is None else b.ctypes.data_as(ctypes.c_void_p),
                             None if x is None else x.ctypes.data_as(ctypes.c_void_p), out, M, N, K, ks, kc, epilogue)
+    return out
+
+
+def linear_wgrad(g, x, rows):
+    """(splits, N, K) partial weight gradients g (M,N)^T . x (M,K) as upp_linear_wgrad_grouped_f32 sums them: runs of `rows` rows,
+    one ascending-row fmaf chain each.  See oracle_linear_wgrad in upp_oracle.c."""
+    g, x = _c(g), _c(x)
+    M, N = g.shape
+    K = x.shape[1]
+    assert x.shape[0] == M and rows > 0
+    out = np.empty(((M + rows - 1) // rows, N, K), np.float32)
+    lib().oracle_linear_wgrad(g, x, out, M, N, K, int(rows))
     return out
 
 

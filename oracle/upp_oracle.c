@@ -489,6 +489,26 @@ void oracle_linear_f32(const float *A, const float *W, const float *bias, const 
     }
 }
 
+/* upp_linear_wgrad_grouped_f32 (csrc/linear_rt.hip): partial weight gradients of a Linear, P (splits, N, K) with
+ * P[s][n][k] = sum over the rows m of run s (rows s*rows .. min(M, (s+1)*rows) - 1) of G[m][n] * X[m][k] as ONE ascending-row
+ * fmaf chain from 0 (the FP32 MFMA adds its two products as fma(g1, x1, fma(g0, x0, c)); rows beyond the run contribute
+ * fma(0, x, c) = c).  Reference: AddmmBackward's G^T . X in torch -- no summation order is specified there. */
+void oracle_linear_wgrad(const float *G, const float *X, float *P, int M, int N, int K, int rows) {
+    const int splits = (M + rows - 1) / rows;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int s = 0; s < splits; ++s)
+        for (int n = 0; n < N; ++n) {
+            const int m0 = s * rows, m1 = m0 + rows < M ? m0 + rows : M;
+            float *out = P + ((size_t)s * N + n) * K;
+            for (int k = 0; k < K; ++k) out[k] = 0.0f;
+            for (int m = m0; m < m1; ++m) {
+                const float gv = G[(size_t)m * N + n];
+                const float *x = X + (size_t)m * K;
+                for (int k = 0; k < K; ++k) out[k] = fmaf(gv, x[k], out[k]);
+            }
+        }
+}
+
 /* upp_linear_smallk_f32 (csrc/smallk.hip): one ascending-k fmaf chain per output, k padded to a multiple of 4 with zeros,
  * then + bias, then act (0 none, 1 ReLU; GELU goes through erff and is compared within a tolerance instead).
  * Stands for torch.nn.functional.linear at the reference's K = 3 / K = 59 layers (models/Point_MAE_pretask_dev.py:395-399, 475-517). */

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_strings():
     lib = _abi.load()
-    assert lib.upp_abi_version() == 1
+    assert lib.upp_abi_version() == 2
     assert b"null pointer" in lib.upp_error_string(-1)
     assert b"range" in lib.upp_error_string(-2)
     assert b"knn" in lib.upp_error_string(-3)
@@ -69,11 +69,15 @@ def test_linear_decomposition_choice_is_a_host_function():
 
     def cfg(M, N, K):
         c = lib.upp_linear_tile(M, N, K)
-        return c >> 12, (c >> 8) & 15, (c >> 4) & 15, c & 15
+        return (c >> 12) & 15, (c >> 8) & 15, (c >> 4) & 15, c & 15
 
+    RT_TALL = 0x2000000 + 0x100000 * 5 + 0x10000 + 4096 * 2 + 256 * 2 + 16 + 1     # 2 x 2 waves of 2 x 2 blocks, 2 stages of 32 (csrc/linear_rt.hip)
     for M in (2400, 2080, 2048, 1120, 65536, 1):
         for N, K in ((1152, 384), (384, 384), (1536, 384), (384, 1536), (384, 1152), (96, 384), (40, 256)):
             bmb, bnb, ks, kc = cfg(M, N, K)
+            if lib.upp_linear_tile(M, N, K) & 0x10000:          # tall: thousands of 128 x 128 tiles -> the register-tiled kernel, no split of k
+                assert lib.upp_linear_tile(M, N, K) == RT_TALL and M == 65536 and N >= 256 and (ks, kc) == (1, 1)
+                continue
             assert 4 <= bmb * bnb * ks <= 16 and K % (32 * ks * kc) == 0
             wgs = -(-M // (32 * bmb)) * -(-N // (32 * bnb))
             if M <= 2400:

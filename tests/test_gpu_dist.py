@@ -112,7 +112,7 @@ def test_bench_gpus_2_reports_two_ranks(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
-                          "--no-gemm-tuning"], env=env, capture_output=True, text=True, timeout=900)
+                          ], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["dist_backend"] == "gloo" and rec["value"] > 0

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 TOKENS = [2400, 2080, 2048, 1120]                                                   # B*L of the classification step (B = 32)
 LAYERS = [("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536)]   # (name, out, in)
-CONFIGS = [0x4412, 0x4311, 0x3411, 0x2421, 0x2321, 0x2241, 0x1241, 0x2221]
+RT_TALL = 0x2512211        # csrc/linear_rt.hip: 2 x 2 waves of 2 x 2 blocks, 2 LDS stages of 32 (the low byte reads KS = 1, KC = 1)
+CONFIGS = [0x4412, 0x4311, 0x3411, 0x2421, 0x2321, 0x2241, 0x1241, 0x2221, RT_TALL]
 
 
 def close(a, b, rtol=1e-5, atol_scale=2e-6):
@@ -140,12 +141,17 @@ def test_strided_rows_and_rejections():
                                    (4160, 1536, 384), (1000, 132, 36)])
 def test_weight_gradient_partials_sum_to_the_product(shape):
     """upp_linear_wgrad_f32: dW = G^T . X, rows split over workgroups, partial tiles summed in split order."""
+    import oracle as O
     M, N, K = shape
     g = torch.Generator(device='cuda').manual_seed(M + N)
     G = torch.randn(M, N, device='cuda', generator=g)
     X = torch.randn(M, K, device='cuda', generator=g)
     part = ops.linear_wgrad(G, X)
     assert part.shape[1:] == (N, K) and part.shape[0] == _abi.load().upp_linear_wgrad_splits(M, N, K)
+    if M * N * K <= 2400 * 1152 * 384:          # bit for bit against the CPU restatement of the kernel's order (one ascending-row chain per run)
+        rows = -(-M // part.shape[0])
+        rows = -(-rows // 32) * 32
+        np.testing.assert_array_equal(part.cpu().numpy(), O.linear_wgrad(G.cpu().numpy(), X.cpu().numpy(), rows))
     ref = G.double().t() @ X.double()
     got = part.double().sum(0)
     np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=2e-6 * ref.abs().max().item())
@@ -155,6 +161,32 @@ def test_weight_gradient_partials_sum_to_the_product(shape):
     wide = torch.randn(M, N + 8, device='cuda', generator=g)
     part2 = ops.linear_wgrad(wide[:, 4:4 + N], X)
     close(part2.sum(0), wide[:, 4:4 + N].t() @ X, atol_scale=5e-6)
+
+
+def test_grouped_weight_gradients_equal_the_single_launches_and_the_oracle():
+    """upp_linear_wgrad_grouped_f32: the weight gradients of a backward pass in one launch -- mixed shapes, ragged edges, strided
+    operands; every partial bit for bit the CPU restatement (one ascending-row fmaf chain per run of rows)."""
+    import oracle as O
+    g = torch.Generator(device='cuda').manual_seed(77)
+    shapes = [(2080, 1152, 384), (864, 384, 1536), (2080, 384, 384), (1000, 132, 36), (77, 52, 36), (4100, 256, 128), (33, 4, 4)]
+    pairs = []
+    for M, N, K in shapes:
+        wide = torch.randn(M, N + 8, device='cuda', generator=g)
+        pairs.append((wide[:, 4:4 + N], torch.randn(M, K, device='cuda', generator=g)))
+    parts = ops.linear_wgrad_grouped(pairs)
+    for (G, X), part, (M, N, K) in zip(pairs, parts, shapes):
+        rows = -(-(-(-M // part.shape[0])) // 32) * 32
+        np.testing.assert_array_equal(part.cpu().numpy(), O.linear_wgrad(G.cpu().numpy(), X.cpu().numpy(), rows))
+        close(part.sum(0), G.t() @ X, atol_scale=5e-6)
+    # inside a deferred scope: queued, launched once at exit, accumulated into the registered gradient buffers
+    ws = [torch.zeros(N, K, device='cuda', requires_grad=True) for _, N, K in shapes[:3]]
+    bufs = {w.data_ptr(): torch.ones(w.numel(), device='cuda') for w in ws}
+    with HF.deferred_sums(bufs) as scope:
+        for w, (G, X) in zip(ws, pairs[:3]):
+            assert HF.weight_grad(G, X, w) is None
+    assert scope.routed == set(bufs)
+    for w, (G, X) in zip(ws, pairs[:3]):
+        close(bufs[w.data_ptr()].view_as(w), 1.0 + G.t() @ X, atol_scale=5e-6)
 
 
 def _reference_encoder(enc, pg):
@@ -187,7 +219,7 @@ def test_patch_embedding_with_a_gradient_runs_on_our_kernels_and_matches_torch_a
         out.backward(gy)
     torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages()]
-    assert any('linear_f32_kernel' in k for k in names) and (not trainable or any('linear_wgrad_kernel' in k for k in names))
+    assert any('linear_f32_kernel' in k for k in names) and (not trainable or any('wgrad_grouped_kernel' in k for k in names))
     assert not any(k.startswith('Cijk') for k in names), [k for k in names if k.startswith('Cijk')]
     got = {'x': pg.grad.clone()}
     got.update({n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None})
@@ -242,6 +274,35 @@ def test_bit_exact_against_the_cpu_restatement_of_its_summation_order(cfg):
                                       O.linear_f32(an, wn, bias=b.cpu().numpy(), ks=ks, kc=kc, epilogue=1))
         np.testing.assert_array_equal(ops.linear_f32(a, w, None, ops.LIN_MUL, aux=x, tile=cfg).cpu().numpy(),
                                       O.linear_f32(an, wn, aux=x.cpu().numpy(), ks=ks, kc=kc, epilogue=4))
+
+
+@pytest.mark.parametrize("M,N,K", [(4100, 200, 96), (300, 50, 64), (65536, 256, 128), (129, 132, 36)])
+def test_register_tiled_kernel_every_epilogue(M, N, K):
+    """The tall-matrix kernel (csrc/linear_rt.hip) forced on small and ragged shapes: every epilogue against torch, the plain ones bit for
+    bit against the oracle (ks = 1), rows that are not 16-byte aligned (N = 50: dword stores), and the library's own choice at 65,536 rows."""
+    import oracle as O
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g) * K ** -0.5
+    b = torch.randn(N, device='cuda', generator=g)
+    x = torch.randn(M, N, device='cuda', generator=g)
+    if M >= 65536:
+        assert _abi.load().upp_linear_tile(M, N, K) == RT_TALL
+    if M * N * K <= 4100 * 200 * 96:
+        an, wn = a.cpu().numpy(), w.cpu().numpy()
+        np.testing.assert_array_equal(ops.linear_f32(a, w, tile=RT_TALL).cpu().numpy(), O.linear_f32(an, wn))
+        np.testing.assert_array_equal(ops.linear_f32(a, w, b, ops.LIN_BIAS, tile=RT_TALL).cpu().numpy(), O.linear_f32(an, wn, bias=b.cpu().numpy(), epilogue=1))
+        np.testing.assert_array_equal(ops.linear_f32(a, w, None, ops.LIN_MUL, aux=x, tile=RT_TALL).cpu().numpy(), O.linear_f32(an, wn, aux=x.cpu().numpy(), epilogue=4))
+    ref = F.linear(a, w, b)
+    close(ops.linear_f32(a, w, b, ops.LIN_BIAS, tile=RT_TALL), ref)
+    close(ops.linear_f32(a, w, b, ops.LIN_BIAS_RELU, tile=RT_TALL), torch.relu(ref))
+    close(ops.linear_f32(a, w, b, ops.LIN_BIAS_GELU, tile=RT_TALL), F.gelu(ref), atol_scale=5e-7 * 4)
+    h, d = ops.linear_f32(a, w, b, ops.LIN_BIAS_GELU_D, tile=RT_TALL)
+    z = ref.detach().clone().requires_grad_(True)
+    F.gelu(z).sum().backward()
+    close(h, F.gelu(ref), atol_scale=5e-7 * 4)
+    close(d, z.grad, atol_scale=5e-7 * 4)
+    close(ops.linear_f32(a, w, None, ops.LIN_MUL, aux=x, tile=RT_TALL), F.linear(a, w) * x)
 
 
 @pytest.mark.parametrize("M,N,K", [(32, 40, 256), (32, 256, 40), (1024, 64, 12), (2400, 384, 100), (35072, 32, 60), (75, 96, 4), (1024, 16, 192)])

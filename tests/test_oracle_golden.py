@@ -221,6 +221,25 @@ def test_linear_oracle_is_a_product_and_its_order_is_what_it_says():
     assert O.linear_f32(a, w, ks=2, kc=1)[m, n] == total
 
 
+def test_weight_gradient_oracle_is_a_product_and_its_order_is_what_it_says():
+    """oracle.linear_wgrad (what upp_linear_wgrad_grouped_f32 is checked against bit for bit on the GPU): runs of `rows` rows, each entry
+    one ascending-row fmaf chain; the runs add up to the f64 product to f32 accuracy."""
+    rng = np.random.default_rng(5)
+    M, N, K, rows = 150, 12, 20, 64
+    g = rng.standard_normal((M, N)).astype(np.float32)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    part = O.linear_wgrad(g, x, rows)
+    assert part.shape == (3, N, K)
+    ref = g.astype(np.float64).T @ x.astype(np.float64)
+    np.testing.assert_allclose(part.astype(np.float64).sum(0), ref, rtol=0, atol=4e-6 * np.abs(ref).max())
+    import math
+    for s, n, k in ((0, 0, 0), (1, 5, 7), (2, 11, 19)):
+        acc = np.float32(0.0)
+        for m in range(s * rows, min(M, (s + 1) * rows)):
+            acc = np.float32(math.fma(float(g[m, n]), float(x[m, k]), float(acc))) if hasattr(math, "fma") else np.float32(np.float64(g[m, n]) * np.float64(x[m, k]) + np.float64(acc))
+        assert part[s, n, k] == acc
+
+
 def test_small_k_linear_oracle_is_the_plain_f32_product():
     import oracle as O
     rng = np.random.default_rng(3)

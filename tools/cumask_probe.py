@@ -12,9 +12,6 @@ import torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'iccv2025-upp_amd'); sys.path.insert(0, 'oracle')
 import bench
 from utils import synthetic as _seeded
-from upp_hip import gemm_tuning
-
-gemm_tuning.enable()
 dev = torch.device('cuda', 0)
 model = bench.build_model(dev).train()
 raw = _seeded.noisy_clouds(32, 1024, seed=0).to(dev)

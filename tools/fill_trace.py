@@ -8,8 +8,6 @@ from torch.profiler import profile, ProfilerActivity
 import bench
 kind = sys.argv[1] if len(sys.argv) > 1 else "pretrain"
 dev = torch.device("cuda", 0)
-from upp_hip import gemm_tuning
-gemm_tuning.enable()
 tr = bench.Trainer(dev, 32, False, use_graph=False) if kind == "cls" else bench.RecipeTrainer(kind, dev, 32, use_graph=False)
 for _ in range(3):
     tr.step()

@@ -21,8 +21,6 @@ def main():
     ap.add_argument("--top", type=int, default=45)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    from upp_hip import gemm_tuning
-    gemm_tuning.enable()
     tr = bench.Trainer(dev, 32, False, use_graph=False)
     for _ in range(3):
         tr.step()

@@ -6,9 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "iccv2025-upp_amd"), os.path.join(ROOT, "test
     sys.path.insert(0, p)
 import torch
 import bench
-from upp_hip import gemm_tuning
 dev = torch.device("cuda", 0)
-gemm_tuning.enable()
 for pipeline in (True, False):
     tr = bench.Trainer(dev, 32, False, use_graph=True, pipeline=pipeline)
     for _ in range(6):

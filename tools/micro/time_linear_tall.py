@@ -5,9 +5,10 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "iccv2025-upp_amd")]
 import torch
 import torch.nn.functional as F
 from bench import time_kernel
-from upp_hip import ops, gemm_tuning
-if "--tuned" in sys.argv:
-    gemm_tuning.enable()
+from upp_hip import ops
+if "--tuned" in sys.argv:            # the library side of the comparison with TunableOp-selected solutions (measurement only)
+    os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"; os.environ["PYTORCH_TUNABLEOP_TUNING"] = "1"; os.environ["PYTORCH_TUNABLEOP_VERBOSE"] = "0"
+    torch.cuda.tunable.enable(True)
 M = 65536
 for N, K in ((1024, 1536), (512, 1024), (256, 512), (52, 256), (512, 512), (384, 512), (256, 128)):
     a = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda') * K ** -0.5; g = torch.randn(M, N, device='cuda')

@@ -35,8 +35,6 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     if args.tuned:
-        from upp_hip import gemm_tuning
-        gemm_tuning.enable()
     lib = _abi.load()
     g = torch.Generator(device=dev).manual_seed(0)
     rows = []
