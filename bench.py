@@ -84,7 +84,7 @@ PRETASK_PEFT = ['rectify_adapter', 'downstream_adapter', 'pretask_adapter', 'rec
                 'predict_token_generator', 'mask_prompter', 'mask_token_generator']   # reference tools/runner_pretask.py:112-117
 STAGE2_PEFT = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'dense_pred', 'mask_token', 'rectify_prompter',
                'shape_pred', 'coarse_pred', 'predict_token_generator', 'mask_prompter', 'mask_token_generator']   # reference tools/runner_module.py:232-238
-SEG_PEFT = ['downstream_adapter', 'downstream_prompts', 'bnorm', 'label_conv', 'propagation_0', 'seg_head']
+SEG_PEFT = ['downstream_adapter', 'downstream_prompts', 'label_conv', 'propagation_0', 'seg_head', 'propagation_1']   # reference tools/runner_unify_seg.py:143-146
 
 
 class RecipeTrainer:

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     constexpr int STAGE = ROWS * 128;
     constexpr int T = ROWS / 8;                     // DMA wave-instructions per stage (8 rows each)
     constexpr int TPW = (T + NW - 1) / NW;
-    constexpr int RED = KS > 1 ? NW * 4096 : 0;
+    constexpr int RED = NW * 4096;                  // every wave's block, turned through the LDS on its way out
     constexpr int LDS_BYTES = 2 * STAGE > RED ? 2 * STAGE : RED;
     static_assert(LDS_BYTES <= 160 * 1024, "stages exceed the 160 KB of LDS");
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];     // (the only LDS object of the kernel)
@@ -188,9 +188,45 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
 #undef UPP_RD1
 
     UPP_STAMP(2)
-    // ---- K-split: partial tiles through the LDS, summed in wave-group order; group ks finishes registers [T0, T0 + TN)
+    // ---- tile -> memory.  Register t of a block = C[row][col]: col = lane & 31, row = (t & 3) + 8 (t >> 2) + 4 (lane >> 5): stored
+    // from the accumulators a block is 16 dword stores of 2 x 128 bytes; the store burst of 16 waves at the end of a launch was
+    // 3.5 us of the 30 us fc1 launch (round 2 stamps).  Every block goes through the LDS instead -- which the K-split shapes need
+    // anyway for their partial tiles -- as [wave][t][lane]: for a fixed row, 4 consecutive columns are 16 contiguous bytes, and a
+    // wave group's share of a block (registers [T0, T0 + TN): 2 TN rows) is one lane-linear ds_read_b128 sweep.  The KS partial
+    // tiles are summed in wave-group order from 0.0f on the way (deterministic; oracle_linear_f32), bias / activation / factor
+    // act on four columns per lane, and a wave stores 4 x fewer, 16-byte-per-lane instructions.
     constexpr int TN = 16 / KS;
     const int T0 = ks * TN;
+    const int rb = m0 + bm * 32, cb = n0 + bn * 32;                         // (scalar) block origin
+    const bool wide = ((g.ldc | N | g.ldaux) & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.aux)) & 15) == 0;
+    if (wide) {
+        __syncthreads();                                     // all fragment reads done: the stages may be overwritten
+        float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) red[(wave * 16 + t) * 64 + lane] = acc[t];
+        if (KS > 1) __syncthreads();
+        const int col = cb + 4 * (lane & 7);
+        const bool col_ok = col < N;
+        f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (g.epi != LEPI_NONE && g.epi != LEPI_MUL && col_ok) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
+#pragma unroll
+        for (int pass = 0; pass < TN / 4; ++pass) {
+            const int ridx = pass * 8 + (lane >> 3), t = T0 + (ridx >> 1);
+            const int row = rb + (t & 3) + 8 * (t >> 2) + 4 * (ridx & 1);
+            const float *src = red + (wb * 16 + T0) * 64 + (pass * 64 + lane) * 4;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(src);
+            if (KS > 1) {
+                const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                v = zero + v;
+#pragma unroll
+                for (int k2 = 1; k2 < KS; ++k2) v += *reinterpret_cast<const f32x4 *>(src + k2 * (BMB * BNB) * 1024);
+            }
+            epilogue_store4(g, g.epi, v, bias4, row, col, col_ok && row < M);
+        }
+        UPP_STAMP(3)
+        return;
+    }
+    // rows that are not 16-byte aligned (N = 3, 50, ...): dword stores from the accumulators
     float outv[TN];
     if (KS > 1) {
         __syncthreads();                                     // all fragment reads done: the stages may be overwritten
@@ -215,7 +251,6 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     // last MFMAs, and the first version (one runtime switch and 64-bit address arithmetic per element: ~1,000 instructions
     // per wave) took 3.8 us of the 31 us fc1 launch WITHOUT its stores.  Now: a wave-uniform block base (scalar), one 32-bit
     // lane offset, a switch outside the element loop, and per-element guards only on edge tiles.
-    const int rb = m0 + bm * 32, cb = n0 + bn * 32;                         // (scalar) block origin
     const bool full = rb + 32 <= M && cb + 32 <= N;                          // (scalar)
     const int ldc = (int)g.ldc, ldx = (int)g.ldaux;
     float *cblk = g.C + (long long)rb * g.ldc + cb;

@@ -209,29 +209,8 @@ __global__ __launch_bounds__(WM *WN * 64) void linear_rt_kernel(LinArgs g) {
             for (int i = 0; i < RN * 4; ++i) {
                 const int row = rb + i * (64 / PER) + prow;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(tt + (i * 64 + lane) * 4);
-                const bool ok = col_ok && row < M;
-                float *dst = g.C + (long long)row * g.ldc + col;
-                if (!FANCY || epi == LEPI_NONE || epi == LEPI_BIAS || epi == LEPI_BIAS_RELU) {
-                    v += bias4;
-                    if (epi == LEPI_BIAS_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-                    }
-                    if (ok) *reinterpret_cast<f32x4 *>(dst) = v;
-                } else if constexpr (FANCY) {
-                    float *xp = g.aux + (long long)row * g.ldaux + col;
-                    if (epi == LEPI_MUL) {
-                        if (ok) *reinterpret_cast<f32x4 *>(dst) = v * *reinterpret_cast<const f32x4 *>(xp);
-                    } else {
-                        f32x4 gv, dv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { float g1, d1; gelu_pair(v[e] + bias4[e], g1, d1); gv[e] = g1; dv[e] = d1; }
-                        if (ok) {
-                            *reinterpret_cast<f32x4 *>(dst) = gv;
-                            if (epi == LEPI_BIAS_GELU_D) *reinterpret_cast<f32x4 *>(xp) = dv;
-                        }
-                    }
-                }
+                if constexpr (FANCY) epilogue_store4(g, epi, v, bias4, row, col, col_ok && row < M);
+                else epilogue_store4(g, epi == LEPI_BIAS_RELU ? LEPI_BIAS_RELU : LEPI_BIAS, v, bias4, row, col, col_ok && row < M);
             }
         }
     } else {

@@ -58,3 +58,30 @@ __device__ __attribute__((aligned(16))) const float g_lin_zeros[4] = {0.0f, 0.0f
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+
+// Epilogue of four consecutive columns of one output row (a lane of the LDS-turned tile: 16-byte loads and stores): v = the
+// accumulated products, bias4 = the four biases (zeros when the epilogue has none).
+__device__ __forceinline__ void epilogue_store4(const LinArgs &g, int epi, f32x4 v, f32x4 bias4, int row, int col, bool ok) {
+    float *dst = g.C + (long long)row * g.ldc + col;
+    if (epi == LEPI_NONE || epi == LEPI_BIAS || epi == LEPI_BIAS_RELU) {
+        v += bias4;
+        if (epi == LEPI_BIAS_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        }
+        if (ok) *reinterpret_cast<f32x4 *>(dst) = v;
+    } else {
+        float *xp = g.aux + (long long)row * g.ldaux + col;
+        if (epi == LEPI_MUL) {
+            if (ok) *reinterpret_cast<f32x4 *>(dst) = v * *reinterpret_cast<const f32x4 *>(xp);
+        } else {
+            f32x4 gv, dv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float g1, d1; gelu_pair(v[e] + bias4[e], g1, d1); gv[e] = g1; dv[e] = d1; }
+            if (ok) {
+                *reinterpret_cast<f32x4 *>(dst) = gv;
+                if (epi == LEPI_BIAS_GELU_D) *reinterpret_cast<f32x4 *>(xp) = dv;
+            }
+        }
+    }
+}

@@ -171,7 +171,66 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float *__res
     if (wave == 0 && c < len) dst[(size_t)blockIdx.y * len + c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
+// Weighted column sums of ONE very tall matrix: dst[ch][w][c] = sum over the rows r of chunk ch of wts[r][w] * src[r][c], w < W <= 4 --
+// the weight gradient of a rank-W update  y += x (rows, W) . wt (W, C)  over the 65,536 label points of the segmentation head
+// (the xyz columns of the commuted first feature-propagation layer: reference models/Point_MAE_unify_segment.py:420,605 under
+// autograd) is x^T . g: W weighted column sums of g.  HBM-bound: every element of g is read once, 16 bytes per lane; grid =
+// (ceil(len / 256), chunks); lane -> 4 columns, the four waves take every fourth row and are combined in wave order.
+template <int W>
+__global__ __launch_bounds__(256) void wcolsum_partials_kernel(const float *__restrict__ src, long long ld, const float *__restrict__ wts,
+                                                               long long ldw, int n, int len, float *__restrict__ dst) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ f32x4 part[4][W][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x * 256 + 4 * lane, cc = min(c, len - 4);
+    const int chunks = gridDim.y, per = (n + chunks - 1) / chunks;
+    const int r0 = blockIdx.y * per, r1 = min(n, r0 + per);
+    f32x4 acc[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) acc[w] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i0 = r0 + wave; i0 < r1; i0 += 4 * 8) {
+        f32x4 v[8];
+        float x[8][W];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = min(i0 + 4 * q, r1 - 1);
+            v[q] = *reinterpret_cast<const f32x4 *>(src + (size_t)i * ld + cc);
+#pragma unroll
+            for (int w = 0; w < W; ++w) x[q][w] = wts[(size_t)i * ldw + w];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (i0 + 4 * q < r1) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) acc[w] += x[q][w] * v[q];
+            }
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) part[wave][w][lane] = acc[w];
+    __syncthreads();
+    if (wave == 0 && c < len) {
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+            *reinterpret_cast<f32x4 *>(dst + ((size_t)blockIdx.y * W + w) * len + c) = ((part[0][w][lane] + part[1][w][lane]) + part[2][w][lane]) + part[3][w][lane];
+    }
+}
+
 }  // namespace
+
+extern "C" int upp_wcolsum_partials(const float *src, long long ld, const float *wts, long long ldw, int W, int n, int len, int chunks,
+                                    float *dst, void *stream) {
+    if (!src || !wts || !dst || n < 1 || len < 1 || chunks < 1 || ld < len || W < 1 || ldw < W) return UPP_E_BADARG;
+    if (chunks > 65535 || W > 4 || len % 4 || ld % 4 || (reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return UPP_E_RANGE;
+    const dim3 grid((len + 255) / 256, chunks);
+    hipStream_t st = (hipStream_t)stream;
+    switch (W) {
+        case 1: hipLaunchKernelGGL(wcolsum_partials_kernel<1>, grid, dim3(256), 0, st, src, ld, wts, ldw, n, len, dst); break;
+        case 2: hipLaunchKernelGGL(wcolsum_partials_kernel<2>, grid, dim3(256), 0, st, src, ld, wts, ldw, n, len, dst); break;
+        case 3: hipLaunchKernelGGL(wcolsum_partials_kernel<3>, grid, dim3(256), 0, st, src, ld, wts, ldw, n, len, dst); break;
+        default: hipLaunchKernelGGL(wcolsum_partials_kernel<4>, grid, dim3(256), 0, st, src, ld, wts, ldw, n, len, dst); break;
+    }
+    return upp_launch_status();
+}
 
 extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, const int *ld,
                                const int *accumulate, int jobs, void *stream) {

@@ -824,7 +824,11 @@ class _InterpAffine(Function):
             g2, x2 = g.reshape(-1, g.shape[-1]), x3.reshape(-1, 3)
             if g2.shape[1] * 3 <= 2048 and g2.shape[1] + 3 <= 512:           # (3, C) = x3^T g over all points: the small-K weight-gradient kernel (transposed roles)
                 g_wt = ops.linear_smallk_wgrad(g2, x2).sum(0).t()
+            elif g2.shape[1] % 4 == 0 and g2.stride(0) % 4 == 0 and g2.data_ptr() % 16 == 0 and g2.is_cuda:
+                # wide rows (C = 1536 over 65,536 label points): three weighted column sums of g, read once
+                g_wt = ops.wcolsum_partials(g2, x2).sum(0)
             else:
+                note_declined("rank-3 weight gradient (3,%d)" % g2.shape[1], "row alignment")
                 g_wt = torch.mm(x2.t(), g2)
         return None, None, g_feat, None, g_wt, None, None
 

@@ -295,6 +295,23 @@ def colsum_partials(part, offset, length, chunks=None):
     return dst
 
 
+def wcolsum_partials(src, wts, chunks=None):
+    """(chunks, W, C) partials of wts (n,W)^T . src (n,C) for W <= 4 over very many rows (upp_wcolsum_partials); sum over dim 0 = the product."""
+    for t_, n_ in ((src, "src"), (wts, "wts")):
+        if not (isinstance(t_, torch.Tensor) and t_.is_cuda and t_.dtype == torch.float32 and t_.dim() == 2 and t_.stride(1) == 1):
+            raise RuntimeError(f"{n_} must be a 2-D f32 HIP (cuda) matrix with contiguous rows; upp_hip has no CPU path")
+    _same_device(src, wts)
+    n, C = src.shape
+    W = wts.shape[1]
+    if wts.shape[0] != n or W > 4 or C % 4:
+        raise RuntimeError(f"wcolsum_partials: wts {tuple(wts.shape)} against src {tuple(src.shape)} (W <= 4, C % 4 == 0)")
+    if chunks is None:
+        chunks = max(1, min(256, (n + 255) // 256))
+    dst = torch.empty((chunks, W, C), dtype=torch.float32, device=src.device)
+    _call(src.device, "upp_wcolsum_partials", _abi.ptr(src), src.stride(0), _abi.ptr(wts), wts.stride(0), W, n, C, chunks, _abi.ptr(dst))
+    return dst
+
+
 def linear_smallk(x, w, bias=None, act=0):
     """act(x (...,K) . w (N,K)^T + bias) for K <= 64, N <= 256, any alignment (upp_linear_smallk_f32); act 0 none / 1 ReLU / 2 GELU."""
     for t_, n_ in ((x, "x"), (w, "w")):

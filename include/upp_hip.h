@@ -365,6 +365,13 @@ int upp_batched_sum(const float *const *src, float *const *dst, const int *n, co
  * point rows of the patch embedding (reference models/Point_MAE_unify.py:191-222 under autograd) -- the second stage is
  * upp_batched_sum over the `chunks` rows. */
 int upp_colsum_partials(const float *src, long long ld, int n, int len, int chunks, float *dst, void *stream);
+/* upp_wcolsum_partials: dst (chunks, W, len)[ch][w][c] = sum over the rows r of chunk ch of wts[r][w] * src[r][c] (W <= 4; every fourth
+ * row per wavefront, wavefronts combined in order): the weight gradient x^T . g of a rank-W update y += x (rows, W) . wt (W, len) over
+ * very many rows -- the xyz columns of the first feature-propagation layer of the segmentation head over its 65,536 label points
+ * (reference models/Point_MAE_unify_segment.py:420,605 under autograd).  Second stage: sum over the chunks (upp_batched_sum).
+ * Limits: len % 4 == 0, ld % 4 == 0, src and dst 16-byte aligned. */
+int upp_wcolsum_partials(const float *src, long long ld, const float *wts, long long ldw, int W, int n, int len, int chunks,
+                         float *dst, void *stream);
 int upp_adamw_flat(float *p, float *g, float *m, float *v, long long n, long long split, float *state, float *scratch,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, void *stream);
 

@@ -15,6 +15,8 @@ Fixtures (all eval mode, key-seeded weights from tests/_seeded.py):
                    (tools/runner_pretask.py:220-225) and the gradient norm of every parameter
   upp_stage2.npz   the stage-2 ("joint optimisation", tools/runner_module.py:230-244) step: logits, loss, gradient norms of every
                    stage-2 trainable tensor and 14 full gradient arrays (prompter heads, mask token, rectify prompter)
+  upp_seg_train.npz  one TRAIN-mode step of the part-segmentation recipe (batch-statistics BatchNorm, dropout 0): log-probabilities, loss,
+                   gradient norms of all trainable tensors, 13 full gradient arrays, sampled rows / columns of the large head weights
   upp_modules.npz  per-module input/output pairs: Encoder, Attention, Block (downstream path
                    with prompt propagation incl. the index-stride behaviour), TransformerDecoder,
                    RectifyPrompter, propagate, Group index outputs
@@ -115,6 +117,45 @@ def gen_stage2(R, out_dir):
           "norms", {k: float(grads[k].norm()) for k in STAGE2_KEEP[:6]})
 
 
+SEG_PEFT = ['downstream_adapter', 'downstream_prompts', 'label_conv', 'propagation_0', 'seg_head', 'propagation_1']   # reference tools/runner_unify_seg.py:143-146
+SEG_KEEP = ['seg_head.7.weight', 'seg_head.7.bias', 'seg_head.5.weight', 'seg_head.1.bias', 'propagation_0.mlp_bns.0.weight', 'propagation_0.mlp_bns.1.bias',
+            'propagation_0.mlp_convs.1.bias', 'label_conv.0.weight', 'label_conv.3.weight', 'blocks.blocks.0.downstream_prompts',
+            'blocks.blocks.5.downstream_prompts', 'blocks.blocks.0.downstream_adapter.ln1.weight', 'blocks.blocks.11.downstream_adapter.ln2.weight']
+SEG_SAMPLED = ['seg_head.0.weight', 'seg_head.4.weight', 'propagation_0.mlp_convs.0.weight', 'propagation_0.mlp_convs.1.weight']   # every 16th row / column
+
+
+def seg_train_inputs():
+    spts = _seeded.noisy_clouds(2, 1552, seed=11)            # (2,1624,3): 1552 + 72 noise points
+    lpts = _seeded.unit_ball_clouds(2, 2048, seed=12)
+    onehot = torch.zeros(2, 16); onehot[0, 3] = 1; onehot[1, 11] = 1
+    tgt = torch.randint(0, 50, (2, 2048), generator=torch.Generator().manual_seed(13))
+    return spts, lpts, onehot, tgt
+
+
+def gen_seg_train(R, out_dir):
+    """upp_seg_train.npz: ONE training step of the part-segmentation recipe (reference tools/runner_unify_seg.py:143-152 parameter list,
+    :190-261 step; models/Point_MAE_unify_segment.py:475-625) on the reference's class in TRAIN mode -- BatchNorm layers on batch
+    statistics, every dropout / drop-path probability 0 -- : log-probabilities, NLL loss, the gradient norm of every trainable tensor,
+    13 full gradient arrays and every 16th row / column of the four large head weights."""
+    seg = R.MODELS.build(ref_shim.model_cfg('unify_shapenetpart_seg'))
+    deterministic_train_mode(_seeded.fill(seg))
+    for name, p in seg.named_parameters():
+        p.requires_grad_(any(k in name for k in SEG_PEFT))
+    spts, lpts, onehot, tgt = seg_train_inputs()
+    logp = seg(spts, onehot, label_points=lpts, completion_prompt=True, denoise=True, point_num=1536)
+    loss = seg.get_loss(logp.reshape(-1, 50), tgt.reshape(-1))
+    loss.backward()
+    grads = {n: p.grad for n, p in seg.named_parameters() if p.requires_grad and p.grad is not None}
+    names = sorted(grads)
+    keep = {"grad::" + k: grads[k].numpy() for k in SEG_KEEP}
+    keep.update({"sampled::" + k: grads[k].squeeze(-1)[::16, ::16].contiguous().numpy() for k in SEG_SAMPLED})
+    np.savez_compressed(os.path.join(out_dir, "upp_seg_train.npz"), logp_head=logp[:, :256].detach().numpy(),
+                        logp_sum=logp.detach().double().sum(-1).numpy(), loss=loss.detach().numpy(), grad_names=np.array(names),
+                        grad_norms=np.array([grads[n].norm().item() for n in names], dtype=np.float64), **keep)
+    print("seg train loss", loss.item(), "trainable tensors with a gradient", len(names), "of",
+          sum(1 for _, p in seg.named_parameters() if p.requires_grad), os.path.getsize(os.path.join(out_dir, "upp_seg_train.npz")) // 1024, "KiB")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -124,6 +165,9 @@ def main():
         return
     if sys.argv[1:] == ['stage2']:
         gen_stage2(R, os.path.join(ROOT, "tests", "golden"))
+        return
+    if sys.argv[1:] == ['seg_train']:
+        gen_seg_train(R, os.path.join(ROOT, "tests", "golden"))
         return
     cfg = ref_shim.model_cfg()
     model = R.MODELS.build(cfg)
@@ -237,6 +281,7 @@ def main():
     print("point_mae loss", mloss.item(), "params", sum(p_.numel() for p_ in mae.parameters()), "masked", int(used_mask[0].sum()))
     gen_pretask(R, out_dir)
     gen_stage2(R, out_dir)
+    gen_seg_train(R, out_dir)
     for f in ("upp_stage2.npz", "upp_model.npz", "upp_modules.npz", "upp_seg.npz", "point_mae.npz", "pretask.npz"):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
 

@@ -256,3 +256,17 @@ def test_feature_propagation_commuted_first_layer_equals_the_concat_formulation(
         ea, eb = (a - r).abs(), (b - r).abs()
         assert eb.max().item() <= 4.0 * ea.max().item() + 1e-5 * scale, (eb.max().item(), ea.max().item(), scale)
         assert eb.mean().item() <= 3.0 * ea.mean().item() + 1e-6 * scale, (eb.mean().item(), ea.mean().item(), scale)
+
+
+@pytest.mark.parametrize("n,C,W", [(65536, 1536, 3), (1000, 260, 3), (77, 8, 4), (5000, 512, 1)])
+def test_weighted_column_sums_are_the_skinny_product(n, C, W):
+    """upp_wcolsum_partials: x (n,W)^T . g (n,C) as W weighted column sums of g read once (the rank-3 xyz weight gradient of the
+    segmentation head's first propagation layer); a column window of a wider matrix is served in place."""
+    from upp_hip import ops
+    gen = torch.Generator(device='cuda').manual_seed(n + C)
+    wide = torch.randn(n, C + 8, device='cuda', generator=gen)
+    g = wide[:, 4:4 + C]
+    x = torch.randn(n, W, device='cuda', generator=gen)
+    part = ops.wcolsum_partials(g, x)
+    ref = x.double().t() @ g.double()
+    np.testing.assert_allclose(part.double().sum(0).cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=3e-6 * ref.abs().max().item())

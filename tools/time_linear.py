@@ -30,11 +30,13 @@ TILES = [0x4412, 0x4311, 0x3411, 0x2421, 0x2321, 0x2241, 0x1241, 0x2221]
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiles", action="store_true", help="time every wave-tile shape, not only the library's choice")
-    ap.add_argument("--tuned", action="store_true", help="library GEMM with the committed TunableOp selections")
+    ap.add_argument("--tuned", action="store_true", help="library GEMM with TunableOp-selected solutions")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "time_linear.json"))
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    if args.tuned:
+    if args.tuned:                      # the library side of the comparison with TunableOp-selected solutions (measurement only)
+        os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"; os.environ["PYTORCH_TUNABLEOP_TUNING"] = "1"
+        torch.cuda.tunable.enable(True)
     lib = _abi.load()
     g = torch.Generator(device=dev).manual_seed(0)
     rows = []
