@@ -338,9 +338,22 @@ class Encoder(nn.Module):
         if torch.is_grad_enabled() and w.requires_grad:
             return F.pad(w.squeeze(-1), (0, 29))
         key = (w.data_ptr(), w._version)
-        if getattr(self, '_w1p_key', None) != key and not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
+        buf = getattr(self, '_w1p', None)
+        if buf is None or buf.device != w.device or buf.dtype != w.dtype:
             self._w1p, self._w1p_key = F.pad(w.detach().squeeze(-1), (0, 29)).contiguous(), key
+        elif self._w1p_key != key and not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.refresh_padded_weight()
         return self._w1p
+
+    def refresh_padded_weight(self):
+        """Re-copy the frozen first-conv weight into its zero-padded K = 32 image IN PLACE: a captured step (and the W^T copy a
+        data-gradient GEMM keeps of it, functional.TRANSPOSED) holds the buffer's address, so after load_state_dict into an already
+        captured model the contents must change, never the storage.  functional.refresh_caches(model) calls this for every encoder."""
+        w = self.first_conv[0].weight
+        if getattr(self, '_w1p', None) is not None and self._w1p.device == w.device:
+            with torch.no_grad():
+                self._w1p[:, :w.shape[1]].copy_(w.detach().squeeze(-1))
+            self._w1p_key = (w.data_ptr(), w._version)
 
     def _forward_torch(self, point_groups):
         """The differentiable formulation (a gradient reaches the encoder: Point-MAE pre-training trains it, stage 2 of the UPP

@@ -419,6 +419,18 @@ class _TransposedWeights:
 TRANSPOSED = _TransposedWeights()
 
 
+def refresh_caches(model=None):
+    """Bring every derived copy of FROZEN weights up to date IN PLACE after weights were loaded into a model whose training step is
+    already captured in a HIP graph (load_state_dict changes contents, not addresses; the captured launches read the copies):
+    the zero-padded first-conv weight of every patch-embedding Encoder, then the W^T copies of the data-gradient GEMMs (which
+    include the transposes of those padded weights -- hence the order)."""
+    if model is not None:
+        for m in model.modules():
+            if hasattr(m, 'refresh_padded_weight'):
+                m.refresh_padded_weight()
+    TRANSPOSED.refresh()
+
+
 def _wt(w):
     """W^T (K,N) contiguous: cached for frozen weights, a fresh upp_transpose_f32 copy for trainable ones (they change every step)."""
     if w.requires_grad:

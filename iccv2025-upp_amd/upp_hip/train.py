@@ -90,6 +90,14 @@ class FlatAdamW:
             h[4] = float(weight_decay)
         self.hyper = tuple(h)
         self._push_hyper()
+        self._sync_groups()
+
+    def _sync_groups(self):
+        """Keep the torch.optim-style view in step with `hyper` (set_lr, load_state_dict): a later sync_param_groups() must not push
+        stale values -- e.g. the weight decay a checkpoint restored -- back to the device."""
+        if hasattr(self, '_groups'):
+            self._groups[0].update(lr=self.hyper[0], weight_decay=0.0)
+            self._groups[1].update(lr=self.hyper[0], weight_decay=self.hyper[4])
 
     @property
     def param_groups(self):
@@ -146,6 +154,7 @@ class FlatAdamW:
             raise RuntimeError("betas / eps differ from the captured optimizer step: build the TrainStep after loading the checkpoint")
         self.hyper = (g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'], groups[-1]['weight_decay'], self.hyper[5])
         self._push_hyper()                              # lr / weight decay reach captured graphs through the device buffer
+        self._sync_groups()
 
 
 class _TrainingState:

@@ -195,6 +195,19 @@ def test_flat_adamw_matches_torch_clip_and_adamw():
         for p, q in zip(nd + d, rnd + rd):
             close(p, q, rtol=2e-5, atol_scale=2e-6)
     assert opt.state[0].item() == 5
+    # the torch.optim-style view follows set_lr / load_state_dict: a scheduler's sync must not push stale values back to the device
+    groups = opt.param_groups
+    sd = opt.state_dict()
+    sd['param_groups'][-1]['weight_decay'] = 0.125
+    sd['param_groups'][0]['lr'] = sd['param_groups'][-1]['lr'] = 2.5e-4
+    opt.load_state_dict(sd)
+    assert groups[-1]['weight_decay'] == 0.125 and groups[0]['lr'] == 2.5e-4
+    for g_ in groups:
+        g_['lr'] = 1e-4                                   # what a scheduler does
+    opt.sync_param_groups()
+    assert abs(opt.state[5].item() - 1e-4) < 1e-10 and abs(opt.state[6].item() - 0.125) < 1e-7      # lr / weight decay on the device
+    opt.set_lr(3e-4)
+    assert groups[0]['lr'] == groups[1]['lr'] == 3e-4 and groups[1]['weight_decay'] == 0.125
 
 
 @pytest.mark.parametrize("R", [2400, 2080, 1120, 45])

@@ -114,6 +114,43 @@ def test_stage2_through_the_step_driver(golden):
     _stage2_check(grads, float(ts.loss), g)
 
 
+def test_weights_loaded_into_a_captured_stage2_step_reach_its_cached_copies(golden):
+    """load_state_dict into an already captured stage-2 step (the gradient runs through the patch embedding: the padded first-conv weight
+    and its W^T copy are read by captured launches) + functional.refresh_caches(model): the next replay equals an eager step of a
+    freshly built model with the new weights."""
+    from upp_hip import functional as HF
+    from upp_hip.train import TrainStep, freeze_for_peft
+    g = golden['upp_stage2']
+    x, y = _seeded.noisy_clouds(2, 1024, 0).cuda(), torch.from_numpy(g['labels']).cuda()
+    m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).eval().cuda()
+    freeze_for_peft(m, STAGE2_KEYS)
+    ts = TrainStep(m, (2, 1096, 3), lr=0.0, grad_clip=None)
+    ts.step(x, y)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(ts.loss), g['loss'], rtol=1e-4)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    for k in sd:
+        if k.startswith('encoder.first_conv.0.') or k.startswith('encoder.second_conv.3.') or 'blocks.blocks.3.attn.qkv.weight' in k:
+            sd[k] = sd[k] * 1.25
+    m.load_state_dict(sd)
+    HF.refresh_caches(m)
+    ts.step(x, y)
+    torch.cuda.synchronize()
+    fresh = build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model).eval().cuda()
+    fresh.load_state_dict(sd)
+    freeze_for_peft(fresh, STAGE2_KEYS)
+    loss, _ = fresh.get_loss_acc(fresh(x, completion_prompt=True, denoise=True, point_num=1024), y)
+    assert abs(float(ts.loss) - float(g['loss'])) > 1e-4 * abs(float(g['loss']))          # the new weights matter
+    np.testing.assert_allclose(float(ts.loss), loss.item(), rtol=2e-5)
+    loss.backward()
+    names = {id(p): n for n, p in m.named_parameters()}
+    ref = dict(fresh.named_parameters())
+    for p, v in zip(ts.trainable, ts.flat.views):
+        r = ref[names[id(p)]].grad
+        if r is not None and r.abs().max() > 0:
+            np.testing.assert_allclose(v.cpu().numpy(), r.cpu().numpy(), rtol=2e-3, atol=2e-3 * r.abs().max().item(), err_msg=names[id(p)])
+
+
 def test_auxiliary_reconstruction_losses_on_the_completion_prompters_points(model):
     """bench.py --workload cls_aux: Chamfer-L1 + EMD on the rebuilt points of the completion prompter, forward and
     backward (gradient w.r.t. rebuild_points), next to the classification forward."""

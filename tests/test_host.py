@@ -111,6 +111,32 @@ def test_transposed_weight_cache_tracks_versions_views_and_refresh():
     assert torch.equal(c.get(w), torch.ones(4, 3))
 
 
+def test_padded_first_conv_weight_is_refreshed_in_place():
+    """Encoder._w1_k32: the zero-padded K = 32 image of the frozen Conv1d(3,128) weight keeps its storage when the weight changes (a
+    captured step and the W^T copy of the data-gradient GEMM hold its address); functional.refresh_caches(model) re-copies it and then
+    the transposes, in that order, even when nobody noticed the change."""
+    from models.upp_layers import Encoder
+    from upp_hip import functional as HF
+    enc = Encoder(384)
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    w = enc.first_conv[0].weight
+    first = enc._w1_k32()
+    ptr = first.data_ptr()
+    assert first.shape == (128, 32) and torch.equal(first[:, :3], w.squeeze(-1)) and float(first[:, 3:].abs().sum()) == 0.0
+    wt = HF.TRANSPOSED.get(first)
+    with torch.no_grad():
+        w.mul_(2.0)                                        # load_state_dict: same storage, new contents
+    again = enc._w1_k32()
+    assert again.data_ptr() == ptr and torch.equal(again[:, :3], w.squeeze(-1))
+    with torch.no_grad():
+        w.add_(1.0)
+    enc._w1p_key = (w.data_ptr(), w._version)              # pretend nobody noticed (the captured-step case)
+    HF.refresh_caches(enc)
+    assert enc._w1p.data_ptr() == ptr and torch.equal(enc._w1p[:, :3], w.squeeze(-1))
+    assert HF.TRANSPOSED.get(enc._w1p) is wt and torch.equal(wt, enc._w1p.t())
+
+
 def test_declined_fused_paths_are_reported_once(monkeypatch, capsys):
     from upp_hip import functional as HF
     monkeypatch.setenv("UPP_VERBOSE", "1")

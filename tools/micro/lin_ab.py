@@ -27,7 +27,7 @@ def main():
         argv, picks = argv[:i], argv[i + 1:]
     so = "/tmp/liblin_ab_%s.so" % ("_".join(argv) or "base")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-shared"]
-                          + ["-D" + a for a in argv] + [SRC, os.path.join(os.path.dirname(SRC), "abi.hip"), "-o", so])
+                          + ["-D" + a for a in argv] + [SRC, os.path.join(os.path.dirname(SRC), "linear_rt.hip"), os.path.join(os.path.dirname(SRC), "abi.hip"), "-o", so])
     lib = ctypes.CDLL(so)
     vp, ll, ci = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int
     lib.upp_linear_f32.argtypes = [vp, ll, vp, ll, vp, vp, ll, vp, ll, ci, ci, ci, ci, ci, vp]

@@ -17,7 +17,7 @@ SO = "/tmp/liblin_stamps.so"
 def main():
     extra = ["-D" + a for a in sys.argv[1:]]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-shared",
-                           "-DUPP_LIN_STAMPS"] + extra + [SRC, os.path.join(os.path.dirname(SRC), "abi.hip"), "-o", SO])
+                           "-DUPP_LIN_STAMPS"] + extra + [SRC, os.path.join(os.path.dirname(SRC), "linear_rt.hip"), os.path.join(os.path.dirname(SRC), "abi.hip"), "-o", SO])
     lib = ctypes.CDLL(SO)
     vp, ll, ci = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int
     lib.upp_linear_f32.argtypes = [vp, ll, vp, ll, vp, vp, ll, vp, ll, ci, ci, ci, ci, ci, vp]
@@ -31,7 +31,7 @@ def main():
         a = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) * 0.05
         c = torch.empty(M, N, device=dev)
-        for _ in range(30):        # back-to-back launches: the last one is read
+        for _ in range(int(os.environ.get('LAUNCHES', '30'))):        # back-to-back launches: the last one is read
             rc = lib.upp_linear_f32(a.data_ptr(), K, w.data_ptr(), K, None, c.data_ptr(), N, None, 0, M, N, K, 0, tile, None)
             assert rc == 0, rc
         torch.cuda.synchronize()
