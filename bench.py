@@ -611,14 +611,22 @@ def main():
             "config": {"workload": tr.workload, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph,
                        "pipeline": "front-end(k+1) || back-end(k) on two streams" if pipeline else "none"}}))
-    elif rank == 0:
+    rccl_ranks = 0
+    if distributed and backend == "nccl" and args.workload == "cls":
+        # "rccl_ranks": only after RCCL has summed a buffer of the gradient all-reduce's size across the ranks and every rank saw the sum
+        probe = torch.ones(tr.ts.flat.flat.numel(), device=device)
+        dist.all_reduce(probe)
+        ok = torch.tensor([float(bool((probe == world).all()))], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        rccl_ranks = world if ok.item() == 1.0 else 0
+    if rank == 0 and args.workload == "cls":
         clouds = args.batch * world * args.steps
         line = {
             "metric": "point-clouds/sec fwd+bwd, UPP/Point-MAE N=1024 G=64 k=32",
             "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "rccl_ranks": world if backend == "nccl" else 0, "dist_backend": backend,
+            "rccl_ranks": rccl_ranks, "dist_backend": backend,
             "config": {"workload": "Point_MAE_unify unify_modelnet_cls noisy-train fwd+bwd+AdamW, PEFT stage-1, "
                                    "B=%d/GPU x (1024+72) pts, G=64 k=32" % args.batch,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,

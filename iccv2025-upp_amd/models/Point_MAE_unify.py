@@ -102,12 +102,7 @@ class PromptedBackbone(nn.Module):
         pos = L.mlp2(self.pos_embed, vis_center)
         tokens = self.blocks(tokens, pos, path='rectify', rectify_adapter=True, rectify_prompts=True,
                              rectify_depth=self.config.prompter_config['rectify_depth'])
-        pred_vector = self.rectify_prompter(pts, vis_center, tokens, require_shape_feature=False)
-        score = torch.norm(pred_vector, p=2, dim=-1)
-        order = torch.argsort(score, dim=1, descending=True)
-        pts = pts + pred_vector * 0.2
-        keep = order[:, -int(point_num * 0.95):, None].expand(-1, -1, 3)
-        return torch.gather(pts, 1, keep)
+        return self.rectify_prompter.select(pts, vis_center, tokens, int(point_num * 0.95), nudge=0.2)
 
     def _complete(self, pts, point_num):
         """Completion prompter (reference :572-610): predict 32 missing centres and 32x32 points
@@ -269,6 +264,16 @@ class Point_MAE_unify(PromptedBackbone):
     def _cls_head(self, feat):
         """cls_head_finetune; on the HIP path every [BatchNorm1d, ReLU, Dropout] run after a Linear is one launch each way."""
         layers = list(self.cls_head_finetune)
+        if L.sync_bn_active(self.training):               # (--sync_bn: batch statistics over all ranks, the tail unfused)
+            x = feat
+            for layer in self.cls_head_finetune:
+                if isinstance(layer, nn.BatchNorm1d):
+                    if self.training and layer.track_running_stats:
+                        L.bump_counter(layer.num_batches_tracked)
+                    x = L._bn_rows(x, layer, self.training)
+                else:
+                    x = HF.linear(x, layer.weight, layer.bias, own_wgrad=True) if isinstance(layer, nn.Linear) and x.is_cuda else layer(x)
+            return x
         if not (feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 2):
             return self.cls_head_finetune(feat)
         x, i = feat, 0

@@ -203,6 +203,8 @@ def pooling(x, transform):
     nowhere in the reference; this is the Point-PEFT form the README credits:
     max + mean over the neighbourhood, then the block's BatchNorm1d over channels.  ASSUMPTION."""
     lc = x.max(dim=2)[0] + x.mean(dim=2)
+    if isinstance(transform, nn.BatchNorm1d) and sync_bn_active(transform.training):
+        return _bn_rows(lc.reshape(-1, lc.shape[-1]), transform, transform.training).view(lc.shape)
     return transform(lc.permute(0, 2, 1)).permute(0, 2, 1)
 
 
@@ -263,9 +265,71 @@ def _no_grad_needed(*tensors):
     return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
 
 
+# ---- optional synchronised BatchNorm (reference tools/runner_module.py:50-52, tools/runner_unify_seg.py:129-131: `--sync_bn` converts every
+# BatchNorm to torch.nn.SyncBatchNorm before the DDP wrap).  Off by default, as in the reference's recipes.  With the switch on and
+# torch.distributed initialised, every training-mode BatchNorm of the model takes its statistics over the rows of ALL ranks: the per-rank
+# (count, sum, sum of squares) of a layer travel in one all-reduce, the backward's two column sums in another; the fused kernels that
+# compute batch statistics on the device (patch-embedding chain, prompt propagation, classification-head tail) decline while it is on.
+SYNC_BN = False
+
+
+def enable_sync_bn(on=True):
+    global SYNC_BN
+    SYNC_BN = bool(on)
+
+
+def sync_bn_active(training=True):
+    import torch.distributed as dist
+    return SYNC_BN and training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _SyncBNRows(torch.autograd.Function):
+    """y = (x - mean) * rstd * gamma + beta over the rows of every rank (biased variance for the output, unbiased for running_var: nn.BatchNorm)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        import torch.distributed as dist
+        C = x.shape[1]
+        xd = x.double()
+        stats = torch.cat([xd.sum(0), (xd * xd).sum(0), torch.full((1,), float(x.shape[0]), dtype=torch.float64, device=x.device)])
+        dist.all_reduce(stats)
+        n = stats[2 * C].item()
+        mean = stats[:C] / n
+        var = (stats[C:2 * C] / n - mean * mean).clamp_min(0.0)
+        rstd = (var + eps).rsqrt()
+        if running_mean is not None and momentum is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                running_var.mul_(1 - momentum).add_((var * (n / max(n - 1.0, 1.0))).to(running_var.dtype), alpha=momentum)
+        xhat = ((xd - mean) * rstd).to(x.dtype)
+        ctx.save_for_backward(xhat, weight, rstd.to(x.dtype))
+        ctx.n = n
+        y = xhat if weight is None else xhat * weight
+        return y if bias is None else y + bias
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        xhat, weight, rstd = ctx.saved_tensors
+        C = g.shape[1]
+        gd = g.double()
+        sums = torch.cat([gd.sum(0), (gd * xhat.double()).sum(0)])
+        local = sums.clone()
+        dist.all_reduce(sums)
+        mg, mgx = (sums[:C] / ctx.n).to(g.dtype), (sums[C:] / ctx.n).to(g.dtype)
+        scale = rstd if weight is None else rstd * weight
+        gx = (g - mg - xhat * mgx) * scale if ctx.needs_input_grad[0] else None
+        gw = local[C:].to(g.dtype) if weight is not None and ctx.needs_input_grad[1] else None      # (rank-local: the gradient all-reduce sums the ranks)
+        gb = local[:C].to(g.dtype) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None, None, None, None
+
+
 def _bn_rows(x, bn, training, relu=False):
     """BatchNorm1d of a channels-last (rows, C) matrix: identical statistics to BatchNorm1d on
     the reference's (BG, C, n) layout (both reduce over every position of every group)."""
+    if x.dim() == 2 and sync_bn_active(training or bn.running_mean is None):
+        y = _SyncBNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        return F.relu(y) if relu else y
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
         if _no_grad_needed(x, bn.weight, bn.bias):
             return HF.bn_rows(x, bn, training, relu)   # 3 launches instead of torch's 5-6 (frozen prompter branches)
@@ -312,7 +376,7 @@ class Encoder(nn.Module):
     def _fusable(self, x):
         """The gfx950 kernel chain is forward-only: usable whenever no gradient has to flow through the
         encoder (it is frozen in every UPP recipe), for the reference's layer sizes and group sizes."""
-        if not x.is_cuda or x.dtype != torch.float32 or x.shape[2] not in (16, 32):
+        if not x.is_cuda or x.dtype != torch.float32 or x.shape[2] not in (16, 32) or sync_bn_active(self.training):
             return False
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
@@ -547,7 +611,7 @@ class Block(nn.Module):
         bn = self.bnorm
         if self.training and bn.track_running_stats:
             bump_counter(bn.num_batches_tracked)
-        if bn.affine and (bn.track_running_stats or self.training) and B * Lp <= 15360:
+        if bn.affine and (bn.track_running_stats or self.training) and B * Lp <= 15360 and not sync_bn_active(self.training):
             return HF.propagate(x, bn, entry, u, keep, self.training)
         pooled = HF.prop_pool(x, entry.i1, u, keep)
         lc = _bn_rows(pooled, bn, self.training).view(B, G2, D)
@@ -866,6 +930,32 @@ class RectifyPrompter(nn.Module):
                 nn.init.constant_(layer.bias, val=0.0)
 
     def forward(self, x, center1, center1_feature, require_shape_feature=False):
+        feature, shape_feature = self.features(x, center1, center1_feature)
+        l0, _, drop, l1 = self.score_head                                  # Linear(32, 64), ReLU, Dropout(0.2), Linear(64, 3): both on our kernels
+        noise_score = HF.linear(drop(HF.linear(feature, l0.weight, l0.bias, act='relu')), l1.weight, l1.bias) * self.score_factor
+        return (noise_score, shape_feature) if require_shape_feature else noise_score
+
+    def select(self, x, center1, center1_feature, keep, nudge=0.2):
+        """The model's use of the prompter in one call (reference models/Point_MAE_unify.py:553-559): score every point, move the cloud by
+        nudge * predicted offset, return the `keep` least suspicious points in descending-score order.  Two launches behind the
+        per-point feature when no gradient is asked for (upp_rectify_select); the reference formulation otherwise."""
+        feature, _ = self.features(x, center1, center1_feature)
+        l0, _, drop, l1 = self.score_head
+        if (feature.is_cuda and feature.dtype == torch.float32 and x.shape[1] <= 16384 and tuple(l0.weight.shape) == (64, 32)
+                and tuple(l1.weight.shape) == (3, 64) and l0.bias is not None and l1.bias is not None
+                and _no_grad_needed(feature, x, l0.weight, l0.bias, l1.weight, l1.bias)):
+            from upp_hip import ops
+            live = self.training and drop.p > 0
+            u = UNIFORMS.take((x.shape[0] * x.shape[1], 64), x.device) if live else None
+            return ops.rectify_select(feature.contiguous(), l0.weight, l0.bias, l1.weight, l1.bias, x.contiguous(), keep, u,
+                                      drop.p if live else 0.0, self.score_factor, nudge)
+        pred = HF.linear(drop(HF.linear(feature, l0.weight, l0.bias, act='relu')), l1.weight, l1.bias) * self.score_factor
+        order = torch.argsort(torch.norm(pred, p=2, dim=-1), dim=1, descending=True)
+        moved = x + pred * nudge
+        return torch.gather(moved, 1, order[:, -keep:, None].expand(-1, -1, 3))
+
+    def features(self, x, center1, center1_feature):
+        """-> (per-point feature (B,N,32) in front of the score head, shape feature (B, num_group * top_center_dim))."""
         B = center1_feature.shape[0]
         center2, center2_feature = self.abstraction(center1, center1_feature)
         shape_feature = center2_feature.reshape(B, -1)
@@ -880,6 +970,4 @@ class RectifyPrompter(nn.Module):
             feature = self.propagation1(x, center1, None, center1_feature, cat_buffer=buf)
         else:
             feature = self.propagation1(x, center1, pe(x), center1_feature)
-        l0, _, drop, l1 = self.score_head                                  # Linear(32, 64), ReLU, Dropout(0.2), Linear(64, 3): both on our kernels
-        noise_score = HF.linear(drop(HF.linear(feature, l0.weight, l0.bias, act='relu')), l1.weight, l1.bias) * self.score_factor
-        return (noise_score, shape_feature) if require_shape_feature else noise_score
+        return feature, shape_feature

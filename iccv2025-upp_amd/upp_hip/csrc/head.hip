@@ -269,6 +269,79 @@ __global__ __launch_bounds__(64 * kBW) void bn_relu_drop_bwd_kernel(const float 
         }
 }
 
+// ---- the tail of the denoising ("rectify") prompter -----------------------------------------------------------------------------
+// reference models/Point_MAE_pretask_dev.py:491-512 (RectifyPrompter.score_head: Linear(32, 64) -> ReLU -> Dropout(0.2) -> Linear(64, 3))
+// and models/Point_MAE_unify.py:553-559: score = ||pred||_2, order = argsort(score, descending), pts += 0.2 pred, keep the last
+// int(0.95 point_num) entries of the order.  Two launches instead of two library GEMMs, ReLU, dropout, scale, norm, a radix sort,
+// add and gather:
+//   rectify_score_kernel : one thread per point -- the 32 -> 64 -> 3 head from the LDS copies of its weights, the nudged point and
+//                          its score.  hidden = relu(W0 f + b0) * keep/(1-p) is an ascending-k fmaf chain per output (as
+//                          upp_linear_smallk_f32), pred = W1 hidden + b1 likewise.
+//   rectify_select_kernel: one workgroup per (cloud, 256 points) -- the cloud's scores in the LDS, rank of a point = how many
+//                          points precede it in the stable descending order (greater score, or equal score and lower index: what
+//                          torch's stable radix sort returns); the points ranked >= N - keep are written at rank - (N - keep).
+constexpr int kRsIn = 32, kRsHid = 64;
+
+__global__ __launch_bounds__(256) void rectify_score_kernel(const float *__restrict__ feat, const float *__restrict__ W0, const float *__restrict__ b0,
+                                                            const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ u,
+                                                            float p, float factor, const float *__restrict__ pts, float nudge, int rows,
+                                                            float *__restrict__ pred, float *__restrict__ moved, float *__restrict__ score) {
+    __shared__ float w0[kRsHid][kRsIn + 1], w1[3][kRsHid], bb0[kRsHid];
+    for (int i = threadIdx.x; i < kRsHid * kRsIn; i += 256) w0[i / kRsIn][i % kRsIn] = W0[i];
+    for (int i = threadIdx.x; i < 3 * kRsHid; i += 256) w1[i / kRsHid][i % kRsHid] = W1[i];
+    if (threadIdx.x < kRsHid) bb0[threadIdx.x] = b0[threadIdx.x];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float f[kRsIn];
+    const float4 *fp = reinterpret_cast<const float4 *>(feat + (size_t)row * kRsIn);
+#pragma unroll
+    for (int q = 0; q < kRsIn / 4; ++q) { const float4 v = fp[q]; f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
+    const float keep_scale = 1.0f / (1.0f - p);
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+    for (int hh = 0; hh < kRsHid; ++hh) {
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kRsIn; ++k) a = __builtin_fmaf(f[k], w0[hh][k], a);
+        a = fmaxf(a + bb0[hh], 0.0f);
+        if (u) a = u[(size_t)row * kRsHid + hh] >= p ? a * keep_scale : 0.0f;
+        o0 = __builtin_fmaf(a, w1[0][hh], o0); o1 = __builtin_fmaf(a, w1[1][hh], o1); o2 = __builtin_fmaf(a, w1[2][hh], o2);
+    }
+    o0 = (o0 + b1[0]) * factor; o1 = (o1 + b1[1]) * factor; o2 = (o2 + b1[2]) * factor;
+    if (pred) { pred[(size_t)row * 3] = o0; pred[(size_t)row * 3 + 1] = o1; pred[(size_t)row * 3 + 2] = o2; }
+    moved[(size_t)row * 3] = pts[(size_t)row * 3] + o0 * nudge;
+    moved[(size_t)row * 3 + 1] = pts[(size_t)row * 3 + 1] + o1 * nudge;
+    moved[(size_t)row * 3 + 2] = pts[(size_t)row * 3 + 2] + o2 * nudge;
+    score[row] = sqrtf(o0 * o0 + o1 * o1 + o2 * o2);
+}
+
+__global__ __launch_bounds__(256) void rectify_select_kernel(const float *__restrict__ score, const float *__restrict__ moved, int N, int keep,
+                                                             float *__restrict__ out, int64_t *__restrict__ order) {
+    extern __shared__ float sc[];
+    const int b = blockIdx.y;
+    const float *s = score + (size_t)b * N;
+    for (int i = threadIdx.x; i < N; i += 256) sc[i] = s[i];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float mine = sc[i];
+    int rank = 0;
+    int j = 0;
+    for (; j + 4 <= N; j += 4) {                          // (every lane reads the same address: LDS broadcast)
+        const float4 v = *reinterpret_cast<const float4 *>(sc + j);
+        rank += (v.x > mine || (v.x == mine && j < i)) + (v.y > mine || (v.y == mine && j + 1 < i)) + (v.z > mine || (v.z == mine && j + 2 < i)) +
+                (v.w > mine || (v.w == mine && j + 3 < i));
+    }
+    for (; j < N; ++j) rank += sc[j] > mine || (sc[j] == mine && j < i);
+    if (order) order[(size_t)b * N + rank] = i;
+    const int slot = rank - (N - keep);
+    if (slot >= 0) {
+        const float *q = moved + ((size_t)b * N + i) * 3;
+        float *o = out + ((size_t)b * keep + slot) * 3;
+        o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+    }
+}
+
 }  // namespace
 
 extern "C" int upp_bn_relu_drop_fwd(const float *z, const float *gamma, const float *beta, float *running_mean, float *running_var,
@@ -312,5 +385,19 @@ extern "C" int upp_ce_acc(const float *logits, const int64_t *labels, float *out
     if (C > 64 * kMaxE) return UPP_E_RANGE;
     int waves = B < 16 ? B : 16;
     hipLaunchKernelGGL(ce_acc_kernel, dim3(1), dim3(64 * waves), 0, (hipStream_t)stream, logits, labels, out2, dlogits, B, C);
+    return upp_launch_status();
+}
+
+extern "C" int upp_rectify_select(const float *feature, const float *W0, const float *b0, const float *W1, const float *b1, const float *u, float p,
+                                  float factor, const float *pts, float nudge, int B, int N, int keep, float *pred, float *moved, float *score,
+                                  float *out, int64_t *order, void *stream) {
+    if (!feature || !W0 || !b0 || !W1 || !b1 || !pts || !moved || !score || !out || B < 1 || N < 1 || keep < 1) return UPP_E_BADARG;
+    if (keep > N || N > 16384 || p < 0.0f || p >= 1.0f || (reinterpret_cast<uintptr_t>(feature) & 15)) return UPP_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = B * N;
+    hipLaunchKernelGGL(rectify_score_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, feature, W0, b0, W1, b1, u, p, factor, pts, nudge, rows, pred,
+                       moved, score);
+    hipLaunchKernelGGL(rectify_select_kernel, dim3((N + 255) / 256, B), dim3(256), (size_t)((N + 3) / 4 * 4) * sizeof(float), st, score, moved, N, keep,
+                       out, order);
     return upp_launch_status();
 }

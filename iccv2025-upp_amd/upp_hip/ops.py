@@ -295,6 +295,31 @@ def colsum_partials(part, offset, length, chunks=None):
     return dst
 
 
+def rectify_select(feature, w0, b0, w1, b1, pts, keep, u=None, p=0.0, factor=1.0, nudge=0.2, want_pred=False, want_order=False, want_score=False):
+    """Tail of the denoising prompter in two launches (upp_rectify_select): pred = score head(feature) * factor, moved = pts + nudge * pred,
+    the `keep` least suspicious points of every cloud in descending-score order.  -> out (B,keep,3) [, pred (B,N,3)] [, order (B,N) int64] [, score (B,N)]."""
+    _need(pts, "pts", torch.float32, 3, 3)
+    B, N, _ = pts.shape
+    for t, n_, shp in ((feature, "feature", (B, N, 32)), (w0, "w0", (64, 32)), (b0, "b0", (64,)), (w1, "w1", (3, 64)), (b1, "b1", (3,))):
+        _need(t, n_, torch.float32)
+        if tuple(t.shape) != shp:
+            raise RuntimeError(f"rectify_select: {n_} must be {shp}, got {tuple(t.shape)}")
+    if u is not None:
+        _need(u, "u", torch.float32)
+        if u.numel() != B * N * 64:
+            raise RuntimeError("rectify_select: u must hold B*N*64 uniforms")
+    dev = pts.device
+    moved = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    score = torch.empty((B, N), dtype=torch.float32, device=dev)
+    out = torch.empty((B, int(keep), 3), dtype=torch.float32, device=dev)
+    pred = torch.empty((B, N, 3), dtype=torch.float32, device=dev) if want_pred else None
+    order = torch.empty((B, N), dtype=torch.int64, device=dev) if want_order else None
+    _call(dev, "upp_rectify_select", _abi.ptr(feature), _abi.ptr(w0), _abi.ptr(b0), _abi.ptr(w1), _abi.ptr(b1), _abi.ptr(u), float(p), float(factor),
+          _abi.ptr(pts), float(nudge), B, N, int(keep), _abi.ptr(pred), _abi.ptr(moved), _abi.ptr(score), _abi.ptr(out), _abi.ptr(order))
+    res = (out,) + ((pred,) if want_pred else ()) + ((order,) if want_order else ()) + ((score,) if want_score else ())
+    return res if len(res) > 1 else out
+
+
 def wcolsum_partials(src, wts, chunks=None):
     """(chunks, W, C) partials of wts (n,W)^T . src (n,C) for W <= 4 over very many rows (upp_wcolsum_partials); sum over dim 0 = the product."""
     for t_, n_ in ((src, "src"), (wts, "wts")):
@@ -770,6 +795,23 @@ def batched_sum(jobs):
     ld = (ctypes.c_int * k)(*[j[4] for j in jobs])
     acc = (ctypes.c_int * k)(*[int(bool(j[6])) for j in jobs])
     _call(jobs[0][0].device, "upp_batched_sum", src, dst, n, ln, ld, acc, k)
+
+
+def copy_batched(dsts, srcs):
+    """dst_j.copy_(src_j) for contiguous same-shape / same-dtype HIP tensors, every pair in one launch (upp_copy_batched)."""
+    if not dsts:
+        return
+    import ctypes
+    k = len(dsts)
+    if len(srcs) != k:
+        raise RuntimeError("copy_batched: as many sources as destinations")
+    for d, s_ in zip(dsts, srcs):
+        if not (d.is_cuda and s_.is_cuda and d.dtype == s_.dtype and d.shape == s_.shape and d.is_contiguous() and s_.is_contiguous()):
+            raise RuntimeError("copy_batched: contiguous HIP (cuda) tensors of equal shape and dtype are required")
+    S = (ctypes.c_void_p * k)(*[t.data_ptr() for t in srcs])
+    D = (ctypes.c_void_p * k)(*[t.data_ptr() for t in dsts])
+    n = (ctypes.c_longlong * k)(*[t.numel() * t.element_size() for t in dsts])
+    _call(dsts[0].device, "upp_copy_batched", S, D, n, k)
 
 
 def transpose_batched(pairs):

@@ -6,13 +6,13 @@ import inspect
 def build_from_cfg(cfg, registry, default_args=None):
     """cfg['NAME'] selects the class; it is constructed as cls(cfg)."""
     if not isinstance(cfg, dict):
-        raise TypeError(f'cfg must be a dict, but got {type(cfg)}')
+        raise TypeError(f'a model config is a dict (EasyDict), not {type(cfg).__name__}')
     if 'NAME' not in cfg and (default_args is None or 'NAME' not in default_args):
-        raise KeyError(f'`cfg` or `default_args` must contain the key "NAME", but got {cfg}\n{default_args}')
+        raise KeyError(f'no "NAME" entry names the class to build: cfg = {cfg}, default_args = {default_args}')
     if not isinstance(registry, Registry):
-        raise TypeError(f'registry must be a Registry object, but got {type(registry)}')
+        raise TypeError(f'build_from_cfg looks classes up in a Registry, not in a {type(registry).__name__}')
     if not (isinstance(default_args, dict) or default_args is None):
-        raise TypeError(f'default_args must be a dict or None, but got {type(default_args)}')
+        raise TypeError(f'default_args: a dict of extra config entries or None, not {type(default_args).__name__}')
     if default_args is not None:
         for k, v in default_args.items():
             cfg[k] = v
@@ -20,11 +20,11 @@ def build_from_cfg(cfg, registry, default_args=None):
     if isinstance(obj_type, str):
         obj_cls = registry.get(obj_type)
         if obj_cls is None:
-            raise KeyError(f'{obj_type} is not in the {registry.name} registry')
+            raise KeyError(f'the {registry.name} registry holds no class called {obj_type}')
     elif inspect.isclass(obj_type):
         obj_cls = obj_type
     else:
-        raise TypeError(f'type must be a str or valid type, but got {type(obj_type)}')
+        raise TypeError(f'"NAME" is a registered name or a class, not {type(obj_type).__name__}')
     try:
         return obj_cls(cfg)
     except Exception as e:  # the plain exception does not name the class
@@ -64,18 +64,18 @@ class Registry:
 
     def _register_module(self, module_class, module_name=None, force=False):
         if not inspect.isclass(module_class):
-            raise TypeError(f'module must be a class, but got {type(module_class)}')
+            raise TypeError(f'only classes can be registered, not {type(module_class).__name__}')
         names = [module_name or module_class.__name__] if not isinstance(module_name, (list, tuple)) else module_name
         for name in names:
             if not force and name in self._module_dict:
-                raise KeyError(f'{name} is already registered in {self.name}')
+                raise KeyError(f'the {self.name} registry already has a class called {name} (force=True replaces it)')
             self._module_dict[name] = module_class
 
     def register_module(self, name=None, force=False, module=None):
         if not isinstance(force, bool):
-            raise TypeError(f'force must be a boolean, but got {type(force)}')
+            raise TypeError(f'force is True or False, not {type(force).__name__}')
         if not (name is None or isinstance(name, str) or (isinstance(name, (list, tuple)) and all(isinstance(n, str) for n in name))):
-            raise TypeError(f'name must be None, a str or a sequence of str, but got {type(name)}')
+            raise TypeError(f'name: None (the class name), one string or several, not {type(name).__name__}')
         if module is not None:
             self._register_module(module, name, force)
             return module

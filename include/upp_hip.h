@@ -360,6 +360,9 @@ long long upp_adamw_scratch_floats(void);
  * prompt gradients), summed straight into the flat gradient buffer after the pass. */
 int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, const int *ld,
                     const int *accumulate, int jobs, void *stream);
+/* upp_copy_batched: dst_j[0 .. bytes_j) = src_j[0 .. bytes_j) for `count` non-overlapping device buffers in one launch (host arrays of
+ * device pointers and byte counts): the hand-over state a pipelined training step passes from its front-end to its back-end. */
+int upp_copy_batched(const void *const *src, void *const *dst, const long long *bytes, int count, void *stream);
 /* upp_colsum_partials: dst (chunks, len)[ch][c] = sum of src[r][c] over the rows r of chunk ch (ceil(n / chunks) rows each, ascending):
  * first stage of the column sum of one very tall matrix -- the bias gradient of a trainable Linear / 1x1 Conv1d over the 65,536
  * point rows of the patch embedding (reference models/Point_MAE_unify.py:191-222 under autograd) -- the second stage is
@@ -415,6 +418,19 @@ int upp_ln_adapter_bwd_fused(const float *g_out, const float *xo, const float *m
 int upp_ln_adapter_bwd(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
                        const float *beta, const float *s1, const float *W1, const float *W2, const float *u, float p,
                        float scale, float *g_ha, float *part, int R, int D, int H, void *stream);
+
+/* ---- tail of the denoising prompter ---------------------------------------------------------
+ * Replaces RectifyPrompter.score_head (reference models/Point_MAE_pretask_dev.py:491-493,512: Linear(32,64) -> ReLU -> Dropout(0.2)
+ * -> Linear(64,3), times score_factor) and the selection that follows it in the model (models/Point_MAE_unify.py:553-559):
+ *   pred = head(feature) * factor;  score = ||pred||_2;  order = argsort(score, descending, stable);
+ *   moved = pts + nudge * pred;     out = moved[order[N - keep :]]            (reference: nudge 0.2, keep int(0.95 point_num))
+ * feature (B*N,32) 16-byte aligned, W0 (64,32), b0 (64), W1 (3,64), b1 (3), u (B*N,64) uniforms in [0,1) or NULL (no dropout;
+ * with u: hidden unit kept iff u >= p and scaled by 1 / (1 - p)), pts (B,N,3).
+ * Outputs: moved (B,N,3), score (B,N) (both always written: scratch of the second launch), out (B,keep,3), pred (B,N,3) or NULL,
+ * order (B,N) int64 or NULL (the full descending order; ties: lower index first).  Limits: N <= 16384. */
+int upp_rectify_select(const float *feature, const float *W0, const float *b0, const float *W1, const float *b1, const float *u, float p,
+                       float factor, const float *pts, float nudge, int B, int N, int keep, float *pred, float *moved, float *score,
+                       float *out, int64_t *order, void *stream);
 
 /* ---- token-matrix Linear (exact f32 on the matrix cores) -------------------------------------
  * Replaces the nn.Linear layers of the Transformer blocks and their data gradients: Attention.qkv / .proj

@@ -124,3 +124,59 @@ def test_flat_grad_buffer_views_survive_backward():
     f.reduce()   # no process group: no-op
     with pytest.raises(ValueError):
         FlatGradAllReduce(frozen.parameters())
+
+
+def _sync_bn_worker(rank, world, port, out_dir):
+    sys.path[:0] = [p for p in os.environ["UPP_TEST_PATHS"].split(os.pathsep)]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from models import upp_layers as L
+    from utils import dist_utils
+    dist_utils.init_dist('pytorch', backend='gloo')
+    L.enable_sync_bn(True)
+    assert L.sync_bn_active(True) and not L.sync_bn_active(False)
+    torch.manual_seed(3)
+    bn = torch.nn.BatchNorm1d(24)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    x_all = torch.randn(40, 24) * 2.0 + 0.7
+    g_all = torch.randn(40, 24)
+    rows = slice(0, 14) if rank == 0 else slice(14, 40)            # uneven shards: the statistics weigh rows, not ranks
+    x = x_all[rows].clone().requires_grad_(True)
+    y = L._bn_rows(x, bn.train(), True, relu=True)
+    (y * g_all[rows]).sum().backward()
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    pooled = L.pooling(x_all[rows].reshape(2, -1, 1, 24).detach(), transform=bn)      # the prompt-propagation site goes the same way
+    torch.save({"y": y.detach(), "gx": x.grad, "gw": bn.weight.grad, "gb": bn.bias.grad, "rm": rm, "rv": rv, "pooled": pooled.detach()}, os.path.join(out_dir, "s%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sync_bn_switch_gives_the_single_process_statistics(tmp_path):
+    """`--sync_bn` (reference tools/runner_module.py:50-52): with the switch on, a training-mode BatchNorm over rows normalises with the
+    statistics of the rows of ALL ranks -- outputs, input gradients and running statistics equal one process seeing every row; the
+    parameter gradients are rank-local partial sums (the step's gradient all-reduce adds them)."""
+    from conftest import ROOT, PKG
+    os.environ["UPP_TEST_PATHS"] = os.pathsep.join([os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), PKG])
+    mp.spawn(_sync_bn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / ("s%d.pt" % k)) for k in range(2)]
+    torch.manual_seed(3)
+    bn = torch.nn.BatchNorm1d(24)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    x_all = (torch.randn(40, 24) * 2.0 + 0.7).requires_grad_(True)
+    g_all = torch.randn(40, 24)
+    y = torch.relu(bn.train()(x_all))
+    (y * g_all).sum().backward()
+    close = lambda a, b: np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=2e-5, atol=2e-6)
+    close(torch.cat([r[0]["y"], r[1]["y"]]), y)
+    close(torch.cat([r[0]["gx"], r[1]["gx"]]), x_all.grad)
+    close(r[0]["gw"] + r[1]["gw"], bn.weight.grad)
+    close(r[0]["gb"] + r[1]["gb"], bn.bias.grad)
+    close(r[0]["rm"], bn.running_mean); close(r[1]["rv"], bn.running_var)
+    assert torch.equal(r[0]["rm"], r[1]["rm"]) and torch.equal(r[0]["rv"], r[1]["rv"])
+    # pooling over groups of one row = 2 x the row (max + mean), normalised with the statistics of all 40 rows
+    with torch.no_grad():
+        want = torch.nn.functional.batch_norm(2.0 * x_all.detach(), None, None, bn.weight, bn.bias, True, 0.0, bn.eps)
+    close(torch.cat([r[0]["pooled"].reshape(-1, 24), r[1]["pooled"].reshape(-1, 24)]), want)

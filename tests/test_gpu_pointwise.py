@@ -270,3 +270,46 @@ def test_weighted_column_sums_are_the_skinny_product(n, C, W):
     part = ops.wcolsum_partials(g, x)
     ref = x.double().t() @ g.double()
     np.testing.assert_allclose(part.double().sum(0).cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=3e-6 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,N,keep,p", [(32, 1096, 972, 0.0), (3, 1624, 1459, 0.2), (2, 100, 100, 0.0), (1, 7, 3, 0.5)])
+def test_rectify_tail_scores_nudges_and_selects_like_the_reference_formulation(B, N, keep, p):
+    """upp_rectify_select: score head (Linear(32,64) -> ReLU -> dropout -> Linear(64,3)) + ||.||_2 + stable descending order + nudge + gather
+    (reference models/Point_MAE_pretask_dev.py:491-512, models/Point_MAE_unify.py:553-559) against the torch ops it replaces; exact ties
+    keep the lower index first, like torch's stable sort."""
+    from upp_hip import ops
+    gen = torch.Generator(device='cuda').manual_seed(B * N + keep)
+    feat = torch.randn(B, N, 32, device='cuda', generator=gen)
+    pts = torch.randn(B, N, 3, device='cuda', generator=gen)
+    if N > 50:                                              # duplicated rows: equal scores
+        feat[:, 40:45] = feat[:, 10:15]
+    w0 = torch.randn(64, 32, device='cuda', generator=gen) * 0.2
+    b0 = torch.randn(64, device='cuda', generator=gen) * 0.1
+    w1 = torch.randn(3, 64, device='cuda', generator=gen) * 0.2
+    b1 = torch.randn(3, device='cuda', generator=gen) * 0.1
+    u = torch.rand(B * N, 64, device='cuda', generator=gen) if p > 0 else None
+    out, pred, order, score = ops.rectify_select(feat, w0, b0, w1, b1, pts, keep, u, p, 1.5, 0.2, want_pred=True, want_order=True, want_score=True)
+    h = torch.relu(feat.double() @ w0.double().t() + b0.double())
+    if u is not None:
+        h = torch.where(u.view(B, N, 64) >= p, h / (1.0 - p), torch.zeros_like(h))
+    ref = (h @ w1.double().t() + b1.double()) * 1.5
+    np.testing.assert_allclose(pred.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=3e-6 * ref.abs().max().item())
+    np.testing.assert_allclose(score.cpu().numpy(), torch.linalg.vector_norm(pred, dim=-1).cpu().numpy(), rtol=1e-6)
+    want_order = torch.sort(score, dim=1, descending=True, stable=True)[1]
+    assert torch.equal(order, want_order)
+    moved = pts + pred * 0.2
+    want = torch.gather(moved, 1, want_order[:, -keep:, None].expand(-1, -1, 3))
+    assert torch.equal(out, want)
+
+
+def test_batched_copy_moves_every_tensor_in_one_launch():
+    """upp_copy_batched: the hand-over state of the pipelined step (mixed dtypes and sizes, odd byte counts)."""
+    from upp_hip import ops
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    srcs = [torch.randn(32, 64, 384, device='cuda', generator=gen), torch.randn(32, 64, 3, device='cuda', generator=gen),
+            torch.randint(0, 1000, (8192,), device='cuda', generator=gen), torch.randint(0, 100, (2401,), device='cuda', dtype=torch.int32, generator=gen),
+            torch.randn(7, device='cuda', generator=gen), torch.randint(0, 2, (33,), device='cuda', dtype=torch.uint8, generator=gen)]
+    dsts = [torch.zeros_like(s) for s in srcs]
+    ops.copy_batched(dsts, srcs)
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)

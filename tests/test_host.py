@@ -19,7 +19,7 @@ def test_registry_contract():
 
     assert R.get('Foo') is Foo and 'Foo' in R and len(R) == 1
     assert R.build(EasyDict(NAME='Foo', v=3)).v == 3
-    with pytest.raises(KeyError, match='already registered'):
+    with pytest.raises(KeyError, match='already has a class'):
         R.register_module()(Foo)
     with pytest.raises(KeyError, match='not in the things registry'):
         R.build(EasyDict(NAME='Bar'))
