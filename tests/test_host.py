@@ -21,7 +21,7 @@ def test_registry_contract():
     assert R.build(EasyDict(NAME='Foo', v=3)).v == 3
     with pytest.raises(KeyError, match='already has a class'):
         R.register_module()(Foo)
-    with pytest.raises(KeyError, match='not in the things registry'):
+    with pytest.raises(KeyError, match='things registry holds no class called Bar'):
         R.build(EasyDict(NAME='Bar'))
     with pytest.raises(KeyError, match='NAME'):
         R.build(EasyDict(v=1))
