@@ -433,6 +433,7 @@ def linear_family_replay(ts, device):
     with ops.time_linear_calls() as scope:
         ts._forward_backward()
     calls = [(M, N, K, e) for M, N, K, e, _ in scope.report()]
+    groups = list(scope.wgrad_groups)           # the weight gradients: one grouped launch per entry (upp_linear_wgrad_grouped_f32)
     gl = torch.Generator(device=device).manual_seed(5)
     bufs = {}
     for M, N, K, e in calls:
@@ -446,9 +447,17 @@ def linear_family_replay(ts, device):
         lib_aux = x if e == ops.LIN_MUL else None
         ops.linear_f32(a, w, b if e in (1, 2, 3, 5) else None, e, aux=lib_aux, out=o)
 
+    wbufs = {}
+    for grp in groups:
+        for M, N, K in grp:
+            if (M, N, K) not in wbufs:
+                wbufs[(M, N, K)] = (torch.randn(M, N, device=device, generator=gl), torch.randn(M, K, device=device, generator=gl))
+
     def run_all():
         for c in calls:
             launch(*c)
+        for grp in groups:
+            ops.linear_wgrad_grouped([wbufs[s_] for s_ in grp])
     ms = time_kernel(run_all, iters=1, warm=2)
     by = {}
     for c in calls:
@@ -457,7 +466,13 @@ def linear_family_replay(ts, device):
     for (M, N, K, e), n in sorted(by.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2]):
         t = time_kernel(lambda: launch(M, N, K, e), iters=10, warm=1)
         shapes.append({"M": M, "N": N, "K": K, "epilogue": e, "launches_per_step": n, "ms_per_launch": t, "tflops": 2.0 * M * N * K / t / 1e9})
-    return sum(2.0 * M * N * K for M, N, K, _ in calls), ms, len(calls), shapes
+    for grp in groups:
+        t = time_kernel(lambda: ops.linear_wgrad_grouped([wbufs[s_] for s_ in grp]), iters=5, warm=1)
+        fl = sum(2.0 * M * N * K for M, N, K in grp)
+        shapes.append({"weight_gradient_group": len(grp), "largest": max(grp, key=lambda s_: s_[0] * s_[1] * s_[2]), "launches_per_step": 1,
+                       "ms_per_launch": t, "tflops": fl / t / 1e9})
+    flops = sum(2.0 * M * N * K for M, N, K, _ in calls) + sum(2.0 * M * N * K for grp in groups for M, N, K in grp)
+    return flops, ms, len(calls) + len(groups), shapes
 
 
 def cpu_baseline(budget_s=20.0, batch=32):
@@ -602,7 +617,20 @@ def main():
         elapsed = t.item()
 
     if rank == 0 and args.workload != "cls":
-        # secondary recipe: throughput only (the kernels are the ones the headline run reports rooflines for)
+        # secondary recipe: throughput + the roofline of its dominant kernel family (the exact-f32 MFMA Linear launches: forward, data
+        # gradient, grouped weight gradients), measured like the headline's: the step's launch list replayed as one HIP graph
+        roof = None
+        if not args.no_stage_report and world == 1:
+            seq = tr if not pipeline else RecipeTrainer(args.workload, device, args.batch, use_graph=False, pipeline=False)
+            flops, ms, n, shapes = linear_family_replay(seq.ts, device)
+            tf = flops / ms / 1e9
+            shapes.sort(key=lambda r: -r["ms_per_launch"] * r["launches_per_step"])
+            roof = {"kernel": "linear_f32_kernel<*> + linear_rt_kernel<*> + wgrad_grouped_kernel (csrc/linear.hip, linear_rt.hip): ALL %d "
+                              "exact-f32 MFMA Linear launches of one step (forward, data gradients, grouped weight gradients)" % n,
+                    "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "ms": ms,
+                    "launches": n, "algorithmic_flops": flops, "traffic": None,
+                    "how": "launch list recorded from an eager step, replayed as one HIP graph, HIP events on the launch stream",
+                    "by_shape": shapes[:14]}
         print(json.dumps({
             "metric": "point-clouds/sec fwd+bwd, secondary recipe '%s'" % args.workload,
             "value": args.batch * world * args.steps / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
@@ -610,7 +638,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": tr.workload, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph,
-                       "pipeline": "front-end(k+1) || back-end(k) on two streams" if pipeline else "none"}}))
+                       "pipeline": "front-end(k+1) || back-end(k) on two streams" if pipeline else "none"},
+            "roofline": roof}))
     rccl_ranks = 0
     if distributed and backend == "nccl" and args.workload == "cls":
         # "rccl_ranks": only after RCCL has summed a buffer of the gradient all-reduce's size across the ranks and every rank saw the sum
@@ -653,7 +682,7 @@ def main():
             stages = stage_report(device, args.batch)
             pmc_step = [stages["linear_" + lab].get("traffic") for lab, *_ in LINEAR_SHAPES]
             # (the Transformer-block layers: token rows x {384, 1152, 1536}^2; the heads have at most B rows, the prompter layers other widths)
-            blk = [r for r in shapes if r["M"] > args.batch and r["N"] in (384, 1152, 1536) and r["K"] in (384, 1152, 1536)]
+            blk = [r for r in shapes if "M" in r and r["M"] > args.batch and r["N"] in (384, 1152, 1536) and r["K"] in (384, 1152, 1536)]
             blk_ms = sum(r["ms_per_launch"] * r["launches_per_step"] for r in blk) or float("nan")
             blk_fl = sum(2.0 * r["M"] * r["N"] * r["K"] * r["launches_per_step"] for r in blk)
             line["roofline"] = {

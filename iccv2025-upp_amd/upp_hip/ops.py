@@ -226,6 +226,7 @@ class time_linear_calls:
 
     def __enter__(self):
         self.calls = []
+        self.wgrad_groups = []          # [(M, N, K), ...] per upp_linear_wgrad_grouped_f32 launch
         time_linear_calls.active = self
         return self
 
@@ -432,6 +433,8 @@ def linear_wgrad_grouped(pairs):
     ldg = (ctypes.c_longlong * k)(*[g.stride(0) for g, _ in pairs])
     ldx = (ctypes.c_longlong * k)(*[x.stride(0) for _, x in pairs])
     _call(dev, "upp_linear_wgrad_grouped_f32", G, ldg, X, ldx, P, M, N, K, rows, k)
+    if time_linear_calls.active is not None:
+        time_linear_calls.active.wgrad_groups.append([(M[i], N[i], K[i]) for i in range(k)])
     return parts
 
 

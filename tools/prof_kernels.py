@@ -90,5 +90,21 @@ for label, M, N, K, epi in LINEAR_SHAPES:
 for _ in range(6):
     for a_, w_, b_, epi, x_ in lin:
         ops.linear_f32(a_, w_, b_, epi, aux=x_)
+# round 3: the tall-matrix kernel and the grouped weight gradient at the segmentation head's largest layer (65,536 x 1536 -> 1024), the
+# grouped weight gradients of one pre-training block, the denoising prompter's tail
+xt = torch.randn(65536, 1536, device='cuda', generator=gl)
+wt_ = torch.randn(1024, 1536, device='cuda', generator=gl) * 1536 ** -0.5
+gt_ = torch.randn(65536, 1024, device='cuda', generator=gl)
+pre = []
+for M_, N_, K_ in ((2080, 1152, 384), (2080, 384, 384), (2080, 1536, 384), (2080, 384, 1536), (864, 1152, 384), (864, 384, 384), (864, 1536, 384), (864, 384, 1536)):
+    pre.append((torch.randn(M_, N_, device='cuda', generator=gl), torch.randn(M_, K_, device='cuda', generator=gl)))
+rf = torch.randn(B, 1096, 32, device='cuda', generator=gl)
+rw0, rb0 = torch.randn(64, 32, device='cuda', generator=gl) * 0.2, torch.zeros(64, device='cuda')
+rw1, rb1 = torch.randn(3, 64, device='cuda', generator=gl) * 0.2, torch.zeros(3, device='cuda')
+for _ in range(4):
+    ops.linear_f32(xt, wt_)
+    ops.linear_wgrad_grouped([(gt_, xt)])
+    ops.linear_wgrad_grouped(pre)
+    ops.rectify_select(rf, rw0, rb0, rw1, rb1, xyz1, 972)
 torch.cuda.synchronize()
 print("done")
