@@ -55,9 +55,14 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     const int nwg = gridDim.x;
     const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, rem = nwg & 7;
     const int lin = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (orig >> 3);
-    const int by = lin / g.tiles_n, bx = lin - by * g.tiles_n;      // row-panel order
+    // row-panel order; with the contraction cut over workgroups (kparts > 1): row panel, then k-part, then column tile -- neighbours
+    // share the A rows AND the k-range of their row panel
+    const int per_panel = g.tiles_n * g.kparts;
+    const int by = lin / per_panel, rem_p = lin - by * per_panel;
+    const int kp = rem_p / g.tiles_n, bx = rem_p - kp * g.tiles_n;
     const int m0 = by * BM, n0 = bx * BN;
     const int M = g.M, N = g.N;
+    const int Kc = g.K / g.kparts;                                   // (kparts > 1: a whole number of k-stages, checked by the host)
     const int ks = wave / (BMB * BNB), wb = wave - ks * (BMB * BNB);
     const int bm = wb / BNB, bn = wb - bm * BNB;
 
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     // Everything that depends on t only (sub-image, A or W, first row) is wave-uniform: scalar code, few VALU instructions.
     const float *src[TPW];
     int koff[TAIL ? TPW : 1];                                          // (TAIL) k of the lane's granule inside a k-stage
-    const int nsc = TAIL ? (g.K + 32 * KS * KC - 1) / (32 * KS * KC) : g.K / (32 * KS * KC);
+    const int nsc = TAIL ? (g.K + 32 * KS * KC - 1) / (32 * KS * KC) : Kc / (32 * KS * KC);
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int t = wave + q * NW;
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
         const int row = min(first + (lane >> 3), last);
         const int ko = sk * 32 + 4 * ((lane & 7) ^ (((rho0 >> 1) + (lane >> 4)) & 7));
         if constexpr (TAIL) koff[q] = ko;
-        src[q] = base + row * ld + ko;
+        src[q] = base + row * ld + ko + kp * Kc;
     }
     static_assert(KC != 1 || TPW <= 6, "DMA slots of the interleaved schedule");
     auto issue1 = [&](int q, int stage, int c) {            // q-th DMA instruction of this wave for k-stage c
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     const int T0 = ks * TN;
     const int rb = m0 + bm * 32, cb = n0 + bn * 32;                         // (scalar) block origin
     const bool wide = ((g.ldc | N | g.ldaux) & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.aux)) & 15) == 0;
+    g.C += kp * g.part_stride;                                       // (this workgroup's partial output)
     if (wide) {
         __syncthreads();                                     // all fragment reads done: the stages may be overwritten
         float *red = reinterpret_cast<float *>(lds);
@@ -304,8 +310,10 @@ int launch_linear(const LinArgs &g0, hipStream_t st) {
     LinArgs g = g0;
     const int tiles_m = (g.M + BMB * 32 - 1) / (BMB * 32);
     g.tiles_n = (g.N + BNB * 32 - 1) / (BNB * 32);
-    if (g.ktail) hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC, true>), dim3((unsigned)(tiles_m * g.tiles_n)), dim3(BMB * BNB * KS * 64), 0, st, g);
-    else hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC, false>), dim3((unsigned)(tiles_m * g.tiles_n)), dim3(BMB * BNB * KS * 64), 0, st, g);
+    if (g.kparts < 1) g.kparts = 1;
+    const dim3 grid((unsigned)(tiles_m * g.tiles_n * g.kparts));
+    if (g.ktail) hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC, true>), grid, dim3(BMB * BNB * KS * 64), 0, st, g);
+    else hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC, false>), grid, dim3(BMB * BNB * KS * 64), 0, st, g);
     return upp_launch_status();
 }
 
@@ -357,6 +365,33 @@ int pick_rt(int M, int N, int K) {
     return tiles >= 1024 && N >= 128 && K >= 32 ? kRtTall : 0;      // at least two rounds of the 512 resident workgroups
 }
 
+// Narrow outputs over a long contraction (fc2, the data gradients of fc1 and qkv: N = 384, K = 1152 ... 1536 at 1,120 ... 4,448 rows): one
+// round of 256 workgroups needs 64 x 64 tiles with the contraction split over the wave groups of a workgroup -- 128 staged rows per 4
+// blocks, four LDS-DMA instructions per wave and 16 MFMAs: measured 68 % MFMA duty in the k-loop (fc2 at M = 2400: 71,700 cycles for
+// 49,152 of MFMA issue) against 98 % for the 128 x 128 tile of fc1.  Cutting the contraction over WORKGROUPS instead keeps the big tile:
+// (tiles x parts) workgroups, each a 128 x 128 (or 128 x 96) tile over K / parts, writing its own partial output; the kernel that consumes
+// the result adds the parts in order while it reads them (row kernels, block tail: a few MB from L2).  -> (parts, tile code) or parts = 1.
+int pick_parts(int M, int N, int K, int *tile_out) {
+    const int i0 = pick_config(M, N, K);
+    if (i0 < 0 || kConfigs[i0].ks == 1) return 1;                  // the one-round choice keeps the contraction whole: nothing to gain
+    const int mb = (M + 31) / 32, nb = (N + 31) / 32;
+    long long best_cost = 0;
+    int best_p = 1, best_tile = 0;
+    for (int i = 0; i < kNumConfigs; ++i) {
+        const LinConfig c = kConfigs[i];
+        if (c.ks != 1) continue;
+        const long long tiles = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
+        for (int p = 2; p <= 8; ++p) {
+            if (K % (p * 32 * c.kc) || tiles * p > 256 || tiles * p < 160) continue;
+            const long long ksteps = K / p / 32;                                      // 32-wide k-steps per wave
+            const long long cost = ksteps * ((c.bmb * c.bnb + 3) / 4) * 1000 + (256 - tiles * p) + p * 4;   // MFMAs per SIMD, then fill, then few parts
+            if (best_p == 1 || cost < best_cost) { best_cost = cost; best_p = p; best_tile = config_code(c); }
+        }
+    }
+    if (best_p > 1 && tile_out) *tile_out = best_tile;
+    return best_p;
+}
+
 }  // namespace
 
 __attribute__((visibility("hidden"))) int upp_detail_linear_rt(const void *args, int code, hipStream_t st);
@@ -398,6 +433,42 @@ extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, lon
         tile = config_code(kConfigs[i]);
     }
     g.ktail = K % (32 * ((tile >> 4) & 15) * (tile & 15)) != 0;
+#define UPP_LIN_CASE(a, b, c, d) case a * 4096 + b * 256 + c * 16 + d: return launch_linear<a, b, c, d>(g, st);
+    switch (tile) {
+        UPP_LIN_CONFIGS(UPP_LIN_CASE)
+        default: return UPP_E_RANGE;
+    }
+#undef UPP_LIN_CASE
+}
+
+extern "C" int upp_linear_parts(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
+    if (K % 4 != 0) return UPP_E_RANGE;
+    if (pick_rt(M, N, K)) return 1;
+    return pick_parts(M, N, K, nullptr);
+}
+
+extern "C" int upp_linear_parts_f32(const float *A, long long lda, const float *W, long long ldw, float *C, long long ldc, long long part_stride,
+                                    int M, int N, int K, int parts, void *stream) {
+    if (!A || !W || !C || M < 1 || N < 1 || K < 1 || parts < 1) return UPP_E_BADARG;
+    if (parts == 1) return upp_linear_f32(A, lda, W, ldw, nullptr, C, ldc, nullptr, 0, M, N, K, LEPI_NONE, 0, stream);
+    if (K % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || lda < K || ldw < K || ldc < N || part_stride < (long long)M * ldc) return UPP_E_RANGE;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return UPP_E_RANGE;
+    if (ldc > (1LL << 24)) return UPP_E_RANGE;
+    int tile = 0;
+    if (pick_parts(M, N, K, &tile) != parts) {                     // a forced part count (tests, measurements): the widest tile that divides
+        tile = 0;
+        for (int i = 0; i < kNumConfigs && !tile; ++i)
+            if (kConfigs[i].ks == 1 && K % (parts * 32 * kConfigs[i].kc) == 0) tile = config_code(kConfigs[i]);
+        if (!tile) return UPP_E_RANGE;
+    }
+    LinArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.epi = LEPI_NONE;
+    g.kparts = parts; g.part_stride = part_stride;
+#ifdef UPP_LIN_STAMPS
+    g.stamps = g_lin_stamps;
+#endif
+    hipStream_t st = (hipStream_t)stream;
 #define UPP_LIN_CASE(a, b, c, d) case a * 4096 + b * 256 + c * 16 + d: return launch_linear<a, b, c, d>(g, st);
     switch (tile) {
         UPP_LIN_CONFIGS(UPP_LIN_CASE)

@@ -20,6 +20,7 @@ struct LinArgs {
     int tiles_n;                  // workgroup tiles along N
     int epi;
     int ktail;                    // K is not a multiple of the k-stage: the last stage reads zeros beyond K (K % 4 == 0)
+    int kparts; long long part_stride;   // linear.hip: the contraction cut into kparts runs over WORKGROUPS, part p -> C + p * part_stride
 #ifdef UPP_LIN_STAMPS
     unsigned long long *stamps;   // diagnostic build only (tools/micro/lin_stamps.py): [workgroup][8] clock readings
 #endif

@@ -281,6 +281,33 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
     return (out, d) if epilogue == LIN_BIAS_GELU_D else out
 
 
+def linear_parts_choice(M, N, K):
+    """The library's number of k-parts for an (M,K) x (N,K)^T product (1 = keep the contraction whole): upp_linear_parts."""
+    return max(1, int(_abi.load().upp_linear_parts(int(M), int(N), int(K))))
+
+
+def linear_parts(a, w, parts=None):
+    """(parts, ..., N) partial products of a (..., K) . w (N, K)^T, the contraction cut into `parts` runs over workgroups (upp_linear_parts_f32);
+    sum over dim 0 = the product.  parts=None: the library's choice."""
+    if not (isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1):
+        raise RuntimeError("w must be a 2-D f32 HIP (cuda) matrix with contiguous rows; upp_hip has no CPU path")
+    if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.float32):
+        raise RuntimeError("a must be a f32 HIP (cuda) tensor; upp_hip has no CPU path")
+    _same_device(a, w)
+    K, N = a.shape[-1], w.shape[0]
+    if w.shape[1] != K:
+        raise RuntimeError(f"linear_parts: a (...,{K}) against w {tuple(w.shape)}")
+    a2 = a.reshape(-1, K)
+    if a2.stride(1) != 1 or a2.stride(0) % 4 != 0 or a2.data_ptr() % 16 != 0:
+        a2 = a2.contiguous()
+    M = a2.shape[0]
+    if parts is None:
+        parts = linear_parts_choice(M, N, K)
+    out = torch.empty((int(parts),) + tuple(a.shape[:-1]) + (N,), dtype=torch.float32, device=a.device)
+    _call(a.device, "upp_linear_parts_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(out), N, M * N, M, N, K, int(parts))
+    return out
+
+
 def colsum_partials(part, offset, length, chunks=None):
     """(chunks, length) partial column sums of columns [offset, offset + length) of the tall 2-D matrix `part` (upp_colsum_partials)."""
     if not (isinstance(part, torch.Tensor) and part.is_cuda and part.dtype == torch.float32 and part.dim() == 2 and part.stride(1) == 1):

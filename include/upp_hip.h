@@ -475,6 +475,15 @@ int upp_linear_wgrad_f32(const float *G, long long ldg, const float *X, long lon
 int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias,
                    float *C, long long ldc, float *aux, long long ldaux,
                    int M, int N, int K, int epilogue, int tile, void *stream);
+/* upp_linear_parts_f32: the same product with the contraction cut into `parts` equal runs over WORKGROUPS: C_p (M,N) = A[:, p K/parts :
+ * (p+1) K/parts] . W[:, same]^T written at C + p * part_stride (floats), no epilogue.  For narrow outputs over a long contraction (fc2 and
+ * the data gradients of fc1 / qkv: N = 384, K >= 1152) this keeps 128-wide tiles AND fills the chip; the consumer of the result adds the
+ * parts in order while it reads them (upp_rowln_fwd / upp_ln_adapter_fwd `y`, upp_rowln_bwd `g_h`: their `parts` arguments).
+ * upp_linear_parts(M,N,K): the library's choice of `parts` (1 = do not cut).  Every part is a KS = 1 chain over its run (oracle_linear_f32
+ * on the column window).  Limits: as upp_linear_f32, K % (32 parts) == 0 (64 parts for the 128 x 128 tile). */
+int upp_linear_parts(int M, int N, int K);
+int upp_linear_parts_f32(const float *A, long long lda, const float *W, long long ldw, float *C, long long ldc, long long part_stride,
+                         int M, int N, int K, int parts, void *stream);
 /* upp_linear_smallk_f32: y (M,N) = act(x (M,K) . W (N,K)^T + bias) for the Linear layers upp_linear_f32 does not take (K not a
  * multiple of 4, unaligned rows): the first layer of every position MLP (K = 3; reference models/Point_MAE_unify.py pos_embed /
  * models/Point_MAE_pretask_dev.py:395-399 `nn.Linear(3, 128), nn.GELU(), nn.Linear(128, dim)`) and the first point-wise layer of
