@@ -346,6 +346,7 @@ struct LnAdapterArgs {
     float p, scale;
     float *xo, *mean, *rstd, *s1, *out;
     int B, Lin, Lout;
+    int yparts; long long ystride;      // y = sum of yparts partial matrices ystride floats apart (upp_linear_parts_f32), added in order
 };
 
 template <int D, int kFW>
@@ -402,6 +403,13 @@ __global__ __launch_bounds__(64 * kFW) void ln_adapter_fwd_kernel(LnAdapterArgs 
             for (int e = 0; e < E; ++e) {
                 xv[q][e] = a.x[off + lane + 64 * e];
                 yv[q][e] = a.y ? a.y[off + lane + 64 * e] : 0.0f;
+            }
+            for (int pp = 1; pp < a.yparts; ++pp) {      // the k-parts of the GEMM that produced y
+                float yp[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) yp[e] = a.y[(size_t)pp * a.ystride + off + lane + 64 * e];
+#pragma unroll
+                for (int e = 0; e < E; ++e) yv[q][e] += yp[e];
             }
         }
 #pragma unroll
@@ -775,13 +783,22 @@ extern "C" int upp_ln_adapter_fwd(const float *x, const float *y, const float *y
                                   const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
                                   const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
                                   float *out, int B, int Lin, int Lout, int D, int H, void *stream) {
+    return upp_ln_adapter_fwd_parts(x, y, 1, 0, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, xo, mean, rstd, s1, out, B, Lin,
+                                    Lout, D, H, stream);
+}
+
+extern "C" int upp_ln_adapter_fwd_parts(const float *x, const float *y, int yparts, long long ystride, const float *ybias, const float *u, float keep,
+                                        int mode, int P, const float *gamma, const float *beta, float eps, const float *W1, const float *b1,
+                                        const float *W2, const float *b2, const float *ud, float p, float scale, float *xo, float *mean,
+                                        float *rstd, float *s1, float *out, int B, int Lin, int Lout, int D, int H, void *stream) {
+    if (yparts < 1 || (yparts > 1 && (!y || ystride < (long long)B * Lin * D))) return UPP_E_BADARG;
     if (!x || !gamma || !beta || !W1 || !b1 || !W2 || !b2 || !xo || !mean || !rstd || !s1 || !out || B < 0 || Lin < 1 || Lout < 1)
         return UPP_E_BADARG;
     if (ybias && !y) return UPP_E_BADARG;
     if (D != 384 || H != kH) return UPP_E_RANGE;
     if (!(mode == 0 || mode == 3 || mode == 4) || P < 0 || (mode == 0 && Lout != Lin) || (mode != 0 && Lout != Lin - P)) return UPP_E_BADARG;
     if (B == 0) return 0;
-    LnAdapterArgs a{x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, xo, mean, rstd, s1, out, B, Lin, Lout};
+    LnAdapterArgs a{x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, xo, mean, rstd, s1, out, B, Lin, Lout, yparts, ystride};
     hipLaunchKernelGGL((ln_adapter_fwd_kernel<384, 8>), dim3((B * Lout + kFR - 1) / kFR), dim3(64 * 8), 0, (hipStream_t)stream, a);
     return upp_launch_status();
 }

@@ -40,6 +40,7 @@ struct RowLnArgs {
     float *h;              // (B, Lout, D) LayerNorm output
     float *mean, *rstd;    // (B, Lout) saved statistics
     int B, Lin, Lout, D;
+    int yparts; long long ystride;   // y = sum of yparts partial matrices ystride floats apart (upp_linear_parts_f32), added in order
 };
 
 // Source row of output row t; -(p+1) selects prompt p.  Token layouts: [cls | prompts | tokens] or [prompts | tokens].
@@ -83,6 +84,13 @@ __global__ __launch_bounds__(256) void rowln_fwd_kernel(RowLnArgs a) {
     if (has_y) {
 #pragma unroll
         for (int e = 0; e < kMaxE; ++e) yv[e] = ys[cc[e]];
+        for (int p = 1; p < a.yparts; ++p) {        // the k-parts of the GEMM that produced y: added here, in part order
+            float yp[kMaxE];
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) yp[e] = ys[(size_t)p * a.ystride + cc[e]];
+#pragma unroll
+            for (int e = 0; e < kMaxE; ++e) yv[e] += yp[e];
+        }
     }
     if (has_yb) {
         float yb[kMaxE];
@@ -136,6 +144,7 @@ struct RowLnBwdArgs {
     float *g_y;            // (B, Lin, D) gradient of the residual branch (same rows as g_x), or null
     float *ln_part;        // (workgroups, 2, D) partial d_gamma / d_beta per workgroup of 4 rows, or null
     int B, Lin, Lout, D, P;
+    int gparts; long long gstride;   // g_h = sum of gparts partial matrices gstride floats apart (upp_linear_parts_f32), added in order
 };
 
 __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
@@ -189,6 +198,13 @@ __global__ __launch_bounds__(256) void rowln_bwd_kernel(RowLnBwdArgs a) {
         if (has_ln) {
 #pragma unroll
             for (int e = 0; e < kMaxE; ++e) { gh[e] = a.g_h[(size_t)row * D + cc[e]]; gm[e] = a.gamma[cc[e]]; xo[e] = a.xo[(size_t)row * D + cc[e]]; }
+            for (int p = 1; p < a.gparts; ++p) {    // the k-parts of the data-gradient GEMM that produced g_h
+                float gp[kMaxE];
+#pragma unroll
+                for (int e = 0; e < kMaxE; ++e) gp[e] = a.g_h[(size_t)p * a.gstride + (size_t)row * D + cc[e]];
+#pragma unroll
+                for (int e = 0; e < kMaxE; ++e) gh[e] += gp[e];
+            }
             mean = a.mean[row]; rstd = a.rstd[row];
         }
         float *gx = nullptr;
@@ -505,6 +521,13 @@ int set_lds(K kernel, size_t bytes) {
 extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y,
                              const float *ybias, const float *u, float keep, const float *gamma, const float *beta, float eps, float *xo, float *h,
                              float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream) {
+    return upp_rowln_fwd_parts(x, add, prompts, mode, P, y, 1, 0, ybias, u, keep, gamma, beta, eps, xo, h, mean, rstd, B, Lin, Lout, D, stream);
+}
+
+extern "C" int upp_rowln_fwd_parts(const float *x, const float *add, const float *prompts, int mode, int P, const float *y, int yparts,
+                                   long long ystride, const float *ybias, const float *u, float keep, const float *gamma, const float *beta,
+                                   float eps, float *xo, float *h, float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream) {
+    if (yparts < 1 || (yparts > 1 && (!y || ystride < (long long)B * Lin * D))) return UPP_E_BADARG;
     if (!x || B < 0 || Lin < 1 || Lout < 1 || D < 1) return UPP_E_BADARG;
     if (gamma && (!beta || !h || !mean || !rstd)) return UPP_E_BADARG;
     if (!gamma && !xo) return UPP_E_BADARG;
@@ -514,7 +537,7 @@ extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prom
         ((mode == 3 || mode == 4) && Lout != Lin - P) || (mode == 0 && Lout != Lin))
         return UPP_E_BADARG;
     if (ybias && !y) return UPP_E_BADARG;
-    RowLnArgs a{x, add, prompts, mode, P, y, ybias, u, keep, gamma, beta, eps, xo, h, mean, rstd, B, Lin, Lout, D};
+    RowLnArgs a{x, add, prompts, mode, P, y, ybias, u, keep, gamma, beta, eps, xo, h, mean, rstd, B, Lin, Lout, D, yparts, ystride};
     hipLaunchKernelGGL(rowln_fwd_kernel, dim3((B * Lout + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return upp_launch_status();
 }
@@ -528,13 +551,20 @@ extern "C" long long upp_rowln_part_floats(int B, int Lin, int Lout, int D, int 
 extern "C" int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
                              const float *gamma, int mode, const float *u, float keep, float *g_x, float *g_prompt,
                              float *g_y, float *ln_part, int B, int Lin, int Lout, int D, int P, void *stream) {
+    return upp_rowln_bwd_parts(g_xo, g_h, 1, 0, xo, mean, rstd, gamma, mode, u, keep, g_x, g_prompt, g_y, ln_part, B, Lin, Lout, D, P, stream);
+}
+
+extern "C" int upp_rowln_bwd_parts(const float *g_xo, const float *g_h, int gparts, long long gstride, const float *xo, const float *mean,
+                                   const float *rstd, const float *gamma, int mode, const float *u, float keep, float *g_x, float *g_prompt,
+                                   float *g_y, float *ln_part, int B, int Lin, int Lout, int D, int P, void *stream) {
+    if (gparts < 1 || (gparts > 1 && (!g_h || gstride < (long long)B * Lout * D))) return UPP_E_BADARG;
     if ((!g_xo && !g_h) || B < 0 || Lin < 1 || Lout < 1 || D < 1) return UPP_E_BADARG;
     if (g_h && (!xo || !mean || !rstd || !gamma)) return UPP_E_BADARG;
     if (D > 64 * kMaxE) return UPP_E_RANGE;
     if (B == 0) return 0;
     if (mode < 0 || mode > 4 || P < 0) return UPP_E_BADARG;
     if (ln_part && !g_h) return UPP_E_BADARG;
-    RowLnBwdArgs a{g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, g_x, g_prompt, g_y, ln_part, B, Lin, Lout, D, P};
+    RowLnBwdArgs a{g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, g_x, g_prompt, g_y, ln_part, B, Lin, Lout, D, P, gparts, gstride};
     const int Lg = (mode == 3 || mode == 4) ? Lin : Lout;      // strip maps are walked by input row (see the kernel)
     hipLaunchKernelGGL(rowln_bwd_kernel, dim3((B * Lg + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return upp_launch_status();

@@ -183,6 +183,16 @@ int upp_patch_embed_fwd(const float *pts, int R, int n,
 int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y, const float *ybias,
                   const float *u, float keep, const float *gamma, const float *beta, float eps,
                   float *xo, float *h, float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream);
+/* upp_rowln_fwd_parts / upp_rowln_bwd_parts / upp_ln_adapter_fwd_parts: the same operators with `y` (forward) / `g_h` (backward) given as
+ * `parts` partial matrices `stride` floats apart -- the output of upp_linear_parts_f32 -- which are added in part order while they are
+ * read: the reduction of a GEMM whose contraction was cut over workgroups costs no launch and no pass (parts = 1: the plain operator). */
+int upp_rowln_fwd_parts(const float *x, const float *add, const float *prompts, int mode, int P, const float *y, int yparts, long long ystride,
+                        const float *ybias, const float *u, float keep, const float *gamma, const float *beta, float eps,
+                        float *xo, float *h, float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream);
+int upp_rowln_bwd_parts(const float *g_xo, const float *g_h, int gparts, long long gstride, const float *xo, const float *mean, const float *rstd,
+                        const float *gamma, int mode, const float *u, float keep,
+                        float *g_x, float *g_prompt, float *g_y, float *ln_part,
+                        int B, int Lin, int Lout, int D, int P, void *stream);
 long long upp_rowln_part_floats(int B, int Lin, int Lout, int D, int mode);
 int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
                   const float *gamma, int mode, const float *u, float keep,
@@ -405,6 +415,10 @@ int upp_ln_adapter_fwd(const float *x, const float *y, const float *ybias, const
                        const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
                        const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
                        float *out, int B, int Lin, int Lout, int D, int H, void *stream);
+int upp_ln_adapter_fwd_parts(const float *x, const float *y, int yparts, long long ystride, const float *ybias, const float *u, float keep,
+                             int mode, int P, const float *gamma, const float *beta, float eps, const float *W1, const float *b1,
+                             const float *W2, const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd,
+                             float *s1, float *out, int B, int Lin, int Lout, int D, int H, void *stream);
 /* upp_ln_adapter_bwd_fused: the whole backward of upp_ln_adapter_fwd in one launch on 16-row workgroups -- the adapter's backward
  * (g_ha, per-workgroup partials [dW1 (H,D) | dW2 (D,H) | db1 (H) | db2 (D)] in `part`, upp_ln_adapter_part_floats(R, D) floats, or
  * part = NULL), the LayerNorm backward with the residual (g_x / g_y (B, Lin, D): every row is written, zeros for the prompt rows

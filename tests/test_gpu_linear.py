@@ -231,24 +231,33 @@ def test_patch_embedding_with_a_gradient_runs_on_our_kernels_and_matches_torch_a
     ref = _reference_encoder(enc, pg)
     ref.backward(gy)
     close(out, ref, atol_scale=5e-6)
-    # The two max-pools route a gradient to ONE point per (group, channel): where the two largest pre-pool values of a column
-    # differ by less than the f32 rounding of the two formulations (the reference concatenates [global | local] for one 512-wide
-    # GEMM, this path splits it), the arg-max -- and with it a few entries of the input gradient -- legitimately flips.
-    # Measured: ~0.3 % of the input-gradient entries.  So: >= 99 % of the entries at 2e-5, and the whole array in L2.
-    a, b = got['x'].double(), pg.grad.double()
-    tol = 2e-5 * b.abs() + 2e-5 * b.abs().max()
-    assert ((a - b).abs() <= tol).double().mean().item() >= 0.99
-    assert ((a - b).norm() / b.norm()).item() < 2e-2
-    for n, p in enc.named_parameters():
+    # The two max-pools route a gradient to ONE point per (group, channel): where the two largest pre-pool values of a column differ by
+    # less than the f32 rounding of a formulation, the arg-max -- and with it a few entries of the input gradient and their share of the
+    # row sums behind every parameter gradient -- legitimately flips (~0.3 % of the entries, in BOTH f32 formulations: the reference
+    # concatenates [global | local] for one 512-wide GEMM, this path splits it).  Arbitrated in f64: every gradient of this path is as
+    # close to an f64 evaluation of the reference formulation as torch's f32 evaluation of it is.
+    enc64 = Encoder(384).cuda().double().train()
+    enc64.load_state_dict({k: v.double() for k, v in {**enc.state_dict(), **stats0}.items()})
+    for p in enc64.parameters():
+        p.requires_grad_(trainable)
+    pg64 = pg.detach().double().requires_grad_(True)
+    _reference_encoder(enc64, pg64).backward(gy.double())
+    exact = {'x': pg64.grad}
+    exact.update({n: p.grad for n, p in enc64.named_parameters() if p.grad is not None})
+    torch32 = {'x': pg.grad}
+    torch32.update({n: p.grad for n, p in enc.named_parameters() if p.grad is not None})
+    for n, r in exact.items():
         if trainable and n in ('first_conv.0.bias', 'first_conv.3.bias', 'second_conv.0.bias'):
             # a bias in front of a training-mode BatchNorm (first_conv.3.bias: through the linear 512 -> 512 layer) has gradient
             # exactly 0: both sides hold rounding noise only
             wmax = got[n.replace('bias', 'weight')].abs().max().item()
-            assert got[n].abs().max().item() < 1e-3 * wmax and p.grad.abs().max().item() < 1e-3 * wmax
-        elif trainable:     # sums over all rows: a flipped arg-max moves them by its share of one row
-            close(got[n], p.grad, rtol=1e-3, atol_scale=3e-3)
-        else:
-            assert n not in got
+            assert got[n].abs().max().item() < 1e-3 * wmax and torch32[n].abs().max().item() < 1e-3 * wmax
+            continue
+        scale = r.abs().max().item()
+        ea, eb = (torch32[n].double() - r).abs(), (got[n].double() - r).abs()
+        assert eb.max().item() <= 4.0 * ea.max().item() + 1e-5 * scale, (n, eb.max().item(), ea.max().item(), scale)
+        assert eb.mean().item() <= 3.0 * ea.mean().item() + 1e-6 * scale, (n, eb.mean().item(), ea.mean().item(), scale)
+    assert trainable or set(got) == {'x'}
     for k in stats1:
         close(stats1[k], enc.state_dict()[k], atol_scale=1e-5)
 
