@@ -37,6 +37,9 @@ SIGNATURES = {
                             + [ctypes.c_float, ctypes.c_float, _c_i] + [_c_f, _c_f, _c_f]),
     "upp_rowln_fwd": (_c_i, [_c_f] * 3 + [_c_i] * 2 + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 2 + [ctypes.c_float] + [_c_f] * 4
                       + [_c_i] * 4 + [_c_f]),
+    "upp_rowln_fwd_parts": (_c_i, [_c_f] * 3 + [_c_i] * 2 + [_c_f, _c_i, ctypes.c_longlong] + [_c_f] * 2 + [ctypes.c_float] + [_c_f] * 2 + [ctypes.c_float]
+                            + [_c_f] * 4 + [_c_i] * 4 + [_c_f]),
+    "upp_rowln_bwd_parts": (_c_i, [_c_f] * 2 + [_c_i, ctypes.c_longlong] + [_c_f] * 4 + [_c_i] + [_c_f] + [ctypes.c_float] + [_c_f] * 4 + [_c_i] * 5 + [_c_f]),
     "upp_bias_gelu_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_longlong, _c_i, _c_f]),
     "upp_bias_gelu_fwd_d": (_c_i, [_c_f] * 4 + [ctypes.c_longlong, _c_i, _c_f]),
     "upp_bias_gelu_bwd": (_c_i, [_c_f] * 4 + [ctypes.c_longlong, _c_i, _c_f]),
@@ -75,6 +78,8 @@ SIGNATURES = {
     "upp_adapter_bwd": (_c_i, [_c_f] * 6 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
     "upp_ln_adapter_fwd": (_c_i, [_c_f] * 4 + [ctypes.c_float, _c_i, _c_i, _c_f, _c_f, ctypes.c_float] + [_c_f] * 5 + [ctypes.c_float] * 2
                            + [_c_f] * 5 + [_c_i] * 5 + [_c_f]),
+    "upp_ln_adapter_fwd_parts": (_c_i, [_c_f] * 2 + [_c_i, ctypes.c_longlong] + [_c_f] * 2 + [ctypes.c_float, _c_i, _c_i, _c_f, _c_f, ctypes.c_float]
+                                 + [_c_f] * 5 + [ctypes.c_float] * 2 + [_c_f] * 5 + [_c_i] * 5 + [_c_f]),
     "upp_ln_adapter_bwd": (_c_i, [_c_f] * 10 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
     "upp_ln_adapter_part_floats": (ctypes.c_longlong, [_c_i, _c_i]),
     "upp_ln_adapter_bwd_fused": (_c_i, [_c_f] * 10 + [ctypes.c_float] * 2 + [_c_f, ctypes.c_float, _c_i, _c_i] + [_c_f] * 4 + [_c_i] * 5 + [_c_f]),

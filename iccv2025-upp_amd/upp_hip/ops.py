@@ -465,9 +465,19 @@ def linear_wgrad_grouped(pairs):
     return parts
 
 
+def _parts_of(t, inner_shape, what):
+    """(parts, stride) of a tensor given either in its plain shape or with a leading k-parts dimension (the output of linear_parts)."""
+    if t is None or t.dim() == len(inner_shape):
+        return 1, 0
+    if t.dim() != len(inner_shape) + 1 or tuple(t.shape[1:]) != tuple(inner_shape) or not t[0].is_contiguous() or t.stride(0) < t[0].numel():
+        raise RuntimeError(f"{what}: expected {tuple(inner_shape)} or (parts,) + that with contiguous parts, got {tuple(t.shape)}")
+    return int(t.shape[0]), int(t.stride(0))
+
+
 def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want_xo=True, ybias=None):
     B, Lin, D = x.shape
     dev = x.device
+    yparts, ystride = _parts_of(y, (B, Lin, D), "rowln_fwd y")
     xo = torch.empty((B, Lout, D), dtype=torch.float32, device=dev) if want_xo else None
     if gamma is not None:
         h = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
@@ -475,8 +485,8 @@ def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want
         rstd = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     else:
         h = mean = rstd = None
-    _call(dev, "upp_rowln_fwd", _abi.ptr(x), _abi.ptr(add), _abi.ptr(prompts), int(mode), int(P), _abi.ptr(y), _abi.ptr(ybias), _abi.ptr(u),
-          float(keep), _abi.ptr(gamma), _abi.ptr(beta), float(eps), _abi.ptr(xo), _abi.ptr(h), _abi.ptr(mean), _abi.ptr(rstd),
+    _call(dev, "upp_rowln_fwd_parts", _abi.ptr(x), _abi.ptr(add), _abi.ptr(prompts), int(mode), int(P), _abi.ptr(y), yparts, ystride, _abi.ptr(ybias),
+          _abi.ptr(u), float(keep), _abi.ptr(gamma), _abi.ptr(beta), float(eps), _abi.ptr(xo), _abi.ptr(h), _abi.ptr(mean), _abi.ptr(rstd),
           B, Lin, Lout, D)
     return xo, h, mean, rstd
 
@@ -490,7 +500,8 @@ def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, 
     if need_ln_part and g_h is not None:
         n = int(_abi.load().upp_rowln_part_floats(B, Lin, Lout, D, int(mode)))
         part = torch.empty((n // (2 * D), 2 * D), dtype=torch.float32, device=dev)     # per workgroup: [d_gamma | d_beta]
-    _call(dev, "upp_rowln_bwd", _abi.ptr(g_xo), _abi.ptr(g_h), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma),
+    gparts, gstride = _parts_of(g_h, (B, Lout, D), "rowln_bwd g_h")
+    _call(dev, "upp_rowln_bwd_parts", _abi.ptr(g_xo), _abi.ptr(g_h), gparts, gstride, _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma),
           int(mode), _abi.ptr(u), float(keep), _abi.ptr(g_x), _abi.ptr(g_p), _abi.ptr(g_y), _abi.ptr(part), B, Lin, Lout, D, P)
     return g_x, g_p, g_y, part
 
@@ -892,14 +903,13 @@ def ln_adapter_fwd(x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, 
         _need(t_, n_, torch.float32)
         if tuple(t_.shape) != shp:
             raise RuntimeError(f"ln_adapter_fwd: {n_} must be {shp}, got {tuple(t_.shape)}")
-    if y is not None and tuple(y.shape) != tuple(x.shape):
-        raise RuntimeError("ln_adapter_fwd: y must have the shape of x")
+    yparts, ystride = _parts_of(y, (B, Lin, D), "ln_adapter_fwd y")
     xo = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
     out = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
     mean = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     rstd = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     s1 = torch.empty((B * Lout, H), dtype=torch.float32, device=dev)
-    _call(dev, "upp_ln_adapter_fwd", _abi.ptr(x), _abi.ptr(y), _abi.ptr(ybias), _abi.ptr(u), float(keep), int(mode), int(P), _abi.ptr(gamma),
+    _call(dev, "upp_ln_adapter_fwd_parts", _abi.ptr(x), _abi.ptr(y), yparts, ystride, _abi.ptr(ybias), _abi.ptr(u), float(keep), int(mode), int(P), _abi.ptr(gamma),
           _abi.ptr(beta), float(eps), _abi.ptr(W1), _abi.ptr(b1), _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(ud), float(p), float(scale),
           _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(s1), _abi.ptr(out), B, Lin, Lout, D, H)
     return out, xo, mean, rstd, s1

@@ -107,9 +107,8 @@ def model():
     return _seeded.fill(m).eval().cuda()
 
 
-def _block_case(model, name):
+def _block_case(model, name, B=4):
     g = torch.Generator(device='cuda').manual_seed(3)
-    B = 4
     pts = _seeded.unit_ball_clouds(B, 1024, seed=2).cuda()
     with torch.no_grad():
         _, center = model.group_divider(pts)
@@ -151,6 +150,52 @@ def test_block_fused_equals_unfused_with_gradients(model, name):
         assert (g is None) == (r is None)
         if g is not None:
             close(g, r, rtol=5e-5, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize("name", ["down7", "rectify", "decoder"])
+def test_block_with_the_contraction_cut_over_workgroups_equals_the_plain_block(model, name, monkeypatch):
+    """At the benched batch (B = 32: 2,400 / 1,120 / 2,048 token rows) the fused block cuts its narrow products -- the fc2 output, the data
+    gradients of fc1 and qkv -- into k-parts that the row kernels / the block tail add while they read them (upp_linear_parts_f32,
+    upp_rowln_fwd_parts / upp_rowln_bwd_parts / upp_ln_adapter_fwd_parts).  Same block with the protocol switched off: outputs and every
+    gradient agree to f32 re-association (1e-5 of scale); and the parts ARE used at these sizes."""
+    blk, x, pos, kw = _block_case(model, name, B=32)
+    params = [p for n, p in blk.named_parameters() if ('adapter' in n or 'prompts' in n or 'bnorm' in n)]
+    frozen = [p for p in blk.parameters() if not any(p is q for q in params)]
+    for p in frozen:                                      # the PEFT recipe: qkv / proj / fc1 / fc2 / LayerNorms frozen
+        p.requires_grad_(False)
+    try:
+        _kparts_ab(blk, x, pos, kw, params, monkeypatch)
+    finally:
+        for p in frozen:
+            p.requires_grad_(True)
+
+
+def _kparts_ab(blk, x, pos, kw, params, monkeypatch):
+    from upp_hip import ops
+    calls = []
+    real = ops.linear_parts
+    monkeypatch.setattr(ops, "linear_parts", lambda a, w, parts=None: (calls.append((tuple(a.shape), tuple(w.shape), parts)), real(a, w, parts))[1])
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(upp_layers, "KPARTS", on)
+        if 'center1' in kw:
+            kw['_prop_cache'] = {}
+        xi, pi = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+        out = blk.forward_fused(xi, pi, **kw)
+        w = torch.linspace(-1, 1, out.numel(), device='cuda').view_as(out)
+        grads = torch.autograd.grad((out * w).sum(), [xi, pi] + params, allow_unused=True)
+        outs.append((out.detach(), grads))
+        if on:
+            cut = [c for c in calls if c[2] is None or c[2] > 1]
+            assert len(cut) >= 3, calls            # fc2 forward, fc1 and qkv data gradients
+        else:
+            assert len(calls) == n_on
+        n_on = len(calls)
+    close(outs[0][0], outs[1][0], rtol=1e-5, atol_scale=3e-6)
+    for g, r in zip(outs[0][1], outs[1][1]):
+        assert (g is None) == (r is None)
+        if g is not None:
+            close(g, r, rtol=2e-5, atol_scale=1e-5)
 
 
 def test_train_mode_drop_path_statistics(model):

@@ -27,8 +27,8 @@ def _run(model, golden, dev, rtol):
     assert sorted(grads) == list(g['grad_names'])
     norms = np.array([grads[n].norm().item() for n in g['grad_names']])
     np.testing.assert_allclose(norms, g['grad_norms'], rtol=20 * rtol, atol=1e-7)
-    np.testing.assert_allclose(grads['mask_token'].cpu().numpy(), g['g_mask_token'], rtol=20 * rtol, atol=1e-6)
-    np.testing.assert_allclose(grads['increase_dim.0.bias'].cpu().numpy(), g['g_increase_bias'], rtol=20 * rtol, atol=1e-7)
+    for got, ref in ((grads['mask_token'].cpu().numpy(), g['g_mask_token']), (grads['increase_dim.0.bias'].cpu().numpy(), g['g_increase_bias'])):
+        np.testing.assert_allclose(got, ref, rtol=20 * rtol, atol=4e-6 * np.abs(ref).max())
     for p in model.parameters():
         p.grad = None
 
@@ -58,7 +58,9 @@ def test_loss_and_gradients_match_reference(mae, oracle_ops, golden):
 def test_point_mae_on_gpu_matches_fixture_and_trains(mae, golden):
     m = mae.cuda()
     try:
-        _run(m, golden, 'cuda', 1e-4)
+        # measured on MI355X (tools/micro/recipe_tolerance.py): loss identical, gradient norms within 3.1e-5, the two gradient arrays within
+        # 1.9e-6 of their scale -> loss 1e-5, norms 2e-4, arrays 2e-4 + 4e-6 of scale
+        _run(m, golden, 'cuda', 1e-5)
         m.train()
         pts = _seeded.unit_ball_clouds(8, 1024, seed=2).cuda()
         opt = torch.optim.AdamW(m.parameters(), lr=1e-3)

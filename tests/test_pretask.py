@@ -82,7 +82,8 @@ def test_losses_and_gradients_match_reference(pretask, oracle_ops, golden):
 def test_pretask_on_gpu_matches_fixture_and_trains(pretask, golden):
     m = pretask.cuda()
     try:
-        _run(m, golden, 'cuda', 2e-4)
+        # measured on MI355X (tools/micro/recipe_tolerance.py): loss terms within 1.2e-7, gradient norms (> 1e-4) within 2.8e-4 -> 2e-5 / 1e-3
+        _run(m, golden, 'cuda', 2e-5)
         _seeded.fill(m).train()
         gt = _seeded.unit_ball_clouds(8, 1280, seed=3).cuda()
         partial, cropping = gt[:, :1024].contiguous(), gt[:, 1024:].contiguous()
