@@ -606,6 +606,16 @@ class Block(nn.Module):
                 cache[key] = entry
         else:
             entry = cache[key]
+        w8 = entry.w8
+        if not _no_grad_needed(c1, c2):
+            # stage 2 of the recipe: the centres carry a gradient back to the prompters, and the interpolation weights 1 / (d + eps)
+            # are functions of them -- one autograd node per forward (HF.prop_weights), shared by every block like the index itself
+            wkey = ('w8',) + key
+            w8 = None if cache is None else cache.get(wkey)
+            if w8 is None:
+                w8 = HF.prop_weights(c1, c2, entry, eps=1e-3)
+                if cache is not None:
+                    cache[wkey] = w8
         u, keep = None, 1.0
         if isinstance(self.drop_path, DropPath) and self.training and self.drop_path.drop_prob > 0:
             u = UNIFORMS.take((B * G2,), x.device)
@@ -614,10 +624,10 @@ class Block(nn.Module):
         if self.training and bn.track_running_stats:
             bump_counter(bn.num_batches_tracked)
         if bn.affine and (bn.track_running_stats or self.training) and B * Lp <= 15360 and not sync_bn_active(self.training):
-            return HF.propagate(x, bn, entry, u, keep, self.training)
+            return HF.propagate(x, bn, entry, u, keep, self.training, w8=w8)
         pooled = HF.prop_pool(x, entry.i1, u, keep)
         lc = _bn_rows(pooled, bn, self.training).view(B, G2, D)
-        return HF.prop_interp(x, lc, entry.i2, entry.idx8, entry.w8)
+        return HF.prop_interp(x, lc, entry.i2, entry.idx8, w8)
 
     def fusable(self, x):
         return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 512 and self.attn.fusable(x)
@@ -679,13 +689,10 @@ class Block(nn.Module):
         u2 = None if u is None else u[1]
         if P and kw.get('prompt_propagation_after'):
             x3, _ = HF.rowln(x2, y=m, ybias=mb, u=u2, keep=keep)
-            if kw['center1_idx'].numel() == B * kw['center2'].shape[1] * 8 and _no_grad_needed(kw['center1'], kw['center2']):
+            if kw['center1_idx'].numel() == B * kw['center2'].shape[1] * 8 and kw['center1'].dtype == torch.float32:
                 x3 = self._propagate_fused(x3, kw)
             else:
-                # (stage 2 of the recipe: the centres carry a gradient back to the prompters, and the interpolation weights
-                # 1 / (d + eps) are functions of them -- the fused kernels treat the weights as constants of the forward)
-                if not _no_grad_needed(kw['center1'], kw['center2']):
-                    HF.note_declined("Block prompt propagation", "the level-1 / level-2 centres require a gradient")
+                HF.note_declined("Block prompt propagation", "level-2 groups of other than 8 neighbours / centres not f32")
                 x3, _ = self._propagate_prompts(x3, kw)
             m, mb, u2, x2 = None, None, None, x3
         if adapter is None:

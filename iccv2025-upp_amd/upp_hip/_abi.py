@@ -72,6 +72,8 @@ SIGNATURES = {
     "upp_posenc_fwd": (_c_i, [_c_f, ctypes.POINTER(ctypes.c_float), _c_i, _c_f, _c_i, _c_i, ctypes.c_longlong, _c_f]),
     "upp_prop_part_floats": (ctypes.c_longlong, [_c_i] * 2),
     "upp_prop_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 7 + [ctypes.c_float] * 2 + [_c_i] + [_c_f] * 6 + [_c_i] * 5 + [_c_f]),
+    "upp_prop_w8_grad": (_c_i, [_c_f] * 10 + [_c_i] * 5 + [_c_f]),
+    "upp_prop_weights_bwd": (_c_i, [_c_f] * 4 + [ctypes.c_float] + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
     "upp_prop_bwd": (_c_i, [_c_f] * 7 + [ctypes.c_float] + [_c_f] * 7 + [_c_i] + [_c_f] * 5 + [_c_i] * 5 + [_c_f]),
     "upp_adapter_part_floats": (ctypes.c_longlong, [_c_i, _c_i]),
     "upp_adapter_fwd": (_c_i, [_c_f] * 7 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),

@@ -711,6 +711,122 @@ __global__ __launch_bounds__(256) void prop_index_kernel(const float *__restrict
     }
 }
 
+// Gradient of the step w.r.t. the interpolation weights (stage 2 of the recipe: the weights are functions of centres that carry a
+// gradient back to the prompters):  g_w8[b,i,k] = 0.3 * < g_out[b, L'-T+i, :], ctr[b, idx8[b,i,k], :] >,
+//   ctr[gj] = lc[gj] + 0.3 * X[i2[gj]],  lc = BatchNorm(pooled) (mean != null: pooled are pre-BatchNorm rows) or `pooled` itself.
+// One wavefront per (sample, level-1 centre); fixed summation order (lane partials in column order, then the wave tree).
+__global__ __launch_bounds__(256) void prop_w8_grad_kernel(const float *__restrict__ g_out, const float *__restrict__ X,
+                                                           const float *__restrict__ pooled, const float *__restrict__ mean,
+                                                           const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, const int32_t *__restrict__ i2,
+                                                           const int32_t *__restrict__ idx8, float *__restrict__ g_w8, int B, int Lp,
+                                                           int T, int G2, int D) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (tok >= B * T) return;
+    const int b = tok / T, i = tok - b * T;
+    const float *grow = g_out + ((size_t)b * Lp + (Lp - T) + i) * D;
+    int cc[kMaxE];
+    float gv[kMaxE], mu[kMaxE], rs[kMaxE], ga[kMaxE], be[kMaxE];
+#pragma unroll
+    for (int e = 0; e < kMaxE; ++e) {
+        const int c = lane + 64 * e;
+        cc[e] = min(c, D - 1);
+        gv[e] = c < D ? grow[cc[e]] : 0.0f;
+        mu[e] = 0.0f; rs[e] = 1.0f; ga[e] = 1.0f; be[e] = 0.0f;
+    }
+    if (mean) {
+#pragma unroll
+        for (int e = 0; e < kMaxE; ++e) { mu[e] = mean[cc[e]]; rs[e] = rstd[cc[e]]; ga[e] = gamma[cc[e]]; be[e] = beta[cc[e]]; }
+    }
+    int j[kNb], cr[kNb];
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) j[k] = idx8[(size_t)tok * kNb + k];
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) cr[k] = i2[b * G2 + j[k]];
+    float dot[kNb];
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) dot[k] = 0.0f;
+#pragma unroll
+    for (int h = 0; h < kMaxE; h += 4) {
+        float lv[4][kNb], cv[4][kNb];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) { lv[e][k] = pooled[((size_t)b * G2 + j[k]) * D + cc[h + e]]; cv[e][k] = X[(size_t)cr[k] * D + cc[h + e]]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < kNb; ++k) {
+                const float lcv = ((lv[e][k] - mu[h + e]) * rs[h + e]) * ga[h + e] + be[h + e];
+                dot[k] = __builtin_fmaf(gv[h + e], lcv + 0.3f * cv[e][k], dot[k]);
+            }
+        if (64 * (h + 4) >= D) break;
+    }
+    float mine = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kNb; ++k) { const float s = wave_sum_f32(dot[k]); if (lane == k) mine = 0.3f * s; }
+    if (lane < kNb) g_w8[(size_t)tok * kNb + lane] = mine;
+}
+
+// Backward of the weights themselves: w_k = r_k / S, r_k = 1 / (d_k + eps), S = sum_k r_k, d_k = |a - b_k|^2 in the reference's
+// square_distance form (a = level-1 centre, b_k = its k-th nearest level-2 centre).  With G_k the incoming gradient of w_k:
+//   dL/dd_k = -r_k^2 * (G_k - sum_j G_j w_j) / S,   dL/da = sum_k dL/dd_k * 2 (a - b_k),   dL/db_j = - sum over (i,k) with idx8 == j.
+// One workgroup of 64 threads per sample: phase 1 thread = level-1 centre (writes g_c1, leaves dL/dd in LDS), phase 2 thread =
+// level-2 centre, which walks the T*8 list in index order -- a fixed summation order, no atomics.
+__global__ __launch_bounds__(64) void prop_weights_bwd_kernel(const float *__restrict__ c1, const float *__restrict__ c2,
+                                                              const int32_t *__restrict__ idx8, const float *__restrict__ g_w8, float eps,
+                                                              float *__restrict__ g_c1, float *__restrict__ g_c2, int T, int G2) {
+    extern __shared__ float sh[];
+    float *gd = sh;                                    // [T * 8]
+    int *jj = reinterpret_cast<int *>(sh + (size_t)T * kNb);
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < T; i += 64) {
+        const float *a = c1 + ((size_t)b * T + i) * 3;
+        const float ax = a[0], ay = a[1], az = a[2];
+        float rc[kNb], G[kNb], dx[kNb], dy[kNb], dz[kNb], S = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) {
+            const int j = idx8[((size_t)b * T + i) * kNb + k];
+            jj[i * kNb + k] = j;
+            const float *q = c2 + ((size_t)b * G2 + j) * 3;
+            const float bx = q[0], by = q[1], bz = q[2];
+            float d = -2.0f * __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));     // the forward's operation order (prop_index_kernel)
+            d += (ax * ax + ay * ay) + az * az;
+            d += (bx * bx + by * by) + bz * bz;
+            rc[k] = 1.0f / (d + eps); S += rc[k];
+            dx[k] = ax - bx; dy[k] = ay - by; dz[k] = az - bz;
+            G[k] = g_w8[((size_t)b * T + i) * kNb + k];
+        }
+        float gw = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) gw = __builtin_fmaf(G[k], rc[k] / S, gw);
+        float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) {
+            const float t = -(rc[k] * rc[k]) * ((G[k] - gw) / S) * 2.0f;
+            gd[i * kNb + k] = t;
+            gx = __builtin_fmaf(t, dx[k], gx); gy = __builtin_fmaf(t, dy[k], gy); gz = __builtin_fmaf(t, dz[k], gz);
+        }
+        float *o = g_c1 + ((size_t)b * T + i) * 3;
+        o[0] = gx; o[1] = gy; o[2] = gz;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < G2; j += 64) {
+        const float *q = c2 + ((size_t)b * G2 + j) * 3;
+        const float bx = q[0], by = q[1], bz = q[2];
+        float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+        for (int e = 0; e < T * kNb; ++e) {
+            if (jj[e] != j) continue;
+            const float *a = c1 + ((size_t)b * T + e / kNb) * 3;
+            const float t = gd[e];
+            gx = __builtin_fmaf(-t, a[0] - bx, gx); gy = __builtin_fmaf(-t, a[1] - by, gy); gz = __builtin_fmaf(-t, a[2] - bz, gz);
+        }
+        float *o = g_c2 + ((size_t)b * G2 + j) * 3;
+        o[0] = gx; o[1] = gy; o[2] = gz;
+    }
+}
+
 }  // namespace
 
 extern "C" int upp_prop_index(const float *c1, const float *c2, const int64_t *i1, const int64_t *i2, int gather_idx, int B, int T,
@@ -824,5 +940,25 @@ extern "C" int upp_prop_bwd(const float *g_out, const float *pooled, const uint8
     hipLaunchKernelGGL(prop_bn_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, st, part, wgs, D, g_gamma, g_beta);
     hipLaunchKernelGGL(prop_x_csr_kernel, rows_grid((long long)B * Lp), dim3(256), 0, st, g_out, g_c2, pooled, amax, mean, rstd, gamma,
                        g_gamma, g_beta, u, keep, start1, perm1, start2, perm2, g_X, B * Lp, groups, D, training);
+    return upp_launch_status();
+}
+
+extern "C" int upp_prop_w8_grad(const float *g_out, const float *X, const float *pooled, const float *mean, const float *rstd,
+                                const float *gamma, const float *beta, const int32_t *i2, const int32_t *idx8, float *g_w8, int B, int Lp,
+                                int T, int G2, int D, void *stream) {
+    if (!g_out || !X || !pooled || !i2 || !idx8 || !g_w8 || B < 1 || Lp < T || T < 1 || G2 < 1 || D < 1) return UPP_E_BADARG;
+    if (mean && (!rstd || !gamma || !beta)) return UPP_E_BADARG;
+    if (D > 64 * kMaxE) return UPP_E_RANGE;
+    hipLaunchKernelGGL(prop_w8_grad_kernel, dim3((unsigned)(((long long)B * T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g_out, X, pooled,
+                       mean, rstd, gamma, beta, i2, idx8, g_w8, B, Lp, T, G2, D);
+    return upp_launch_status();
+}
+
+extern "C" int upp_prop_weights_bwd(const float *c1, const float *c2, const int32_t *idx8, const float *g_w8, float eps, float *g_c1,
+                                    float *g_c2, int B, int T, int G2, void *stream) {
+    if (!c1 || !c2 || !idx8 || !g_w8 || !g_c1 || !g_c2 || B < 1 || T < 1 || G2 < 1) return UPP_E_BADARG;
+    const size_t lds = (size_t)T * kNb * (sizeof(float) + sizeof(int));
+    if (lds > 64 * 1024) return UPP_E_RANGE;
+    hipLaunchKernelGGL(prop_weights_bwd_kernel, dim3((unsigned)B), dim3(64), lds, (hipStream_t)stream, c1, c2, idx8, g_w8, eps, g_c1, g_c2, T, G2);
     return upp_launch_status();
 }

@@ -733,23 +733,29 @@ class _PropPool(Function):
 
 
 class _PropInterp(Function):
-    """X (B,L',D), lc (B,G2,D) -> X with its last T rows += 0.3 * sum_k w8 * (lc + 0.3 * X[i2])[idx8]."""
+    """X (B,L',D), lc (B,G2,D) -> X with its last T rows += 0.3 * sum_k w8 * (lc + 0.3 * X[i2])[idx8].  w8 may carry a gradient."""
 
     @staticmethod
     def forward(ctx, X, lc, i2, idx8, w8):
         X, lc = X.contiguous(), lc.contiguous()
         B, Lp, D = X.shape
         T, G2 = idx8.shape[1], lc.shape[1]
-        ctx.save_for_backward(i2, idx8, w8)
+        w8 = w8.contiguous()
+        ctx.save_for_backward(i2, idx8, w8, *((X, lc) if ctx.needs_input_grad[4] else ()))
         ctx.meta = (B, Lp, T, G2)
         return ops.prop_interp_fwd(X, lc, i2, idx8, w8, B, Lp, T, G2)
 
     @staticmethod
     def backward(ctx, g):
-        i2, idx8, w8 = ctx.saved_tensors
+        i2, idx8, w8 = ctx.saved_tensors[:3]
         B, Lp, T, G2 = ctx.meta
-        g_c2, g_X = ops.prop_interp_bwd(g.contiguous(), i2, idx8, w8, B, Lp, T, G2)
-        return g_X, g_c2.view(B, G2, -1), None, None, None
+        g = g.contiguous()
+        g_c2, g_X = ops.prop_interp_bwd(g, i2, idx8, w8, B, Lp, T, G2)
+        g_w8 = None
+        if ctx.needs_input_grad[4]:
+            X, lc = ctx.saved_tensors[3:]
+            g_w8 = ops.prop_w8_grad(g, X, lc, None, i2, idx8, B, Lp, T, G2)
+        return g_X, g_c2.view(B, G2, -1), None, None, g_w8
 
 
 def prop_pool(X, i1, u=None, keep=1.0):
@@ -786,33 +792,64 @@ class PropIndex:
         return cls(t[0], t[1], t[2], t[3], rows, csr=((t[4], t[5]), (t[6], t[7]), (t[8], t[9])))
 
 
-class _Propagate(Function):
-    """Fused pool -> BatchNorm1d -> interpolate of one block (upp_prop_fwd / upp_prop_bwd)."""
+class _PropWeights(Function):
+    """The interpolation weights of a PropIndex as a differentiable function of the centres (stage 2 of the recipe: the point cloud, and so
+    the centres, carry a gradient back to the prompters).  Forward: the weights the index kernel computed (the reference's sort + 1/(d+eps)
+    normalisation, models/Point_MAE_unify.py:33-44); backward: upp_prop_weights_bwd.  The neighbour choice idx8 is piecewise constant."""
 
     @staticmethod
-    def forward(ctx, X, gamma, beta, index, u, keep, running_mean, running_var, momentum, eps, training):
+    def forward(ctx, c1, c2, idx8, w8, eps):
+        ctx.save_for_backward(c1, c2, idx8)
+        ctx.eps = eps
+        return w8.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        c1, c2, idx8 = ctx.saved_tensors
+        g1, g2 = ops.prop_weights_bwd(c1.contiguous(), c2.contiguous(), idx8, g.contiguous(), ctx.eps)
+        return g1, g2, None, None, None
+
+
+def prop_weights(c1, c2, index, eps=1e-3):
+    """index.w8 with the autograd edge to the centres c1 (B,T,3) / c2 (B,G2,3) it was built from."""
+    return _PropWeights.apply(c1, c2, index.idx8, index.w8, float(eps))
+
+
+class _Propagate(Function):
+    """Fused pool -> BatchNorm1d -> interpolate of one block (upp_prop_fwd / upp_prop_bwd; upp_prop_w8_grad when w8 carries a gradient)."""
+
+    @staticmethod
+    def forward(ctx, X, gamma, beta, index, u, keep, running_mean, running_var, momentum, eps, training, w8):
         X = X.contiguous()
         B, Lp, D = X.shape
-        out, pooled, amax, mean, rstd = ops.prop_fwd(X, index.i1, u, keep, index.i2, index.idx8, index.w8, gamma, beta, running_mean,
+        w8 = w8.contiguous()
+        out, pooled, amax, mean, rstd = ops.prop_fwd(X, index.i1, u, keep, index.i2, index.idx8, w8, gamma, beta, running_mean,
                                                      running_var, momentum, eps, training, B, Lp, index.T, index.G2)
-        ctx.save_for_backward(pooled, amax, mean, rstd, gamma, u)
+        ctx.save_for_backward(pooled, amax, mean, rstd, gamma, u, w8, *((X, beta) if ctx.needs_input_grad[11] else ()))
         ctx.meta = (index, keep, training, B, Lp)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        pooled, amax, mean, rstd, gamma, u = ctx.saved_tensors
+        pooled, amax, mean, rstd, gamma, u, w8 = ctx.saved_tensors[:7]
         index, keep, training, B, Lp = ctx.meta
-        g_X, g_gamma, g_beta = ops.prop_bwd(g.contiguous(), pooled, amax, mean, rstd, gamma, u, keep, index.w8, index.csr1, index.csr2,
+        g = g.contiguous()
+        g_X, g_gamma, g_beta = ops.prop_bwd(g, pooled, amax, mean, rstd, gamma, u, keep, w8, index.csr1, index.csr2,
                                             index.csr8, training, B, Lp, index.T, index.G2)
-        return (g_X, g_gamma, g_beta) + (None,) * 8
+        g_w8 = None
+        if ctx.needs_input_grad[11]:
+            X, beta = ctx.saved_tensors[7:]
+            g_w8 = ops.prop_w8_grad(g, X, pooled, (mean, rstd, gamma, beta), index.i2, index.idx8, B, Lp, index.T, index.G2)
+        return (g_X, g_gamma, g_beta) + (None,) * 8 + (g_w8,)
 
 
-def propagate(X, bn, index, u=None, keep=1.0, training=True):
-    """X (B,L',D) -> X with its last T rows += 0.3 * interp(bn(pool(X)) + 0.3 * X[i2]); bn: nn.BatchNorm1d (affine)."""
+def propagate(X, bn, index, u=None, keep=1.0, training=True, w8=None):
+    """X (B,L',D) -> X with its last T rows += 0.3 * interp(bn(pool(X)) + 0.3 * X[i2]); bn: nn.BatchNorm1d (affine).
+    w8: the interpolation weights when they carry a gradient (prop_weights), default index.w8 (constants of the forward)."""
     use_batch = training or bn.running_mean is None
     momentum = 0.0 if bn.momentum is None else bn.momentum
-    return _Propagate.apply(X, bn.weight, bn.bias, index, u, float(keep), bn.running_mean, bn.running_var, momentum, bn.eps, use_batch)
+    return _Propagate.apply(X, bn.weight, bn.bias, index, u, float(keep), bn.running_mean, bn.running_var, momentum, bn.eps, use_batch,
+                            index.w8 if w8 is None else w8)
 
 
 # ------------------------------------------------------------------ forward-only row operators (frozen prompter branches)

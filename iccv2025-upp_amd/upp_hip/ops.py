@@ -648,6 +648,37 @@ def prop_bwd(g_out, pooled, amax, mean, rstd, gamma, u, keep, w8, csr1, csr2, cs
     return g_X, g_gamma, g_beta
 
 
+def prop_w8_grad(g_out, X, pooled, bn_stats, i2, idx8, B, Lp, T, G2):
+    """Gradient w.r.t. the interpolation weights (B,T,8); bn_stats = (mean, rstd, gamma, beta) saved by prop_fwd, or None when `pooled`
+    already holds the post-BatchNorm rows (prop_interp).  See upp_prop_w8_grad."""
+    _need(g_out, "g_out", torch.float32)
+    _need(X, "X", torch.float32)
+    _need(pooled, "pooled", torch.float32)
+    D = g_out.shape[-1]
+    if g_out.numel() != B * Lp * D or X.numel() != B * Lp * D or pooled.numel() != B * G2 * D or idx8.numel() != B * T * 8 or i2.numel() != B * G2:
+        raise RuntimeError("prop_w8_grad: operand shapes do not match (B, L', T, G2, D)")
+    g_w8 = torch.empty((B, T, 8), dtype=torch.float32, device=g_out.device)
+    st = bn_stats if bn_stats is not None else (None, None, None, None)
+    _call(g_out.device, "upp_prop_w8_grad", _abi.ptr(g_out), _abi.ptr(X), _abi.ptr(pooled), _abi.ptr(st[0]), _abi.ptr(st[1]), _abi.ptr(st[2]),
+          _abi.ptr(st[3]), _abi.ptr(i2), _abi.ptr(idx8), _abi.ptr(g_w8), B, Lp, T, G2, D)
+    return g_w8
+
+
+def prop_weights_bwd(c1, c2, idx8, g_w8, eps):
+    """(g_c1 (B,T,3), g_c2 (B,G2,3)) from the gradient of the interpolation weights; see upp_prop_weights_bwd."""
+    _need(c1, "c1", torch.float32, ndim=3)
+    _need(c2, "c2", torch.float32, ndim=3)
+    _need(g_w8, "g_w8", torch.float32)
+    B, T, _ = c1.shape
+    G2 = c2.shape[1]
+    if c1.shape[2] != 3 or c2.shape[2] != 3 or c2.shape[0] != B or idx8.numel() != B * T * 8 or g_w8.numel() != B * T * 8 or idx8.dtype != torch.int32:
+        raise RuntimeError("prop_weights_bwd: operand shapes do not match")
+    g_c1, g_c2 = torch.empty_like(c1), torch.empty_like(c2)
+    _call(c1.device, "upp_prop_weights_bwd", _abi.ptr(c1), _abi.ptr(c2), _abi.ptr(idx8), _abi.ptr(g_w8), float(eps), _abi.ptr(g_c1), _abi.ptr(g_c2),
+          B, T, G2)
+    return g_c1, g_c2
+
+
 # ------------------------------------------------------------------ row operators of the frozen prompter branches
 def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, want_stats=False):
     _need(x, "x", torch.float32, ndim=2)

@@ -281,6 +281,17 @@ int upp_prop_bwd(const float *g_out, const float *pooled, const uint8_t *amax, c
                  const int32_t *perm1, const int32_t *start2, const int32_t *perm2, const int32_t *start8,
                  const int32_t *perm8, int training, float *g_c2, float *part, float *g_gamma, float *g_beta, float *g_X,
                  int B, int Lp, int T, int G2, int D, void *stream);
+/* Stage 2 of the recipe (run.sh:16, models/Point_MAE_unify.py:22-48 under autograd): the centres carry a gradient, so the
+ * interpolation weights w8 do too.
+ *   upp_prop_w8_grad    : g_w8 (B,T,8) = 0.3 * <g_out[token], lc[j] + 0.3 * X[i2[j]]>, j = idx8[token,k]; lc = BatchNorm(pooled) when
+ *                         mean / rstd / gamma / beta are given (the tensors upp_prop_fwd saved), `pooled` itself when mean == NULL.
+ *   upp_prop_weights_bwd: g_c1 (B,T,3), g_c2 (B,G2,3) from g_w8 through w = (1/(d+eps)) / sum, d = the reference's square_distance
+ *                         form (models/modules.py:13-32); idx8 is a constant of the forward.  Fixed summation order, no atomics. */
+int upp_prop_w8_grad(const float *g_out, const float *X, const float *pooled, const float *mean, const float *rstd,
+                     const float *gamma, const float *beta, const int32_t *i2, const int32_t *idx8, float *g_w8, int B, int Lp,
+                     int T, int G2, int D, void *stream);
+int upp_prop_weights_bwd(const float *c1, const float *c2, const int32_t *idx8, const float *g_w8, float eps, float *g_c1,
+                         float *g_c2, int B, int T, int G2, void *stream);
 
 /* ---- row operators of the prompter branches and the per-point heads ---------------------------------
  * Replace the element-wise / reduction chains of the reference's rectify prompter

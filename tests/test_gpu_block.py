@@ -403,6 +403,47 @@ def test_fused_propagation_matches_pool_batchnorm_interp(B, Lp, off, training, d
     assert torch.equal(a, b) and torch.equal(ga, gb)
 
 
+@pytest.mark.parametrize("is_cls,gather,training", [(True, False, True), (False, True, True), (True, False, False)])
+def test_fused_propagation_gradients_reach_the_centres(is_cls, gather, training):
+    """Stage 2 of the recipe: the centres require a gradient (they are functions of the prompted point cloud), and the interpolation weights
+    1/(d+eps) depend on them.  The fused step (HF.prop_weights + upp_prop_w8_grad) against the reference's torch formulation
+    (Block._propagate_prompts) in f32, arbitrated by the same formulation in f64: tokens, centre gradients, BatchNorm gradients."""
+    from models import upp_layers as L
+    torch.manual_seed(5 + is_cls)
+    B, T, D, P = 8, 64, 384, 10
+    dev = 'cuda'
+    blk = L.Block(D, 6).to(dev).train(training)
+    with torch.no_grad():
+        blk.bnorm.weight.copy_(torch.linspace(0.5, 1.5, D)); blk.bnorm.bias.copy_(torch.linspace(-0.2, 0.2, D))
+        blk.bnorm.running_mean.copy_(torch.linspace(-0.1, 0.4, D)); blk.bnorm.running_var.copy_(torch.linspace(0.6, 1.7, D))
+    state = {k: v.clone() for k, v in blk.bnorm.state_dict().items()}
+    c1 = (torch.rand(B, T, 3, device=dev) * 2 - 1)
+    Lp = T + P + (1 if is_cls else 0)
+    X = torch.randn(B, Lp, D, device=dev) * 0.7 + 0.3
+    wgt = torch.linspace(-1, 1, X.numel(), device=dev).view_as(X)
+    _, c2_const, i1, i2 = L.Group(T // 2, 8)(c1, require_index=True, gather_idx=gather)
+    pick = (i2.view(B, -1) - (0 if gather else torch.arange(B, device=dev).view(B, 1) * T)).long()
+
+    def run(kind, dtype):
+        blk.bnorm.load_state_dict(state)
+        blk.to(dtype)
+        a = c1.to(dtype).requires_grad_(True)
+        b = torch.gather(a, 1, pick.unsqueeze(-1).expand(-1, -1, 3)) * 1.0      # level-2 centres: a differentiable selection of the level-1 ones
+        x = X.to(dtype).requires_grad_(True)
+        kw = dict(center1=a, center1_idx=i1, center2=b, center2_idx=i2, gather_idx=gather, classification=is_cls, _prop_cache={})
+        out = blk._propagate_fused(x, kw) if kind == 'fused' else blk._propagate_prompts(x, kw)[0]
+        grads = torch.autograd.grad((out * wgt.to(dtype)).sum(), [x, a, blk.bnorm.weight, blk.bnorm.bias])
+        blk.float()
+        return [out.detach().double()] + [g.double() for g in grads]
+
+    fused, plain, exact = run('fused', torch.float32), run('plain', torch.float32), run('plain', torch.float64)
+    assert float(exact[2].abs().max()) > 1e-3                               # the centre gradient is not trivially zero
+    for name, f, p_, e in zip(("tokens", "g_tokens", "g_centres", "g_bn_weight", "g_bn_bias"), fused, plain, exact):
+        scale = float(e.abs().max())
+        err_f, err_p = float((f - e).abs().max()) / scale, float((p_ - e).abs().max()) / scale
+        assert err_f <= max(2.0 * err_p, 2e-6), (name, err_f, err_p)
+
+
 def test_batched_sum_and_deferred_scope():
     from upp_hip import ops
     g = torch.Generator(device='cuda').manual_seed(1)
