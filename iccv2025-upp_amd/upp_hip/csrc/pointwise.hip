@@ -279,6 +279,84 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
     }
 }
 
+// Tall matrices (the 65,536-row activations of the per-point heads), C % 256 == 0: a wave owns 256 consecutive columns -- one 1 KB
+// row segment per load instruction -- and walks down the rows with the column parameters in registers (the flat kernels above spend
+// 16-24 dword parameter loads per 16 bytes of payload and read at a third of the HBM rate).  Block = 4 waves on 4 interleaved rows
+// of the same 256 columns, kTallRows rows per block, 8 row loads in flight per lane.  Same expressions: same bits as the flat kernels.
+constexpr int kTallRows = 32;
+
+template <bool NT>
+__global__ __launch_bounds__(256) void bn_rows_apply_tall_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                                 const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, int relu, float *__restrict__ y, int R,
+                                                                 int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.y * 256 + lane * 4;
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + c0), rs = *reinterpret_cast<const float4 *>(rstd + c0);
+    const float4 ga = gamma ? *reinterpret_cast<const float4 *>(gamma + c0) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    const float4 be = beta ? *reinterpret_cast<const float4 *>(beta + c0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int r0 = blockIdx.x * kTallRows + wave;
+    constexpr int U = kTallRows / 4;
+    float4 v[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const size_t o = (size_t)min(r0 + 4 * j, R - 1) * C + c0;
+        v[j] = NT ? nt_load4(x + o) : *reinterpret_cast<const float4 *>(x + o);
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        if (r0 + 4 * j >= R) break;
+        float o0 = ((v[j].x - mu.x) * rs.x) * ga.x + be.x, o1 = ((v[j].y - mu.y) * rs.y) * ga.y + be.y;
+        float o2 = ((v[j].z - mu.z) * rs.z) * ga.z + be.z, o3 = ((v[j].w - mu.w) * rs.w) * ga.w + be.w;
+        if (relu) { o0 = fmaxf(o0, 0.0f); o1 = fmaxf(o1, 0.0f); o2 = fmaxf(o2, 0.0f); o3 = fmaxf(o3, 0.0f); }
+        float *dst = y + (size_t)(r0 + 4 * j) * C + c0;
+        if (NT) nt_store4(dst, o0, o1, o2, o3); else *reinterpret_cast<float4 *>(dst) = make_float4(o0, o1, o2, o3);
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void bn_rows_bwd_apply_tall_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                                     const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                     const float *__restrict__ g_gamma, const float *__restrict__ g_beta,
+                                                                     int relu, float inv_rows, float *__restrict__ g_x, int R, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.y * 256 + lane * 4;
+    const float4 mu4 = *reinterpret_cast<const float4 *>(mean + c0), rs4 = *reinterpret_cast<const float4 *>(rstd + c0);
+    const float4 ga4 = gamma ? *reinterpret_cast<const float4 *>(gamma + c0) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    const float4 be4 = beta ? *reinterpret_cast<const float4 *>(beta + c0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 gg4 = *reinterpret_cast<const float4 *>(g_gamma + c0), gb4 = *reinterpret_cast<const float4 *>(g_beta + c0);
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w}, ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
+    const float be[4] = {be4.x, be4.y, be4.z, be4.w}, gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, gb[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
+    const int r0 = blockIdx.x * kTallRows + wave;
+    constexpr int U = kTallRows / 8;                           // two streams: 2 x 4 row loads in flight per lane, twice
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 xv[U], gv[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const size_t o = (size_t)min(r0 + 4 * (h * U + j), R - 1) * C + c0;
+            xv[j] = NT ? nt_load4(x + o) : *reinterpret_cast<const float4 *>(x + o);
+            gv[j] = NT ? nt_load4(g + o) : *reinterpret_cast<const float4 *>(g + o);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int r = r0 + 4 * (h * U + j);
+            if (r >= R) break;
+            const float xs[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, gs[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float xh = (xs[q] - mu[q]) * rs[q];
+                const float gm = (relu && !(xh * ga[q] + be[q] > 0.0f)) ? 0.0f : gs[q];
+                o[q] = (ga[q] * rs[q]) * (gm - (gb[q] + xh * gg[q]) * inv_rows);
+            }
+            float *dst = g_x + (size_t)r * C + c0;
+            if (NT) nt_store4(dst, o[0], o[1], o[2], o[3]); else *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // ---- k nearest source points per query, in the reference's square_distance form ----------------------------------
 // dist[row][0..k) / idx[row][0..k) = the k smallest  d = |a|^2 + |b|^2 - 2 a.b  over the S source points of the query's
 // cloud, ascending (d, index) -- what `square_distance(xyz1, xyz2).sort(dim=-1)` followed by `[:, :, :k]` yields in the
@@ -620,6 +698,12 @@ extern "C" int upp_bn_rows_fwd(const float *x, const float *gamma, const float *
     }
     upp_bn_finalize_launch(part, slabs, per, R, C, training, momentum, eps, running_mean, running_var, mean, rstd, st);
     const long long total = (long long)R * C;
+    if (C % 256 == 0 && R >= 4096) {
+        const dim3 grid((unsigned)((R + kTallRows - 1) / kTallRows), (unsigned)(C / 256));
+        if (total >= kStreamElems) hipLaunchKernelGGL(bn_rows_apply_tall_kernel<true>, grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y, R, C);
+        else hipLaunchKernelGGL(bn_rows_apply_tall_kernel<false>, grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y, R, C);
+        return upp_launch_status();
+    }
     hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y,
                        total, C, total >= kStreamElems ? 1 : 0);
     return upp_launch_status();
@@ -635,6 +719,16 @@ extern "C" int upp_bn_rows_bwd(const float *x, const float *g, const float *mean
     hipLaunchKernelGGL(bn_rows_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64 * kBnWaves), 0, st, part, slabs, C, g_gamma, g_beta);
     if (g_x) {
         const long long total = (long long)R * C;
+        if (C % 256 == 0 && R >= 4096) {
+            const dim3 grid((unsigned)((R + kTallRows - 1) / kTallRows), (unsigned)(C / 256));
+            if (total >= kStreamElems)
+                hipLaunchKernelGGL(bn_rows_bwd_apply_tall_kernel<true>, grid, dim3(256), 0, st, x, g, mean, rstd, gamma, beta, g_gamma, g_beta, relu,
+                                   1.0f / (float)R, g_x, R, C);
+            else
+                hipLaunchKernelGGL(bn_rows_bwd_apply_tall_kernel<false>, grid, dim3(256), 0, st, x, g, mean, rstd, gamma, beta, g_gamma, g_beta, relu,
+                                   1.0f / (float)R, g_x, R, C);
+            return upp_launch_status();
+        }
         hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, g, mean, rstd, gamma, beta,
                            g_gamma, g_beta, relu, 1.0f / (float)R, g_x, total, C, total >= kStreamElems ? 1 : 0);
     }
