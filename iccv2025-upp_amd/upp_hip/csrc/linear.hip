@@ -365,6 +365,46 @@ int pick_rt(int M, int N, int K) {
     return tiles >= 1024 && N >= 128 && K >= 32 ? kRtTall : 0;      // at least two rounds of the 512 resident workgroups
 }
 
+// Problems that fit no decomposition into one round of 256 workgroups and are not tall enough for pick_rt (the Transformer blocks at
+// 2,700 ... 9,000 token rows: part segmentation 4,416, the auxiliary-task recipes 4,128 / 4,448): estimate, per candidate,
+//   rounds x (MFMA time of the SIMD's share of a CU's resident workgroups + prologue / epilogue that nothing covers),
+// rounds = ceil(workgroups / (256 x resident workgroups per CU)) -- 64 KB workgroups (8 waves, and linear_rt.hip's 4 waves of 2 x 2
+// blocks) sit two to a CU and cover each other's prologue / epilogue, 96-128 KB ones sit alone and pay ~5 us per round.  Fitted to
+// tools/time_linear.py --tiles --rows 2720,3072,4128,4416,6144,8832 (ranks the measured order within ~10 %); the cost model of
+// pick_config -- made for one round -- took (1,2,4,128) at fc1 x 4,416 rows: 76.5 us against 51.8 for (2,2,2,64) chosen here.
+int pick_multi_round(int M, int N, int K) {
+    const int mb = (M + 31) / 32, nb = (N + 31) / 32;
+    int best = 0;
+    double best_t = 0.0;
+    auto consider = [&](int code, long long wgs, int per_cu, int waves_per_simd, int blocks_per_wave, long long ksteps, double overhead_us) {
+        const long long rounds = (wgs + 256LL * per_cu - 1) / (256LL * per_cu);
+        const double mfma_us = (double)per_cu * waves_per_simd * blocks_per_wave * (double)ksteps * 1024.0 / 2400.0;   // 16 MFMAs x 64 cycles per k-step
+        const double t = (double)rounds * (mfma_us + overhead_us);
+        if (!best || t < best_t) { best = code; best_t = t; }
+    };
+    for (int i = 0; i < kNumConfigs; ++i) {
+        const LinConfig c = kConfigs[i];
+        const int waves = c.bmb * c.bnb * c.ks;
+        const long long wgs = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
+        const long long ksteps = (K + 32 * c.ks * c.kc - 1) / (32 * c.ks * c.kc) * c.kc;
+        // measured per-round residue: 5 us alone on the CU, 3 us with a partner, 5.5 us for the two-block tile whose partner is as short
+        consider(config_code(c), wgs, waves <= 8 ? 2 : 1, (waves + 3) / 4, 1, ksteps, waves > 8 ? 5.0 : (c.bmb * c.bnb >= 4 ? 3.0 : 5.5));
+    }
+    if (N >= 128 && K >= 32) consider(kRtTall, (long long)((M + 127) / 128) * ((N + 127) / 128), 2, 1, 4, (K + 31) / 32, 3.0);
+    return best;
+}
+
+// The decomposition upp_linear_f32 uses when the caller leaves the choice to it (tile <= 0), as a tile code.
+int pick_code(int M, int N, int K) {
+    if (const int rt = pick_rt(M, N, K)) return rt;
+    const int i = pick_config(M, N, K);
+    if (i < 0) return 0;
+    const LinConfig c = kConfigs[i];
+    const int mb = (M + 31) / 32, nb = (N + 31) / 32;
+    const long long wgs = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
+    return wgs <= 256 ? config_code(c) : pick_multi_round(M, N, K);
+}
+
 // Narrow outputs over a long contraction (fc2, the data gradients of fc1 and qkv: N = 384, K = 1152 ... 1536 at 1,120 ... 4,448 rows): one
 // round of 256 workgroups needs 64 x 64 tiles with the contraction split over the wave groups of a workgroup -- 128 staged rows per 4
 // blocks, four LDS-DMA instructions per wave and 16 MFMAs: measured 68 % MFMA duty in the k-loop (fc2 at M = 2400: 71,700 cycles for
@@ -403,10 +443,8 @@ extern "C" void upp_linear_set_stamps(unsigned long long *p) { g_lin_stamps = p;
 extern "C" int upp_linear_tile(int M, int N, int K) {
     if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
     if (K % 4 != 0) return UPP_E_RANGE;
-    if (const int rt = pick_rt(M, N, K)) return rt;
-    const int i = pick_config(M, N, K);
-    if (i < 0) return UPP_E_RANGE;
-    return config_code(kConfigs[i]);
+    const int code = pick_code(M, N, K);
+    return code ? code : UPP_E_RANGE;
 }
 
 extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias, float *C, long long ldc,
@@ -425,13 +463,9 @@ extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, lon
     g.stamps = g_lin_stamps;
 #endif
     hipStream_t st = (hipStream_t)stream;
-    if (tile <= 0) tile = pick_rt(M, N, K);
+    if (tile <= 0) tile = pick_code(M, N, K);
+    if (tile <= 0) return UPP_E_RANGE;
     if (tile & 0x10000) return upp_detail_linear_rt(&g, tile, st);
-    if (tile <= 0) {
-        const int i = pick_config(M, N, K);
-        if (i < 0) return UPP_E_RANGE;
-        tile = config_code(kConfigs[i]);
-    }
     g.ktail = K % (32 * ((tile >> 4) & 15) * (tile & 15)) != 0;
 #define UPP_LIN_CASE(a, b, c, d) case a * 4096 + b * 256 + c * 16 + d: return launch_linear<a, b, c, d>(g, st);
     switch (tile) {

@@ -1,7 +1,7 @@
 """upp_linear_f32 against the library GEMM (torch F.linear -> hipBLASLt) at the Transformer-block shapes:
 correctness vs an f64 reference and device time per call (HIP-graph replay, HIP events).
 
-    python tools/time_linear.py [--tiles] [--tuned]
+    python tools/time_linear.py [--tiles] [--tuned] [--rows M[,M...]]     (--rows: the five block shapes at other token counts)
 """
 import argparse
 import json
@@ -24,7 +24,7 @@ SHAPES = [  # (name, M, N, K)
     ("qkv_2048", 2048, 1152, 384), ("fc1_2048", 2048, 1536, 384), ("fc2_2048", 2048, 384, 1536),
     ("qkv_1120", 1120, 1152, 384), ("proj_1120", 1120, 384, 384), ("fc1_1120", 1120, 1536, 384), ("fc2_1120", 1120, 384, 1536),
 ]
-TILES = [0x4412, 0x4311, 0x3411, 0x2421, 0x2321, 0x2241, 0x1241, 0x2221]
+TILES = [0x4412, 0x4311, 0x3411, 0x2421, 0x2321, 0x2241, 0x1241, 0x2221, 0x2512211]      # the last: linear_rt.hip's register-tiled kernel
 
 
 def main():
@@ -32,7 +32,12 @@ def main():
     ap.add_argument("--tiles", action="store_true", help="time every wave-tile shape, not only the library's choice")
     ap.add_argument("--tuned", action="store_true", help="library GEMM with TunableOp-selected solutions")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "time_linear.json"))
+    ap.add_argument("--rows", default="", help="comma-separated row counts: time qkv / proj / fc1 / fc2 / dqkv at these instead")
     args = ap.parse_args()
+    global SHAPES
+    if args.rows:
+        SHAPES = [("%s_%d" % (n, int(m)), int(m), N, K) for m in args.rows.split(",")
+                  for n, N, K in (("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536), ("dqkv", 384, 1152))]
     dev = torch.device("cuda", 0)
     if args.tuned:                      # the library side of the comparison with TunableOp-selected solutions (measurement only)
         os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"; os.environ["PYTORCH_TUNABLEOP_TUNING"] = "1"
@@ -64,7 +69,7 @@ def main():
                "err_ours": err, "err_lib": err_lib, "err_gelu": err_g}
         if args.tiles:
             for t in TILES:
-                if K % (32 * ((t >> 4) & 15) * (t & 15)):
+                if not (t & 0x10000) and K % (32 * ((t >> 4) & 15) * (t & 15)):
                     continue
                 row["us_tile_%x" % t] = time_kernel(lambda: ops.linear_f32(a, w, out=out, tile=t)) * 1e3
         rows.append(row)
