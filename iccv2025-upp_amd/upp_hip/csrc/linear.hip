@@ -35,7 +35,7 @@ namespace {
 
 #include "linear_shared.h"
 
-template <int BMB, int BNB, int KS, int KC, bool TAIL>
+template <int BMB, int BNB, int KS, int KC, bool TAIL, bool PARTS = false>
 __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g) {
     constexpr int NW = BMB * BNB * KS, BM = BMB * 32, BN = BNB * 32;
     constexpr int ROWS = (BM + BN) * KS * KC;       // 128-byte row images per stage: [ks][kc][A rows | W rows]
@@ -55,14 +55,15 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     const int nwg = gridDim.x;
     const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, rem = nwg & 7;
     const int lin = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (orig >> 3);
-    // row-panel order; with the contraction cut over workgroups (kparts > 1): row panel, then k-part, then column tile -- neighbours
-    // share the A rows AND the k-range of their row panel
-    const int per_panel = g.tiles_n * g.kparts;
+    // row-panel order; with the contraction cut over workgroups (PARTS): row panel, then k-part, then column tile -- neighbours share the
+    // A rows AND the k-range of their row panel.  A separate instantiation: the three runtime divisions and the per-part pointers cost the
+    // whole-contraction kernels 5-15 % when compiled into them (fc2 at 2,400 rows 29.7 -> 34.2 us, measured on one box).
+    const int per_panel = PARTS ? g.tiles_n * g.kparts : g.tiles_n;
     const int by = lin / per_panel, rem_p = lin - by * per_panel;
-    const int kp = rem_p / g.tiles_n, bx = rem_p - kp * g.tiles_n;
+    const int kp = PARTS ? rem_p / g.tiles_n : 0, bx = PARTS ? rem_p - kp * g.tiles_n : rem_p;
     const int m0 = by * BM, n0 = bx * BN;
     const int M = g.M, N = g.N;
-    const int Kc = g.K / g.kparts;                                   // (kparts > 1: a whole number of k-stages, checked by the host)
+    const int Kc = PARTS ? g.K / g.kparts : g.K;                     // (PARTS: a whole number of k-stages, checked by the host)
     const int ks = wave / (BMB * BNB), wb = wave - ks * (BMB * BNB);
     const int bm = wb / BNB, bn = wb - bm * BNB;
 
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
         const int row = min(first + (lane >> 3), last);
         const int ko = sk * 32 + 4 * ((lane & 7) ^ (((rho0 >> 1) + (lane >> 4)) & 7));
         if constexpr (TAIL) koff[q] = ko;
-        src[q] = base + row * ld + ko + kp * Kc;
+        src[q] = PARTS ? base + row * ld + ko + kp * Kc : base + row * ld + ko;
     }
     static_assert(KC != 1 || TPW <= 6, "DMA slots of the interleaved schedule");
     auto issue1 = [&](int q, int stage, int c) {            // q-th DMA instruction of this wave for k-stage c
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     const int T0 = ks * TN;
     const int rb = m0 + bm * 32, cb = n0 + bn * 32;                         // (scalar) block origin
     const bool wide = ((g.ldc | N | g.ldaux) & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.aux)) & 15) == 0;
-    g.C += kp * g.part_stride;                                       // (this workgroup's partial output)
+    if constexpr (PARTS) g.C += kp * g.part_stride;                  // (this workgroup's partial output)
     if (wide) {
         __syncthreads();                                     // all fragment reads done: the stages may be overwritten
         float *red = reinterpret_cast<float *>(lds);
@@ -312,6 +313,13 @@ int launch_linear(const LinArgs &g0, hipStream_t st) {
     g.tiles_n = (g.N + BNB * 32 - 1) / (BNB * 32);
     if (g.kparts < 1) g.kparts = 1;
     const dim3 grid((unsigned)(tiles_m * g.tiles_n * g.kparts));
+    if constexpr (KS == 1) {                                 // (only whole-contraction-per-wave tiles are cut over workgroups: pick_parts)
+        if (g.kparts > 1) {
+            if (g.ktail) return UPP_E_RANGE;
+            hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC, false, true>), grid, dim3(BMB * BNB * KS * 64), 0, st, g);
+            return upp_launch_status();
+        }
+    } else if (g.kparts > 1) return UPP_E_RANGE;
     if (g.ktail) hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC, true>), grid, dim3(BMB * BNB * KS * 64), 0, st, g);
     else hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC, false>), grid, dim3(BMB * BNB * KS * 64), 0, st, g);
     return upp_launch_status();

@@ -33,8 +33,8 @@ if [ "$PART" = "recipes" ]; then
 # secondary recipes: un-profiled lines + one kernel summary for the pre-training step (8 executions: 2 eager + 1 replay + 5 timed)
 for w in cls_aux stage2 pretask pretrain seg; do python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > $O/r03_workload_$w.json 2> $O/w_$w.err; done
 python3 bench.py --workload seg --steps 10 --warmup 3 --no-cpu-baseline --no-pipeline --no-stage-report > $O/r03_workload_seg_sequential.json 2>> $O/w_seg.err
-# kernel summaries of the two recipes that used to run library GEMMs (8 executions of the step each: 2 eager + 1 replay + 5 timed; one stream)
-for w in pretrain seg; do
+# kernel summaries of the recipes that used to run library GEMMs / unfused torch formulations (8 executions of the step each: 2 eager + 1 replay + 5 timed; one stream)
+for w in pretrain seg stage2; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_$w -- python3 bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline --no-pipeline --no-stage-report > $O/p_$w.log 2>&1
   cp "$(stats $O/p_$w)" $O/r03_workload_${w}_kernel_stats.csv
   rm -rf $O/p_$w
@@ -43,6 +43,11 @@ python3 tools/micro/time_linear_tall.py --tuned 2> /dev/null | grep -v amdgpu.id
 ./tools/micro/bin/rt_bench 100 tall > $O/r03_rt_bench.txt 2>&1
 ./tools/micro/bin/rt_bench 30 wgrad >> $O/r03_rt_bench.txt 2>&1
 python3 tools/glue_census_recipe.py seg 2> /dev/null | grep -v amdgpu.ids > $O/r03_glue_census_seg.txt
+python3 tools/glue_census_recipe.py stage2 2> /dev/null | grep -v amdgpu.ids > $O/r03_glue_census_stage2.txt
+python3 tools/micro/time_bn_rows.py 50 2> /dev/null | grep -v amdgpu.ids > $O/r03_time_bn_rows.txt
+python3 tools/linear_calls.py seg 2> /dev/null | grep -v amdgpu.ids > $O/r03_linear_calls_seg.txt
+python3 tools/linear_calls.py headline 2> /dev/null | grep -v amdgpu.ids > $O/r03_linear_calls_headline.txt
+python3 tools/time_linear.py --tiles --rows 2720,4128,4416,8832 --out $O/time_linear_rows.json > $O/r03_time_linear_rows.jsonl 2> /dev/null
 python3 tools/time_linear.py --tiles > $O/r03_time_linear.jsonl 2> /dev/null
 python3 tools/_fmt_linear.py $O/r03_time_linear.jsonl > $O/r03_time_linear.txt
 python3 tools/time_attention.py 2> /dev/null | grep -v amdgpu.ids > $O/r03_time_attention.txt
