@@ -44,7 +44,7 @@ class Point_MAE_unify_seg(PromptedBackbone):
     def _label_feature(self, cls_label):
         """label_conv on the (B,16) one-hot object class -> (B,128); BatchNorm over the batch."""
         c1, b1, a1, c2, b2, a2 = self.label_conv
-        x = cls_label.reshape(cls_label.shape[0], 16).float()
+        x = cls_label.reshape(cls_label.shape[0], 16).to(self.label_conv[0].weight.dtype)      # (.float() in the reference; f64 in the tests' arbitration runs)
         for conv, bn, act in ((c1, b1, a1), (c2, b2, a2)):
             if self.training and bn.track_running_stats:
                 L.bump_counter(bn.num_batches_tracked)

@@ -847,7 +847,7 @@ class PointNetSetAbstraction(nn.Module):
 
     def forward(self, xyz, points):
         B, N, _ = xyz.shape
-        _, center, idx, _ = self.group_divider(xyz.float(), require_index=True)
+        _, center, idx, _ = self.group_divider(xyz if xyz.dtype == torch.float64 else xyz.float(), require_index=True)   # (f64: arbitration runs of the tests)
         x = points.reshape(B * N, -1)[idx]                              # (B*G*k, C) rows
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
             x = _pointwise_bn_relu(x, conv, bn, self.training)

@@ -156,6 +156,74 @@ def gen_seg_train(R, out_dir):
           sum(1 for _, p in seg.named_parameters() if p.requires_grad), os.path.getsize(os.path.join(out_dir, "upp_seg_train.npz")) // 1024, "KiB")
 
 
+class _keep_f64:
+    """The reference calls `.float()` on coordinates in a few places (models/Point_MAE_pretask_dev.py:411); inside this scope a float64
+    tensor stays float64 there, so that `.double()` models really evaluate in f64.  Generator-side only; the reference is not edited."""
+
+    def __enter__(self):
+        self.orig = torch.Tensor.float
+        orig = self.orig
+        torch.Tensor.float = lambda t, *a, **k: t if t.dtype == torch.float64 else orig(t, *a, **k)
+
+    def __exit__(self, *exc):
+        torch.Tensor.float = self.orig
+        return False
+
+
+def gen_seg_train_f64(R, out_dir):
+    """upp_seg_train_f64.npz: the SAME step as gen_seg_train with the reference's class converted to float64 (`.double()`; the shimmed
+    FPS / kNN take the f32 image of the coordinates, so the index sets are those of the f32 run) -- the arbiter for tests that compare
+    two f32 evaluations of an ill-conditioned step (train-mode BatchNorm over 2 x 2048 rows, ReLU gates): loss, all gradient norms, the
+    kept / sampled gradient arrays, as float64."""
+    seg = R.MODELS.build(ref_shim.model_cfg('unify_shapenetpart_seg'))
+    deterministic_train_mode(_seeded.fill(seg))
+    for name, p in seg.named_parameters():
+        p.requires_grad_(any(k in name for k in SEG_PEFT))
+    seg = seg.double()
+    spts, lpts, onehot, tgt = seg_train_inputs()
+    with _keep_f64():
+        logp = seg(spts.double(), onehot.double(), label_points=lpts.double(), completion_prompt=True, denoise=True, point_num=1536)
+        loss = seg.get_loss(logp.reshape(-1, 50), tgt.reshape(-1))
+        loss.backward()
+    grads = {n: p.grad for n, p in seg.named_parameters() if p.requires_grad and p.grad is not None}
+    assert all(g.dtype == torch.float64 for g in grads.values()) and logp.dtype == torch.float64
+    names = sorted(grads)
+    keep = {"grad::" + k: grads[k].numpy() for k in SEG_KEEP}
+    keep.update({"sampled::" + k: grads[k].squeeze(-1)[::16, ::16].contiguous().numpy() for k in SEG_SAMPLED})
+    path = os.path.join(out_dir, "upp_seg_train_f64.npz")
+    np.savez_compressed(path, logp_head=logp[:, :256].detach().numpy(), loss=loss.detach().numpy(), grad_names=np.array(names),
+                        grad_norms=np.array([grads[n].norm().item() for n in names], dtype=np.float64), **keep)
+    print("seg train (f64) loss", loss.item(), "tensors", len(names), os.path.getsize(path) // 1024, "KiB")
+
+
+def gen_stage2_f64(R, out_dir):
+    """upp_stage2_f64.npz: gen_stage2 with the reference's class in float64 (same index sets): loss, logits, gradient norms and the kept
+    arrays as float64 -- the arbiter for the geometry-path gradients, where two f32 evaluations differ through max-pool arg-max flips."""
+    model = R.MODELS.build(ref_shim.model_cfg())
+    _seeded.fill(model).eval()
+    for name, p in model.named_parameters():
+        p.requires_grad_(any(k in name for k in STAGE2_KEYS))
+    model = model.double()
+    with _keep_f64():
+        logits = model(_seeded.noisy_clouds(2, 1024, seed=0).double(), completion_prompt=True, denoise=True, point_num=1024)
+        loss, _ = model.get_loss_acc(logits, torch.tensor([3, 17]))
+        loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    assert all(g.dtype == torch.float64 for g in grads.values())
+    names = sorted(grads)
+    path = os.path.join(out_dir, "upp_stage2_f64.npz")
+    keep = {}
+    for k in STAGE2_KEEP:                                  # arrays above 64 KiB: every 4th row / column (the norms cover the rest)
+        a = grads[k].numpy()
+        if a.nbytes > 65536:
+            keep["sampled4::" + k] = np.ascontiguousarray(a[::4, ::4])
+        else:
+            keep["grad::" + k] = a
+    np.savez_compressed(path, logits=logits.detach().numpy(), loss=loss.detach().numpy(), grad_names=np.array(names),
+                        grad_norms=np.array([grads[n].norm().item() for n in names], dtype=np.float64), **keep)
+    print("stage2 (f64) loss", loss.item(), "tensors", len(names), os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -168,6 +236,12 @@ def main():
         return
     if sys.argv[1:] == ['seg_train']:
         gen_seg_train(R, os.path.join(ROOT, "tests", "golden"))
+        return
+    if sys.argv[1:] == ['seg_train_f64']:
+        gen_seg_train_f64(R, os.path.join(ROOT, "tests", "golden"))
+        return
+    if sys.argv[1:] == ['stage2_f64']:
+        gen_stage2_f64(R, os.path.join(ROOT, "tests", "golden"))
         return
     cfg = ref_shim.model_cfg()
     model = R.MODELS.build(cfg)

@@ -83,7 +83,7 @@ def load():
         def forward(self, ref, query):
             assert self.t
             d, i = O.knn(ref.detach().numpy(), query.detach().numpy(), self.k)
-            return torch.from_numpy(d), torch.from_numpy(i)
+            return torch.from_numpy(d).to(ref.dtype), torch.from_numpy(i)        # (f64 arbitration runs: indices from the f32 image)
 
     def furthest_point_sample(xyz, npoint):
         return torch.from_numpy(O.fps(xyz.detach().numpy(), int(npoint)))
@@ -108,7 +108,7 @@ def load():
         d, i = O.knn(p2.detach().numpy(), p1.detach().numpy(), K)            # (B, n1, K) distances (sqrt) and indices
         i = torch.from_numpy(i)
         nn_pts = torch.gather(p2.unsqueeze(1).expand(-1, p1.shape[1], -1, -1), 2, i.unsqueeze(-1).expand(-1, -1, -1, 3)) if return_nn else None
-        return torch.from_numpy(d) ** 2, i, nn_pts
+        return torch.from_numpy(d).to(p1.dtype) ** 2, i, nn_pts
 
     p3 = _mod('pytorch3d.ops', knn_points=knn_points)
     _mod('pytorch3d', ops=p3); _mod('chamfer', forward=_ch_fwd, backward=_ch_bwd); _mod('emd_cuda')

@@ -38,4 +38,4 @@ def oracle_ops(monkeypatch):
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
-    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("upp_model", "upp_modules", "upp_seg", "point_mae", "pretask", "ref_ops", "upp_stage2", "upp_seg_train")}
+    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("upp_model", "upp_modules", "upp_seg", "point_mae", "pretask", "ref_ops", "upp_stage2", "upp_seg_train", "upp_stage2_f64", "upp_seg_train_f64")}

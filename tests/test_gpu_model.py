@@ -56,13 +56,12 @@ def test_train_step_gradients_match_fixture(model, golden):
     grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
     assert sorted(grads) == list(g['grad_names'])
     norms = np.array([grads[n].norm().item() for n in g['grad_names']])
-    np.testing.assert_allclose(norms, g['grad_norms'], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(norms, g['grad_norms'], rtol=2e-5, atol=1e-7)     # (measured 1e-6, tools/micro/recipe_tolerance.py)
     for k in g.files:                       # every full gradient array the fixture holds, element by element, from the HIP backward
         if k.startswith('grad::'):
             ref = g[k]
-            # (block 0's prompts sit behind 12 blocks of f32 backward; measured worst cases: 4.6e-5 of the array's scale there,
-            # one element of a bnorm.weight gradient -- a sum over max-pooled rows -- at 4.5e-4 relative)
-            np.testing.assert_allclose(grads[k[6:]].cpu().numpy(), ref, rtol=5e-4, atol=2e-4 * np.abs(ref).max(), err_msg=k)
+            # measured: 2.9e-6 of the array's scale, 1.8e-6 relative L2, 6.3e-5 relative on entries above 1 % of the scale
+            np.testing.assert_allclose(grads[k[6:]].cpu().numpy(), ref, rtol=2e-4, atol=1e-5 * np.abs(ref).max(), err_msg=k)
     for p in model.parameters():
         p.requires_grad_(True)
         p.grad = None
@@ -73,14 +72,20 @@ STAGE2_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts'
 
 
 def _stage2_check(grads, loss, g):
-    np.testing.assert_allclose(loss, g['loss'], rtol=1e-4)
+    """Measured (tools/micro/recipe_tolerance.py): loss 6e-8, norms <= 3.8e-4, arrays <= 5.4e-4 of their scale / 4.5e-4 relative L2 on the
+    gradients that come through the prompted geometry, 2e-6 on the others.  The geometry-path figure is ONE max-pool arg-max flip in one
+    group of the last patch embedding between two f32 evaluations (tests/test_model_golden.py: in float64 this formulation and the
+    reference's agree to 1e-14 on every array, and the CPU f32 path of this repository reproduces the HIP figures to three digits)."""
+    np.testing.assert_allclose(loss, g['loss'], rtol=1e-6)
     assert sorted(grads) == list(g['grad_names'])
     norms = np.array([grads[n].norm().item() for n in g['grad_names']])
-    np.testing.assert_allclose(norms, g['grad_norms'], rtol=5e-3, atol=1e-6)
+    np.testing.assert_allclose(norms, g['grad_norms'], rtol=1e-3, atol=1e-6)
     for k in g.files:
         if k.startswith('grad::'):
             ref = g[k]
-            np.testing.assert_allclose(grads[k[6:]].cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max(), err_msg=k)
+            got = grads[k[6:]].cpu().numpy()
+            assert np.linalg.norm(got - ref) <= 1e-3 * np.linalg.norm(ref), k
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1.5e-3 * np.abs(ref).max(), err_msg=k)
 
 
 def test_stage2_joint_optimisation_gradients_match_fixture(model, golden):

@@ -41,3 +41,37 @@ big = g['grad_norms'] > 1e-4
 print("pretask    loss rel %.2e | terms %s | norms max rel (norm > 1e-4) %.2e, max abs (others) %.2e" % (
     abs(total.item() / g['loss'] - 1), {k: "%.1e" % abs(terms[t].item() / g[k] - 1) for k, t in (('coarse', 'cropping_coarse'), ('crop_dense', 'cropping_dense'), ('dense', 'dense'), ('noise_loss', 'noise'))},
     np.abs(norms[big] / g['grad_norms'][big] - 1).max(), np.abs(norms[~big] - g['grad_norms'][~big]).max()))
+
+# ---- headline PEFT step and stage 2 (tests/test_gpu_model.py): loss, gradient norms, gradient arrays of the reference-class fixtures
+PEFT_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'bnorm', 'cls_pos', 'cls_token', 'cls_head_finetune']
+STAGE2_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'dense_pred', 'mask_token', 'rectify_prompter',
+               'shape_pred', 'coarse_pred', 'predict_token_generator', 'mask_prompter', 'mask_token_generator']
+m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).eval().cuda()
+for name, keys in (("upp_model", PEFT_KEYS), ("upp_stage2", STAGE2_KEYS)):
+    g = G(name)
+    for n, p in m.named_parameters():
+        p.requires_grad_(any(k in n for k in keys)); p.grad = None
+    logits = m(_seeded.noisy_clouds(2, 1024, 0).cuda(), completion_prompt=True, denoise=True, point_num=1024)
+    loss, _ = m.get_loss_acc(logits, torch.from_numpy(g['labels']).cuda())
+    loss.backward()
+    grads = {n: p.grad for n, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+    norms = np.array([grads[n].norm().item() for n in g['grad_names']])
+    worst_abs, worst_rel, worst_l2 = 0.0, 0.0, 0.0
+    for k in g.files:
+        if k.startswith('grad::'):
+            ref = g[k]; got = grads[k[6:]].cpu().numpy()
+            scale = np.abs(ref).max()
+            worst_abs = max(worst_abs, np.abs(got - ref).max() / scale)
+            worst_l2 = max(worst_l2, np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            sig = np.abs(ref) > 1e-2 * scale
+            worst_rel = max(worst_rel, (np.abs(got - ref)[sig] / np.abs(ref)[sig]).max())
+    print("%-10s loss rel %.2e | norms max rel %.2e | arrays: max abs/scale %.2e, max rel (|ref| > 1e-2 scale) %.2e, rel L2 %.2e" % (
+        name, abs(loss.item() / g['loss'] - 1), np.abs(norms / g['grad_norms'] - 1).max(), worst_abs, worst_rel, worst_l2))
+    if name == "upp_stage2":
+        for k in g.files:
+            if k.startswith('grad::'):
+                ref = g[k]; got = grads[k[6:]].cpu().numpy()
+                print("    %-60s max abs/scale %.2e  rel L2 %.2e  |ref|max %.2e" % (k[6:], np.abs(got - ref).max() / np.abs(ref).max(), np.linalg.norm(got - ref) / np.linalg.norm(ref), np.abs(ref).max()))
+        bad = [(abs(a / b - 1), n) for n, a, b in zip(g['grad_names'], norms, g['grad_norms']) if abs(a / b - 1) > 5e-5]
+        for e, n in sorted(bad, reverse=True)[:12]:
+            print("    norm %-60s rel %.2e" % (n, e))
