@@ -310,8 +310,11 @@ void oracle_chamfer_bwd(const float *xyz1, const float *xyz2, const int32_t *idx
 /* approxmatch (emd_kernel.cu:24-157).  xyz1 (B,n,3), xyz2 (B,m,3) ->
  * match (B,m,n).  The per-thread sums run sequentially over the other cloud
  * in index order, so the summation order is independent of the launch shape.
- * __expf is the CUDA fast intrinsic; expf is used here, hence EMD parity is
- * tolerance-based (see tests). */
+ * __expf is the CUDA fast intrinsic, ex2.approx(x * log2(e)) with the product rounded to f32; it is restated as
+ * exp2f(x * 1.44269504f) -- the same product rounding, a correctly rounded 2^y where the hardware (NVIDIA's ex2.approx, gfx950's
+ * v_exp_f32) is within ~1-2 ulp -- so the remaining difference to a device kernel is the exponential unit's own approximation,
+ * not the argument's (|x| log2(e) 2^-24 relative: 1e-5 at x = -100); EMD parity stays tolerance-based (see tests). */
+static inline float oracle_fast_expf(float x) { return exp2f(x * 1.44269504088896340736f); }
 void oracle_emd_approxmatch(const float *xyz1, const float *xyz2, int B, int n, int m, float *match) {
     float multiL, multiR;
     if (n >= m) { multiL = 1; multiR = (float)(n / m); }   /* integer division, :28-34 */
@@ -336,7 +339,7 @@ void oracle_emd_approxmatch(const float *xyz1, const float *xyz2, int B, int n, 
                 for (int l = 0; l < m; ++l) {
                     const float x2 = p2[l * 3 + 0], y2 = p2[l * 3 + 1], z2 = p2[l * 3 + 2];
                     const float d = level * sumsq3(x2 - x1, y2 - y1, z2 - z1);
-                    suml = fmaf(expf(d), remainR[l], suml); /* w = e*remainR; suml += w (contracted) */
+                    suml = fmaf(oracle_fast_expf(d), remainR[l], suml); /* w = e*remainR; suml += w (contracted) */
                 }
                 ratioL[k] = remainL[k] / suml;
             }
@@ -345,7 +348,7 @@ void oracle_emd_approxmatch(const float *xyz1, const float *xyz2, int B, int n, 
                 float sumr = 0;
                 for (int k = 0; k < n; ++k) {
                     const float x1 = p1[k * 3 + 0], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
-                    sumr = fmaf(expf(level * sumsq3(x2 - x1, y2 - y1, z2 - z1)), ratioL[k], sumr);
+                    sumr = fmaf(oracle_fast_expf(level * sumsq3(x2 - x1, y2 - y1, z2 - z1)), ratioL[k], sumr);
                 }
                 sumr *= remainR[l];
                 const float consumption = fminf(remainR[l] / (sumr + 1e-9f), 1.0f);
@@ -360,7 +363,7 @@ void oracle_emd_approxmatch(const float *xyz1, const float *xyz2, int B, int n, 
                     const float x2 = p2[l * 3 + 0], y2 = p2[l * 3 + 1], z2 = p2[l * 3 + 2];
                     /* w = e*rl*ratioR; match += w; suml += w -- NVPTX fuses aggressively,
                      * so both adds become fma(e*rl, ratioR, acc). */
-                    const float er = expf(level * sumsq3(x2 - x1, y2 - y1, z2 - z1)) * rl;
+                    const float er = oracle_fast_expf(level * sumsq3(x2 - x1, y2 - y1, z2 - z1)) * rl;
                     mt[(size_t)l * n + k] = fmaf(er, ratioR[l], mt[(size_t)l * n + k]);
                     suml = fmaf(er, ratioR[l], suml);
                 }

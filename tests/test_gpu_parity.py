@@ -210,11 +210,15 @@ def test_emd_against_oracle(B, n, m):
     wc = O.emd_matchcost(a, b, wm)
     hm = ops.emd_approxmatch(dev(a), dev(b))
     hc = ops.emd_matchcost(dev(a), dev(b), hm)
-    # the reference uses the approximate __expf (so does the HIP kernel) and the oracle expf, and the
-    # auction iterates 10 levels on those values: tolerance-based (1e-2 rel on single match entries,
-    # 1e-4 rel on the cost, which is the quantity the loss uses)
-    np.testing.assert_allclose(hm.cpu().numpy(), wm, rtol=1e-2, atol=1e-4)
-    np.testing.assert_allclose(hc.cpu().numpy(), wc, rtol=1e-4)
+    # the reference uses the approximate __expf = ex2.approx(x * log2 e); the oracle restates it as exp2f(x * log2 e) (same product
+    # rounding), the HIP kernel runs v_exp_f32 on the same product; the auction iterates 10 levels on those values.  Measured
+    # (tools/micro/emd_tolerance.py): match entries within 5e-6 absolute / 4e-4 relative up to 300 x 300, 1e-3 absolute / 5e-3 relative
+    # at 1024 x 1024 (the auction amplifies the exponential unit's last-bit differences); cost, the quantity the loss uses, within 4e-6.
+    if n * m <= 300 * 300:
+        np.testing.assert_allclose(hm.cpu().numpy(), wm, rtol=1e-3, atol=2e-5)
+    else:
+        np.testing.assert_allclose(hm.cpu().numpy(), wm, rtol=1e-2, atol=2e-3)
+    np.testing.assert_allclose(hc.cpu().numpy(), wc, rtol=2e-5)
     # cost / gradients for a FIXED match are plain sums: tight tolerance
     hc2 = ops.emd_matchcost(dev(a), dev(b), dev(wm))
     np.testing.assert_allclose(hc2.cpu().numpy(), wc, rtol=2e-5)
