@@ -27,8 +27,9 @@ __global__ __launch_bounds__(256) void chamfer_dir_kernel(const float *__restric
     __shared__ int ci[4][64];
     // wave-uniform wave index: the pair loop's counter, its bounds and the candidate index then live in SGPRs
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    const int j = blockIdx.x * 64 + lane;
+    int tile_x, b;
+    xcd_cloud_tile(tile_x, b);                            // whole clouds per XCD: the other cloud is fetched into ONE L2
+    const int j = tile_x * 64 + lane;
     const int jc = j < n ? j : n - 1;
     const float *a = xyz1 + ((size_t)b * n + jc) * 3;
     const float x1 = a[0], y1 = a[1], z1 = a[2];
@@ -119,6 +120,41 @@ __global__ void chamfer_grad_kernel(const float *__restrict__ xyz1, const float 
     }
 }
 
+// The same sums with ONE workgroup per cloud pair and both gradient arrays in the LDS: every global operand is read once, every gradient
+// written once (algorithmic bytes; the grid-wide atomics above touch each line from up to 8 L2s: PMC 5.7 x).  The accumulation order
+// inside the LDS is the order the LDS unit retires the adds in -- as unordered as the reference's global atomicAdd.
+__global__ __launch_bounds__(1024) void chamfer_grad_cloud_kernel(const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                                  const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
+                                                                  const float *__restrict__ gd1, const float *__restrict__ gd2,
+                                                                  float *__restrict__ g1, float *__restrict__ g2, int n, int m) {
+    extern __shared__ float acc[];                       // [n * 3 | m * 3]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float *a1 = acc, *a2 = acc + (size_t)n * 3;
+    for (int i = tid; i < (n + m) * 3; i += 1024) acc[i] = 0.0f;
+    __syncthreads();
+    const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+    for (int r = tid; r < n + m; r += 1024) {
+        const bool dir1 = r < n;
+        const int j = dir1 ? r : r - n;
+        const float *pa = (dir1 ? p1 : p2) + (size_t)j * 3;
+        const int j2 = dir1 ? idx1[(size_t)b * n + j] : idx2[(size_t)b * m + j];
+        const float *pb = (dir1 ? p2 : p1) + (size_t)j2 * 3;
+        const float g = (dir1 ? gd1[(size_t)b * n + j] : gd2[(size_t)b * m + j]) * 2;
+        const float vx = g * (pa[0] - pb[0]), vy = g * (pa[1] - pb[1]), vz = g * (pa[2] - pb[2]);
+        float *ga = (dir1 ? a1 : a2) + j * 3, *gb = (dir1 ? a2 : a1) + j2 * 3;
+        __hip_atomic_fetch_add(ga + 0, vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(ga + 1, vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(ga + 2, vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(gb + 0, -vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(gb + 1, -vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(gb + 2, -vz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    float *o1 = g1 + (size_t)b * n * 3, *o2 = g2 + (size_t)b * m * 3;
+    for (int i = tid; i < n * 3; i += 1024) o1[i] = a1[i];
+    for (int i = tid; i < m * 3; i += 1024) o2[i] = a2[i];
+}
+
 }  // namespace
 
 extern "C" int upp_chamfer_fwd(const float *xyz1, const float *xyz2, float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
@@ -138,9 +174,18 @@ extern "C" int upp_chamfer_bwd(const float *xyz1, const float *xyz2, const int32
     if (!xyz1 || !xyz2 || !idx1 || !idx2 || !grad_dist1 || !grad_dist2 || !g1 || !g2 || B < 0 || n < 1 || m < 1)
         return UPP_E_BADARG;
     if (B == 0) return 0;
+    const size_t lds = (size_t)(n + m) * 3 * sizeof(float);
+    if (lds <= 64 * 1024 && B <= 65535) {                // both gradient arrays of a cloud pair in the LDS (n + m <= 5,461)
+        hipLaunchKernelGGL(chamfer_grad_cloud_kernel, dim3((unsigned)B), dim3(1024), lds, (hipStream_t)stream, xyz1, xyz2, idx1, idx2, grad_dist1,
+                           grad_dist2, g1, g2, n, m);
+        return upp_launch_status();
+    }
     const long long total = (long long)B * (n + m);
     long long grid = (total + 255) / 256;
     if (grid > 2048) grid = 2048;
+    if (hipMemsetAsync(g1, 0, sizeof(float) * 3 * (size_t)B * n, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(g2, 0, sizeof(float) * 3 * (size_t)B * m, (hipStream_t)stream) != hipSuccess)
+        return upp_launch_status();
     hipLaunchKernelGGL(chamfer_grad_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, xyz1, xyz2, idx1, idx2,
                        grad_dist1, grad_dist2, g1, g2, B, n, m);
     return upp_launch_status();

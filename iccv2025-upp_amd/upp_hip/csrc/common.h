@@ -99,6 +99,16 @@ __device__ __forceinline__ int xcd_contiguous(int orig, int nwg) {
 #endif
 }
 
+// 2-D grids of (tiles of a cloud, cloud): the hardware deals consecutive workgroups to the 8 XCDs in turn, so the tiles of ONE cloud -- which
+// all stage the same "other" cloud -- would sit on 8 different L2s and fetch it 8 times (PMC, round 2: Chamfer 5.9 x, kNN 2.7 x its
+// algorithmic bytes).  -> (tile, cloud) with every XCD owning whole clouds.
+__device__ __forceinline__ void xcd_cloud_tile(int &tile, int &cloud) {
+    const int nx = (int)gridDim.x;
+    const int lin = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), nx * (int)gridDim.y);
+    cloud = lin / nx;
+    tile = lin - cloud * nx;
+}
+
 // Cooperative global -> LDS copy of n floats by `nthreads` threads.  Each thread keeps 8 independent loads in flight
 // per round: a load -> ds_write -> next load loop pays the full ~1 us memory latency on every iteration.
 __device__ __forceinline__ void stage_floats(float *dst, const float *__restrict__ src, int n, int tid, int nthreads) {

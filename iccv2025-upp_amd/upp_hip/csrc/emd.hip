@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void emd_row_kernel(const float *__restrict__ 
     __shared__ float tr[kT];      // ratioR of the previous level
     __shared__ float part[2][4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * 64 + lane;
+    int tile_x, b;
+    xcd_cloud_tile(tile_x, b);                            // whole clouds per XCD (common.h)
+    const int k = tile_x * 64 + lane;
     const int kc = k < n ? k : n - 1;
     const float *a = xyz1 + ((size_t)b * n + kc) * 3;
     const float x1 = a[0], y1 = a[1], z1 = a[2];
@@ -114,8 +115,9 @@ __global__ __launch_bounds__(256) void emd_col_kernel(const float *__restrict__ 
     __shared__ float4 tile[kT];  // x, y, z, ratioL
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
-    const int b = blockIdx.y;
-    const int l = blockIdx.x * 64 + lane;
+    int tile_x, b;
+    xcd_cloud_tile(tile_x, b);                            // whole clouds per XCD (common.h)
+    const int l = tile_x * 64 + lane;
     const int lc = l < m ? l : m - 1;
     const float *a = xyz2 + ((size_t)b * m + lc) * 3;
     const float x2 = a[0], y2 = a[1], z2 = a[2];
@@ -158,10 +160,14 @@ __global__ __launch_bounds__(256) void emd_match_kernel(const float *__restrict_
     __shared__ float4 pt[kMT];
     __shared__ float rr[kLevels][kMT];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
-    const int b = blockIdx.z;
-    const int k = blockIdx.x * 64 + lane;
+    // (3-D grid: whole clouds per XCD, as xcd_cloud_tile does for the 2-D ones)
+    const int per_cloud = (int)(gridDim.x * gridDim.y);
+    const int lin = xcd_contiguous((int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), per_cloud * (int)gridDim.z);
+    const int b = lin / per_cloud, in_cloud = lin - b * per_cloud;
+    const int tile_y = in_cloud / (int)gridDim.x, tile_x = in_cloud - tile_y * (int)gridDim.x;
+    const int k = tile_x * 64 + lane;
     const int kc = k < n ? k : n - 1;
-    const int l_base = blockIdx.y * kMT;
+    const int l_base = tile_y * kMT;
     const int len = min(kMT, m - l_base);
     const float *a = xyz1 + ((size_t)b * n + kc) * 3;
     const float x1 = a[0], y1 = a[1], z1 = a[2];
@@ -193,8 +199,9 @@ __global__ __launch_bounds__(256) void emd_cost_kernel(const float *__restrict__
     __shared__ float4 tile[kT];
     __shared__ float part[4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * 64 + lane;
+    int tile_x, b;
+    xcd_cloud_tile(tile_x, b);                            // whole clouds per XCD (common.h)
+    const int k = tile_x * 64 + lane;
     const int kc = k < n ? k : n - 1;
     const float *a = xyz1 + ((size_t)b * n + kc) * 3;
     const float x1 = a[0], y1 = a[1], z1 = a[2];
@@ -230,8 +237,9 @@ __global__ __launch_bounds__(256) void emd_grad1_kernel(const float *__restrict_
     __shared__ float4 tile[kT];
     __shared__ float part[3][4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
-    const int b = blockIdx.y;
-    const int l = blockIdx.x * 64 + lane;
+    int tile_x, b;
+    xcd_cloud_tile(tile_x, b);                            // whole clouds per XCD (common.h)
+    const int l = tile_x * 64 + lane;
     const int lc = l < n ? l : n - 1;
     const float *a = xyz1 + ((size_t)b * n + lc) * 3;
     const float x1 = a[0], y1 = a[1], z1 = a[2];
@@ -272,8 +280,9 @@ __global__ __launch_bounds__(256) void emd_grad2_kernel(const float *__restrict_
                                                         const float *__restrict__ xyz2, const float *__restrict__ match,
                                                         float *__restrict__ grad2, int n, int m) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: loop counters and LDS offsets in SGPRs
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * 4 + wave;
+    int tile_x, b;
+    xcd_cloud_tile(tile_x, b);                            // whole clouds per XCD (common.h)
+    const int k = tile_x * 4 + wave;
     if (k >= m) return;
     const float *q = xyz2 + ((size_t)b * m + k) * 3;
     const float x2 = q[0], y2 = q[1], z2 = q[2];

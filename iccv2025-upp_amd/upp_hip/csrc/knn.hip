@@ -34,8 +34,9 @@ __global__ __launch_bounds__(64 * kKnnWaves) void knn_kernel(const float *__rest
                                                              float *__restrict__ neigh, int N, int Q, int K) {
     __shared__ float chunk[3 * kKnnChunk];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y;
-    const int q_raw = blockIdx.x * kKnnWaves + wave;
+    int tile_x, b;
+    xcd_cloud_tile(tile_x, b);                            // whole clouds per XCD: the reference cloud is fetched into ONE L2
+    const int q_raw = tile_x * kKnnWaves + wave;
     const bool q_live = q_raw < Q;
     const int q = q_live ? q_raw : Q - 1;  // surplus waves shadow the last query (they must reach the barriers)
     const float *rp = ref + (size_t)b * N * 3;

@@ -140,8 +140,8 @@ def chamfer_bwd(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2):
     _need(grad_dist2, "grad_dist2", torch.float32, 2)
     B, n, _ = xyz1.shape
     m = xyz2.shape[1]
-    g1 = torch.zeros_like(xyz1)
-    g2 = torch.zeros_like(xyz2)
+    g1 = torch.empty_like(xyz1)          # (overwritten by the kernel: include/upp_hip.h)
+    g2 = torch.empty_like(xyz2)
     _call(xyz1.device, "upp_chamfer_bwd", _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(idx1), _abi.ptr(idx2),
           _abi.ptr(grad_dist1), _abi.ptr(grad_dist2), _abi.ptr(g1), _abi.ptr(g2), B, n, m)
     return g1, g2

@@ -107,8 +107,9 @@ int upp_group_bwd(const float *grad_out, const int64_t *idx, float *grad_xyz, fl
  *   dist1 (B,n) f32, idx1 (B,n) int32: squared distance to, and index of, the
  *         nearest xyz2 point (lowest index among equal minima); dist2/idx2 the
  *         other direction.
- * Backward: g1 (B,n,3) and g2 (B,m,3) must be zero-filled by the caller; f32
- * atomics as in chamfer.cu:194-199. */
+ * Backward: g1 (B,n,3) and g2 (B,m,3) are OVERWRITTEN (no pre-zeroing: the reference's wrapper allocates zeros and its kernel adds,
+ * chamfer.cu:194-199,215-222); sums by f32 atomics in an unspecified order as there -- in the LDS, one workgroup per cloud pair, when
+ * both gradient arrays fit (n + m <= 5,461), in global memory otherwise. */
 int upp_chamfer_fwd(const float *xyz1, const float *xyz2,
                     float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
                     int B, int n, int m, void *stream);
