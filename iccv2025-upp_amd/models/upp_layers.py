@@ -133,7 +133,12 @@ def trunc_normal_(t, std=.02):
 
 def square_distance(src, dst):
     """|s|^2 + |d|^2 - 2 s.d^T, (B,N,C) x (B,M,C) -> (B,N,M)  (models/modules.py:13-32)."""
-    dist = -2 * torch.matmul(src, dst.transpose(1, 2))
+    if src.is_cuda and src.shape[-1] == 3 and src.shape[0] * src.shape[1] * dst.shape[1] <= (1 << 20):
+        # a few thousand pairs of 3-vectors (the prompters' centre sets when the geometry carries a gradient): the products as element-wise
+        # ops -- a batched library GEMM with K = 3 plus its two backward GEMMs otherwise; same formula, the dot product summed x, y, z
+        dist = -2 * (src.unsqueeze(2) * dst.unsqueeze(1)).sum(-1)
+    else:
+        dist = -2 * torch.matmul(src, dst.transpose(1, 2))
     dist += torch.sum(src ** 2, -1).unsqueeze(-1)
     dist += torch.sum(dst ** 2, -1).unsqueeze(1)
     return dist

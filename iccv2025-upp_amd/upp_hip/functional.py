@@ -379,13 +379,22 @@ class _TransposedWeights:
         if e is None or e[0]() is None:
             if len(self.entries) > 1024:
                 self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
-            wt = w.detach().t().contiguous()
-            self.entries[key] = [weakref.ref(owner), owner._version, wt, geom]
+            K = w.shape[1]
+            full = torch.zeros(((K + 3) // 4 * 4, w.shape[0]), dtype=w.dtype, device=w.device)   # rows padded to a multiple of 4: get_padded()
+            wt = full[:K]
+            wt.copy_(w.detach().t())
+            self.entries[key] = [weakref.ref(owner), owner._version, wt, geom, full]
             return wt
         if e[1] != owner._version and not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
             e[2].copy_(w.detach().t())
             e[1] = owner._version
         return e[2]
+
+    def get_padded(self, w):
+        """W^T with zero rows up to a multiple of 4 (K, ceil4(K) x N): the B operand of a data-gradient GEMM whose output width K is
+        not a multiple of 4 (K = 3: the first layer of a position MLP whose input carries a gradient); same storage as get(w)."""
+        self.get(w)
+        return self.entries[(w.data_ptr(), tuple(w.shape), tuple(w.stride()), w.storage_offset())][4]
 
     def refresh(self):
         for e in self.entries.values():
@@ -487,6 +496,9 @@ class _LinearMFMA(Function):
                 gx = ops.linear_parts(g2, wt, ctx.x_parts).view((ctx.x_parts,) + g.shape[:-1] + (w.shape[1],))
             elif wt.shape[1] % 4 == 0 and g2.stride(0) % 4 == 0:
                 gx = ops.linear_f32(g2, wt).view(g.shape[:-1] + (w.shape[1],))
+            elif wt.shape[1] <= 64 and wt.shape[0] <= 256:
+                # a narrow layer (the 64 -> 3 score head of the denoising prompter): the data gradient contracts over its few outputs
+                gx = ops.linear_smallk(g2, wt, None, 0).view(g.shape[:-1] + (w.shape[1],))
             else:
                 note_declined("linear data gradient", "N = %d is not a multiple of 4" % wt.shape[1])
                 gx = torch.mm(g2, w).view(g.shape[:-1] + (w.shape[1],))
@@ -569,8 +581,11 @@ class _LinearSmallK(Function):
             g2 = g2.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = ops.linear_smallk(g2, w.detach().t().contiguous() if not w.requires_grad else ops.transpose(w.detach()), None, 0)
-            gx = gx.view(g.shape[:-1] + (K,))
+            if N > 64:      # (_smallk_with_grad: N % 4 == 0, frozen weight) contraction too long for the small kernel: the matrix cores,
+                gx = ops.linear_f32(g2, TRANSPOSED.get_padded(w))[:, :K]            # with W^T zero-padded to 4 output columns
+            else:
+                gx = ops.linear_smallk(g2, w.detach().t().contiguous() if not w.requires_grad else ops.transpose(w.detach()), None, 0)
+            gx = gx.reshape(g.shape[:-1] + (K,))
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, K)
             if x2.stride(1) != 1:
@@ -588,7 +603,8 @@ def _smallk_with_grad(x, weight):
     trainable position MLP reads the centres)"""
     N, K = weight.shape
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and x.shape[-1] == K
-            and K <= 64 and (N <= 64 or (N <= 256 and not x.requires_grad)) and N * K <= 2048 and N + K <= 512 and x.numel() > 0
+            and K <= 64 and (N <= 64 or (N <= 256 and (not x.requires_grad or (N % 4 == 0 and not weight.requires_grad))))
+            and N * K <= 2048 and N + K <= 512 and x.numel() > 0
             and weight.stride(1) == 1)
 
 

@@ -58,3 +58,25 @@ def test_segmentation_step_declines_nothing_and_launches_no_library_gemm():
     declined, gemms = _profile(step)
     assert declined == DOCUMENTED_DECLINES, declined
     assert not gemms, gemms
+
+
+STAGE2_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'dense_pred', 'mask_token', 'rectify_prompter',
+               'shape_pred', 'coarse_pred', 'predict_token_generator', 'mask_prompter', 'mask_token_generator']   # reference tools/runner_module.py:232-238
+
+
+def test_stage2_step_declines_nothing_and_launches_no_library_gemm():
+    """Stage 2 of the recipe: the gradient runs through the prompted geometry (propagation weights, the 3 -> 128 position layers, the
+    64 -> 3 score head, the patch embedding's data gradients) -- all on own kernels since round 3."""
+    m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda().train()
+    freeze_for_peft(m, STAGE2_KEYS)
+    x = _seeded.noisy_clouds(4, 1024, seed=0).cuda()
+    y = torch.tensor([1, 2, 3, 4], device='cuda')
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        loss, _ = m.get_loss_acc(m(x, completion_prompt=True, denoise=True, point_num=1024), y)
+        loss.backward()
+    declined, gemms = _profile(step)
+    assert declined == DOCUMENTED_DECLINES, declined
+    assert not gemms, gemms

@@ -438,6 +438,28 @@ def test_small_k_linear_with_gradients(M, N, K):
     close(part.sum(0), rw, rtol=2e-5, atol_scale=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 128, 3), (1024, 128, 3), (35072, 3, 64), (1000, 3, 32)])
+def test_narrow_layers_with_a_gradient_on_the_input_stay_on_own_kernels(M, N, K, monkeypatch, capsys):
+    """Stage 2 of the recipe differentiates through frozen narrow layers: the 3 -> 128 first layer of the position MLPs (input = centres
+    that carry a gradient: forward on the small-K kernel, data gradient on the matrix cores with W^T zero-padded to 4 output columns) and
+    the 64 -> 3 score head (data gradient contracts over its 3 outputs: small-K kernel).  Against torch autograd; nothing declined."""
+    monkeypatch.setenv("UPP_VERBOSE", "1")
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    x = torch.randn(M, K, device='cuda', generator=g).requires_grad_(True)
+    w = torch.randn(N, K, device='cuda', generator=g) * K ** -0.5              # frozen
+    b = torch.randn(N, device='cuda', generator=g)
+    go = torch.randn(M, N, device='cuda', generator=g)
+    HF._declined.clear()
+    out = HF.linear(x, w, b)
+    gx, = torch.autograd.grad(out, [x], go)
+    xr = x.detach().clone().requires_grad_(True)
+    ref = F.linear(xr, w, b)
+    rx, = torch.autograd.grad(ref, [xr], go)
+    close(out, ref)
+    close(gx, rx)
+    assert not HF._declined and "fused path declined" not in capsys.readouterr().err
+
+
 def test_trainable_weight_transposes_follow_the_weights_inside_a_step_driver():
     """Inside a step driver (TRANSPOSED.managed) the W^T copy of a trainable weight is persistent and refreshed by ONE batched launch
     (upp_transpose_batched_f32) at the start of a step: the data gradient must follow in-place weight updates; outside a driver every
