@@ -96,25 +96,31 @@ struct SumJobs {
     int wg0[kMaxSumJobs + 1];                  // per group: first workgroup (256 columns per workgroup)
     int groups;
 };
+// V = 4: long rows whose sources, strides and destination are 16-byte aligned (the partial tiles of the grouped weight gradients: 1-3
+// partial matrices of 147,456 ... 589,824 elements each in the pre-training step) -- 1,024 columns per workgroup, 16 bytes per lane; the
+// one-dword-per-lane form spent its time on workgroup start-up (2,304 workgroups of one to three loads per thread: 0.7 TB/s).  Same sums.
+template <int V>
 __global__ __launch_bounds__(256) void batched_sum_kernel(SumJobs t) {
+    typedef float vec_t __attribute__((ext_vector_type(V)));
     int g = 0;
     while (g + 1 < t.groups && (int)blockIdx.x >= t.wg0[g + 1]) ++g;          // wave-uniform scan of <= 64 entries
-    const int c = ((int)blockIdx.x - t.wg0[g]) * 256 + threadIdx.x;
+    const int c = (((int)blockIdx.x - t.wg0[g]) * 256 + threadIdx.x) * V;
     const int len = t.len[g];
     if (c >= len) return;
-    float acc = t.acc[g] ? t.dst[g][c] : 0.0f;
+    vec_t acc = t.acc[g] ? *reinterpret_cast<const vec_t *>(t.dst[g] + c) : vec_t(0.0f);
     for (int j = t.first[g]; j < t.first[g + 1]; ++j) {
         const float *src = t.src[j] + c;
         const int n = t.n[j], ld = t.ld[j];
-        for (int i0 = 0; i0 < n; i0 += 16) {                                   // 16 independent loads in flight
-            float v[16];
+        constexpr int U = V == 1 ? 16 : 8;                                      // independent loads in flight
+        for (int i0 = 0; i0 < n; i0 += U) {
+            vec_t v[U];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = src[(size_t)min(i0 + q, n - 1) * ld];
+            for (int q = 0; q < U; ++q) v[q] = *reinterpret_cast<const vec_t *>(src + (size_t)min(i0 + q, n - 1) * ld);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) if (i0 + q < n) acc += v[q];
+            for (int q = 0; q < U; ++q) if (i0 + q < n) acc += v[q];
         }
     }
-    t.dst[g][c] = acc;
+    *reinterpret_cast<vec_t *>(t.dst[g] + c) = acc;
 }
 
 // Tall jobs (more than kTallRows rows: the bias gradients of trainable Linear layers are column sums of (B L, N) output
@@ -281,15 +287,26 @@ extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const
         tall[g] = false;
         for (int q = gstart[g]; q < gstart[g + 1]; ++q) tall[g] = tall[g] || n[order[q]] > kTallRows;
     }
-    for (int pass = 0; pass < 2; ++pass) {
-        const int cols = pass ? 64 : 256;
+    // ... and the short ones with long, 16-byte aligned rows (pass 2: 1,024 columns per workgroup, 16 bytes per lane)
+    int cls[4096];
+    for (int g = 0; g < ngroups; ++g) {
+        const int head = order[gstart[g]];
+        bool wide = !tall[g] && len[head] >= 4096 && len[head] % 4 == 0 && (reinterpret_cast<uintptr_t>(dst[head]) & 15) == 0;
+        for (int q = gstart[g]; q < gstart[g + 1] && wide; ++q) {
+            const int k = order[q];
+            wide = ld[k] % 4 == 0 && (reinterpret_cast<uintptr_t>(src[k]) & 15) == 0;
+        }
+        cls[g] = tall[g] ? 1 : (wide ? 2 : 0);
+    }
+    for (int pass = 0; pass < 3; ++pass) {
+        const int cols = pass == 1 ? 64 : (pass == 2 ? 1024 : 256);
         int g0 = 0;
         while (g0 < ngroups) {
             SumJobs t;
             int g = 0, nj = 0, wg = 0, used = 0;
             while (g0 + used < ngroups && g < kMaxSumJobs) {
                 const int gi = g0 + used;
-                if (tall[gi] != (pass == 1)) { ++used; continue; }
+                if (cls[gi] != pass) { ++used; continue; }
                 if (nj + (gstart[gi + 1] - gstart[gi]) > kMaxSumJobs) break;
                 const int lo = gstart[gi], hi = gstart[gi + 1], head = order[lo];
                 t.first[g] = nj;
@@ -303,8 +320,9 @@ extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const
                 return UPP_E_RANGE;                          // a single destination with more than 64 partial matrices
             }
             t.first[g] = nj; t.wg0[g] = wg; t.groups = g;
-            if (pass) hipLaunchKernelGGL(batched_sum_tall_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
-            else hipLaunchKernelGGL(batched_sum_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
+            if (pass == 1) hipLaunchKernelGGL(batched_sum_tall_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
+            else if (pass == 2) hipLaunchKernelGGL(batched_sum_kernel<4>, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
+            else hipLaunchKernelGGL(batched_sum_kernel<1>, dim3(wg), dim3(256), 0, (hipStream_t)stream, t);
             g0 += used;
         }
     }
