@@ -372,7 +372,12 @@ extern "C" int upp_patch_embed_fwd(const float *pts, int R, int n, const float *
     // hg = fg . W3[:, :256]^T + b3      (once per group)
     g = GemmArgs{};
     g.A = k.fg; g.lda = 256; g.W = w3; g.ldw = 512; g.bias = b3; g.C = k.hg; g.ldc = 512; g.M = G; g.N = 512; g.K = 256;
-    launch_gemm<PRO_NONE, EPI_BIAS | EPI_STORE>(g, st);
+    // (a G x 512 x 256 product: 64 tiles of this file's 128 x 128 kernel are 16 latency-bound k-steps on a quarter of the CUs, 31 us at
+    // G = 2048; upp_linear_f32 picks a one-round decomposition of the same product: 8 us)
+    {
+        const int rc = upp_linear_f32(k.fg, 256, w3, 512, b3, k.hg, 512, nullptr, 0, G, 512, 256, /*LEPI_BIAS*/ 1, 0, stream);
+        if (rc) return rc;
+    }
     // h3 = f . W3[:, 256:]^T + hg[group] ; BN3 statistics
     g = GemmArgs{};
     g.A = k.f; g.lda = 256; g.W = w3 + 256; g.ldw = 512; g.C = k.h3; g.ldc = 512; g.M = R; g.N = 512; g.K = 256;
