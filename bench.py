@@ -21,7 +21,7 @@ upp_linear_f32 launches -- QKV / proj / fc1 / fc2 of every block pass and their 
 on the launch stream inside one eager step; FLOPs / time against the FP32-MFMA peak), `ms_per_step_sequential` (the same step
 on one stream), `kernels` (stand-alone timings of the hand-written kernels against their rooflines; `traffic` = HBM bytes per
 call from the committed rocprofv3 --pmc passes, profiles/r0*_pmc_kernels.json), `cpu_baseline` (same step, same batch, on the
-host cores with the CPU oracle, bounded sample).  tools/make_profiles.sh regenerates profiles/r02_* with the same commands.
+host cores with the CPU oracle, bounded sample).  tools/make_profiles.sh regenerates profiles/r03_* with the same commands.
 """
 import argparse
 import json
@@ -241,11 +241,11 @@ MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f
 
 
 def _pmc_traffic():
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_kernels.json, produced by
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r03_pmc_kernels.json, produced by
     tools/make_profiles.sh: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH doubled per the gfx950 note in
-    MI355X_MICROARCH.md; kernels not re-profiled this round keep their profiles/r01_pmc_kernels.json entry)."""
+    MI355X_MICROARCH.md; kernels not re-profiled in a round keep the entry of the last round that profiled them)."""
     out = {}
-    for name in ("r01_pmc_kernels.json", "r02_pmc_kernels.json"):
+    for name in ("r01_pmc_kernels.json", "r02_pmc_kernels.json", "r03_pmc_kernels.json"):
         try:
             raw = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -268,10 +268,12 @@ def stage_report(device, B):
     from models.upp_layers import Encoder
     from upp_hip import functional as HF, ops
     pmc = _pmc_traffic()
-    try:
-        mfma_pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_mfma.json")))
-    except Exception:
-        mfma_pmc = {}
+    mfma_pmc = {}
+    for name in ("r02_pmc_mfma.json", "r03_pmc_mfma.json"):
+        try:
+            mfma_pmc.update(json.load(open(os.path.join(ROOT, "profiles", name))))
+        except Exception:
+            pass
 
     def traffic(keys):
         """HBM bytes per call: sum over the kernels of the call (key prefix, or (prefix, launches per call))."""
@@ -390,7 +392,7 @@ def stage_report(device, B):
                              "VALU-bound: 2*n*m*8 flop = %.1f TFLOP/s f32 VALU" % (B * 2 * 1024 * 1024 * 8 / t / 1e9))
     d1, d2, ix1, ix2 = ops.chamfer_fwd(ca, cb)
     t = time_kernel(lambda: ops.chamfer_bwd(ca, cb, ix1, ix2, d1, d2))
-    out["chamfer_bwd"] = hbm("chamfer_grad_kernel (B,1024)x(B,1024)", t, B * 65536, "chamfer_grad_kernel")
+    out["chamfer_bwd"] = hbm("chamfer_grad_cloud_kernel (B,1024)x(B,1024): sums in the LDS, one workgroup per cloud pair", t, B * 65536, "chamfer_grad_cloud")
     t = time_kernel(lambda: ops.emd_approxmatch(ca, cb), iters=3)
     out["emd_approxmatch"] = hbm("upp_emd_approxmatch (22 launches; match (B,1024,1024) written once)", t, B * (1024 * 1024 * 4 + 24576),
                                  [("emd_row_kernel", 10), ("emd_col_kernel", 10), ("emd_match_kernel", 1), ("emd_init_kernel", 1)],
@@ -410,7 +412,7 @@ def stage_report(device, B):
         out["linear_" + label] = mfma("linear_f32_kernel<%s> %s: (%d,%d) x (%d,%d)^T, epilogue %d" % (tile, label, M, K, N, K, epi), t,
                                       2.0 * M * N * K)
         out["linear_" + label]["traffic"] = traffic("linear:" + label)
-        if "linear:" + label in mfma_pmc:           # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch time x 2.1 GHz): profiles/r02_pmc_mfma.json
+        if "linear:" + label in mfma_pmc:           # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch time x 2.1 GHz): profiles/r03_pmc_mfma.json
             out["linear_" + label]["mfma_pipe_frac_pmc"] = mfma_pmc["linear:" + label].get("mfma_pipe_frac")
         out["linear_" + label]["algorithmic_bytes"] = 4.0 * (M * K + N * K + M * N * (2 if epi in (3, 4) else 1))
     return out
@@ -698,7 +700,7 @@ def main():
                 "traffic": None if any(v is None for v in pmc_step) else sum(pmc_step),
                 "traffic_note": "PMC bytes of the eight launches of ONE block at M = 2400 (kernels.linear_*), not of the whole step",
                 "how": "the step's launch sequence (recorded from an eager step) replayed as one HIP graph, HIP events on the launch "
-                       "stream; kernel-to-kernel boundaries included.  profiles/r02_bench_sequential_kernel_stats.csv holds the same "
+                       "stream; kernel-to-kernel boundaries included.  profiles/r03_bench_sequential_kernel_stats.csv holds the same "
                        "launches inside the step under rocprofv3 (sum of linear_f32_kernel<*> over 14 executions of the step)",
                 "by_shape": shapes}
             line["kernels"] = stages
