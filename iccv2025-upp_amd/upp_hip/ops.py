@@ -46,6 +46,8 @@ def fps(xyz, npoint, want_centers=False, waves=0):
     npoint = int(npoint)
     idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     centers = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if want_centers else None
+    if B == 0:                               # an empty batch: nothing to launch (an empty tensor has no device pointer to hand over)
+        return (idx, centers) if want_centers else idx
     _call(xyz.device, "upp_fps_ex", _abi.ptr(xyz), _abi.ptr(idx), _abi.ptr(centers), B, N, npoint, int(waves))
     return (idx, centers) if want_centers else idx
 
@@ -84,6 +86,10 @@ def knn(ref, query, k, want_dist=True, want_neigh=False, prefilter=True):
     idx = torch.empty((B, Q, k), dtype=torch.int64, device=ref.device)
     dist = torch.empty((B, Q, k), dtype=torch.float32, device=ref.device) if want_dist else None
     neigh = torch.empty((B, Q, k, 3), dtype=torch.float32, device=ref.device) if want_neigh else None
+    if B == 0:
+        if k < 1 or k > min(N, 64):
+            raise RuntimeError("knn: k must be in [1, min(N, 64)]")
+        return dist, idx, neigh
     _call(ref.device, "upp_knn_ex", _abi.ptr(ref), _abi.ptr(query), _abi.ptr(dist), _abi.ptr(idx), _abi.ptr(neigh), B, N, Q, k, int(bool(prefilter)))
     return dist, idx, neigh
 
@@ -124,6 +130,8 @@ def chamfer_fwd(xyz1, xyz2):
     dist2 = torch.empty((B, m), dtype=torch.float32, device=dev)
     idx1 = torch.empty((B, n), dtype=torch.int32, device=dev)
     idx2 = torch.empty((B, m), dtype=torch.int32, device=dev)
+    if B == 0:
+        return dist1, dist2, idx1, idx2
     _call(xyz1.device, "upp_chamfer_fwd", _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(dist1), _abi.ptr(dist2),
           _abi.ptr(idx1), _abi.ptr(idx2), B, n, m)
     return dist1, dist2, idx1, idx2
@@ -142,6 +150,8 @@ def chamfer_bwd(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2):
     m = xyz2.shape[1]
     g1 = torch.empty_like(xyz1)          # (overwritten by the kernel: include/upp_hip.h)
     g2 = torch.empty_like(xyz2)
+    if B == 0:
+        return g1, g2
     _call(xyz1.device, "upp_chamfer_bwd", _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(idx1), _abi.ptr(idx2),
           _abi.ptr(grad_dist1), _abi.ptr(grad_dist2), _abi.ptr(g1), _abi.ptr(g2), B, n, m)
     return g1, g2
@@ -157,6 +167,8 @@ def emd_approxmatch(xyz1, xyz2):
         raise RuntimeError("xyz1 and xyz2 batch sizes differ")
     m = xyz2.shape[1]
     match = torch.empty((B, m, n), dtype=torch.float32, device=xyz1.device)
+    if B == 0:
+        return match
     nwork = int(_abi.load().upp_emd_work_floats(B, n, m))
     work = torch.empty((max(nwork, 1),), dtype=torch.float32, device=xyz1.device)
     _call(xyz1.device, "upp_emd_approxmatch", _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(match), _abi.ptr(work), B, n, m)
@@ -172,6 +184,8 @@ def emd_matchcost(xyz1, xyz2, match):
     if tuple(match.shape) != (B, m, n):
         raise RuntimeError("match must be (B, n2, n1)")
     cost = torch.empty((B,), dtype=torch.float32, device=xyz1.device)
+    if B == 0:
+        return cost
     _call(xyz1.device, "upp_emd_matchcost", _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(match), _abi.ptr(cost), B, n, m)
     return cost
 
@@ -185,6 +199,8 @@ def emd_matchcost_bwd(grad_cost, xyz1, xyz2, match):
     m = xyz2.shape[1]
     g1 = torch.empty_like(xyz1)
     g2 = torch.empty_like(xyz2)
+    if B == 0:
+        return g1, g2
     _call(xyz1.device, "upp_emd_matchcost_bwd", _abi.ptr(grad_cost), _abi.ptr(xyz1), _abi.ptr(xyz2), _abi.ptr(match),
           _abi.ptr(g1), _abi.ptr(g2), B, n, m)
     return g1, g2

@@ -331,3 +331,41 @@ def test_fps_and_knn_kernels_reproduce_the_references_own_numpy_and_torch_statem
             d, nb, _ = ops.knn(x, cen[:, :Q].contiguous(), k, want_dist=True, want_neigh=False)
             np.testing.assert_array_equal(np.sort(nb.cpu().numpy(), axis=-1), g[name + "/knn"])
             assert (d[..., 1:] >= d[..., :-1]).all()
+
+
+def test_empty_batches_and_limit_sizes():
+    """Edge cases of the boundary: an empty batch is a no-op that returns empty tensors (the reference's wrappers allocate (0, ...) outputs
+    and launch nothing useful); sizes at the documented limits run and agree with the oracle: FPS at N = 32,768 (15-bit point ids), kNN at
+    k = 64 = min(N, 64), Chamfer with one point against many (ragged n != m), and one-point clouds."""
+    e3 = torch.zeros(0, 128, 3, device='cuda')
+    idx = ops.fps(e3, 16)
+    assert tuple(idx.shape) == (0, 16)
+    e2 = torch.zeros(0, 64, 3, device='cuda')
+    d1, d2, i1, i2 = ops.chamfer_fwd(e3, e2)
+    assert tuple(d1.shape) == (0, 128) and tuple(i2.shape) == (0, 64)
+    g1, g2 = ops.chamfer_bwd(e3, e2, i1, i2, d1, d2)
+    assert tuple(g1.shape) == (0, 128, 3) and tuple(g2.shape) == (0, 64, 3)
+    kd, ki, _ = ops.knn(e3, e2, 8)
+    assert tuple(ki.shape) == (0, 64, 8) and ki.dtype == torch.int64
+    assert tuple(ops.emd_matchcost(e3, e2, ops.emd_approxmatch(e3, e2)).shape) == (0,)
+    # FPS at the size limit (one cloud): indices equal the oracle's
+    big = clouds(1, 32768, "ball", 5)
+    got = ops.fps(dev(big), 64).cpu().numpy()
+    np.testing.assert_array_equal(got, O.fps(big, 64))
+    with pytest.raises(RuntimeError):
+        ops.fps(torch.zeros(1, 32769, 3, device='cuda'), 8)
+    # kNN at k = 64 with exactly 64 reference points: every query lists every point, ascending distance
+    ref, q = clouds(2, 64, "ball", 6), clouds(2, 5, "ball", 7)
+    wd, wi = O.knn(ref, q, 64)
+    hd, hi, _ = ops.knn(dev(ref), dev(q), 64, want_dist=True, want_neigh=False)
+    np.testing.assert_array_equal(hi.cpu().numpy(), wi)
+    np.testing.assert_array_equal(hd.cpu().numpy(), wd)
+    with pytest.raises(RuntimeError):
+        ops.knn(dev(ref), dev(q), 65)
+    # Chamfer: one point against many, and one against one
+    for n, m in ((1, 777), (777, 1), (1, 1)):
+        a, b = clouds(3, n, "ball", n), clouds(3, m, "ball", m + 9)
+        w = O.chamfer_fwd(a, b)
+        h = ops.chamfer_fwd(dev(a), dev(b))
+        for x, y in zip(h, w):
+            np.testing.assert_array_equal(x.cpu().numpy(), y)
