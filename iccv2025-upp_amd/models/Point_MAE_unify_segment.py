@@ -57,7 +57,8 @@ class Point_MAE_unify_seg(PromptedBackbone):
         B, N, C = point_feat.shape
         w1 = c1.weight.squeeze(-1)
         per_sample = HF.linear(global_feat, w1[:, C:], c1.bias, own_wgrad=True)                       # (B,512), once per sample
-        h = HF.linear(point_feat.reshape(B * N, C), w1[:, :C]).view(B, N, -1) + per_sample.unsqueeze(1)
+        h = HF.linear_group_bias(point_feat.reshape(B * N, C), w1[:, :C], per_sample, N).view(B, N, -1) if (N & (N - 1)) == 0 and N >= 32 \
+            else HF.linear(point_feat.reshape(B * N, C), w1[:, :C]).view(B, N, -1) + per_sample.unsqueeze(1)    # (per-sample term: GEMM epilogue)
         if self.training and bn1.track_running_stats:
             L.bump_counter(bn1.num_batches_tracked)
         h = drop(_bn_rows(h.view(B * N, -1), bn1, self.training, relu=True))

@@ -448,7 +448,10 @@ class Encoder(nn.Module):
         fg = f.view(bs * g, n, 256).max(dim=1)[0]                           # (BG, 256)
         w3 = c3.weight.squeeze(-1)                                          # (512, 512): [global | local]
         hg = HF.linear(fg, w3[:, :256], c3.bias, own_wgrad=True)                            # (BG, 512) once per group (column windows: no copies)
-        h = HF.linear(f, w3[:, 256:], own_wgrad=True).view(bs * g, n, 512) + hg.unsqueeze(1)
+        if (n & (n - 1)) == 0 and n >= 32:
+            h = HF.linear_group_bias(f, w3[:, 256:], hg, n)                  # (the group's half: a bias per n rows in the GEMM's epilogue)
+        else:
+            h = HF.linear(f, w3[:, 256:], own_wgrad=True).view(bs * g, n, 512) + hg.unsqueeze(1)
         h = _bn_rows(h.view(bs * g * n, 512), bn3, self.training, relu=True)
         out = HF.linear(h, c4.weight.squeeze(-1), c4.bias, own_wgrad=True)                  # (BGn, C)
         return out.view(bs * g, n, self.encoder_channel).max(dim=1)[0].view(bs, g, self.encoder_channel)

@@ -483,6 +483,26 @@ extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, lon
 #undef UPP_LIN_CASE
 }
 
+// C (M,N) = A . W^T + bias[m >> group_shift][:]  -- a bias per GROUP of 2^group_shift consecutive rows (group_shift >= 5), added in the
+// epilogue of the register-tiled kernel; only for problems that kernel is chosen for (upp_linear_tile(M, N, K) & 0x10000) with 16-byte
+// aligned output rows, UPP_E_RANGE otherwise (the caller then adds the broadcast term itself).
+extern "C" int upp_linear_group_bias_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias, int group_shift,
+                                         float *C, long long ldc, int M, int N, int K, void *stream) {
+    if (!A || !W || !C || !bias || M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
+    if (K % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || lda < K || ldw < K || ldc < N) return UPP_E_RANGE;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15) return UPP_E_RANGE;
+    if (group_shift < 5 || group_shift > 30 || N % 4 != 0 || ldc % 4 != 0 || ldc > (1LL << 24)) return UPP_E_RANGE;
+    const int tile = pick_code(M, N, K);
+    if (tile <= 0 || !(tile & 0x10000)) return UPP_E_RANGE;                    // (not a problem the register-tiled kernel is chosen for)
+    LinArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.bias = bias; g.M = M; g.N = N; g.K = K; g.epi = LEPI_BIAS;
+    g.bias_shift = group_shift;
+#ifdef UPP_LIN_STAMPS
+    g.stamps = g_lin_stamps;
+#endif
+    return upp_detail_linear_rt(&g, tile, (hipStream_t)stream);
+}
+
 extern "C" int upp_linear_parts(int M, int N, int K) {
     if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
     if (K % 4 != 0) return UPP_E_RANGE;

@@ -201,6 +201,9 @@ __global__ __launch_bounds__(WM *WN * 64) void linear_rt_kernel(LinArgs g) {
 #pragma unroll
         for (int a = 0; a < RM; ++a) {
             const int rb = m0 + (wm * RM + a) * 32;                                 // (scalar) first row of this row of blocks
+            if constexpr (FANCY) {      // a bias per group of 2^bias_shift >= 32 rows: one row of the bias matrix per 32-row block
+                if (g.bias_shift > 0 && col_ok && rb < M) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + (size_t)(rb >> g.bias_shift) * N + col);
+            }
 #pragma unroll
             for (int b = 0; b < RN; ++b)
 #pragma unroll
@@ -272,7 +275,7 @@ int launch_rt(const LinArgs &g0, hipStream_t st) {
     g.tiles_n = (g.N + BN - 1) / BN;
     const dim3 grid((unsigned)(tiles_m * g.tiles_n)), block(WM * WN * 64);
     const bool tail = g.K % (32 * KC) != 0;
-    const bool fancy = g.epi == LEPI_BIAS_GELU || g.epi == LEPI_BIAS_GELU_D || g.epi == LEPI_MUL;
+    const bool fancy = g.epi == LEPI_BIAS_GELU || g.epi == LEPI_BIAS_GELU_D || g.epi == LEPI_MUL || g.bias_shift > 0;
     if (fancy) {
 #ifdef UPP_RT_NO_FANCY
         return UPP_E_RANGE;

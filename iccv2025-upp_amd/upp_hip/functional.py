@@ -598,6 +598,48 @@ class _LinearSmallK(Function):
         return gx, gw, gb
 
 
+class _LinearGroupBias(Function):
+    """x (M,K) . W^T + gb[m // rows] with the per-group term added in the GEMM's epilogue (upp_linear_group_bias_f32).  Backward: the data
+    gradient and the (deferred, grouped) weight gradient of _LinearMFMA; the group term's gradient is the sum of g over each group's rows."""
+
+    @staticmethod
+    def forward(ctx, x, w, gb, rows):
+        ctx.save_for_backward(x if w.requires_grad else None, w)
+        ctx.rows = rows
+        return ops.linear_group_bias(x, w, gb, rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2 = g if g.is_contiguous() else g.contiguous()
+        gx = gw = ggb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear_f32(g2, _wt(w))
+        if ctx.needs_input_grad[1]:
+            gw = weight_grad(g2, x, w, True)
+        if ctx.needs_input_grad[2]:
+            ggb = g2.view(g2.shape[0] // ctx.rows, ctx.rows, g2.shape[1]).sum(dim=1)
+        return gx, gw, ggb, None
+
+
+def linear_group_bias(x, weight, group_bias, rows_per_group):
+    """F.linear(x, weight) + group_bias.repeat_interleave(rows_per_group, 0) for a (M,K) matrix x whose rows come in groups of
+    `rows_per_group` (a power of two >= 32) that share one bias row: in the GEMM's epilogue when the problem is tall enough for the
+    register-tiled kernel, as a broadcast add otherwise."""
+    M, K = x.shape
+    N = weight.shape[0]
+    r = int(rows_per_group)
+    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and weight.stride(1) == 1 and weight.stride(0) % 4 == 0 and weight.data_ptr() % 16 == 0
+            and (K % 4 == 0 and weight.shape[1] == K) and ops.linear_group_bias_usable(M, N, K, r)
+            and (not (torch.is_grad_enabled() and x.requires_grad) or K % 4 == 0)):
+        gb = group_bias.contiguous()
+        if not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad or gb.requires_grad):
+            return ops.linear_group_bias(x, weight, gb, r)
+        return _LinearGroupBias.apply(x, weight, gb, r)
+    return (linear(x, weight, own_wgrad=True).view(M // r, r, N) + group_bias.unsqueeze(1)).view(M, N)
+
+
 def _smallk_with_grad(x, weight):
     """(the data gradient contracts over N on the same kernel: N <= 64 unless the input needs none -- the 3 -> 128 first layer of a
     trainable position MLP reads the centres)"""

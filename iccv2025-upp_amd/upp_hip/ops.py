@@ -450,6 +450,35 @@ def linear_wgrad(g, x):
     return part
 
 
+def linear_group_bias_usable(M, N, K, rows_per_group):
+    """Does upp_linear_group_bias_f32 serve this problem (tall: the register-tiled kernel; groups of 2^s >= 32 rows; N, K % 4 == 0)?"""
+    r = int(rows_per_group)
+    if not (r >= 32 and (r & (r - 1)) == 0 and M % r == 0 and N % 4 == 0 and K % 4 == 0):
+        return False
+    tile = int(_abi.load().upp_linear_tile(M, N, K))
+    return tile > 0 and bool(tile & 0x10000)
+
+
+def linear_group_bias(a, w, bias, rows_per_group):
+    """C (M,N) = a (M,K) . w (N,K)^T + bias[m // rows_per_group] -- the bias of a GROUP of rows added in the GEMM's epilogue
+    (upp_linear_group_bias_f32); bias (M / rows_per_group, N) contiguous."""
+    for t, name in ((a, "a"), (w, "w"), (bias, "bias")):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise RuntimeError(f"{name} must be a 2-D f32 HIP (cuda) matrix with contiguous rows; upp_hip has no CPU path")
+    _same_device(a, w, bias)
+    M, K = a.shape
+    N = w.shape[0]
+    r = int(rows_per_group)
+    if w.shape[1] != K or not bias.is_contiguous() or tuple(bias.shape) != (M // r, N) or not linear_group_bias_usable(M, N, K, r):
+        raise RuntimeError("linear_group_bias: shapes do not fit (see linear_group_bias_usable)")
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _call(a.device, "upp_linear_group_bias_f32", _abi.ptr(a), a.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(bias), r.bit_length() - 1,
+          _abi.ptr(out), N, M, N, K)
+    if time_linear_calls.active is not None:
+        time_linear_calls.active.group_bias = getattr(time_linear_calls.active, "group_bias", []) + [(M, N, K)]
+    return out
+
+
 def linear_wgrad_grouped(pairs):
     """pairs: list of (g (M,N), x (M,K)) -- the weight gradients of several Linear layers in ONE launch (upp_linear_wgrad_grouped_f32).
     -> list of partial gradients (splits_p, N_p, K_p); the caller sums each over dim 0 in order (batched_sum)."""

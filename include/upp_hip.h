@@ -501,6 +501,13 @@ int upp_linear_wgrad_f32(const float *G, long long ldg, const float *X, long lon
 int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias,
                    float *C, long long ldc, float *aux, long long ldaux,
                    int M, int N, int K, int epilogue, int tile, void *stream);
+/* upp_linear_group_bias_f32: C = A . W^T + bias[m >> group_shift][:], bias a (ceil(M / 2^group_shift), N) matrix -- a bias per group of
+ * 2^group_shift >= 32 consecutive rows in the GEMM's epilogue: `h + per_sample.unsqueeze(1)` of the segmentation head
+ * (models/Point_MAE_unify_segment.py:424-433 with the concat's broadcast half multiplied once per sample) and the per-group half of the
+ * patch embedding's Conv1d(512, 512) (models/Point_MAE_unify.py:213-216).  Tall problems only (the register-tiled kernel:
+ * upp_linear_tile(M, N, K) & 0x10000), UPP_E_RANGE otherwise. */
+int upp_linear_group_bias_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias, int group_shift,
+                              float *C, long long ldc, int M, int N, int K, void *stream);
 /* upp_linear_parts_f32: the same product with the contraction cut into `parts` equal runs over WORKGROUPS: C_p (M,N) = A[:, p K/parts :
  * (p+1) K/parts] . W[:, same]^T written at C + p * part_stride (floats), no epilogue.  For narrow outputs over a long contraction (fc2 and
  * the data gradients of fc1 / qkv: N = 384, K >= 1152) this keeps 128-wide tiles AND fills the chip; the consumer of the result adds the

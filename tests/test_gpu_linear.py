@@ -460,6 +460,36 @@ def test_narrow_layers_with_a_gradient_on_the_input_stay_on_own_kernels(M, N, K,
     assert not HF._declined and "fused path declined" not in capsys.readouterr().err
 
 
+@pytest.mark.parametrize("M,N,K,rows", [(65536, 512, 256, 32), (65536, 512, 1024, 2048), (32768, 512, 256, 64), (65536 + 96, 512, 256, 32)])
+def test_group_bias_in_the_epilogue_of_the_tall_kernel(M, N, K, rows):
+    """upp_linear_group_bias_f32: a bias per group of 2^s rows added in the register-tiled kernel's epilogue -- bit-identical to the plain
+    product followed by the broadcast add (one f32 add per element either way), gradients against torch autograd."""
+    g = torch.Generator(device='cuda').manual_seed(M + K)
+    if M % rows:
+        M -= M % rows
+    x = torch.randn(M, K, device='cuda', generator=g).requires_grad_(True)
+    w = (torch.randn(N, K, device='cuda', generator=g) * K ** -0.5).requires_grad_(True)
+    gb = torch.randn(M // rows, N, device='cuda', generator=g).requires_grad_(True)
+    assert ops.linear_group_bias_usable(M, N, K, rows)
+    out = HF.linear_group_bias(x, w, gb, rows)
+    assert type(out.grad_fn).__name__ == '_LinearGroupBiasBackward'
+    plain = (ops.linear_f32(x.detach(), w.detach()).view(M // rows, rows, N) + gb.detach().unsqueeze(1)).view(M, N)
+    assert torch.equal(out.detach(), plain)
+    go = torch.randn(M, N, device='cuda', generator=g)
+    gx, gw, ggb = torch.autograd.grad(out, [x, w, gb], go)
+    xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, gb))
+    ref = (F.linear(xr, wr).view(M // rows, rows, N) + br.unsqueeze(1)).view(M, N)
+    rx, rw, rb = torch.autograd.grad(ref, [xr, wr, br], go)
+    close(gx, rx, rtol=2e-5, atol_scale=2e-5)
+    close(gw, rw, rtol=2e-5, atol_scale=2e-5)
+    close(ggb, rb, rtol=2e-5, atol_scale=2e-5)
+    # not a tall problem / not a power of two: the broadcast add on the short kernels, same function
+    xs = torch.randn(4096, K, device='cuda', generator=g)
+    gs = torch.randn(4096 // 32, N, device='cuda', generator=g)
+    assert not ops.linear_group_bias_usable(4096, N, K, 32)
+    close(HF.linear_group_bias(xs, w.detach(), gs, 32), (F.linear(xs, w.detach()).view(-1, 32, N) + gs.unsqueeze(1)).view(4096, N))
+
+
 def test_trainable_weight_transposes_follow_the_weights_inside_a_step_driver():
     """Inside a step driver (TRANSPOSED.managed) the W^T copy of a trainable weight is persistent and refreshed by ONE batched launch
     (upp_transpose_batched_f32) at the start of a step: the data gradient must follow in-place weight updates; outside a driver every
