@@ -50,6 +50,18 @@ def split_decay(model):
     return no_decay, decay
 
 
+def _copy_many(dsts, srcs):
+    """dst_j <- src_j; the contiguous HIP pairs in launches of 64 (upp_copy_batched), the rest one by one."""
+    batched = [(d, s) for d, s in zip(dsts, srcs)
+               if d.is_cuda and s.is_cuda and d.dtype == s.dtype and d.shape == s.shape and d.is_contiguous() and s.is_contiguous() and d.numel() > 0]
+    taken = {id(d) for d, _ in batched}
+    if batched:
+        HF.ops.copy_batched([d for d, _ in batched], [s.detach() for _, s in batched])
+    for d, s in zip(dsts, srcs):
+        if id(d) not in taken:
+            d.copy_(s)
+
+
 class FlatAdamW:
     """clip_grad_norm_ + AdamW as three gfx950 kernels (csrc/optim.hip) over flat buffers: the parameters are
     re-pointed into one flat buffer (no-decay group first), the gradients are FlatGradAllReduce's buffer."""
@@ -64,9 +76,9 @@ class FlatAdamW:
         self.split = self._offsets[len(no_decay)] if len(decay) else self.n
         self.p = torch.zeros(self.n, device=dev)
         with torch.no_grad():
-            for q, off in zip(params, self._offsets):
-                view = self.p[off:off + q.numel()].view_as(q)
-                view.copy_(q)
+            views = [self.p[off:off + q.numel()].view_as(q) for q, off in zip(params, self._offsets)]
+            _copy_many(views, [q.detach() for q in params])            # (one launch per 64 parameters, not one runtime copy each)
+            for q, view in zip(params, views):
                 q.data = view                      # the model now reads its trainable weights from the flat buffer
         self._shapes = [tuple(q.shape) for q in params]
         self._n_no_decay = len(no_decay)
@@ -174,12 +186,18 @@ class _TrainingState:
             self.tensors += [p for p in model.parameters() if p.requires_grad]
             self.opt, self.opt_state = opt, copy.deepcopy(opt.state_dict())
         with torch.no_grad():
-            self.saved = [t.detach().clone() for t in self.tensors]
+            self.saved = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in self.tensors]
+            self._copy(self.saved, self.tensors)
+
+    @staticmethod
+    def _copy(dsts, srcs):
+        """(one runtime copy per tensor is ~550 launches per snapshot of the headline model, which a kernel trace of a short run then shows
+        as its most frequent 'kernel')"""
+        _copy_many(dsts, srcs)
 
     def restore(self):
         with torch.no_grad():
-            for t, s in zip(self.tensors, self.saved):
-                t.copy_(s)
+            self._copy(self.tensors, self.saved)
         if self.opt is not None:
             self.opt.load_state_dict(self.opt_state)
 
@@ -253,7 +271,9 @@ class TrainStep:
         finally:
             HF.TRANSPOSED.managed = was
         got = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None and p.data_ptr() not in scope.routed]
-        torch._foreach_copy_([v for v, _ in got], [g for _, g in got])   # one multi-tensor copy into the flat buffer
+        # into the flat buffer in launches of 64 (upp_copy_batched): torch._foreach_copy_ issues one runtime copy per tensor here -- 55 ...
+        # 100 `__amd_rocclr_copyBuffer` launches per step, 0.2 ... 0.35 ms in the round-2 / early round-3 kernel summaries
+        _TrainingState._copy([v for v, _ in got], [g for _, g in got])
         both = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None and p.data_ptr() in scope.routed]
         if both:                       # a parameter with a routed sum AND an autograd gradient: add the latter
             torch._foreach_add_([v for v, _ in both], [g for _, g in both])
