@@ -16,6 +16,7 @@ if [ "$PART" = "headline" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/seq -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipeline --no-stage-report > $O/seq.log 2>&1
 cp "$(stats $O/seq)" $O/r03_bench_sequential_kernel_stats.csv
 python3 tools/phase_summary.py "$(trace $O/seq)" > $O/r03_phase_summary.txt
+python3 tools/step_census.py "$(trace $O/seq)" > $O/r03_step_census.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pipe -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stage-report > $O/pipe.log 2>&1
 cp "$(stats $O/pipe)" $O/r03_bench_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kern -- python3 tools/prof_kernels.py > $O/kern.log 2>&1
