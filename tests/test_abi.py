@@ -87,6 +87,14 @@ def test_linear_decomposition_choice_is_a_host_function():
     assert cfg(2400, 384, 1536)[:3] == (2, 2, 4)           # 228 workgroups, contraction split 4 ways: 1 block per SIMD
     assert cfg(2400, 384, 384)[:3] == (2, 2, 4)            # (the 2-way split is faster stand-alone and slower in the two-stream step)
     assert lib.upp_linear_tile(0, 1, 32) == -1 and lib.upp_linear_tile(32, 32, 50) == -2 and lib.upp_linear_tile(32, 32, 48) > 0
+    # problems that fit no one-round decomposition (part segmentation: 4,096 ... 4,448 token rows): the fitted multi-round model picks
+    # within 2 % of the best measured choice (profiles/r03_time_linear_rows.jsonl) -- (2,2,2,64) or the register-tiled kernel for the wide
+    # layers, (2,4,2,64) for the narrow ones; the one-round model's leftover (1,2,4,128) cost fc1 47 % there
+    RT = 0x2512211
+    assert lib.upp_linear_tile(4416, 1536, 384) in (0x2221, RT) and lib.upp_linear_tile(4128, 1152, 384) in (0x2221, RT)
+    assert lib.upp_linear_tile(4416, 384, 1536) == 0x2421 and lib.upp_linear_tile(4128, 384, 1152) == 0x2421
+    assert lib.upp_linear_tile(2720, 1536, 384) == 0x2321 and lib.upp_linear_tile(6144, 1152, 384) == RT
+    assert lib.upp_linear_tile(65536, 1024, 1536) == RT and lib.upp_linear_tile(65536, 512, 256) == RT
 
 
 def test_exported_symbols_are_exactly_the_declared_ones():
