@@ -10,6 +10,8 @@
 //   upp_interp_fwd  : inverse-distance interpolation from the k nearest of a sorted neighbour table   [1 launch]
 //   upp_posenc_fwd  : (x, sin(f x), cos(f x))_f positional embedding                                  [1 launch]
 // interp / posenc write into a column window of a wider row-major buffer, so the reference's torch.cat is free.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -647,6 +649,125 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float *__restrict
     }
 }
 
+// Few source rows, narrow features (the rectify prompter's 1096 <- 32, k = 16, C = 32 layer in stage 2 / the pre-task recipe): the pull
+// kernel above spends its time scanning -- each of its B S workgroups reads the sample's whole N k table (17,536 entries) to find its
+// ~550 hits: 125 us for 4.5 MB of gradients.  Here ONE workgroup per sample walks the rows in tiles of TR: the tile's table entries are
+// read coalesced into the LDS, turned into weights by one thread per row (the forward's expression: 1 / (d + eps) summed in neighbour order)
+// and scattered into a dense (TR x S) weight matrix (k plain stores per row: the k neighbours of a row are distinct); the tile's gradient
+// rows are staged beside it, and  g_feat[s][c] += sum_r Wd[r][s] * g[r][c]  runs out of the LDS: a thread owns four source rows x four
+// columns (two 16-byte LDS reads per 16 fmaf), the four waves take every fourth row of the tile and their partial sums are added in wave
+// order at the end.  Deterministic; (S + C + 2 kInterpK) TR floats of LDS; S % 4 == 0, C % 4 == 0, S C <= 4,096.
+__global__ __launch_bounds__(256) void interp_bwd_dense_kernel(const float *__restrict__ dist, const int64_t *__restrict__ idx, int ld_tab,
+                                                               const float *__restrict__ g_out, int ld_g, int col0, int S, int C, int k,
+                                                               float eps, int N, int TR, float *__restrict__ g_feat) {
+    extern __shared__ float lds_f[];
+    float *wd = lds_f;                                            // [TR][S]
+    float *gl = wd + (size_t)TR * S;                              // [TR][C]
+    float *td = gl + (size_t)TR * C;                              // [TR][k] distances
+    int *ti = reinterpret_cast<int *>(td + (size_t)TR * kInterpK);   // [TR][k] source rows
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t base = (size_t)b * N;
+    const int quads = C >> 2, sq = S >> 2, units = sq * quads;    // unit = (s-quad, c-quad); lane owns units lane, lane + 64, ... (<= kDU)
+    constexpr int kDU = 4;
+    float4 acc[kDU][4];                                           // acc[j][e] = g_feat[o_s + e][o_c .. o_c + 3] of unit j, this wave's rows
+#pragma unroll
+    for (int j = 0; j < kDU; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int t0 = 0; t0 < N; t0 += TR) {
+        const int rows = min(TR, N - t0);
+        __syncthreads();                                          // the previous tile's readers are done
+        for (int i = tid; i < rows * S; i += 256) wd[i] = 0.0f;
+        for (int i0 = tid; i0 < rows * quads; i0 += 256 * 8) {    // 8 global loads in flight per thread (a load -> store loop pays ~1 us each)
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + 256 * u, rows * quads - 1);
+                const int r = i / quads, q = i - r * quads;
+                v[u] = *reinterpret_cast<const float4 *>(g_out + (base + t0 + r) * ld_g + col0 + 4 * q);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < rows * quads) { const int r = i / quads, q = i - r * quads; *reinterpret_cast<float4 *>(gl + r * C + 4 * q) = v[u]; }
+            }
+        }
+        for (int i0 = tid; i0 < rows * k; i0 += 256 * 4) {        // the tile's table entries, consecutive lanes on consecutive entries
+            float dv[4];
+            int iv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, rows * k - 1);
+                const int r = i / k, q = i - r * k;
+                dv[u] = dist[(base + t0 + r) * ld_tab + q]; iv[u] = (int)idx[(base + t0 + r) * ld_tab + q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < rows * k) { const int r = i / k, q = i - r * k; td[r * kInterpK + q] = dv[u]; ti[r * kInterpK + q] = iv[u]; }
+            }
+        }
+        __syncthreads();
+        if (tid < rows) {
+            float rc[kInterpK];
+            float norm = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kInterpK; ++q) { rc[q] = 1.0f / (td[tid * kInterpK + min(q, k - 1)] + eps); if (q < k) norm += rc[q]; }
+#pragma unroll
+            for (int q = 0; q < kInterpK; ++q) if (q < k) wd[tid * S + ti[tid * kInterpK + q]] = rc[q] / norm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kDU; ++j) {
+            const int unit = lane + 64 * j;
+            if (unit >= units) break;
+            const int o_s = (unit / quads) * 4, o_c = (unit % quads) * 4;
+            for (int r0 = wave; r0 < rows; r0 += 4 * 4) {          // this wave's rows r0, r0 + 4, ...: four rows of reads in flight
+                float4 w[4], v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = min(r0 + 4 * u, rows - 1);
+                    w[u] = *reinterpret_cast<const float4 *>(wd + r * S + o_s);
+                    v[u] = *reinterpret_cast<const float4 *>(gl + r * C + o_c);
+                    if (r0 + 4 * u >= rows) w[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float ws[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[j][e].x = __builtin_fmaf(ws[e], v[u].x, acc[j][e].x); acc[j][e].y = __builtin_fmaf(ws[e], v[u].y, acc[j][e].y);
+                        acc[j][e].z = __builtin_fmaf(ws[e], v[u].z, acc[j][e].z); acc[j][e].w = __builtin_fmaf(ws[e], v[u].w, acc[j][e].w);
+                    }
+                }
+            }
+        }
+    }
+    // the four waves' partial sums, added in wave order (through the weight-matrix area: S C floats per wave <= 4 KB)
+    __syncthreads();
+    float *red = lds_f;
+#pragma unroll
+    for (int j = 0; j < kDU; ++j) {
+        const int unit = lane + 64 * j;
+        if (unit >= units) break;
+        const int o_s = (unit / quads) * 4, o_c = (unit % quads) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<float4 *>(red + (size_t)wave * S * C + (o_s + e) * C + o_c) = acc[j][e];
+    }
+    __syncthreads();
+    for (int i = tid; i < S * quads; i += 256) {
+        const int srow = i / quads, q = i - srow * quads;
+        const float *p0 = red + srow * C + 4 * q;
+        float4 a = *reinterpret_cast<const float4 *>(p0);
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) {
+            const float4 t = *reinterpret_cast<const float4 *>(p0 + (size_t)w2 * S * C);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        *reinterpret_cast<float4 *>(g_feat + ((size_t)b * S + srow) * C + 4 * q) = a;
+    }
+}
+
 // ---- positional embedding ---------------------------------------------------------------------------------------
 // out[row][col0 + ...] = (x, sin(f0 x), cos(f0 x), sin(f1 x), cos(f1 x), ...) for x (rows, 3)
 // (reference models/Point_MAE_pretask_dev.py:22-52).  One thread per (row, coordinate).
@@ -780,6 +901,17 @@ extern "C" int upp_interp_bwd(const float *dist, const int64_t *idx, int ld_tab,
     if (!dist || !idx || !g_out || !g_feat || B < 1 || N < 1 || S < 1 || C < 1 || k < 1 || ld_tab < k || ld_g < col0 + C || col0 < 0)
         return UPP_E_BADARG;
     if (k > kInterpK || k > S || N > kInterpMaxRows || (long long)B * S > 0x7fffffffLL) return UPP_E_RANGE;
+    {   // few source rows and narrow, 16-byte aligned features: the dense-in-LDS kernel (see interp_bwd_dense_kernel)
+        const bool aligned = C % 4 == 0 && S % 4 == 0 && ld_g % 4 == 0 && col0 % 4 == 0 &&
+                             ((reinterpret_cast<uintptr_t>(g_out) | reinterpret_cast<uintptr_t>(g_feat)) & 15) == 0;
+        int TR = (int)((60 * 1024) / ((size_t)(S + C + 2 * kInterpK) * sizeof(float)));
+        TR = TR > 256 ? 256 : TR / 8 * 8;
+        if (aligned && TR >= 64 && (long long)(S / 4) * (C / 4) <= 256 && (size_t)4 * S * C <= (size_t)TR * (S + C)) {
+            hipLaunchKernelGGL(interp_bwd_dense_kernel, dim3((unsigned)B), dim3(256), (size_t)TR * (S + C + 2 * kInterpK) * sizeof(float),
+                               (hipStream_t)stream, dist, idx, ld_tab, g_out, ld_g, col0, S, C, k, eps, N, TR, g_feat);
+            return upp_launch_status();
+        }
+    }
     hipLaunchKernelGGL(interp_bwd_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, g_out, ld_g, col0, S, C,
                        pow2_at_least(C), k, eps, N, g_feat);
     return upp_launch_status();
