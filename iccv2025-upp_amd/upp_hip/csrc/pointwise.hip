@@ -657,9 +657,11 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float *__restrict
 // rows are staged beside it, and  g_feat[s][c] += sum_r Wd[r][s] * g[r][c]  runs out of the LDS: a thread owns four source rows x four
 // columns (two 16-byte LDS reads per 16 fmaf), the four waves take every fourth row of the tile and their partial sums are added in wave
 // order at the end.  Deterministic; (S + C + 2 kInterpK) TR floats of LDS; S % 4 == 0, C % 4 == 0, S C <= 4,096.
-__global__ __launch_bounds__(256) void interp_bwd_dense_kernel(const float *__restrict__ dist, const int64_t *__restrict__ idx, int ld_tab,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void interp_bwd_dense_kernel(const float *__restrict__ dist, const int64_t *__restrict__ idx, int ld_tab,
                                                                const float *__restrict__ g_out, int ld_g, int col0, int S, int C, int k,
                                                                float eps, int N, int TR, float *__restrict__ g_feat) {
+    constexpr int NT = 64 * NW;              // (a lone wave per SIMD issues one VALU instruction per ~10 cycles: NW = 8 puts two on each)
     extern __shared__ float lds_f[];
     float *wd = lds_f;                                            // [TR][S]
     float *gl = wd + (size_t)TR * S;                              // [TR][C]
@@ -677,33 +679,33 @@ __global__ __launch_bounds__(256) void interp_bwd_dense_kernel(const float *__re
     for (int t0 = 0; t0 < N; t0 += TR) {
         const int rows = min(TR, N - t0);
         __syncthreads();                                          // the previous tile's readers are done
-        for (int i = tid; i < rows * S; i += 256) wd[i] = 0.0f;
-        for (int i0 = tid; i0 < rows * quads; i0 += 256 * 8) {    // 8 global loads in flight per thread (a load -> store loop pays ~1 us each)
+        for (int i = tid; i < rows * S; i += NT) wd[i] = 0.0f;
+        for (int i0 = tid; i0 < rows * quads; i0 += NT * 8) {     // 8 global loads in flight per thread (a load -> store loop pays ~1 us each)
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = min(i0 + 256 * u, rows * quads - 1);
+                const int i = min(i0 + NT * u, rows * quads - 1);
                 const int r = i / quads, q = i - r * quads;
                 v[u] = *reinterpret_cast<const float4 *>(g_out + (base + t0 + r) * ld_g + col0 + 4 * q);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 256 * u;
+                const int i = i0 + NT * u;
                 if (i < rows * quads) { const int r = i / quads, q = i - r * quads; *reinterpret_cast<float4 *>(gl + r * C + 4 * q) = v[u]; }
             }
         }
-        for (int i0 = tid; i0 < rows * k; i0 += 256 * 4) {        // the tile's table entries, consecutive lanes on consecutive entries
+        for (int i0 = tid; i0 < rows * k; i0 += NT * 4) {         // the tile's table entries, consecutive lanes on consecutive entries
             float dv[4];
             int iv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = min(i0 + 256 * u, rows * k - 1);
+                const int i = min(i0 + NT * u, rows * k - 1);
                 const int r = i / k, q = i - r * k;
                 dv[u] = dist[(base + t0 + r) * ld_tab + q]; iv[u] = (int)idx[(base + t0 + r) * ld_tab + q];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + 256 * u;
+                const int i = i0 + NT * u;
                 if (i < rows * k) { const int r = i / k, q = i - r * k; td[r * kInterpK + q] = dv[u]; ti[r * kInterpK + q] = iv[u]; }
             }
         }
@@ -722,14 +724,14 @@ __global__ __launch_bounds__(256) void interp_bwd_dense_kernel(const float *__re
             const int unit = lane + 64 * j;
             if (unit >= units) break;
             const int o_s = (unit / quads) * 4, o_c = (unit % quads) * 4;
-            for (int r0 = wave; r0 < rows; r0 += 4 * 4) {          // this wave's rows r0, r0 + 4, ...: four rows of reads in flight
+            for (int r0 = wave; r0 < rows; r0 += NW * 4) {         // this wave's rows r0, r0 + NW, ...: four rows of reads in flight
                 float4 w[4], v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int r = min(r0 + 4 * u, rows - 1);
+                    const int r = min(r0 + NW * u, rows - 1);
                     w[u] = *reinterpret_cast<const float4 *>(wd + r * S + o_s);
                     v[u] = *reinterpret_cast<const float4 *>(gl + r * C + o_c);
-                    if (r0 + 4 * u >= rows) w[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (r0 + NW * u >= rows) w[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -755,12 +757,12 @@ __global__ __launch_bounds__(256) void interp_bwd_dense_kernel(const float *__re
         for (int e = 0; e < 4; ++e) *reinterpret_cast<float4 *>(red + (size_t)wave * S * C + (o_s + e) * C + o_c) = acc[j][e];
     }
     __syncthreads();
-    for (int i = tid; i < S * quads; i += 256) {
+    for (int i = tid; i < S * quads; i += NT) {
         const int srow = i / quads, q = i - srow * quads;
         const float *p0 = red + srow * C + 4 * q;
         float4 a = *reinterpret_cast<const float4 *>(p0);
 #pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2) {
+        for (int w2 = 1; w2 < NW; ++w2) {
             const float4 t = *reinterpret_cast<const float4 *>(p0 + (size_t)w2 * S * C);
             a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
@@ -907,8 +909,13 @@ extern "C" int upp_interp_bwd(const float *dist, const int64_t *idx, int ld_tab,
         int TR = (int)((60 * 1024) / ((size_t)(S + C + 2 * kInterpK) * sizeof(float)));
         TR = TR > 256 ? 256 : TR / 8 * 8;
         if (aligned && TR >= 64 && (long long)(S / 4) * (C / 4) <= 256 && (size_t)4 * S * C <= (size_t)TR * (S + C)) {
-            hipLaunchKernelGGL(interp_bwd_dense_kernel, dim3((unsigned)B), dim3(256), (size_t)TR * (S + C + 2 * kInterpK) * sizeof(float),
-                               (hipStream_t)stream, dist, idx, ld_tab, g_out, ld_g, col0, S, C, k, eps, N, TR, g_feat);
+            const size_t lds = (size_t)TR * (S + C + 2 * kInterpK) * sizeof(float);
+            if ((size_t)8 * S * C <= (size_t)TR * (S + C))      // eight waves when their partial sums fit the weight / gradient area
+                hipLaunchKernelGGL(interp_bwd_dense_kernel<8>, dim3((unsigned)B), dim3(512), lds, (hipStream_t)stream, dist, idx, ld_tab, g_out, ld_g,
+                                   col0, S, C, k, eps, N, TR, g_feat);
+            else
+                hipLaunchKernelGGL(interp_bwd_dense_kernel<4>, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, dist, idx, ld_tab, g_out, ld_g,
+                                   col0, S, C, k, eps, N, TR, g_feat);
             return upp_launch_status();
         }
     }
