@@ -38,6 +38,28 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Wave-wide max of a signed 32-bit key, result in an SGPR: six v_max_i32 with the DPP permute ON the max instruction (quad swaps, half-row and
+// row mirrors, then row_bcast 15 / 31 carry the row maxima down to lane 63) and one v_readlane -- 13 instructions with their hazard nops;
+// common.h's wave_max_u32 (update_dpp + max per step, four readlanes, SALU / VALU combine) compiles to 24, and a lone wave issues one
+// instruction per ~10 cycles (tools/micro/clock_probe.cpp): the round loop below is priced by its instruction COUNT.
+__device__ __forceinline__ int wave_max_i32(int v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 struct FpsGeom {
     int N, M;
     int T, log2T;  // CUDA block size of the reference kernel and its log2
@@ -66,7 +88,9 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
     }
 
     f32x2 px[S / 2], py[S / 2], pz[S / 2];
-    float tmp[S];
+    int tmp[S];          // running min-distance of the slot as its IEEE bit pattern: every value is >= +0 or exactly -1.0f (never a
+                         // candidate), for which signed-integer order IS float order -- v_min_i32 / v_max3_i32 need no NaN canonicalisation
+                         // (fminf costs a v_max x,x,x per operand) and no compare + select pairs
     int kk[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -83,7 +107,7 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
         // double) -> never a candidate.  A slot with tmp = -1 can never beat
         // best (init -1, strict '>') and min(d, -1) keeps it at -1.
         const float mag = sumsq3(x, y, z);
-        tmp[s] = (valid && !((double)mag <= 1e-3)) ? 1e10f : -1.0f;
+        tmp[s] = __float_as_int((valid && !((double)mag <= 1e-3)) ? 1e10f : -1.0f);
     }
 
     float x1 = coord(0, 0), y1 = coord(0, 1), z1 = coord(0, 2);
@@ -99,10 +123,10 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
     }
     const int lane = tid & 63, wave = tid >> 6;
 
+    constexpr int kNone = (int)0xBF800000u;                  // bits of -1.0f: negative as an integer, below every real distance
     for (int j = 1; j < M; ++j) {
-        float best = -1.0f;
-        int bk = 0;
         const f32x2 X1 = {x1, x1}, Y1 = {y1, y1}, Z1 = {z1, z1};
+        int d2[S];
 #pragma unroll
         for (int h = 0; h < S / 2; ++h) {
             // sumsq3 on two slots at once: t = dy*dy; t = fma(dx,dx,t); t = fma(dz,dz,t)   (v_pk_* f32, IEEE per element)
@@ -110,36 +134,103 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
             f32x2 t = dy * dy;
             t = __builtin_elementwise_fma(dx, dx, t);
             t = __builtin_elementwise_fma(dz, dz, t);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int s = 2 * h + e;
-                const float d2 = fminf(t[e], tmp[s]);
-                tmp[s] = d2;
-                const bool gt = d2 > best;
-                bk = gt ? kk[s] : bk;
-                best = gt ? d2 : best;
-            }
+            d2[2 * h] = min(__float_as_int(t[0]), tmp[2 * h]); d2[2 * h + 1] = min(__float_as_int(t[1]), tmp[2 * h + 1]);
+            tmp[2 * h] = d2[2 * h]; tmp[2 * h + 1] = d2[2 * h + 1];
         }
-        // distance bits are monotone for d >= 0; +1 so that "no candidate" = 0
-        const uint32_t kb = best < 0.0f ? 0u : __float_as_uint(best) + 1u;
-        uint32_t m = wave_max_u32(kb);
+        int best = d2[0];
+#pragma unroll
+        for (int sl = 1; sl < S; ++sl) best = max(best, d2[sl]);         // (v_max3_i32 pairs)
+        best = max(best, kNone);
+        int bk = 0;                                               // the FIRST slot that holds the maximum (strict '>' of the reference scan)
+        int m_wave;
+        if constexpr (S == 6 || S == 4) {
+            // The wave reduction's six DPP steps need two wait states each before the next one reads the register, and every
+            // v_cmp -> v_cndmask pair of the slot search two as well; an s_nop costs a lone wave 8 cycles (tools/micro/nop_probe.cpp), as
+            // much as a real instruction.  So the two chains are interleaved by hand: each hazard shadow holds two instructions of the
+            // other chain -- compares first (one SGPR pair per slot), selects in descending slot order afterwards.
+            int v = best;
+            unsigned long long e0, e1, e2, e3, e4, e5;           // (ONE asm statement: between separate ones hipcc puts an s_nop of its own)
+#define UPP_DPP(CTRL) "v_max_i32_dpp %[v], %[v], %[v] " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define UPP_DPPB(CTRL) "v_max_i32_dpp %[v], %[v], %[v] " CTRL " bank_mask:0xf\n\t"
+#define UPP_CMP(E, D) "v_cmp_eq_u32_e64 %[" E "], %[" D "], %[b]\n\t"
+#define UPP_SEL(E, K) "v_cndmask_b32_e64 %[bk], %[bk], %[" K "], %[" E "]\n\t"
+            if constexpr (S == 6) {
+                asm volatile("s_nop 1\n\t"
+                             UPP_DPP("quad_perm:[1,0,3,2]") UPP_CMP("e5", "d5") UPP_CMP("e4", "d4")
+                             UPP_DPP("quad_perm:[2,3,0,1]") UPP_CMP("e3", "d3") UPP_CMP("e2", "d2")
+                             UPP_DPP("row_half_mirror") UPP_CMP("e1", "d1") UPP_CMP("e0", "d0")
+                             UPP_DPP("row_mirror") UPP_SEL("e5", "k5") UPP_SEL("e4", "k4")
+                             UPP_DPPB("row_bcast:15 row_mask:0xa") UPP_SEL("e3", "k3") UPP_SEL("e2", "k2")
+                             UPP_DPPB("row_bcast:31 row_mask:0xc") UPP_SEL("e1", "k1") UPP_SEL("e0", "k0")
+                             : [v] "+v"(v), [bk] "+v"(bk), [e0] "=&s"(e0), [e1] "=&s"(e1), [e2] "=&s"(e2), [e3] "=&s"(e3), [e4] "=&s"(e4), [e5] "=&s"(e5)
+                             : [b] "v"(best), [d0] "v"(d2[0]), [d1] "v"(d2[1]), [d2] "v"(d2[2]), [d3] "v"(d2[3]), [d4] "v"(d2[S > 4 ? 4 : 0]),
+                               [d5] "v"(d2[S > 5 ? 5 : 0]), [k0] "v"(kk[0]), [k1] "v"(kk[1]), [k2] "v"(kk[2]), [k3] "v"(kk[3]),
+                               [k4] "v"(kk[S > 4 ? 4 : 0]), [k5] "v"(kk[S > 5 ? 5 : 0]));
+            } else {
+                asm volatile("s_nop 1\n\t"
+                             UPP_DPP("quad_perm:[1,0,3,2]") UPP_CMP("e3", "d3") UPP_CMP("e2", "d2")
+                             UPP_DPP("quad_perm:[2,3,0,1]") UPP_CMP("e1", "d1") UPP_CMP("e0", "d0")
+                             UPP_DPP("row_half_mirror") UPP_SEL("e3", "k3") UPP_SEL("e2", "k2")
+                             UPP_DPP("row_mirror") UPP_SEL("e1", "k1") UPP_SEL("e0", "k0")
+                             UPP_DPPB("row_bcast:15 row_mask:0xa") "s_nop 1\n\t"
+                             UPP_DPPB("row_bcast:31 row_mask:0xc") "s_nop 1\n\t"
+                             : [v] "+v"(v), [bk] "+v"(bk), [e0] "=&s"(e0), [e1] "=&s"(e1), [e2] "=&s"(e2), [e3] "=&s"(e3)
+                             : [b] "v"(best), [d0] "v"(d2[0]), [d1] "v"(d2[1]), [d2] "v"(d2[2]), [d3] "v"(d2[3]), [k0] "v"(kk[0]), [k1] "v"(kk[1]),
+                               [k2] "v"(kk[2]), [k3] "v"(kk[3]));
+                (void)e4; (void)e5;
+            }
+#undef UPP_DPP
+#undef UPP_DPPB
+#undef UPP_CMP
+#undef UPP_SEL
+            m_wave = __builtin_amdgcn_readlane(v, 63);
+        } else {
+#pragma unroll
+            for (int sl = S - 1; sl >= 0; --sl) bk = d2[sl] == best ? kk[sl] : bk;
+            m_wave = wave_max_i32(best);
+        }
         // lanes are in rank order: the first lane that holds the maximum wins the wave
-        const int wl = __builtin_ctzll(__ballot(kb == m));
+        const int wl = __builtin_ctzll(__ballot(best == m_wave));
+        int m = m_wave;
         uint32_t wk = readlane_u32((uint32_t)bk, wl);
         if (W > 1) {
             uint32_t *r = rec + (j & 1) * (2 * W);
-            if (lane == 0) { r[2 * wave] = m; r[2 * wave + 1] = wk; }
+            if (lane == 0) { r[2 * wave] = (uint32_t)m; r[2 * wave + 1] = wk; }
             __syncthreads();
-            m = r[0]; wk = r[1];
+            if constexpr (W == 4) {
+                // max of the four keys, then the LOWEST wave that holds it (waves are in rank order), all compares ahead of all selects:
+                // no hazard nops; a key < 0 (no candidate anywhere) selects point 0
+                const uint4 ra = *reinterpret_cast<const uint4 *>(r), rb = *reinterpret_cast<const uint4 *>(r + 4);
+                unsigned long long q0, q1, q2, qn;
+                int mm;
+                uint32_t sel = rb.w;                              // wave 3's point unless a lower wave holds the maximum
+                asm volatile("v_max3_i32 %[m], %[r0], %[r1], %[r2]\n\t"
+                             "v_max_i32_e32 %[m], %[m], %[r3]\n\t"
+                             "v_cmp_eq_u32_e64 %[q2], %[r2], %[m]\n\t"
+                             "v_cmp_eq_u32_e64 %[q1], %[r1], %[m]\n\t"
+                             "v_cmp_eq_u32_e64 %[q0], %[r0], %[m]\n\t"
+                             "v_cmp_gt_i32_e64 %[qn], 0, %[m]\n\t"
+                             "v_cndmask_b32_e64 %[s], %[s], %[k2], %[q2]\n\t"
+                             "v_cndmask_b32_e64 %[s], %[s], %[k1], %[q1]\n\t"
+                             "v_cndmask_b32_e64 %[s], %[s], %[k0], %[q0]\n\t"
+                             "v_cndmask_b32_e64 %[s], %[s], 0, %[qn]\n\t"
+                             : [m] "=&v"(mm), [s] "+v"(sel), [q0] "=&s"(q0), [q1] "=&s"(q1), [q2] "=&s"(q2), [qn] "=&s"(qn)
+                             : [r0] "v"(ra.x), [r1] "v"(ra.z), [r2] "v"(rb.x), [r3] "v"(rb.z), [k0] "v"(ra.y), [k1] "v"(ra.w), [k2] "v"(rb.y));
+                m = 0;                                            // (the "no candidate" case is already folded into sel)
+                wk = sel;
+            } else {
+                m = (int)r[0]; wk = r[1];
 #pragma unroll
-            for (int w = 1; w < W; ++w) {            // waves are in rank order too: strict '>' keeps the lower wave
-                const uint32_t mw = r[2 * w], kw = r[2 * w + 1];
-                const bool take = mw > m;
-                m = take ? mw : m;
-                wk = take ? kw : wk;
+                for (int w = 1; w < W; ++w) {        // waves are in rank order too: strict '>' keeps the lower wave
+                    const int mw = (int)r[2 * w];
+                    const uint32_t kw = r[2 * w + 1];
+                    const bool take = mw > m;
+                    m = take ? mw : m;
+                    wk = take ? kw : wk;
+                }
             }
         }
-        const int old = (m == 0u) ? 0 : (int)wk;
+        const int old = m < 0 ? 0 : (int)wk;                      // (no candidate at all: every slot at -1)
         x1 = coord(old, 0); y1 = coord(old, 1); z1 = coord(old, 2);
         if (tid == 0) {
             if (USE_LDS) won[j] = old;
