@@ -158,7 +158,7 @@ def test_rectify_prompter_fused_path_equals_torch_path():
 
 
 @pytest.mark.parametrize("B,N,S,C,k", [(8, 2048, 128, 1152, 3), (4, 1076, 32, 32, 16), (2, 32, 32, 12, 16), (3, 33, 40, 300, 3), (1, 1, 16, 1, 1),
-                                       (2, 4096, 5, 7, 5), (2, 64, 200, 96, 6), (2, 300, 150, 70, 4)])
+                                       (2, 4096, 5, 7, 5), (2, 64, 200, 96, 6), (2, 300, 150, 70, 4), (2, 500, 64, 64, 8), (3, 257, 16, 20, 5), (2, 1000, 128, 32, 3)])
 def test_interp_train_forward_and_feature_gradient(B, N, S, C, k):
     """upp_interp_fwd / upp_interp_bwd (trainable features, constant geometry) against the reference's torch formula."""
     g = torch.Generator(device='cuda').manual_seed(B * N + C)
