@@ -93,6 +93,10 @@ SIGNATURES = {
     "upp_linear_tile": (_c_i, [_c_i, _c_i, _c_i]),
     "upp_linear_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong]
                        + [_c_i] * 5 + [_c_f]),
+    "upp_linear_sb_tile": (_c_i, [_c_i, _c_i, _c_i]),
+    "upp_linear_sb_planes_bytes": (ctypes.c_longlong, [_c_i, _c_i]),
+    "upp_linear_sb_prep": (_c_i, [_c_f, ctypes.c_longlong, _c_i, _c_i, _c_f, _c_f]),
+    "upp_linear_sb_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong] + [_c_i] * 5 + [_c_f]),
     "upp_linear_group_bias_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
     "upp_linear_parts": (_c_i, [_c_i, _c_i, _c_i]),
     "upp_linear_parts_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, ctypes.c_longlong] + [_c_i] * 4 + [_c_f]),

@@ -1,0 +1,435 @@
+// linear_sb.hip -- the token-matrix Linear layers (reference models/Point_MAE_pretask_dev.py:153-169 Mlp.fc1 / fc2, :172-196
+// Attention.qkv / proj) and their data gradients at f32 accuracy on the BF16 matrix pipe of gfx950:
+//
+//     C (M,N) = epilogue( A (M,K) . W (N,K)^T )      A f32, W a FROZEN f32 weight handed over as three bf16 planes
+//
+// v_mfma_f32_32x32x2_f32 issues at 64 FLOP/clk/SIMD -- 1/16 of v_mfma_f32_32x32x16_bf16.  linear.hip (the exact-f32 kernel) runs its
+// k-loop at 98 % of that pipe on the wide shapes and is bound by it.  Here every f32 operand is split EXACTLY into three bf16 terms
+//     x = x1 + x2 + x3,   x1 = rne_bf16(x), x2 = rne_bf16(x - x1), x3 = x - x1 - x2         (both residuals are exact in f32; 3 x 8
+//                                                                                            significand bits + signs = the 24 of f32)
+// and a product is accumulated in f32 from the six terms of weight >= 2^-16:
+//     a w = a1 w1 + (a1 w2 + a2 w1) + (a2 w2 + a1 w3 + a3 w1)  +  [a2 w3 + a3 w2 + a3 w3: |.| <= 2^-25 |a w|, dropped]
+// Each bf16 x bf16 product is exact in f32, so the result carries the error of an f32 GEMM (measured against float64 in
+// tests/test_gpu_linear_sb.py: not larger than that of the f32 fmaf chain of linear.hip) for 6/16 of its matrix-pipe time.  With the
+// matrix pipe 2.7 x cheaper the loop is bound by operand delivery (L2 -> LDS, ~25 B/clk/CU), so:
+//
+//   * W is split ONCE per weight version (upp_linear_sb_prep) into the exact LDS image of the kernel: [32-row block][32-wide k-stage]
+//     [plane][16-byte granule of 8 k][row] -- every LDS-DMA instruction copies 1 KB of contiguous global memory, a lane's fragment of a
+//     k-step is one conflict-free ds_read_b128 per plane, and no swizzle arithmetic is left in the kernel for W.
+//   * A arrives as f32 (4 B per element, the compact form) by LDS-DMA, 8 rows x 128 B per instruction with the granule swizzle of
+//     linear.hip applied to the source address, and is split in registers after the fragment read: 11 VALU instructions per pair of
+//     values (v_cvt_pk_bf16_f32, shift / and, subtract), amortised over the RN column blocks a wave owns.
+//   * Three (four) LDS stages with COUNTED vmcnt: the DMA of k-stage c + NST - 1 is issued while k-stage c is multiplied, one raw
+//     s_barrier per k-stage, DMA in flight across it.
+//   * One workgroup per CU in one round, tiles as linear.hip; the contraction may be cut over KS = 2 wave groups (narrow N);
+//     partial tiles, bias / GELU / GELU' / multiply epilogues and 16-byte stores through the LDS exactly as linear.hip.
+//
+// Not bit-reproducible against a scalar restatement (the internal summation of the bf16 MFMA is not documented): parity is by
+// tolerance against float64 (oracle/oracle.py linear_f64) -- the exact-f32 kernel stays the bit-pinned one and serves every weight that
+// is not frozen, every shape this file does not take (K % 32, unaligned rows, more than one round) and every caller that asks for it.
+#include "common.h"
+
+namespace {
+
+#include "linear_shared.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SB_CHUNK = 6144;          // bytes of one (32-row block, 32-wide k-stage) of the planes: 3 planes x 4 granules x 32 rows x 16 B
+
+struct SbArgs {
+    LinArgs l;                          // A, C, bias, aux, M, N, K, epi, tiles_n as linear.hip (W unused)
+    const unsigned char *planes;        // upp_linear_sb_prep image of W
+    int nblocks, kstages;               // ceil(N / 32), ceil(K / 32) of that image
+};
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));        // v_cvt_pk_bf16_f32 (round to nearest even)
+}
+
+// 8 f32 -> the three bf16 planes (8 bf16 = 4 VGPRs each).  x - x1 and (x - x1) - x2 are exact, x3 needs no rounding.
+__device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
+#ifdef UPP_SB_NO_SPLIT            // diagnostic build: no split arithmetic (wrong results)
+    p1 = __builtin_bit_cast(u32x4, lo); p2 = __builtin_bit_cast(u32x4, hi); p3 = p1 ^ p2;
+    return;
+#endif
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = q < 2 ? lo[2 * q] : hi[2 * q - 4], x1 = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
+        const uint32_t u = pack_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(u << 16), r1 = x1 - __uint_as_float(u & 0xFFFF0000u);
+        const uint32_t v = pack_bf16(r0, r1);
+        const float t0 = r0 - __uint_as_float(v << 16), t1 = r1 - __uint_as_float(v & 0xFFFF0000u);
+        p1[q] = u; p2[q] = v; p3[q] = pack_bf16(t0, t1);
+    }
+}
+
+template <int BMB, int BNB, int RN, int KS, int NST>
+__global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(SbArgs ga) {
+    static_assert(BNB % RN == 0 && (RN == 1 || RN == 2), "wave tile: 1 x RN blocks");
+    constexpr int WPG = BMB * (BNB / RN), NW = WPG * KS, BM = BMB * 32, BN = BNB * 32;
+    constexpr int AG = BM * 128, GB = AG + BNB * SB_CHUNK;          // bytes of one wave group's share of a k-stage: [A rows | W blocks]
+    constexpr int STAGE = KS * GB, TG = GB / 1024, T = KS * TG;     // DMA wave-instructions per stage (1 KB each)
+    constexpr int TPW = (T + NW - 1) / NW;
+    constexpr bool PADDED = TPW * NW != T;                          // some waves issue a dummy instruction into a scratch KB
+    constexpr int RED = NW * RN * 4096;
+    constexpr int LDS_BYTES = (NST * STAGE + (PADDED ? 1024 : 0)) > RED ? (NST * STAGE + (PADDED ? 1024 : 0)) : RED;
+    static_assert(LDS_BYTES <= 160 * 1024, "stages exceed the 160 KB of LDS");
+    static_assert(NST >= 2 && NST <= 4, "LDS stages");
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+
+    const LinArgs &g = ga.l;
+    UPP_STAMP(0)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int by = lin / g.tiles_n, bx = lin - by * g.tiles_n;
+    const int m0 = by * BM, n0 = bx * BN;
+    const int M = g.M, N = g.N;
+    const int nsc = g.K / (32 * KS);                                 // k-stages per wave group (K % (32 KS) == 0: checked by the host)
+    const int ks = wave / WPG, wb = wave - ks * WPG;
+    const int bm = wb / (BNB / RN), bnp = wb - bm * (BNB / RN);
+
+    // ---- DMA sources.  Instruction t of a stage fills KB t of it: group t / TG, then [A: 8 rows x 128 B | W: block j, piece 0..5].
+    const char *src[TPW];
+    int adv[TPW];                                                    // (scalar) bytes from one k-stage to the next
+    unsigned dst[TPW];                                               // (scalar) LDS offset inside a stage
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * NW;
+        if (PADDED && t >= T) {                                      // dummy: 1 KB of the planes into the scratch KB, every stage
+            src[q] = reinterpret_cast<const char *>(ga.planes) + lane * 16; adv[q] = 0; dst[q] = NST * STAGE;
+            continue;
+        }
+        const int grp = t / TG, idx = t - grp * TG;
+        dst[q] = grp * GB + idx * 1024;
+        if (idx < BM / 8) {
+            const int rt = idx * 8 + (lane >> 3);                    // row of the tile
+            const int row = min(m0 + rt, M - 1);
+            const int ko = grp * (g.K / KS) + 4 * ((lane & 7) ^ ((rt >> 1) & 7));
+            src[q] = reinterpret_cast<const char *>(g.A + (long long)row * g.lda + ko); adv[q] = 128;
+        } else {
+            const int wi = idx - BM / 8, j = wi / 6, piece = wi - j * 6;
+            const int nb = min(n0 / 32 + j, ga.nblocks - 1);
+            src[q] = reinterpret_cast<const char *>(ga.planes) + ((long long)nb * ga.kstages + (long long)grp * nsc) * SB_CHUNK + piece * 1024 + lane * 16;
+            adv[q] = SB_CHUNK;
+        }
+    }
+    auto issue1 = [&](int q, int stage, int c) {
+#ifdef UPP_SB_NO_DMA          // diagnostic build: no operand stream (the loop runs on whatever the LDS holds)
+        (void)q; (void)stage; (void)c;
+        return;
+#endif
+        const unsigned off = (PADDED && wave + q * NW >= T) ? dst[q] : stage * STAGE + dst[q];
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[q] + (long long)c * adv[q]), (lds_ptr_t)(lds + off), 16, 0, 0);
+    };
+    auto issue = [&](int stage, int c) {
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) issue1(q, stage, c);
+    };
+
+    // ---- fragment addresses.  A: row image (bm 32 + r) of the group, granules 4 s + 2 h + {0, 1} of k-step s, XOR-swizzled;
+    //      W: block (bnp RN + jj), plane p, granule 2 s + h, row r  ->  one base + immediates.
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)lds;
+    const int sw = (r >> 1) & 7;
+    unsigned adrA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) adrA[i] = lds0 + ks * GB + (bm * 32 + r) * 128 + (((4 * (i >> 1) + 2 * h + (i & 1)) ^ sw) << 4);
+    const unsigned adrW = lds0 + ks * GB + AG + bnp * RN * SB_CHUNK + h * 512 + r * 16;
+
+    f32x16 acc[RN];
+#pragma unroll
+    for (int jj = 0; jj < RN; ++jj)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[jj][t] = 0.0f;
+
+    // Fragment reads are inline asm (to hipcc an LDS-DMA is a pending LDS write that any compiler-visible ds_read may alias: it would wait
+    // vmcnt(0) in front of each); the wait that retires them names the destination registers as read-write operands, which orders every
+    // consumer behind it without a scheduling barrier.
+    struct WSet { u32x4 w[RN][3]; };
+    struct ASplit { u32x4 p1, p2, p3; };
+    f32x4 ra0, ra1;                       // the f32 A fragment of the step being fetched (split as soon as it has landed)
+#define SB_RDA(DST, ADR) asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(ADR));
+#define SB_RDW(DST, ADR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADR), "n"(OFF));
+#define SB_READ(WS, S, SA)                                                                     \
+    SB_RDA(ra0, adrA[2 * (S)] + (SA)) SB_RDA(ra1, adrA[2 * (S) + 1] + (SA))                    \
+    SB_RDW(WS.w[0][0], adrW + (SA), (S) * 1024) SB_RDW(WS.w[0][1], adrW + (SA), 2048 + (S) * 1024) SB_RDW(WS.w[0][2], adrW + (SA), 4096 + (S) * 1024) \
+    if constexpr (RN > 1) {                                                                    \
+        SB_RDW(WS.w[RN - 1][0], adrW + (SA), SB_CHUNK + (S) * 1024) SB_RDW(WS.w[RN - 1][1], adrW + (SA), SB_CHUNK + 2048 + (S) * 1024) \
+        SB_RDW(WS.w[RN - 1][2], adrW + (SA), SB_CHUNK + 4096 + (S) * 1024)                     \
+    }
+    // acc[0] among the wait's operands pins the first half's matrix instructions IN FRONT of the wait (otherwise hipcc may sink them behind
+    // it and the fragment reads are not covered): k-loop of the 128 x 128 tile 21,400 -> 19,700 cycles; at ONE wave per SIMD the same pin
+    // costs 25 % (nothing else can issue while the lone wave sits in the wait), so only workgroups of >= 8 waves carry it.
+#define SB_WAIT(WS)                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if constexpr (RN > 1 && NW >= 8)                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(WS.w[0][0]), "+v"(WS.w[0][1]), "+v"(WS.w[0][2]), \
+                     "+v"(WS.w[RN - 1][0]), "+v"(WS.w[RN - 1][1]), "+v"(WS.w[RN - 1][2]), "+v"(acc[0])); \
+    else if constexpr (NW >= 8)                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(WS.w[0][0]), "+v"(WS.w[0][1]), "+v"(WS.w[0][2]), "+v"(acc[0])); \
+    else if constexpr (RN > 1)                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(WS.w[0][0]), "+v"(WS.w[0][1]), "+v"(WS.w[0][2]), \
+                     "+v"(WS.w[RN - 1][0]), "+v"(WS.w[RN - 1][1]), "+v"(WS.w[RN - 1][2]));     \
+    else                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(WS.w[0][0]), "+v"(WS.w[0][1]), "+v"(WS.w[0][2])); \
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef UPP_SB_NO_MFMA          // diagnostic build: operands delivered, read and split, no matrix instructions
+#define SB_MFMA(AV, WV, JJ) asm volatile("" ::"v"(AV), "v"(WV));
+#else
+#define SB_MFMA(AV, WV, JJ) acc[JJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AV), __builtin_bit_cast(bf16x8, WV), acc[JJ], 0, 0, 0);
+#endif
+    // the six products of one block and k-step, smallest terms first.  SB_M1: one matrix instruction pinned in program order; SB_D: the
+    // q-th DMA instruction of this wave for k-stage CC (into LDS stage ST) pinned behind it -- issued as ONE burst behind the barrier the
+    // DMA instructions cost every wave 60-180 issue cycles each at the same moment with the matrix pipe idle (measured: the loop took
+    // delivery-alone + multiply-alone); one at a time between matrix instructions they are covered.
+#define SB_M1(AV, WV, JJ) SB_MFMA(AV, WV, JJ) __builtin_amdgcn_sched_barrier(0);
+#define SB_D(Q, ST, CC) if constexpr ((Q) < TPW) { issue1(Q, ST, CC); __builtin_amdgcn_sched_barrier(0); }
+    // first half of a k-step's matrix work: runs while the NEXT step's fragments are on their way from the LDS.  DO: issue DMA
+    // instructions Q0 ... Q0 + 3 (those below QE) of k-stage CC behind the first matrix instructions.
+#define SB_HALF1(X, WS, DO, Q0, QE, ST, CC)                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    SB_M1(X.p3, WS.w[0][0], 0) if constexpr (DO && (Q0) < (QE)) { SB_D(Q0, ST, CC) }           \
+    SB_M1(X.p1, WS.w[0][2], 0) if constexpr (DO && (Q0) + 1 < (QE)) { SB_D((Q0) + 1, ST, CC) } \
+    SB_M1(X.p2, WS.w[0][1], 0) if constexpr (DO && (Q0) + 2 < (QE)) { SB_D((Q0) + 2, ST, CC) } \
+    if constexpr (RN > 1) { SB_M1(X.p2, WS.w[0][0], 0) if constexpr (DO && (Q0) + 3 < (QE)) { SB_D((Q0) + 3, ST, CC) } SB_M1(X.p1, WS.w[0][1], 0) SB_M1(X.p1, WS.w[0][0], 0) } \
+    if constexpr (DO) { _Pragma("unroll") for (int q_ = (Q0) + QSLOT; q_ < (QE); ++q_) issue1(q_, ST, CC); }     /* (more instructions than slots: the few-wave tiles) */
+    // second half, interleaved with the split of the next step's A fragment (one matrix instruction, then its share of the ~44 VALU)
+#define SB_PROD_LO(X, WS, JJ) SB_MFMA(X.p3, WS.w[JJ][0], JJ) SB_MFMA(X.p1, WS.w[JJ][2], JJ) SB_MFMA(X.p2, WS.w[JJ][1], JJ)
+#define SB_PROD_HI(X, WS, JJ) SB_MFMA(X.p2, WS.w[JJ][0], JJ) SB_MFMA(X.p1, WS.w[JJ][1], JJ) SB_MFMA(X.p1, WS.w[JJ][0], JJ)
+#define SB_HALF2(X, WS, XN)                                                                    \
+    split8(ra0, ra1, XN.p1, XN.p2, XN.p3);                                                     \
+    if constexpr (RN > 1) { SB_PROD_LO(X, WS, RN - 1) SB_PROD_HI(X, WS, RN - 1) } else { SB_PROD_HI(X, WS, 0) } \
+    asm volatile("" : "+v"(XN.p1), "+v"(XN.p2), "+v"(XN.p3));           /* (the split belongs HERE: not sunk to its first use) */ \
+    _Pragma("unroll") for (int i_ = 0; i_ < (RN > 1 ? 6 : 3); ++i_) {                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+        __builtin_amdgcn_sched_group_barrier(0x002, RN > 1 ? 8 : 15, 0);                       \
+    }                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- main loop.  NST LDS stages, all of them filled ahead: k-stage c + NST goes into the buffer of k-stage c as soon as the barrier
+    // in the middle of iteration c has shown that every wave is done reading it -- its first QH instructions behind the matrix
+    // instructions of step (c, 1), the rest behind those of step (c + 1, 0).  The matrix work is software-pipelined over 16-wide k-steps
+    // (two per stage): while a step is multiplied, the next step's fragments are read from the LDS (first half of its matrix
+    // instructions) and its A fragment is split (second half); the barrier that opens the next stage sits between the two steps of a
+    // stage, where every wave still has a step's worth of matrix work whose operands are in registers.
+    constexpr int QSLOT = RN > 1 ? 4 : 3;                              // DMA slots behind the first matrix instructions of a k-step
+    constexpr int QH = (TPW + 1) / 2 > QSLOT ? QSLOT : (TPW + 1) / 2;   // instructions of a k-stage issued behind step 1, the rest behind step 0
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(s, s);
+#pragma unroll
+    for (int q = 0; q < QH; ++q) issue1(q, NST - 1, NST - 1);
+    wait_vmcnt<(NST - 2) * TPW + QH>();
+    __builtin_amdgcn_s_barrier();
+    WSet w0, w1;
+    ASplit x0, x1;
+    SB_READ(w0, 0, 0u)
+    SB_WAIT(w0)
+    split8(ra0, ra1, x0.p1, x0.p2, x0.p3);
+    // one iteration = k-stage c.  D1: the rest of k-stage c + NST - 1 is issued behind step 0; D2: the head of k-stage c + NST behind step 1.
+#define SB_ITER(D1, D2, VM_STMT)                                                               \
+    {                                                                                          \
+        const unsigned sa = stage * STAGE;                                                     \
+        const int nxt = stage == NST - 1 ? 0 : stage + 1, prv = stage == 0 ? NST - 1 : stage - 1; \
+        SB_READ(w1, 1, sa)                                                                     \
+        SB_HALF1(x0, w0, D1, QH, TPW, prv, c + NST - 1)                                        \
+        SB_WAIT(w1)                                                                            \
+        SB_HALF2(x0, w0, x1)                                                                   \
+        VM_STMT                                                                                \
+        __builtin_amdgcn_s_barrier();         /* k-stage c + 1 is complete; everyone is done reading k-stage c */ \
+        SB_READ(w0, 0, nxt * STAGE)                                                            \
+        SB_HALF1(x1, w1, D2, 0, QH, stage, c + NST)                                            \
+        SB_WAIT(w0)                                                                            \
+        SB_HALF2(x1, w1, x0)                                                                   \
+        stage = nxt;                                                                           \
+    }
+    UPP_STAMP(1)
+    int stage = 0, c = 0;
+    for (; c < nsc - NST; ++c) SB_ITER(true, true, wait_vmcnt<(NST - 2) * TPW>();)
+    SB_ITER(true, false, wait_vmcnt<(NST - 2) * TPW>();)                                      // c = nsc - NST (nsc >= NST: checked by the host)
+    ++c;
+    for (; c + 1 < nsc; ++c)
+        SB_ITER(false, false, if (NST >= 4 && nsc - 2 - c == 1) wait_vmcnt<TPW>(); else wait_vmcnt<0>();)
+    {   // the last k-stage: nothing left to fetch behind step 1
+        const unsigned sa = stage * STAGE;
+        SB_READ(w1, 1, sa)
+        SB_HALF1(x0, w0, false, 0, 0, 0, 0)
+        SB_WAIT(w1)
+        SB_HALF2(x0, w0, x1)
+        SB_HALF1(x1, w1, false, 0, 0, 0, 0)
+        if constexpr (RN > 1) { SB_PROD_LO(x1, w1, RN - 1) SB_PROD_HI(x1, w1, RN - 1) } else { SB_PROD_HI(x1, w1, 0) }
+    }
+#undef SB_ITER
+#undef SB_D
+#undef SB_M1
+#undef SB_HALF2
+#undef SB_HALF1
+#undef SB_PROD_HI
+#undef SB_PROD_LO
+#undef SB_MFMA
+#undef SB_WAIT
+#undef SB_READ
+#undef SB_RDW
+#undef SB_RDA
+
+    // ---- tile -> memory (as linear.hip): every block through the LDS as [slot][t][lane], slot = ks (BMB BNB) + wb RN + jj; the KS partial
+    // tiles are summed in wave-group order from 0.0f, bias / activation / factor act on four columns per lane, 16-byte stores.
+    UPP_STAMP(2)
+    constexpr int TN = 16 / KS;
+    const int T0 = ks * TN;
+    __syncthreads();                                         // all fragment reads done (and no DMA in flight): the stages may be overwritten
+    float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int jj = 0; jj < RN; ++jj)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) red[((wave * RN + jj) * 16 + t) * 64 + lane] = acc[jj][t];
+    if (KS > 1) __syncthreads();
+    const int rb = m0 + bm * 32;
+#pragma unroll
+    for (int jj = 0; jj < RN; ++jj) {
+        const int cb = n0 + (bnp * RN + jj) * 32;
+        const int col = cb + 4 * (lane & 7);
+        const bool col_ok = col < N;
+        f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (g.epi != LEPI_NONE && g.epi != LEPI_MUL && col_ok) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
+#pragma unroll
+        for (int pass = 0; pass < TN / 4; ++pass) {
+            const int ridx = pass * 8 + (lane >> 3), t = T0 + (ridx >> 1);
+            const int row = rb + (t & 3) + 8 * (t >> 2) + 4 * (ridx & 1);
+            const float *sp = red + ((wb * RN + jj) * 16 + T0) * 64 + (pass * 64 + lane) * 4;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(sp);
+            if (KS > 1) {
+                const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                v = zero + v;
+#pragma unroll
+                for (int k2 = 1; k2 < KS; ++k2) v += *reinterpret_cast<const f32x4 *>(sp + k2 * (BMB * BNB) * 1024);
+            }
+            epilogue_store4(g, g.epi, v, bias4, row, col, col_ok && row < M);
+        }
+    }
+    UPP_STAMP(3)
+}
+
+// W (N,K) f32 -> the plane image [block][k-stage][plane][granule][row][8 bf16], zero beyond N and K.  One thread per (row, granule).
+__global__ __launch_bounds__(128) void linear_sb_prep_kernel(const float *__restrict__ W, long long ldw, int N, int K, int kstages, unsigned char *__restrict__ out) {
+    const int chunk = blockIdx.x, nb = chunk / kstages, kst = chunk - nb * kstages;
+    const int row = threadIdx.x & 31, gq = threadIdx.x >> 5;
+    const int n = nb * 32 + row, k0 = kst * 32 + gq * 8;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (n < N && k0 + e < K) ? W[(long long)n * ldw + k0 + e] : 0.0f;
+    const f32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
+    u32x4 p1, p2, p3;
+    split8(lo, hi, p1, p2, p3);
+    unsigned char *base = out + (long long)chunk * SB_CHUNK + gq * 512 + row * 16;
+    *reinterpret_cast<u32x4 *>(base) = p1;
+    *reinterpret_cast<u32x4 *>(base + 2048) = p2;
+    *reinterpret_cast<u32x4 *>(base + 4096) = p3;
+}
+
+struct SbConfig { int bmb, bnb, rn, ks, nst; };
+#ifndef UPP_SB_NST44
+#define UPP_SB_NST44 3
+#endif
+#define UPP_SB_CONFIGS(X) X(4, 4, 2, 1, UPP_SB_NST44) X(4, 3, 1, 1, 4) X(3, 4, 2, 1, 4) X(2, 4, 2, 1, 4) X(2, 3, 1, 1, 4) X(2, 2, 1, 2, 3) X(2, 2, 2, 4, 2) X(1, 2, 1, 2, 4)
+#define UPP_SB_ENTRY(a, b, c, d, e) {a, b, c, d, e},
+constexpr SbConfig kSbConfigs[] = {UPP_SB_CONFIGS(UPP_SB_ENTRY)};
+#undef UPP_SB_ENTRY
+constexpr int kNumSbConfigs = sizeof(kSbConfigs) / sizeof(kSbConfigs[0]);
+inline int sb_code(const SbConfig &c) { return 0x400000 + c.bmb * 65536 + c.bnb * 4096 + c.rn * 256 + c.ks * 16 + c.nst; }     // hex digits 4 BMB BNB RN KS NST
+
+// One round of at most 256 workgroups; among the shapes that fit, the smallest of max(matrix-pipe cycles of the busiest SIMD + 0.7 x the
+// VALU cycles of its A splits, bytes a workgroup stages / 40 B per clock) -- fitted to the in-kernel stamps of tools/micro/sb_stamps.py
+// (fc1 128 x 128: 23.7k cycles for 18.4k + 0.7 x 9.6k; fc2 64 x 64 with one block per wave: 34k for 18.4k + 0.7 x 19.2k, which is why
+// the narrow shapes take the tile whose waves own both column blocks).  0: not a problem for this file.
+int pick_sb(int M, int N, int K) {
+    if (K % 32 != 0 || K < 64) return 0;
+    const int mb = (M + 31) / 32, nb = (N + 31) / 32;
+    int best = 0;
+    long long best_cost = 0;
+    for (int i = 0; i < kNumSbConfigs; ++i) {
+        const SbConfig c = kSbConfigs[i];
+        if (K % (32 * c.ks) != 0 || K / (32 * c.ks) < c.nst) continue;          // (every LDS stage is filled before the loop starts)
+        const long long wgs = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
+        if (wgs > 256) continue;
+        const int waves = c.bmb * (c.bnb / c.rn) * c.ks;
+        const long long mfma = (long long)((waves + 3) / 4) * c.rn * (K / c.ks / 16) * 192;
+        const long long bytes = (long long)(c.bmb * 32 * 128 + c.bnb * SB_CHUNK) * (K / 32);
+        const long long valu = (long long)((waves + 3) / 4) * (K / c.ks / 16) * 200;          // ~44 instructions per split of 8 values
+        const long long pipe = mfma + valu * 7 / 10;
+        long long cost = (pipe > bytes / 40 ? pipe : bytes / 40) * 1000 + (256 - wgs);
+        if (wgs < 128) cost += cost / 2;                       // half the chip idle: the stream beside it gains, this launch does not
+        if (!best || cost < best_cost) { best = sb_code(c); best_cost = cost; }
+    }
+    return best;
+}
+
+template <int BMB, int BNB, int RN, int KS, int NST>
+int launch_sb(const SbArgs &g0, hipStream_t st) {
+    SbArgs g = g0;
+    const int tiles_m = (g.l.M + BMB * 32 - 1) / (BMB * 32);
+    g.l.tiles_n = (g.l.N + BNB * 32 - 1) / (BNB * 32);
+    hipLaunchKernelGGL((linear_sb_kernel<BMB, BNB, RN, KS, NST>), dim3((unsigned)(tiles_m * g.l.tiles_n)), dim3(BMB * (BNB / RN) * KS * 64), 0, st, g);
+    return upp_launch_status();
+}
+
+}  // namespace
+
+#ifdef UPP_LIN_STAMPS
+extern "C" void upp_linear_sb_set_stamps(unsigned long long *p) { g_lin_stamps = p; }
+#endif
+
+extern "C" int upp_linear_sb_tile(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
+    return pick_sb(M, N, K);
+}
+
+extern "C" long long upp_linear_sb_planes_bytes(int N, int K) {
+    if (N < 1 || K < 1) return UPP_E_BADARG;
+    return (long long)((N + 31) / 32) * ((K + 31) / 32) * SB_CHUNK;
+}
+
+extern "C" int upp_linear_sb_prep(const float *W, long long ldw, int N, int K, void *planes, void *stream) {
+    if (!W || !planes || N < 1 || K < 1) return UPP_E_BADARG;
+    if (ldw < K || (reinterpret_cast<uintptr_t>(planes) & 15)) return UPP_E_RANGE;
+    const int kstages = (K + 31) / 32, nblocks = (N + 31) / 32;
+    hipLaunchKernelGGL(linear_sb_prep_kernel, dim3((unsigned)(nblocks * kstages)), dim3(128), 0, (hipStream_t)stream, W, ldw, N, K, kstages,
+                       reinterpret_cast<unsigned char *>(planes));
+    return upp_launch_status();
+}
+
+extern "C" int upp_linear_sb_f32(const float *A, long long lda, const void *planes, const float *bias, float *C, long long ldc, float *aux,
+                                 long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream) {
+    if (!A || !planes || !C || M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
+    if (K % 32 != 0 || lda % 4 != 0 || lda < K || ldc < N || N % 4 != 0 || ldc % 4 != 0) return UPP_E_RANGE;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(C)) & 15) return UPP_E_RANGE;
+    if (ldc > (1LL << 24) || ldaux > (1LL << 24)) return UPP_E_RANGE;
+    if (epilogue < LEPI_NONE || epilogue > LEPI_BIAS_RELU) return UPP_E_RANGE;
+    if ((epilogue == LEPI_BIAS || epilogue == LEPI_BIAS_GELU || epilogue == LEPI_BIAS_GELU_D || epilogue == LEPI_BIAS_RELU) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15))) return UPP_E_BADARG;
+    if ((epilogue == LEPI_BIAS_GELU_D || epilogue == LEPI_MUL) && (!aux || ldaux < N || ldaux % 4 != 0 || (reinterpret_cast<uintptr_t>(aux) & 15))) return UPP_E_BADARG;
+    if (tile <= 0) tile = pick_sb(M, N, K);
+    if (tile <= 0) return UPP_E_RANGE;
+    SbArgs g{};
+    g.l.A = A; g.l.lda = lda; g.l.C = C; g.l.ldc = ldc; g.l.bias = bias; g.l.aux = aux; g.l.ldaux = ldaux;
+    g.l.M = M; g.l.N = N; g.l.K = K; g.l.epi = epilogue;
+#ifdef UPP_LIN_STAMPS
+    g.l.stamps = g_lin_stamps;
+#endif
+    g.planes = reinterpret_cast<const unsigned char *>(planes);
+    g.nblocks = (N + 31) / 32; g.kstages = (K + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+#define UPP_SB_CASE(a, b, c, d, e)                                                                    \
+    case 0x400000 + a * 65536 + b * 4096 + c * 256 + d * 16 + e:                                          \
+        if (K % (32 * d) != 0 || K / (32 * d) < e) return UPP_E_RANGE;                                \
+        return launch_sb<a, b, c, d, e>(g, st);
+    switch (tile) {
+        UPP_SB_CONFIGS(UPP_SB_CASE)
+        default: return UPP_E_RANGE;
+    }
+#undef UPP_SB_CASE
+}

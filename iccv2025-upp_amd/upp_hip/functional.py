@@ -446,6 +446,7 @@ def refresh_caches(model=None):
             if hasattr(m, 'refresh_padded_weight'):
                 m.refresh_padded_weight()
     TRANSPOSED.refresh()
+    ops.PLANES.refresh()              # (after the transposes: the plane images of W^T copies are split from the refreshed copies)
 
 
 def _wt(w):
@@ -479,7 +480,7 @@ class _LinearMFMA(Function):
         ctx.x_parts, ctx.out_parts = int(x_parts), bool(out_parts)
         if out_parts:
             return ops.linear_parts(xin, w)
-        return ops.linear_f32(xin, w, b, ops.LIN_BIAS if b is not None else ops.LIN_NONE)
+        return ops.linear_f32(xin, w, b, ops.LIN_BIAS if b is not None else ops.LIN_NONE, frozen=not w.requires_grad)
 
     @staticmethod
     def backward(ctx, g):
@@ -495,7 +496,7 @@ class _LinearMFMA(Function):
             if ctx.x_parts:
                 gx = ops.linear_parts(g2, wt, ctx.x_parts).view((ctx.x_parts,) + g.shape[:-1] + (w.shape[1],))
             elif wt.shape[1] % 4 == 0 and g2.stride(0) % 4 == 0:
-                gx = ops.linear_f32(g2, wt).view(g.shape[:-1] + (w.shape[1],))
+                gx = ops.linear_f32(g2, wt, frozen=not w.requires_grad).view(g.shape[:-1] + (w.shape[1],))
             elif wt.shape[1] <= 64 and wt.shape[0] <= 256:
                 # a narrow layer (the 64 -> 3 score head of the denoising prompter): the data gradient contracts over its few outputs
                 gx = ops.linear_smallk(g2, wt, None, 0).view(g.shape[:-1] + (w.shape[1],))
@@ -614,7 +615,7 @@ class _LinearGroupBias(Function):
         g2 = g if g.is_contiguous() else g.contiguous()
         gx = gw = ggb = None
         if ctx.needs_input_grad[0]:
-            gx = ops.linear_f32(g2, _wt(w))
+            gx = ops.linear_f32(g2, _wt(w), frozen=not w.requires_grad)
         if ctx.needs_input_grad[1]:
             gw = weight_grad(g2, x, w, True)
         if ctx.needs_input_grad[2]:
@@ -670,7 +671,7 @@ def linear(x, weight, bias=None, own_wgrad=False, act=None, x_parts=0, out_parts
             raise ValueError("linear: k-parts need a servable f32 HIP operand, no activation and (out_parts) no bias")
         if not needs_grad:
             xin = x[0] if x_parts else x
-            return ops.linear_parts(xin, weight) if out_parts else ops.linear_f32(xin, weight, bias, ops.LIN_BIAS if bias is not None else ops.LIN_NONE)
+            return ops.linear_parts(xin, weight) if out_parts else ops.linear_f32(xin, weight, bias, ops.LIN_BIAS if bias is not None else ops.LIN_NONE, frozen=not weight.requires_grad)
         return _LinearMFMA.apply(x, weight, bias, bool(own_wgrad), int(x_parts), bool(out_parts))
     if (x.is_cuda and weight.dim() == 2 and weight.dtype == torch.float32 and weight.shape[1] % 4 == 0 and weight.shape[1] > 64
             and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16)):
@@ -696,7 +697,7 @@ def linear(x, weight, bias=None, own_wgrad=False, act=None, x_parts=0, out_parts
     if not needs_grad:
         if act is not None and bias is None:
             bias = _zero_bias(weight)
-        return ops.linear_f32(x, weight, bias, _ACT_EPI[act][0] if bias is not None else ops.LIN_NONE)
+        return ops.linear_f32(x, weight, bias, _ACT_EPI[act][0] if bias is not None else ops.LIN_NONE, frozen=not weight.requires_grad)
     return _act_torch(_LinearMFMA.apply(x, weight, bias, bool(own_wgrad)), act)
 
 
@@ -721,14 +722,14 @@ class _MlpGelu(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2=None, x_parts=0, out_parts=False):
         xin = x[0] if x_parts else x            # (k-parts protocol: see _LinearMFMA)
-        hid, d = ops.linear_f32(xin, w1, b1, ops.LIN_BIAS_GELU_D)
+        hid, d = ops.linear_f32(xin, w1, b1, ops.LIN_BIAS_GELU_D, frozen=not w1.requires_grad)
         train = w1.requires_grad or w2.requires_grad or b1.requires_grad
         ctx.save_for_backward(d, w1, w2, xin if train else None, hid if w2.requires_grad else None)
         ctx.bias_ptrs = (b1.data_ptr(), b2.data_ptr() if b2 is not None else 0)
         ctx.x_parts, ctx.out_parts = int(x_parts), bool(out_parts)
         if out_parts:
             return ops.linear_parts(hid, w2)
-        return ops.linear_f32(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE)
+        return ops.linear_f32(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE, frozen=not w2.requires_grad)
 
     @staticmethod
     def backward(ctx, g):
@@ -739,13 +740,13 @@ class _MlpGelu(Function):
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        g_z = ops.linear_f32(g2, _wt(w2), None, ops.LIN_MUL, aux=d.view(-1, d.shape[-1]))
+        g_z = ops.linear_f32(g2, _wt(w2), None, ops.LIN_MUL, aux=d.view(-1, d.shape[-1]), frozen=not w2.requires_grad)
         gx = None
         if need[0]:
             if ctx.x_parts:
                 gx = ops.linear_parts(g_z, _wt(w1), ctx.x_parts).view((ctx.x_parts,) + g.shape[:-1] + (w1.shape[1],))
             else:
-                gx = ops.linear_f32(g_z, _wt(w1)).view(g.shape[:-1] + (w1.shape[1],))
+                gx = ops.linear_f32(g_z, _wt(w1), frozen=not w1.requires_grad).view(g.shape[:-1] + (w1.shape[1],))
         gw1 = gb1 = gw2 = gb2 = None
         if need[1]:
             gw1 = weight_grad(g_z, x.reshape(-1, x.shape[-1]), w1)
@@ -765,8 +766,8 @@ def mlp_gelu(x, w1, b1, w2, b2=None, x_parts=0, out_parts=False):
         raise ValueError("mlp_gelu: out_parts leaves the fc2 bias to the consumer (ybias)")
     if not torch.is_grad_enabled() or not (x.requires_grad or w1.requires_grad or w2.requires_grad or b1.requires_grad
                                            or (b2 is not None and b2.requires_grad)):
-        hid = ops.linear_f32(x[0] if x_parts else x, w1, b1, ops.LIN_BIAS_GELU)
-        return ops.linear_parts(hid, w2) if out_parts else ops.linear_f32(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE)
+        hid = ops.linear_f32(x[0] if x_parts else x, w1, b1, ops.LIN_BIAS_GELU, frozen=not w1.requires_grad)
+        return ops.linear_parts(hid, w2) if out_parts else ops.linear_f32(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE, frozen=not w2.requires_grad)
     return _MlpGelu.apply(x, w1, b1, w2, b2, int(x_parts), bool(out_parts))
 
 

@@ -5,6 +5,9 @@ Each function validates its tensors the way the reference extensions do
 never allocates), and enqueues the HIP kernels on torch's current stream.
 CPU tensors raise: there is no fallback path.
 """
+import os
+import weakref
+
 import torch
 
 from . import _abi
@@ -252,11 +255,61 @@ class time_linear_calls:
 
     def report(self):
         torch.cuda.synchronize()
-        return [(M, N, K, e, a.elapsed_time(b)) for (M, N, K, e, a, b) in self.calls]
+        return [(M, N, K, e, a.elapsed_time(b)) for (M, N, K, e, a, b, *_) in self.calls]
 
 
-def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
-    """C (M,N) = epilogue(a (M,K) . w (N,K)^T) on the FP32 matrix cores (upp_linear_f32).
+SPLIT_BF16 = os.environ.get("UPP_SPLIT_BF16", "1") != "0"      # frozen weights on the bf16 matrix pipe at f32 accuracy (csrc/linear_sb.hip)
+
+
+class _WeightPlanes:
+    """bf16 plane images (upp_linear_sb_prep) of FROZEN weights and of their cached transposes: one image per weight, made on first use
+    (the eager warm-up of a captured step) and refreshed IN PLACE when the version counter of the weight's storage moved (load_state_dict,
+    the in-place refresh of a cached W^T) -- in place, so that HIP graphs that captured the image's address stay valid.  `refresh()`
+    re-splits every live entry (functional.refresh_caches: weights loaded into a model whose step is already captured)."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, w):
+        owner = w._base if w._base is not None else w
+        key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()))
+        e = self.entries.get(key)
+        if e is None or e[0]() is None:
+            if len(self.entries) > 1024:
+                self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
+            N, K = w.shape
+            nbytes = int(_abi.load().upp_linear_sb_planes_bytes(N, K))
+            planes = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            _call(w.device, "upp_linear_sb_prep", _abi.ptr(w), w.stride(0), N, K, _abi.ptr(planes))
+            self.entries[key] = [weakref.ref(owner), owner._version, planes, (tuple(w.shape), tuple(w.stride()), w.storage_offset())]
+            return planes
+        if e[1] != owner._version and not torch.cuda.is_current_stream_capturing():
+            _call(w.device, "upp_linear_sb_prep", _abi.ptr(w), w.stride(0), w.shape[0], w.shape[1], _abi.ptr(e[2]))
+            e[1] = owner._version
+        return e[2]
+
+    def refresh(self):
+        for e in self.entries.values():
+            owner = e[0]()
+            if owner is not None:
+                w = torch.as_strided(owner.detach(), e[3][0], e[3][1], e[3][2])
+                _call(w.device, "upp_linear_sb_prep", _abi.ptr(w), w.stride(0), w.shape[0], w.shape[1], _abi.ptr(e[2]))
+                e[1] = owner._version
+
+
+PLANES = _WeightPlanes()
+
+
+def linear_sb_tile(M, N, K):
+    """Tile code of the split-bf16 kernel for (M,N,K), 0 = not a problem for it (upp_linear_sb_tile)."""
+    return max(0, int(_abi.load().upp_linear_sb_tile(int(M), int(N), int(K))))
+
+
+def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None, frozen=False):
+    """C (M,N) = epilogue(a (M,K) . w (N,K)^T) on the matrix cores: upp_linear_f32 (exact f32 MFMA, bit-pinned order), or -- frozen=True: w
+    is a frozen weight or a cached copy of one, its contents change only through torch (version counter) -- upp_linear_sb_f32 (three-way
+    bf16 split of both operands, six bf16 MFMA products, f32 accumulate: f32 accuracy at 6/16 of the matrix-pipe time) where that kernel
+    takes the shape.
     a: (..., K) f32 whose rows are K-contiguous with one common row stride; w: (N,K).
     epilogue LIN_BIAS_GELU_D returns (C, GELU'); LIN_MUL multiplies by aux (M,N)."""
     if not (isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1):
@@ -285,15 +338,23 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None):
             raise RuntimeError("linear_f32: aux must be (M,N)")
     if bias is not None:
         _need(bias, "bias", torch.float32, 1, N)
+    sb = 0
+    if (frozen and SPLIT_BF16 and tile == 0 and N % 4 == 0 and K % 32 == 0 and out.data_ptr() % 16 == 0
+            and (bias is None or bias.data_ptr() % 16 == 0) and (aux is None or aux.data_ptr() % 16 == 0)):
+        sb = linear_sb_tile(M, N, K)
     scope = time_linear_calls.active
     if scope is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _call(a.device, "upp_linear_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(bias), _abi.ptr(out), N,
-          _abi.ptr(aux), N, M, N, K, int(epilogue), int(tile))
+    if sb:
+        _call(a.device, "upp_linear_sb_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(PLANES.get(w)), _abi.ptr(bias), _abi.ptr(out), N,
+              _abi.ptr(aux), N, M, N, K, int(epilogue), sb)
+    else:
+        _call(a.device, "upp_linear_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(bias), _abi.ptr(out), N,
+              _abi.ptr(aux), N, M, N, K, int(epilogue), int(tile))
     if scope is not None:
         ev1.record()
-        scope.calls.append((M, N, K, int(epilogue), ev0, ev1))
+        scope.calls.append((M, N, K, int(epilogue), ev0, ev1, sb))
     return (out, d) if epilogue == LIN_BIAS_GELU_D else out
 
 

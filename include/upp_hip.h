@@ -517,6 +517,27 @@ int upp_linear_group_bias_f32(const float *A, long long lda, const float *W, lon
 int upp_linear_parts(int M, int N, int K);
 int upp_linear_parts_f32(const float *A, long long lda, const float *W, long long ldw, float *C, long long ldc, long long part_stride,
                          int M, int N, int K, int parts, void *stream);
+/* ---- the same Linear layers at f32 accuracy on the BF16 matrix pipe (csrc/linear_sb.hip) ------------------------------
+ * Replaces the same reference calls as upp_linear_f32 (models/Point_MAE_pretask_dev.py:153-196, nn.Linear -> cuBLAS) for FROZEN
+ * weights: C (M,N) = epilogue( A (M,K) . W (N,K)^T ) with every f32 operand split exactly into three bf16 terms (x = x1 + x2 + x3,
+ * round-to-nearest, both residuals exact) and the six products of weight >= 2^-16 accumulated in f32 by v_mfma_f32_32x32x16_bf16;
+ * the dropped terms are below 2^-25 |a w|: the error against an exact product is that of an f32 GEMM (tests/test_gpu_linear_sb.py
+ * measures both against float64), at 6/16 of the matrix-pipe time of v_mfma_f32_32x32x2_f32.  Not bit-pinned (the summation order
+ * inside a bf16 MFMA is not documented): the exact-f32 kernel above stays the bit-pinned one.
+ *   upp_linear_sb_planes_bytes(N, K): size of the plane image of a (N,K) weight (6 bytes per element, N and K rounded up to 32).
+ *   upp_linear_sb_prep(W, ldw, N, K, planes): split W once per weight version into the kernel's LDS image
+ *       [32-row block][32-wide k-stage][plane 0..2][16-byte granule of 8 k][row] (zero beyond N, K); planes 16-byte aligned.
+ *   upp_linear_sb_tile(M, N, K): the tile code the library would take (hex digits 0x4 BMB BNB RN KS NST: workgroups of
+ *       BMB x BNB blocks of 32 x 32, a wave owns 1 x RN of them, the contraction cut over KS wave groups, NST LDS stages of 32 KS values
+ *       of k), or 0 when the problem is not one for this kernel (K % 32, K < 64, more than one round of 256 workgroups).
+ *   upp_linear_sb_f32: epilogues and aux as upp_linear_f32; tile 0 = the library's choice.  Limits: K % 32 == 0 (% 64 for KS = 2 tiles),
+ *       N % 4 == 0, lda % 4 == 0, ldc % 4 == 0, ldaux % 4 == 0, A / C / bias / aux 16-byte aligned; UPP_E_RANGE otherwise (the caller
+ *       then takes upp_linear_f32). */
+int upp_linear_sb_tile(int M, int N, int K);
+long long upp_linear_sb_planes_bytes(int N, int K);
+int upp_linear_sb_prep(const float *W, long long ldw, int N, int K, void *planes, void *stream);
+int upp_linear_sb_f32(const float *A, long long lda, const void *planes, const float *bias, float *C, long long ldc, float *aux,
+                      long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream);
 /* upp_linear_smallk_f32: y (M,N) = act(x (M,K) . W (N,K)^T + bias) for the Linear layers upp_linear_f32 does not take (K not a
  * multiple of 4, unaligned rows): the first layer of every position MLP (K = 3; reference models/Point_MAE_unify.py pos_embed /
  * models/Point_MAE_pretask_dev.py:395-399 `nn.Linear(3, 128), nn.GELU(), nn.Linear(128, dim)`) and the first point-wise layer of

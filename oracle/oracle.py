@@ -185,6 +185,37 @@ def linear_f32(a, w, bias=None, aux=None, ks=1, kc=1, epilogue=0):
     return out
 
 
+def bf16_rne(x):
+    """f32 -> the nearest bf16 (ties to even), returned as f32: v_cvt_pk_bf16_f32 (finite inputs)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def split3_bf16(x):
+    """x (f32) -> (x1, x2, x3), each a bf16 value held in f32, with x1 + x2 + x3 == x exactly for x = 0 and |x| >= 2^-110 (absolute
+    error below 2^-133 otherwise): x1 = rne(x), x2 = rne(x - x1), x3 = rne(x - x1 - x2) (both residuals are exact in f32).  The operand split of upp_linear_sb_f32 / upp_linear_sb_prep (csrc/linear_sb.hip)."""
+    x = np.ascontiguousarray(x, np.float32)
+    x1 = bf16_rne(x)
+    r = x - x1
+    x2 = bf16_rne(r)
+    x3 = bf16_rne(r - x2)          # (exact, i.e. no rounding happens, for |x| >= 2^-110: below, x - x1 - x2 falls under the bf16 subnormal grid)
+    return x1, x2, x3
+
+
+def linear_split(a, w, bias=None):
+    """C = a . w^T as upp_linear_sb_f32 forms it, in EXACT arithmetic (float64 sums of the exact bf16 x bf16 products): the six terms
+    a1 w1 + a1 w2 + a2 w1 + a2 w2 + a1 w3 + a3 w1 of the three-way bf16 split of both operands.  What the kernel adds to this is only
+    the rounding of its f32 accumulation (the summation order inside a bf16 MFMA is not documented, so the kernel is held to this by
+    tolerance, not bit for bit).  Stands for torch.nn.functional.linear (reference models/Point_MAE_pretask_dev.py:153-196)."""
+    a1, a2, a3 = (t.astype(np.float64) for t in split3_bf16(a))
+    w1, w2, w3 = (t.astype(np.float64) for t in split3_bf16(w))
+    c = a1 @ w1.T + (a1 @ w2.T + a2 @ w1.T) + (a2 @ w2.T + a1 @ w3.T + a3 @ w1.T)
+    if bias is not None:
+        c = c + np.asarray(bias, np.float64)
+    return c
+
+
 def linear_wgrad(g, x, rows):
     """(splits, N, K) partial weight gradients g (M,N)^T . x (M,K) as upp_linear_wgrad_grouped_f32 sums them: runs of `rows` rows,
     one ascending-row fmaf chain each.  See oracle_linear_wgrad in upp_oracle.c."""

@@ -1,0 +1,152 @@
+"""upp_linear_sb_f32 / upp_linear_sb_prep (csrc/linear_sb.hip): the Linear layers of the Transformer blocks (reference
+models/Point_MAE_pretask_dev.py:153-196) with frozen weights, f32 operands split exactly into three bf16 terms, six bf16 MFMA
+products accumulated in f32.  Checked against float64 and against the exact-f32 kernel (upp_linear_f32) on the same operands; the
+split arithmetic itself is restated in oracle.linear_split (tests/test_linear_split_oracle.py, no GPU)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from upp_hip import functional as HF, ops, _abi
+
+pytestmark = pytest.mark.gpu
+
+SB_CONFIGS = [0x400000 + a * 65536 + b * 4096 + c * 256 + d * 16 + e for (a, b, c, d, e) in
+              [(4, 4, 2, 1, 3), (4, 3, 1, 1, 4), (3, 4, 2, 1, 4), (2, 4, 2, 1, 4), (2, 3, 1, 1, 4), (2, 2, 1, 2, 3), (2, 2, 2, 4, 2), (1, 2, 1, 2, 4)]]
+TOKENS = [2400, 2080, 2048, 1120]
+LAYERS = [("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536), ("dqkv", 384, 1152)]
+
+
+def _operands(M, N, K, seed=0, spread=0):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g) * K ** -0.5
+    if spread:                       # a wide range of magnitudes inside every row
+        a = a * torch.exp2(torch.randint(-spread, spread + 1, (M, K), device='cuda', generator=g).float())
+        w = w * torch.exp2(torch.randint(-spread, spread + 1, (N, K), device='cuda', generator=g).float())
+    b = torch.randn(N, device='cuda', generator=g)
+    return a, w, b
+
+
+def _sb(a, w, bias=None, epilogue=ops.LIN_NONE, aux=None, tile=0):
+    """upp_linear_sb_f32 with a forced tile (ops.linear_f32(..., frozen=True) takes the library's choice)."""
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device='cuda')
+    d = torch.empty(M, N, device='cuda') if epilogue == ops.LIN_BIAS_GELU_D else aux
+    ops._call(a.device, "upp_linear_sb_f32", _abi.ptr(a), a.stride(0), _abi.ptr(ops.PLANES.get(w)), _abi.ptr(bias), _abi.ptr(out), N,
+              _abi.ptr(d), N, M, N, K, int(epilogue), int(tile))
+    return (out, d) if epilogue == ops.LIN_BIAS_GELU_D else out
+
+
+def _planes_to_terms(planes, N, K):
+    """The plane image [block][k-stage][plane][granule][row][8 bf16] -> (3, N, K) f32."""
+    nb, ks = (N + 31) // 32, (K + 31) // 32
+    t = planes.view(torch.int16).view(nb, ks, 3, 4, 32, 8).permute(2, 0, 4, 1, 3, 5).reshape(3, nb * 32, ks * 32)
+    return (t.to(torch.int32) << 16).view(torch.float32)
+
+
+@pytest.mark.parametrize("shape", [(384, 384), (1536, 384), (40, 128), (50, 100), (33, 32)])
+def test_prep_writes_the_exact_three_way_split_in_the_kernel_image(shape):
+    N, K = shape
+    w = torch.randn(N, K, device='cuda') * torch.exp2(torch.randint(-12, 13, (N, K), device='cuda').float())
+    planes = ops.PLANES.get(w)
+    assert planes.numel() == _abi.load().upp_linear_sb_planes_bytes(N, K) == ((N + 31) // 32) * ((K + 31) // 32) * 6144
+    terms = _planes_to_terms(planes, N, K).cpu().numpy()
+    want = np.stack(oracle.split3_bf16(w.cpu().numpy()))
+    assert np.array_equal(terms[:, :N, :K], want)                                  # bit for bit the restated split
+    assert not terms[:, N:, :].any() and not terms[:, :, K:].any()                 # zero beyond N and K
+    assert np.array_equal(terms[:, :N, :K].astype(np.float64).sum(0), w.cpu().numpy().astype(np.float64))   # and it is exact
+
+
+@pytest.mark.parametrize("cfg", SB_CONFIGS, ids=[hex(c) for c in SB_CONFIGS])
+@pytest.mark.parametrize("shape", [(75, 384, 384), (2400, 1152, 384), (333, 96, 256), (1, 40, 128), (129, 1536, 512), (2080, 384, 1536), (31, 36, 64)])
+def test_every_compiled_tile_small_integers_exactly(cfg, shape):
+    """Integer operands (|.| <= 16): every partial sum is an integer below 2^24, so ANY correct summation order gives the exact
+    product -- a layout test (rows, columns, k-groups, edge tiles, the asymmetric weight) that no tolerance can blur."""
+    M, N, K = shape
+    if K % (32 * ((cfg >> 4) & 15)) or K // (32 * ((cfg >> 4) & 15)) < (cfg & 15):
+        pytest.skip("the wave groups' k-stages do not divide K, or fewer k-stages than LDS stages")
+    g = torch.Generator(device='cuda').manual_seed(cfg)
+    a = torch.randint(-16, 17, (M, K), device='cuda', generator=g).float()
+    w = torch.randint(-16, 17, (N, K), device='cuda', generator=g).float()
+    got = _sb(a, w, tile=cfg)
+    assert torch.equal(got.double(), a.double() @ w.double().t())
+
+
+@pytest.mark.parametrize("M", TOKENS)
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+@pytest.mark.parametrize("spread", [0, 8])
+def test_block_shapes_are_as_accurate_as_the_exact_f32_kernel(M, layer, spread):
+    _, N, K = layer
+    a, w, b = _operands(M, N, K, seed=M + N, spread=spread)
+    assert ops.linear_sb_tile(M, N, K) > 0
+    got = ops.linear_f32(a, w, b, ops.LIN_BIAS, frozen=True)
+    f32 = ops.linear_f32(a, w, b, ops.LIN_BIAS)
+    exact = a.double() @ w.double().t() + b.double()
+    bound = a.abs().double() @ w.abs().double().t() + b.abs().double()            # sum over k of |a w|: the scale every rounding refers to
+    e_sb = ((got.double() - exact).abs() / bound).max().item()
+    e_f32 = ((f32.double() - exact).abs() / bound).max().item()
+    # measured on MI355X over these 40 cases: e_sb 1.3e-7 ... 3.4e-7, e_f32 0.9e-7 ... 4.1e-7 -- the f32 accumulation of either kernel
+    assert e_sb <= 1.5 * e_f32 + 1e-7, (e_sb, e_f32)          # (spread = 8: both 0.6e-6 ... 1.5e-6)
+    # north_star's bar, with a decade to spare: 1e-6 of the output scale
+    assert (got.double() - exact).abs().max().item() <= 1e-6 * exact.abs().max().item()
+    # and the kernel adds only f32 accumulation rounding to the restated arithmetic (oracle.linear_split: the six products, exact sums)
+    if M <= 1200:
+        split = torch.from_numpy(oracle.linear_split(a.cpu().numpy(), w.cpu().numpy(), b.cpu().numpy())).cuda()
+        assert ((got.double() - split).abs() / bound).max().item() <= 1.5 * e_f32 + 1e-7
+
+
+@pytest.mark.parametrize("cfg", SB_CONFIGS, ids=[hex(c) for c in SB_CONFIGS])
+def test_epilogues_match_the_exact_f32_kernel(cfg):
+    M, N, K = 333, 224, 256
+    a, w, b = _operands(M, N, K, seed=cfg)
+    tol = dict(rtol=1e-5, atol=5e-6)
+    torch.testing.assert_close(_sb(a, w, b, ops.LIN_BIAS, tile=cfg), ops.linear_f32(a, w, b, ops.LIN_BIAS), **tol)
+    torch.testing.assert_close(_sb(a, w, b, ops.LIN_BIAS_RELU, tile=cfg), ops.linear_f32(a, w, b, ops.LIN_BIAS_RELU), **tol)
+    torch.testing.assert_close(_sb(a, w, b, ops.LIN_BIAS_GELU, tile=cfg), ops.linear_f32(a, w, b, ops.LIN_BIAS_GELU), **tol)
+    h, d = _sb(a, w, b, ops.LIN_BIAS_GELU_D, tile=cfg)
+    h0, d0 = ops.linear_f32(a, w, b, ops.LIN_BIAS_GELU_D)
+    torch.testing.assert_close(h, h0, **tol)
+    torch.testing.assert_close(d, d0, **tol)
+    fac = torch.randn(M, N, device='cuda')
+    torch.testing.assert_close(_sb(a, w, None, ops.LIN_MUL, aux=fac, tile=cfg), ops.linear_f32(a, w, None, ops.LIN_MUL, aux=fac), **tol)
+
+
+def test_shapes_the_kernel_does_not_take_fall_back_to_the_exact_f32_kernel():
+    assert ops.linear_sb_tile(2400, 384, 100) == 0          # K % 32
+    assert ops.linear_sb_tile(2400, 384, 64) == 0           # fewer k-stages than LDS stages
+    assert ops.linear_sb_tile(65536, 1024, 1536) == 0       # more than one round of 256 workgroups
+    a, w, _ = _operands(64, 48, 100)
+    assert torch.equal(ops.linear_f32(a, w, frozen=True), ops.linear_f32(a, w))
+    lib = _abi.load()
+    out = torch.empty(64, 48, device='cuda')
+    pl = torch.empty(int(lib.upp_linear_sb_planes_bytes(48, 100)), dtype=torch.uint8, device='cuda')
+    assert lib.upp_linear_sb_f32(_abi.ptr(a), 100, _abi.ptr(pl), None, _abi.ptr(out), 48, None, 0, 64, 48, 100, 0, 0, None) != 0
+
+
+def test_plane_cache_follows_the_weight_and_its_cached_transpose():
+    lin = torch.nn.Linear(384, 1152, bias=False).cuda().requires_grad_(False)
+    x = torch.randn(2400, 384, device='cuda', requires_grad=True)
+    y = HF.linear(x, lin.weight)
+    y.sum().backward()
+    g0 = x.grad.clone()
+    torch.testing.assert_close(y, x.detach() @ lin.weight.t(), rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(g0, torch.ones_like(y) @ lin.weight, rtol=2e-6, atol=2e-5)
+    with torch.no_grad():
+        lin.weight.mul_(-2.0)                              # a new version of the frozen weight (load_state_dict does the same)
+    x.grad = None
+    y2 = HF.linear(x, lin.weight)
+    y2.sum().backward()
+    torch.testing.assert_close(y2, -2.0 * y, rtol=1e-5, atol=5e-6)
+    torch.testing.assert_close(x.grad, -2.0 * g0, rtol=1e-5, atol=5e-5)
+
+
+def test_a_trainable_weight_stays_on_the_exact_f32_kernel():
+    w = torch.randn(384, 384, device='cuda', requires_grad=True)
+    x = torch.randn(2400, 384, device='cuda')
+    with ops.time_linear_calls() as scope:
+        HF.linear(x, w)
+        HF.linear(x, w.detach())
+    torch.cuda.synchronize()
+    assert [c[6] for c in scope.calls] == [0, ops.linear_sb_tile(2400, 384, 384)]
