@@ -412,6 +412,7 @@ class Encoder(nn.Module):
         buf = getattr(self, '_w1p', None)
         if buf is None or buf.device != w.device or buf.dtype != w.dtype:
             self._w1p, self._w1p_key = F.pad(w.detach().squeeze(-1), (0, 29)).contiguous(), key
+            self._w1p._upp_persistent = True       # (ops.PLANES may cache the bf16 plane image of this buffer)
         elif self._w1p_key != key and not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
             self.refresh_padded_weight()
         return self._w1p

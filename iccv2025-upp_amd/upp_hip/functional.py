@@ -376,11 +376,12 @@ class _TransposedWeights:
         geom = (tuple(w.shape), tuple(w.stride()), w.storage_offset())
         key = (w.data_ptr(),) + geom
         e = self.entries.get(key)
-        if e is None or e[0]() is None:
+        if e is None or e[0]() is not owner:         # (another tensor on the same address is another weight)
             if len(self.entries) > 1024:
                 self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
             K = w.shape[1]
             full = torch.zeros(((K + 3) // 4 * 4, w.shape[0]), dtype=w.dtype, device=w.device)   # rows padded to a multiple of 4: get_padded()
+            full._upp_persistent = True            # (ops.PLANES may keep the bf16 plane image of this copy: it lives as long as the entry)
             wt = full[:K]
             wt.copy_(w.detach().t())
             self.entries[key] = [weakref.ref(owner), owner._version, wt, geom, full]

@@ -262,29 +262,41 @@ SPLIT_BF16 = os.environ.get("UPP_SPLIT_BF16", "1") != "0"      # frozen weights 
 
 
 class _WeightPlanes:
-    """bf16 plane images (upp_linear_sb_prep) of FROZEN weights and of their cached transposes: one image per weight, made on first use
-    (the eager warm-up of a captured step) and refreshed IN PLACE when the version counter of the weight's storage moved (load_state_dict,
-    the in-place refresh of a cached W^T) -- in place, so that HIP graphs that captured the image's address stay valid.  `refresh()`
-    re-splits every live entry (functional.refresh_caches: weights loaded into a model whose step is already captured)."""
+    """bf16 plane images (upp_linear_sb_prep) of FROZEN weights and of their cached transposes.  Cached -- one image per weight, made on
+    first use (the eager warm-up of a captured step) and refreshed IN PLACE when the version counter of the weight's storage moved
+    (load_state_dict, the in-place refresh of a cached W^T), so that HIP graphs that captured the image's address stay valid -- only for
+    weights whose storage owner is PERSISTENT: an nn.Parameter, or a buffer marked `_upp_persistent` by its keeper (functional.TRANSPOSED's
+    W^T copies, the patch embedding's zero-padded first-layer weight).  An entry is valid for the owner OBJECT it was made for: another
+    tensor that lands on the same address gets a new image.  Any other weight (a `.contiguous()` copy of a misaligned column window, a
+    padded temporary) is split afresh at every use into a buffer of its own: replacing a cached image would free memory that an already
+    captured graph still reads.  `refresh()` re-splits every live entry (functional.refresh_caches: weights loaded into a model whose
+    step is already captured)."""
 
     def __init__(self):
         self.entries = {}
 
+    @staticmethod
+    def _split(w, planes=None):
+        N, K = w.shape
+        if planes is None:
+            planes = torch.empty(int(_abi.load().upp_linear_sb_planes_bytes(N, K)), dtype=torch.uint8, device=w.device)
+        _call(w.device, "upp_linear_sb_prep", _abi.ptr(w), w.stride(0), N, K, _abi.ptr(planes))
+        return planes
+
     def get(self, w):
         owner = w._base if w._base is not None else w
+        if not (isinstance(owner, torch.nn.Parameter) or getattr(owner, "_upp_persistent", False)):
+            return self._split(w)
         key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()))
         e = self.entries.get(key)
-        if e is None or e[0]() is None:
+        if e is None or e[0]() is not owner:
             if len(self.entries) > 1024:
                 self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
-            N, K = w.shape
-            nbytes = int(_abi.load().upp_linear_sb_planes_bytes(N, K))
-            planes = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-            _call(w.device, "upp_linear_sb_prep", _abi.ptr(w), w.stride(0), N, K, _abi.ptr(planes))
+            planes = self._split(w)
             self.entries[key] = [weakref.ref(owner), owner._version, planes, (tuple(w.shape), tuple(w.stride()), w.storage_offset())]
             return planes
         if e[1] != owner._version and not torch.cuda.is_current_stream_capturing():
-            _call(w.device, "upp_linear_sb_prep", _abi.ptr(w), w.stride(0), w.shape[0], w.shape[1], _abi.ptr(e[2]))
+            self._split(w, e[2])
             e[1] = owner._version
         return e[2]
 
@@ -292,8 +304,7 @@ class _WeightPlanes:
         for e in self.entries.values():
             owner = e[0]()
             if owner is not None:
-                w = torch.as_strided(owner.detach(), e[3][0], e[3][1], e[3][2])
-                _call(w.device, "upp_linear_sb_prep", _abi.ptr(w), w.stride(0), w.shape[0], w.shape[1], _abi.ptr(e[2]))
+                self._split(torch.as_strided(owner.detach(), e[3][0], e[3][1], e[3][2]), e[2])
                 e[1] = owner._version
 
 

@@ -25,6 +25,7 @@ def _operands(M, N, K, seed=0, spread=0):
         a = a * torch.exp2(torch.randint(-spread, spread + 1, (M, K), device='cuda', generator=g).float())
         w = w * torch.exp2(torch.randint(-spread, spread + 1, (N, K), device='cuda', generator=g).float())
     b = torch.randn(N, device='cuda', generator=g)
+    w._upp_persistent = True             # (a plain tensor standing for a frozen weight: ops.PLANES may keep its plane image)
     return a, w, b
 
 
@@ -70,7 +71,7 @@ def test_every_compiled_tile_small_integers_exactly(cfg, shape):
     g = torch.Generator(device='cuda').manual_seed(cfg)
     a = torch.randint(-16, 17, (M, K), device='cuda', generator=g).float()
     w = torch.randint(-16, 17, (N, K), device='cuda', generator=g).float()
-    got = _sb(a, w, tile=cfg)
+    got = _sb(a, w, tile=cfg)             # (w is a temporary to ops.PLANES: split at this use, not cached)
     assert torch.equal(got.double(), a.double() @ w.double().t())
 
 
@@ -150,3 +151,19 @@ def test_a_trainable_weight_stays_on_the_exact_f32_kernel():
         HF.linear(x, w.detach())
     torch.cuda.synchronize()
     assert [c[6] for c in scope.calls] == [0, ops.linear_sb_tile(2400, 384, 384)]
+
+
+def test_plane_images_are_cached_per_owner_object_and_never_for_temporaries():
+    lin = torch.nn.Linear(384, 384, bias=False).cuda().requires_grad_(False)
+    p1 = ops.PLANES.get(lin.weight)
+    assert ops.PLANES.get(lin.weight) is p1                                   # a parameter: one image, kept
+    tmp = lin.weight.detach().clone()
+    q1, q2 = ops.PLANES.get(tmp), ops.PLANES.get(tmp)
+    assert q1 is not q2 and torch.equal(q1, q2) and torch.equal(q1, p1)        # a temporary: split at every use, into its own buffer
+    key = (lin.weight.data_ptr(), tuple(lin.weight.shape), tuple(lin.weight.stride()))
+    other = torch.nn.Parameter(torch.randn(384, 384, device='cuda'), requires_grad=False)
+    ops.PLANES.entries[(other.data_ptr(), tuple(other.shape), tuple(other.stride()))] = ops.PLANES.entries[key]   # "another tensor landed on this address"
+    p_other = ops.PLANES.get(other)
+    assert p_other is not p1                                                   # the entry was made for another owner object: not served
+    terms = _planes_to_terms(p_other, 384, 384).double().sum(0)
+    assert torch.equal(terms, other.detach().double())

@@ -36,6 +36,7 @@ def main():
         for name, N, K in LAYERS:
             a = torch.randn(M, K, device=dev, generator=g)
             w = torch.randn(N, K, device=dev, generator=g) * K ** -0.5
+            w._upp_persistent = True            # (a plain tensor as a frozen weight: let ops.PLANES keep its plane image)
             b = torch.randn(N, device=dev, generator=g)
             ref = a.double() @ w.double().t()
             bound = a.abs().double() @ w.abs().double().t()
