@@ -95,7 +95,10 @@ SIGNATURES = {
                        + [_c_i] * 5 + [_c_f]),
     "upp_linear_sb_tile": (_c_i, [_c_i, _c_i, _c_i]),
     "upp_linear_sb_planes_bytes": (ctypes.c_longlong, [_c_i, _c_i]),
-    "upp_linear_sb_prep": (_c_i, [_c_f, ctypes.c_longlong, _c_i, _c_i, _c_f, _c_f]),
+    "upp_linear_sb_prep": (_c_i, [_c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f, _c_f]),
+    "upp_linear_sb_prep_batched": (_c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong)] + [ctypes.POINTER(ctypes.c_int)] * 3
+                                   + [ctypes.POINTER(ctypes.c_void_p), _c_i, _c_f]),
+    "upp_linear_sb_group_bias_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
     "upp_linear_sb_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong] + [_c_i] * 5 + [_c_f]),
     "upp_linear_group_bias_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
     "upp_linear_parts": (_c_i, [_c_i, _c_i, _c_i]),

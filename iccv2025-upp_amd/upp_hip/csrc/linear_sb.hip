@@ -296,11 +296,13 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
         const int col = cb + 4 * (lane & 7);
         const bool col_ok = col < N;
         f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (g.epi != LEPI_NONE && g.epi != LEPI_MUL && col_ok) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
+        if (g.epi != LEPI_NONE && g.epi != LEPI_MUL && col_ok && g.bias_shift == 0) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
 #pragma unroll
         for (int pass = 0; pass < TN / 4; ++pass) {
             const int ridx = pass * 8 + (lane >> 3), t = T0 + (ridx >> 1);
             const int row = rb + (t & 3) + 8 * (t >> 2) + 4 * (ridx & 1);
+            if (g.bias_shift > 0 && col_ok)                      // a bias per group of 2^bias_shift rows (upp_linear_sb_group_bias_f32)
+                bias4 = *reinterpret_cast<const f32x4 *>(g.bias + (long long)(min(row, M - 1) >> g.bias_shift) * N + col);
             const float *sp = red + ((wb * RN + jj) * 16 + T0) * 64 + (pass * 64 + lane) * 4;
             f32x4 v = *reinterpret_cast<const f32x4 *>(sp);
             if (KS > 1) {
@@ -316,13 +318,18 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
 }
 
 // W (N,K) f32 -> the plane image [block][k-stage][plane][granule][row][8 bf16], zero beyond N and K.  One thread per (row, granule).
-__global__ __launch_bounds__(128) void linear_sb_prep_kernel(const float *__restrict__ W, long long ldw, int N, int K, int kstages, unsigned char *__restrict__ out) {
-    const int chunk = blockIdx.x, nb = chunk / kstages, kst = chunk - nb * kstages;
+// `transposed`: the operand is W^T of a row-major (K,N) matrix `W` (the B operand of a data-gradient GEMM, dX = dY . W): element (n,k) is
+// read from W[k ldw + n] -- the 32 rows of a block are 32 consecutive floats of a source row -- so no f32 copy of W^T is ever made.
+constexpr int kMaxPrep = 48;
+struct PrepJobs { const float *W[kMaxPrep]; long long ldw[kMaxPrep]; unsigned char *out[kMaxPrep]; int N[kMaxPrep], K[kMaxPrep], tr[kMaxPrep], first[kMaxPrep + 1]; int count; };
+
+__device__ __forceinline__ void prep_chunk(const float *__restrict__ W, long long ldw, int N, int K, int transposed, int kstages, int chunk, unsigned char *__restrict__ out) {
+    const int nb = chunk / kstages, kst = chunk - nb * kstages;
     const int row = threadIdx.x & 31, gq = threadIdx.x >> 5;
     const int n = nb * 32 + row, k0 = kst * 32 + gq * 8;
     float x[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = (n < N && k0 + e < K) ? W[(long long)n * ldw + k0 + e] : 0.0f;
+    for (int e = 0; e < 8; ++e) x[e] = (n < N && k0 + e < K) ? (transposed ? W[(long long)(k0 + e) * ldw + n] : W[(long long)n * ldw + k0 + e]) : 0.0f;
     const f32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
     u32x4 p1, p2, p3;
     split8(lo, hi, p1, p2, p3);
@@ -330,6 +337,18 @@ __global__ __launch_bounds__(128) void linear_sb_prep_kernel(const float *__rest
     *reinterpret_cast<u32x4 *>(base) = p1;
     *reinterpret_cast<u32x4 *>(base + 2048) = p2;
     *reinterpret_cast<u32x4 *>(base + 4096) = p3;
+}
+
+__global__ __launch_bounds__(128) void linear_sb_prep_kernel(const float *__restrict__ W, long long ldw, int N, int K, int transposed, int kstages, unsigned char *__restrict__ out) {
+    prep_chunk(W, ldw, N, K, transposed, kstages, (int)blockIdx.x, out);
+}
+
+// several weights in one launch (the trainable weights of a step driver, re-split at the start of every step): workgroup -> (job, chunk)
+__global__ __launch_bounds__(128) void linear_sb_prep_batched_kernel(PrepJobs t) {
+    const int b = blockIdx.x;
+    int j = 0;
+    while (j + 1 < t.count && b >= t.first[j + 1]) ++j;                // (scalar: at most kMaxPrep compares)
+    prep_chunk(t.W[j], t.ldw[j], t.N[j], t.K[j], t.tr[j], (t.K[j] + 31) / 32, b - t.first[j], t.out[j]);
 }
 
 struct SbConfig { int bmb, bnb, rn, ks, nst; };
@@ -343,7 +362,7 @@ constexpr SbConfig kSbConfigs[] = {UPP_SB_CONFIGS(UPP_SB_ENTRY)};
 constexpr int kNumSbConfigs = sizeof(kSbConfigs) / sizeof(kSbConfigs[0]);
 inline int sb_code(const SbConfig &c) { return 0x400000 + c.bmb * 65536 + c.bnb * 4096 + c.rn * 256 + c.ks * 16 + c.nst; }     // hex digits 4 BMB BNB RN KS NST
 
-// One round of at most 256 workgroups; among the shapes that fit, the smallest of max(matrix-pipe cycles of the busiest SIMD + 0.7 x the
+// One round of at most 256 workgroups (the big tiles also in several rounds: the tall point-row matrices); among the shapes that fit, the smallest of max(matrix-pipe cycles of the busiest SIMD + 0.7 x the
 // VALU cycles of its A splits, bytes a workgroup stages / 40 B per clock) -- fitted to the in-kernel stamps of tools/micro/sb_stamps.py
 // (fc1 128 x 128: 23.7k cycles for 18.4k + 0.7 x 9.6k; fc2 64 x 64 with one block per wave: 34k for 18.4k + 0.7 x 19.2k, which is why
 // the narrow shapes take the tile whose waves own both column blocks).  0: not a problem for this file.
@@ -356,13 +375,14 @@ int pick_sb(int M, int N, int K) {
         const SbConfig c = kSbConfigs[i];
         if (K % (32 * c.ks) != 0 || K / (32 * c.ks) < c.nst) continue;          // (every LDS stage is filled before the loop starts)
         const long long wgs = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
-        if (wgs > 256) continue;
+        const long long rounds = (wgs + 255) / 256;
+        if (rounds > 1 && c.bmb * c.bnb < 12) continue;          // (several rounds: the big tiles only -- one workgroup per CU, prologue and store burst per round)
         const int waves = c.bmb * (c.bnb / c.rn) * c.ks;
         const long long mfma = (long long)((waves + 3) / 4) * c.rn * (K / c.ks / 16) * 192;
         const long long bytes = (long long)(c.bmb * 32 * 128 + c.bnb * SB_CHUNK) * (K / 32);
         const long long valu = (long long)((waves + 3) / 4) * (K / c.ks / 16) * 200;          // ~44 instructions per split of 8 values
         const long long pipe = mfma + valu * 7 / 10;
-        long long cost = (pipe > bytes / 40 ? pipe : bytes / 40) * 1000 + (256 - wgs);
+        long long cost = rounds * ((pipe > bytes / 40 ? pipe : bytes / 40) + (rounds > 1 ? 8000 : 0)) * 1000 + (256 - (wgs < 256 ? wgs : 256));
         if (wgs < 128) cost += cost / 2;                       // half the chip idle: the stream beside it gains, this launch does not
         if (!best || cost < best_cost) { best = sb_code(c); best_cost = cost; }
     }
@@ -394,17 +414,38 @@ extern "C" long long upp_linear_sb_planes_bytes(int N, int K) {
     return (long long)((N + 31) / 32) * ((K + 31) / 32) * SB_CHUNK;
 }
 
-extern "C" int upp_linear_sb_prep(const float *W, long long ldw, int N, int K, void *planes, void *stream) {
+extern "C" int upp_linear_sb_prep(const float *W, long long ldw, int N, int K, int transposed, void *planes, void *stream) {
     if (!W || !planes || N < 1 || K < 1) return UPP_E_BADARG;
-    if (ldw < K || (reinterpret_cast<uintptr_t>(planes) & 15)) return UPP_E_RANGE;
+    if (ldw < (transposed ? N : K) || (reinterpret_cast<uintptr_t>(planes) & 15)) return UPP_E_RANGE;
     const int kstages = (K + 31) / 32, nblocks = (N + 31) / 32;
-    hipLaunchKernelGGL(linear_sb_prep_kernel, dim3((unsigned)(nblocks * kstages)), dim3(128), 0, (hipStream_t)stream, W, ldw, N, K, kstages,
+    hipLaunchKernelGGL(linear_sb_prep_kernel, dim3((unsigned)(nblocks * kstages)), dim3(128), 0, (hipStream_t)stream, W, ldw, N, K, transposed ? 1 : 0, kstages,
                        reinterpret_cast<unsigned char *>(planes));
     return upp_launch_status();
 }
 
-extern "C" int upp_linear_sb_f32(const float *A, long long lda, const void *planes, const float *bias, float *C, long long ldc, float *aux,
-                                 long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream) {
+extern "C" int upp_linear_sb_prep_batched(const float *const *W, const long long *ldw, const int *N, const int *K, const int *transposed,
+                                          void *const *planes, int count, void *stream) {
+    if (count < 0 || (count > 0 && (!W || !ldw || !N || !K || !transposed || !planes))) return UPP_E_BADARG;
+    for (int j0 = 0; j0 < count; j0 += kMaxPrep) {
+        PrepJobs t;
+        const int n = count - j0 < kMaxPrep ? count - j0 : kMaxPrep;
+        int total = 0;
+        for (int j = 0; j < n; ++j) {
+            const int i = j0 + j;
+            if (!W[i] || !planes[i] || N[i] < 1 || K[i] < 1) return UPP_E_BADARG;
+            if (ldw[i] < (transposed[i] ? N[i] : K[i]) || (reinterpret_cast<uintptr_t>(planes[i]) & 15)) return UPP_E_RANGE;
+            t.W[j] = W[i]; t.ldw[j] = ldw[i]; t.out[j] = reinterpret_cast<unsigned char *>(planes[i]); t.N[j] = N[i]; t.K[j] = K[i]; t.tr[j] = transposed[i] ? 1 : 0;
+            t.first[j] = total;
+            total += ((N[i] + 31) / 32) * ((K[i] + 31) / 32);
+        }
+        t.first[n] = total; t.count = n;
+        hipLaunchKernelGGL(linear_sb_prep_batched_kernel, dim3((unsigned)total), dim3(128), 0, (hipStream_t)stream, t);
+    }
+    return upp_launch_status();
+}
+
+static int linear_sb_launch(const float *A, long long lda, const void *planes, const float *bias, int bias_shift, float *C, long long ldc, float *aux,
+                            long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream) {
     if (!A || !planes || !C || M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
     if (K % 32 != 0 || lda % 4 != 0 || lda < K || ldc < N || N % 4 != 0 || ldc % 4 != 0) return UPP_E_RANGE;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(C)) & 15) return UPP_E_RANGE;
@@ -416,7 +457,7 @@ extern "C" int upp_linear_sb_f32(const float *A, long long lda, const void *plan
     if (tile <= 0) return UPP_E_RANGE;
     SbArgs g{};
     g.l.A = A; g.l.lda = lda; g.l.C = C; g.l.ldc = ldc; g.l.bias = bias; g.l.aux = aux; g.l.ldaux = ldaux;
-    g.l.M = M; g.l.N = N; g.l.K = K; g.l.epi = epilogue;
+    g.l.M = M; g.l.N = N; g.l.K = K; g.l.epi = epilogue; g.l.bias_shift = bias_shift;
 #ifdef UPP_LIN_STAMPS
     g.l.stamps = g_lin_stamps;
 #endif
@@ -432,4 +473,17 @@ extern "C" int upp_linear_sb_f32(const float *A, long long lda, const void *plan
         default: return UPP_E_RANGE;
     }
 #undef UPP_SB_CASE
+}
+
+extern "C" int upp_linear_sb_f32(const float *A, long long lda, const void *planes, const float *bias, float *C, long long ldc, float *aux,
+                                 long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream) {
+    return linear_sb_launch(A, lda, planes, bias, 0, C, ldc, aux, ldaux, M, N, K, epilogue, tile, stream);
+}
+
+// C (M,N) = A . W^T + bias[m >> group_shift][:] -- a bias per GROUP of 2^group_shift >= 5 consecutive rows, as upp_linear_group_bias_f32.
+extern "C" int upp_linear_sb_group_bias_f32(const float *A, long long lda, const void *planes, const float *bias, int group_shift, float *C,
+                                            long long ldc, int M, int N, int K, void *stream) {
+    if (!bias) return UPP_E_BADARG;
+    if (group_shift < 5 || group_shift > 30) return UPP_E_RANGE;
+    return linear_sb_launch(A, lda, planes, bias, group_shift, C, ldc, nullptr, 0, M, N, K, LEPI_BIAS, 0, stream);
 }

@@ -466,6 +466,22 @@ def linear_usable(x, weight):
             and x.shape[-1] == weight.shape[1] and weight.shape[1] % 4 == 0 and x.numel() > 0)
 
 
+def _lin(a, w, bias=None, epi=None, aux=None, dgrad=False):
+    """a . op(w)^T with op(w) = w (N,K) -- or, dgrad, w^T: the data gradient dX = dY . W -- on the kernel that serves the weight:
+    frozen -> upp_linear_sb_f32 on the cached plane image of w / of its cached transpose (exact-f32 kernel where the split kernel does not
+    take the shape); trainable inside a step driver (ops.PLANES.managed) -> upp_linear_sb_f32 on the persistent image that the driver
+    re-splits once per step, the transpose read straight from w; trainable elsewhere -> the exact-f32 kernel (a fresh W^T for dgrad)."""
+    epi = ops.LIN_NONE if epi is None else epi
+    if not w.requires_grad:
+        return ops.linear_f32(a, _wt(w) if dgrad else w, bias, epi, aux=aux, frozen=True)
+    N, K = (w.shape[1], w.shape[0]) if dgrad else w.shape
+    M = a.numel() // a.shape[-1]
+    if (ops.PLANES.managed and w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.data_ptr() % 16 == 0 and w.stride(0) % 4 == 0
+            and ops.linear_sb_usable(M, N, K) and (bias is None or bias.data_ptr() % 16 == 0)):
+        return ops.linear_f32(a, None, bias, epi, aux=aux, planes=ops.PLANES.get_trainable(w, transposed=dgrad), wshape=(N, K))
+    return ops.linear_f32(a, _wt(w) if dgrad else w, bias, epi, aux=aux)
+
+
 class _LinearMFMA(Function):
     """x . W^T (+ b) on upp_linear_f32, forward and data gradient.  The weight gradient of a TRAINABLE layer is a library GEMM
     (not on the PEFT hot path: the Transformer weights are frozen there); a trainable bias takes the deferred column sum."""
@@ -481,7 +497,7 @@ class _LinearMFMA(Function):
         ctx.x_parts, ctx.out_parts = int(x_parts), bool(out_parts)
         if out_parts:
             return ops.linear_parts(xin, w)
-        return ops.linear_f32(xin, w, b, ops.LIN_BIAS if b is not None else ops.LIN_NONE, frozen=not w.requires_grad)
+        return _lin(xin, w, b, ops.LIN_BIAS if b is not None else ops.LIN_NONE)
 
     @staticmethod
     def backward(ctx, g):
@@ -493,14 +509,13 @@ class _LinearMFMA(Function):
             g2 = g2.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wt = _wt(w)
             if ctx.x_parts:
-                gx = ops.linear_parts(g2, wt, ctx.x_parts).view((ctx.x_parts,) + g.shape[:-1] + (w.shape[1],))
-            elif wt.shape[1] % 4 == 0 and g2.stride(0) % 4 == 0:
-                gx = ops.linear_f32(g2, wt, frozen=not w.requires_grad).view(g.shape[:-1] + (w.shape[1],))
-            elif wt.shape[1] <= 64 and wt.shape[0] <= 256:
+                gx = ops.linear_parts(g2, _wt(w), ctx.x_parts).view((ctx.x_parts,) + g.shape[:-1] + (w.shape[1],))
+            elif w.shape[0] % 4 == 0 and g2.stride(0) % 4 == 0:
+                gx = _lin(g2, w, dgrad=True).view(g.shape[:-1] + (w.shape[1],))
+            elif w.shape[0] <= 64 and w.shape[1] <= 256:
                 # a narrow layer (the 64 -> 3 score head of the denoising prompter): the data gradient contracts over its few outputs
-                gx = ops.linear_smallk(g2, wt, None, 0).view(g.shape[:-1] + (w.shape[1],))
+                gx = ops.linear_smallk(g2, _wt(w), None, 0).view(g.shape[:-1] + (w.shape[1],))
             else:
                 note_declined("linear data gradient", "N = %d is not a multiple of 4" % wt.shape[1])
                 gx = torch.mm(g2, w).view(g.shape[:-1] + (w.shape[1],))
@@ -608,7 +623,9 @@ class _LinearGroupBias(Function):
     def forward(ctx, x, w, gb, rows):
         ctx.save_for_backward(x if w.requires_grad else None, w)
         ctx.rows = rows
-        return ops.linear_group_bias(x, w, gb, rows)
+        if w.requires_grad and ops.PLANES.managed and ops.linear_sb_usable(x.shape[0], w.shape[0], w.shape[1]) and w.data_ptr() % 16 == 0 and w.stride(0) % 4 == 0:
+            return ops.linear_group_bias(x, w, gb, rows, planes=ops.PLANES.get_trainable(w))
+        return ops.linear_group_bias(x, w, gb, rows, frozen=not w.requires_grad)
 
     @staticmethod
     def backward(ctx, g):
@@ -616,7 +633,7 @@ class _LinearGroupBias(Function):
         g2 = g if g.is_contiguous() else g.contiguous()
         gx = gw = ggb = None
         if ctx.needs_input_grad[0]:
-            gx = ops.linear_f32(g2, _wt(w), frozen=not w.requires_grad)
+            gx = _lin(g2, w, dgrad=True)
         if ctx.needs_input_grad[1]:
             gw = weight_grad(g2, x, w, True)
         if ctx.needs_input_grad[2]:
@@ -637,7 +654,7 @@ def linear_group_bias(x, weight, group_bias, rows_per_group):
             and (not (torch.is_grad_enabled() and x.requires_grad) or K % 4 == 0)):
         gb = group_bias.contiguous()
         if not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad or gb.requires_grad):
-            return ops.linear_group_bias(x, weight, gb, r)
+            return ops.linear_group_bias(x, weight, gb, r, frozen=not weight.requires_grad)
         return _LinearGroupBias.apply(x, weight, gb, r)
     return (linear(x, weight, own_wgrad=True).view(M // r, r, N) + group_bias.unsqueeze(1)).view(M, N)
 
@@ -723,14 +740,14 @@ class _MlpGelu(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2=None, x_parts=0, out_parts=False):
         xin = x[0] if x_parts else x            # (k-parts protocol: see _LinearMFMA)
-        hid, d = ops.linear_f32(xin, w1, b1, ops.LIN_BIAS_GELU_D, frozen=not w1.requires_grad)
+        hid, d = _lin(xin, w1, b1, ops.LIN_BIAS_GELU_D)
         train = w1.requires_grad or w2.requires_grad or b1.requires_grad
         ctx.save_for_backward(d, w1, w2, xin if train else None, hid if w2.requires_grad else None)
         ctx.bias_ptrs = (b1.data_ptr(), b2.data_ptr() if b2 is not None else 0)
         ctx.x_parts, ctx.out_parts = int(x_parts), bool(out_parts)
         if out_parts:
             return ops.linear_parts(hid, w2)
-        return ops.linear_f32(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE, frozen=not w2.requires_grad)
+        return _lin(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE)
 
     @staticmethod
     def backward(ctx, g):
@@ -741,13 +758,13 @@ class _MlpGelu(Function):
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        g_z = ops.linear_f32(g2, _wt(w2), None, ops.LIN_MUL, aux=d.view(-1, d.shape[-1]), frozen=not w2.requires_grad)
+        g_z = _lin(g2, w2, None, ops.LIN_MUL, aux=d.view(-1, d.shape[-1]), dgrad=True)
         gx = None
         if need[0]:
             if ctx.x_parts:
                 gx = ops.linear_parts(g_z, _wt(w1), ctx.x_parts).view((ctx.x_parts,) + g.shape[:-1] + (w1.shape[1],))
             else:
-                gx = ops.linear_f32(g_z, _wt(w1), frozen=not w1.requires_grad).view(g.shape[:-1] + (w1.shape[1],))
+                gx = _lin(g_z, w1, dgrad=True).view(g.shape[:-1] + (w1.shape[1],))
         gw1 = gb1 = gw2 = gb2 = None
         if need[1]:
             gw1 = weight_grad(g_z, x.reshape(-1, x.shape[-1]), w1)

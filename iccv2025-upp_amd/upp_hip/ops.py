@@ -239,8 +239,9 @@ LIN_NONE, LIN_BIAS, LIN_BIAS_GELU, LIN_BIAS_GELU_D, LIN_MUL, LIN_BIAS_RELU = 0, 
 
 
 class time_linear_calls:
-    """Measurement scope (bench.py): every upp_linear_f32 launch inside it is bracketed by a pair of HIP events recorded on
-    the launch stream; `.report()` -> [(M, N, K, epilogue, ms)] after a synchronize.  Eager launches only (not under capture)."""
+    """Measurement scope (bench.py): every upp_linear_f32 / upp_linear_sb_f32 launch inside it is bracketed by a pair of HIP events recorded
+    on the launch stream; `.report()` -> [(M, N, K, epilogue, ms, sb)] after a synchronize (sb: the split-bf16 kernel's tile code, 0 = the
+    exact-f32 kernel).  Eager launches only (not under capture)."""
     active = None
 
     def __enter__(self):
@@ -255,7 +256,7 @@ class time_linear_calls:
 
     def report(self):
         torch.cuda.synchronize()
-        return [(M, N, K, e, a.elapsed_time(b)) for (M, N, K, e, a, b, *_) in self.calls]
+        return [(M, N, K, e, a.elapsed_time(b), sb) for (M, N, K, e, a, b, sb) in self.calls]
 
 
 SPLIT_BF16 = os.environ.get("UPP_SPLIT_BF16", "1") != "0"      # frozen weights on the bf16 matrix pipe at f32 accuracy (csrc/linear_sb.hip)
@@ -274,14 +275,54 @@ class _WeightPlanes:
 
     def __init__(self):
         self.entries = {}
+        self.trainable = {}
 
     @staticmethod
-    def _split(w, planes=None):
-        N, K = w.shape
+    def _split(w, planes=None, transposed=False):
+        """planes of the (N,K) operand `w`, or -- transposed -- of w^T for a row-major w (K,N) (upp_linear_sb_prep reads it transposed)."""
+        N, K = (w.shape[1], w.shape[0]) if transposed else w.shape
         if planes is None:
             planes = torch.empty(int(_abi.load().upp_linear_sb_planes_bytes(N, K)), dtype=torch.uint8, device=w.device)
-        _call(w.device, "upp_linear_sb_prep", _abi.ptr(w), w.stride(0), N, K, _abi.ptr(planes))
+        _call(w.device, "upp_linear_sb_prep", _abi.ptr(w), w.stride(0), N, K, 1 if transposed else 0, _abi.ptr(planes))
         return planes
+
+    # -- trainable weights inside a step driver (train.TrainStep sets `managed`): the plane images of W (forward) and of W^T (data gradient,
+    #    split straight from W) are persistent and ALL re-split by one launch at the start of every step (`refresh_trainable`), i.e. after
+    #    whatever changed the weights since the last step (the flat AdamW kernel writes them without touching torch's version counters).
+    #    Outside a step driver a trainable weight stays on the exact-f32 kernel (it may have changed by any means).
+    managed = False
+
+    def get_trainable(self, w, transposed=False):
+        owner = w._base if w._base is not None else w
+        if not isinstance(owner, torch.nn.Parameter):           # a computed weight (padded, concatenated ...): split where it is used
+            return self._split(w.detach(), None, transposed)
+        key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), bool(transposed))
+        e = self.trainable.get(key)
+        if e is None or e[0]() is not owner:
+            planes = self._split(w.detach(), None, transposed)
+            self.trainable[key] = [weakref.ref(owner), planes, bool(transposed), (tuple(w.shape), tuple(w.stride()), w.storage_offset())]
+            return planes
+        return e[1]
+
+    def refresh_trainable(self):
+        import ctypes
+        jobs = []
+        for key, e in list(self.trainable.items()):
+            owner = e[0]()
+            if owner is None:
+                del self.trainable[key]
+            else:
+                jobs.append((torch.as_strided(owner.detach(), e[3][0], e[3][1], e[3][2]), e[1], e[2]))
+        if not jobs:
+            return
+        k = len(jobs)
+        W = (ctypes.c_void_p * k)(*[w.data_ptr() for w, _, _ in jobs])
+        ld = (ctypes.c_longlong * k)(*[w.stride(0) for w, _, _ in jobs])
+        N = (ctypes.c_int * k)(*[(w.shape[1] if tr else w.shape[0]) for w, _, tr in jobs])
+        K = (ctypes.c_int * k)(*[(w.shape[0] if tr else w.shape[1]) for w, _, tr in jobs])
+        T = (ctypes.c_int * k)(*[1 if tr else 0 for _, _, tr in jobs])
+        P = (ctypes.c_void_p * k)(*[p.data_ptr() for _, p, _ in jobs])
+        _call(jobs[0][0].device, "upp_linear_sb_prep_batched", W, ld, N, K, T, P, k)
 
     def get(self, w):
         owner = w._base if w._base is not None else w
@@ -316,22 +357,36 @@ def linear_sb_tile(M, N, K):
     return max(0, int(_abi.load().upp_linear_sb_tile(int(M), int(N), int(K))))
 
 
-def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None, frozen=False):
+def _sb_servable(N, K, out, bias, aux):
+    return (N % 4 == 0 and K % 32 == 0 and out.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0)
+            and (aux is None or aux.data_ptr() % 16 == 0))
+
+
+def linear_sb_usable(M, N, K):
+    """Does the split-bf16 kernel take an (M,K) x (N,K)^T product (freshly allocated, 16-byte aligned operands assumed)?"""
+    return bool(SPLIT_BF16 and N % 4 == 0 and K % 32 == 0 and linear_sb_tile(M, N, K))
+
+
+def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None, frozen=False, planes=None, wshape=None):
     """C (M,N) = epilogue(a (M,K) . w (N,K)^T) on the matrix cores: upp_linear_f32 (exact f32 MFMA, bit-pinned order), or -- frozen=True: w
     is a frozen weight or a cached copy of one, its contents change only through torch (version counter) -- upp_linear_sb_f32 (three-way
     bf16 split of both operands, six bf16 MFMA products, f32 accumulate: f32 accuracy at 6/16 of the matrix-pipe time) where that kernel
-    takes the shape.
+    takes the shape.  planes / wshape: the plane image of the (N,K) operand made by the caller (ops.PLANES.get_trainable: a trainable
+    weight inside a step driver, or its transpose) -- then w may be None and the split-bf16 kernel is taken (linear_sb_usable must hold).
     a: (..., K) f32 whose rows are K-contiguous with one common row stride; w: (N,K).
     epilogue LIN_BIAS_GELU_D returns (C, GELU'); LIN_MUL multiplies by aux (M,N)."""
-    if not (isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1):
-        raise RuntimeError("w must be a 2-D f32 HIP (cuda) matrix with contiguous rows; upp_hip has no CPU path")
+    if planes is not None:
+        N, Kw = wshape
+    else:
+        if not (isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1):
+            raise RuntimeError("w must be a 2-D f32 HIP (cuda) matrix with contiguous rows; upp_hip has no CPU path")
+        _same_device(a, w)
+        N, Kw = w.shape
     if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.float32):
         raise RuntimeError("a must be a f32 HIP (cuda) tensor; upp_hip has no CPU path")
-    _same_device(a, w)
     K = a.shape[-1]
-    N = w.shape[0]
-    if w.shape[1] != K:
-        raise RuntimeError(f"linear_f32: a (...,{K}) against w {tuple(w.shape)}")
+    if Kw != K:
+        raise RuntimeError(f"linear_f32: a (...,{K}) against w ({N},{Kw})")
     a2 = a.reshape(-1, K)
     if a2.stride(1) != 1 or a2.stride(0) % 4 != 0 or a2.data_ptr() % 16 != 0:      # (a column window with a misaligned base: one copy)
         a2 = a2.contiguous()
@@ -350,15 +405,20 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None, f
     if bias is not None:
         _need(bias, "bias", torch.float32, 1, N)
     sb = 0
-    if (frozen and SPLIT_BF16 and tile == 0 and N % 4 == 0 and K % 32 == 0 and out.data_ptr() % 16 == 0
-            and (bias is None or bias.data_ptr() % 16 == 0) and (aux is None or aux.data_ptr() % 16 == 0)):
+    if planes is None and frozen and SPLIT_BF16 and tile == 0 and _sb_servable(N, K, out, bias, aux):
         sb = linear_sb_tile(M, N, K)
+        if sb:
+            planes = PLANES.get(w)
+    elif planes is not None:
+        sb = linear_sb_tile(M, N, K)
+        if not (sb and _sb_servable(N, K, out, bias, aux)):
+            raise RuntimeError("linear_f32: plane images given for a problem the split-bf16 kernel does not take (ask linear_sb_usable first)")
     scope = time_linear_calls.active
     if scope is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     if sb:
-        _call(a.device, "upp_linear_sb_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(PLANES.get(w)), _abi.ptr(bias), _abi.ptr(out), N,
+        _call(a.device, "upp_linear_sb_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(planes), _abi.ptr(bias), _abi.ptr(out), N,
               _abi.ptr(aux), N, M, N, K, int(epilogue), sb)
     else:
         _call(a.device, "upp_linear_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(bias), _abi.ptr(out), N,
@@ -531,9 +591,10 @@ def linear_group_bias_usable(M, N, K, rows_per_group):
     return tile > 0 and bool(tile & 0x10000)
 
 
-def linear_group_bias(a, w, bias, rows_per_group):
+def linear_group_bias(a, w, bias, rows_per_group, frozen=False, planes=None):
     """C (M,N) = a (M,K) . w (N,K)^T + bias[m // rows_per_group] -- the bias of a GROUP of rows added in the GEMM's epilogue
-    (upp_linear_group_bias_f32); bias (M / rows_per_group, N) contiguous."""
+    (upp_linear_group_bias_f32, or upp_linear_sb_group_bias_f32 for a frozen weight / a plane image handed over by the caller: see
+    linear_f32); bias (M / rows_per_group, N) contiguous."""
     for t, name in ((a, "a"), (w, "w"), (bias, "bias")):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
             raise RuntimeError(f"{name} must be a 2-D f32 HIP (cuda) matrix with contiguous rows; upp_hip has no CPU path")
@@ -544,10 +605,25 @@ def linear_group_bias(a, w, bias, rows_per_group):
     if w.shape[1] != K or not bias.is_contiguous() or tuple(bias.shape) != (M // r, N) or not linear_group_bias_usable(M, N, K, r):
         raise RuntimeError("linear_group_bias: shapes do not fit (see linear_group_bias_usable)")
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    _call(a.device, "upp_linear_group_bias_f32", _abi.ptr(a), a.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(bias), r.bit_length() - 1,
-          _abi.ptr(out), N, M, N, K)
-    if time_linear_calls.active is not None:
-        time_linear_calls.active.group_bias = getattr(time_linear_calls.active, "group_bias", []) + [(M, N, K)]
+    sb = 0
+    if (planes is not None or frozen) and linear_sb_usable(M, N, K) and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and bias.data_ptr() % 16 == 0:
+        sb = linear_sb_tile(M, N, K)
+        if planes is None:
+            planes = PLANES.get(w)
+    scope = time_linear_calls.active
+    if scope is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    if sb:
+        _call(a.device, "upp_linear_sb_group_bias_f32", _abi.ptr(a), a.stride(0), _abi.ptr(planes), _abi.ptr(bias), r.bit_length() - 1,
+              _abi.ptr(out), N, M, N, K)
+    else:
+        _call(a.device, "upp_linear_group_bias_f32", _abi.ptr(a), a.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(bias), r.bit_length() - 1,
+              _abi.ptr(out), N, M, N, K)
+    if scope is not None:
+        ev1.record()
+        scope.group_bias = getattr(scope, "group_bias", []) + [(M, N, K)]
+        scope.calls.append((M, N, K, LIN_BIAS, ev0, ev1, sb))
     return out
 
 

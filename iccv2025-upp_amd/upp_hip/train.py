@@ -256,10 +256,11 @@ class TrainStep:
             p.grad = None              # let autograd write fresh gradients: no per-parameter accumulate kernels
         # W^T copies of the trainable weights (data-gradient GEMMs): persistent inside this driver, all refreshed by one launch here,
         # i.e. after whatever changed the weights since the last step (optimizer, load_state_dict, a restore)
-        was = HF.TRANSPOSED.managed
-        HF.TRANSPOSED.managed = True
+        was, was_p = HF.TRANSPOSED.managed, HF.ops.PLANES.managed
+        HF.TRANSPOSED.managed = HF.ops.PLANES.managed = True
         try:
             HF.TRANSPOSED.refresh_trainable()
+            HF.ops.PLANES.refresh_trainable()          # (the bf16 plane images of the trainable weights and of their transposes: one launch)
             if self.loss_fn is not None:
                 loss, acc = self.loss_fn(self.model, *self.inputs)
             else:
@@ -269,7 +270,7 @@ class TrainStep:
             with HF.deferred_sums(self._grad_targets) as scope:
                 loss.backward()
         finally:
-            HF.TRANSPOSED.managed = was
+            HF.TRANSPOSED.managed, HF.ops.PLANES.managed = was, was_p
         got = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None and p.data_ptr() not in scope.routed]
         # into the flat buffer in launches of 64 (upp_copy_batched): torch._foreach_copy_ issues one runtime copy per tensor here -- 55 ...
         # 100 `__amd_rocclr_copyBuffer` launches per step, 0.2 ... 0.35 ms in the round-2 / early round-3 kernel summaries

@@ -525,19 +525,28 @@ int upp_linear_parts_f32(const float *A, long long lda, const float *W, long lon
  * measures both against float64), at 6/16 of the matrix-pipe time of v_mfma_f32_32x32x2_f32.  Not bit-pinned (the summation order
  * inside a bf16 MFMA is not documented): the exact-f32 kernel above stays the bit-pinned one.
  *   upp_linear_sb_planes_bytes(N, K): size of the plane image of a (N,K) weight (6 bytes per element, N and K rounded up to 32).
- *   upp_linear_sb_prep(W, ldw, N, K, planes): split W once per weight version into the kernel's LDS image
- *       [32-row block][32-wide k-stage][plane 0..2][16-byte granule of 8 k][row] (zero beyond N, K); planes 16-byte aligned.
+ *   upp_linear_sb_prep(W, ldw, N, K, transposed, planes): split the (N,K) weight operand once per weight version into the kernel's LDS image
+ *       [32-row block][32-wide k-stage][plane 0..2][16-byte granule of 8 k][row] (zero beyond N, K); planes 16-byte aligned.  transposed != 0:
+ *       the operand is the TRANSPOSE of the row-major (K,N) matrix at W (leading dimension ldw >= N) -- the B operand of a data gradient
+ *       dX = dY . W read straight from W, no f32 copy of W^T.  upp_linear_sb_prep_batched: `count` weights in one launch (HOST arrays of
+ *       device pointers / sizes): the trainable weights of a step driver, re-split at the start of every step.
  *   upp_linear_sb_tile(M, N, K): the tile code the library would take (hex digits 0x4 BMB BNB RN KS NST: workgroups of
  *       BMB x BNB blocks of 32 x 32, a wave owns 1 x RN of them, the contraction cut over KS wave groups, NST LDS stages of 32 KS values
- *       of k), or 0 when the problem is not one for this kernel (K % 32, K < 64, more than one round of 256 workgroups).
- *   upp_linear_sb_f32: epilogues and aux as upp_linear_f32; tile 0 = the library's choice.  Limits: K % 32 == 0 (% 64 for KS = 2 tiles),
+ *       of k), or 0 when the problem is not one for this kernel (K % 32, fewer k-stages than LDS stages, no tile fits).
+ *   upp_linear_sb_f32: epilogues and aux as upp_linear_f32; tile 0 = the library's choice.  Limits: K % 32 == 0 (% 64, % 128 for KS = 2, 4 tiles),
  *       N % 4 == 0, lda % 4 == 0, ldc % 4 == 0, ldaux % 4 == 0, A / C / bias / aux 16-byte aligned; UPP_E_RANGE otherwise (the caller
- *       then takes upp_linear_f32). */
+ *       then takes upp_linear_f32).
+ *   upp_linear_sb_group_bias_f32: C = A . W^T + bias[m >> group_shift][:] (a bias per group of 2^group_shift >= 32 rows), the split-bf16
+ *       form of upp_linear_group_bias_f32 (reference models/Point_MAE_unify_segment.py:424-433, models/Point_MAE_unify.py:213-216). */
 int upp_linear_sb_tile(int M, int N, int K);
 long long upp_linear_sb_planes_bytes(int N, int K);
-int upp_linear_sb_prep(const float *W, long long ldw, int N, int K, void *planes, void *stream);
+int upp_linear_sb_prep(const float *W, long long ldw, int N, int K, int transposed, void *planes, void *stream);
+int upp_linear_sb_prep_batched(const float *const *W, const long long *ldw, const int *N, const int *K, const int *transposed,
+                               void *const *planes, int count, void *stream);
 int upp_linear_sb_f32(const float *A, long long lda, const void *planes, const float *bias, float *C, long long ldc, float *aux,
                       long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream);
+int upp_linear_sb_group_bias_f32(const float *A, long long lda, const void *planes, const float *bias, int group_shift, float *C,
+                                 long long ldc, int M, int N, int K, void *stream);
 /* upp_linear_smallk_f32: y (M,N) = act(x (M,K) . W (N,K)^T + bias) for the Linear layers upp_linear_f32 does not take (K not a
  * multiple of 4, unaligned rows): the first layer of every position MLP (K = 3; reference models/Point_MAE_unify.py pos_embed /
  * models/Point_MAE_pretask_dev.py:395-399 `nn.Linear(3, 128), nn.GELU(), nn.Linear(128, dim)`) and the first point-wise layer of

@@ -117,7 +117,6 @@ def test_epilogues_match_the_exact_f32_kernel(cfg):
 def test_shapes_the_kernel_does_not_take_fall_back_to_the_exact_f32_kernel():
     assert ops.linear_sb_tile(2400, 384, 100) == 0          # K % 32
     assert ops.linear_sb_tile(2400, 384, 64) == 0           # fewer k-stages than LDS stages
-    assert ops.linear_sb_tile(65536, 1024, 1536) == 0       # more than one round of 256 workgroups
     a, w, _ = _operands(64, 48, 100)
     assert torch.equal(ops.linear_f32(a, w, frozen=True), ops.linear_f32(a, w))
     lib = _abi.load()
@@ -167,3 +166,68 @@ def test_plane_images_are_cached_per_owner_object_and_never_for_temporaries():
     assert p_other is not p1                                                   # the entry was made for another owner object: not served
     terms = _planes_to_terms(p_other, 384, 384).double().sum(0)
     assert torch.equal(terms, other.detach().double())
+
+
+def test_transposed_and_batched_prep_equal_the_plain_split():
+    ws = [torch.randn(384, 1536, device='cuda'), torch.randn(1152, 384, device='cuda'), torch.randn(50, 100, device='cuda')]
+    for w in ws:
+        direct = ops._WeightPlanes._split(w.t().contiguous())                   # planes of w^T from an explicit copy
+        assert torch.equal(ops._WeightPlanes._split(w, None, True), direct)       # ... and read transposed from w itself
+    ps = [torch.nn.Parameter(w) for w in ws]
+    ops.PLANES.trainable.clear()
+    imgs = [ops.PLANES.get_trainable(p, transposed=(i == 1)) for i, p in enumerate(ps)]
+    with torch.no_grad():
+        for p in ps:
+            p.mul_(1.7).add_(0.3)                                                 # "the optimizer stepped"
+    ops.PLANES.refresh_trainable()                                                # one launch for all three
+    for i, p in enumerate(ps):
+        assert torch.equal(imgs[i], ops._WeightPlanes._split(p.detach(), None, i == 1))
+    ops.PLANES.trainable.clear()
+
+
+@pytest.mark.parametrize("shape", [(4096, 1024, 512), (65536, 512, 256), (8192, 256, 1536)])
+def test_tall_matrices_run_in_several_rounds(shape):
+    M, N, K = shape
+    assert ops.linear_sb_tile(M, N, K) > 0
+    g = torch.Generator(device='cuda').manual_seed(M)
+    a = torch.randint(-8, 9, (M, K), device='cuda', generator=g).float()
+    w = torch.randint(-8, 9, (N, K), device='cuda', generator=g).float()
+    w._upp_persistent = True
+    got = ops.linear_f32(a, w, frozen=True)
+    assert torch.equal(got.double(), a.double() @ w.double().t())
+
+
+def test_group_bias_epilogue_equals_product_plus_broadcast():
+    M, N, K, r = 65536, 512, 256, 2048
+    a, w, _ = _operands(M, N, K, seed=3)
+    gb = torch.randn(M // r, N, device='cuda')
+    assert ops.linear_group_bias_usable(M, N, K, r)
+    got = ops.linear_group_bias(a, w, gb, r, frozen=True)
+    want = ops.linear_f32(a, w, frozen=True).view(M // r, r, N) + gb.unsqueeze(1)
+    assert torch.equal(got, want.view(M, N))                                      # same kernel, same sums: the bias is one f32 add either way
+    torch.testing.assert_close(got, ops.linear_group_bias(a, w, gb, r), rtol=1e-5, atol=5e-6)
+
+
+def test_trainable_weights_take_the_split_kernel_inside_a_step_driver_only():
+    lin = torch.nn.Linear(384, 1536).cuda()
+    x = torch.randn(2400, 384, device='cuda', requires_grad=True)
+    with ops.time_linear_calls() as scope:
+        HF.linear(x, lin.weight, lin.bias).sum().backward()
+    assert [c[6] for c in scope.calls] == [0, 0]                                  # outside a driver: exact-f32 kernel, forward and data gradient
+    g_ref = x.grad.clone()
+    x.grad = None
+    ops.PLANES.managed = True
+    try:
+        ops.PLANES.refresh_trainable()
+        with ops.time_linear_calls() as scope:
+            y = HF.linear(x, lin.weight, lin.bias)
+            y.sum().backward()
+        assert all(c[6] for c in scope.calls) and len(scope.calls) == 2
+        torch.testing.assert_close(x.grad, g_ref, rtol=1e-5, atol=1e-4)
+        with torch.no_grad():
+            lin.weight.mul_(0.5)
+        ops.PLANES.refresh_trainable()                                            # what TrainStep does at the start of every step
+        torch.testing.assert_close(HF.linear(x, lin.weight, lin.bias) - lin.bias, 0.5 * (y - lin.bias), rtol=1e-5, atol=5e-6)
+    finally:
+        ops.PLANES.managed = False
+        ops.PLANES.trainable.clear()

@@ -22,7 +22,7 @@ def main():
     lib = ctypes.CDLL(SO)
     vp, ll, ci = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int
     lib.upp_linear_sb_f32.argtypes = [vp, ll, vp, vp, vp, ll, vp, ll, ci, ci, ci, ci, ci, vp]
-    lib.upp_linear_sb_prep.argtypes = [vp, ll, ci, ci, vp, vp]
+    lib.upp_linear_sb_prep.argtypes = [vp, ll, ci, ci, ci, vp, vp]
     lib.upp_linear_sb_planes_bytes.restype = ll
     lib.upp_linear_sb_set_stamps.argtypes = [vp]
     dev = torch.device("cuda", 0)
@@ -36,7 +36,7 @@ def main():
         w = torch.randn(N, K, device=dev) * 0.05
         c = torch.empty(M, N, device=dev)
         planes = torch.empty(int(lib.upp_linear_sb_planes_bytes(N, K)), dtype=torch.uint8, device=dev)
-        assert lib.upp_linear_sb_prep(w.data_ptr(), K, N, K, planes.data_ptr(), None) == 0
+        assert lib.upp_linear_sb_prep(w.data_ptr(), K, N, K, 0, planes.data_ptr(), None) == 0
         tile = lib.upp_linear_sb_tile(M, N, K)
         for _ in range(int(os.environ.get('LAUNCHES', '2000'))):        # back-to-back launches (clock ramp): the last one is read
             rc = lib.upp_linear_sb_f32(a.data_ptr(), K, planes.data_ptr(), None, c.data_ptr(), N, None, 0, M, N, K, 0, tile, None)

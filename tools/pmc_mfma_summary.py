@@ -17,7 +17,7 @@ import statistics
 import sys
 
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
-from pmc_summary import labelled  # noqa: E402
+from pmc_summary import labelled, name  # noqa: E402
 
 CLOCK_GHZ = 2.1
 
@@ -29,9 +29,10 @@ def main():
     for n in names:
         for k, r in labelled([r for r in rows if r['Counter_Name'] == n], 'Dispatch_Id'):
             vals[n][k].append(float(r['Counter_Value']))
-    dur = collections.defaultdict(list)
+    dur, kern = collections.defaultdict(list), {}
     for k, r in labelled(list(csv.DictReader(open(sys.argv[2]))), 'Dispatch_Id'):
         dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        kern.setdefault(k, name(r))
     out = {}
     med = lambda n, k: statistics.median(vals[n][k]) if n in vals and k in vals[n] else None
     for k in sorted(vals.get('SQ_VALU_MFMA_BUSY_CYCLES', {})):
@@ -41,7 +42,8 @@ def main():
         if not mf:
             continue
         us = statistics.median(dur[k]) if k in dur else None
-        e = {'us': us, 'mfma_busy_cycles': mf, 'mfma_pipe_frac': mf / (1024 * us * 1e3 * CLOCK_GHZ) if us else None}
+        e = {'us': us, 'kernel': kern.get(k), 'mfma_busy_cycles': mf, 'mfma_pipe_frac': mf / (1024 * us * 1e3 * CLOCK_GHZ) if us else None,
+             'clock_ghz': CLOCK_GHZ}
         for n, label in (('SQ_WAIT_ANY', 'wait_any'), ('SQ_WAIT_INST_ANY', 'wait_inst'), ('SQ_ACTIVE_INST_ANY', 'active')):
             v = med(n, k)
             e[label] = v / wc if (v is not None and wc) else None
