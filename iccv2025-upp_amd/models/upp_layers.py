@@ -294,48 +294,61 @@ class _SyncBNRows(torch.autograd.Function):
     """y = (x - mean) * rstd * gamma + beta over the rows of every rank (biased variance for the output, unbiased for running_var: nn.BatchNorm)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, counter=None):
+        # The row count stays ON THE DEVICE (a 1-element tensor): a .item() here is a host sync, which a HIP-graph capture refuses -- and the
+        # multi-GPU step drivers this switch exists for capture their step.  Sums in float64 (one pass; cancellation-free for E[x^2] - mean^2),
+        # the normalised rows in the input's precision.
         import torch.distributed as dist
         C = x.shape[1]
         xd = x.double()
         stats = torch.cat([xd.sum(0), (xd * xd).sum(0), torch.full((1,), float(x.shape[0]), dtype=torch.float64, device=x.device)])
         dist.all_reduce(stats)
-        n = stats[2 * C].item()
+        n = stats[2 * C:2 * C + 1]
         mean = stats[:C] / n
         var = (stats[C:2 * C] / n - mean * mean).clamp_min(0.0)
         rstd = (var + eps).rsqrt()
-        if running_mean is not None and momentum is not None:
+        if running_mean is not None:
             with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
-                running_var.mul_(1 - momentum).add_((var * (n / max(n - 1.0, 1.0))).to(running_var.dtype), alpha=momentum)
-        xhat = ((xd - mean) * rstd).to(x.dtype)
-        ctx.save_for_backward(xhat, weight, rstd.to(x.dtype))
-        ctx.n = n
+                unbiased = var * (n / (n - 1.0).clamp_min(1.0))
+                if momentum is None:            # cumulative moving average, as nn.BatchNorm: factor 1 / num_batches_tracked (already bumped)
+                    f = (1.0 / counter.double().clamp_min(1.0)).to(running_mean.dtype)
+                    running_mean.mul_(1 - f).add_(mean.to(running_mean.dtype) * f)
+                    running_var.mul_(1 - f).add_(unbiased.to(running_var.dtype) * f)
+                else:
+                    running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+        mean32, rstd32 = mean.to(x.dtype), rstd.to(x.dtype)
+        xhat = (x - mean32) * rstd32
+        ctx.save_for_backward(xhat, weight, rstd32, n)
         y = xhat if weight is None else xhat * weight
         return y if bias is None else y + bias
 
     @staticmethod
     def backward(ctx, g):
         import torch.distributed as dist
-        xhat, weight, rstd = ctx.saved_tensors
+        xhat, weight, rstd, n = ctx.saved_tensors
         C = g.shape[1]
         gd = g.double()
         sums = torch.cat([gd.sum(0), (gd * xhat.double()).sum(0)])
         local = sums.clone()
         dist.all_reduce(sums)
-        mg, mgx = (sums[:C] / ctx.n).to(g.dtype), (sums[C:] / ctx.n).to(g.dtype)
+        mg, mgx = (sums[:C] / n).to(g.dtype), (sums[C:] / n).to(g.dtype)
         scale = rstd if weight is None else rstd * weight
         gx = (g - mg - xhat * mgx) * scale if ctx.needs_input_grad[0] else None
-        gw = local[C:].to(g.dtype) if weight is not None and ctx.needs_input_grad[1] else None      # (rank-local: the gradient all-reduce sums the ranks)
+        # rank-local sums for the parameters: the step driver's gradient all-reduce (utils.dist_utils.FlatGradAllReduce, an average of the
+        # ranks' buffers as DistributedDataParallel's) then yields what nn.SyncBatchNorm + DDP yield
+        gw = local[C:].to(g.dtype) if weight is not None and ctx.needs_input_grad[1] else None
         gb = local[:C].to(g.dtype) if ctx.needs_input_grad[2] else None
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 def _bn_rows(x, bn, training, relu=False):
     """BatchNorm1d of a channels-last (rows, C) matrix: identical statistics to BatchNorm1d on
     the reference's (BG, C, n) layout (both reduce over every position of every group)."""
     if x.dim() == 2 and sync_bn_active(training or bn.running_mean is None):
-        y = _SyncBNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        if bn.running_mean is not None and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)          # (at once, not with the forward's batched bump: momentum=None reads it below)
+        y = _SyncBNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.num_batches_tracked)
         return F.relu(y) if relu else y
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
         if _no_grad_needed(x, bn.weight, bn.bias):

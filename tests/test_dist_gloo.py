@@ -126,7 +126,10 @@ def test_flat_grad_buffer_views_survive_backward():
         FlatGradAllReduce(frozen.parameters())
 
 
-def _sync_bn_worker(rank, world, port, out_dir):
+_SHARDS = {2: [0, 14, 40], 4: [0, 5, 14, 27, 40]}          # uneven shards: the statistics weigh rows, not ranks
+
+
+def _sync_bn_worker(rank, world, port, out_dir, cumulative):
     sys.path[:0] = [p for p in os.environ["UPP_TEST_PATHS"].split(os.pathsep)]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
@@ -136,47 +139,65 @@ def _sync_bn_worker(rank, world, port, out_dir):
     L.enable_sync_bn(True)
     assert L.sync_bn_active(True) and not L.sync_bn_active(False)
     torch.manual_seed(3)
-    bn = torch.nn.BatchNorm1d(24)
+    bn = torch.nn.BatchNorm1d(24, momentum=None if cumulative else 0.1)
     with torch.no_grad():
         bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
     x_all = torch.randn(40, 24) * 2.0 + 0.7
     g_all = torch.randn(40, 24)
-    rows = slice(0, 14) if rank == 0 else slice(14, 40)            # uneven shards: the statistics weigh rows, not ranks
+    rows = slice(_SHARDS[world][rank], _SHARDS[world][rank + 1])
     x = x_all[rows].clone().requires_grad_(True)
-    y = L._bn_rows(x, bn.train(), True, relu=True)
-    (y * g_all[rows]).sum().backward()
+    # no host synchronisation inside the layer: a HIP-graph capture (the multi-GPU step drivers capture their step) refuses .item()
+    real_item = torch.Tensor.item
+    torch.Tensor.item = lambda self: (_ for _ in ()).throw(RuntimeError("host sync inside synchronised BatchNorm"))
+    try:
+        y = L._bn_rows(x, bn.train(), True, relu=True)
+        (y * g_all[rows]).sum().backward()
+        y2 = L._bn_rows(x.detach() * 0.5 + 1.0, bn, True)          # a second batch: running statistics after two updates
+    finally:
+        torch.Tensor.item = real_item
+    pooled = L.pooling(x_all[rows].reshape(rows.stop - rows.start, 1, 1, 24).detach(), transform=bn) if not cumulative else y2
     rm, rv = bn.running_mean.clone(), bn.running_var.clone()
-    pooled = L.pooling(x_all[rows].reshape(2, -1, 1, 24).detach(), transform=bn)      # the prompt-propagation site goes the same way
-    torch.save({"y": y.detach(), "gx": x.grad, "gw": bn.weight.grad, "gb": bn.bias.grad, "rm": rm, "rv": rv, "pooled": pooled.detach()}, os.path.join(out_dir, "s%d.pt" % rank))
+    torch.save({"y": y.detach(), "gx": x.grad, "gw": bn.weight.grad, "gb": bn.bias.grad, "rm": rm, "rv": rv, "pooled": pooled.detach(),
+                "count": bn.num_batches_tracked.clone()}, os.path.join(out_dir, "s%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_sync_bn_switch_gives_the_single_process_statistics(tmp_path):
+@pytest.mark.parametrize("world,cumulative", [(2, False), (4, False), (4, True)])
+def test_sync_bn_switch_gives_the_single_process_statistics(tmp_path, world, cumulative):
     """`--sync_bn` (reference tools/runner_module.py:50-52): with the switch on, a training-mode BatchNorm over rows normalises with the
-    statistics of the rows of ALL ranks -- outputs, input gradients and running statistics equal one process seeing every row; the
-    parameter gradients are rank-local partial sums (the step's gradient all-reduce adds them)."""
+    statistics of the rows of ALL ranks -- outputs, input gradients, running statistics and the batch counter equal one process seeing
+    every row (also with momentum=None: the cumulative average of nn.BatchNorm); the parameter gradients are rank-local partial sums (the
+    step's gradient all-reduce adds them).  World sizes 2 and 4, uneven shards, and no host synchronisation inside the layer."""
     from conftest import ROOT, PKG
     os.environ["UPP_TEST_PATHS"] = os.pathsep.join([os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), PKG])
-    mp.spawn(_sync_bn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    r = [torch.load(tmp_path / ("s%d.pt" % k)) for k in range(2)]
+    mp.spawn(_sync_bn_worker, args=(world, _free_port(), str(tmp_path), cumulative), nprocs=world, join=True)
+    r = [torch.load(tmp_path / ("s%d.pt" % k)) for k in range(world)]
     torch.manual_seed(3)
-    bn = torch.nn.BatchNorm1d(24)
+    bn = torch.nn.BatchNorm1d(24, momentum=None if cumulative else 0.1)
     with torch.no_grad():
         bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
     x_all = (torch.randn(40, 24) * 2.0 + 0.7).requires_grad_(True)
     g_all = torch.randn(40, 24)
     y = torch.relu(bn.train()(x_all))
     (y * g_all).sum().backward()
+    y2 = bn(x_all.detach() * 0.5 + 1.0)
     close = lambda a, b: np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=2e-5, atol=2e-6)
-    close(torch.cat([r[0]["y"], r[1]["y"]]), y)
-    close(torch.cat([r[0]["gx"], r[1]["gx"]]), x_all.grad)
-    close(r[0]["gw"] + r[1]["gw"], bn.weight.grad)
-    close(r[0]["gb"] + r[1]["gb"], bn.bias.grad)
-    close(r[0]["rm"], bn.running_mean); close(r[1]["rv"], bn.running_var)
-    assert torch.equal(r[0]["rm"], r[1]["rm"]) and torch.equal(r[0]["rv"], r[1]["rv"])
+    close(torch.cat([r[k]["y"] for k in range(world)]), y)
+    close(torch.cat([r[k]["gx"] for k in range(world)]), x_all.grad)
+    close(sum(r[k]["gw"] for k in range(world)), bn.weight.grad)
+    close(sum(r[k]["gb"] for k in range(world)), bn.bias.grad)
+    if cumulative:
+        close(torch.cat([r[k]["pooled"] for k in range(world)]), y2)
+        close(r[0]["rm"], bn.running_mean); close(r[world - 1]["rv"], bn.running_var)
+        assert all(int(r[k]["count"]) == 2 for k in range(world))
+        assert all(torch.equal(r[0]["rm"], r[k]["rm"]) and torch.equal(r[0]["rv"], r[k]["rv"]) for k in range(world))
+        return
+    # (momentum 0.1: the workers went on to the pooling site, which updates the statistics once more -- compare after the same three updates)
     # pooling over groups of one row = 2 x the row (max + mean), normalised with the statistics of all 40 rows
     with torch.no_grad():
-        want = torch.nn.functional.batch_norm(2.0 * x_all.detach(), None, None, bn.weight, bn.bias, True, 0.0, bn.eps)
-    close(torch.cat([r[0]["pooled"].reshape(-1, 24), r[1]["pooled"].reshape(-1, 24)]), want)
+        want = torch.nn.functional.batch_norm(2.0 * x_all.detach(), bn.running_mean, bn.running_var, bn.weight, bn.bias, True, 0.1, bn.eps)
+    close(torch.cat([r[k]["pooled"].reshape(-1, 24) for k in range(world)]), want)
+    close(r[0]["rm"], bn.running_mean); close(r[world - 1]["rv"], bn.running_var)
+    assert all(torch.equal(r[0]["rm"], r[k]["rm"]) and torch.equal(r[0]["rv"], r[k]["rv"]) for k in range(world))

@@ -60,6 +60,10 @@ def _worker(rank, world, port, out_dir, paths, kind="pipelined"):
         assert float(ts.opt.state[0]) == 0.0, "the capture warm-up left optimizer steps behind"
         assert torch.equal(bn.running_mean, before[0]) and torch.equal(bn.num_batches_tracked, before[1])
         ts.flush = lambda: None
+    elif kind == "onestream":
+        from upp_hip.train import TrainStep
+        ts = TrainStep(m, (4, 1096, 3))
+        ts.flush = lambda: None
     else:
         ts = PipelinedTrainStep(m, (4, 1096, 3))
     assert ts.distributed == (world > 1)
@@ -90,6 +94,22 @@ def test_two_ranks_keep_identical_parameters(tmp_path):
     np.testing.assert_array_equal(a, b)                       # one all-reduce per step: bit-identical replicas
     assert np.abs(a - solo).max() > 1e-6                      # ... and the other rank's batches did contribute
     assert np.isfinite(np.load(tmp_path / "loss_pipelined_w2_r0.npy")) and np.isfinite(np.load(tmp_path / "loss_pipelined_w2_r1.npy"))
+
+
+def test_pipelined_and_one_stream_steps_agree_at_world_size_two(tmp_path):
+    """The pipelined step places its gradient all-reduce between the back-end graph and the optimizer graph while the next batch's
+    front-end is already running (train.py PipelinedTrainStep._finish); the one-stream step reduces after its only graph.  Same batches,
+    two ranks: the same parameters on every rank either way (the front-end reads no trainable parameter: order does not matter)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    paths = [here, os.path.join(root, "iccv2025-upp_amd"), os.path.join(root, "oracle")]
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), paths), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), paths, "onestream"), nprocs=2, join=True)
+    pipe = [np.load(tmp_path / ("params_pipelined_w2_r%d.npy" % r)) for r in range(2)]
+    one = [np.load(tmp_path / ("params_onestream_w2_r%d.npy" % r)) for r in range(2)]
+    np.testing.assert_array_equal(one[0], one[1])
+    np.testing.assert_array_equal(pipe[0], pipe[1])
+    np.testing.assert_allclose(pipe[0], one[0], rtol=5e-4, atol=5e-5 * np.abs(one[0]).max())
 
 
 def test_replicas_stay_identical_when_ranks_start_apart_and_feed_data_before_the_first_step(tmp_path):
