@@ -51,8 +51,6 @@ class UniformBank:
 
 
 UNIFORMS = UniformBank()
-KPARTS = False             # Block.forward_fused: k-parts protocol for the narrow products (qkv / fc1 data gradients, fc2 output); measured: the
-                           # GEMMs gain 16-26 % stand-alone, the step loses it again in the consumers (NOTEBOOK 9.2) -- off by default
 FUSE_LN_ADAPTER = True     # Block.forward_fused: close the block with HF.ln_adapter (one launch) instead of HF.rowln + HF.adapter
 
 
@@ -675,18 +673,14 @@ class Block(nn.Module):
         n1, n2 = self.norm1, self.norm2
         attn, mlp = self.attn, self.mlp
         fused_attn = _frozen_bias(attn.proj) and attn.proj_drop.p == 0
-        # k-parts (csrc/linear.hip pick_parts): the data gradients of qkv and fc1 and the output of fc2 are narrow (384 wide) products over a
-        # long contraction -- cut over workgroups, their parts are added by the row kernel that consumes them.  p1 / p2: parts of the
-        # gradient that comes back to h1 / h2 (1 = plain); KPARTS = False switches the protocol off (A/B, tests).
-        p1 = HF.dx_parts(x, attn.qkv.weight, rows=B * (x.shape[1] + (P if ins in (HF.ROW_INSERT_CLS, HF.ROW_INSERT) else 0))) if (KPARTS and fused_attn) else 1
         xa, h1 = HF.rowln(x, add=pos, prompts=prompts, mode=ins, P=P, gamma=n1.weight, beta=n1.bias, eps=n1.eps,
-                          cls_add=kw.get('_cls_pos'), h_parts=p1)
+                          cls_add=kw.get('_cls_pos'))
         # The four Linear layers run on upp_linear_f32 (csrc/linear.hip).  Frozen output biases ride along in the row kernel
         # that consumes the GEMM result (proj.bias, fc2.bias); fc1's bias, the GELU and -- for backward -- GELU' are the
         # epilogue of the fc1 GEMM, and the fc2 data gradient multiplies by that GELU' in its own epilogue.
         yb = mb = None
         if fused_attn:
-            qkv = HF.linear(h1, attn.qkv.weight, attn.qkv.bias, x_parts=p1) if p1 > 1 else HF.linear(h1, attn.qkv.weight, attn.qkv.bias)
+            qkv = HF.linear(h1, attn.qkv.weight, attn.qkv.bias)
             ctx = HF.attention(qkv, attn.num_heads, attn.scale)
             y, yb = HF.linear(ctx, attn.proj.weight), attn.proj.bias
         else:
@@ -694,12 +688,9 @@ class Block(nn.Module):
         fc1, fc2 = mlp.fc1, mlp.fc2
         fused_mlp = (_frozen_bias(fc1) and _frozen_bias(fc2) and isinstance(mlp.act, nn.GELU) and mlp.act.approximate == 'none'
                      and HF.linear_usable(xa, fc1.weight) and fc1.out_features % 32 == 0 and _no_grad_needed(fc1.weight, fc2.weight))
-        p2 = HF.dx_parts(xa, fc1.weight) if (KPARTS and fused_mlp) else 1
-        x2, h2 = HF.rowln(xa, y=y, ybias=yb, u=None if u is None else u[0], keep=keep, gamma=n2.weight, beta=n2.bias, eps=n2.eps, h_parts=p2)
+        x2, h2 = HF.rowln(xa, y=y, ybias=yb, u=None if u is None else u[0], keep=keep, gamma=n2.weight, beta=n2.bias, eps=n2.eps)
         if fused_mlp:
-            rows = xa.shape[0] * xa.shape[1]
-            cut = KPARTS and HF.ops.linear_parts_choice(rows, fc2.weight.shape[0], fc2.weight.shape[1]) > 1
-            m, mb = HF.mlp_gelu(h2, fc1.weight, fc1.bias, fc2.weight, x_parts=p2 if p2 > 1 else 0, out_parts=cut), fc2.bias
+            m, mb = HF.mlp_gelu(h2, fc1.weight, fc1.bias, fc2.weight), fc2.bias
         elif _frozen_bias(fc1) and _frozen_bias(fc2) and isinstance(mlp.act, nn.GELU) and fc1.out_features % 4 == 0:
             hid = HF.bias_gelu(HF.linear(h2, fc1.weight), fc1.bias)
             m, mb = HF.linear(hid, fc2.weight), fc2.bias
@@ -981,7 +972,7 @@ class RectifyPrompter(nn.Module):
         per-point feature when no gradient is asked for (upp_rectify_select); the reference formulation otherwise."""
         feature, _ = self.features(x, center1, center1_feature)
         l0, _, drop, l1 = self.score_head
-        if (feature.is_cuda and feature.dtype == torch.float32 and x.shape[1] <= 16384 and tuple(l0.weight.shape) == (64, 32)
+        if (feature.is_cuda and feature.dtype == torch.float32 and x.shape[1] <= 16384 and 0 < keep <= x.shape[1] and tuple(l0.weight.shape) == (64, 32)
                 and tuple(l1.weight.shape) == (3, 64) and l0.bias is not None and l1.bias is not None
                 and _no_grad_needed(feature, x, l0.weight, l0.bias, l1.weight, l1.bias)):
             from upp_hip import ops

@@ -37,9 +37,6 @@ SIGNATURES = {
                             + [ctypes.c_float, ctypes.c_float, _c_i] + [_c_f, _c_f, _c_f]),
     "upp_rowln_fwd": (_c_i, [_c_f] * 3 + [_c_i] * 2 + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 2 + [ctypes.c_float] + [_c_f] * 4
                       + [_c_i] * 4 + [_c_f]),
-    "upp_rowln_fwd_parts": (_c_i, [_c_f] * 3 + [_c_i] * 2 + [_c_f, _c_i, ctypes.c_longlong] + [_c_f] * 2 + [ctypes.c_float] + [_c_f] * 2 + [ctypes.c_float]
-                            + [_c_f] * 4 + [_c_i] * 4 + [_c_f]),
-    "upp_rowln_bwd_parts": (_c_i, [_c_f] * 2 + [_c_i, ctypes.c_longlong] + [_c_f] * 4 + [_c_i] + [_c_f] + [ctypes.c_float] + [_c_f] * 4 + [_c_i] * 5 + [_c_f]),
     "upp_bias_gelu_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_longlong, _c_i, _c_f]),
     "upp_bias_gelu_fwd_d": (_c_i, [_c_f] * 4 + [ctypes.c_longlong, _c_i, _c_f]),
     "upp_bias_gelu_bwd": (_c_i, [_c_f] * 4 + [ctypes.c_longlong, _c_i, _c_f]),
@@ -48,8 +45,6 @@ SIGNATURES = {
     "upp_ln_param_grad": (_c_i, [_c_f] * 5 + [_c_i] * 3 + [_c_f]),
     "upp_attn_fwd": (_c_i, [_c_f] * 3 + [_c_i] * 4 + [ctypes.c_float, _c_f]),
     "upp_attn_bwd": (_c_i, [_c_f] * 5 + [_c_i] * 4 + [ctypes.c_float, _c_f]),
-    "upp_attn_fwd_ex": (_c_i, [_c_f] * 3 + [_c_i] * 4 + [ctypes.c_float, _c_i, _c_f]),
-    "upp_attn_bwd_ex": (_c_i, [_c_f] * 5 + [_c_i] * 4 + [ctypes.c_float, _c_i, _c_f]),
     "upp_prop_pool_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 2 + [_c_i] * 2 + [_c_f]),
     "upp_prop_pool_bwd": (_c_i, [_c_f] * 4 + [ctypes.c_float] + [_c_f] + [_c_i] * 3 + [_c_f]),
     "upp_prop_interp_fwd": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f]),
@@ -80,8 +75,6 @@ SIGNATURES = {
     "upp_adapter_bwd": (_c_i, [_c_f] * 6 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
     "upp_ln_adapter_fwd": (_c_i, [_c_f] * 4 + [ctypes.c_float, _c_i, _c_i, _c_f, _c_f, ctypes.c_float] + [_c_f] * 5 + [ctypes.c_float] * 2
                            + [_c_f] * 5 + [_c_i] * 5 + [_c_f]),
-    "upp_ln_adapter_fwd_parts": (_c_i, [_c_f] * 2 + [_c_i, ctypes.c_longlong] + [_c_f] * 2 + [ctypes.c_float, _c_i, _c_i, _c_f, _c_f, ctypes.c_float]
-                                 + [_c_f] * 5 + [ctypes.c_float] * 2 + [_c_f] * 5 + [_c_i] * 5 + [_c_f]),
     "upp_ln_adapter_bwd": (_c_i, [_c_f] * 10 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
     "upp_ln_adapter_part_floats": (ctypes.c_longlong, [_c_i, _c_i]),
     "upp_ln_adapter_bwd_fused": (_c_i, [_c_f] * 10 + [ctypes.c_float] * 2 + [_c_f, ctypes.c_float, _c_i, _c_i] + [_c_f] * 4 + [_c_i] * 5 + [_c_f]),
@@ -101,8 +94,6 @@ SIGNATURES = {
     "upp_linear_sb_group_bias_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
     "upp_linear_sb_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong] + [_c_i] * 5 + [_c_f]),
     "upp_linear_group_bias_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
-    "upp_linear_parts": (_c_i, [_c_i, _c_i, _c_i]),
-    "upp_linear_parts_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, ctypes.c_longlong] + [_c_i] * 4 + [_c_f]),
     "upp_linear_smallk_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_f, ctypes.c_longlong] + [_c_i] * 4 + [_c_f]),
     "upp_linear_smallk_wgrad_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_transpose_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_f]),
@@ -133,7 +124,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError -> loud failure on a stale build
         fn.restype = res
         fn.argtypes = args
-    if lib.upp_abi_version() != 2:
+    if lib.upp_abi_version() != 3:
         raise RuntimeError("libupp_hip.so ABI version mismatch")
     _lib = lib
     return lib

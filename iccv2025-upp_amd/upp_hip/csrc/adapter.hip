@@ -779,15 +779,7 @@ extern "C" int upp_adapter_fwd(const float *ha, const float *x, const float *W1,
     return upp_launch_status();
 }
 
-extern "C" int upp_ln_adapter_fwd(const float *x, const float *y, const float *ybias, const float *u, float keep, int mode, int P,
-                                  const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
-                                  const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
-                                  float *out, int B, int Lin, int Lout, int D, int H, void *stream) {
-    return upp_ln_adapter_fwd_parts(x, y, 1, 0, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, xo, mean, rstd, s1, out, B, Lin,
-                                    Lout, D, H, stream);
-}
-
-extern "C" int upp_ln_adapter_fwd_parts(const float *x, const float *y, int yparts, long long ystride, const float *ybias, const float *u, float keep,
+static int ln_adapter_fwd_impl(const float *x, const float *y, int yparts, long long ystride, const float *ybias, const float *u, float keep,
                                         int mode, int P, const float *gamma, const float *beta, float eps, const float *W1, const float *b1,
                                         const float *W2, const float *b2, const float *ud, float p, float scale, float *xo, float *mean,
                                         float *rstd, float *s1, float *out, int B, int Lin, int Lout, int D, int H, void *stream) {
@@ -801,6 +793,14 @@ extern "C" int upp_ln_adapter_fwd_parts(const float *x, const float *y, int ypar
     LnAdapterArgs a{x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, xo, mean, rstd, s1, out, B, Lin, Lout, yparts, ystride};
     hipLaunchKernelGGL((ln_adapter_fwd_kernel<384, 8>), dim3((B * Lout + kFR - 1) / kFR), dim3(64 * 8), 0, (hipStream_t)stream, a);
     return upp_launch_status();
+}
+
+extern "C" int upp_ln_adapter_fwd(const float *x, const float *y, const float *ybias, const float *u, float keep, int mode, int P,
+                                  const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
+                                  const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
+                                  float *out, int B, int Lin, int Lout, int D, int H, void *stream) {
+    return ln_adapter_fwd_impl(x, y, 1, 0, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, xo, mean, rstd, s1, out, B, Lin,
+                                    Lout, D, H, stream);
 }
 
 static int adapter_bwd_launch(const float *g_out, const float *ha, const float *mean, const float *rstd, const float *gamma,

@@ -1,4 +1,4 @@
-// attn_tiles.h -- FP32-MFMA tile helpers shared by the attention kernels (attn_mfma.hip: L <= 96, attn_long.hip: L <= 160).
+// attn_tiles.h -- FP32-MFMA tile helpers of attn_long.hip (L <= 160; and of tools/micro/attn_mfma.hip, round 1's L <= 96 kernels).
 // Operand tiles live in LDS with a row stride of kLD = 65 floats, so that both the row-major and the transposed
 // one-dword-per-lane operand reads of v_mfma_f32_32x32x2_f32 are bank-conflict free.  K (the contraction length) is one of
 // 32 / 64 / 96 / 128 / 160.

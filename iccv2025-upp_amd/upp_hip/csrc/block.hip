@@ -281,191 +281,6 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float *__restr
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// attention, head dim 64.  qkv (B, L, 3, H, 64); ctx (B, L, H*64); lse (B, H, L).
-// One workgroup (8 waves) per (b, h).  Each wave owns query rows i = wave, wave+8, ...
-//   scores : lane = key j (NS key slots of 64), k_j in VGPRs, q_i through uniform (scalar) loads
-//   softmax: two DPP wave reductions
-//   context: lane = channel d, p_j broadcast from LDS, v_j[d] from LDS
-constexpr int kAW = 8;
-
-template <int NS>
-__global__ __launch_bounds__(64 * kAW) void attn_fwd_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
-                                                            float *__restrict__ lse, int L, int H, float scale) {
-    extern __shared__ float sm[];
-    float *Vs = sm;                         // [L][64]
-    float *Ps = sm + (size_t)L * 64;        // [kAW][2][NS*64]
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
-    const size_t rs = (size_t)3 * H * 64;   // row stride of qkv
-    const float *base = qkv + (size_t)b * L * rs + (size_t)hh * 64;
-    for (int i = threadIdx.x; i < L * 64; i += 64 * kAW) Vs[i] = base[(size_t)(i >> 6) * rs + 2 * H * 64 + (i & 63)];
-    float kreg[NS][64];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int j = s * 64 + lane;
-        const float *kr = base + (size_t)(j < L ? j : L - 1) * rs + H * 64;
-#pragma unroll
-        for (int d = 0; d < 64; d += 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(kr + d);
-            kreg[s][d] = t.x; kreg[s][d + 1] = t.y; kreg[s][d + 2] = t.z; kreg[s][d + 3] = t.w;
-        }
-    }
-    __syncthreads();
-    float *pw = Ps + wave * (2 * NS * 64);
-    // two query rows per iteration share every v_j read; rows past L are computed on a clamped index and dropped
-    for (int i0 = wave * 2; i0 < L; i0 += 2 * kAW) {
-        const int i1 = min(i0 + 1, L - 1);
-        const float *q0 = base + (size_t)i0 * rs, *q1 = base + (size_t)i1 * rs;   // wave-uniform -> scalar loads
-        float s0[NS], s1[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { s0[s] = 0.0f; s1[s] = 0.0f; }
-#pragma unroll
-        for (int d = 0; d < 64; ++d) {
-            const float a = q0[d], c = q1[d];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) { s0[s] = __builtin_fmaf(a, kreg[s][d], s0[s]); s1[s] = __builtin_fmaf(c, kreg[s][d], s1[s]); }
-        }
-        float m0 = -__builtin_inff(), m1 = -__builtin_inff();
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const bool ok = s * 64 + lane < L;
-            s0[s] = ok ? s0[s] * scale : -__builtin_inff(); m0 = fmaxf(m0, s0[s]);
-            s1[s] = ok ? s1[s] * scale : -__builtin_inff(); m1 = fmaxf(m1, s1[s]);
-        }
-        m0 = wave_max_f32(m0); m1 = wave_max_f32(m1);
-        float t0 = 0.0f, t1 = 0.0f;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const bool ok = s * 64 + lane < L;
-            s0[s] = ok ? expf(s0[s] - m0) : 0.0f; t0 += s0[s];
-            s1[s] = ok ? expf(s1[s] - m1) : 0.0f; t1 += s1[s];
-        }
-        t0 = wave_sum(t0); t1 = wave_sum(t1);
-        const float r0 = 1.0f / t0, r1 = 1.0f / t1;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { pw[s * 64 + lane] = s0[s] * r0; pw[NS * 64 + s * 64 + lane] = s1[s] * r1; }
-        if (lane == 0) {
-            lse[((size_t)b * H + hh) * L + i0] = m0 + logf(t0);
-            if (i0 + 1 < L) lse[((size_t)b * H + hh) * L + i0 + 1] = m1 + logf(t1);
-        }
-        float o0 = 0.0f, o1 = 0.0f;
-        const float4 *p0 = reinterpret_cast<const float4 *>(pw), *p1 = reinterpret_cast<const float4 *>(pw + NS * 64);
-        const int L4 = L & ~3;
-        for (int j = 0; j < L4; j += 4) {
-            const float4 a = p0[j >> 2], c = p1[j >> 2];    // broadcast reads
-            const float v0 = Vs[(j + 0) * 64 + lane], v1 = Vs[(j + 1) * 64 + lane], v2 = Vs[(j + 2) * 64 + lane], v3 = Vs[(j + 3) * 64 + lane];
-            o0 = __builtin_fmaf(a.x, v0, o0); o1 = __builtin_fmaf(c.x, v0, o1);
-            o0 = __builtin_fmaf(a.y, v1, o0); o1 = __builtin_fmaf(c.y, v1, o1);
-            o0 = __builtin_fmaf(a.z, v2, o0); o1 = __builtin_fmaf(c.z, v2, o1);
-            o0 = __builtin_fmaf(a.w, v3, o0); o1 = __builtin_fmaf(c.w, v3, o1);
-        }
-        for (int j = L4; j < L; ++j) {
-            const float v = Vs[j * 64 + lane];
-            o0 = __builtin_fmaf(pw[j], v, o0); o1 = __builtin_fmaf(pw[NS * 64 + j], v, o1);
-        }
-        ctx[((size_t)b * L + i0) * (H * 64) + hh * 64 + lane] = o0;
-        if (i0 + 1 < L) ctx[((size_t)b * L + i0 + 1) * (H * 64) + hh * 64 + lane] = o1;
-    }
-}
-
-// backward: d_qkv (B, L, 3, H, 64) from d_ctx (B, L, H*64); probabilities recomputed from lse.
-template <int NS, int LMAX>
-__global__ __launch_bounds__(64 * kAW) void attn_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ ctx,
-                                                            const float *__restrict__ d_ctx, const float *__restrict__ lse,
-                                                            float *__restrict__ d_qkv, int L, int H, float scale) {
-    extern __shared__ float sm[];
-    float *Ks = sm;                              // [L][65]  (lane = key reads a row: padded)
-    float *Vs = Ks + (size_t)L * 65;             // [L][65]
-    float *Pw = Vs + (size_t)L * 65;             // [kAW][2][NS*64]   p and ds of the wave's current row
-    float *Red = Pw + (size_t)kAW * 2 * NS * 64; // [kAW][2][kAW][64] scratch for the dK/dV combine
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
-    const size_t rs = (size_t)3 * H * 64;
-    const float *base = qkv + (size_t)b * L * rs + (size_t)hh * 64;
-    float *dbase = d_qkv + (size_t)b * L * rs + (size_t)hh * 64;
-    for (int i = threadIdx.x; i < L * 64; i += 64 * kAW) {
-        const int r = i >> 6, c = i & 63;
-        Ks[r * 65 + c] = base[(size_t)r * rs + H * 64 + c];
-        Vs[r * 65 + c] = base[(size_t)r * rs + 2 * H * 64 + c];
-    }
-    __syncthreads();
-    float dk[LMAX], dv[LMAX];   // lane = channel d: dK[j][d], dV[j][d] partial sums over this wave's rows
-#pragma unroll
-    for (int j = 0; j < LMAX; ++j) { dk[j] = 0.0f; dv[j] = 0.0f; }
-    float *pw = Pw + wave * (2 * NS * 64);
-    float *dsw = pw + NS * 64;
-    for (int i = wave; i < L; i += kAW) {
-        const float *q = base + (size_t)i * rs;
-        const size_t orow = ((size_t)b * L + i) * (H * 64) + hh * 64;
-        const float *go = d_ctx + orow;               // wave-uniform rows
-        const float lse_i = lse[((size_t)b * H + hh) * L + i];
-        // lane = key: scores, probabilities, dP = dO . v_j
-        float p[NS], dp[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { p[s] = 0.0f; dp[s] = 0.0f; }
-#pragma unroll 8
-        for (int d = 0; d < 64; ++d) {
-            const float qd = q[d], gd = go[d];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int j = min(s * 64 + lane, L - 1);
-                p[s] = __builtin_fmaf(qd, Ks[j * 65 + d], p[s]);
-                dp[s] = __builtin_fmaf(gd, Vs[j * 65 + d], dp[s]);
-            }
-        }
-        float delta = 0.0f;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            p[s] = (s * 64 + lane < L) ? expf(p[s] * scale - lse_i) : 0.0f;
-            delta = __builtin_fmaf(p[s], dp[s], delta);
-        }
-        delta = wave_sum(delta);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            pw[s * 64 + lane] = p[s];
-            dsw[s * 64 + lane] = p[s] * (dp[s] - delta) * scale;   // dS * scale
-        }
-        // lane = channel: dQ_i[d] = sum_j dS_ij k_j[d];  dK[j][d] += dS_ij q_i[d];  dV[j][d] += P_ij dO_i[d]
-        const float qd = q[lane], gd = go[lane];
-        float dq = 0.0f;
-#pragma unroll
-        for (int j = 0; j < LMAX; ++j) {
-            if (j < L) {
-                const float ds = dsw[j], pj = pw[j];
-                dq = __builtin_fmaf(ds, Ks[j * 65 + lane], dq);
-                dk[j] = __builtin_fmaf(ds, qd, dk[j]);
-                dv[j] = __builtin_fmaf(pj, gd, dv[j]);
-            }
-        }
-        dbase[(size_t)i * rs + lane] = dq;
-    }
-    // combine the kAW partial dK / dV through LDS, kAW key rows per round (fixed wave order: deterministic);
-    // wave w of a round finishes key row j0 + w
-#pragma unroll
-    for (int j0 = 0; j0 < LMAX; j0 += kAW) {
-        if (j0 < L) {
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < kAW; ++t) {
-                if (j0 + t < LMAX) {
-                    Red[((wave * 2 + 0) * kAW + t) * 64 + lane] = dk[j0 + t];
-                    Red[((wave * 2 + 1) * kAW + t) * 64 + lane] = dv[j0 + t];
-                }
-            }
-            __syncthreads();
-            const int j = j0 + wave;
-            if (j < L) {
-                float sk = 0.0f, sv = 0.0f;
-#pragma unroll
-                for (int w = 0; w < kAW; ++w) { sk += Red[((w * 2 + 0) * kAW + wave) * 64 + lane]; sv += Red[((w * 2 + 1) * kAW + wave) * 64 + lane]; }
-                dbase[(size_t)j * rs + H * 64 + lane] = sk;
-                dbase[(size_t)j * rs + 2 * H * 64 + lane] = sv;
-            }
-        }
-    }
-}
-
 // h = GELU(z + b) (erf form) of a Linear's bias-free GEMM output z (rows, C), and its backward g_z = g_h * GELU'(z + b).
 // The GEMM runs without its bias epilogue (the bias-free library kernels are 1.5-3 us faster at these shapes) and the
 // bias costs nothing here.  C % 4 == 0.
@@ -507,24 +322,9 @@ __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const float *__restr
                                                      g.w * gelu_der(v.w + bb.w));
 }
 
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
-}
-
 }  // namespace
 
-extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y,
-                             const float *ybias, const float *u, float keep, const float *gamma, const float *beta, float eps, float *xo, float *h,
-                             float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream) {
-    return upp_rowln_fwd_parts(x, add, prompts, mode, P, y, 1, 0, ybias, u, keep, gamma, beta, eps, xo, h, mean, rstd, B, Lin, Lout, D, stream);
-}
-
-extern "C" int upp_rowln_fwd_parts(const float *x, const float *add, const float *prompts, int mode, int P, const float *y, int yparts,
+static int rowln_fwd_impl(const float *x, const float *add, const float *prompts, int mode, int P, const float *y, int yparts,
                                    long long ystride, const float *ybias, const float *u, float keep, const float *gamma, const float *beta,
                                    float eps, float *xo, float *h, float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream) {
     if (yparts < 1 || (yparts > 1 && (!y || ystride < (long long)B * Lin * D))) return UPP_E_BADARG;
@@ -542,19 +342,19 @@ extern "C" int upp_rowln_fwd_parts(const float *x, const float *add, const float
     return upp_launch_status();
 }
 
+extern "C" int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y,
+                             const float *ybias, const float *u, float keep, const float *gamma, const float *beta, float eps, float *xo, float *h,
+                             float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream) {
+    return rowln_fwd_impl(x, add, prompts, mode, P, y, 1, 0, ybias, u, keep, gamma, beta, eps, xo, h, mean, rstd, B, Lin, Lout, D, stream);
+}
+
 extern "C" long long upp_rowln_part_floats(int B, int Lin, int Lout, int D, int mode) {
     if (B < 1 || Lin < 1 || Lout < 1 || D < 1) return 0;
     const int Lg = (mode == 3 || mode == 4) ? Lin : Lout;
     return (long long)((B * Lg + 3) / 4) * 2 * D;
 }
 
-extern "C" int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
-                             const float *gamma, int mode, const float *u, float keep, float *g_x, float *g_prompt,
-                             float *g_y, float *ln_part, int B, int Lin, int Lout, int D, int P, void *stream) {
-    return upp_rowln_bwd_parts(g_xo, g_h, 1, 0, xo, mean, rstd, gamma, mode, u, keep, g_x, g_prompt, g_y, ln_part, B, Lin, Lout, D, P, stream);
-}
-
-extern "C" int upp_rowln_bwd_parts(const float *g_xo, const float *g_h, int gparts, long long gstride, const float *xo, const float *mean,
+static int rowln_bwd_impl(const float *g_xo, const float *g_h, int gparts, long long gstride, const float *xo, const float *mean,
                                    const float *rstd, const float *gamma, int mode, const float *u, float keep, float *g_x, float *g_prompt,
                                    float *g_y, float *ln_part, int B, int Lin, int Lout, int D, int P, void *stream) {
     if (gparts < 1 || (gparts > 1 && (!g_h || gstride < (long long)B * Lout * D))) return UPP_E_BADARG;
@@ -570,6 +370,12 @@ extern "C" int upp_rowln_bwd_parts(const float *g_xo, const float *g_h, int gpar
     return upp_launch_status();
 }
 
+extern "C" int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
+                             const float *gamma, int mode, const float *u, float keep, float *g_x, float *g_prompt,
+                             float *g_y, float *ln_part, int B, int Lin, int Lout, int D, int P, void *stream) {
+    return rowln_bwd_impl(g_xo, g_h, 1, 0, xo, mean, rstd, gamma, mode, u, keep, g_x, g_prompt, g_y, ln_part, B, Lin, Lout, D, P, stream);
+}
+
 extern "C" int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, const float *rstd, float *part,
                                  int rows, int D, int chunks, void *stream) {
     if (!g_h || !xo || !mean || !rstd || !part || rows < 1 || D < 1 || chunks < 1) return UPP_E_BADARG;
@@ -578,63 +384,30 @@ extern "C" int upp_ln_param_grad(const float *g_h, const float *xo, const float 
     return upp_launch_status();
 }
 
-int upp_attn_fwd_mfma(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st);
-int upp_attn_bwd_mfma(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
-                      float scale, hipStream_t st);
+// attention core, head dim 64: qkv (B, L, 3, H, 64); ctx (B, L, H*64); lse (B, H, L).  L <= 96: attn_flash16.hip (operands in registers);
+// L <= 160: attn_long.hip.  (Rounds 1-3 also shipped a VALU pair and the LDS-staged 32x32x2 pair of attn_mfma.hip behind a `variant`
+// argument, for measurements: removed from the library in round 4 -- tools/micro/attn_mfma.hip keeps the latter reproducible.)
 int upp_attn_fwd_long(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st);
 int upp_attn_bwd_long(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
                       float scale, hipStream_t st);
 int upp_attn_fwd_flash16(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st);
-extern "C" int upp_attn_fwd_ex(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, int variant,
-                               void *stream) {
-    if (!qkv || !ctx || !lse || B < 0 || L < 1 || H < 1 || variant < 0 || variant > 2) return UPP_E_BADARG;
-    const bool g_attn_mfma = variant != 1;
-    if (head_dim != 64 || L > 192) return UPP_E_RANGE;
-    if (B == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    if (variant == 0 && L <= 96) return upp_attn_fwd_flash16(qkv, ctx, lse, B, L, H, scale, st);
-    if (g_attn_mfma && L <= 96) return upp_attn_fwd_mfma(qkv, ctx, lse, B, L, H, scale, st);
-    if (g_attn_mfma && L <= 160) return upp_attn_fwd_long(qkv, ctx, lse, B, L, H, scale, st);
-    const int ns = (L + 63) / 64;
-    const size_t lds = ((size_t)L * 64 + (size_t)kAW * 2 * ns * 64) * sizeof(float);
-    dim3 grid(B * H), block(64 * kAW);
-    int rc = 0;
-    if (ns == 1) { rc = set_lds(attn_fwd_kernel<1>, lds); if (!rc) hipLaunchKernelGGL((attn_fwd_kernel<1>), grid, block, lds, st, qkv, ctx, lse, L, H, scale); }
-    else if (ns == 2) { rc = set_lds(attn_fwd_kernel<2>, lds); if (!rc) hipLaunchKernelGGL((attn_fwd_kernel<2>), grid, block, lds, st, qkv, ctx, lse, L, H, scale); }
-    else { rc = set_lds(attn_fwd_kernel<3>, lds); if (!rc) hipLaunchKernelGGL((attn_fwd_kernel<3>), grid, block, lds, st, qkv, ctx, lse, L, H, scale); }
-    return rc ? rc : upp_launch_status();
-}
-
-extern "C" int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, void *stream) {
-    return upp_attn_fwd_ex(qkv, ctx, lse, B, L, H, head_dim, scale, 0, stream);
-}
-
 int upp_attn_bwd_flash16(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L, int H,
                          float scale, hipStream_t st);
-extern "C" int upp_attn_bwd_ex(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L,
-                               int H, int head_dim, float scale, int variant, void *stream) {
-    if (!qkv || !ctx || !d_ctx || !lse || !d_qkv || B < 0 || L < 1 || H < 1 || variant < 0 || variant > 2) return UPP_E_BADARG;
-    const bool g_attn_mfma = variant != 1;
-    if (head_dim != 64 || L > 160 || (!g_attn_mfma && L > 144)) return UPP_E_RANGE;
+extern "C" int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, void *stream) {
+    if (!qkv || !ctx || !lse || B < 0 || L < 1 || H < 1) return UPP_E_BADARG;
+    if (head_dim != 64 || L > 160) return UPP_E_RANGE;
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (variant == 0 && L <= 96) return upp_attn_bwd_flash16(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
-    if (g_attn_mfma && L <= 96) return upp_attn_bwd_mfma(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
-    if (g_attn_mfma && L <= 160) return upp_attn_bwd_long(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
-    const int ns = (L + 63) / 64;
-    const size_t lds = ((size_t)2 * L * 65 + (size_t)kAW * 2 * ns * 64 + (size_t)2 * kAW * kAW * 64) * sizeof(float);
-    dim3 grid(B * H), block(64 * kAW);
-    int rc = 0;
-    if (L <= 64) { rc = set_lds(attn_bwd_kernel<1, 64>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<1, 64>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
-    else if (L <= 80) { rc = set_lds(attn_bwd_kernel<2, 80>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<2, 80>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
-    else if (L <= 128) { rc = set_lds(attn_bwd_kernel<2, 128>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<2, 128>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
-    else { rc = set_lds(attn_bwd_kernel<3, 144>, lds); if (!rc) hipLaunchKernelGGL((attn_bwd_kernel<3, 144>), grid, block, lds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale); }
-    return rc ? rc : upp_launch_status();
+    return L <= 96 ? upp_attn_fwd_flash16(qkv, ctx, lse, B, L, H, scale, st) : upp_attn_fwd_long(qkv, ctx, lse, B, L, H, scale, st);
 }
 
 extern "C" int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv, int B, int L,
                             int H, int head_dim, float scale, void *stream) {
-    return upp_attn_bwd_ex(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, head_dim, scale, 0, stream);
+    if (!qkv || !ctx || !d_ctx || !lse || !d_qkv || B < 0 || L < 1 || H < 1) return UPP_E_BADARG;
+    if (head_dim != 64 || L > 160) return UPP_E_RANGE;
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    return L <= 96 ? upp_attn_bwd_flash16(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st) : upp_attn_bwd_long(qkv, ctx, d_ctx, lse, d_qkv, B, L, H, scale, st);
 }
 
 extern "C" int upp_bias_gelu_fwd(const float *z, const float *bias, float *h, long long rows, int C, void *stream) {

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
                              UPP_DPP("row_mirror") UPP_SEL("e5", "k5") UPP_SEL("e4", "k4")
                              UPP_DPPB("row_bcast:15 row_mask:0xa") UPP_SEL("e3", "k3") UPP_SEL("e2", "k2")
                              UPP_DPPB("row_bcast:31 row_mask:0xc") UPP_SEL("e1", "k1") UPP_SEL("e0", "k0")
-                             : [v] "+v"(v), [bk] "+v"(bk), [e0] "=&s"(e0), [e1] "=&s"(e1), [e2] "=&s"(e2), [e3] "=&s"(e3), [e4] "=&s"(e4), [e5] "=&s"(e5)
+                             : [v] "+&v"(v), [bk] "+&v"(bk), [e0] "=&s"(e0), [e1] "=&s"(e1), [e2] "=&s"(e2), [e3] "=&s"(e3), [e4] "=&s"(e4), [e5] "=&s"(e5)
                              : [b] "v"(best), [d0] "v"(d2[0]), [d1] "v"(d2[1]), [d2] "v"(d2[2]), [d3] "v"(d2[3]), [d4] "v"(d2[S > 4 ? 4 : 0]),
                                [d5] "v"(d2[S > 5 ? 5 : 0]), [k0] "v"(kk[0]), [k1] "v"(kk[1]), [k2] "v"(kk[2]), [k3] "v"(kk[3]),
                                [k4] "v"(kk[S > 4 ? 4 : 0]), [k5] "v"(kk[S > 5 ? 5 : 0]));
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
                              UPP_DPP("row_mirror") UPP_SEL("e1", "k1") UPP_SEL("e0", "k0")
                              UPP_DPPB("row_bcast:15 row_mask:0xa") "s_nop 1\n\t"
                              UPP_DPPB("row_bcast:31 row_mask:0xc") "s_nop 1\n\t"
-                             : [v] "+v"(v), [bk] "+v"(bk), [e0] "=&s"(e0), [e1] "=&s"(e1), [e2] "=&s"(e2), [e3] "=&s"(e3)
+                             : [v] "+&v"(v), [bk] "+&v"(bk), [e0] "=&s"(e0), [e1] "=&s"(e1), [e2] "=&s"(e2), [e3] "=&s"(e3)
                              : [b] "v"(best), [d0] "v"(d2[0]), [d1] "v"(d2[1]), [d2] "v"(d2[2]), [d3] "v"(d2[3]), [k0] "v"(kk[0]), [k1] "v"(kk[1]),
                                [k2] "v"(kk[2]), [k3] "v"(kk[3]));
                 (void)e4; (void)e5;

@@ -320,7 +320,10 @@ __global__ __launch_bounds__(256) void rectify_select_kernel(const float *__rest
     extern __shared__ float sc[];
     const int b = blockIdx.y;
     const float *s = score + (size_t)b * N;
-    for (int i = threadIdx.x; i < N; i += 256) sc[i] = s[i];
+    // (a NaN score compares false to everything: every NaN point would get the rank of the largest score and collide with it, leaving
+    // slots of `order` / `out` unwritten.  torch.argsort -- the reference, models/Point_MAE_unify.py:553-559 -- sorts NaN as the LARGEST
+    // value: NaN -> +inf here, ties in index order like every other tie, so the ranks stay a permutation.)
+    for (int i = threadIdx.x; i < N; i += 256) { const float v = s[i]; sc[i] = v != v ? __builtin_inff() : v; }
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;

@@ -35,7 +35,7 @@ namespace {
 
 #include "linear_shared.h"
 
-template <int BMB, int BNB, int KS, int KC, bool TAIL, bool PARTS = false>
+template <int BMB, int BNB, int KS, int KC, bool TAIL>
 __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g) {
     constexpr int NW = BMB * BNB * KS, BM = BMB * 32, BN = BNB * 32;
     constexpr int ROWS = (BM + BN) * KS * KC;       // 128-byte row images per stage: [ks][kc][A rows | W rows]
@@ -55,15 +55,9 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     const int nwg = gridDim.x;
     const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, rem = nwg & 7;
     const int lin = (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (orig >> 3);
-    // row-panel order; with the contraction cut over workgroups (PARTS): row panel, then k-part, then column tile -- neighbours share the
-    // A rows AND the k-range of their row panel.  A separate instantiation: the three runtime divisions and the per-part pointers cost the
-    // whole-contraction kernels 5-15 % when compiled into them (fc2 at 2,400 rows 29.7 -> 34.2 us, measured on one box).
-    const int per_panel = PARTS ? g.tiles_n * g.kparts : g.tiles_n;
-    const int by = lin / per_panel, rem_p = lin - by * per_panel;
-    const int kp = PARTS ? rem_p / g.tiles_n : 0, bx = PARTS ? rem_p - kp * g.tiles_n : rem_p;
+    const int by = lin / g.tiles_n, bx = lin - by * g.tiles_n;       // row-panel order: neighbours share the A rows of their panel
     const int m0 = by * BM, n0 = bx * BN;
     const int M = g.M, N = g.N;
-    const int Kc = PARTS ? g.K / g.kparts : g.K;                     // (PARTS: a whole number of k-stages, checked by the host)
     const int ks = wave / (BMB * BNB), wb = wave - ks * (BMB * BNB);
     const int bm = wb / BNB, bn = wb - bm * BNB;
 
@@ -71,7 +65,7 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     // Everything that depends on t only (sub-image, A or W, first row) is wave-uniform: scalar code, few VALU instructions.
     const float *src[TPW];
     int koff[TAIL ? TPW : 1];                                          // (TAIL) k of the lane's granule inside a k-stage
-    const int nsc = TAIL ? (g.K + 32 * KS * KC - 1) / (32 * KS * KC) : Kc / (32 * KS * KC);
+    const int nsc = TAIL ? (g.K + 32 * KS * KC - 1) / (32 * KS * KC) : g.K / (32 * KS * KC);
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int t = wave + q * NW;
@@ -84,7 +78,7 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
         const int row = min(first + (lane >> 3), last);
         const int ko = sk * 32 + 4 * ((lane & 7) ^ (((rho0 >> 1) + (lane >> 4)) & 7));
         if constexpr (TAIL) koff[q] = ko;
-        src[q] = PARTS ? base + row * ld + ko + kp * Kc : base + row * ld + ko;
+        src[q] = base + row * ld + ko;
     }
     static_assert(KC != 1 || TPW <= 6, "DMA slots of the interleaved schedule");
     auto issue1 = [&](int q, int stage, int c) {            // q-th DMA instruction of this wave for k-stage c
@@ -205,7 +199,6 @@ __global__ __launch_bounds__(BMB *BNB *KS * 64) void linear_f32_kernel(LinArgs g
     const int T0 = ks * TN;
     const int rb = m0 + bm * 32, cb = n0 + bn * 32;                         // (scalar) block origin
     const bool wide = ((g.ldc | N | g.ldaux) & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.aux)) & 15) == 0;
-    if constexpr (PARTS) g.C += kp * g.part_stride;                  // (this workgroup's partial output)
     if (wide) {
         __syncthreads();                                     // all fragment reads done: the stages may be overwritten
         float *red = reinterpret_cast<float *>(lds);
@@ -311,15 +304,7 @@ int launch_linear(const LinArgs &g0, hipStream_t st) {
     LinArgs g = g0;
     const int tiles_m = (g.M + BMB * 32 - 1) / (BMB * 32);
     g.tiles_n = (g.N + BNB * 32 - 1) / (BNB * 32);
-    if (g.kparts < 1) g.kparts = 1;
-    const dim3 grid((unsigned)(tiles_m * g.tiles_n * g.kparts));
-    if constexpr (KS == 1) {                                 // (only whole-contraction-per-wave tiles are cut over workgroups: pick_parts)
-        if (g.kparts > 1) {
-            if (g.ktail) return UPP_E_RANGE;
-            hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC, false, true>), grid, dim3(BMB * BNB * KS * 64), 0, st, g);
-            return upp_launch_status();
-        }
-    } else if (g.kparts > 1) return UPP_E_RANGE;
+    const dim3 grid((unsigned)(tiles_m * g.tiles_n));
     if (g.ktail) hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC, true>), grid, dim3(BMB * BNB * KS * 64), 0, st, g);
     else hipLaunchKernelGGL((linear_f32_kernel<BMB, BNB, KS, KC, false>), grid, dim3(BMB * BNB * KS * 64), 0, st, g);
     return upp_launch_status();
@@ -355,10 +340,8 @@ int pick_config(int M, int N, int K) {
         else cost = 1000000000LL + quarters * 1000000LL + traffic * 1000LL;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
     }
-    // (2,2,2,64) -- the same 64 x 64 tile with the contraction split 2 ways, k-stages of 64 -- is compiled and can be forced, but is
-    // never chosen: stand-alone it is 3-7 % faster than (2,2,4,128) (10.1 vs 10.9 us at K = 384, 28.9 vs 30.2 at K = 1536), in the
-    // pipelined step it costs 0.28 ms (5.71 vs 5.43 ms per step, measured twice): with 64 KB of LDS instead of 128 KB a workgroup of
-    // the other stream's GEMM moves onto the same CU and the two share its matrix pipe and L2 slice instead of taking turns.
+    // ((2,2,2,64) -- the 64 x 64 tile with the contraction split 2 ways -- is never the one-round choice: 64 KB of LDS lets a workgroup of the
+    // other stream's GEMM onto the same CU, measured 0.28 ms slower per pipelined step; pick_multi_round takes it for 4,000 ... 4,500 rows)
     return best;
 }
 
@@ -411,33 +394,6 @@ int pick_code(int M, int N, int K) {
     const int mb = (M + 31) / 32, nb = (N + 31) / 32;
     const long long wgs = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
     return wgs <= 256 ? config_code(c) : pick_multi_round(M, N, K);
-}
-
-// Narrow outputs over a long contraction (fc2, the data gradients of fc1 and qkv: N = 384, K = 1152 ... 1536 at 1,120 ... 4,448 rows): one
-// round of 256 workgroups needs 64 x 64 tiles with the contraction split over the wave groups of a workgroup -- 128 staged rows per 4
-// blocks, four LDS-DMA instructions per wave and 16 MFMAs: measured 68 % MFMA duty in the k-loop (fc2 at M = 2400: 71,700 cycles for
-// 49,152 of MFMA issue) against 98 % for the 128 x 128 tile of fc1.  Cutting the contraction over WORKGROUPS instead keeps the big tile:
-// (tiles x parts) workgroups, each a 128 x 128 (or 128 x 96) tile over K / parts, writing its own partial output; the kernel that consumes
-// the result adds the parts in order while it reads them (row kernels, block tail: a few MB from L2).  -> (parts, tile code) or parts = 1.
-int pick_parts(int M, int N, int K, int *tile_out) {
-    const int i0 = pick_config(M, N, K);
-    if (i0 < 0 || kConfigs[i0].ks == 1) return 1;                  // the one-round choice keeps the contraction whole: nothing to gain
-    const int mb = (M + 31) / 32, nb = (N + 31) / 32;
-    long long best_cost = 0;
-    int best_p = 1, best_tile = 0;
-    for (int i = 0; i < kNumConfigs; ++i) {
-        const LinConfig c = kConfigs[i];
-        if (c.ks != 1) continue;
-        const long long tiles = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
-        for (int p = 2; p <= 8; ++p) {
-            if (K % (p * 32 * c.kc) || tiles * p > 256 || tiles * p < 160) continue;
-            const long long ksteps = K / p / 32;                                      // 32-wide k-steps per wave
-            const long long cost = ksteps * ((c.bmb * c.bnb + 3) / 4) * 1000 + (256 - tiles * p) + p * 4;   // MFMAs per SIMD, then fill, then few parts
-            if (best_p == 1 || cost < best_cost) { best_cost = cost; best_p = p; best_tile = config_code(c); }
-        }
-    }
-    if (best_p > 1 && tile_out) *tile_out = best_tile;
-    return best_p;
 }
 
 }  // namespace
@@ -501,40 +457,4 @@ extern "C" int upp_linear_group_bias_f32(const float *A, long long lda, const fl
     g.stamps = g_lin_stamps;
 #endif
     return upp_detail_linear_rt(&g, tile, (hipStream_t)stream);
-}
-
-extern "C" int upp_linear_parts(int M, int N, int K) {
-    if (M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
-    if (K % 4 != 0) return UPP_E_RANGE;
-    if (pick_rt(M, N, K)) return 1;
-    return pick_parts(M, N, K, nullptr);
-}
-
-extern "C" int upp_linear_parts_f32(const float *A, long long lda, const float *W, long long ldw, float *C, long long ldc, long long part_stride,
-                                    int M, int N, int K, int parts, void *stream) {
-    if (!A || !W || !C || M < 1 || N < 1 || K < 1 || parts < 1) return UPP_E_BADARG;
-    if (parts == 1) return upp_linear_f32(A, lda, W, ldw, nullptr, C, ldc, nullptr, 0, M, N, K, LEPI_NONE, 0, stream);
-    if (K % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0 || lda < K || ldw < K || ldc < N || part_stride < (long long)M * ldc) return UPP_E_RANGE;
-    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return UPP_E_RANGE;
-    if (ldc > (1LL << 24)) return UPP_E_RANGE;
-    int tile = 0;
-    if (pick_parts(M, N, K, &tile) != parts) {                     // a forced part count (tests, measurements): the widest tile that divides
-        tile = 0;
-        for (int i = 0; i < kNumConfigs && !tile; ++i)
-            if (kConfigs[i].ks == 1 && K % (parts * 32 * kConfigs[i].kc) == 0) tile = config_code(kConfigs[i]);
-        if (!tile) return UPP_E_RANGE;
-    }
-    LinArgs g{};
-    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.epi = LEPI_NONE;
-    g.kparts = parts; g.part_stride = part_stride;
-#ifdef UPP_LIN_STAMPS
-    g.stamps = g_lin_stamps;
-#endif
-    hipStream_t st = (hipStream_t)stream;
-#define UPP_LIN_CASE(a, b, c, d) case a * 4096 + b * 256 + c * 16 + d: return launch_linear<a, b, c, d>(g, st);
-    switch (tile) {
-        UPP_LIN_CONFIGS(UPP_LIN_CASE)
-        default: return UPP_E_RANGE;
-    }
-#undef UPP_LIN_CASE
 }

@@ -20,7 +20,6 @@ struct LinArgs {
     int tiles_n;                  // workgroup tiles along N
     int epi;
     int ktail;                    // K is not a multiple of the k-stage: the last stage reads zeros beyond K (K % 4 == 0)
-    int kparts; long long part_stride;   // linear.hip: the contraction cut into kparts runs over WORKGROUPS, part p -> C + p * part_stride
     int bias_shift;               // linear_rt.hip, > 0: bias is a (M >> bias_shift, N) matrix, row m takes row m >> bias_shift of it (a bias
                                   // per GROUP of 2^bias_shift >= 32 rows: the per-sample term of the segmentation head, the per-group
                                   // half of the patch embedding's 512 -> 512 layer)

@@ -165,11 +165,9 @@ class _RowLN(Function):
     One kernel forward, one backward (+ one for trainable LayerNorm parameters).  See upp_rowln_fwd."""
 
     @staticmethod
-    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps, cls_add=None, ybias=None, h_parts=1):
+    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps, cls_add=None, ybias=None):
         x = x.contiguous()
         B, Lin, D = x.shape
-        ctx.y_parts = y.shape[0] if (y is not None and y.dim() == 4) else 0          # y given as k-parts (linear_parts): added while read
-        ctx.h_parts = int(h_parts) if gamma is not None else 1
         Lout = Lin + P if mode in (ROW_INSERT_CLS, ROW_INSERT) else (Lin - P if mode in (ROW_STRIP_CLS, ROW_STRIP) else Lin)
         add_c = add.contiguous() if add is not None else None
         y_c = y.contiguous() if y is not None else None
@@ -182,9 +180,7 @@ class _RowLN(Function):
         ctx.cls_shape = tuple(cls_add.shape) if cls_add is not None else None
         if gamma is None:
             return xo, xo.new_empty(0)
-        # h_parts > 1: the LayerNorm output leaves as an expanded (h_parts, B, Lout, D) view, so that the Linear that consumes it can hand
-        # its data gradient back AS h_parts k-parts (upp_linear_parts_f32) -- shapes agree, and this backward adds them while it reads
-        return xo, (h if ctx.h_parts == 1 else h.unsqueeze(0).expand(ctx.h_parts, B, Lout, D))
+        return xo, h
 
     @staticmethod
     def backward(ctx, g_xo, g_h):
@@ -195,7 +191,7 @@ class _RowLN(Function):
         g_xo = g_xo.contiguous() if g_xo is not None else None
         g_hc = g_h.contiguous() if (has_ln and g_h is not None) else None
         if g_xo is None and g_hc is None:
-            return (None,) * 14
+            return (None,) * 13
         strip = mode in (ROW_STRIP_CLS, ROW_STRIP) and P > 0
         need_cls = ctx.cls_shape is not None and len(need) > 11 and need[11]
         need_ln = has_ln and g_hc is not None and (need[4] or need[5])
@@ -216,17 +212,13 @@ class _RowLN(Function):
             _, g_prompts = _DEFERRED.reduce(p_prompts, g_p.view(B, P * D), 0, P * D)
             if g_prompts is not None:
                 g_prompts = g_prompts.view(P, D)
-        if g_y is not None and ctx.y_parts:
-            g_y = g_y.unsqueeze(0).expand(ctx.y_parts, B, Lin, D)          # d (sum of the parts) / d part = 1
         return (g_x if need[0] else None, g_x if (has_add and need[1]) else None, g_prompts, g_y,
-                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None, g_cls, None, None)
+                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None, g_cls, None)
 
 
 def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDENTITY, P=0, u=None, keep=1.0, eps=1e-5, cls_add=None,
-          ybias=None, h_parts=1):
+          ybias=None):
     """-> (rows (B,Lout,D), LayerNorm(rows) or None).  mode / P: see ROW_* and upp_rowln_fwd.
-    y may carry a leading k-parts dimension (the output of linear(..., out_parts=True)): the parts are added while they are read.
-    h_parts > 1: the LayerNorm output is returned as an expanded (h_parts, B, Lout, D) view for a consumer called with x_parts=h_parts.
     ybias: optional (D) frozen bias added to y (the Linear that produced y then runs its GEMM bias-free).
     cls_add: optional (1,1,D) parameter that `add` (passed detached) carries in its row 0 for every sample; its gradient
     (batch sum of the row-0 input gradient) is produced here instead of through a (B,L,D) gradient of `add`."""
@@ -234,7 +226,7 @@ def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDE
         raise ValueError("cls_add needs a detached `add` and a row map that keeps source row 0 in place")
     if ybias is not None and (y is None or (torch.is_grad_enabled() and ybias.requires_grad)):
         raise ValueError("ybias is the frozen bias of the Linear that produced y")
-    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps), cls_add, ybias, int(h_parts))
+    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps), cls_add, ybias)
     return xo, (h if gamma is not None else None)
 
 
@@ -242,24 +234,24 @@ class _Attention(Function):
     """ctx = softmax(q k^T * scale) v from the packed qkv projection (B, L, 3*H*64)."""
 
     @staticmethod
-    def forward(ctx, qkv, num_heads, scale, variant=0):
+    def forward(ctx, qkv, num_heads, scale):
         qkv = qkv.contiguous()
         B, L, _ = qkv.shape
-        out, lse = ops.attn_fwd(qkv, B, L, num_heads, scale, variant)
+        out, lse = ops.attn_fwd(qkv, B, L, num_heads, scale)
         ctx.save_for_backward(qkv, out, lse)
-        ctx.meta = (B, L, num_heads, scale, variant)
+        ctx.meta = (B, L, num_heads, scale)
         return out
 
     @staticmethod
     def backward(ctx, g):
         qkv, out, lse = ctx.saved_tensors
-        B, L, H, scale, variant = ctx.meta
-        return ops.attn_bwd(qkv, out, g.contiguous(), lse, B, L, H, scale, variant), None, None, None
+        B, L, H, scale = ctx.meta
+        return ops.attn_bwd(qkv, out, g.contiguous(), lse, B, L, H, scale), None, None
 
 
-def attention(qkv, num_heads, scale, variant=0):
-    """variant 0: the library's kernel choice (FP32 MFMA where it applies); 1: the VALU kernels (tests / measurements)."""
-    return _Attention.apply(qkv, int(num_heads), float(scale), int(variant))
+def attention(qkv, num_heads, scale):
+    """softmax(q k^T scale) v per head on the FP32-MFMA attention kernels (L <= 96: attn_flash16.hip, L <= 160: attn_long.hip)."""
+    return _Attention.apply(qkv, int(num_heads), float(scale))
 
 
 # ------------------------------------------------------------------ deferred parameter-gradient sums
@@ -487,67 +479,33 @@ class _LinearMFMA(Function):
     (not on the PEFT hot path: the Transformer weights are frozen there); a trainable bias takes the deferred column sum."""
 
     @staticmethod
-    def forward(ctx, x, w, b, own_wgrad=False, x_parts=0, out_parts=False):
-        # x_parts: x is the expanded (x_parts, ..., K) view a rowln(..., h_parts) returned: row 0 is the operand, and the data gradient goes
-        # back as x_parts k-parts.  out_parts: the output is (parts, ..., N), the contraction cut over workgroups (no bias).
-        xin = x[0] if x_parts else x
-        ctx.save_for_backward(xin if w.requires_grad else None, w)
+    def forward(ctx, x, w, b, own_wgrad=False):
+        ctx.save_for_backward(x if w.requires_grad else None, w)
         ctx.bias_ptr = b.data_ptr() if b is not None else 0
         ctx.own_wgrad = own_wgrad
-        ctx.x_parts, ctx.out_parts = int(x_parts), bool(out_parts)
-        if out_parts:
-            return ops.linear_parts(xin, w)
-        return _lin(xin, w, b, ops.LIN_BIAS if b is not None else ops.LIN_NONE)
+        return _lin(x, w, b, ops.LIN_BIAS if b is not None else ops.LIN_NONE)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        if ctx.out_parts:
-            g = _one_of_equal_parts(g)
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            if ctx.x_parts:
-                gx = ops.linear_parts(g2, _wt(w), ctx.x_parts).view((ctx.x_parts,) + g.shape[:-1] + (w.shape[1],))
-            elif w.shape[0] % 4 == 0 and g2.stride(0) % 4 == 0:
+            if w.shape[0] % 4 == 0 and g2.stride(0) % 4 == 0:
                 gx = _lin(g2, w, dgrad=True).view(g.shape[:-1] + (w.shape[1],))
             elif w.shape[0] <= 64 and w.shape[1] <= 256:
                 # a narrow layer (the 64 -> 3 score head of the denoising prompter): the data gradient contracts over its few outputs
                 gx = ops.linear_smallk(g2, _wt(w), None, 0).view(g.shape[:-1] + (w.shape[1],))
             else:
-                note_declined("linear data gradient", "N = %d is not a multiple of 4" % wt.shape[1])
+                note_declined("linear data gradient", "N = %d is not a multiple of 4" % w.shape[0])
                 gx = torch.mm(g2, w).view(g.shape[:-1] + (w.shape[1],))
         if ctx.needs_input_grad[1]:
             gw = weight_grad(g2, x.reshape(-1, x.shape[-1]), w, ctx.own_wgrad)
         if b_needed(ctx):
             _, gb = _DEFERRED.reduce(ctx.bias_ptr, g2, 0, g2.shape[1])
-        return gx, gw, gb, None, None, None
-
-
-def _one_of_equal_parts(g):
-    """Gradient w.r.t. a (parts, ...) output whose consumers all take the SUM of the parts (row kernels, block tail, .sum(0)): every part
-    receives the same gradient, normally as an expanded view (stride 0).  A materialised tensor is checked once per shape in eager mode."""
-    if g.stride(0) != 0 and not torch.cuda.is_current_stream_capturing():
-        key = tuple(g.shape)
-        if key not in _checked_parts:
-            _checked_parts.add(key)
-            if not all(torch.equal(g[0], g[p]) for p in range(1, g.shape[0])):
-                raise RuntimeError("a k-parts output (linear(..., out_parts=True)) was consumed by something that does not sum its parts")
-    return g[0]
-
-
-_checked_parts = set()
-
-
-def dx_parts(x, weight, rows=None):
-    """How many k-parts the data gradient of y = x . weight^T is cut into (1: not at all): the h_parts / x_parts of the rowln -> linear pair.
-    rows: the row count of the product when it differs from x's (a row map that inserts prompts in between)."""
-    if not (x.is_cuda and torch.is_grad_enabled() and x.requires_grad and linear_usable(x, weight) and weight.shape[0] % 4 == 0):
-        return 1
-    rows = x.numel() // x.shape[-1] if rows is None else int(rows)
-    return ops.linear_parts_choice(rows, weight.shape[1], weight.shape[0])          # (M, K) output, contraction over the N outputs
+        return gx, gw, gb, None
 
 
 def weight_grad(g2, x2, w, own=False):
@@ -676,21 +634,12 @@ def _act_torch(y, act):
     return y if act is None else (F.relu(y) if act == 'relu' else F.gelu(y))
 
 
-def linear(x, weight, bias=None, own_wgrad=False, act=None, x_parts=0, out_parts=False):
+def linear(x, weight, bias=None, own_wgrad=False, act=None):
     """act(F.linear(x, weight, bias)) on this library's kernels: upp_linear_f32 (FP32 matrix cores) for 16-byte aligned rows and
     K % 4 == 0, upp_linear_smallk_f32 (K <= 64, N <= 256, forward only) for the rest; otherwise the library GEMM (said once under
     UPP_VERBOSE).  act: None / 'relu' / 'gelu' (erf) -- fused into the epilogue when nothing needs a gradient, applied by torch
     otherwise.  own_wgrad: kept for callers of round 2 (every weight gradient is ours now, whatever the row count)."""
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))
-    if x_parts or out_parts:
-        # k-parts protocol (see rowln / _LinearMFMA): x_parts = x is the expanded view of rowln(..., h_parts); out_parts = return
-        # (parts, ..., N) partial products for a consumer that adds them while it reads (rowln / ln_adapter `y`)
-        if act is not None or (out_parts and bias is not None) or not linear_usable(x[0] if x_parts else x, weight):
-            raise ValueError("linear: k-parts need a servable f32 HIP operand, no activation and (out_parts) no bias")
-        if not needs_grad:
-            xin = x[0] if x_parts else x
-            return ops.linear_parts(xin, weight) if out_parts else ops.linear_f32(xin, weight, bias, ops.LIN_BIAS if bias is not None else ops.LIN_NONE, frozen=not weight.requires_grad)
-        return _LinearMFMA.apply(x, weight, bias, bool(own_wgrad), int(x_parts), bool(out_parts))
     if (x.is_cuda and weight.dim() == 2 and weight.dtype == torch.float32 and weight.shape[1] % 4 == 0 and weight.shape[1] > 64
             and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16)):
         # a column window of a wider weight whose rows start off a 16-byte boundary (w[:, 3:] of the (1536, 1155) first layer of the
@@ -738,33 +687,24 @@ class _MlpGelu(Function):
     dW2 = g^T hid, dW1 = g_z^T x, db1 = column sum of g_z, db2 = column sum of g follow weight_grad / the deferred sums."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2=None, x_parts=0, out_parts=False):
-        xin = x[0] if x_parts else x            # (k-parts protocol: see _LinearMFMA)
-        hid, d = _lin(xin, w1, b1, ops.LIN_BIAS_GELU_D)
+    def forward(ctx, x, w1, b1, w2, b2=None):
+        hid, d = _lin(x, w1, b1, ops.LIN_BIAS_GELU_D)
         train = w1.requires_grad or w2.requires_grad or b1.requires_grad
-        ctx.save_for_backward(d, w1, w2, xin if train else None, hid if w2.requires_grad else None)
+        ctx.save_for_backward(d, w1, w2, x if train else None, hid if w2.requires_grad else None)
         ctx.bias_ptrs = (b1.data_ptr(), b2.data_ptr() if b2 is not None else 0)
-        ctx.x_parts, ctx.out_parts = int(x_parts), bool(out_parts)
-        if out_parts:
-            return ops.linear_parts(hid, w2)
         return _lin(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE)
 
     @staticmethod
     def backward(ctx, g):
         d, w1, w2, x, hid = ctx.saved_tensors
         need = ctx.needs_input_grad
-        if ctx.out_parts:
-            g = _one_of_equal_parts(g)
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         g_z = _lin(g2, w2, None, ops.LIN_MUL, aux=d.view(-1, d.shape[-1]), dgrad=True)
         gx = None
         if need[0]:
-            if ctx.x_parts:
-                gx = ops.linear_parts(g_z, _wt(w1), ctx.x_parts).view((ctx.x_parts,) + g.shape[:-1] + (w1.shape[1],))
-            else:
-                gx = _lin(g_z, w1, dgrad=True).view(g.shape[:-1] + (w1.shape[1],))
+            gx = _lin(g_z, w1, dgrad=True).view(g.shape[:-1] + (w1.shape[1],))
         gw1 = gb1 = gw2 = gb2 = None
         if need[1]:
             gw1 = weight_grad(g_z, x.reshape(-1, x.shape[-1]), w1)
@@ -774,19 +714,16 @@ class _MlpGelu(Function):
             gw2 = weight_grad(g2, hid.reshape(-1, hid.shape[-1]), w2)
         if len(need) > 4 and need[4]:
             _, gb2 = _DEFERRED.reduce(ctx.bias_ptrs[1], g2, 0, g2.shape[1])
-        return gx, gw1, gb1, gw2, gb2, None, None
+        return gx, gw1, gb1, gw2, gb2
 
 
-def mlp_gelu(x, w1, b1, w2, b2=None, x_parts=0, out_parts=False):
-    """fc2(GELU(fc1(x) + b1)) (+ b2); both GEMMs and the activation on upp_linear_f32.  x_parts / out_parts: the k-parts protocol of
-    linear() for the input (expanded view of rowln(..., h_parts)) and for the fc2 output (consumed by rowln / ln_adapter as `y`)."""
-    if out_parts and b2 is not None:
-        raise ValueError("mlp_gelu: out_parts leaves the fc2 bias to the consumer (ybias)")
+def mlp_gelu(x, w1, b1, w2, b2=None):
+    """fc2(GELU(fc1(x) + b1)) (+ b2); both GEMMs and the activation on the Linear kernels (split-bf16 for frozen / managed weights)."""
     if not torch.is_grad_enabled() or not (x.requires_grad or w1.requires_grad or w2.requires_grad or b1.requires_grad
                                            or (b2 is not None and b2.requires_grad)):
-        hid = ops.linear_f32(x[0] if x_parts else x, w1, b1, ops.LIN_BIAS_GELU, frozen=not w1.requires_grad)
-        return ops.linear_parts(hid, w2) if out_parts else ops.linear_f32(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE, frozen=not w2.requires_grad)
-    return _MlpGelu.apply(x, w1, b1, w2, b2, int(x_parts), bool(out_parts))
+        hid = ops.linear_f32(x, w1, b1, ops.LIN_BIAS_GELU, frozen=not w1.requires_grad)
+        return ops.linear_f32(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE, frozen=not w2.requires_grad)
+    return _MlpGelu.apply(x, w1, b1, w2, b2)
 
 
 # ------------------------------------------------------------------ prompt propagation
@@ -1180,7 +1117,6 @@ class _LnAdapter(Function):
         ctx.save_for_backward(xo, mean, rstd, gamma, beta, u, s1, W1, W2, ud)
         ctx.dims = (B, Lin, Lout, D, P, mode)
         ctx.meta = (keep, pd, scale, y is not None)
-        ctx.y_parts = y.shape[0] if (y is not None and y.dim() == 4) else 0
         ctx.param_ptrs = (gamma.data_ptr(), beta.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr())
         return out
 
@@ -1213,8 +1149,6 @@ class _LnAdapter(Function):
             _, gb2 = _DEFERRED.reduce(pb2, part, 2 * H * D + H, D)
             gW1 = gW1.view(H, D) if gW1 is not None else None
             gW2 = gW2.view(D, H) if gW2 is not None else None
-        if g_y is not None and ctx.y_parts:
-            g_y = g_y.unsqueeze(0).expand(ctx.y_parts, B, Lin, D)
         return (g_x if need[0] else None, g_y, None, None, None, None, None, g_gamma if need[7] else None, g_beta if need[8] else None,
                 None, gW1 if need[10] else None, gb1 if need[11] else None, gW2 if need[12] else None, gb2 if need[13] else None,
                 None, None, None)

@@ -43,7 +43,9 @@ def _call(dev, name, *args):
 
 # ------------------------------------------------------------------ FPS / gather
 def fps(xyz, npoint, want_centers=False, waves=0):
-    """(B,N,3) f32 -> idx (B,npoint) int32 [, centers (B,npoint,3)].  waves: wavefronts per cloud (0 = the library's choice)."""
+    """(B,N,3) f32 -> idx (B,npoint) int32 [, centers (B,npoint,3)].  waves: wavefronts per cloud (0 = the library's choice).
+    Precondition: finite coordinates (include/upp_hip.h upp_fps: with a NaN in a cloud the indices stay in range but need not be the
+    reference kernel's; not checked here -- a check would be a host synchronisation on the hot path)."""
     _need(xyz, "xyz", torch.float32, 3, 3)
     B, N, _ = xyz.shape
     npoint = int(npoint)
@@ -429,33 +431,6 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None, f
     return (out, d) if epilogue == LIN_BIAS_GELU_D else out
 
 
-def linear_parts_choice(M, N, K):
-    """The library's number of k-parts for an (M,K) x (N,K)^T product (1 = keep the contraction whole): upp_linear_parts."""
-    return max(1, int(_abi.load().upp_linear_parts(int(M), int(N), int(K))))
-
-
-def linear_parts(a, w, parts=None):
-    """(parts, ..., N) partial products of a (..., K) . w (N, K)^T, the contraction cut into `parts` runs over workgroups (upp_linear_parts_f32);
-    sum over dim 0 = the product.  parts=None: the library's choice."""
-    if not (isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1):
-        raise RuntimeError("w must be a 2-D f32 HIP (cuda) matrix with contiguous rows; upp_hip has no CPU path")
-    if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == torch.float32):
-        raise RuntimeError("a must be a f32 HIP (cuda) tensor; upp_hip has no CPU path")
-    _same_device(a, w)
-    K, N = a.shape[-1], w.shape[0]
-    if w.shape[1] != K:
-        raise RuntimeError(f"linear_parts: a (...,{K}) against w {tuple(w.shape)}")
-    a2 = a.reshape(-1, K)
-    if a2.stride(1) != 1 or a2.stride(0) % 4 != 0 or a2.data_ptr() % 16 != 0:
-        a2 = a2.contiguous()
-    M = a2.shape[0]
-    if parts is None:
-        parts = linear_parts_choice(M, N, K)
-    out = torch.empty((int(parts),) + tuple(a.shape[:-1]) + (N,), dtype=torch.float32, device=a.device)
-    _call(a.device, "upp_linear_parts_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(out), N, M * N, M, N, K, int(parts))
-    return out
-
-
 def colsum_partials(part, offset, length, chunks=None):
     """(chunks, length) partial column sums of columns [offset, offset + length) of the tall 2-D matrix `part` (upp_colsum_partials)."""
     if not (isinstance(part, torch.Tensor) and part.is_cuda and part.dtype == torch.float32 and part.dim() == 2 and part.stride(1) == 1):
@@ -658,19 +633,9 @@ def linear_wgrad_grouped(pairs):
     return parts
 
 
-def _parts_of(t, inner_shape, what):
-    """(parts, stride) of a tensor given either in its plain shape or with a leading k-parts dimension (the output of linear_parts)."""
-    if t is None or t.dim() == len(inner_shape):
-        return 1, 0
-    if t.dim() != len(inner_shape) + 1 or tuple(t.shape[1:]) != tuple(inner_shape) or not t[0].is_contiguous() or t.stride(0) < t[0].numel():
-        raise RuntimeError(f"{what}: expected {tuple(inner_shape)} or (parts,) + that with contiguous parts, got {tuple(t.shape)}")
-    return int(t.shape[0]), int(t.stride(0))
-
-
 def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want_xo=True, ybias=None):
     B, Lin, D = x.shape
     dev = x.device
-    yparts, ystride = _parts_of(y, (B, Lin, D), "rowln_fwd y")
     xo = torch.empty((B, Lout, D), dtype=torch.float32, device=dev) if want_xo else None
     if gamma is not None:
         h = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
@@ -678,7 +643,7 @@ def rowln_fwd(x, add, prompts, mode, P, y, u, keep, gamma, beta, eps, Lout, want
         rstd = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     else:
         h = mean = rstd = None
-    _call(dev, "upp_rowln_fwd_parts", _abi.ptr(x), _abi.ptr(add), _abi.ptr(prompts), int(mode), int(P), _abi.ptr(y), yparts, ystride, _abi.ptr(ybias),
+    _call(dev, "upp_rowln_fwd", _abi.ptr(x), _abi.ptr(add), _abi.ptr(prompts), int(mode), int(P), _abi.ptr(y), _abi.ptr(ybias),
           _abi.ptr(u), float(keep), _abi.ptr(gamma), _abi.ptr(beta), float(eps), _abi.ptr(xo), _abi.ptr(h), _abi.ptr(mean), _abi.ptr(rstd),
           B, Lin, Lout, D)
     return xo, h, mean, rstd
@@ -693,8 +658,7 @@ def rowln_bwd(g_xo, g_h, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, 
     if need_ln_part and g_h is not None:
         n = int(_abi.load().upp_rowln_part_floats(B, Lin, Lout, D, int(mode)))
         part = torch.empty((n // (2 * D), 2 * D), dtype=torch.float32, device=dev)     # per workgroup: [d_gamma | d_beta]
-    gparts, gstride = _parts_of(g_h, (B, Lout, D), "rowln_bwd g_h")
-    _call(dev, "upp_rowln_bwd_parts", _abi.ptr(g_xo), _abi.ptr(g_h), gparts, gstride, _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma),
+    _call(dev, "upp_rowln_bwd", _abi.ptr(g_xo), _abi.ptr(g_h), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma),
           int(mode), _abi.ptr(u), float(keep), _abi.ptr(g_x), _abi.ptr(g_p), _abi.ptr(g_y), _abi.ptr(part), B, Lin, Lout, D, P)
     return g_x, g_p, g_y, part
 
@@ -730,19 +694,19 @@ def ln_param_grad(g_h, xo, mean, rstd, chunks=32):
     return part          # (2, chunks, D): [0] d_gamma partials, [1] d_beta partials; the caller sums over the chunks
 
 
-def attn_fwd(qkv, B, L, H, scale, variant=0):
+def attn_fwd(qkv, B, L, H, scale):
     _need(qkv, "qkv", torch.float32)
     hd = qkv.numel() // (B * L * 3 * H)
     ctx = torch.empty((B, L, H * hd), dtype=torch.float32, device=qkv.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
-    _call(qkv.device, "upp_attn_fwd_ex", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(lse), B, L, H, hd, float(scale), int(variant))
+    _call(qkv.device, "upp_attn_fwd", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(lse), B, L, H, hd, float(scale))
     return ctx, lse
 
 
-def attn_bwd(qkv, ctx, d_ctx, lse, B, L, H, scale, variant=0):
+def attn_bwd(qkv, ctx, d_ctx, lse, B, L, H, scale):
     hd = qkv.numel() // (B * L * 3 * H)
     d_qkv = torch.empty_like(qkv)
-    _call(qkv.device, "upp_attn_bwd_ex", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(d_ctx), _abi.ptr(lse), _abi.ptr(d_qkv), B, L, H, hd, float(scale), int(variant))
+    _call(qkv.device, "upp_attn_bwd", _abi.ptr(qkv), _abi.ptr(ctx), _abi.ptr(d_ctx), _abi.ptr(lse), _abi.ptr(d_qkv), B, L, H, hd, float(scale))
     return d_qkv
 
 
@@ -1127,13 +1091,12 @@ def ln_adapter_fwd(x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, 
         _need(t_, n_, torch.float32)
         if tuple(t_.shape) != shp:
             raise RuntimeError(f"ln_adapter_fwd: {n_} must be {shp}, got {tuple(t_.shape)}")
-    yparts, ystride = _parts_of(y, (B, Lin, D), "ln_adapter_fwd y")
     xo = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
     out = torch.empty((B, Lout, D), dtype=torch.float32, device=dev)
     mean = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     rstd = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     s1 = torch.empty((B * Lout, H), dtype=torch.float32, device=dev)
-    _call(dev, "upp_ln_adapter_fwd_parts", _abi.ptr(x), _abi.ptr(y), yparts, ystride, _abi.ptr(ybias), _abi.ptr(u), float(keep), int(mode), int(P), _abi.ptr(gamma),
+    _call(dev, "upp_ln_adapter_fwd", _abi.ptr(x), _abi.ptr(y), _abi.ptr(ybias), _abi.ptr(u), float(keep), int(mode), int(P), _abi.ptr(gamma),
           _abi.ptr(beta), float(eps), _abi.ptr(W1), _abi.ptr(b1), _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(ud), float(p), float(scale),
           _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(s1), _abi.ptr(out), B, Lin, Lout, D, H)
     return out, xo, mean, rstd, s1

@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define UPP_ABI_VERSION 2   /* 2: grouped weight gradients, register-tiled Linear codes; the round-1 *_set_* toggles are gone */
+#define UPP_ABI_VERSION 3   /* 3: split-bf16 Linear (upp_linear_sb_*); the k-parts protocol (upp_linear_parts*, upp_*_parts), the attention
+                               `variant` entry points (upp_attn_*_ex) and the VALU / 32x32x2 attention kernels behind them are gone.
+                               2: grouped weight gradients, register-tiled Linear codes; the round-1 *_set_* toggles are gone */
 
 #define UPP_E_BADARG   (-1)  /* null pointer / non-positive size                   */
 #define UPP_E_RANGE    (-2)  /* size outside what the kernels support (see below)  */
@@ -184,16 +186,6 @@ int upp_patch_embed_fwd(const float *pts, int R, int n,
 int upp_rowln_fwd(const float *x, const float *add, const float *prompts, int mode, int P, const float *y, const float *ybias,
                   const float *u, float keep, const float *gamma, const float *beta, float eps,
                   float *xo, float *h, float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream);
-/* upp_rowln_fwd_parts / upp_rowln_bwd_parts / upp_ln_adapter_fwd_parts: the same operators with `y` (forward) / `g_h` (backward) given as
- * `parts` partial matrices `stride` floats apart -- the output of upp_linear_parts_f32 -- which are added in part order while they are
- * read: the reduction of a GEMM whose contraction was cut over workgroups costs no launch and no pass (parts = 1: the plain operator). */
-int upp_rowln_fwd_parts(const float *x, const float *add, const float *prompts, int mode, int P, const float *y, int yparts, long long ystride,
-                        const float *ybias, const float *u, float keep, const float *gamma, const float *beta, float eps,
-                        float *xo, float *h, float *mean, float *rstd, int B, int Lin, int Lout, int D, void *stream);
-int upp_rowln_bwd_parts(const float *g_xo, const float *g_h, int gparts, long long gstride, const float *xo, const float *mean, const float *rstd,
-                        const float *gamma, int mode, const float *u, float keep,
-                        float *g_x, float *g_prompt, float *g_y, float *ln_part,
-                        int B, int Lin, int Lout, int D, int P, void *stream);
 long long upp_rowln_part_floats(int B, int Lin, int Lout, int D, int mode);
 int upp_rowln_bwd(const float *g_xo, const float *g_h, const float *xo, const float *mean, const float *rstd,
                   const float *gamma, int mode, const float *u, float keep,
@@ -220,13 +212,7 @@ int upp_ln_param_grad(const float *g_h, const float *xo, const float *mean, cons
 int upp_attn_fwd(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, void *stream);
 int upp_attn_bwd(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv,
                  int B, int L, int H, int head_dim, float scale, void *stream);
-/* the same with the kernel family chosen by the caller: variant 0 = the library's choice (L <= 96: the register-resident 16x16x4
- * MFMA kernels of attn_flash16.hip; L <= 160: attn_long.hip), 1 = the VALU kernels (L <= 192 forward, L <= 144 backward),
- * 2 = the LDS-staged 32x32x2 MFMA kernels of attn_mfma.hip for L <= 96 (round 1's choice); for measurements and tests. */
-int upp_attn_fwd_ex(const float *qkv, float *ctx, float *lse, int B, int L, int H, int head_dim, float scale, int variant, void *stream);
-int upp_attn_bwd_ex(const float *qkv, const float *ctx, const float *d_ctx, const float *lse, float *d_qkv,
-                    int B, int L, int H, int head_dim, float scale, int variant, void *stream);
-
+/* (L <= 96: the register-resident 16x16x4 MFMA kernels of attn_flash16.hip; L <= 160: attn_long.hip; UPP_E_RANGE beyond) */
 /* ---- prompt propagation (Block.forward, reference models/Point_MAE_pretask_dev.py:275-303) ----
  * X (rows, D): the block's token matrix viewed as rows = B*L' rows [cls | prompts | T centre tokens] per sample.
  * Index arguments are ABSOLUTE row numbers of X (the host converts the reference's flat / per-sample index
@@ -427,10 +413,6 @@ int upp_ln_adapter_fwd(const float *x, const float *y, const float *ybias, const
                        const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
                        const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
                        float *out, int B, int Lin, int Lout, int D, int H, void *stream);
-int upp_ln_adapter_fwd_parts(const float *x, const float *y, int yparts, long long ystride, const float *ybias, const float *u, float keep,
-                             int mode, int P, const float *gamma, const float *beta, float eps, const float *W1, const float *b1,
-                             const float *W2, const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd,
-                             float *s1, float *out, int B, int Lin, int Lout, int D, int H, void *stream);
 /* upp_ln_adapter_bwd_fused: the whole backward of upp_ln_adapter_fwd in one launch on 16-row workgroups -- the adapter's backward
  * (g_ha, per-workgroup partials [dW1 (H,D) | dW2 (D,H) | db1 (H) | db2 (D)] in `part`, upp_ln_adapter_part_floats(R, D) floats, or
  * part = NULL), the LayerNorm backward with the residual (g_x / g_y (B, Lin, D): every row is written, zeros for the prompt rows
@@ -508,15 +490,6 @@ int upp_linear_f32(const float *A, long long lda, const float *W, long long ldw,
  * upp_linear_tile(M, N, K) & 0x10000), UPP_E_RANGE otherwise. */
 int upp_linear_group_bias_f32(const float *A, long long lda, const float *W, long long ldw, const float *bias, int group_shift,
                               float *C, long long ldc, int M, int N, int K, void *stream);
-/* upp_linear_parts_f32: the same product with the contraction cut into `parts` equal runs over WORKGROUPS: C_p (M,N) = A[:, p K/parts :
- * (p+1) K/parts] . W[:, same]^T written at C + p * part_stride (floats), no epilogue.  For narrow outputs over a long contraction (fc2 and
- * the data gradients of fc1 / qkv: N = 384, K >= 1152) this keeps 128-wide tiles AND fills the chip; the consumer of the result adds the
- * parts in order while it reads them (upp_rowln_fwd / upp_ln_adapter_fwd `y`, upp_rowln_bwd `g_h`: their `parts` arguments).
- * upp_linear_parts(M,N,K): the library's choice of `parts` (1 = do not cut).  Every part is a KS = 1 chain over its run (oracle_linear_f32
- * on the column window).  Limits: as upp_linear_f32, K % (32 parts) == 0 (64 parts for the 128 x 128 tile). */
-int upp_linear_parts(int M, int N, int K);
-int upp_linear_parts_f32(const float *A, long long lda, const float *W, long long ldw, float *C, long long ldc, long long part_stride,
-                         int M, int N, int K, int parts, void *stream);
 /* ---- the same Linear layers at f32 accuracy on the BF16 matrix pipe (csrc/linear_sb.hip) ------------------------------
  * Replaces the same reference calls as upp_linear_f32 (models/Point_MAE_pretask_dev.py:153-196, nn.Linear -> cuBLAS) for FROZEN
  * weights: C (M,N) = epilogue( A (M,K) . W (N,K)^T ) with every f32 operand split exactly into three bf16 terms (x = x1 + x2 + x3,

@@ -71,6 +71,9 @@ def _worker(rank, world, port, out_dir, paths, kind="pipelined"):
         pts = _seeded.noisy_clouds(4, 1024, seed=100 * rank + k).cuda()
         labels = torch.tensor([(rank + k) % 40, 3, 17, 39 - k], device='cuda')
         ts.step(pts, labels)
+        if k == (1 if kind == "pipelined" else 0):        # the (all-reduced) gradient buffer of batch 0: the pipelined step finishes it one call later
+            torch.cuda.synchronize()
+            np.save(os.path.join(out_dir, "grad0_%s_w%d_r%d.npy" % (kind, world, rank)), ts.flat.flat.detach().cpu().numpy())
     ts.flush()
     torch.cuda.synchronize()
     flat = torch.cat([p.detach().reshape(-1) for p in ts.trainable]).cpu().numpy()
@@ -107,9 +110,18 @@ def test_pipelined_and_one_stream_steps_agree_at_world_size_two(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), paths, "onestream"), nprocs=2, join=True)
     pipe = [np.load(tmp_path / ("params_pipelined_w2_r%d.npy" % r)) for r in range(2)]
     one = [np.load(tmp_path / ("params_onestream_w2_r%d.npy" % r)) for r in range(2)]
-    np.testing.assert_array_equal(one[0], one[1])
+    np.testing.assert_array_equal(one[0], one[1])             # bit-identical replicas either way
     np.testing.assert_array_equal(pipe[0], pipe[1])
-    np.testing.assert_allclose(pipe[0], one[0], rtol=5e-4, atol=5e-5 * np.abs(one[0]).max())
+    # the reduced gradient of the first batch (same parameters on both sides): equal up to the f32 re-association between the front-end's
+    # no-grad kernels (fused activation epilogues) and the one-graph forward -- 1e-4 of the gradient's scale.  (The PARAMETERS after four
+    # AdamW steps are not compared element-wise: m / sqrt(v) turns a 1e-7 gradient difference at a near-zero gradient into a full +-lr step.)
+    gp = [np.load(tmp_path / ("grad0_pipelined_w2_r%d.npy" % r)) for r in range(2)]
+    go = [np.load(tmp_path / ("grad0_onestream_w2_r%d.npy" % r)) for r in range(2)]
+    np.testing.assert_array_equal(gp[0], gp[1])
+    np.testing.assert_array_equal(go[0], go[1])
+    np.testing.assert_allclose(gp[0], go[0], rtol=1e-3, atol=1e-4 * np.abs(go[0]).max())
+    # ... and the runs stay together: after four steps no parameter is further apart than the four +-lr steps AdamW can take
+    assert np.abs(pipe[0] - one[0]).max() <= 4 * 2 * 5e-4 * 1.1 + 1e-6          # (lr = 5e-4: at most +-lr per step on each side)
 
 
 def test_replicas_stay_identical_when_ranks_start_apart_and_feed_data_before_the_first_step(tmp_path):

@@ -526,24 +526,3 @@ def test_trainable_weight_transposes_follow_the_weights_inside_a_step_driver():
     ops.transpose_batched(pairs)
     for src, dst in pairs:
         assert torch.equal(dst, src.t().contiguous())
-
-
-@pytest.mark.parametrize("M,N,K,parts", [(2400, 384, 1536, None), (2400, 384, 1152, None), (1120, 384, 1536, None), (4448, 384, 1536, None),
-                                          (300, 100, 384, 2), (300, 100, 384, 3), (129, 384, 512, 8), (2400, 1536, 384, None)])
-def test_contraction_cut_over_workgroups_gives_bit_exact_parts(M, N, K, parts):
-    """upp_linear_parts_f32: part p is the product over the p-th run of k, one KS = 1 fmaf chain per output (oracle_linear_f32 on the column
-    window), bit for bit; the parts add up to the product; the library cuts narrow outputs over long contractions and nothing else."""
-    import oracle as O
-    lib = _abi.load()
-    a, w, _ = _operands(M, N, K, seed=M + K)
-    out = ops.linear_parts(a, w, parts)
-    P = out.shape[0]
-    assert P == (parts or lib.upp_linear_parts(M, N, K)) and out.shape[1:] == (M, N)
-    if parts is None:
-        assert (P > 1) == (N <= 384 and K >= 1152), (M, N, K, P)
-    an, wn = a.cpu().numpy(), w.cpu().numpy()
-    Kc = K // P
-    if M * N * K <= 2400 * 384 * 1536:
-        for p in range(P):
-            np.testing.assert_array_equal(out[p].cpu().numpy(), O.linear_f32(an[:, p * Kc:(p + 1) * Kc], wn[:, p * Kc:(p + 1) * Kc]))
-    close(out.sum(0), F.linear(a, w))

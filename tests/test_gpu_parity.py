@@ -196,7 +196,7 @@ def test_chamfer_modules_and_autograd():
     assert torch.isfinite(ChamferDistanceL2(ignore_zeros=True)(one, one))
 
 
-EMD_SHAPES = [(3, 2, 2), (4, 64, 64), (2, 96, 32), (2, 40, 100), (2, 300, 300), (8, 1024, 1024)]
+EMD_SHAPES = [(3, 2, 2), (4, 64, 64), (2, 96, 32), (2, 40, 100), (2, 300, 300), (8, 1024, 1024), (32, 1024, 1024)]     # the last: BASELINE's batch
 
 
 @pytest.mark.parametrize("B,n,m", EMD_SHAPES)

@@ -302,6 +302,28 @@ def test_rectify_tail_scores_nudges_and_selects_like_the_reference_formulation(B
     assert torch.equal(out, want)
 
 
+def test_rectify_tail_ranks_nan_scores_as_the_largest_like_argsort():
+    """A NaN score compares false to everything; torch.argsort (the reference formulation) sorts NaN as the largest value and always
+    returns a permutation.  The rank kernel does the same: no slot of `order` / `out` is left unwritten."""
+    from upp_hip import ops
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    B, N, keep = 2, 300, 250
+    feat = torch.randn(B, N, 32, device='cuda', generator=gen)
+    feat[0, 17, 0] = float('inf'); feat[0, 200, 0] = float('inf'); feat[1, 0, 0] = float('inf')
+    pts = torch.randn(B, N, 3, device='cuda', generator=gen)
+    # a score head that passes channel 0 through: score = relu(feat[..., 0]); an infinite channel gives pred = (inf, 0 * inf, 0 * inf) -> NaN norm
+    w0, b0 = torch.zeros(64, 32, device='cuda'), torch.zeros(64, device='cuda')
+    w1, b1 = torch.zeros(3, 64, device='cuda'), torch.zeros(3, device='cuda')
+    w0[0, 0] = 1.0; w1[0, 0] = 1.0
+    out, pred, order, score = ops.rectify_select(feat, w0, b0, w1, b1, pts, keep, None, 0.0, 1.0, 0.2, want_pred=True, want_order=True, want_score=True)
+    assert bool(torch.isnan(score[0, 17])) and bool(torch.isnan(score[1, 0]))
+    for b in range(B):
+        assert sorted(order[b].tolist()) == list(range(N))                      # a permutation
+    assert order[0, :2].tolist() == [17, 200] and order[1, 0].item() == 0          # NaN first in descending order, ties in index order
+    want_order = torch.sort(score, dim=1, descending=True, stable=True)[1]
+    assert torch.equal(order, want_order)
+
+
 def test_batched_copy_moves_every_tensor_in_one_launch():
     """upp_copy_batched: the hand-over state of the pipelined step (mixed dtypes and sizes, odd byte counts)."""
     from upp_hip import ops
