@@ -142,6 +142,8 @@ class Point_MAE(nn.Module):
             raise NotImplementedError(self.loss)
 
     def loss_func(self, a, b):
+        if a.is_cuda and getattr(OPS["chamfer"], "__self__", None) is HF.ChamferFunction:      # (not replaced by a test's injection)
+            return HF.chamfer_loss(a, b, self.loss != 'cdl2')       # one node: upp_chamfer_fwd + upp_chamfer_loss, upp_chamfer_bwd
         d1, d2 = OPS["chamfer"](a, b)
         if self.loss == 'cdl2':
             return torch.mean(d1) + torch.mean(d2)                        # ChamferDistanceL2

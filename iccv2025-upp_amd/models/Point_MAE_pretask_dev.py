@@ -85,6 +85,9 @@ def pretask_losses(model, gt, partial, cropping, points, point_num, chamfer_l1=N
     `points` = partial cloud (+ appended noise points), `cropping` = the removed region, `gt` = the complete cloud.
     -> (total loss, dict of the individual terms)."""
     def cd_l1(a, b):                                   # ChamferDistanceL1 (extensions/chamfer_dist/__init__.py:61-73) on the op table
+        from upp_hip import functional as HF
+        if a.is_cuda and getattr(L.OPS["chamfer"], "__self__", None) is HF.ChamferFunction:        # (not replaced by a test's injection)
+            return HF.chamfer_loss(a, b, True)           # (one node: upp_chamfer_fwd + upp_chamfer_loss, upp_chamfer_bwd)
         d1, d2 = L.OPS["chamfer"](a.contiguous(), b.contiguous())
         return (torch.mean(torch.sqrt(d1)) + torch.mean(torch.sqrt(d2))) / 2
     cd = chamfer_l1 if chamfer_l1 is not None else cd_l1

@@ -51,6 +51,7 @@ class UniformBank:
 
 
 UNIFORMS = UniformBank()
+FUSE_INTERP_GEO = True     # _inverse_distance_interp: HF.interp_geo when the coordinates carry a gradient (False: the torch formulation; tests A/B it)
 FUSE_LN_ADAPTER = True     # Block.forward_fused: close the block with HF.ln_adapter (one launch) instead of HF.rowln + HF.adapter
 
 
@@ -153,6 +154,10 @@ def _inverse_distance_interp(xyz1, xyz2, points2, k, eps, out=None, col0=0):
     """k nearest of xyz2 for each xyz1 point (full sort, as the reference), 1/(d+eps) weights.
     `out`/`col0`: optional (B,N,W) buffer whose columns [col0, col0+C) receive the result (fused path only)."""
     S = xyz2.shape[1]
+    if (out is None and xyz1.is_cuda and xyz1.dtype == torch.float32 and xyz2.dtype == torch.float32 and points2.dtype == torch.float32
+            and S <= 256 and min(k, S) <= 16 and xyz1.shape[-1] == 3 and not _no_grad_needed(xyz1, xyz2) and FUSE_INTERP_GEO):
+        # the geometry carries a gradient (stage 2, the pre-task recipe): one autograd node for table + interpolation + all three gradients
+        return HF.interp_geo(xyz1, xyz2, points2, k, eps)
     if (xyz1.is_cuda and xyz1.dtype == torch.float32 and xyz2.dtype == torch.float32 and S <= 256 and min(k, S) <= 16
             and xyz1.shape[-1] == 3 and _no_grad_needed(xyz1, xyz2)):
         dists, idx = HF.sqdist_topk(xyz1, xyz2, min(k, S))       # one launch for matmul + 5 element-wise passes + full sort

@@ -28,6 +28,8 @@ SIGNATURES = {
     "upp_group_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_chamfer_fwd": (_c_i, [_c_f] * 6 + [_c_i] * 3 + [_c_f]),
     "upp_chamfer_bwd": (_c_i, [_c_f] * 8 + [_c_i] * 3 + [_c_f]),
+    "upp_chamfer_loss_work_floats": (ctypes.c_longlong, []),
+    "upp_chamfer_loss": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f, _c_f]),
     "upp_emd_work_floats": (ctypes.c_longlong, [_c_i, _c_i, _c_i]),
     "upp_emd_approxmatch": (_c_i, [_c_f] * 4 + [_c_i] * 3 + [_c_f]),
     "upp_emd_matchcost": (_c_i, [_c_f] * 4 + [_c_i] * 3 + [_c_f]),
@@ -64,6 +66,7 @@ SIGNATURES = {
     "upp_interp_fwd": (_c_i, [_c_f] * 2 + [_c_i] + [_c_f] * 2 + [_c_i] * 7 + [ctypes.c_float] + [_c_f]),
     "upp_interp_affine_fwd": (_c_i, [_c_f] * 2 + [_c_i] + [_c_f] * 4 + [_c_i] * 5 + [ctypes.c_float] + [_c_f]),
     "upp_interp_bwd": (_c_i, [_c_f] * 2 + [_c_i] + [_c_f] + [_c_i] * 2 + [_c_f] + [_c_i] * 5 + [ctypes.c_float] + [_c_f]),
+    "upp_interp_geo_bwd": (_c_i, [_c_f, _c_f, _c_i, _c_f, _c_f, _c_i, _c_i, _c_f, _c_f] + [_c_i] * 5 + [ctypes.c_float] + [_c_f] * 4),
     "upp_posenc_fwd": (_c_i, [_c_f, ctypes.POINTER(ctypes.c_float), _c_i, _c_f, _c_i, _c_i, ctypes.c_longlong, _c_f]),
     "upp_prop_part_floats": (ctypes.c_longlong, [_c_i] * 2),
     "upp_prop_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 7 + [ctypes.c_float] * 2 + [_c_i] + [_c_f] * 6 + [_c_i] * 5 + [_c_f]),

@@ -155,6 +155,42 @@ __global__ __launch_bounds__(1024) void chamfer_grad_cloud_kernel(const float *_
     for (int i = tid; i < m * 3; i += 1024) o2[i] = a2[i];
 }
 
+// Loss reduction of the Chamfer modules (reference extensions/chamfer_dist/__init__.py:44-84): ChamferDistanceL1 = (mean sqrt d1 + mean
+// sqrt d2) / 2, ChamferDistanceL2 = mean d1 + mean d2, as ONE partial-sum launch + a finalize (torch: sqrt x 2, mean x 2, add, div forward
+// and the same again backward, per term).  fac1 / fac2 receive d loss / d dist element-wise (coef / (count 2 sqrt d) resp. coef / count):
+// the backward of the module is upp_chamfer_bwd on upstream x fac.  Sums in a fixed order (deterministic).
+constexpr int kLossBlocks = 128;
+__global__ __launch_bounds__(256) void chamfer_loss_part_kernel(const float *__restrict__ d1, const float *__restrict__ d2, long long n1, long long n2,
+                                                               int l1, float c1, float c2, float *__restrict__ fac1, float *__restrict__ fac2,
+                                                               float *__restrict__ part) {
+    __shared__ float red[2][4];
+    float s1 = 0.0f, s2 = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n1; i += (long long)kLossBlocks * 256) {
+        const float d = d1[i], r = l1 ? sqrtf(d) : d;
+        s1 += r;
+        fac1[i] = l1 ? c1 * 0.5f / r : c1;
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)kLossBlocks * 256) {
+        const float d = d2[i], r = l1 ? sqrtf(d) : d;
+        s2 += r;
+        fac2[i] = l1 ? c2 * 0.5f / r : c2;
+    }
+    s1 = wave_sum_f32(s1); s2 = wave_sum_f32(s2);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        part[blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+__global__ __launch_bounds__(64) void chamfer_loss_final_kernel(const float *__restrict__ part, float c1, float c2, float *__restrict__ out) {
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int i = threadIdx.x; i < kLossBlocks; i += 64) { s1 += part[i * 2]; s2 += part[i * 2 + 1]; }
+    s1 = wave_sum_f32(s1); s2 = wave_sum_f32(s2);
+    if (threadIdx.x == 0) out[0] = c1 * s1 + c2 * s2;
+}
+
 }  // namespace
 
 extern "C" int upp_chamfer_fwd(const float *xyz1, const float *xyz2, float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
@@ -188,5 +224,19 @@ extern "C" int upp_chamfer_bwd(const float *xyz1, const float *xyz2, const int32
         return upp_launch_status();
     hipLaunchKernelGGL(chamfer_grad_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, xyz1, xyz2, idx1, idx2,
                        grad_dist1, grad_dist2, g1, g2, B, n, m);
+    return upp_launch_status();
+}
+
+extern "C" long long upp_chamfer_loss_work_floats(void) { return 2 * kLossBlocks; }
+
+extern "C" int upp_chamfer_loss(const float *dist1, const float *dist2, int B, int n, int m, int l1, float *loss, float *fac1, float *fac2,
+                                float *work, void *stream) {
+    if (!dist1 || !dist2 || !loss || !fac1 || !fac2 || !work || B < 1 || n < 1 || m < 1) return UPP_E_BADARG;
+    const float coef = l1 ? 0.5f : 1.0f;
+    const float c1 = coef / ((float)B * (float)n), c2 = coef / ((float)B * (float)m);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(chamfer_loss_part_kernel, dim3(kLossBlocks), dim3(256), 0, st, dist1, dist2, (long long)B * n, (long long)B * m, l1 ? 1 : 0, c1, c2,
+                       fac1, fac2, work);
+    hipLaunchKernelGGL(chamfer_loss_final_kernel, dim3(1), dim3(64), 0, st, work, c1, c2, loss);
     return upp_launch_status();
 }

@@ -791,6 +791,79 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float *__restrict__ x
 int bn_per(int R) { int per = (R + 255) / 256; return per < 8 ? 8 : per; }
 int pow2_at_least(int c) { int p = 4; while (p < c && p < 256) p <<= 1; return p; }
 
+
+// Backward of the interpolation w.r.t. the GEOMETRY (the queries xyz1 and the sources xyz2; stage 2 of the recipe and the pre-task
+// recipe differentiate through the prompters' interpolations: reference models/Point_MAE_unify.py:22-48 / models/modules.py:13-32 under
+// autograd -- about forty element-wise / sort / index kernels per site there).  out[row] = sum_j w_j feat[idx_j], w_j = r_j / R,
+// r_j = 1 / (d_j + eps), d_j = |x1 - x2_j|^2:
+//     g_w_j = <g_out[row], feat[idx_j]>,  g_r_j = (g_w_j - sum_l g_w_l w_l) / R,  g_d_j = -g_r_j r_j^2,
+//     g_x1 = sum_j 2 g_d_j (x1 - x2_j),   g_x2[idx_j] -= 2 g_d_j (x1 - x2_j)
+// One wave per query row: the k dot products as wave reductions, the rest on uniform values.  The source-side terms leave as one
+// (row, j) contribution each (contrib (B*N, k, 3)); interp_geo_src_kernel adds them per source point in (row, j) order: deterministic.
+__global__ __launch_bounds__(256) void interp_geo_bwd_kernel(const float *__restrict__ dist, const int64_t *__restrict__ idx, int ld_tab,
+                                                            const float *__restrict__ feat, const float *__restrict__ g_out, int ld_g, int col0,
+                                                            const float *__restrict__ xyz1, const float *__restrict__ xyz2, int B, int N, int S, int C,
+                                                            int k, float eps, float *__restrict__ g_xyz1, float *__restrict__ contrib) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (row >= B * N) return;
+    const int b = row / N;
+    const float *d = dist + (size_t)row * ld_tab;
+    const int64_t *ix = idx + (size_t)row * ld_tab;
+    const float *g = g_out + (size_t)row * ld_g + col0;
+    float r[kInterpK], gw[kInterpK];
+    int src[kInterpK];
+    float R = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kInterpK; ++j) {
+        if (j < k) { r[j] = 1.0f / (d[j] + eps); src[j] = (int)ix[j]; R += r[j]; } else { r[j] = 0.0f; src[j] = 0; }
+    }
+#pragma unroll
+    for (int j = 0; j < kInterpK; ++j) {
+        float acc = 0.0f;
+        if (j < k) {
+            const float *f = feat + ((size_t)b * S + src[j]) * C;
+            for (int c = lane; c < C; c += 64) acc = __builtin_fmaf(g[c], f[c], acc);
+        }
+        gw[j] = wave_sum_f32(acc);
+    }
+    if (lane != 0) return;
+    float mix = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kInterpK; ++j) if (j < k) mix = __builtin_fmaf(gw[j], r[j] / R, mix);
+    const float x = xyz1[(size_t)row * 3], y = xyz1[(size_t)row * 3 + 1], z = xyz1[(size_t)row * 3 + 2];
+    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kInterpK; ++j) {
+        if (j < k) {
+            const float gd2 = -2.0f * ((gw[j] - mix) / R) * r[j] * r[j];            // 2 g_d_j
+            const float *q = xyz2 + ((size_t)b * S + src[j]) * 3;
+            const float dx = (x - q[0]) * gd2, dy = (y - q[1]) * gd2, dz = (z - q[2]) * gd2;
+            gx += dx; gy += dy; gz += dz;
+            if (contrib) { float *o = contrib + ((size_t)row * k + j) * 3; o[0] = -dx; o[1] = -dy; o[2] = -dz; }
+        }
+    }
+    if (g_xyz1) { g_xyz1[(size_t)row * 3] = gx; g_xyz1[(size_t)row * 3 + 1] = gy; g_xyz1[(size_t)row * 3 + 2] = gz; }
+}
+
+// g_xyz2[b][s] = sum over the (row, j) entries of sample b whose source is s, in (row, j) order: one wave per (b, s).
+__global__ __launch_bounds__(256) void interp_geo_src_kernel(const int64_t *__restrict__ idx, int ld_tab, const float *__restrict__ contrib, int B, int N,
+                                                            int S, int k, float *__restrict__ g_xyz2) {
+    const int lane = threadIdx.x & 63;
+    const int bs = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (bs >= B * S) return;
+    const int b = bs / S, s = bs - b * S;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    const int total = N * k;
+    for (int e = lane; e < total; e += 64) {                        // (lane-strided: a fixed assignment of entries to lanes, fixed lane order below)
+        const int n = e / k, j = e - n * k;
+        const size_t row = (size_t)b * N + n;
+        if ((int)idx[row * ld_tab + j] == s) { const float *c = contrib + (row * k + j) * 3; ax += c[0]; ay += c[1]; az += c[2]; }
+    }
+    ax = wave_sum_f32(ax); ay = wave_sum_f32(ay); az = wave_sum_f32(az);
+    if (lane == 0) { g_xyz2[(size_t)bs * 3] = ax; g_xyz2[(size_t)bs * 3 + 1] = ay; g_xyz2[(size_t)bs * 3 + 2] = az; }
+}
+
 }  // namespace
 
 // shared with prop.hip: finalize of (sum, M2) slab partials
@@ -931,5 +1004,21 @@ extern "C" int upp_posenc_fwd(const float *x, const float *freqs, int F, float *
     for (int q = 0; q < 8; ++q) fr.f[q] = q < F ? freqs[q] : 0.0f;       // freqs is a HOST array (a handful of scalars)
     const long long total = rows * 3;
     hipLaunchKernelGGL(posenc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, fr, F, out, ld_out, col0, total);
+    return upp_launch_status();
+}
+
+extern "C" int upp_interp_geo_bwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, const float *g_out, int ld_g, int col0,
+                                  const float *xyz1, const float *xyz2, int B, int N, int S, int C, int k, float eps, float *g_xyz1,
+                                  float *g_xyz2, float *contrib, void *stream) {
+    if (!dist || !idx || !feat || !g_out || !xyz1 || !xyz2 || B < 0 || N < 1 || S < 1 || C < 1 || k < 1) return UPP_E_BADARG;
+    if (k > kInterpK || k > S || ld_tab < k || ld_g < col0 + C) return UPP_E_RANGE;
+    if (!g_xyz1 && !g_xyz2) return UPP_E_BADARG;
+    if (g_xyz2 && !contrib) return UPP_E_BADARG;
+    if (B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(interp_geo_bwd_kernel, dim3((unsigned)((B * N + 3) / 4)), dim3(256), 0, st, dist, idx, ld_tab, feat, g_out, ld_g, col0, xyz1, xyz2,
+                       B, N, S, C, k, eps, g_xyz1, g_xyz2 ? contrib : nullptr);
+    if (g_xyz2)
+        hipLaunchKernelGGL(interp_geo_src_kernel, dim3((unsigned)((B * S + 3) / 4)), dim3(256), 0, st, idx, ld_tab, contrib, B, N, S, k, g_xyz2);
     return upp_launch_status();
 }

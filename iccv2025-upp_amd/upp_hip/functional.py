@@ -112,6 +112,29 @@ class ChamferFunction(Function):
         return ops.chamfer_bwd(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)
 
 
+class _ChamferLoss(Function):
+    """ChamferDistanceL1 / L2 as one node: two direction kernels + the fused reduction forward (4 launches), a scalar x factor pair and the
+    gradient kernel backward -- torch's formulation issues ~7 launches forward and ~8 backward around the same two kernels."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, l1):
+        dist1, dist2, idx1, idx2 = ops.chamfer_fwd(xyz1, xyz2)
+        loss, fac1, fac2 = ops.chamfer_loss(dist1, dist2, l1)
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2, fac1, fac2)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz1, xyz2, idx1, idx2, fac1, fac2 = ctx.saved_tensors
+        g1, g2 = ops.chamfer_bwd(xyz1, xyz2, idx1, idx2, fac1 * g, fac2 * g)
+        return g1, g2, None
+
+
+def chamfer_loss(xyz1, xyz2, l1=True):
+    """ChamferDistanceL1 (l1) / ChamferDistanceL2 of two batches of clouds (reference extensions/chamfer_dist/__init__.py:44-84)."""
+    return _ChamferLoss.apply(xyz1.contiguous(), xyz2.contiguous(), bool(l1))
+
+
 class EarthMoverDistanceFunction(Function):
     """extensions.emd.emd.EarthMoverDistanceFunction (reference extensions/emd/emd.py:5-21)."""
 
@@ -930,6 +953,36 @@ class _InterpTrain(Function):
 def interp_train(dists, idx, feat, k, eps):
     """Differentiable (w.r.t. feat) inverse-distance interpolation from the k nearest of a sorted neighbour table."""
     return _InterpTrain.apply(dists, idx, feat, k, eps)
+
+
+class _InterpGeo(Function):
+    """Inverse-distance interpolation with gradients for the features AND the geometry (queries and sources): forward upp_sqdist_topk +
+    upp_interp_fwd, backward upp_interp_bwd (features) + upp_interp_geo_bwd (coordinates) -- the autograd chain of the reference's
+    square_distance / sort / index / weights formulation (models/Point_MAE_unify.py:22-48) in five launches."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, feat, k, eps):
+        xyz1, xyz2, feat = xyz1.contiguous(), xyz2.contiguous(), feat.contiguous()
+        dists, idx = ops.sqdist_topk(xyz1, xyz2, k)
+        ctx.save_for_backward(xyz1, xyz2, feat, dists, idx)
+        ctx.k, ctx.eps = k, eps
+        return ops.interp_fwd(dists, idx, feat, k, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz1, xyz2, feat, dists, idx = ctx.saved_tensors
+        g = g.contiguous()
+        need = ctx.needs_input_grad
+        g_feat = ops.interp_bwd(dists, idx, g, feat.shape[1], ctx.k, ctx.eps) if need[2] else None
+        g1 = g2 = None
+        if need[0] or need[1]:
+            g1, g2 = ops.interp_geo_bwd(dists, idx, feat, g, xyz1, xyz2, ctx.k, ctx.eps, need[0], need[1])
+        return g1, g2, g_feat, None, None
+
+
+def interp_geo(xyz1, xyz2, feat, k, eps):
+    """(B,N,C) inverse-distance interpolation of feat (B,S,C) at xyz1 from its k nearest of xyz2, differentiable w.r.t. all three."""
+    return _InterpGeo.apply(xyz1, xyz2, feat, int(min(k, xyz2.shape[1])), float(eps))
 
 
 class _InterpAffine(Function):

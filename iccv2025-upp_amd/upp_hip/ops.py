@@ -162,6 +162,20 @@ def chamfer_bwd(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2):
     return g1, g2
 
 
+def chamfer_loss(dist1, dist2, l1):
+    """-> (loss (1,), fac1 (B,n), fac2 (B,m)): the reduction of ChamferDistanceL1 (l1) / L2 and d loss / d dist (upp_chamfer_loss)."""
+    _need(dist1, "dist1", torch.float32, 2)
+    _need(dist2, "dist2", torch.float32, 2)
+    B, n = dist1.shape
+    m = dist2.shape[1]
+    dev = dist1.device
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    fac1, fac2 = torch.empty_like(dist1), torch.empty_like(dist2)
+    work = torch.empty((int(_abi.load().upp_chamfer_loss_work_floats()),), dtype=torch.float32, device=dev)
+    _call(dev, "upp_chamfer_loss", _abi.ptr(dist1), _abi.ptr(dist2), B, n, m, 1 if l1 else 0, _abi.ptr(loss), _abi.ptr(fac1), _abi.ptr(fac2), _abi.ptr(work))
+    return loss, fac1, fac2
+
+
 # ------------------------------------------------------------------ EMD
 def emd_approxmatch(xyz1, xyz2):
     _need(xyz1, "xyz1", torch.float32, 3, 3)
@@ -933,6 +947,29 @@ def interp_bwd(dist, idx, g_out, S, k, eps):
     _call(g_out.device, "upp_interp_bwd", _abi.ptr(dist), _abi.ptr(idx), dist.stride(1), _abi.ptr(g_out), C, 0, _abi.ptr(g_feat),
           B, N, int(S), C, int(k), float(eps))
     return g_feat
+
+
+def interp_geo_bwd(dist, idx, feat, g_out, xyz1, xyz2, k, eps, need1=True, need2=True):
+    """Gradient of interp_fwd w.r.t. the geometry behind the neighbour table: -> (g_xyz1 (B,N,3) or None, g_xyz2 (B,S,3) or None);
+    upp_interp_geo_bwd."""
+    _need(g_out, "g_out", torch.float32, ndim=3)
+    _need(feat, "feat", torch.float32, ndim=3)
+    _need(xyz1, "xyz1", torch.float32, ndim=3, last=3)
+    _need(xyz2, "xyz2", torch.float32, ndim=3, last=3)
+    B, N, C = g_out.shape
+    S = feat.shape[1]
+    for t, name, dt in ((dist, "dist", torch.float32), (idx, "idx", torch.int64)):
+        if not t.is_cuda or t.dtype != dt or t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != N * t.stride(1):
+            raise RuntimeError(f"{name} must be a HIP {dt} (B,N,S') table with contiguous rows")
+    if dist.stride(1) != idx.stride(1) or tuple(dist.shape[:2]) != (B, N) or tuple(xyz1.shape[:2]) != (B, N) or tuple(xyz2.shape[:2]) != (B, S) or feat.shape[2] != C:
+        raise RuntimeError("interp_geo_bwd: shapes do not match")
+    dev = g_out.device
+    g1 = torch.empty((B, N, 3), dtype=torch.float32, device=dev) if need1 else None
+    g2 = torch.empty((B, S, 3), dtype=torch.float32, device=dev) if need2 else None
+    contrib = torch.empty((B * N, int(k), 3), dtype=torch.float32, device=dev) if need2 else None
+    _call(dev, "upp_interp_geo_bwd", _abi.ptr(dist), _abi.ptr(idx), dist.stride(1), _abi.ptr(feat), _abi.ptr(g_out), C, 0, _abi.ptr(xyz1), _abi.ptr(xyz2),
+          B, N, S, C, int(k), float(eps), _abi.ptr(g1), _abi.ptr(g2), _abi.ptr(contrib))
+    return g1, g2
 
 
 def posenc_fwd(x, freqs, out=None, col0=0):

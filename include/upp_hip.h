@@ -118,6 +118,13 @@ int upp_chamfer_fwd(const float *xyz1, const float *xyz2,
 int upp_chamfer_bwd(const float *xyz1, const float *xyz2, const int32_t *idx1, const int32_t *idx2,
                     const float *grad_dist1, const float *grad_dist2, float *g1, float *g2,
                     int B, int n, int m, void *stream);
+/* upp_chamfer_loss: the reductions of ChamferDistanceL1 / ChamferDistanceL2 (reference extensions/chamfer_dist/__init__.py:44-84) in two
+ * launches: loss[0] = (mean sqrt dist1 + mean sqrt dist2) / 2 (l1 != 0) or mean dist1 + mean dist2 (l1 == 0), means over all B n resp.
+ * B m entries; fac1 (B,n) / fac2 (B,m) receive d loss / d dist element-wise, so that the module's backward is upp_chamfer_bwd on
+ * (upstream scalar x fac).  work: upp_chamfer_loss_work_floats() floats of scratch.  Sums in a fixed order. */
+long long upp_chamfer_loss_work_floats(void);
+int upp_chamfer_loss(const float *dist1, const float *dist2, int B, int n, int m, int l1, float *loss, float *fac1, float *fac2,
+                     float *work, void *stream);
 
 /* ---- approximate earth mover's distance ----------------------------------------
  * Replaces emd_cuda.approxmatch_forward / matchcost_forward / matchcost_backward
@@ -322,6 +329,14 @@ int upp_interp_affine_fwd(const float *dist, const int64_t *idx, int ld_tab, con
                           float *out, int B, int N, int S, int C, int k, float eps, void *stream);
 int upp_interp_bwd(const float *dist, const int64_t *idx, int ld_tab, const float *g_out, int ld_g, int col0, float *g_feat,
                    int B, int N, int S, int C, int k, float eps, void *stream);
+/* upp_interp_geo_bwd: gradient of upp_interp_fwd w.r.t. the GEOMETRY -- the queries xyz1 (B,N,3) and the sources xyz2 (B,S,3) behind the
+ * squared distances of the neighbour table (d_j = |x1 - x2_j|^2, reference models/modules.py:13-32; the autograd chain of
+ * models/Point_MAE_unify.py:22-48 / models/Point_MAE_pretask_dev.py:446-470 when the prompters train: stage 2, the pre-task recipe).
+ * g_xyz1 (B,N,3) and / or g_xyz2 (B,S,3) are written (either may be NULL); contrib: (B*N, k, 3) floats of scratch, needed with g_xyz2
+ * (the source-side terms are summed per source point in (row, j) order: deterministic).  k <= 16, k <= S. */
+int upp_interp_geo_bwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, const float *g_out, int ld_g, int col0,
+                       const float *xyz1, const float *xyz2, int B, int N, int S, int C, int k, float eps, float *g_xyz1,
+                       float *g_xyz2, float *contrib, void *stream);
 int upp_posenc_fwd(const float *x, const float *freqs, int F, float *out, int ld_out, int col0, long long rows, void *stream);
 
 /* ---- classification tail (reference models/Point_MAE_unify.py:650-655 and get_loss_acc :499-503) ----------------

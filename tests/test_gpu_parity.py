@@ -369,3 +369,27 @@ def test_empty_batches_and_limit_sizes():
         h = ops.chamfer_fwd(dev(a), dev(b))
         for x, y in zip(h, w):
             np.testing.assert_array_equal(x.cpu().numpy(), y)
+
+
+@pytest.mark.parametrize("B,n,m", [(32, 1024, 1024), (2, 2048, 8192), (3, 40, 100), (1, 1, 1)])
+@pytest.mark.parametrize("l1", [True, False])
+def test_fused_chamfer_loss_equals_the_module_formulation(B, n, m, l1):
+    """upp_chamfer_loss (one node: direction kernels + fused reduction, factor x upstream + gradient kernel) against the reference's
+    formulation on the same direction kernels: (mean sqrt d1 + mean sqrt d2) / 2 resp. mean d1 + mean d2 (extensions/chamfer_dist/__init__.py:44-84)."""
+    from upp_hip import functional as HF
+    a = torch.from_numpy(clouds(B, n, "ball", n + 5)).cuda().requires_grad_(True)
+    b = torch.from_numpy(clouds(B, m, "ball", m + 7)).cuda().requires_grad_(True)
+    w = 1.7
+    loss = HF.chamfer_loss(a, b, l1)
+    (loss * w).backward()
+    ga, gb = a.grad.clone(), b.grad.clone()
+    a.grad = b.grad = None
+    d1, d2 = HF.ChamferFunction.apply(a, b)
+    ref = (torch.mean(torch.sqrt(d1)) + torch.mean(torch.sqrt(d2))) / 2 if l1 else torch.mean(d1) + torch.mean(d2)
+    (ref * w).backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+    np.testing.assert_allclose(ga.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * a.grad.abs().max().item())
+    np.testing.assert_allclose(gb.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * b.grad.abs().max().item())
+    from extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
+    mod = (ChamferDistanceL1 if l1 else ChamferDistanceL2)()
+    assert mod(a.detach(), b.detach()).item() == loss.item()           # the modules take the fused node on the HIP path

@@ -319,9 +319,13 @@ def test_rectify_tail_ranks_nan_scores_as_the_largest_like_argsort():
     assert bool(torch.isnan(score[0, 17])) and bool(torch.isnan(score[1, 0]))
     for b in range(B):
         assert sorted(order[b].tolist()) == list(range(N))                      # a permutation
-    assert order[0, :2].tolist() == [17, 200] and order[1, 0].item() == 0          # NaN first in descending order, ties in index order
-    want_order = torch.sort(score, dim=1, descending=True, stable=True)[1]
-    assert torch.equal(order, want_order)
+    assert order[0, :2].tolist() == [17, 200] and order[1, 0].item() == 0          # NaN = the largest: first in descending order, ties in index order
+    # (torch.sort on this ROCm build puts NaN LAST in a descending sort although its documentation ranks NaN above every number: the
+    #  finite part is compared with torch, the NaN rows with the documented rule)
+    for b, nn in ((0, 2), (1, 1)):
+        finite = order[b, nn:]
+        want = torch.sort(score[b][finite.sort()[0]], descending=True, stable=True)[1]
+        assert torch.equal(finite, finite.sort()[0][want])
 
 
 def test_batched_copy_moves_every_tensor_in_one_launch():
@@ -335,3 +339,29 @@ def test_batched_copy_moves_every_tensor_in_one_launch():
     ops.copy_batched(dsts, srcs)
     for d, s in zip(dsts, srcs):
         assert torch.equal(d, s)
+
+
+@pytest.mark.parametrize("B,N,S,C,k", [(32, 32, 32, 384, 6), (8, 1096, 32, 32, 16), (2, 100, 7, 12, 16), (3, 5, 64, 256, 3)])
+def test_interpolation_with_geometry_gradients_equals_the_reference_formulation(B, N, S, C, k):
+    """HF.interp_geo (upp_sqdist_topk + upp_interp_fwd; upp_interp_bwd + upp_interp_geo_bwd) against the reference's autograd chain
+    (models/Point_MAE_unify.py:22-48: square_distance, sort, 1/(d+eps) weights, index_points): output and the gradients w.r.t. the
+    queries, the sources and the features."""
+    from models import upp_layers as L
+    gen = torch.Generator(device='cuda').manual_seed(B * N + S)
+    x1 = torch.rand(B, N, 3, device='cuda', generator=gen).requires_grad_(True)
+    x2 = torch.rand(B, S, 3, device='cuda', generator=gen).requires_grad_(True)
+    f = torch.randn(B, S, C, device='cuda', generator=gen).requires_grad_(True)
+    w = torch.randn(B, N, C, device='cuda', generator=gen)
+    out = L._inverse_distance_interp(x1, x2, f, k, 1e-3)
+    (out * w).sum().backward()
+    got = [out.detach(), x1.grad.clone(), x2.grad.clone(), f.grad.clone()]
+    x1.grad = x2.grad = f.grad = None
+    L.FUSE_INTERP_GEO = False
+    try:
+        ref = L._inverse_distance_interp(x1, x2, f, k, 1e-3)
+        (ref * w).sum().backward()
+    finally:
+        L.FUSE_INTERP_GEO = True
+    want = [ref.detach(), x1.grad, x2.grad, f.grad]
+    for a, b, name in zip(got, want, ("out", "g_xyz1", "g_xyz2", "g_feat")):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * b.abs().max().item(), err_msg=name)
