@@ -237,6 +237,10 @@ def time_kernel(fn, iters=20, warm=3):
     return s.elapsed_time(e) / (iters * reps)
 
 
+DTYPE_NOTE = ("f32 storage, f32 results at f32 accuracy everywhere.  Linear layers with frozen / driver-managed weights: both f32 operands split "
+              "EXACTLY into three bf16 terms, the six products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16, f32 accumulation (error vs float64 "
+              "<= that of the f32 fmaf chain, tests/test_gpu_linear_sb.py); everything else on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 or f32 VALU.  "
+              "UPP_SPLIT_BF16=0 runs every Linear on the exact-f32 MFMA kernels")
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32
 MFMA_BF16_PEAK_TF = 2516.6  # 16 x the f32 rate (v_mfma_f32_32x32x16_bf16: 32 cycles for 16 x the products of a 64-cycle 32x32x2 f32): "~2.5 PF dense"
 
@@ -667,7 +671,7 @@ def main():
             "metric": "point-clouds/sec fwd+bwd, secondary recipe '%s'" % args.workload,
             "value": args.batch * world * args.steps / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "dtype_note": DTYPE_NOTE, "data": "synthetic",
             "config": {"workload": tr.workload, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph,
                        "pipeline": "front-end(k+1) || back-end(k) on two streams" if pipeline else "none"},
@@ -686,7 +690,7 @@ def main():
             "metric": "point-clouds/sec fwd+bwd, UPP/Point-MAE N=1024 G=64 k=32",
             "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "dtype_note": DTYPE_NOTE, "data": "synthetic",
             "rccl_ranks": rccl_ranks, "dist_backend": backend,
             "config": {"workload": "Point_MAE_unify unify_modelnet_cls noisy-train fwd+bwd+AdamW, PEFT stage-1, "
                                    "B=%d/GPU x (1024+72) pts, G=64 k=32" % args.batch,
