@@ -254,11 +254,12 @@ class Point_MAE_unify(PromptedBackbone):
         x = self.blocks(x, pos, path='downstream', downstream_adapter=True, downstream_prompts=True,
                         classification=True, **propagation)
         if (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 512 and x.shape[1] >= 2 and isinstance(self.norm, nn.LayerNorm)
+                and L.POOL_TRACE is None
                 and not (torch.is_grad_enabled() and (self.norm.weight.requires_grad or self.norm.bias.requires_grad))):
             feat = HF.cls_pool(x, self.norm)                   # final LayerNorm + [cls | max over tokens]: one launch each way
         else:
             x = self.norm(x)
-            feat = torch.cat([x[:, 0], x[:, 1:].max(1)[0]], dim=-1)
+            feat = torch.cat([x[:, 0], L.max_over(x[:, 1:], 1, 'cls.max')], dim=-1)
         return self._cls_head(feat)
 
     def _cls_head(self, feat):

@@ -11,6 +11,10 @@ def fps(data, number):
     transposed copy and transposes back; here the sampled coordinates come out of the FPS
     kernel itself (same values: a gather is an exact copy)."""
     fps_data, fps_idx = _F.fps_gather(data.contiguous(), number)
+    from models import upp_layers as L
+    if L.POOL_TRACE is not None:          # (test instrument, see upp_layers.trace_idx)
+        fps_idx = L.trace_idx('misc.fps', fps_idx)
+        fps_data = L.index_points(data, fps_idx.long())
     return fps_data, fps_idx
 
 
