@@ -105,12 +105,18 @@ SIGNATURES = {
     "upp_linear_wgrad_grouped_f32": (_c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p),
                                             ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p)] + [ctypes.POINTER(ctypes.c_int)] * 4
                                      + [_c_i, _c_f]),
+    "upp_linear_wgrad_grouped_sb": (_c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p),
+                                            ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p)] + [ctypes.POINTER(ctypes.c_int)] * 4
+                                     + [_c_i, _c_f]),
     "upp_linear_wgrad_splits": (_c_i, [_c_i, _c_i, _c_i]),
     "upp_linear_wgrad_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_i, _c_i, _c_f]),
     "upp_adamw_flat": (_c_i, [_c_f] * 4 + [ctypes.c_longlong] * 2 + [_c_f] * 2 + [ctypes.c_float] * 6 + [_c_f]),
 }
 
 _lib = None
+
+
+ABI_VERSION = 3            # include/upp_hip.h UPP_ABI_VERSION
 
 
 def load():
@@ -127,7 +133,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError -> loud failure on a stale build
         fn.restype = res
         fn.argtypes = args
-    if lib.upp_abi_version() != 3:
+    if lib.upp_abi_version() != ABI_VERSION:
         raise RuntimeError("libupp_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libupp_hip.so")
-SOURCES = ["abi.hip", "fps.hip", "knn.hip", "group.hip", "chamfer.hip", "emd.hip", "dense.hip", "linear.hip", "linear_sb.hip", "linear_rt.hip", "smallk.hip", "block.hip", "prop.hip", "optim.hip", "attn_flash16.hip", "attn_long.hip", "adapter.hip", "pointwise.hip", "head.hip"]
+SOURCES = ["abi.hip", "fps.hip", "knn.hip", "group.hip", "chamfer.hip", "emd.hip", "dense.hip", "linear.hip", "linear_sb.hip", "linear_rt.hip", "wgrad_sb.hip", "smallk.hip", "block.hip", "prop.hip", "optim.hip", "attn_flash16.hip", "attn_long.hip", "adapter.hip", "pointwise.hip", "head.hip"]
 # -ffp-contract=off: every fma in the kernels is written explicitly so that the
 # arithmetic matches the oracle bit for bit (see csrc/common.h sumsq3()).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",

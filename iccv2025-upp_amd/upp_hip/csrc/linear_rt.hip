@@ -304,17 +304,6 @@ int launch_rt(const LinArgs &g0, hipStream_t st) {
 // the rows), so a lane's MFMA operands are dwords of one LDS row: with ds_read_b64 lane r takes columns 2r, 2r+1 -- the wave's
 // two blocks are the even and the odd columns of its 64 -- one read per operand and row pair, conflict-free without a swizzle.
 // Every output is ONE ascending-row fmaf chain per split: fma(g[m+1], x[m+1], fma(g[m], x[m], acc)).
-constexpr int kMaxWgProblems = 40;
-struct WgGroup {
-    const float *G[kMaxWgProblems], *X[kMaxWgProblems];
-    float *P[kMaxWgProblems];                     // (splits, N, K) partial gradients
-    int ldg[kMaxWgProblems], ldx[kMaxWgProblems];
-    int M[kMaxWgProblems], N[kMaxWgProblems], K[kMaxWgProblems];
-    int rows[kMaxWgProblems];                     // rows of G / X per split (a multiple of 32)
-    int tiles_k[kMaxWgProblems], tiles[kMaxWgProblems];
-    int unit0[kMaxWgProblems + 1];                // first work unit of each problem; unit = unit0 + split * tiles + tile
-};
-
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(WgGroup g) {
     constexpr int BT = 128;                         // tile edge (N and K direction)
     constexpr int PART = 32 * BT * 4;               // 32 rows x 128 columns of one operand

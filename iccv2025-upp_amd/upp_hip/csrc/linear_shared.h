@@ -28,6 +28,18 @@ struct LinArgs {
 #endif
 };
 
+// Work list of the grouped weight-gradient kernels (linear_rt.hip wgrad_grouped_kernel: exact f32; wgrad_sb.hip: split bf16)
+constexpr int kMaxWgProblems = 40;
+struct WgGroup {
+    const float *G[kMaxWgProblems], *X[kMaxWgProblems];
+    float *P[kMaxWgProblems];                     // (splits, N, K) partial gradients
+    int ldg[kMaxWgProblems], ldx[kMaxWgProblems];
+    int M[kMaxWgProblems], N[kMaxWgProblems], K[kMaxWgProblems];
+    int rows[kMaxWgProblems];                     // rows of G / X per split (a multiple of 32)
+    int tiles_k[kMaxWgProblems], tiles[kMaxWgProblems];
+    int unit0[kMaxWgProblems + 1];                // first work unit of each problem; unit = unit0 + split * tiles + tile
+};
+
 #ifdef UPP_LIN_STAMPS
 unsigned long long *g_lin_stamps = nullptr;
 #define UPP_STAMP(slot)                                                                                   \

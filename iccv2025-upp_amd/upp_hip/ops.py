@@ -565,6 +565,8 @@ def linear_wgrad(g, x):
     K = x.shape[1]
     if x.shape[0] != M:
         raise RuntimeError("linear_wgrad: row counts differ")
+    if SPLIT_BF16 and WGRAD_SPLIT_BF16:
+        return linear_wgrad_grouped([(g, x)])[0]
     splits = _abi.load().upp_linear_wgrad_splits(M, N, K)
     part = torch.empty((splits, N, K), dtype=torch.float32, device=g.device)
     _call(g.device, "upp_linear_wgrad_f32", _abi.ptr(g), g.stride(0), _abi.ptr(x), x.stride(0), _abi.ptr(part), M, N, K)
@@ -616,6 +618,9 @@ def linear_group_bias(a, w, bias, rows_per_group, frozen=False, planes=None):
     return out
 
 
+WGRAD_SPLIT_BF16 = os.environ.get("UPP_WGRAD_SPLIT_BF16", "1") != "0"     # grouped weight gradients on the bf16 pipe (wgrad_sb.hip)
+
+
 def linear_wgrad_grouped(pairs):
     """pairs: list of (g (M,N), x (M,K)) -- the weight gradients of several Linear layers in ONE launch (upp_linear_wgrad_grouped_f32).
     -> list of partial gradients (splits_p, N_p, K_p); the caller sums each over dim 0 in order (batched_sum)."""
@@ -641,7 +646,7 @@ def linear_wgrad_grouped(pairs):
     P = (ctypes.c_void_p * k)(*[q.data_ptr() for q in parts])
     ldg = (ctypes.c_longlong * k)(*[g.stride(0) for g, _ in pairs])
     ldx = (ctypes.c_longlong * k)(*[x.stride(0) for _, x in pairs])
-    _call(dev, "upp_linear_wgrad_grouped_f32", G, ldg, X, ldx, P, M, N, K, rows, k)
+    _call(dev, "upp_linear_wgrad_grouped_sb" if (SPLIT_BF16 and WGRAD_SPLIT_BF16) else "upp_linear_wgrad_grouped_f32", G, ldg, X, ldx, P, M, N, K, rows, k)
     if time_linear_calls.active is not None:
         time_linear_calls.active.wgrad_groups.append([(M[i], N[i], K[i]) for i in range(k)])
     return parts
