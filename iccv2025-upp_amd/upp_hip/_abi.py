@@ -102,6 +102,7 @@ SIGNATURES = {
     "upp_transpose_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_f]),
     "upp_transpose_batched_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f]),
     "upp_linear_wgrad_grouped_rows": (_c_i, [_c_i] + [ctypes.POINTER(ctypes.c_int)] * 4),
+    "upp_linear_wgrad_grouped_sb_rows": (_c_i, [_c_i] + [ctypes.POINTER(ctypes.c_int)] * 4),
     "upp_linear_wgrad_grouped_f32": (_c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p),
                                             ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p)] + [ctypes.POINTER(ctypes.c_int)] * 4
                                      + [_c_i, _c_f]),

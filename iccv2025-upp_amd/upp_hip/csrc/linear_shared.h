@@ -38,6 +38,7 @@ struct WgGroup {
     int rows[kMaxWgProblems];                     // rows of G / X per split (a multiple of 32)
     int tiles_k[kMaxWgProblems], tiles[kMaxWgProblems];
     int unit0[kMaxWgProblems + 1];                // first work unit of each problem; unit = unit0 + split * tiles + tile
+    int tr[kMaxWgProblems];                       // wgrad_sb.hip: G and X were handed over swapped, the tile is stored transposed (P stays (splits, N, K))
 };
 
 #ifdef UPP_LIN_STAMPS

@@ -639,14 +639,15 @@ def linear_wgrad_grouped(pairs):
     N = (ctypes.c_int * k)(*[g.shape[1] for g, _ in pairs])
     K = (ctypes.c_int * k)(*[x.shape[1] for _, x in pairs])
     rows = (ctypes.c_int * k)()
-    _abi.check(_abi.load().upp_linear_wgrad_grouped_rows(k, M, N, K, rows))
+    sb = SPLIT_BF16 and WGRAD_SPLIT_BF16
+    _abi.check((_abi.load().upp_linear_wgrad_grouped_sb_rows if sb else _abi.load().upp_linear_wgrad_grouped_rows)(k, M, N, K, rows))
     parts = [torch.empty(((M[i] + rows[i] - 1) // rows[i], N[i], K[i]), dtype=torch.float32, device=dev) for i in range(k)]
     G = (ctypes.c_void_p * k)(*[g.data_ptr() for g, _ in pairs])
     X = (ctypes.c_void_p * k)(*[x.data_ptr() for _, x in pairs])
     P = (ctypes.c_void_p * k)(*[q.data_ptr() for q in parts])
     ldg = (ctypes.c_longlong * k)(*[g.stride(0) for g, _ in pairs])
     ldx = (ctypes.c_longlong * k)(*[x.stride(0) for _, x in pairs])
-    _call(dev, "upp_linear_wgrad_grouped_sb" if (SPLIT_BF16 and WGRAD_SPLIT_BF16) else "upp_linear_wgrad_grouped_f32", G, ldg, X, ldx, P, M, N, K, rows, k)
+    _call(dev, "upp_linear_wgrad_grouped_sb" if sb else "upp_linear_wgrad_grouped_f32", G, ldg, X, ldx, P, M, N, K, rows, k)
     if time_linear_calls.active is not None:
         time_linear_calls.active.wgrad_groups.append([(M[i], N[i], K[i]) for i in range(k)])
     return parts

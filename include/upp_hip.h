@@ -495,6 +495,7 @@ int upp_linear_wgrad_grouped_f32(const float *const *G, const long long *ldg, co
 /* upp_linear_wgrad_grouped_sb (round 4): the same work list, limits and partial layout on the BF16 matrix pipe -- both operands split
  * into three bf16 terms inside the kernel, six products per pair as upp_linear_sb_f32 (error of an f32 GEMM against float64; each entry a
  * fixed-order sum, not bit-comparable with the f32 chain).  csrc/wgrad_sb.hip. */
+int upp_linear_wgrad_grouped_sb_rows(int count, const int *M, const int *N, const int *K, int *rows);   /* its plan of rows[] (tile classes) */
 int upp_linear_wgrad_grouped_sb(const float *const *G, const long long *ldg, const float *const *X, const long long *ldx,
                                 float *const *partials, const int *M, const int *N, const int *K, const int *rows,
                                 int count, void *stream);

@@ -137,9 +137,18 @@ def test_strided_rows_and_rejections():
     assert lib.upp_linear_f32(a.data_ptr(), 384, w.data_ptr(), 384, None, a.data_ptr(), 96, None, 0, 4, 96, 384, 0, 0x9999, None) == -2
 
 
+@pytest.fixture
+def exact_wgrad():
+    """The bit-pinned weight-gradient kernel (linear_rt.hip); the default since round 4 is the split-bf16 one (tests/test_gpu_linear_sb.py)."""
+    saved = ops.WGRAD_SPLIT_BF16
+    ops.WGRAD_SPLIT_BF16 = False
+    yield
+    ops.WGRAD_SPLIT_BF16 = saved
+
+
 @pytest.mark.parametrize("shape", [(2400, 1152, 384), (2400, 384, 1536), (65536, 384, 512), (75, 40, 96), (1, 4, 4), (33, 256, 128),
                                    (4160, 1536, 384), (1000, 132, 36)])
-def test_weight_gradient_partials_sum_to_the_product(shape):
+def test_weight_gradient_partials_sum_to_the_product(shape, exact_wgrad):
     """upp_linear_wgrad_f32: dW = G^T . X, rows split over workgroups, partial tiles summed in split order."""
     import oracle as O
     M, N, K = shape
@@ -163,7 +172,7 @@ def test_weight_gradient_partials_sum_to_the_product(shape):
     close(part2.sum(0), wide[:, 4:4 + N].t() @ X, atol_scale=5e-6)
 
 
-def test_grouped_weight_gradients_equal_the_single_launches_and_the_oracle():
+def test_grouped_weight_gradients_equal_the_single_launches_and_the_oracle(exact_wgrad):
     """upp_linear_wgrad_grouped_f32: the weight gradients of a backward pass in one launch -- mixed shapes, ragged edges, strided
     operands; every partial bit for bit the CPU restatement (one ascending-row fmaf chain per run of rows)."""
     import oracle as O
@@ -219,7 +228,7 @@ def test_patch_embedding_with_a_gradient_runs_on_our_kernels_and_matches_torch_a
         out.backward(gy)
     torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages()]
-    assert any('linear_f32_kernel' in k for k in names) and (not trainable or any('wgrad_grouped_kernel' in k for k in names))
+    assert any('linear_f32_kernel' in k for k in names) and (not trainable or any('wgrad_grouped_kernel' in k or 'wgrad_sb_kernel' in k for k in names))
     assert not any(k.startswith('Cijk') for k in names), [k for k in names if k.startswith('Cijk')]
     got = {'x': pg.grad.clone()}
     got.update({n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None})

@@ -231,3 +231,64 @@ def test_trainable_weights_take_the_split_kernel_inside_a_step_driver_only():
     finally:
         ops.PLANES.managed = False
         ops.PLANES.trainable.clear()
+
+
+# ------------------------------------------------------------------ weight gradients on the bf16 pipe (csrc/wgrad_sb.hip)
+def _wgrad(pairs, split):
+    from upp_hip import ops
+    saved = ops.WGRAD_SPLIT_BF16
+    ops.WGRAD_SPLIT_BF16 = split
+    try:
+        return [p.sum(0) if p.shape[0] > 1 else p[0] for p in ops.linear_wgrad_grouped(pairs)]
+    finally:
+        ops.WGRAD_SPLIT_BF16 = saved
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 200, 132), (5, 4, 4), (33, 36, 260), (4096, 128, 128), (1031, 384, 96), (20000, 52, 256),
+                                   (140000, 256, 260),          # wide tiles (256 x 256), ragged in K
+                                   (70000, 132, 380),           # 128 x 384 tiles
+                                   (70000, 1152, 136),          # 384 x 128: operands swapped, tile stored transposed
+                                   (300, 384, 384)])            # eligible, but not a round of wide units: 128 x 128 tiles
+def test_wgrad_sb_is_exact_on_small_integers(M, N, K):
+    """Integer operands of a few bits: every bf16 term, product and f32 partial sum is exact, so the transposed fragment reads, the
+    operand maps, the row masks of the last step, the clamped columns of partial tiles and the split order are all checked bit for bit."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    g = torch.randint(-7, 8, (M, N), generator=gen).float().cuda()
+    x = torch.randint(-7, 8, (M, K), generator=gen).float().cuda()
+    (dw,) = _wgrad([(g, x)], True)
+    want = (g.double().t() @ x.double()).float()
+    assert torch.equal(dw, want)
+
+
+def test_wgrad_sb_group_and_strided_operands():
+    """A group of three problems in one launch, operands that are column slices of wider matrices (leading dimensions > widths)."""
+    gen = torch.Generator().manual_seed(11)
+    big = torch.randint(-5, 6, (900, 640), generator=gen).float().cuda()
+    pairs = [(big[:, :256], big[:, 256:640]), (big[:513, 4:68], big[:513, 100:228]), (big[:64, 8:12], big[:64, 320:352])]
+    got = _wgrad(pairs, True)
+    for (g, x), dw in zip(pairs, got):
+        assert torch.equal(dw, (g.double().t() @ x.double()).float())
+
+
+def test_wgrad_sb_error_is_that_of_the_f32_kernel():
+    """Random operands with a wide dynamic range: error against float64 in units of sum |g| |x|, beside the exact-f32 kernel's."""
+    gen = torch.Generator().manual_seed(5)
+    M, N, K = 8192, 256, 384
+    g = (torch.randn(M, N, generator=gen) * torch.exp(2 * torch.randn(M, 1, generator=gen))).cuda()
+    x = (torch.randn(M, K, generator=gen) * torch.exp(2 * torch.randn(1, K, generator=gen))).cuda()
+    (sb,), (f32,) = _wgrad([(g, x)], True), _wgrad([(g, x)], False)
+    want = g.double().t() @ x.double()
+    scale = g.double().abs().t() @ x.double().abs()
+    e_sb, e_f32 = ((sb.double() - want).abs() / scale).max().item(), ((f32.double() - want).abs() / scale).max().item()
+    print("wgrad error / sum |g||x|: split bf16 %.2e, exact f32 %.2e" % (e_sb, e_f32))
+    assert e_sb <= 6e-7 and e_sb <= 3 * e_f32 + 1e-7
+
+
+def test_wgrad_sb_special_values_and_determinism():
+    gen = torch.Generator().manual_seed(6)
+    g, x = torch.randn(3000, 132, generator=gen).cuda(), torch.randn(3000, 200, generator=gen).cuda()
+    a, b = _wgrad([(g, x)], True)[0], _wgrad([(g, x)], True)[0]
+    assert torch.equal(a, b)
+    g[17, 5] = float('inf')
+    dw = _wgrad([(g, x)], True)[0]
+    assert not torch.isfinite(dw[5]).any() and torch.isfinite(dw[6]).all()
