@@ -15,6 +15,7 @@
 // Each output is a fixed-order sum (rows ascending in steps of 16, six products per step): deterministic, not bit-comparable with a
 // scalar chain -- parity by tolerance against float64 like linear_sb.hip (tests/test_gpu_linear_sb.py); the exact-f32 kernel stays.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -44,6 +45,14 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2 &p1, u32x2 &p2, u32x
         const uint32_t v = pack_bf16(r0, r1);
         const float t0 = r0 - __uint_as_float(v << 16), t1 = r1 - __uint_as_float(v & 0xFFFF0000u);
         p1[q] = u; p2[q] = v; p3[q] = pack_bf16(t0, t1);
+    }
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
     }
 }
 
@@ -130,21 +139,91 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void wgrad_sb_kernel(WgGroup g) 
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[a][b][t] = 0.0f;
 
-    auto step = [&](int sb) {
-        s16x8 fg[BA][3], fx[BB][3];
+    // One step, in issue order (pinned: a sched_barrier behind every MFMA slot).  Plane 1 of the step's fragments is in registers when it
+    // starts; the products run in the order g1 x1, g1 x2 | g2 x1, g1 x3, g3 x1 | g2 x2:
+    //   behind the first 2 NB MFMAs  the reads of planes 2 and 3 of stage c & 1;
+    //   behind the next 3 NB          the split of step c + 1 (three dependent stages per pair of values), its LDS writes into the other
+    //                                 stage and the loads of step c + 2, in chunks;
+    //   the step's ONE barrier        (every wave has read stage c & 1 and written stage (c + 1) & 1: the writes of the next step go to
+    //                                 stage c & 1 again, behind it);
+    //   behind the last NB (g2 x2)    the reads of plane 1 of step c + 1, into the registers the first five products are done with.
+    s16x8 fg[BA][3], fx[BB][3];
+    auto body = [&](int c, auto st_c, auto ld_c) {
+        constexpr bool ST = decltype(st_c)::value, LD = decltype(ld_c)::value;
+        constexpr int NB = BA * BB, NF = BA + BB, NP = 2 * PASSES, NC = 7 * PASSES + 1, NS = 5 * NB;
+        const int sb = (c & 1) * STAGE, sn = ((c + 1) & 1) * STAGE;
+        auto read_frag = [&](int stage_off, auto plc, auto fc) {
+            constexpr int pl = decltype(plc)::value, f = decltype(fc)::value;
+            if constexpr (f < BA) fg[f][pl] = frag(rG, stage_off + pl * PLANE + f * 64);
+            else fx[f - BA][pl] = frag(rX, stage_off + pl * PLANE + (f - BA) * 64);
+        };
+        float x0[NP], x1[NP];
+        uint32_t pu[NP], pv[NP], pw[NP], live[PASSES];
+        if constexpr (ST) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-            for (int a = 0; a < BA; ++a) fg[a][pl] = frag(rG, sb + pl * PLANE + a * 64);
-#pragma unroll
-            for (int b = 0; b < BB; ++b) fx[b][pl] = frag(rX, sb + pl * PLANE + b * 64);
+            for (int i = 0; i < PASSES; ++i) live[i] = ms + 16 * (c + 1) + rg + RPP * i < me ? 0xFFFFFFFFu : 0u;
         }
-#define WS_MFMA(GP, XP) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fg[a][GP]), __builtin_bit_cast(bf16x8, fx[b][XP]), acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int a = 0; a < BA; ++a)
-#pragma unroll
-            for (int b = 0; b < BB; ++b) { WS_MFMA(2, 0) WS_MFMA(0, 2) WS_MFMA(1, 1) WS_MFMA(1, 0) WS_MFMA(0, 1) WS_MFMA(0, 0) }
-#undef WS_MFMA
+        char *wb = wbase + sn;
+        // chunks: 2 PASSES first stages (they consume `raw`), the loads of step c + 2 (a whole step ahead of their use), then per 16-byte
+        // piece the second and third stages of its two pairs and its three LDS writes
+        auto chunk = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k == NP) {
+                if constexpr (LD) load(c + 2);
+            } else if constexpr (ST) {
+                if constexpr (k < NP) {                        // rows beyond the run: zeros (bitwise: the clamped row may hold anything)
+                    constexpr int j = k, i = j / 2, e = 2 * (j & 1);
+                    const float a0 = __uint_as_float(__float_as_uint(raw[i][e]) & live[i]);
+                    const float a1 = __uint_as_float(__float_as_uint(raw[i][e + 1]) & live[i]);
+                    pu[j] = pack_bf16(a0, a1);
+                    x0[j] = a0 - __uint_as_float(pu[j] << 16); x1[j] = a1 - __uint_as_float(pu[j] & 0xFFFF0000u);
+                } else {
+                    constexpr int i = (k - NP - 1) / 5, q = (k - NP - 1) % 5;
+                    if constexpr (q == 4) {
+                        *reinterpret_cast<u32x2 *>(wb + RPP * i * PITCH) = u32x2{pu[2 * i], pu[2 * i + 1]};
+                        *reinterpret_cast<u32x2 *>(wb + RPP * i * PITCH + PLANE) = u32x2{pv[2 * i], pv[2 * i + 1]};
+                        *reinterpret_cast<u32x2 *>(wb + RPP * i * PITCH + 2 * PLANE) = u32x2{pw[2 * i], pw[2 * i + 1]};
+                    } else {
+                        constexpr int j = 2 * i + (q & 1);
+                        if constexpr (q < 2) {
+                            pv[j] = pack_bf16(x0[j], x1[j]);
+                            x0[j] -= __uint_as_float(pv[j] << 16); x1[j] -= __uint_as_float(pv[j] & 0xFFFF0000u);
+                        } else {
+                            pw[j] = pack_bf16(x0[j], x1[j]);
+                        }
+                    }
+                }
+            }
+        };
+        static_for<0, 6 * NB>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int pr = m / NB, blk = m % NB, a = blk / BB, b = blk % BB;
+            constexpr int gp = pr == 0 ? 0 : pr == 1 ? 0 : pr == 2 ? 1 : pr == 3 ? 0 : pr == 4 ? 2 : 1;
+            constexpr int xp = pr == 0 ? 0 : pr == 1 ? 1 : pr == 2 ? 0 : pr == 3 ? 2 : pr == 4 ? 0 : 1;
+            if constexpr (m == 5 * NB) {
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifndef UPP_WS_NO_MFMA        // (diagnostic builds, tools/micro/ws_ablate.sh: wrong results)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fg[a][gp]), __builtin_bit_cast(bf16x8, fx[b][xp]), acc[a][b], 0, 0, 0);
+#else
+            acc[a][b][m % 16] += __builtin_bit_cast(float, (int)fg[a][gp][m % 8] | ((int)fx[b][xp][m % 8] << 16));
+#endif
+            constexpr int sl = m % NB;
+#ifndef UPP_WS_NO_READS
+            if constexpr (m < 2 * NB) {                     // the reads of plane 2 (m < NB), then of plane 3
+                static_for<sl * NF / NB, (sl + 1) * NF / NB>([&](auto fc) { read_frag(sb, std::integral_constant<int, 1 + m / NB>{}, fc); });
+            }
+#endif
+            if constexpr (m < 5 * NB) {
+#ifndef UPP_WS_NO_SPLIT
+                static_for<m * NC / NS, (m + 1) * NC / NS>([&](auto kc) { chunk(kc); });
+#endif
+            } else if constexpr (ST) {                      // plane 1 of the next step
+                static_for<sl * NF / NB, (sl + 1) * NF / NB>([&](auto fc) { read_frag(sn, std::integral_constant<int, 0>{}, fc); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
 
     if (nst > 0) {
@@ -152,14 +231,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void wgrad_sb_kernel(WgGroup g) 
         split_store(0);
         if (nst > 1) load(1);
         __syncthreads();
-        for (int c = 0; c < nst; ++c) {
-            if (c + 1 < nst) {
-                split_store(c + 1);                     // (stage (c + 1) & 1 was last read in step c - 1, behind that step's barrier)
-                if (c + 2 < nst) load(c + 2);
-            }
-            step((c & 1) * STAGE);
-            __syncthreads();
-        }
+        static_for<0, BA + BB>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (f < BA) fg[f][0] = frag(rG, f * 64);
+            else fx[f - BA][0] = frag(rX, (f - BA) * 64);
+        });
+        int c = 0;
+        for (; c + 2 < nst; ++c) body(c, std::true_type{}, std::true_type{});
+        if (c + 1 < nst) { body(c, std::true_type{}, std::false_type{}); ++c; }
+        body(c, std::false_type{}, std::false_type{});
     }
 
     // ---- partial tile: block (a, b) register t = dW[n][k], n = n0 + 32 (wm BA + a) + (t & 3) + 8 (t >> 2) + 4 h, k = k0 + 32 (wn BB + b) + r
