@@ -355,7 +355,7 @@ struct SbConfig { int bmb, bnb, rn, ks, nst; };
 #ifndef UPP_SB_NST44
 #define UPP_SB_NST44 3
 #endif
-#define UPP_SB_CONFIGS(X) X(4, 4, 2, 1, UPP_SB_NST44) X(4, 3, 1, 1, 4) X(3, 4, 2, 1, 4) X(2, 4, 2, 1, 4) X(2, 3, 1, 1, 4) X(2, 2, 1, 2, 3) X(2, 2, 2, 4, 2) X(1, 2, 1, 2, 4)
+#define UPP_SB_CONFIGS(X) X(8, 4, 2, 1, 2) X(4, 4, 2, 1, UPP_SB_NST44) X(4, 3, 1, 1, 4) X(3, 4, 2, 1, 4) X(2, 4, 2, 1, 4) X(2, 3, 1, 1, 4) X(2, 2, 1, 2, 3) X(2, 2, 2, 4, 2) X(1, 2, 1, 2, 4)
 #define UPP_SB_ENTRY(a, b, c, d, e) {a, b, c, d, e},
 constexpr SbConfig kSbConfigs[] = {UPP_SB_CONFIGS(UPP_SB_ENTRY)};
 #undef UPP_SB_ENTRY
@@ -376,6 +376,7 @@ int pick_sb(int M, int N, int K) {
         if (K % (32 * c.ks) != 0 || K / (32 * c.ks) < c.nst) continue;          // (every LDS stage is filled before the loop starts)
         const long long wgs = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
         const long long rounds = (wgs + 255) / 256;
+        if (c.bmb == 8 && wgs < 192) continue;                   // (the 256-row tile: tall matrices only -- 16 waves per workgroup, two LDS stages)
         if (rounds > 1 && c.bmb * c.bnb < 12) continue;          // (several rounds: the big tiles only -- one workgroup per CU, prologue and store burst per round)
         const int waves = c.bmb * (c.bnb / c.rn) * c.ks;
         const long long mfma = (long long)((waves + 3) / 4) * c.rn * (K / c.ks / 16) * 192;
