@@ -112,6 +112,8 @@ class PromptedBackbone(nn.Module):
         _, rebuild = self._reconstruct(self.encoder(neighborhood), vis_center)
         self.aux['rebuild_points'] = rebuild          # (B, n_masked * group_size, 3): what a reconstruction loss would look at
         sampled, _ = misc.fps(rebuild, point_num // 4)
+        if L.DIAG_AUX:
+            self.aux['dbg_vis_center'], self.aux['dbg_sampled'] = vis_center, sampled
         pts = torch.cat([pts, sampled], dim=1).contiguous()
         if pts.shape[1] > point_num:
             pts = misc.fps(pts, point_num)[0]

@@ -82,6 +82,8 @@ class Point_MAE_unify_seg(PromptedBackbone):
         grouping -> (prompted pts, tokens, centres, pos[, centre2, centre1_idx, centre2_idx])."""
         if denoise:
             pts = self._rectify(pts, point_num)
+            if L.DIAG_AUX:
+                self.aux['dbg_rectified'] = pts
         if completion_prompt:
             pts = self._complete(pts, point_num)
         neighborhood, center = self.group_divider(pts)

@@ -7,6 +7,7 @@ Conv1d/transposes.  file:line citations point into the reference repository.
 """
 import math
 
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -214,6 +215,7 @@ def propagate(xyz1, xyz2, points1, points2, de_neighbors=64, dist_e=1e-8):
     return points1 + 0.3 * _inverse_distance_interp(xyz1, xyz2, points2, de_neighbors, dist_e)
 
 
+DIAG_AUX = bool(os.environ.get('UPP_DIAG_AUX'))       # (diagnostic: models keep front-end intermediates in .aux -- tools/micro/pipe_race_probe.py)
 POOL_TRACE = None          # test instrument (tests/test_gpu_model.py): {'mode': 'record' | 'replay', 'items': [...]} -- see max_over
 
 

@@ -17,8 +17,13 @@ LIB = os.path.join(LIB_DIR, "libupp_hip.so")
 SOURCES = ["abi.hip", "fps.hip", "knn.hip", "group.hip", "chamfer.hip", "emd.hip", "dense.hip", "linear.hip", "linear_sb.hip", "linear_rt.hip", "wgrad_sb.hip", "smallk.hip", "block.hip", "prop.hip", "optim.hip", "attn_flash16.hip", "attn_long.hip", "adapter.hip", "pointwise.hip", "head.hip"]
 # -ffp-contract=off: every fma in the kernels is written explicitly so that the
 # arithmetic matches the oracle bit for bit (see csrc/common.h sumsq3()).
+# -target-feature -packed-fp32-ops: no v_pk_add/mul/fma_f32 in any kernel.  Measured on MI355X (tools/micro/src/lds_canary.cpp, round 4):
+# v_pk_add_f32 with op_sel:[0,1] on a VGPR pair returns a - 0 in its low half every so often while a split-bf16 Linear workgroup
+# (v_mfma_f32_32x32x16_bf16, 128 KB of LDS) is resident on the same CU -- never on an idle CU.  The FPS round loop used that form and
+# picked other points beside the back-end of the pipelined step; hipcc also SLP-packs plain f32 arithmetic of other kernels into it.
+# (the x86 pass of hipcc warns that it does not know the feature)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _hipcc():

@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void moments3_kernel(const float *__restrict__
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(int C, double count, const float *stat_part, int slabs, const double *mom,
                                                           const float *w, const float *b, const float *gamma, float *rmean, float *rvar,
-                                                          float momentum, float eps, int training, float *out_mean, float *out_a) {
+                                                          float momentum, float eps, int training, float *out_mean, float *out_a,
+                                                          const float *beta = nullptr, float *out_shift = nullptr) {
     // 16 channels per workgroup; the 16 thread-rows split the slab partials, then sum in row order (deterministic)
     __shared__ double rs[16][16], rq[16][16];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int C, double count, c
     }
     out_mean[c] = (float)mean;
     out_a[c] = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+    if (out_shift) out_shift[c] = (float)((double)beta[c] - mean * (double)out_a[c]);      // relu((h - mean) a + beta) = relu(h a + shift)
 }
 
 template <int PRO, int EPI>
@@ -310,19 +312,25 @@ void launch_gemm(const GemmArgs &g, hipStream_t st) {
 }
 
 struct EmbedWork {
-    float *f, *h3, *fg, *hg, *mean1, *a1, *mean3, *a3, *part3;
+    float *f, *h3, *fg, *hg, *mean1, *a1, *mean3, *a3, *part3, *shift3;
+    unsigned char *planes3, *planes4;       // split-bf16 images of W3[:, 256:] and W4 (linear_sb.hip), rebuilt by every call
     double *mom;
 };
 inline size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
 inline size_t slabs_of(int R) { return (size_t)((R + BM - 1) / BM) * 2; }
+inline size_t stat_floats(int R) { return align64((size_t)2 * ((R + 31) / 32) * 512); }     // (per 32-row block: the split-bf16 chain; >= the 64-row slabs of this file's kernel)
+constexpr int kMaxEmbedC = 1024;
+inline size_t plane_floats(int N, int K) { return align64((size_t)((N + 31) / 32) * ((K + 31) / 32) * 6144 / 4); }
 inline EmbedWork carve_embed(float *w, int R, int n) {
     EmbedWork k;
     const size_t G = (size_t)R / n;
     size_t o = 0;
     k.mom = reinterpret_cast<double *>(w + o); o += 32;            // 16 doubles
-    k.part3 = w + o; o += align64((size_t)2 * slabs_of(R) * 512);
+    k.part3 = w + o; o += stat_floats(R);
     k.mean1 = w + o; o += 128;  k.a1 = w + o; o += 128;
-    k.mean3 = w + o; o += 512;  k.a3 = w + o; o += 512;
+    k.mean3 = w + o; o += 512;  k.a3 = w + o; o += 512;  k.shift3 = w + o; o += 512;
+    k.planes3 = reinterpret_cast<unsigned char *>(w + o); o += plane_floats(512, 256);
+    k.planes4 = reinterpret_cast<unsigned char *>(w + o); o += plane_floats(kMaxEmbedC, 512);
     k.fg = w + o; o += align64(G * 256);
     k.hg = w + o; o += align64(G * 512);
     k.f = w + o; o += align64((size_t)R * 256);
@@ -332,10 +340,17 @@ inline EmbedWork carve_embed(float *w, int R, int n) {
 
 }  // namespace
 
+extern "C" int upp_linear_sb_prep_batched(const float *const *W, const long long *ldw, const int *N, const int *K, const int *transposed,
+                                          void *const *planes, int count, void *stream);
+__attribute__((visibility("hidden"))) int upp_detail_linear_sb_chain(const float *A, long long lda, const void *planes, const float *bias, int bias_shift,
+                                                                     float *C, long long ldc, int M, int N, int K, const float *pro_scale,
+                                                                     const float *pro_shift, float *gmax, int ldgmax, int gshift, float *stat_part,
+                                                                     void *stream);
+
 extern "C" long long upp_patch_embed_work_floats(int R, int n) {
     if (R <= 0 || n <= 0) return 0;
     const size_t G = (size_t)R / n;
-    return (long long)(32 + align64((size_t)2 * slabs_of(R) * 512) + 256 + 1024 + align64(G * 256) + align64(G * 512) +
+    return (long long)(32 + stat_floats(R) + 256 + 1536 + plane_floats(512, 256) + plane_floats(kMaxEmbedC, 512) + align64(G * 256) + align64(G * 512) +
                        align64((size_t)R * 256) + align64((size_t)R * 512));
 }
 
@@ -378,7 +393,28 @@ extern "C" int upp_patch_embed_fwd(const float *pts, int R, int n, const float *
         const int rc = upp_linear_f32(k.fg, 256, w3, 512, b3, k.hg, 512, nullptr, 0, G, 512, 256, /*LEPI_BIAS*/ 1, 0, stream);
         if (rc) return rc;
     }
-    // h3 = f . W3[:, 256:]^T + hg[group] ; BN3 statistics
+    // h3 = f . W3[:, 256:]^T + hg[group] ; BN3 statistics ;  out = group max( relu(bn3(h3)) . W4^T + b4 )
+    const char *env = getenv("UPP_EMBED_SPLIT_BF16");       // (read per call: tests switch between the two chains inside one process)
+    const bool split_bf16 = !(env && env[0] == '0');
+    if (split_bf16 && C <= kMaxEmbedC) {
+        // the two large products on the BF16 matrix pipe (linear_sb.hip: f32 operands split into three bf16 terms, six products; error of an
+        // f32 GEMM), with this chain's fusions as that kernel's prologue / epilogues: 100 -> 180-200 TFLOP/s on 65,536 rows
+        const float *ws[2] = {w3 + 256, w4};
+        const long long ldws[2] = {512, 512};
+        const int ns[2] = {512, C}, ks[2] = {256, 512}, trs[2] = {0, 0};
+        void *pls[2] = {k.planes3, k.planes4};
+        int rc = upp_linear_sb_prep_batched(ws, ldws, ns, ks, trs, pls, 2, stream);
+        if (rc) return rc;
+        const int gshift = n == 16 ? 4 : 5;
+        rc = upp_detail_linear_sb_chain(k.f, 256, k.planes3, k.hg, gshift, k.h3, 512, R, 512, 256, nullptr, nullptr, nullptr, 0, 0,
+                                        training ? k.part3 : nullptr, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(32), dim3(256), 0, st, 512, (double)R, k.part3, (R + 31) / 32, nullptr,
+                           nullptr, nullptr, bn3_gamma, bn3_rmean, bn3_rvar, momentum, eps, training, k.mean3, k.a3, bn3_beta, k.shift3);
+        rc = upp_detail_linear_sb_chain(k.h3, 512, k.planes4, b4, 0, nullptr, 0, R, C, 512, k.a3, k.shift3, out, C, gshift, nullptr, stream);
+        if (rc) return rc;
+        return upp_launch_status();
+    }
     g = GemmArgs{};
     g.A = k.f; g.lda = 256; g.W = w3 + 256; g.ldw = 512; g.C = k.h3; g.ldc = 512; g.M = R; g.N = 512; g.K = 256;
     g.rowgroup = k.hg; g.ldg = 512; g.n = n; g.stat_part = k.part3;

@@ -130,10 +130,24 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
 #pragma unroll
         for (int h = 0; h < S / 2; ++h) {
             // sumsq3 on two slots at once: t = dy*dy; t = fma(dx,dx,t); t = fma(dz,dz,t)   (v_pk_* f32, IEEE per element)
+#ifdef UPP_FPS_DIAG_SCALAR
+            f32x2 t;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float dx = px[h][e] - x1, dy = py[h][e] - y1, dz = pz[h][e] - z1;
+                float tt = dy * dy;
+                asm volatile("" : "+v"(tt));
+                tt = __builtin_fmaf(dx, dx, tt);
+                asm volatile("" : "+v"(tt));
+                tt = __builtin_fmaf(dz, dz, tt);
+                t[e] = tt;
+            }
+#else
             const f32x2 dx = px[h] - X1, dy = py[h] - Y1, dz = pz[h] - Z1;
             f32x2 t = dy * dy;
             t = __builtin_elementwise_fma(dx, dx, t);
             t = __builtin_elementwise_fma(dz, dz, t);
+#endif
             d2[2 * h] = min(__float_as_int(t[0]), tmp[2 * h]); d2[2 * h + 1] = min(__float_as_int(t[1]), tmp[2 * h + 1]);
             tmp[2 * h] = d2[2 * h]; tmp[2 * h + 1] = d2[2 * h + 1];
         }
@@ -143,7 +157,11 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
         best = max(best, kNone);
         int bk = 0;                                               // the FIRST slot that holds the maximum (strict '>' of the reference scan)
         int m_wave;
+#ifdef UPP_FPS_DIAG_NOASM
+        if constexpr (false) {
+#else
         if constexpr (S == 6 || S == 4) {
+#endif
             // The wave reduction's six DPP steps need two wait states each before the next one reads the register, and every
             // v_cmp -> v_cndmask pair of the slot search two as well; an s_nop costs a lone wave 8 cycles (tools/micro/nop_probe.cpp), as
             // much as a real instruction.  So the two chains are interleaved by hand: each hazard shadow holds two instructions of the
@@ -187,7 +205,11 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
         } else {
 #pragma unroll
             for (int sl = S - 1; sl >= 0; --sl) bk = d2[sl] == best ? kk[sl] : bk;
+#ifdef UPP_FPS_DIAG_NOASM
+            m_wave = (int)(wave_max_u32((uint32_t)best ^ 0x80000000u) ^ 0x80000000u);
+#else
             m_wave = wave_max_i32(best);
+#endif
         }
         // lanes are in rank order: the first lane that holds the maximum wins the wave
         const int wl = __builtin_ctzll(__ballot(best == m_wave));
@@ -197,7 +219,11 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
             uint32_t *r = rec + (j & 1) * (2 * W);
             if (lane == 0) { r[2 * wave] = (uint32_t)m; r[2 * wave + 1] = wk; }
             __syncthreads();
+#ifdef UPP_FPS_DIAG_NOASM
+            if constexpr (false) {
+#else
             if constexpr (W == 4) {
+#endif
                 // max of the four keys, then the LOWEST wave that holds it (waves are in rank order), all compares ahead of all selects:
                 // no hazard nops; a key < 0 (no candidate anywhere) selects point 0
                 const uint4 ra = *reinterpret_cast<const uint4 *>(r), rb = *reinterpret_cast<const uint4 *>(r + 4);
@@ -267,7 +293,11 @@ constexpr int kFpsLdsBytes = 160 * 1024 - 256;  // cloud copy + winner list + wa
 template <int S, int W>
 int launch(const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom &g, hipStream_t st) {
     const size_t lds_bytes = (size_t)(4 * W + 3 * g.N + g.M) * 4;
+#ifdef UPP_FPS_DIAG_NOLDS
+    if (false) {
+#else
     if (lds_bytes <= (size_t)kFpsLdsBytes) {
+#endif
         if (lds_bytes > 64 * 1024) {
             static std::atomic<bool> raised{false};  // one attribute call per instantiation
             if (!raised) {

@@ -44,6 +44,10 @@ struct SbArgs {
     LinArgs l;                          // A, C, bias, aux, M, N, K, epi, tiles_n as linear.hip (W unused)
     const unsigned char *planes;        // upp_linear_sb_prep image of W
     int nblocks, kstages;               // ceil(N / 32), ceil(K / 32) of that image
+    // the patch embedding's fused layers (dense.hip; PRO = 1 instantiations serve pro_*, every instantiation the epilogues):
+    const float *pro_scale, *pro_shift; // a' = max(a * scale[k] + shift[k], 0) applied to the A fragment in front of its split (K <= 512)
+    float *gmax; int ldgmax, gshift;    // gmax[row >> gshift][col] = max over the 2^gshift (16 | 32) rows of a group of C (+ bias); C is NOT stored
+    float *stat_part;                   // [2][ceil(M / 32)][N]: column sums / sums of squares of C over each 32-row block (rows < M)
 };
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -68,16 +72,18 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &p1
     }
 }
 
-template <int BMB, int BNB, int RN, int KS, int NST>
+template <int BMB, int BNB, int RN, int KS, int NST, int PRO = 0>
 __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(SbArgs ga) {
     static_assert(BNB % RN == 0 && (RN == 1 || RN == 2), "wave tile: 1 x RN blocks");
+    static_assert(!PRO || (RN == 2 && KS == 1 && BMB * (BNB / RN) >= 8), "the prologue variant: the 8-wave tiles with two blocks per wave");
     constexpr int WPG = BMB * (BNB / RN), NW = WPG * KS, BM = BMB * 32, BN = BNB * 32;
     constexpr int AG = BM * 128, GB = AG + BNB * SB_CHUNK;          // bytes of one wave group's share of a k-stage: [A rows | W blocks]
     constexpr int STAGE = KS * GB, TG = GB / 1024, T = KS * TG;     // DMA wave-instructions per stage (1 KB each)
     constexpr int TPW = (T + NW - 1) / NW;
     constexpr bool PADDED = TPW * NW != T;                          // some waves issue a dummy instruction into a scratch KB
     constexpr int RED = NW * RN * 4096;
-    constexpr int LDS_BYTES = (NST * STAGE + (PADDED ? 1024 : 0)) > RED ? (NST * STAGE + (PADDED ? 1024 : 0)) : RED;
+    constexpr int TABOFF = NST * STAGE + (PADDED ? 1024 : 0);      // PRO: [scale 512 | shift 512] floats behind the stages
+    constexpr int LDS_BYTES = (TABOFF + (PRO ? 4096 : 0)) > RED ? (TABOFF + (PRO ? 4096 : 0)) : RED;
     static_assert(LDS_BYTES <= 160 * 1024, "stages exceed the 160 KB of LDS");
     static_assert(NST >= 2 && NST <= 4, "LDS stages");
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
@@ -154,10 +160,21 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
     struct WSet { u32x4 w[RN][3]; };
     struct ASplit { u32x4 p1, p2, p3; };
     f32x4 ra0, ra1;                       // the f32 A fragment of the step being fetched (split as soon as it has landed)
+    f32x4 sc0, sc1, sh0, sh1;             // PRO: scale / shift of its 8 values of k
+    const unsigned adrT = lds0 + TABOFF + h * 32;
+    if constexpr (PRO) {                  // the table: plain stores, visible behind the barrier in front of the first fragment read
+        float *tab = reinterpret_cast<float *>(lds + TABOFF);
+        for (int i = threadIdx.x; i < 512; i += NW * 64) {
+            tab[i] = i < g.K ? ga.pro_scale[i] : 0.0f;
+            tab[512 + i] = i < g.K ? ga.pro_shift[i] : 0.0f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 #define SB_RDA(DST, ADR) asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(ADR));
 #define SB_RDW(DST, ADR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADR), "n"(OFF));
-#define SB_READ(WS, S, SA)                                                                     \
+#define SB_READ(WS, S, SA, TA)                                                                 \
     SB_RDA(ra0, adrA[2 * (S)] + (SA)) SB_RDA(ra1, adrA[2 * (S) + 1] + (SA))                    \
+    if constexpr (PRO) { SB_RDW(sc0, adrT + (TA), 0) SB_RDW(sc1, adrT + (TA), 16) SB_RDW(sh0, adrT + (TA), 2048) SB_RDW(sh1, adrT + (TA), 2064) } \
     SB_RDW(WS.w[0][0], adrW + (SA), (S) * 1024) SB_RDW(WS.w[0][1], adrW + (SA), 2048 + (S) * 1024) SB_RDW(WS.w[0][2], adrW + (SA), 4096 + (S) * 1024) \
     if constexpr (RN > 1) {                                                                    \
         SB_RDW(WS.w[RN - 1][0], adrW + (SA), SB_CHUNK + (S) * 1024) SB_RDW(WS.w[RN - 1][1], adrW + (SA), SB_CHUNK + 2048 + (S) * 1024) \
@@ -168,7 +185,10 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
     // costs 25 % (nothing else can issue while the lone wave sits in the wait), so only workgroups of >= 8 waves carry it.
 #define SB_WAIT(WS)                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                         \
-    if constexpr (RN > 1 && NW >= 8)                                                           \
+    if constexpr (PRO)                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(WS.w[0][0]), "+v"(WS.w[0][1]), "+v"(WS.w[0][2]), \
+                     "+v"(WS.w[RN - 1][0]), "+v"(WS.w[RN - 1][1]), "+v"(WS.w[RN - 1][2]), "+v"(acc[0]), "+v"(sc0), "+v"(sc1), "+v"(sh0), "+v"(sh1)); \
+    else if constexpr (RN > 1 && NW >= 8)                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(WS.w[0][0]), "+v"(WS.w[0][1]), "+v"(WS.w[0][2]), \
                      "+v"(WS.w[RN - 1][0]), "+v"(WS.w[RN - 1][1]), "+v"(WS.w[RN - 1][2]), "+v"(acc[0])); \
     else if constexpr (NW >= 8)                                                                \
@@ -202,7 +222,15 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
     // second half, interleaved with the split of the next step's A fragment (one matrix instruction, then its share of the ~44 VALU)
 #define SB_PROD_LO(X, WS, JJ) SB_MFMA(X.p3, WS.w[JJ][0], JJ) SB_MFMA(X.p1, WS.w[JJ][2], JJ) SB_MFMA(X.p2, WS.w[JJ][1], JJ)
 #define SB_PROD_HI(X, WS, JJ) SB_MFMA(X.p2, WS.w[JJ][0], JJ) SB_MFMA(X.p1, WS.w[JJ][1], JJ) SB_MFMA(X.p1, WS.w[JJ][0], JJ)
+#define SB_PRO()                                                                               \
+    if constexpr (PRO) {                                                                       \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                     \
+            ra0[e_] = fmaxf(__builtin_fmaf(ra0[e_], sc0[e_], sh0[e_]), 0.0f);                  \
+            ra1[e_] = fmaxf(__builtin_fmaf(ra1[e_], sc1[e_], sh1[e_]), 0.0f);                  \
+        }                                                                                      \
+    }
 #define SB_HALF2(X, WS, XN)                                                                    \
+    SB_PRO()                                                                                   \
     split8(ra0, ra1, XN.p1, XN.p2, XN.p3);                                                     \
     if constexpr (RN > 1) { SB_PROD_LO(X, WS, RN - 1) SB_PROD_HI(X, WS, RN - 1) } else { SB_PROD_HI(X, WS, 0) } \
     asm volatile("" : "+v"(XN.p1), "+v"(XN.p2), "+v"(XN.p3));           /* (the split belongs HERE: not sunk to its first use) */ \
@@ -228,21 +256,22 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
     __builtin_amdgcn_s_barrier();
     WSet w0, w1;
     ASplit x0, x1;
-    SB_READ(w0, 0, 0u)
+    SB_READ(w0, 0, 0u, 0u)
     SB_WAIT(w0)
+    SB_PRO()
     split8(ra0, ra1, x0.p1, x0.p2, x0.p3);
     // one iteration = k-stage c.  D1: the rest of k-stage c + NST - 1 is issued behind step 0; D2: the head of k-stage c + NST behind step 1.
 #define SB_ITER(D1, D2, VM_STMT)                                                               \
     {                                                                                          \
         const unsigned sa = stage * STAGE;                                                     \
         const int nxt = stage == NST - 1 ? 0 : stage + 1, prv = stage == 0 ? NST - 1 : stage - 1; \
-        SB_READ(w1, 1, sa)                                                                     \
+        SB_READ(w1, 1, sa, (unsigned)(c * 128 + 64))                                           \
         SB_HALF1(x0, w0, D1, QH, TPW, prv, c + NST - 1)                                        \
         SB_WAIT(w1)                                                                            \
         SB_HALF2(x0, w0, x1)                                                                   \
         VM_STMT                                                                                \
         __builtin_amdgcn_s_barrier();         /* k-stage c + 1 is complete; everyone is done reading k-stage c */ \
-        SB_READ(w0, 0, nxt * STAGE)                                                            \
+        SB_READ(w0, 0, nxt * STAGE, (unsigned)(c * 128 + 128))                                 \
         SB_HALF1(x1, w1, D2, 0, QH, stage, c + NST)                                            \
         SB_WAIT(w0)                                                                            \
         SB_HALF2(x1, w1, x0)                                                                   \
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
         SB_ITER(false, false, if (NST >= 4 && nsc - 2 - c == 1) wait_vmcnt<TPW>(); else wait_vmcnt<0>();)
     {   // the last k-stage: nothing left to fetch behind step 1
         const unsigned sa = stage * STAGE;
-        SB_READ(w1, 1, sa)
+        SB_READ(w1, 1, sa, (unsigned)(c * 128 + 64))
         SB_HALF1(x0, w0, false, 0, 0, 0, 0)
         SB_WAIT(w1)
         SB_HALF2(x0, w0, x1)
@@ -268,6 +297,7 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
 #undef SB_D
 #undef SB_M1
 #undef SB_HALF2
+#undef SB_PRO
 #undef SB_HALF1
 #undef SB_PROD_HI
 #undef SB_PROD_LO
@@ -297,6 +327,10 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
         const bool col_ok = col < N;
         f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
         if (g.epi != LEPI_NONE && g.epi != LEPI_MUL && col_ok && g.bias_shift == 0) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
+        // the patch embedding's epilogues (KS = 1 tiles): group max over 16 | 32 rows instead of the store, column sums of the stored values
+        const bool want_max = KS == 1 && ga.gmax != nullptr, want_stats = KS == 1 && ga.stat_part != nullptr;
+        const float ninf = -__builtin_inff();
+        f32x4 mx[2] = {{ninf, ninf, ninf, ninf}, {ninf, ninf, ninf, ninf}}, sm = {0.0f, 0.0f, 0.0f, 0.0f}, sq = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int pass = 0; pass < TN / 4; ++pass) {
             const int ridx = pass * 8 + (lane >> 3), t = T0 + (ridx >> 1);
@@ -311,7 +345,44 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
 #pragma unroll
                 for (int k2 = 1; k2 < KS; ++k2) v += *reinterpret_cast<const f32x4 *>(sp + k2 * (BMB * BNB) * 1024);
             }
+            if (want_max || want_stats) {                        // (epilogue NONE / BIAS, checked by the host)
+                const f32x4 val = v + bias4;
+                const bool live = row < M;
+                if (want_stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sm[e] += live ? val[e] : 0.0f; sq[e] += live ? val[e] * val[e] : 0.0f; }
+                }
+                if (want_max) {
+                    const int gi = ga.gshift == 4 ? pass >> 1 : 0;          // rows 0..15 of a block are passes 0, 1
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = live ? val[e] : ninf;
+                        if (gi == 0) mx[0][e] = fmaxf(mx[0][e], c); else mx[1][e] = fmaxf(mx[1][e], c);
+                    }
+                    continue;
+                }
+            }
             epilogue_store4(g, g.epi, v, bias4, row, col, col_ok && row < M);
+        }
+        if (want_max || want_stats) {                            // the 8 lanes lane & 7 + 8 i hold the 32 rows of these four columns
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (want_max) { mx[0][e] = fmaxf(mx[0][e], __shfl_xor(mx[0][e], off)); mx[1][e] = fmaxf(mx[1][e], __shfl_xor(mx[1][e], off)); }
+                    if (want_stats) { sm[e] += __shfl_xor(sm[e], off); sq[e] += __shfl_xor(sq[e], off); }
+                }
+            if ((lane >> 3) == 0 && col_ok && rb < M) {
+                if (want_stats) {
+                    const long long nblk = (M + 31) / 32;
+                    *reinterpret_cast<f32x4 *>(ga.stat_part + (long long)(rb >> 5) * N + col) = sm;
+                    *reinterpret_cast<f32x4 *>(ga.stat_part + (nblk + (rb >> 5)) * N + col) = sq;
+                }
+                if (want_max) {
+                    *reinterpret_cast<f32x4 *>(ga.gmax + (long long)(rb >> ga.gshift) * ga.ldgmax + col) = mx[0];
+                    if (ga.gshift == 4 && rb + 16 < M) *reinterpret_cast<f32x4 *>(ga.gmax + (long long)((rb >> 4) + 1) * ga.ldgmax + col) = mx[1];
+                }
+            }
         }
     }
     UPP_STAMP(3)
@@ -474,6 +545,39 @@ static int linear_sb_launch(const float *A, long long lda, const void *planes, c
         default: return UPP_E_RANGE;
     }
 #undef UPP_SB_CASE
+}
+
+// The two large products of the patch embedding (dense.hip upp_patch_embed_fwd) on this kernel, with the chain's prologue and epilogues:
+//   C = A . W^T + bias (a bias per column, or per group of 2^bias_shift rows);  pro_scale / pro_shift: A is max(A * scale + shift, 0) (the
+//   BatchNorm + ReLU between the layers; the 128 x 128 tile); stat_part: column sums / sums of squares of C per 32-row block (the next
+//   BatchNorm's batch statistics); gmax: the max-pool over each group of 2^gshift rows replaces the store of C.
+__attribute__((visibility("hidden"))) int upp_detail_linear_sb_chain(const float *A, long long lda, const void *planes, const float *bias, int bias_shift,
+                                                                     float *C, long long ldc, int M, int N, int K, const float *pro_scale,
+                                                                     const float *pro_shift, float *gmax, int ldgmax, int gshift, float *stat_part,
+                                                                     void *stream) {
+    if (!A || !planes || !bias || (!C && !gmax) || M < 1 || N < 1 || K < 96) return UPP_E_BADARG;
+    if (K % 32 != 0 || K > 512 || lda % 4 != 0 || lda < K || N % 4 != 0 || (C && (ldc < N || ldc % 4 != 0))) return UPP_E_RANGE;
+    if (gmax && ((gshift != 4 && gshift != 5) || ldgmax < N || ldgmax % 4 != 0 || M % (1 << gshift) != 0)) return UPP_E_RANGE;
+    if ((pro_scale == nullptr) != (pro_shift == nullptr)) return UPP_E_BADARG;
+    SbArgs g{};
+    g.l.A = A; g.l.lda = lda; g.l.C = C; g.l.ldc = ldc; g.l.bias = bias; g.l.M = M; g.l.N = N; g.l.K = K;
+    g.l.epi = bias_shift > 0 ? LEPI_NONE : LEPI_BIAS; g.l.bias_shift = bias_shift;
+#ifdef UPP_LIN_STAMPS
+    g.l.stamps = nullptr;
+#endif
+    g.planes = reinterpret_cast<const unsigned char *>(planes);
+    g.nblocks = (N + 31) / 32; g.kstages = (K + 31) / 32;
+    g.pro_scale = pro_scale; g.pro_shift = pro_shift; g.gmax = gmax; g.ldgmax = ldgmax; g.gshift = gshift; g.stat_part = stat_part;
+    hipStream_t st = (hipStream_t)stream;
+    const long long wgs256 = (long long)((M + 255) / 256) * ((N + 127) / 128);
+    if (pro_scale) {
+        const int tiles_m = (M + 127) / 128;
+        g.l.tiles_n = (N + 127) / 128;
+        hipLaunchKernelGGL((linear_sb_kernel<4, 4, 2, 1, UPP_SB_NST44, 1>), dim3((unsigned)(tiles_m * g.l.tiles_n)), dim3(512), 0, st, g);
+        return upp_launch_status();
+    }
+    if (wgs256 >= 192) return launch_sb<8, 4, 2, 1, 2>(g, st);
+    return launch_sb<4, 4, 2, 1, UPP_SB_NST44>(g, st);
 }
 
 extern "C" int upp_linear_sb_f32(const float *A, long long lda, const void *planes, const float *bias, float *C, long long ldc, float *aux,

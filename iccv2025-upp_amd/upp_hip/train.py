@@ -9,6 +9,7 @@ tools/runner_module.py:193-212) built for MI355X:
     graph launch (the eager step is launch-bound: 32 ms wall vs 24 ms of kernels).  The
     all-reduce stays outside the graphs; clip + AdamW are a second graph.
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -552,6 +553,8 @@ class PipelinedTrainStep(TrainStep):
         with torch.cuda.stream(self.s_front):
             self._g_front[p].replay()                  # batch k: raw -> prompted[p]
             self._ev_front[p].record(self.s_front)
+        if os.environ.get("UPP_PIPE_SERIAL"):          # (diagnostic, tools/micro/pipe_race_probe.py: the two halves one after the other)
+            cur.wait_stream(self.s_front)
         if self._k > 0:
             self._g_back[1 - p].replay()               # batch k-1: forward + loss + backward
             self._ev_back[1 - p].record(cur)

@@ -1,0 +1,32 @@
+"""Furthest point sampling beside other work on the same GPU (the pipelined step's situation); parity with the oracle: test_gpu_parity.py."""
+import pytest
+import torch
+
+import _seeded
+from upp_hip import ops
+
+
+@pytest.mark.gpu
+def test_fps_is_bit_stable_beside_a_co_running_split_bf16_linear_stream():
+    """Round 4: with packed-f32 VALU instructions in the round loop (v_pk_add_f32 ... op_sel:[0,1]) the picks changed in ~3 of 4 calls while a
+    split-bf16 Linear workgroup shared the CU -- the instruction returned a - 0 in its low half (tools/micro/src/lds_canary.cpp) -- which
+    is exactly the situation of the pipelined step (front-end FPS beside the back-end's GEMMs).  The library is built without packed-f32
+    instructions (upp_hip/build.py); this is the regression test: every result beside the co-runner equals the result on an idle GPU."""
+    s2 = torch.cuda.Stream()
+    a = torch.randn(4096, 1536, device='cuda')
+    w = torch.randn(384, 1536, device='cuda') * 1536 ** -0.5
+    w._upp_persistent = True
+    out = torch.empty(4096, 384, device='cuda')
+    ops.linear_f32(a, w, out=out, frozen=True)
+    assert ops.linear_sb_tile(4096, 384, 1536) > 0
+    for N, M in ((1024, 1024), (1228, 1024), (1936, 1536)):
+        x = _seeded.noisy_clouds(2, N, seed=5).cuda().contiguous()
+        ref = ops.fps(x, M)
+        torch.cuda.synchronize()
+        for it in range(12):
+            with torch.cuda.stream(s2):
+                for _ in range(60):
+                    ops.linear_f32(a, w, out=out, frozen=True)
+            got = ops.fps(x, M)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), (N, M, it)
