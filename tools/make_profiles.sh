@@ -52,6 +52,17 @@ python3 tools/time_linear.py --tiles --rows 2720,4128,4416,8832 --out $O/time_li
 python3 tools/time_linear.py --tiles > $O/r04_time_linear.jsonl 2> /dev/null
 python3 tools/time_linear_sb.py --tiles --out $O/r04_time_linear_sb.jsonl > /dev/null 2>&1
 python3 tools/micro/sb_stamps.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_sb_stamps.txt
+python3 tools/micro/time_wgrad.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_wgrad.txt
+for w in pretrain seg; do echo "== $w" >> $O/r04_time_wgrad.txt; python3 tools/micro/wgrad_groups.py $w 2> /dev/null | grep -v amdgpu.ids >> $O/r04_time_wgrad.txt; done
+python3 tools/micro/time_tall_tiles.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_tall_tiles.txt
+python3 tools/time_patch_embed.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_patch_embed.txt
+UPP_EMBED_SPLIT_BF16=0 python3 tools/time_patch_embed.py 2> /dev/null | grep -v amdgpu.ids | sed 's/^/exact-f32 chain: /' >> $O/r04_time_patch_embed.txt
+python3 tools/fps_sweep.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_fps_sweep.txt
+# the packed-f32 anomaly beside a co-resident bf16-MFMA workgroup (canary kernels with their own inline asm; co-runner: upp_linear_sb_f32)
+mkdir -p tools/micro/bin
+hipcc --offload-arch=gfx950 -O2 tools/micro/src/lds_canary.cpp -o tools/micro/bin/lds_canary -Liccv2025-upp_amd/upp_hip/lib -lupp_hip -Wl,-rpath,$PWD/iccv2025-upp_amd/upp_hip/lib 2> /dev/null
+for a in "384 1536 0 0 2" "384 1536 0 0 0" "384 1536 0 0 1" "384 1536 0 29696 1"; do ./tools/micro/bin/lds_canary $a 2>&1 | grep -v "^VGPR op_sel" ; done > $O/r04_packed_f32_canary.txt
+python3 tools/micro/fps_corun_probe.py 0 1024 2> /dev/null | grep -v amdgpu.ids >> $O/r04_packed_f32_canary.txt
 python3 tools/_fmt_linear.py $O/r04_time_linear.jsonl > $O/r04_time_linear.txt
 python3 tools/time_attention.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_attention.txt
 python3 tools/micro/time_ln_adapter.py 2> /dev/null | grep -v amdgpu.ids >> $O/r04_time_attention.txt
