@@ -261,7 +261,7 @@ def test_full_size_properties():
     assert (e1 == 0).all() and (e2 == 0).all()                             # permutation invariance
 
 
-@pytest.mark.parametrize("B,G,n", [(32, 64, 32), (4, 32, 16), (3, 5, 32), (2, 7, 16)])
+@pytest.mark.parametrize("B,G,n", [(32, 64, 32), (4, 32, 16), (3, 5, 32), (2, 7, 16), (1, 13, 16), (5, 3, 16), (16, 128, 32)])     # (R = 208, 240: half-valid last 32-row block)
 @pytest.mark.parametrize("training", [False, True])
 def test_patch_embed_mfma_chain_matches_library_path(B, G, n, training):
     """Fused FP32-MFMA patch embedding vs the same Encoder through torch/rocBLAS ops (which is pinned to the
