@@ -660,9 +660,10 @@ def main():
             flops, ms, n, shapes, sb_flops = linear_family_replay(seq.ts, device)
             tf = flops / ms / 1e9
             shapes.sort(key=lambda r: -r["ms_per_launch"] * r["launches_per_step"])
-            roof = {"kernel": "linear_sb_kernel<*> + linear_f32_kernel<*> + linear_rt_kernel<*> + wgrad_grouped_kernel (csrc/linear_sb.hip, "
-                              "linear.hip, linear_rt.hip): ALL %d Linear launches of one step (forward, data gradients, grouped weight "
-                              "gradients); %.0f %% of the flops on the split-bf16 kernel (frozen weights)" % (n, 100.0 * sb_flops / flops),
+            roof = {"kernel": "linear_sb_kernel<*> + linear_f32_kernel<*> + linear_rt_kernel<*> + wgrad_sb_kernel<*> (csrc/linear_sb.hip, "
+                              "linear.hip, linear_rt.hip, wgrad_sb.hip): ALL %d Linear launches of one step (forward, data gradients, grouped "
+                              "weight gradients); %.0f %% of the forward / data-gradient flops on the split-bf16 kernel (frozen and "
+                              "driver-managed weights), the weight gradients on its two-operand form" % (n, 100.0 * sb_flops / flops),
                     "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "ms": ms,
                     "launches": n, "algorithmic_flops": flops, "traffic": None,
                     "how": "launch list recorded from an eager step, replayed as one HIP graph, HIP events on the launch stream",
