@@ -74,7 +74,7 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &p1
 
 template <int BMB, int BNB, int RN, int KS, int NST, int PRO = 0>
 __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(SbArgs ga) {
-    static_assert(BNB % RN == 0 && (RN == 1 || RN == 2), "wave tile: 1 x RN blocks");
+    static_assert(BNB % RN == 0 && (RN == 1 || RN == 2 || RN == 4), "wave tile: 1 x RN blocks");
     static_assert(!PRO || (RN == 2 && KS == 1 && BMB * (BNB / RN) >= 8), "the prologue variant: the 8-wave tiles with two blocks per wave");
     constexpr int WPG = BMB * (BNB / RN), NW = WPG * KS, BM = BMB * 32, BN = BNB * 32;
     constexpr int AG = BM * 128, GB = AG + BNB * SB_CHUNK;          // bytes of one wave group's share of a k-stage: [A rows | W blocks]
@@ -176,16 +176,28 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
     SB_RDA(ra0, adrA[2 * (S)] + (SA)) SB_RDA(ra1, adrA[2 * (S) + 1] + (SA))                    \
     if constexpr (PRO) { SB_RDW(sc0, adrT + (TA), 0) SB_RDW(sc1, adrT + (TA), 16) SB_RDW(sh0, adrT + (TA), 2048) SB_RDW(sh1, adrT + (TA), 2064) } \
     SB_RDW(WS.w[0][0], adrW + (SA), (S) * 1024) SB_RDW(WS.w[0][1], adrW + (SA), 2048 + (S) * 1024) SB_RDW(WS.w[0][2], adrW + (SA), 4096 + (S) * 1024) \
-    if constexpr (RN > 1) {                                                                    \
-        SB_RDW(WS.w[RN - 1][0], adrW + (SA), SB_CHUNK + (S) * 1024) SB_RDW(WS.w[RN - 1][1], adrW + (SA), SB_CHUNK + 2048 + (S) * 1024) \
-        SB_RDW(WS.w[RN - 1][2], adrW + (SA), SB_CHUNK + 4096 + (S) * 1024)                     \
+    if constexpr (RN == 2) {                                                                   \
+        SB_RDW(WS.w[1][0], adrW + (SA), SB_CHUNK + (S) * 1024) SB_RDW(WS.w[1][1], adrW + (SA), SB_CHUNK + 2048 + (S) * 1024) \
+        SB_RDW(WS.w[1][2], adrW + (SA), SB_CHUNK + 4096 + (S) * 1024)                          \
+    }                                                                                          \
+    if constexpr (RN == 4) {                                                                   \
+        SB_RDW(WS.w[1][0], adrW + (SA), SB_CHUNK + (S) * 1024) SB_RDW(WS.w[1][1], adrW + (SA), SB_CHUNK + 2048 + (S) * 1024) \
+        SB_RDW(WS.w[1][2], adrW + (SA), SB_CHUNK + 4096 + (S) * 1024)                          \
+        SB_RDW(WS.w[2][0], adrW + (SA), 2 * SB_CHUNK + (S) * 1024) SB_RDW(WS.w[2][1], adrW + (SA), 2 * SB_CHUNK + 2048 + (S) * 1024) \
+        SB_RDW(WS.w[2][2], adrW + (SA), 2 * SB_CHUNK + 4096 + (S) * 1024)                      \
+        SB_RDW(WS.w[3][0], adrW + (SA), 3 * SB_CHUNK + (S) * 1024) SB_RDW(WS.w[3][1], adrW + (SA), 3 * SB_CHUNK + 2048 + (S) * 1024) \
+        SB_RDW(WS.w[3][2], adrW + (SA), 3 * SB_CHUNK + 4096 + (S) * 1024)                      \
     }
     // acc[0] among the wait's operands pins the first half's matrix instructions IN FRONT of the wait (otherwise hipcc may sink them behind
     // it and the fragment reads are not covered): k-loop of the 128 x 128 tile 21,400 -> 19,700 cycles; at ONE wave per SIMD the same pin
     // costs 25 % (nothing else can issue while the lone wave sits in the wait), so only workgroups of >= 8 waves carry it.
 #define SB_WAIT(WS)                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                         \
-    if constexpr (PRO)                                                                         \
+    if constexpr (RN == 4)                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(WS.w[0][0]), "+v"(WS.w[0][1]), "+v"(WS.w[0][2]), \
+                     "+v"(WS.w[1][0]), "+v"(WS.w[1][1]), "+v"(WS.w[1][2]), "+v"(WS.w[2][0]), "+v"(WS.w[2][1]), "+v"(WS.w[2][2]), \
+                     "+v"(WS.w[3][0]), "+v"(WS.w[3][1]), "+v"(WS.w[3][2]), "+v"(acc[0]));       \
+    else if constexpr (PRO)                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(WS.w[0][0]), "+v"(WS.w[0][1]), "+v"(WS.w[0][2]), \
                      "+v"(WS.w[RN - 1][0]), "+v"(WS.w[RN - 1][1]), "+v"(WS.w[RN - 1][2]), "+v"(acc[0]), "+v"(sc0), "+v"(sc1), "+v"(sh0), "+v"(sh1)); \
     else if constexpr (RN > 1 && NW >= 8)                                                      \
@@ -232,11 +244,12 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
 #define SB_HALF2(X, WS, XN)                                                                    \
     SB_PRO()                                                                                   \
     split8(ra0, ra1, XN.p1, XN.p2, XN.p3);                                                     \
-    if constexpr (RN > 1) { SB_PROD_LO(X, WS, RN - 1) SB_PROD_HI(X, WS, RN - 1) } else { SB_PROD_HI(X, WS, 0) } \
+    if constexpr (RN == 4) { SB_PROD_LO(X, WS, 1) SB_PROD_HI(X, WS, 1) SB_PROD_LO(X, WS, 2) SB_PROD_HI(X, WS, 2) SB_PROD_LO(X, WS, 3) SB_PROD_HI(X, WS, 3) } \
+    else if constexpr (RN > 1) { SB_PROD_LO(X, WS, RN - 1) SB_PROD_HI(X, WS, RN - 1) } else { SB_PROD_HI(X, WS, 0) } \
     asm volatile("" : "+v"(XN.p1), "+v"(XN.p2), "+v"(XN.p3));           /* (the split belongs HERE: not sunk to its first use) */ \
-    _Pragma("unroll") for (int i_ = 0; i_ < (RN > 1 ? 6 : 3); ++i_) {                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < (RN == 4 ? 18 : RN > 1 ? 6 : 3); ++i_) {          \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
-        __builtin_amdgcn_sched_group_barrier(0x002, RN > 1 ? 8 : 15, 0);                       \
+        __builtin_amdgcn_sched_group_barrier(0x002, RN == 4 ? 3 : RN > 1 ? 8 : 15, 0);         \
     }                                                                                          \
     __builtin_amdgcn_sched_barrier(0);
 
@@ -291,7 +304,8 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
         SB_WAIT(w1)
         SB_HALF2(x0, w0, x1)
         SB_HALF1(x1, w1, false, 0, 0, 0, 0)
-        if constexpr (RN > 1) { SB_PROD_LO(x1, w1, RN - 1) SB_PROD_HI(x1, w1, RN - 1) } else { SB_PROD_HI(x1, w1, 0) }
+        if constexpr (RN == 4) { SB_PROD_LO(x1, w1, 1) SB_PROD_HI(x1, w1, 1) SB_PROD_LO(x1, w1, 2) SB_PROD_HI(x1, w1, 2) SB_PROD_LO(x1, w1, 3) SB_PROD_HI(x1, w1, 3) }
+        else if constexpr (RN > 1) { SB_PROD_LO(x1, w1, RN - 1) SB_PROD_HI(x1, w1, RN - 1) } else { SB_PROD_HI(x1, w1, 0) }
     }
 #undef SB_ITER
 #undef SB_D
@@ -426,7 +440,7 @@ struct SbConfig { int bmb, bnb, rn, ks, nst; };
 #ifndef UPP_SB_NST44
 #define UPP_SB_NST44 3
 #endif
-#define UPP_SB_CONFIGS(X) X(8, 4, 2, 1, 2) X(4, 4, 2, 1, UPP_SB_NST44) X(4, 3, 1, 1, 4) X(3, 4, 2, 1, 4) X(2, 4, 2, 1, 4) X(2, 3, 1, 1, 4) X(2, 2, 1, 2, 3) X(2, 2, 2, 4, 2) X(1, 2, 1, 2, 4)
+#define UPP_SB_CONFIGS(X) X(8, 4, 4, 1, 2) X(8, 4, 2, 1, 2) X(4, 4, 2, 1, UPP_SB_NST44) X(4, 3, 1, 1, 4) X(3, 4, 2, 1, 4) X(2, 4, 2, 1, 4) X(2, 3, 1, 1, 4) X(2, 2, 1, 2, 3) X(2, 2, 2, 4, 2) X(1, 2, 1, 2, 4)
 #define UPP_SB_ENTRY(a, b, c, d, e) {a, b, c, d, e},
 constexpr SbConfig kSbConfigs[] = {UPP_SB_CONFIGS(UPP_SB_ENTRY)};
 #undef UPP_SB_ENTRY
@@ -447,7 +461,8 @@ int pick_sb(int M, int N, int K) {
         if (K % (32 * c.ks) != 0 || K / (32 * c.ks) < c.nst) continue;          // (every LDS stage is filled before the loop starts)
         const long long wgs = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
         const long long rounds = (wgs + 255) / 256;
-        if (c.bmb == 8 && wgs < 192) continue;                   // (the 256-row tile: tall matrices only -- 16 waves per workgroup, two LDS stages)
+        if (c.bmb == 8 && wgs < 192) continue;                   // (the 256-row tiles: tall matrices only -- two LDS stages; <8,4,4>: 8 waves of 1 x 4 blocks, half the split
+                                                                 //  and A-fragment work per matrix instruction of <8,4,2>'s 16 waves: 207 -> 222 TFLOP/s at 65,536 rows)
         if (rounds > 1 && c.bmb * c.bnb < 12) continue;          // (several rounds: the big tiles only -- one workgroup per CU, prologue and store burst per round)
         const int waves = c.bmb * (c.bnb / c.rn) * c.ks;
         const long long mfma = (long long)((waves + 3) / 4) * c.rn * (K / c.ks / 16) * 192;
@@ -576,7 +591,7 @@ __attribute__((visibility("hidden"))) int upp_detail_linear_sb_chain(const float
         hipLaunchKernelGGL((linear_sb_kernel<4, 4, 2, 1, UPP_SB_NST44, 1>), dim3((unsigned)(tiles_m * g.l.tiles_n)), dim3(512), 0, st, g);
         return upp_launch_status();
     }
-    if (wgs256 >= 192) return launch_sb<8, 4, 2, 1, 2>(g, st);
+    if (wgs256 >= 192) return launch_sb<8, 4, 4, 1, 2>(g, st);
     return launch_sb<4, 4, 2, 1, UPP_SB_NST44>(g, st);
 }
 

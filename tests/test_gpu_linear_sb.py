@@ -12,7 +12,7 @@ from upp_hip import functional as HF, ops, _abi
 pytestmark = pytest.mark.gpu
 
 SB_CONFIGS = [0x400000 + a * 65536 + b * 4096 + c * 256 + d * 16 + e for (a, b, c, d, e) in
-              [(8, 4, 2, 1, 2), (4, 4, 2, 1, 3), (4, 3, 1, 1, 4), (3, 4, 2, 1, 4), (2, 4, 2, 1, 4), (2, 3, 1, 1, 4), (2, 2, 1, 2, 3), (2, 2, 2, 4, 2), (1, 2, 1, 2, 4)]]
+              [(8, 4, 4, 1, 2), (8, 4, 2, 1, 2), (4, 4, 2, 1, 3), (4, 3, 1, 1, 4), (3, 4, 2, 1, 4), (2, 4, 2, 1, 4), (2, 3, 1, 1, 4), (2, 2, 1, 2, 3), (2, 2, 2, 4, 2), (1, 2, 1, 2, 4)]]
 TOKENS = [2400, 2080, 2048, 1120]
 LAYERS = [("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536), ("dqkv", 384, 1152)]
 

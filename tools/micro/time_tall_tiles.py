@@ -5,7 +5,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "iccv2025-upp_amd")]
 import torch
 from bench import time_kernel
 from upp_hip import ops, _abi
-TILES = [0x484212, 0x444213, 0x443114, 0x434214]
+TILES = [0x484412, 0x484212, 0x444213, 0x443114, 0x434214]
 dev = torch.device("cuda", 0)
 for M, N, K in ((65536, 1024, 1536), (65536, 1536, 1024), (65536, 512, 1024), (65536, 1024, 512), (65536, 512, 256), (65536, 384, 512), (16384, 512, 256), (16384, 384, 512), (4128, 1536, 384), (4128, 384, 1536)):
     a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * K ** -0.5; w._upp_persistent = True

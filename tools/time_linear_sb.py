@@ -18,7 +18,7 @@ from upp_hip import ops, _abi  # noqa: E402
 
 LAYERS = (("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536), ("dqkv", 384, 1152))
 SB_TILES = [0x400000 + a * 65536 + b * 4096 + c * 256 + d * 16 + e for (a, b, c, d, e) in
-            [(8, 4, 2, 1, 2), (4, 4, 2, 1, int(os.environ.get("UPP_SB_NST44", "3"))), (4, 3, 1, 1, 4), (3, 4, 2, 1, 4), (2, 4, 2, 1, 4), (2, 3, 1, 1, 4), (2, 2, 1, 2, 3), (2, 2, 2, 4, 2), (1, 2, 1, 2, 4)]]
+            [(8, 4, 4, 1, 2), (8, 4, 2, 1, 2), (4, 4, 2, 1, int(os.environ.get("UPP_SB_NST44", "3"))), (4, 3, 1, 1, 4), (3, 4, 2, 1, 4), (2, 4, 2, 1, 4), (2, 3, 1, 1, 4), (2, 2, 1, 2, 3), (2, 2, 2, 4, 2), (1, 2, 1, 2, 4)]]
 
 
 def main():
