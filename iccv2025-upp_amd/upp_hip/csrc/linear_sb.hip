@@ -75,7 +75,7 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &p1
 template <int BMB, int BNB, int RN, int KS, int NST, int PRO = 0>
 __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(SbArgs ga) {
     static_assert(BNB % RN == 0 && (RN == 1 || RN == 2 || RN == 4), "wave tile: 1 x RN blocks");
-    static_assert(!PRO || (RN == 2 && KS == 1 && BMB * (BNB / RN) >= 8), "the prologue variant: the 8-wave tiles with two blocks per wave");
+    static_assert(!PRO || ((RN == 2 || RN == 4) && KS == 1 && BMB * (BNB / RN) >= 8), "the prologue variant: 8-wave tiles with two or four blocks per wave");
     constexpr int WPG = BMB * (BNB / RN), NW = WPG * KS, BM = BMB * 32, BN = BNB * 32;
     constexpr int AG = BM * 128, GB = AG + BNB * SB_CHUNK;          // bytes of one wave group's share of a k-stage: [A rows | W blocks]
     constexpr int STAGE = KS * GB, TG = GB / 1024, T = KS * TG;     // DMA wave-instructions per stage (1 KB each)
@@ -197,6 +197,8 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(WS.w[0][0]), "+v"(WS.w[0][1]), "+v"(WS.w[0][2]), \
                      "+v"(WS.w[1][0]), "+v"(WS.w[1][1]), "+v"(WS.w[1][2]), "+v"(WS.w[2][0]), "+v"(WS.w[2][1]), "+v"(WS.w[2][2]), \
                      "+v"(WS.w[3][0]), "+v"(WS.w[3][1]), "+v"(WS.w[3][2]), "+v"(acc[0]));       \
+    if constexpr (RN == 4 && PRO) asm volatile("" : "+v"(sc0), "+v"(sc1), "+v"(sh0), "+v"(sh1));      /* (30-operand limit: the table fragments ride on a second statement) */ \
+    if constexpr (RN == 4) {}                                                                  \
     else if constexpr (PRO)                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(WS.w[0][0]), "+v"(WS.w[0][1]), "+v"(WS.w[0][2]), \
                      "+v"(WS.w[RN - 1][0]), "+v"(WS.w[RN - 1][1]), "+v"(WS.w[RN - 1][2]), "+v"(acc[0]), "+v"(sc0), "+v"(sc1), "+v"(sh0), "+v"(sh1)); \
@@ -586,9 +588,12 @@ __attribute__((visibility("hidden"))) int upp_detail_linear_sb_chain(const float
     hipStream_t st = (hipStream_t)stream;
     const long long wgs256 = (long long)((M + 255) / 256) * ((N + 127) / 128);
     if (pro_scale) {
-        const int tiles_m = (M + 127) / 128;
         g.l.tiles_n = (N + 127) / 128;
-        hipLaunchKernelGGL((linear_sb_kernel<4, 4, 2, 1, UPP_SB_NST44, 1>), dim3((unsigned)(tiles_m * g.l.tiles_n)), dim3(512), 0, st, g);
+        if (wgs256 >= 192) {                       // (the 256-row tile with 1 x 4 blocks per wave: 383 -> 366 us for the chain at 65,536 rows)
+            hipLaunchKernelGGL((linear_sb_kernel<8, 4, 4, 1, 2, 1>), dim3((unsigned)(((M + 255) / 256) * g.l.tiles_n)), dim3(512), 0, st, g);
+        } else {
+            hipLaunchKernelGGL((linear_sb_kernel<4, 4, 2, 1, UPP_SB_NST44, 1>), dim3((unsigned)(((M + 127) / 128) * g.l.tiles_n)), dim3(512), 0, st, g);
+        }
         return upp_launch_status();
     }
     if (wgs256 >= 192) return launch_sb<8, 4, 4, 1, 2>(g, st);
