@@ -223,8 +223,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-// 9 second moments + 3 first moments of the input rows, f64.  mom[0..2] = sum x,y,z;
-// mom[3..8] = sum xx, xy, xz, yy, yz, zz.
+// 9 second moments + 3 first moments of the input rows, f64: per workgroup b, mom[b][0..2] = sum x,y,z; mom[b][3..8] = sum xx, xy, xz, yy,
+// yz, zz over its rows.  (Round 4: partial sums per workgroup, added in workgroup order by bn_finalize_kernel<1> -- no f64 atomics any more
+// (their order made BN1's statistics depend on scheduling in the last bit), no zero-fill launch in front.)
+constexpr int kMomBlocks = 64;
 __global__ __launch_bounds__(256) void moments3_kernel(const float *__restrict__ pts, int R, double *__restrict__ mom) {
     double s[9];
 #pragma unroll
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void moments3_kernel(const float *__restrict__
         if (lane == 0) red[i][wave] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 9) atomicAdd(&mom[threadIdx.x], (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
+    if (threadIdx.x < 9) mom[(size_t)blockIdx.x * 9 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
 // BatchNorm parameters for a prologue: mean[c], a[c] = gamma * rsqrt(var + eps), and the running-stat update
@@ -277,6 +279,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int C, double count, c
         rs[ty][tx] = s; rq[ty][tx] = q;
         __syncthreads();
     }
+    __shared__ double m9s[9];
+    if (MODE == 1 && training) {                            // the moments: thread i sums component i over the workgroups of moments3_kernel, ascending
+        if (threadIdx.x < 9) {
+            double acc9 = 0.0;
+            for (int b0 = 0; b0 < slabs; b0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = mom[(size_t)min(b0 + t, slabs - 1) * 9 + threadIdx.x];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) if (b0 + t < slabs) acc9 += v[t];
+            }
+            m9s[threadIdx.x] = acc9;
+        }
+        __syncthreads();
+    }
     if (ty != 0 || !live) return;
     double mean, var;
     if (!training) {
@@ -288,9 +305,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int C, double count, c
             mean = s / count;
             var = q / count - mean * mean;
         } else {
-            const double mx = mom[0] / count, my = mom[1] / count, mz = mom[2] / count;
-            const double cxx = mom[3] / count - mx * mx, cxy = mom[4] / count - mx * my, cxz = mom[5] / count - mx * mz;
-            const double cyy = mom[6] / count - my * my, cyz = mom[7] / count - my * mz, czz = mom[8] / count - mz * mz;
+            const double *m9 = m9s;
+            const double mx = m9[0] / count, my = m9[1] / count, mz = m9[2] / count;
+            const double cxx = m9[3] / count - mx * mx, cxy = m9[4] / count - mx * my, cxz = m9[5] / count - mx * mz;
+            const double cyy = m9[6] / count - my * my, cyz = m9[7] / count - my * mz, czz = m9[8] / count - mz * mz;
             const double w0 = w[c * 3 + 0], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
             mean = w0 * mx + w1 * my + w2 * mz + (double)b[c];
             var = w0 * (w0 * cxx + 2 * (w1 * cxy + w2 * cxz)) + w1 * (w1 * cyy + 2 * w2 * cyz) + w2 * w2 * czz;
@@ -325,7 +343,7 @@ inline EmbedWork carve_embed(float *w, int R, int n) {
     EmbedWork k;
     const size_t G = (size_t)R / n;
     size_t o = 0;
-    k.mom = reinterpret_cast<double *>(w + o); o += 32;            // 16 doubles
+    k.mom = reinterpret_cast<double *>(w + o); o += align64((size_t)kMomBlocks * 9 * 2);            // [workgroup][9] doubles
     k.part3 = w + o; o += stat_floats(R);
     k.mean1 = w + o; o += 128;  k.a1 = w + o; o += 128;
     k.mean3 = w + o; o += 512;  k.a3 = w + o; o += 512;  k.shift3 = w + o; o += 512;
@@ -350,7 +368,7 @@ __attribute__((visibility("hidden"))) int upp_detail_linear_sb_chain(const float
 extern "C" long long upp_patch_embed_work_floats(int R, int n) {
     if (R <= 0 || n <= 0) return 0;
     const size_t G = (size_t)R / n;
-    return (long long)(32 + stat_floats(R) + 256 + 1536 + plane_floats(512, 256) + plane_floats(kMaxEmbedC, 512) + align64(G * 256) + align64(G * 512) +
+    return (long long)(align64((size_t)kMomBlocks * 9 * 2) + stat_floats(R) + 256 + 1536 + plane_floats(512, 256) + plane_floats(kMaxEmbedC, 512) + align64(G * 256) + align64(G * 512) +
                        align64((size_t)R * 256) + align64((size_t)R * 512));
 }
 
@@ -366,15 +384,11 @@ extern "C" int upp_patch_embed_fwd(const float *pts, int R, int n, const float *
     hipStream_t st = (hipStream_t)stream;
     const EmbedWork k = carve_embed(work, R, n);
     const int G = R / n;
-    hipError_t e = hipMemsetAsync(work, 0, 32 * sizeof(float), st);   // the f64 moment accumulators
-    if (e != hipSuccess) return (int)e;
 
     // BN1 statistics from the moments of the input rows
-    if (training) {
-        int blocks = (R + 255) / 256; if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(moments3_kernel, dim3(blocks), dim3(256), 0, st, pts, R, k.mom);
-    }
-    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(8), dim3(256), 0, st, 128, (double)R, nullptr, 0, k.mom, w1, b1,
+    int blocks = (R + 255) / 256; if (blocks > kMomBlocks) blocks = kMomBlocks;
+    if (training) hipLaunchKernelGGL(moments3_kernel, dim3(blocks), dim3(256), 0, st, pts, R, k.mom);
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(8), dim3(256), 0, st, 128, (double)R, nullptr, blocks, k.mom, w1, b1,
                        bn1_gamma, bn1_rmean, bn1_rvar, momentum, eps, training, k.mean1, k.a1);
 
     GemmArgs g{};
