@@ -30,3 +30,34 @@ def test_fps_is_bit_stable_beside_a_co_running_split_bf16_linear_stream():
             got = ops.fps(x, M)
             torch.cuda.synchronize()
             assert torch.equal(got, ref), (N, M, it)
+
+
+@pytest.mark.gpu
+def test_knn_and_chamfer_indices_are_bit_stable_beside_a_co_running_split_bf16_linear_stream():
+    """The other exact-index operators of the path (kNN grouping, Chamfer arg-mins) had hipcc-packed f32 arithmetic as well before the
+    library lost its packed-f32 instructions: their results beside the co-runner equal the results on an idle GPU, bit for bit."""
+    s2 = torch.cuda.Stream()
+    a = torch.randn(4096, 1536, device='cuda')
+    w = torch.randn(384, 1536, device='cuda') * 1536 ** -0.5
+    w._upp_persistent = True
+    out = torch.empty(4096, 384, device='cuda')
+    ops.linear_f32(a, w, out=out, frozen=True)
+    x = _seeded.noisy_clouds(32, 1024, seed=9).cuda().contiguous()
+    y = _seeded.noisy_clouds(32, 1024, seed=10).cuda().contiguous()
+    _, cen = ops.fps(x, 64, want_centers=True)
+    torch.cuda.synchronize()
+
+    def run():
+        d, ki, nb = ops.knn(x, cen, 32, want_dist=True, want_neigh=True)
+        d1, d2, i1, i2 = ops.chamfer_fwd(x, y)
+        return [t.clone() for t in (d, ki, nb, d1, d2, i1, i2)]
+    ref = run()
+    torch.cuda.synchronize()
+    for it in range(10):
+        with torch.cuda.stream(s2):
+            for _ in range(40):
+                ops.linear_f32(a, w, out=out, frozen=True)
+        got = run()
+        torch.cuda.synchronize()
+        for g_, r_ in zip(got, ref):
+            assert torch.equal(g_, r_), it
