@@ -159,6 +159,10 @@ int upp_emd_matchcost_bwd(const float *grad_cost, const float *xyz1, const float
  *   work: upp_patch_embed_work_floats(R, n) floats of scratch (16-byte aligned)
  *   out  (R/n, C) f32
  * Forward only (the encoder is frozen in every UPP recipe).
+ * Arithmetic (round 4): the 256 -> 512 and 512 -> C products run on the split-bf16 kernel of upp_linear_sb_f32 (both f32 operands as
+ * three bf16 terms, six products, f32 accumulation: the error of an f32 GEMM) for C <= 1024, their weights split into `work` by every
+ * call; the environment variable UPP_EMBED_SPLIT_BF16=0 (read per call) keeps the exact-f32 chain of rounds 1-3.  BatchNorm batch
+ * statistics are sums of per-workgroup partial sums in a fixed order (no atomics): the call is deterministic.
  * Limits: n in {16, 32}, R % n == 0, C % 4 == 0. */
 long long upp_patch_embed_work_floats(int R, int n);
 int upp_patch_embed_fwd(const float *pts, int R, int n,
