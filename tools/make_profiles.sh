@@ -61,7 +61,7 @@ python3 tools/fps_sweep.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_fps_sweep.
 # the packed-f32 anomaly beside a co-resident bf16-MFMA workgroup (canary kernels with their own inline asm; co-runner: upp_linear_sb_f32)
 mkdir -p tools/micro/bin
 hipcc --offload-arch=gfx950 -O2 tools/micro/src/lds_canary.cpp -o tools/micro/bin/lds_canary -Liccv2025-upp_amd/upp_hip/lib -lupp_hip -Wl,-rpath,$PWD/iccv2025-upp_amd/upp_hip/lib 2> /dev/null
-for a in "384 1536 0 0 2" "384 1536 0 0 0" "384 1536 0 0 1" "384 1536 0 29696 1"; do ./tools/micro/bin/lds_canary $a 2>&1 | grep -v "^VGPR op_sel" ; done > $O/r04_packed_f32_canary.txt
+for a in "384 1536 0 0 2" "384 1536 0 0 0" "384 1536 0 0 1" "384 1536 0 0 3" "1536 384 0 0 1" "384 1536 0 29696 1"; do ./tools/micro/bin/lds_canary $a 2>&1 | grep -v "^VGPR op_sel" ; done > $O/r04_packed_f32_canary.txt
 python3 tools/micro/fps_corun_probe.py 0 1024 2> /dev/null | grep -v amdgpu.ids >> $O/r04_packed_f32_canary.txt
 python3 tools/_fmt_linear.py $O/r04_time_linear.jsonl > $O/r04_time_linear.txt
 python3 tools/time_attention.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_attention.txt
