@@ -140,3 +140,28 @@ def test_library_contains_no_packed_f32_instruction():
             kernels += text.count("s_endpgm")
     assert kernels > 200 and mfma > 1000, (kernels, mfma)
     assert packed == 0, "%d packed-f32 instructions in libupp_hip.so" % packed
+
+
+def test_wgrad_sb_row_plan_is_well_formed_on_the_host():
+    """upp_linear_wgrad_grouped_sb_rows (host-only planning, no GPU call): every run length is a whole multiple of 32 rows, at most the
+    problem's rows rounded up to 32, the same plan for the same group, and tall problems are cut into many runs while short ones are not."""
+    lib = _abi.load()
+    groups = [
+        [(1216, 96, 384)] + [(2048, 1536, 384), (2048, 384, 1536), (2048, 384, 384), (2048, 1152, 384)] * 4
+        + [(832, 1536, 384), (832, 384, 1536), (832, 384, 384), (832, 1152, 384)] * 12 + [(65536, 384, 512), (65536, 256, 128)],
+        [(65536, 256, 512), (65536, 1024, 1536), (32, 128, 64), (32, 64, 16)],
+        [(1, 4, 4)], [(33, 36, 260)], [(140000, 256, 260)],
+    ]
+    for grp in groups:
+        k = len(grp)
+        M = (ctypes.c_int * k)(*[g[0] for g in grp]); N = (ctypes.c_int * k)(*[g[1] for g in grp]); K = (ctypes.c_int * k)(*[g[2] for g in grp])
+        r1, r2 = (ctypes.c_int * k)(), (ctypes.c_int * k)()
+        assert lib.upp_linear_wgrad_grouped_sb_rows(k, M, N, K, r1) == 0 and lib.upp_linear_wgrad_grouped_sb_rows(k, M, N, K, r2) == 0
+        assert list(r1) == list(r2)
+        for (m, n, kk), rows in zip(grp, r1):
+            assert rows >= 32 and rows % 32 == 0 and rows <= (m + 31) // 32 * 32, (m, n, kk, rows)
+            if m >= 65536 and n > 128 and kk > 128:
+                assert (m + rows - 1) // rows >= 8, (m, n, kk, rows)          # a tall problem feeds many workgroups
+            if m <= 1024:
+                assert (m + rows - 1) // rows <= 4, (m, n, kk, rows)
+    assert lib.upp_linear_wgrad_grouped_sb_rows(0, None, None, None, None) != 0
