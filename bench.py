@@ -243,13 +243,14 @@ DTYPE_NOTE = ("f32 storage, f32 results at f32 accuracy everywhere.  Linear laye
               "UPP_SPLIT_BF16=0 runs every Linear on the exact-f32 MFMA kernels")
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense f32
 MFMA_BF16_PEAK_TF = 2516.6  # 16 x the f32 rate (v_mfma_f32_32x32x16_bf16: 32 cycles for 16 x the products of a 64-cycle 32x32x2 f32): "~2.5 PF dense"
+SPLIT_BF16_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0   # 419.4: the ceiling of an f32 product formed from SIX bf16 matrix products (csrc/linear_sb.hip, wgrad_sb.hip)
 
 
 def _pmc_raw():
     """The committed rocprofv3 --pmc passes (profiles/r0N_pmc_kernels.json, produced by tools/make_profiles.sh: FETCH_SIZE and WRITE_SIZE in
     KB, separate passes; kernels not re-profiled in a round keep the entry of the last round that profiled them)."""
     raw = {}
-    for name in ("r01_pmc_kernels.json", "r02_pmc_kernels.json", "r03_pmc_kernels.json", "r04_pmc_kernels.json"):
+    for name in ("r01_pmc_kernels.json", "r02_pmc_kernels.json", "r03_pmc_kernels.json", "r04_pmc_kernels.json", "r05_pmc_kernels.json"):
         try:
             raw.update(json.load(open(os.path.join(ROOT, "profiles", name))))
         except Exception:
@@ -268,6 +269,43 @@ def _pmc_traffic():
 # gradients, as launched by models/upp_layers.py (label, M, N, K, epilogue).
 LINEAR_SHAPES = [("qkv", 2400, 1152, 384, 0), ("proj", 2400, 384, 384, 0), ("fc1_gelu_d", 2400, 1536, 384, 3), ("fc2", 2400, 384, 1536, 0),
                  ("dfc2_mul", 2400, 1536, 384, 4), ("dfc1", 2400, 384, 1536, 0), ("dproj", 2400, 384, 384, 0), ("dqkv", 2400, 384, 1152, 0)]
+# ... and every other Transformer-block shape of the headline step: the six prompt-free blocks of the back-end (65 tokens: M = 2080, forward
+# and data gradients), the rectify path's three blocks (35 tokens: M = 1120, forward only: GELU without its derivative) and the completion
+# prompter's four decoder blocks (64 tokens: M = 2048, forward only).  tools/prof_kernels.py launches each of them behind a marker and
+# tools/pmc_summary.py keys the counters 'linear:<label>'; roofline.traffic sums them over the step's launch list.
+STEP_LINEAR_SHAPES = (LINEAR_SHAPES
+                      + [("%s@2080" % lab, 2080, N, K, e) for lab, _, N, K, e in LINEAR_SHAPES]
+                      + [("%s@%d" % (lab, M), M, N, K, e) for M in (1120, 2048)
+                         for lab, N, K, e in (("qkv", 1152, 384, 0), ("proj", 384, 384, 0), ("fc1_gelu", 1536, 384, 2), ("fc2", 384, 1536, 0))])
+
+
+def linear_label(M, N, K, epi):
+    """The counter label of a step launch (first label of that shape: fc2 / dfc1 and proj / dproj are the same launch), or None."""
+    for lab, m, n, k, e in STEP_LINEAR_SHAPES:
+        if (m, n, k, e) == (M, N, K, epi):
+            return lab
+    return None
+
+
+def linear_algorithmic_bytes(M, N, K, epi, split):
+    """A + W + C (+ the second (M,N) tensor of the GELU' / multiply epilogues), f32; the split-bf16 kernel reads W as three bf16 planes."""
+    return 4.0 * (M * K + N * K + M * N * (2 if epi in (3, 4) else 1)) + (2.0 * N * K if split else 0.0)
+
+
+def sb_kernel_name(M, N, K):
+    """Kernel name (as rocprofv3 prints it) that serves a frozen-weight (M,N,K) Linear: host-side tile choice, no GPU needed."""
+    from upp_hip import _abi
+    sb = max(0, int(_abi.load().upp_linear_sb_tile(int(M), int(N), int(K))))
+    return ("linear_sb_kernel<%s>" % _sb_tile_str(sb)) if sb else ("linear_f32_kernel<%s>" % _abi_tile(M, N, K))
+
+
+def pmc_linear_entry(raw, label, kname):
+    """Committed counters of a labelled launch -- only if they were taken on the kernel this build launches for that label (a changed tile
+    choice or template signature makes the entry stale: tests/test_host.py asserts on the CPU that none is)."""
+    v = raw.get("linear:" + label)
+    if not v or "kernel" not in v or v["kernel"].replace(" ", "") != kname.replace(" ", ""):
+        return None
+    return (2.0 * v["fetch_kb_raw"] + v["write_kb"]) * 1024.0
 
 
 def stage_report(device, B):
@@ -279,15 +317,8 @@ def stage_report(device, B):
     pmc = _pmc_traffic()
     pmc_raw = _pmc_raw()
 
-    def pmc_entry(key, kname):
-        """Traffic of a labelled launch -- only if the committed counters were taken on the kernel this run launches for that label."""
-        v = pmc_raw.get(key)
-        if not v or "kernel" not in v or v["kernel"].replace(" ", "") != kname.replace(" ", ""):
-            return None
-        return (2.0 * v["fetch_kb_raw"] + v["write_kb"]) * 1024.0
-
     mfma_pmc = {}
-    for name in ("r04_pmc_mfma.json",):
+    for name in ("r04_pmc_mfma.json", "r05_pmc_mfma.json"):
         try:
             mfma_pmc.update(json.load(open(os.path.join(ROOT, "profiles", name))))
         except Exception:
@@ -310,10 +341,14 @@ def stage_report(device, B):
                 "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": nbytes, "traffic": traffic(pmc_key) if pmc_key else None,
                 **({"note": note} if note else {})}
 
-    def mfma(name, ms, flops, note=None, pmc_key=None):
+    def mfma(name, ms, flops, note=None, pmc_key=None, split=False):
+        """split: a split-bf16 kernel -- its ceiling is the BF16 pipe's rate / 6 products per f32 product (419.4 TFLOP/s algorithmic);
+        everything else forms its products with the f32 matrix instruction (157.3)."""
         tf = flops / ms / 1e9
-        return {"kernel": name, "bound": "mfma", "ms": ms, "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": tf / MFMA_F32_PEAK_TF, "algorithmic_flops": flops, **({"traffic": traffic(pmc_key)} if pmc_key else {}),
+        peak = SPLIT_BF16_PEAK_TF if split else MFMA_F32_PEAK_TF
+        return {"kernel": name, "bound": "mfma", "ms": ms, "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                "frac": tf / peak, **({"frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TF} if split else {}),
+                "algorithmic_flops": flops, **({"traffic": traffic(pmc_key)} if pmc_key else {}),
                 **({"note": note} if note else {})}
 
     x = _seeded.unit_ball_clouds(B, 1024, seed=7).to(device)
@@ -420,6 +455,7 @@ def stage_report(device, B):
     # the Linear layers of one block, stand-alone at M = 2400, on the kernel the step uses for a frozen weight (csrc/linear_sb.hip) and,
     # beside it, on the exact-f32 kernel (csrc/linear.hip)
     gl = torch.Generator(device=device).manual_seed(11)
+    missing = []
     for label, M, N, K, epi in LINEAR_SHAPES:
         a = torch.randn(M, K, device=device, generator=gl)
         w = torch.randn(N, K, device=device, generator=gl) * K ** -0.5
@@ -431,21 +467,30 @@ def stage_report(device, B):
         t = time_kernel(lambda: ops.linear_f32(a, w, bias if epi in (1, 2, 3, 5) else None, epi, aux=aux, out=res, frozen=True))
         t32 = time_kernel(lambda: ops.linear_f32(a, w, bias if epi in (1, 2, 3, 5) else None, epi, aux=aux, out=res))
         kname = ("linear_sb_kernel<%s>" % _sb_tile_str(sb)) if sb else ("linear_f32_kernel<%s>" % _abi_tile(M, N, K))
-        out["linear_" + label] = mfma("%s %s: (%d,%d) x (%d,%d)^T, epilogue %d" % (kname, label, M, K, N, K, epi), t, 2.0 * M * N * K)
+        out["linear_" + label] = mfma("%s %s: (%d,%d) x (%d,%d)^T, epilogue %d" % (kname, label, M, K, N, K, epi), t, 2.0 * M * N * K, split=bool(sb))
         e = out["linear_" + label]
         e["ms_exact_f32_kernel"] = t32
-        e["algorithmic_bytes"] = 4.0 * (M * K + N * K + M * N * (2 if epi in (3, 4) else 1)) + (2.0 * N * K if sb else 0.0)   # (W as three bf16 planes)
-        p = pmc_entry("linear:" + label, kname)
-        e["traffic"] = p
+        e["algorithmic_bytes"] = linear_algorithmic_bytes(M, N, K, epi, bool(sb))
+        e["traffic"] = pmc_linear_entry(pmc_raw, label, kname)
+        if e["traffic"] is None:
+            missing.append("linear:%s (%s)" % (label, kname))
+        else:
+            e["traffic_over_algorithmic"] = e["traffic"] / e["algorithmic_bytes"]
         m = mfma_pmc.get("linear:" + label)
-        if m and m.get("kernel", "").startswith(kname.split("<")[0]):      # counters of THIS kernel family only (profiles/r04_pmc_mfma.json)
+        if m and m.get("kernel", "").replace(" ", "") == kname.replace(" ", ""):      # counters of THIS kernel only (profiles/r0N_pmc_mfma.json)
             e["mfma_pipe_frac_pmc"] = m.get("mfma_pipe_frac")
             e["clock_ghz_pmc"] = m.get("clock_ghz")
+    if missing:
+        msg = "bench.py: no committed PMC counters for the kernel this build launches: " + ", ".join(missing)
+        if os.environ.get("UPP_BENCH_STRICT", "0") == "1":         # tools/make_profiles.sh: a profile set whose join lost a label is rejected
+            raise RuntimeError(msg)
+        print(msg, file=sys.stderr)
     return out
 
 
 def _sb_tile_str(c):
-    return "%d, %d, %d, %d, %d" % ((c >> 16) & 15, (c >> 12) & 15, (c >> 8) & 15, (c >> 4) & 15, c & 15)
+    """Template arguments of linear_sb_kernel<BMB, BNB, RN, KS, NST, PRO> as rocprofv3 prints them (PRO = 0: no A-operand prologue)."""
+    return "%d, %d, %d, %d, %d, 0" % ((c >> 16) & 15, (c >> 12) & 15, (c >> 8) & 15, (c >> 4) & 15, c & 15)
 
 
 def _abi_tile(M, N, K):
@@ -456,10 +501,13 @@ def _abi_tile(M, N, K):
 
 def linear_family_replay(ts, device):
     """The upp_linear_f32 launches of ONE training step: their (M, N, K, epilogue) sequence is recorded from an eager run of the
-    step driver's forward + loss + backward, then the same sequence of launches (same shapes, same order, synthetic operands)
-    is captured into a HIP graph and its replay timed with HIP events on the launch stream -- device time of the family without
-    the host, with the kernel-to-kernel boundaries of a real step (~1.2 us each) included.
-    -> (flops per step, ms per step, launches, per-shape rows)."""
+    step driver's forward + loss + backward, then the same sequence of launches, in step order, is captured into a HIP graph and its
+    replay timed with HIP events on the launch stream -- device time of the family without the host, with the kernel-to-kernel
+    boundaries of a real step (~1.2 us each) included.  EVERY launch has its own weight (plane image), its own input and its own
+    output, as in the step: the twelve layers' weights do not fit the L2 and are not hot in it (round 4 replayed one weight per shape
+    and read 10 % high).  Launches of more than 64 MB of activations (the point-row matrices of the segmentation head) share a ring of
+    four activation sets per shape; their weights stay distinct.
+    -> (flops per step, ms per step, launches, per-shape rows, split-bf16 flops, the (M, N, K, epilogue, sb) list)."""
     from upp_hip import ops
     ts._forward_backward()
     with ops.time_linear_calls() as scope:
@@ -467,18 +515,30 @@ def linear_family_replay(ts, device):
     calls = [(M, N, K, e, sb) for M, N, K, e, _, sb in scope.report()]      # sb: tile code of the split-bf16 kernel (frozen weights), 0 = exact f32
     groups = list(scope.wgrad_groups)           # the weight gradients: one grouped launch per entry (upp_linear_wgrad_grouped_f32)
     gl = torch.Generator(device=device).manual_seed(5)
-    bufs = {}
-    for M, N, K, e, sb in calls:
-        if (M, N, K) not in bufs:
-            bufs[(M, N, K)] = (torch.randn(M, K, device=device, generator=gl), torch.randn(N, K, device=device, generator=gl) * K ** -0.5,
-                               torch.randn(N, device=device, generator=gl), torch.randn(M, N, device=device, generator=gl),
-                               torch.empty(M, N, device=device), torch.empty(M, N, device=device))
-            bufs[(M, N, K)][1]._upp_persistent = True          # (stands for a frozen weight: ops.PLANES keeps its plane image)
 
-    def launch(M, N, K, e, sb):
-        a, w, b, x, o, d = bufs[(M, N, K)]
-        lib_aux = x if e == ops.LIN_MUL else None
-        ops.linear_f32(a, w, b if e in (1, 2, 3, 5) else None, e, aux=lib_aux, out=o, frozen=bool(sb))
+    def operands(M, N, K):
+        return [torch.randn(M, K, device=device, generator=gl), torch.randn(N, device=device, generator=gl),
+                torch.randn(M, N, device=device, generator=gl), torch.empty(M, N, device=device)]
+
+    ring, seen, per_launch = {}, {}, []
+    for M, N, K, e, sb in calls:
+        w = torch.randn(N, K, device=device, generator=gl) * K ** -0.5
+        w._upp_persistent = True                # (stands for a frozen weight: ops.PLANES keeps its plane image)
+        n_prev = seen.get((M, N, K), 0)
+        seen[(M, N, K)] = n_prev + 1
+        if 4.0 * M * (K + 2 * N) > 64e6:
+            sets = ring.setdefault((M, N, K), [])
+            if len(sets) < 4:
+                sets.append(operands(M, N, K))
+            act = sets[n_prev % 4]
+        else:
+            act = operands(M, N, K)
+        per_launch.append((w, act))
+
+    def launch(i):
+        M, N, K, e, sb = calls[i]
+        w, (a, b, x, o) = per_launch[i]
+        ops.linear_f32(a, w, b if e in (1, 2, 3, 5) else None, e, aux=x if e == ops.LIN_MUL else None, out=o, frozen=bool(sb))
 
     wbufs = {}
     for grp in groups:
@@ -487,18 +547,19 @@ def linear_family_replay(ts, device):
                 wbufs[(M, N, K)] = (torch.randn(M, N, device=device, generator=gl), torch.randn(M, K, device=device, generator=gl))
 
     def run_all():
-        for c in calls:
-            launch(*c)
+        for i in range(len(calls)):
+            launch(i)
         for grp in groups:
             ops.linear_wgrad_grouped([wbufs[s_] for s_ in grp])
     ms = time_kernel(run_all, iters=1, warm=2)
     by = {}
-    for c in calls:
-        by[c] = by.get(c, 0) + 1
+    for i, c in enumerate(calls):
+        by.setdefault(c, []).append(i)
     shapes = []
-    for (M, N, K, e, sb), n in sorted(by.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2]):
-        t = time_kernel(lambda: launch(M, N, K, e, sb), iters=10, warm=1)
-        shapes.append({"M": M, "N": N, "K": K, "epilogue": e, "kernel": ("linear_sb %x" % sb) if sb else "linear_f32", "launches_per_step": n,
+    for (M, N, K, e, sb), idx in sorted(by.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1] * kv[0][2]):
+        # stand-alone figure of a shape: its launches of the step one after the other (distinct weights), not one launch repeated
+        t = time_kernel(lambda: [launch(i) for i in idx], iters=max(1, 10 // len(idx)), warm=1) / len(idx)
+        shapes.append({"M": M, "N": N, "K": K, "epilogue": e, "kernel": ("linear_sb %x" % sb) if sb else "linear_f32", "launches_per_step": len(idx),
                        "ms_per_launch": t, "tflops": 2.0 * M * N * K / t / 1e9})
     for grp in groups:
         t = time_kernel(lambda: ops.linear_wgrad_grouped([wbufs[s_] for s_ in grp]), iters=5, warm=1)
@@ -507,7 +568,36 @@ def linear_family_replay(ts, device):
                        "ms_per_launch": t, "tflops": fl / t / 1e9})
     flops = sum(2.0 * M * N * K for M, N, K, _, _ in calls) + sum(2.0 * M * N * K for grp in groups for M, N, K in grp)
     sb_flops = sum(2.0 * M * N * K for M, N, K, _, sb in calls if sb)
-    return flops, ms, len(calls) + len(groups), shapes, sb_flops
+    return flops, ms, len(calls) + len(groups), shapes, sb_flops, calls
+
+
+def family_traffic(calls):
+    """HBM-side bytes of the family per step from the committed counters: every launch of the recorded list whose (M, N, K, epilogue) carries
+    a label in STEP_LINEAR_SHAPES contributes that label's measured bytes (taken on the same kernel: pmc_linear_entry); the rest -- heads,
+    position MLPs, point-wise layers: tiny -- are reported as uncovered with their share of the flops.
+    -> dict(traffic, algorithmic_bytes, covered_launches, covered_flops_frac, uncovered) or None if any labelled launch lacks counters."""
+    raw = _pmc_raw()
+    total = alg = cov_fl = all_fl = 0.0
+    covered, uncovered = 0, []
+    for M, N, K, e, sb in calls:
+        fl = 2.0 * M * N * K
+        all_fl += fl
+        lab = linear_label(M, N, K, e)
+        if lab is None:
+            uncovered.append([M, N, K, e])
+            continue
+        kname = ("linear_sb_kernel<%s>" % _sb_tile_str(sb)) if sb else ("linear_f32_kernel<%s>" % _abi_tile(M, N, K))
+        t = pmc_linear_entry(raw, lab, kname)
+        if t is None:
+            return None
+        total += t
+        alg += linear_algorithmic_bytes(M, N, K, e, bool(sb))
+        covered += 1
+        cov_fl += fl
+    if not covered:
+        return None
+    return {"traffic": total, "algorithmic_bytes": alg, "traffic_over_algorithmic": total / alg, "covered_launches": covered,
+            "covered_flops_frac": cov_fl / all_fl, "uncovered_launches": len(uncovered)}
 
 
 def cpu_baseline(budget_s=20.0, batch=32):
@@ -657,16 +747,19 @@ def main():
         roof = None
         if not args.no_stage_report and world == 1:
             seq = tr if not pipeline else RecipeTrainer(args.workload, device, args.batch, use_graph=False, pipeline=False)
-            flops, ms, n, shapes, sb_flops = linear_family_replay(seq.ts, device)
+            flops, ms, n, shapes, sb_flops, _ = linear_family_replay(seq.ts, device)
             tf = flops / ms / 1e9
             shapes.sort(key=lambda r: -r["ms_per_launch"] * r["launches_per_step"])
             roof = {"kernel": "linear_sb_kernel<*> + linear_f32_kernel<*> + linear_rt_kernel<*> + wgrad_sb_kernel<*> (csrc/linear_sb.hip, "
                               "linear.hip, linear_rt.hip, wgrad_sb.hip): ALL %d Linear launches of one step (forward, data gradients, grouped "
                               "weight gradients); %.0f %% of the forward / data-gradient flops on the split-bf16 kernel (frozen and "
                               "driver-managed weights), the weight gradients on its two-operand form" % (n, 100.0 * sb_flops / flops),
-                    "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "ms": ms,
-                    "launches": n, "algorithmic_flops": flops, "traffic": None,
-                    "how": "launch list recorded from an eager step, replayed as one HIP graph, HIP events on the launch stream",
+                    "bound": "mfma", "achieved": tf, "peak": SPLIT_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / SPLIT_BF16_PEAK_TF,
+                    "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TF,
+                    "peak_note": "peak = 2,516.6 TFLOP/s (v_mfma_f32_32x32x16_bf16, dense) / 6 bf16 products per f32 product",
+                    "ms": ms, "launches": n, "algorithmic_flops": flops, "traffic": None,
+                    "how": "launch list recorded from an eager step, replayed in step order as one HIP graph (own weight per launch), HIP "
+                           "events on the launch stream",
                     "by_shape": shapes[:14]}
         print(json.dumps({
             "metric": "point-clouds/sec fwd+bwd, secondary recipe '%s'" % args.workload,
@@ -714,15 +807,14 @@ def main():
                 line["ms_per_step_sequential"] = 1000.0 * (time.perf_counter() - t1) / args.steps
             elif not pipeline:
                 line["ms_per_step_sequential"] = line["ms_per_step"]
-            flops, ms, n, shapes, sb_flops = linear_family_replay(seq.ts, device)
+            flops, ms, n, shapes, sb_flops, calls = linear_family_replay(seq.ts, device)
             tf = flops / ms / 1e9
             stages = stage_report(device, args.batch)
-            pmc_step = [stages["linear_" + lab].get("traffic") for lab, *_ in LINEAR_SHAPES]
+            fam = family_traffic(calls)
             # (the Transformer-block layers: token rows x {384, 1152, 1536}^2; the heads have at most B rows, the prompter layers other widths)
             blk = [r for r in shapes if "M" in r and r["M"] > args.batch and r["N"] in (384, 1152, 1536) and r["K"] in (384, 1152, 1536)]
             blk_ms = sum(r["ms_per_launch"] * r["launches_per_step"] for r in blk) or float("nan")
             blk_fl = sum(2.0 * r["M"] * r["N"] * r["K"] * r["launches_per_step"] for r in blk)
-            executed = 6.0 * sb_flops / ms / 1e9           # bf16 matrix-pipe TFLOP/s actually issued by the split kernel (six products per f32 product)
             line["roofline"] = {
                 "kernel": "Linear family = linear_sb_kernel<*> (csrc/linear_sb.hip: frozen weights, f32 operands split exactly into three bf16 "
                           "terms, six bf16 MFMA products, f32 accumulate; %.1f %% of the flops) + linear_f32_kernel<*> (csrc/linear.hip: exact-f32 "
@@ -731,23 +823,27 @@ def main():
                           "(tiny: launch-bound); the kernel family with the most GPU time per step"
                           % (100.0 * sb_flops / flops, n, sum(r["launches_per_step"] for r in blk), 100.0 * blk_fl / flops),
                 "block_layers": {"launches": sum(r["launches_per_step"] for r in blk), "ms": blk_ms, "achieved": blk_fl / blk_ms / 1e9,
-                                 "frac": blk_fl / blk_ms / 1e9 / MFMA_F32_PEAK_TF,
-                                 "how": "sum over by_shape rows of the Transformer-block shapes: stand-alone graph-replay time x launches"},
-                "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-                "peak_note": "achieved = ALGORITHMIC f32 flops (sum 2 M N K) per second; peak = the FP32 matrix instruction's 157.3 TFLOP/s, the "
-                             "ceiling of any kernel that forms these f32 products on v_mfma_f32_32x32x2_f32 (rounds 1-3).  The split-bf16 kernel "
-                             "leaves that pipe: see bf16_pipe for the same time priced on the pipe it runs on",
-                "bf16_pipe": {"executed_tflops": executed, "peak": MFMA_BF16_PEAK_TF, "frac": executed / MFMA_BF16_PEAK_TF,
-                              "note": "6 x the algorithmic flops of the split-bf16 launches / the family's time (the exact-f32 launches' "
-                                      "time included, their flops not): the loop is bound by operand delivery (L2 -> LDS) and the in-register "
-                                      "operand split, not by the bf16 matrix pipe (DESIGN.md section 4)"},
+                                 "frac": blk_fl / blk_ms / 1e9 / SPLIT_BF16_PEAK_TF,
+                                 "how": "sum over by_shape rows of the Transformer-block shapes: the shape's launches of the step replayed back "
+                                        "to back (own weights) x launches"},
+                "bound": "mfma", "achieved": tf, "peak": SPLIT_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / SPLIT_BF16_PEAK_TF,
+                "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TF,
+                "peak_note": "achieved = ALGORITHMIC f32 flops (sum 2 M N K) per second over the family's time.  peak = the ceiling of the "
+                             "arithmetic the kernel performs: 2,516.6 TFLOP/s of v_mfma_f32_32x32x16_bf16 (dense) / 6 bf16 products per f32 "
+                             "product = 419.4; frac is therefore the share of the BF16 matrix pipe's time the family keeps busy (compare "
+                             "kernels.linear_*.mfma_pipe_frac_pmc).  frac_of_f32_mfma_peak prices the same flops against the f32 matrix "
+                             "instruction's 157.3 (the scale of rounds 1-4; it exceeds 1 where the split kernel beats that pipe's ceiling)",
                 "ms": ms, "launches": n, "algorithmic_flops": flops,
-                "traffic": None if any(v is None for v in pmc_step) else sum(pmc_step),
-                "traffic_note": "PMC bytes of the eight launches of ONE block at M = 2400 (kernels.linear_*), not of the whole step",
+                "traffic": None if fam is None else fam["traffic"],
+                "traffic_detail": fam,
+                "traffic_note": "HBM-side bytes of the family per STEP (like achieved: per replay of the launch list): sum over the recorded "
+                                "launches of the committed rocprofv3 --pmc counters of that launch's shape (2 x FETCH_SIZE + WRITE_SIZE, "
+                                "profiles/r05_pmc_kernels.json 'linear:<label>', each taken on the kernel this run launches); launches "
+                                "without a label (heads, position MLPs: < 1 % of the flops) are not counted on either side",
                 "how": "the step's launch sequence (recorded from an eager step: shapes, epilogues and which of the two kernels served each "
-                       "launch) replayed as one HIP graph, HIP events on the launch stream; kernel-to-kernel boundaries included.  "
-                       "profiles/r04_bench_sequential_kernel_stats.csv holds the same launches inside the step under rocprofv3 (sum of "
-                       "linear_sb_kernel<*> + linear_f32_kernel<*> over 14 executions of the step), profiles/r04_step_census.txt ONE step",
+                       "launch) replayed in step order as one HIP graph, every launch with its own weight / input / output, HIP events on "
+                       "the launch stream; kernel-to-kernel boundaries included.  profiles/r05_bench_sequential_kernel_stats.csv holds the "
+                       "same launches inside the step under rocprofv3, profiles/r05_step_census.txt ONE replayed step",
                 "by_shape": shapes}
             line["kernels"] = stages
         if not args.no_cpu_baseline and world == 1:

@@ -169,3 +169,29 @@ def test_capture_state_snapshot_restores_in_place():
         assert torch.equal(v, before[k]), k
     assert [p.data_ptr() for p in m.parameters()] == ptrs and float(flat.abs().sum()) == 0.0
     assert torch.equal(opt.state_dict()['state'][0]['step'], step_before)
+
+
+def test_committed_pmc_counters_were_taken_on_the_kernels_this_build_launches():
+    """bench.py attaches the committed rocprofv3 --pmc counters of a labelled Linear launch only if they were measured on the kernel the
+    present build launches for that label (name with ALL template arguments).  Round 4's driver line carried traffic = null for every
+    label because a sixth template argument had been added after the counters were taken; this is the commit-time guard: the tile choice
+    is a host function of the library, so the join can be checked without a GPU."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    raw = bench._pmc_raw()
+    stale, missing = [], []
+    for label, M, N, K, epi in bench.STEP_LINEAR_SHAPES:
+        kname = bench.sb_kernel_name(M, N, K)
+        assert kname.startswith("linear_sb_kernel<") and kname.count(",") == 5, kname      # six template arguments, as rocprofv3 prints them
+        if "linear:" + label not in raw:
+            missing.append(label)
+        elif bench.pmc_linear_entry(raw, label, kname) is None:
+            stale.append("%s: counters on %s, build launches %s" % (label, raw["linear:" + label].get("kernel"), kname))
+    assert not stale, stale
+    assert not [m for m in missing if "@" not in m], missing          # the eight labels of one block at M = 2400: always present
+    # every labelled shape of the step resolves back to its (first) label
+    for label, M, N, K, epi in bench.STEP_LINEAR_SHAPES:
+        assert bench.linear_label(M, N, K, epi) in [l for l, m, n, k, e in bench.STEP_LINEAR_SHAPES if (m, n, k, e) == (M, N, K, epi)]

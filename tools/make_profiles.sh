@@ -1,12 +1,12 @@
 #!/bin/bash
-# Regenerate profiles/r04_* on a GPU box (run from the repo root through gpurun), in two calls (each fits one gpurun limit):
+# Regenerate profiles/r05_* on a GPU box (run from the repo root through gpurun), in two calls (each fits one gpurun limit):
 #     gpurun --timeout 1200 -- 'bash tools/make_profiles.sh headline'
 #     gpurun --timeout 1200 -- 'bash tools/make_profiles.sh recipes'
 # rocprofv3 kernel traces of the headline step (one stream / pipelined), of the stand-alone kernels, two PMC passes
 # (FETCH_SIZE, WRITE_SIZE: separate runs, never combined with a trace domain), then the un-profiled bench lines.
 set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r04
+O=gpurun_out/r05
 mkdir -p $O
 PART=${1:-headline}
 stats() { ls $1/*/*kernel_stats.csv | head -1; }
@@ -14,59 +14,59 @@ trace() { ls $1/*/*kernel_trace.csv | head -1; }
 if [ "$PART" = "headline" ]; then
 # (executions of the step per trace: 2 eager warm-ups + 2 replays + 10 timed = 14)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/seq -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipeline --no-stage-report > $O/seq.log 2>&1
-cp "$(stats $O/seq)" $O/r04_bench_sequential_kernel_stats.csv
-python3 tools/phase_summary.py "$(trace $O/seq)" > $O/r04_phase_summary.txt
-python3 tools/step_census.py "$(trace $O/seq)" > $O/r04_step_census.txt
+cp "$(stats $O/seq)" $O/r05_bench_sequential_kernel_stats.csv
+python3 tools/phase_summary.py "$(trace $O/seq)" > $O/r05_phase_summary.txt
+python3 tools/step_census.py "$(trace $O/seq)" > $O/r05_step_census.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pipe -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-stage-report > $O/pipe.log 2>&1
-cp "$(stats $O/pipe)" $O/r04_bench_kernel_stats.csv
+cp "$(stats $O/pipe)" $O/r05_bench_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kern -- python3 tools/prof_kernels.py > $O/kern.log 2>&1
-cp "$(stats $O/kern)" $O/r04_kernels_kernel_stats.csv
+cp "$(stats $O/kern)" $O/r05_kernels_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 tools/prof_kernels.py > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 tools/prof_kernels.py > $O/write.log 2>&1
-python3 tools/pmc_summary.py "$(ls $O/fetch/*/*counter_collection.csv | head -1)" "$(ls $O/write/*/*counter_collection.csv | head -1)" "$(trace $O/kern)" > $O/r04_pmc_kernels.json || { echo "PMC self-check FAILED (see pmc_summary.py)"; mv $O/r04_pmc_kernels.json $O/r04_pmc_kernels.REJECTED.json; }
+python3 tools/pmc_summary.py "$(ls $O/fetch/*/*counter_collection.csv | head -1)" "$(ls $O/write/*/*counter_collection.csv | head -1)" "$(trace $O/kern)" > $O/r05_pmc_kernels.json || { echo "PMC self-check FAILED (see pmc_summary.py)"; mv $O/r05_pmc_kernels.json $O/r05_pmc_kernels.REJECTED.json; }
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES --output-format csv -d $O/mfma -- python3 tools/prof_kernels.py > $O/mfma.log 2>&1
-python3 tools/pmc_mfma_summary.py "$(ls $O/mfma/*/*counter_collection.csv | head -1)" "$(trace $O/kern)" > $O/r04_pmc_mfma.json
-python3 bench.py --no-cpu-baseline --no-pipeline > $O/r04_bench_sequential.json 2> $O/bench_seq.err
-python3 bench.py > $O/r04_bench.json 2> $O/bench.err
+python3 tools/pmc_mfma_summary.py "$(ls $O/mfma/*/*counter_collection.csv | head -1)" "$(trace $O/kern)" > $O/r05_pmc_mfma.json
+python3 bench.py --no-cpu-baseline --no-pipeline > $O/r05_bench_sequential.json 2> $O/bench_seq.err
+python3 bench.py > $O/r05_bench.json 2> $O/bench.err
 rm -rf $O/seq $O/pipe $O/kern $O/fetch $O/write $O/mfma
 fi
 if [ "$PART" = "recipes" ]; then
 # secondary recipes: un-profiled lines + one kernel summary for the pre-training step (8 executions: 2 eager + 1 replay + 5 timed)
-for w in cls_aux stage2 pretask pretrain seg; do python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > $O/r04_workload_$w.json 2> $O/w_$w.err; done
-python3 bench.py --workload seg --steps 10 --warmup 3 --no-cpu-baseline --no-pipeline --no-stage-report > $O/r04_workload_seg_sequential.json 2>> $O/w_seg.err
+for w in cls_aux stage2 pretask pretrain seg; do python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > $O/r05_workload_$w.json 2> $O/w_$w.err; done
+python3 bench.py --workload seg --steps 10 --warmup 3 --no-cpu-baseline --no-pipeline --no-stage-report > $O/r05_workload_seg_sequential.json 2>> $O/w_seg.err
 # kernel summaries of the recipes that used to run library GEMMs / unfused torch formulations (8 executions of the step each: 2 eager + 1 replay + 5 timed; one stream)
 for w in pretrain seg stage2; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_$w -- python3 bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline --no-pipeline --no-stage-report > $O/p_$w.log 2>&1
-  cp "$(stats $O/p_$w)" $O/r04_workload_${w}_kernel_stats.csv
+  cp "$(stats $O/p_$w)" $O/r05_workload_${w}_kernel_stats.csv
   rm -rf $O/p_$w
 done
-python3 tools/micro/time_linear_tall.py --tuned 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_linear_tall.txt
-./tools/micro/bin/rt_bench 100 tall > $O/r04_rt_bench.txt 2>&1
-./tools/micro/bin/rt_bench 30 wgrad >> $O/r04_rt_bench.txt 2>&1
-python3 tools/glue_census_recipe.py seg 2> /dev/null | grep -v amdgpu.ids > $O/r04_glue_census_seg.txt
-python3 tools/glue_census_recipe.py stage2 2> /dev/null | grep -v amdgpu.ids > $O/r04_glue_census_stage2.txt
-python3 tools/micro/time_bn_rows.py 50 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_bn_rows.txt
-python3 tools/linear_calls.py seg 2> /dev/null | grep -v amdgpu.ids > $O/r04_linear_calls_seg.txt
-python3 tools/linear_calls.py headline 2> /dev/null | grep -v amdgpu.ids > $O/r04_linear_calls_headline.txt
-python3 tools/time_linear.py --tiles --rows 2720,4128,4416,8832 --out $O/time_linear_rows.json > $O/r04_time_linear_rows.jsonl 2> /dev/null
-python3 tools/time_linear.py --tiles > $O/r04_time_linear.jsonl 2> /dev/null
-python3 tools/time_linear_sb.py --tiles --out $O/r04_time_linear_sb.jsonl > /dev/null 2>&1
-python3 tools/micro/sb_stamps.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_sb_stamps.txt
-python3 tools/micro/time_wgrad.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_wgrad.txt
-for w in pretrain seg; do echo "== $w" >> $O/r04_time_wgrad.txt; python3 tools/micro/wgrad_groups.py $w 2> /dev/null | grep -v amdgpu.ids >> $O/r04_time_wgrad.txt; done
-python3 tools/micro/time_tall_tiles.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_tall_tiles.txt
-python3 tools/time_patch_embed.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_patch_embed.txt
-UPP_EMBED_SPLIT_BF16=0 python3 tools/time_patch_embed.py 2> /dev/null | grep -v amdgpu.ids | sed 's/^/exact-f32 chain: /' >> $O/r04_time_patch_embed.txt
-python3 tools/fps_sweep.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_fps_sweep.txt
+python3 tools/micro/time_linear_tall.py --tuned 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_linear_tall.txt
+./tools/micro/bin/rt_bench 100 tall > $O/r05_rt_bench.txt 2>&1
+./tools/micro/bin/rt_bench 30 wgrad >> $O/r05_rt_bench.txt 2>&1
+python3 tools/glue_census_recipe.py seg 2> /dev/null | grep -v amdgpu.ids > $O/r05_glue_census_seg.txt
+python3 tools/glue_census_recipe.py stage2 2> /dev/null | grep -v amdgpu.ids > $O/r05_glue_census_stage2.txt
+python3 tools/micro/time_bn_rows.py 50 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_bn_rows.txt
+python3 tools/linear_calls.py seg 2> /dev/null | grep -v amdgpu.ids > $O/r05_linear_calls_seg.txt
+python3 tools/linear_calls.py headline 2> /dev/null | grep -v amdgpu.ids > $O/r05_linear_calls_headline.txt
+python3 tools/time_linear.py --tiles --rows 2720,4128,4416,8832 --out $O/time_linear_rows.json > $O/r05_time_linear_rows.jsonl 2> /dev/null
+python3 tools/time_linear.py --tiles > $O/r05_time_linear.jsonl 2> /dev/null
+python3 tools/time_linear_sb.py --tiles --out $O/r05_time_linear_sb.jsonl > /dev/null 2>&1
+python3 tools/micro/sb_stamps.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_sb_stamps.txt
+python3 tools/micro/time_wgrad.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_wgrad.txt
+for w in pretrain seg; do echo "== $w" >> $O/r05_time_wgrad.txt; python3 tools/micro/wgrad_groups.py $w 2> /dev/null | grep -v amdgpu.ids >> $O/r05_time_wgrad.txt; done
+python3 tools/micro/time_tall_tiles.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_tall_tiles.txt
+python3 tools/time_patch_embed.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_patch_embed.txt
+UPP_EMBED_SPLIT_BF16=0 python3 tools/time_patch_embed.py 2> /dev/null | grep -v amdgpu.ids | sed 's/^/exact-f32 chain: /' >> $O/r05_time_patch_embed.txt
+python3 tools/fps_sweep.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_fps_sweep.txt
 # the packed-f32 anomaly beside a co-resident bf16-MFMA workgroup (canary kernels with their own inline asm; co-runner: upp_linear_sb_f32)
 mkdir -p tools/micro/bin
 hipcc --offload-arch=gfx950 -O2 tools/micro/src/lds_canary.cpp -o tools/micro/bin/lds_canary -Liccv2025-upp_amd/upp_hip/lib -lupp_hip -Wl,-rpath,$PWD/iccv2025-upp_amd/upp_hip/lib 2> /dev/null
-for a in "384 1536 0 0 2" "384 1536 0 0 0" "384 1536 0 0 1" "384 1536 0 0 3" "1536 384 0 0 1" "384 1536 0 29696 1"; do ./tools/micro/bin/lds_canary $a 2>&1 | grep -v "^VGPR op_sel" ; done > $O/r04_packed_f32_canary.txt
-python3 tools/micro/fps_corun_probe.py 0 1024 2> /dev/null | grep -v amdgpu.ids >> $O/r04_packed_f32_canary.txt
-python3 tools/_fmt_linear.py $O/r04_time_linear.jsonl > $O/r04_time_linear.txt
-python3 tools/time_attention.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_time_attention.txt
-python3 tools/micro/time_ln_adapter.py 2> /dev/null | grep -v amdgpu.ids >> $O/r04_time_attention.txt
-python3 tools/glue_census.py 2> /dev/null | grep -v amdgpu.ids > $O/r04_glue_census.txt
+for a in "384 1536 0 0 2" "384 1536 0 0 0" "384 1536 0 0 1" "384 1536 0 0 3" "1536 384 0 0 1" "384 1536 0 29696 1"; do ./tools/micro/bin/lds_canary $a 2>&1 | grep -v "^VGPR op_sel" ; done > $O/r05_packed_f32_canary.txt
+python3 tools/micro/fps_corun_probe.py 0 1024 2> /dev/null | grep -v amdgpu.ids >> $O/r05_packed_f32_canary.txt
+python3 tools/_fmt_linear.py $O/r05_time_linear.jsonl > $O/r05_time_linear.txt
+python3 tools/time_attention.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_attention.txt
+python3 tools/micro/time_ln_adapter.py 2> /dev/null | grep -v amdgpu.ids >> $O/r05_time_attention.txt
+python3 tools/glue_census.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_glue_census.txt
 ls -la $O
 fi
 ls -la $O

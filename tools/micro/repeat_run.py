@@ -1,4 +1,4 @@
-"""Call one test function several times in ONE process and report every failure:  python tools/micro/repeat_test.py tests/test_gpu_block.py test_name [n]"""
+"""Call one test function several times in ONE process and report every failure:  python tools/micro/repeat_run.py tests/test_gpu_block.py test_name [n]"""
 import importlib.util, os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("oracle", "tests", "iccv2025-upp_amd"):

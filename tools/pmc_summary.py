@@ -6,7 +6,7 @@ us, fetch_kb_raw (FETCH_SIZE as reported, KB -- bench.py doubles it per the gfx9
 
 Labelled Linear launches: prof_kernels.py puts a MARKER dispatch (transpose_kernel) in front of each; the first linear_sb_kernel /
 linear_f32_kernel dispatch behind the i-th marker gets the key 'linear:<label>' (split-bf16 kernel) or 'linear_f32:<label>' (exact-f32
-kernel) of LINEAR_ORDER[i % 16], and the entry carries the kernel name it was measured on.  Self-check (exit code 2 on failure): the bytes
+kernel) of LINEAR_ORDER[i % len(LINEAR_ORDER)], and the entry carries the kernel name it was measured on.  Self-check (exit code 2 on failure): the bytes
 written by a labelled launch must be its M x N x 4 (x 2 with the GELU' output) within 10 %, and its traffic at least 0.9 x its algorithmic
 bytes -- a rotated join (round 3) fails both."""
 import collections
@@ -18,9 +18,8 @@ import statistics
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-LINEAR_SHAPES = [("qkv", 2400, 1152, 384, 0), ("proj", 2400, 384, 384, 0), ("fc1_gelu_d", 2400, 1536, 384, 3), ("fc2", 2400, 384, 1536, 0),
-                 ("dfc2_mul", 2400, 1536, 384, 4), ("dfc1", 2400, 384, 1536, 0), ("dproj", 2400, 384, 384, 0), ("dqkv", 2400, 384, 1152, 0)]   # == bench.LINEAR_SHAPES
-LINEAR_ORDER = [("linear:", s) for s in LINEAR_SHAPES] + [("linear_f32:", s) for s in LINEAR_SHAPES]      # prof_kernels.py: frozen=True, then False
+from bench import LINEAR_SHAPES, STEP_LINEAR_SHAPES  # noqa: E402
+LINEAR_ORDER = [("linear:", s) for s in STEP_LINEAR_SHAPES] + [("linear_f32:", s) for s in LINEAR_SHAPES]      # prof_kernels.py: frozen=True (every block shape), then False (M = 2400)
 MARKER = 'transpose_kernel'
 
 

@@ -75,15 +75,16 @@ for _ in range(5):
     xa, h = HF.rowln(tok, add=pos, prompts=prm, mode=HF.ROW_INSERT_CLS, P=10, gamma=g1, beta=b1)
     out = HF.attention(qkv, 6, 0.125)
     out.sum().backward()
-# The Linear layers of one Transformer block (bench.LINEAR_SHAPES) on the kernel the step uses for a frozen weight (csrc/linear_sb.hip), then
-# on the exact-f32 kernel (csrc/linear.hip).  Every labelled launch is preceded by a MARKER launch (transpose_kernel: used nowhere else in
-# this script): tools/pmc_summary.py gives the first Linear dispatch behind the i-th marker the label LINEAR_LABELS[i % 16] -- whatever else
-# of the same kernel name ran before (round 3 counted dispatches modulo 8 and was rotated by five un-labelled launches of the patch embedding).
+# The Linear layers of the Transformer blocks at every token count of the headline step (bench.STEP_LINEAR_SHAPES) on the kernel the step uses
+# for a frozen weight (csrc/linear_sb.hip), then the M = 2400 ones (bench.LINEAR_SHAPES) on the exact-f32 kernel (csrc/linear.hip).  Every labelled
+# launch is preceded by a MARKER launch (transpose_kernel: used nowhere else in this script): tools/pmc_summary.py gives the first Linear
+# dispatch behind the i-th marker the label LINEAR_ORDER[i % len] -- whatever else of the same kernel name ran before (round 3 counted
+# dispatches modulo 8 and was rotated by five un-labelled launches of the patch embedding).
 sys.path.insert(0, ROOT)
-from bench import LINEAR_SHAPES  # noqa: E402
+from bench import LINEAR_SHAPES, STEP_LINEAR_SHAPES  # noqa: E402
 gl = torch.Generator(device='cuda').manual_seed(11)
 lin = []
-for label, M, N, K, epi in LINEAR_SHAPES:
+for label, M, N, K, epi in STEP_LINEAR_SHAPES:
     a_ = torch.randn(M, K, device='cuda', generator=gl)
     w_ = torch.randn(N, K, device='cuda', generator=gl) * K ** -0.5
     w_._upp_persistent = True
@@ -94,8 +95,8 @@ marker = torch.zeros(8, 8, device='cuda')
 for a_, w_, b_, epi, x_ in lin:            # (plane images made before the labelled section: the split kernel of upp_linear_sb_prep is not a marker)
     ops.linear_f32(a_, w_, b_, epi, aux=x_, frozen=True)
 for _ in range(6):
-    for frozen in (True, False):
-        for a_, w_, b_, epi, x_ in lin:
+    for frozen, part in ((True, lin), (False, lin[:len(LINEAR_SHAPES)])):        # == pmc_summary.LINEAR_ORDER
+        for a_, w_, b_, epi, x_ in part:
             ops.transpose(marker)
             ops.linear_f32(a_, w_, b_, epi, aux=x_, frozen=frozen)
 # round 3: the tall-matrix kernel and the grouped weight gradient at the segmentation head's largest layer (65,536 x 1536 -> 1024), the
