@@ -18,7 +18,9 @@ class _ChamferBase(torch.nn.Module):
 
     def _fused(self, xyz1, xyz2, l1):
         """The module as one autograd node on the HIP path (upp_chamfer_loss), or None: the torch formulation follows."""
-        if xyz1.is_cuda and xyz1.dtype == torch.float32 and xyz2.dtype == torch.float32 and xyz1.size(0) > 0 and not (xyz1.size(0) == 1 and self.ignore_zeros):
+        if (xyz1.is_cuda and xyz2.is_cuda and xyz1.device == xyz2.device and xyz1.dtype == torch.float32 and xyz2.dtype == torch.float32
+                and xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.shape[-1] == 3 and xyz2.shape[-1] == 3 and xyz1.size(0) == xyz2.size(0)
+                and xyz1.size(0) > 0 and not (xyz1.size(0) == 1 and self.ignore_zeros)):
             return chamfer_loss(xyz1, xyz2, l1)
         return None
 

@@ -81,7 +81,10 @@ _pending_counters = None
 
 
 def bump_counter(t):
-    if _pending_counters is None:
+    """`num_batches_tracked += 1` of a BatchNorm the caller is about to run in training mode -- THE one place a counter moves: every call
+    site of _bn_rows / the fused BatchNorm kernels bumps through here, the layer functions themselves never do.  Under synchronised
+    BatchNorm the bump is immediate (momentum=None reads the counter inside the layer); otherwise it joins the forward's batched bump."""
+    if _pending_counters is None or sync_bn_active():
         t.add_(1)
     else:
         _pending_counters.append(t)
@@ -263,6 +266,8 @@ def pooling(x, transform):
     max + mean over the neighbourhood, then the block's BatchNorm1d over channels.  ASSUMPTION."""
     lc = max_over(x, 2, 'block.pooling') + x.mean(dim=2)
     if isinstance(transform, nn.BatchNorm1d) and sync_bn_active(transform.training):
+        if transform.track_running_stats and transform.num_batches_tracked is not None:
+            bump_counter(transform.num_batches_tracked)
         return _bn_rows(lc.reshape(-1, lc.shape[-1]), transform, transform.training).view(lc.shape)
     return transform(lc.permute(0, 2, 1)).permute(0, 2, 1)
 
@@ -402,8 +407,7 @@ def _bn_rows(x, bn, training, relu=False):
     """BatchNorm1d of a channels-last (rows, C) matrix: identical statistics to BatchNorm1d on
     the reference's (BG, C, n) layout (both reduce over every position of every group)."""
     if x.dim() == 2 and sync_bn_active(training or bn.running_mean is None):
-        if bn.running_mean is not None and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)          # (at once, not with the forward's batched bump: momentum=None reads it below)
+        # (the caller has bumped num_batches_tracked already -- bump_counter is immediate while this switch is on: momentum=None reads it)
         y = _SyncBNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.num_batches_tracked)
         return F.relu(y) if relu else y
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:

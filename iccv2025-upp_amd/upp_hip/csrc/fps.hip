@@ -11,8 +11,9 @@
 //    minimum (the cloud once in, the indices once out).  A round is pure
 //    latency (M rounds are inherently serial), so everything is arranged to
 //    shorten the dependent chain:
-//      - the distance update runs on packed-f32 VALU ops, two slots per
-//        instruction (v_pk_add/mul/fma_f32);
+//      - the distance update is written on two-slot vectors; since round 4 the library is built with -packed-fp32-ops OFF
+//        (build.py: v_pk_add/mul/fma_f32 with op_sel misbehaved beside bf16-MFMA workgroups), so the compiler
+//        emits scalar f32 VALU ops for them (347 -> 389 us at 1228 -> 1024; tests/test_abi.py asserts no v_pk_*_f32 in any code object);
 //      - the arg-max is ONE wave reduction (u32 max of the distance bits on DPP
 //        row operations) + a ballot: points are dealt to lanes so that the
 //        reference's tie-break order is (wave, lane, slot) lexicographic, hence
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ x
         int d2[S];
 #pragma unroll
         for (int h = 0; h < S / 2; ++h) {
-            // sumsq3 on two slots at once: t = dy*dy; t = fma(dx,dx,t); t = fma(dz,dz,t)   (v_pk_* f32, IEEE per element)
+            // sumsq3 on two slots at once: t = dy*dy; t = fma(dx,dx,t); t = fma(dz,dz,t)   (two-slot vectors; scalar f32 VALU in the shipped build, IEEE per element)
 #ifdef UPP_FPS_DIAG_SCALAR
             f32x2 t;
 #pragma unroll

@@ -56,6 +56,12 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 }
 
 // 8 f32 -> the three bf16 planes (8 bf16 = 4 VGPRs each).  x - x1 and (x - x1) - x2 are exact, x3 needs no rounding.
+// Non-finite values: x1 = rne_bf16(x) is +-inf for x = +-inf and for |x| > 0x7F7F0000 (3.39e38, the largest bf16), and x - x1 is then
+// inf - inf = NaN.  SAFE (the one-time split of a WEIGHT, upp_linear_sb_prep): residual terms are zeroed when x1 is not finite, so an
+// infinite weight gives +-inf (or NaN against a zero) exactly as the f32 kernel does.  The in-loop split of the A operand does not pay
+// those 16 instructions per 8 values: a non-finite ACTIVATION gives NaN where the exact-f32 kernel gives +-inf (precondition stated in
+// include/upp_hip.h; tests/test_gpu_linear_sb.py test_non_finite_operands...).
+template <bool SAFE = false>
 __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
 #ifdef UPP_SB_NO_SPLIT            // diagnostic build: no split arithmetic (wrong results)
     p1 = __builtin_bit_cast(u32x4, lo); p2 = __builtin_bit_cast(u32x4, hi); p3 = p1 ^ p2;
@@ -65,7 +71,11 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &p1
     for (int q = 0; q < 4; ++q) {
         const float x0 = q < 2 ? lo[2 * q] : hi[2 * q - 4], x1 = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
         const uint32_t u = pack_bf16(x0, x1);
-        const float r0 = x0 - __uint_as_float(u << 16), r1 = x1 - __uint_as_float(u & 0xFFFF0000u);
+        float r0 = x0 - __uint_as_float(u << 16), r1 = x1 - __uint_as_float(u & 0xFFFF0000u);
+        if constexpr (SAFE) {
+            if (((u << 16) & 0x7F800000u) == 0x7F800000u) r0 = 0.0f;
+            if ((u & 0x7F800000u) == 0x7F800000u) r1 = 0.0f;
+        }
         const uint32_t v = pack_bf16(r0, r1);
         const float t0 = r0 - __uint_as_float(v << 16), t1 = r1 - __uint_as_float(v & 0xFFFF0000u);
         p1[q] = u; p2[q] = v; p3[q] = pack_bf16(t0, t1);
@@ -419,7 +429,7 @@ __device__ __forceinline__ void prep_chunk(const float *__restrict__ W, long lon
     for (int e = 0; e < 8; ++e) x[e] = (n < N && k0 + e < K) ? (transposed ? W[(long long)(k0 + e) * ldw + n] : W[(long long)n * ldw + k0 + e]) : 0.0f;
     const f32x4 lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
     u32x4 p1, p2, p3;
-    split8(lo, hi, p1, p2, p3);
+    split8<true>(lo, hi, p1, p2, p3);
     unsigned char *base = out + (long long)chunk * SB_CHUNK + gq * 512 + row * 16;
     *reinterpret_cast<u32x4 *>(base) = p1;
     *reinterpret_cast<u32x4 *>(base + 2048) = p2;

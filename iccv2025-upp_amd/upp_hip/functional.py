@@ -401,7 +401,10 @@ class _TransposedWeights:
             wt.copy_(w.detach().t())
             self.entries[key] = [weakref.ref(owner), owner._version, wt, geom, full]
             return wt
-        if e[1] != owner._version and not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
+        if e[1] != owner._version:
+            if w.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("upp_hip: a frozen weight changed after its W^T copy was made and the stream is capturing; call "
+                                   "upp_hip.functional.refresh_caches(model) after changing weights and before capturing a step")
             e[2].copy_(w.detach().t())
             e[1] = owner._version
         return e[2]
@@ -456,7 +459,9 @@ def refresh_caches(model=None):
     """Bring every derived copy of FROZEN weights up to date IN PLACE after weights were loaded into a model whose training step is
     already captured in a HIP graph (load_state_dict changes contents, not addresses; the captured launches read the copies):
     the zero-padded first-conv weight of every patch-embedding Encoder, then the W^T copies of the data-gradient GEMMs (which
-    include the transposes of those padded weights -- hence the order)."""
+    include the transposes of those padded weights -- hence the order), then the bf16 plane images of both.
+    Also REQUIRED after any write to a frozen weight that bypasses torch's version counter (`p.data.copy_()`, `p.data.mul_()`, an EMA
+    update through `.data`, a custom kernel): the caches key their validity on that counter and cannot see such a write."""
     if model is not None:
         for m in model.modules():
             if hasattr(m, 'refresh_padded_weight'):

@@ -287,7 +287,10 @@ class _WeightPlanes:
     tensor that lands on the same address gets a new image.  Any other weight (a `.contiguous()` copy of a misaligned column window, a
     padded temporary) is split afresh at every use into a buffer of its own: replacing a cached image would free memory that an already
     captured graph still reads.  `refresh()` re-splits every live entry (functional.refresh_caches: weights loaded into a model whose
-    step is already captured)."""
+    step is already captured).
+    CONTRACT: validity is keyed on torch's version counter of the owner.  A write that bypasses it -- `p.data.copy_()`, `p.data.mul_()`, a
+    custom kernel writing a frozen weight -- leaves the image stale without any error: call functional.refresh_caches(model) after such
+    a write (README "Changing frozen weights").  train.TrainStep calls it at construction."""
 
     def __init__(self):
         self.entries = {}
@@ -352,7 +355,12 @@ class _WeightPlanes:
             planes = self._split(w)
             self.entries[key] = [weakref.ref(owner), owner._version, planes, (tuple(w.shape), tuple(w.stride()), w.storage_offset())]
             return planes
-        if e[1] != owner._version and not torch.cuda.is_current_stream_capturing():
+        if e[1] != owner._version:
+            if torch.cuda.is_current_stream_capturing():
+                # the image is stale and a re-split here would be baked into the graph as a launch of its own: refuse loudly instead of
+                # multiplying by the old weight (round-4 advisor).  Weights change BETWEEN captures: refresh the caches there.
+                raise RuntimeError("upp_hip: a frozen weight changed after its bf16 plane image was made and the stream is capturing; call "
+                                   "upp_hip.functional.refresh_caches(model) after changing weights and before capturing a step")
             self._split(w, e[2])
             e[1] = owner._version
         return e[2]

@@ -247,6 +247,10 @@ class TrainStep:
         self._g_fb = self._g_opt = None
         self._grad_targets = ({p.data_ptr(): v for p, v in zip(self.trainable, self.flat.views)}
                               if self.device.type == 'cuda' else None)
+        if self.device.type == 'cuda':
+            # derived copies of frozen weights (W^T, bf16 plane images) that an earlier eager forward cached are brought up to date before
+            # anything is captured: a weight written through `.data` since then moved no version counter (ops._WeightPlanes CONTRACT)
+            HF.refresh_caches(model)
 
     # -- the two halves of a step ------------------------------------------------------------
     def _forward_backward(self, pts=None, labels=None, kw=None):

@@ -535,6 +535,10 @@ int upp_linear_group_bias_f32(const float *A, long long lda, const float *W, lon
  *   upp_linear_sb_f32: epilogues and aux as upp_linear_f32; tile 0 = the library's choice.  Limits: K % 32 == 0 (% 64, % 128 for KS = 2, 4 tiles),
  *       N % 4 == 0, lda % 4 == 0, ldc % 4 == 0, ldaux % 4 == 0, A / C / bias / aux 16-byte aligned; UPP_E_RANGE otherwise (the caller
  *       then takes upp_linear_f32).
+ *       Value range: the split is exact for finite operands up to the largest bf16 (|x| <= 0x7F7F0000 = 3.39e38).  A weight beyond it
+ *       or infinite is split finite-safely by upp_linear_sb_prep (residual terms zeroed: the product is +-inf as in upp_linear_f32);
+ *       a non-finite ACTIVATION (A operand; also both operands of the weight-gradient kernel, which splits in its loop) yields NaN in
+ *       every output it reaches where upp_linear_f32 yields +-inf -- overflow still surfaces as a non-finite output, its sign is lost.
  *   upp_linear_sb_group_bias_f32: C = A . W^T + bias[m >> group_shift][:] (a bias per group of 2^group_shift >= 32 rows), the split-bf16
  *       form of upp_linear_group_bias_f32 (reference models/Point_MAE_unify_segment.py:424-433, models/Point_MAE_unify.py:213-216). */
 int upp_linear_sb_tile(int M, int N, int K);

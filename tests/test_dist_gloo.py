@@ -150,11 +150,20 @@ def _sync_bn_worker(rank, world, port, out_dir, cumulative):
     real_item = torch.Tensor.item
     torch.Tensor.item = lambda self: (_ for _ in ()).throw(RuntimeError("host sync inside synchronised BatchNorm"))
     try:
+        L.bump_counter(bn.num_batches_tracked)                      # (as every model call site does in front of _bn_rows)
         y = L._bn_rows(x, bn.train(), True, relu=True)
         (y * g_all[rows]).sum().backward()
+        L.bump_counter(bn.num_batches_tracked)
         y2 = L._bn_rows(x.detach() * 0.5 + 1.0, bn, True)          # a second batch: running statistics after two updates
     finally:
         torch.Tensor.item = real_item
+    # model level: ONE forward of a layer that runs a BatchNorm moves its counter by ONE, inside the forward's counter scope too (the
+    # layer function used to bump on top of its callers: 2 per forward, and a cumulative average over 2k batches -- round-4 advisor)
+    conv, bn_m = torch.nn.Conv1d(24, 8, 1), torch.nn.BatchNorm1d(8, momentum=None if cumulative else 0.1)
+    L.begin_forward(torch.device('cpu'), True)
+    L._pointwise_bn_relu(x_all[rows].detach(), conv, bn_m.train(), True)
+    L.end_forward()
+    assert int(bn_m.num_batches_tracked) == 1, int(bn_m.num_batches_tracked)
     pooled = L.pooling(x_all[rows].reshape(rows.stop - rows.start, 1, 1, 24).detach(), transform=bn) if not cumulative else y2
     rm, rv = bn.running_mean.clone(), bn.running_var.clone()
     torch.save({"y": y.detach(), "gx": x.grad, "gw": bn.weight.grad, "gb": bn.bias.grad, "rm": rm, "rv": rv, "pooled": pooled.detach(),

@@ -142,6 +142,72 @@ def test_plane_cache_follows_the_weight_and_its_cached_transpose():
     torch.testing.assert_close(x.grad, -2.0 * g0, rtol=1e-5, atol=5e-5)
 
 
+def test_a_write_through_data_needs_refresh_caches_and_a_stale_image_is_refused_under_capture():
+    """ops._WeightPlanes CONTRACT: validity is keyed on torch's version counter.  `.data` writes bypass it (the image stays as it was --
+    that is the documented blind spot), functional.refresh_caches() brings every derived copy up to date in place, and a stale image met
+    while a stream is capturing raises instead of being baked into the graph (round-4 advisor)."""
+    lin = torch.nn.Linear(384, 384, bias=False).cuda().requires_grad_(False)
+    x = torch.randn(2400, 384, device='cuda', requires_grad=True)
+    y = HF.linear(x, lin.weight)
+    y.sum().backward()
+    g0 = x.grad.clone()
+    image = ops.PLANES.get(lin.weight)
+    lin.weight.data.mul_(3.0)                                  # no version bump
+    assert ops.PLANES.get(lin.weight) is image
+    HF.refresh_caches()
+    x.grad = None
+    y3 = HF.linear(x, lin.weight)
+    y3.sum().backward()
+    assert ops.PLANES.get(lin.weight) is image                 # refreshed IN PLACE: captured graphs keep reading this address
+    torch.testing.assert_close(y3, 3.0 * y, rtol=1e-5, atol=5e-6)
+    torch.testing.assert_close(x.grad, 3.0 * g0, rtol=1e-5, atol=5e-5)
+    with torch.no_grad():
+        lin.weight.mul_(0.5)                                   # version moved, image now stale
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    raised = False
+    with torch.cuda.stream(side):
+        try:
+            with torch.cuda.graph(graph, stream=side):
+                try:
+                    ops.linear_f32(x.detach(), lin.weight, frozen=True)
+                except RuntimeError as e:
+                    raised = "refresh_caches" in str(e)
+        except RuntimeError:
+            pass                                               # (an empty capture may itself complain on some builds)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert raised
+    y4 = HF.linear(x.detach(), lin.weight)                     # eager: the version check refreshes the image
+    torch.testing.assert_close(y4, 1.5 * y.detach(), rtol=1e-5, atol=5e-6)
+
+
+def test_non_finite_operands_stay_visible():
+    """include/upp_hip.h "Value range": x - bf16(x) is inf - inf = NaN for x = +-inf.  The one-time split of a WEIGHT is finite-safe (an
+    infinite weight gives +-inf / NaN exactly where the exact-f32 kernel does); a non-finite ACTIVATION gives a non-finite output in every
+    element it reaches (NaN where the f32 kernel has +-inf), and nothing else is disturbed (round-4 advisor)."""
+    M, N, K = 128, 64, 64
+    g = torch.Generator(device='cuda').manual_seed(3)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    w = torch.randn(N, K, device='cuda', generator=g)
+    w._upp_persistent = True
+    assert ops.linear_sb_tile(M, N, K) != 0
+    w[1, 0] = float('inf'); w[2, 5] = float('-inf'); w[3, 7] = float('nan'); w[4, 9] = 3.3e38
+    got, ref = ops.linear_f32(a, w, frozen=True).cpu(), ops.linear_f32(a, w).cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.equal(torch.isinf(got), torch.isinf(ref))
+    assert torch.equal(got[torch.isinf(ref)], ref[torch.isinf(ref)])                      # weights: the sign of the overflow survives
+    fin = torch.isfinite(ref)
+    torch.testing.assert_close(got[fin], ref[fin], rtol=2e-5, atol=1e-5 * float(ref[fin].abs().max()))
+    w2 = torch.randn(N, K, device='cuda', generator=g)
+    w2._upp_persistent = True
+    a[3, 0] = float('inf'); a[5, 1] = float('-inf'); a[7, 2] = float('nan')
+    got, ref = ops.linear_f32(a, w2, frozen=True).cpu(), ops.linear_f32(a, w2).cpu()
+    assert torch.equal(torch.isfinite(got), torch.isfinite(ref))                          # activations: non-finite exactly where the f32 kernel is
+    fin = torch.isfinite(ref)
+    torch.testing.assert_close(got[fin], ref[fin], rtol=2e-5, atol=1e-5 * float(ref[fin].abs().max()))
+
+
 def test_a_trainable_weight_stays_on_the_exact_f32_kernel():
     w = torch.randn(384, 384, device='cuda', requires_grad=True)
     x = torch.randn(2400, 384, device='cuda')

@@ -10,6 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "iccv2025-upp_amd")]
 import torch  # noqa: E402
+from upp_hip.build import FLAGS as PRODUCT_FLAGS  # noqa: E402  (the flag list of the shipped library, -packed-fp32-ops included: a micro build measures the same code)
 
 from bench import time_kernel  # noqa: E402
 
@@ -26,7 +27,7 @@ def main():
         i = argv.index("--")
         argv, picks = argv[:i], argv[i + 1:]
     so = "/tmp/liblin_ab_%s.so" % ("_".join(argv) or "base")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-shared"]
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + PRODUCT_FLAGS + ["-shared"]
                           + ["-D" + a for a in argv] + [SRC, os.path.join(os.path.dirname(SRC), "linear_rt.hip"), os.path.join(os.path.dirname(SRC), "abi.hip"), "-o", so])
     lib = ctypes.CDLL(so)
     vp, ll, ci = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int

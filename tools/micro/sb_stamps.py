@@ -10,6 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "iccv2025-upp_amd")]
 import torch  # noqa: E402
+from upp_hip.build import FLAGS as PRODUCT_FLAGS  # noqa: E402  (the flag list of the shipped library, -packed-fp32-ops included: a micro build measures the same code)
 
 CSRC = os.path.join(ROOT, "iccv2025-upp_amd", "upp_hip", "csrc")
 SO = "/tmp/libsb_stamps.so"
@@ -17,7 +18,7 @@ SO = "/tmp/libsb_stamps.so"
 
 def main():
     extra = ["-D" + a for a in sys.argv[1:]]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-shared",
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + PRODUCT_FLAGS + ["-shared",
                            "-DUPP_LIN_STAMPS"] + extra + [os.path.join(CSRC, "linear_sb.hip"), os.path.join(CSRC, "abi.hip"), "-o", SO])
     lib = ctypes.CDLL(SO)
     vp, ll, ci = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int

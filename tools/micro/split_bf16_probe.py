@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 for p in (ROOT, os.path.join(ROOT, "iccv2025-upp_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402
+from upp_hip.build import FLAGS as PRODUCT_FLAGS  # noqa: E402  (the flag list of the shipped library, -packed-fp32-ops included: a micro build measures the same code)
 import torch.nn.functional as F  # noqa: E402
 
 from bench import time_kernel  # noqa: E402
@@ -27,7 +28,7 @@ def build():
     src = os.path.join(HERE, "split_bf16_gemm.hip")
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + PRODUCT_FLAGS + [
                                "-shared", src, "-o", out])
     lib = ctypes.CDLL(out)
     vp, i = ctypes.c_void_p, ctypes.c_int
