@@ -62,7 +62,7 @@ class TransformerDecoder(_Stack):
                     nn.init.constant_(m.bias, 0)
 
     def forward(self, x, pos, return_token_num):
-        return self.head(self.norm(self.run(x, pos)[:, -return_token_num:]))
+        return self.head(HF.layer_norm(self.run(x, pos), self.norm, last=return_token_num))
 
 
 def _mlp2(i, h, o):
@@ -95,11 +95,11 @@ class MaskTransformer(nn.Module):
         if noaug or n == 0:
             return torch.zeros(B, G, dtype=torch.bool, device=center.device)
         if self.mask_type == 'rand':
-            order = torch.rand(B, G, device=center.device).argsort(dim=1)
+            order = HF.argsort_rows(torch.rand(B, G, device=center.device))
         else:
             pick = torch.randint(0, G, (B, 1, 1), device=center.device)
             anchor = torch.gather(center, 1, pick.expand(-1, -1, 3))
-            order = torch.norm(anchor - center, p=2, dim=-1).argsort(dim=1)
+            order = HF.argsort_rows(torch.norm(anchor - center, p=2, dim=-1))
         mask = torch.zeros(B, G, dtype=torch.bool, device=center.device)
         return mask.scatter_(1, order[:, :n], True)
 
@@ -112,12 +112,12 @@ class MaskTransformer(nn.Module):
         tokens = self.encoder(neighborhood)
         # visible positions first (ascending), masked ones after (ascending): the order boolean indexing would give,
         # without its host sync (shapes stay static for HIP-graph capture)
-        order = torch.argsort(mask.int(), dim=1, stable=True)
+        order = HF.argsort_rows(mask)               # (stable: equal keys in index order)
         n_vis = G - (int(mask[0].sum()) if n_masked is None else n_masked)
         vis = order[:, :n_vis]
         x_vis = torch.gather(tokens, 1, vis.unsqueeze(-1).expand(-1, -1, tokens.shape[-1]))
         c_vis = torch.gather(center, 1, vis.unsqueeze(-1).expand(-1, -1, 3))
-        x_vis = self.norm(self.blocks(x_vis, L.mlp2(self.pos_embed, c_vis)))
+        x_vis = HF.layer_norm(self.blocks(x_vis, L.mlp2(self.pos_embed, c_vis)), self.norm)
         return x_vis, mask, order, n_vis
 
 

@@ -11,6 +11,7 @@ from extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
 from utils import misc
 from .build import MODELS
 from . import upp_layers as L
+from upp_hip import functional as HF
 from .Point_MAE_unify import PromptedBackbone
 from .upp_layers import Group
 
@@ -60,7 +61,7 @@ class Point_MAE_pretask_dev(PromptedBackbone):
             positive = torch.mean(torch.norm(pred_noise - noise_vector, 2, dim=-1, keepdim=True) ** 2)
         negative = torch.mean(torch.norm(pred_pure, 2, dim=-1, keepdim=True) ** 2)
         score = torch.norm(pred, p=2, dim=-1)
-        order = torch.argsort(score, dim=1, descending=True)
+        order = HF.argsort_rows(score, descending=True)          # (rank-counting kernel: no library sort in the step)
         recall = torch.mean(torch.sum(order[:, :-point_num].detach() > point_num, dim=-1) / (P - point_num))
         kept = torch.gather(pts, 1, order[:, -point_num:, None].expand(-1, -1, 3)).detach()
         return positive + negative, recall, kept

@@ -127,7 +127,7 @@ class PromptedBackbone(nn.Module):
         pos = L.mlp2(self.pos_embed, vis_center)
         x_vis = self.blocks(x_vis, pos, path='pretask', pretask_adapter=True, pretask_prompts=True,
                             pretask_depth=self.config.prompter_config['pretask_depth'])
-        x_vis = self.norm(x_vis)
+        x_vis = HF.layer_norm(x_vis, self.norm)                    # (row kernel: no torch launch in the front-end)
         pos_vis = L.mlp2(self.decoder_pos_embed, vis_center).reshape(B, -1, self.trans_dim)
         shape_feature = L.mlp2(self.shape_pred, x_vis).reshape(B, self.vis_short * self.vis_num)
         predict_center = L.mlp2(self.coarse_pred, shape_feature).reshape(B, self.n_masked, 3)

@@ -882,7 +882,7 @@ class TransformerDecoder(nn.Module):
     def forward(self, x, pos, return_token_num, **kwargs):
         for block in self.blocks:
             x = block.forward_fused(x, pos, **kwargs) if block.fusable(x) else block(x + pos, **kwargs)
-        return self.head(self.norm(x[:, -return_token_num:]))
+        return self.head(HF.layer_norm(x, self.norm, last=return_token_num))      # (strip row map: no copy of the row window)
 
 
 # --------------------------------------------------------------------------- rectify prompter

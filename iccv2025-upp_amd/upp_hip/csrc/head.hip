@@ -345,7 +345,41 @@ __global__ __launch_bounds__(256) void rectify_select_kernel(const float *__rest
     }
 }
 
+// order[b][rank] = i: the stable argsort of every row of `key` (B,N) by rank counting, as rectify_select_kernel ranks its scores -- one
+// workgroup per (row, 256 elements), the row in the LDS, rank of an element = how many elements precede it (smaller key -- greater, if
+// descending -- or equal key and lower index: the order of torch's stable sort).  NaN ranks as +inf, ties by index: always a permutation.
+template <bool DESC>
+__global__ __launch_bounds__(256) void argsort_rows_kernel(const float *__restrict__ key, int N, int64_t *__restrict__ order) {
+    extern __shared__ float sc[];
+    const int b = blockIdx.y;
+    const float *s = key + (size_t)b * N;
+    for (int i = threadIdx.x; i < N; i += 256) { const float v = s[i]; sc[i] = v != v ? __builtin_inff() : v; }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float mine = sc[i];
+    int rank = 0;
+    int j = 0;
+    auto before = [&](float v, int jj) { return (DESC ? v > mine : v < mine) || (v == mine && jj < i); };
+    for (; j + 4 <= N; j += 4) {                          // (every lane reads the same address: LDS broadcast)
+        const float4 v = *reinterpret_cast<const float4 *>(sc + j);
+        rank += before(v.x, j) + before(v.y, j + 1) + before(v.z, j + 2) + before(v.w, j + 3);
+    }
+    for (; j < N; ++j) rank += before(sc[j], j);
+    order[(size_t)b * N + rank] = i;
+}
+
 }  // namespace
+
+extern "C" int upp_argsort_rows(const float *key, int B, int N, int descending, int64_t *order, void *stream) {
+    if (!key || !order || B < 1 || N < 1) return UPP_E_BADARG;
+    if (N > 16384 || B > 65535) return UPP_E_RANGE;
+    const dim3 grid((N + 255) / 256, B);
+    const size_t lds = (size_t)((N + 3) / 4 * 4) * sizeof(float);
+    if (descending) hipLaunchKernelGGL(argsort_rows_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, key, N, order);
+    else hipLaunchKernelGGL(argsort_rows_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, key, N, order);
+    return upp_launch_status();
+}
 
 extern "C" int upp_bn_relu_drop_fwd(const float *z, const float *gamma, const float *beta, float *running_mean, float *running_var,
                                     float momentum, float eps, int training, const float *u, float p, float *a, float *mean,

@@ -422,7 +422,7 @@ extern "C" int upp_linear_f32(const float *A, long long lda, const float *W, lon
     if ((epilogue == LEPI_BIAS_GELU_D || epilogue == LEPI_MUL) && (!aux || ldaux < N)) return UPP_E_BADARG;
     LinArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.bias = bias; g.aux = aux; g.ldaux = ldaux;
-    g.M = M; g.N = N; g.K = K; g.epi = epilogue;
+    g.M = M; g.N = N; g.K = K; g.epi = epilogue; g.wt = upp_store_policy();
 #ifdef UPP_LIN_STAMPS
     g.stamps = g_lin_stamps;
 #endif

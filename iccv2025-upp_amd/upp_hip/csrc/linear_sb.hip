@@ -556,7 +556,7 @@ static int linear_sb_launch(const float *A, long long lda, const void *planes, c
     if (tile <= 0) return UPP_E_RANGE;
     SbArgs g{};
     g.l.A = A; g.l.lda = lda; g.l.C = C; g.l.ldc = ldc; g.l.bias = bias; g.l.aux = aux; g.l.ldaux = ldaux;
-    g.l.M = M; g.l.N = N; g.l.K = K; g.l.epi = epilogue; g.l.bias_shift = bias_shift;
+    g.l.M = M; g.l.N = N; g.l.K = K; g.l.epi = epilogue; g.l.bias_shift = bias_shift; g.l.wt = upp_store_policy();
 #ifdef UPP_LIN_STAMPS
     g.l.stamps = g_lin_stamps;
 #endif

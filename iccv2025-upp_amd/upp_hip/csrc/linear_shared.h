@@ -2,6 +2,9 @@
 // the token matrices of the Transformer blocks; linear_rt.hip: register-tiled waves, the tall point-row matrices and the grouped
 // weight gradients).  Included inside each file's anonymous namespace.
 #pragma once
+#ifndef UPP_STORE_WT_DEFAULT
+#define UPP_STORE_WT_DEFAULT 1
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -20,6 +23,7 @@ struct LinArgs {
     int tiles_n;                  // workgroup tiles along N
     int epi;
     int ktail;                    // K is not a multiple of the k-stage: the last stage reads zeros beyond K (K % 4 == 0)
+    int wt;                       // != 0: the output leaves by write-through (sc1) stores (upp_store_policy(); see store4())
     int bias_shift;               // linear_rt.hip, > 0: bias is a (M >> bias_shift, N) matrix, row m takes row m >> bias_shift of it (a bias
                                   // per GROUP of 2^bias_shift >= 32 rows: the per-sample term of the segmentation head, the per-group
                                   // half of the patch embedding's 512 -> 512 layer)
@@ -75,6 +79,22 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 
+// 16-byte store of an output granule.  wt: agent-scope write-through (`sc1`): the bytes leave the XCD's L2 as they are stored instead of
+// staying dirty in it until the end-of-kernel release writes them back -- that write-back is serial time between this kernel and the
+// next (MI355X_MICROARCH.md, price list "boundary": + B / 6 TB/s for B dirty bytes; "publish-large": 64 KB per workgroup 8.2 -> 3.0 us
+// with write-through stores).  The next kernel reads the tensor from the memory side either way (per-XCD L2s are not coherent).
+__device__ __forceinline__ void store4(float *dst, f32x4 v, int wt) {
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    else *reinterpret_cast<f32x4 *>(dst) = v;
+}
+
+// UPP_STORE_WT=0|1 (read once): the store policy of the Linear kernels' epilogues.
+static inline int upp_store_policy(void) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("UPP_STORE_WT"); v = e ? (e[0] != '0') : UPP_STORE_WT_DEFAULT; }
+    return v;
+}
+
 // Epilogue of four consecutive columns of one output row (a lane of the LDS-turned tile: 16-byte loads and stores): v = the
 // accumulated products, bias4 = the four biases (zeros when the epilogue has none).
 __device__ __forceinline__ void epilogue_store4(const LinArgs &g, int epi, f32x4 v, f32x4 bias4, int row, int col, bool ok) {
@@ -85,18 +105,18 @@ __device__ __forceinline__ void epilogue_store4(const LinArgs &g, int epi, f32x4
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
         }
-        if (ok) *reinterpret_cast<f32x4 *>(dst) = v;
+        if (ok) store4(dst, v, g.wt);
     } else {
         float *xp = g.aux + (long long)row * g.ldaux + col;
         if (epi == LEPI_MUL) {
-            if (ok) *reinterpret_cast<f32x4 *>(dst) = v * *reinterpret_cast<const f32x4 *>(xp);
+            if (ok) store4(dst, v * *reinterpret_cast<const f32x4 *>(xp), g.wt);
         } else {
             f32x4 gv, dv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { float g1, d1; gelu_pair(v[e] + bias4[e], g1, d1); gv[e] = g1; dv[e] = d1; }
             if (ok) {
-                *reinterpret_cast<f32x4 *>(dst) = gv;
-                if (epi == LEPI_BIAS_GELU_D) *reinterpret_cast<f32x4 *>(xp) = dv;
+                store4(dst, gv, g.wt);
+                if (epi == LEPI_BIAS_GELU_D) store4(xp, dv, g.wt);
             }
         }
     }

@@ -253,6 +253,28 @@ def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDE
     return xo, (h if gamma is not None else None)
 
 
+def layer_norm(x, ln, last=None):
+    """ln(x) -- or, with `last`, ln(x[:, -last:]) -- for an nn.LayerNorm over the last dimension of a (B,L,D) / (R,D) f32 HIP tensor on
+    the row kernel of csrc/block.hip (upp_rowln_fwd: identity / strip row map, the normalised rows only); the module itself for anything
+    else.  The prompting front-end calls it (reference models/Point_MAE_unify.py:588 `self.norm`, models/Point_MAE_pretask_dev.py:381
+    the decoder's norm over the returned tokens): no torch kernel, no copy of the row window."""
+    ok = (isinstance(ln, torch.nn.LayerNorm) and x.is_cuda and x.dtype == torch.float32 and x.dim() in (2, 3) and len(ln.normalized_shape) == 1
+          and ln.normalized_shape[0] == x.shape[-1] and x.shape[-1] <= 512 and ln.elementwise_affine and ln.bias is not None and x.numel() > 0)
+    if not ok:
+        return ln(x if last is None else x[:, -last:])
+    x3 = x if x.dim() == 3 else x.unsqueeze(0)
+    L = x3.shape[1]
+    strip = 0 if last is None else L - int(last)
+    if strip < 0:
+        raise ValueError("layer_norm: last = %d of %d rows" % (last, L))
+    mode = ROW_STRIP if strip else ROW_IDENTITY
+    if torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad or ln.bias.requires_grad):
+        _, h = rowln(x3, gamma=ln.weight, beta=ln.bias, mode=mode, P=strip, eps=ln.eps)
+    else:
+        _, h, _, _ = ops.rowln_fwd(x3.contiguous(), None, None, mode, strip, None, None, 1.0, ln.weight, ln.bias, float(ln.eps), L - strip, want_xo=False)
+    return h if x.dim() == 3 else h.squeeze(0)
+
+
 class _Attention(Function):
     """ctx = softmax(q k^T * scale) v from the packed qkv projection (B, L, 3*H*64)."""
 
@@ -926,6 +948,18 @@ def bn_rows_train(x, bn, relu=False):
     """Differentiable training-mode BatchNorm(+ReLU) over the rows of a channels-last (R,C) matrix."""
     momentum = 0.0 if bn.momentum is None else bn.momentum
     return _BnRowsTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
+
+
+def argsort_rows(key, descending=False, stable=True):
+    """torch.argsort(key, dim=-1, descending=..., stable=True) of short rows (N <= 16384) on the rank-counting kernel (upp_argsort_rows)
+    for f32 HIP tensors; anything else (CPU tensors on a GPU-less host, other dtypes, long rows) takes torch.argsort.  Integer / bool
+    keys of small magnitude (a mask) are ranked through their exact f32 image."""
+    if isinstance(key, torch.Tensor) and key.is_cuda and key.dim() >= 1 and 1 <= key.shape[-1] <= 16384 and key.numel() // key.shape[-1] <= 65535:
+        if key.dtype == torch.float32:
+            return ops.argsort_rows(key.detach(), descending)
+        if key.dtype in (torch.bool, torch.uint8, torch.int8, torch.int16):          # exact in f32
+            return ops.argsort_rows(key.to(torch.float32), descending)
+    return torch.argsort(key, dim=-1, descending=descending, stable=stable)
 
 
 def sqdist_topk(xyz1, xyz2, k):

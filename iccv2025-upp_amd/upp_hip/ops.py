@@ -493,6 +493,17 @@ def rectify_select(feature, w0, b0, w1, b1, pts, keep, u=None, p=0.0, factor=1.0
     return res if len(res) > 1 else out
 
 
+def argsort_rows(key, descending=False):
+    """Stable argsort of every row of `key` (..., N) f32 -> int64 indices of the same shape (upp_argsort_rows: rank counting, no library
+    sort; NaN ranks as +inf, equal keys in index order)."""
+    _need(key, "key", torch.float32)
+    N = key.shape[-1]
+    k2 = key.reshape(-1, N).contiguous()
+    order = torch.empty(k2.shape, dtype=torch.int64, device=key.device)
+    _call(key.device, "upp_argsort_rows", _abi.ptr(k2), k2.shape[0], N, 1 if descending else 0, _abi.ptr(order))
+    return order.view(key.shape)
+
+
 def wcolsum_partials(src, wts, chunks=None):
     """(chunks, W, C) partials of wts (n,W)^T . src (n,C) for W <= 4 over very many rows (upp_wcolsum_partials); sum over dim 0 = the product."""
     for t_, n_ in ((src, "src"), (wts, "wts")):

@@ -62,7 +62,7 @@ def seprate_point_cloud(xyz, num_points, crop, fixed_points=None, padding_zeros=
         else:
             centers = torch.nn.functional.normalize(torch.randn(B, 1, 3, device=xyz.device, generator=generator), p=2, dim=-1)
     dist = torch.norm(centers - xyz, p=2, dim=-1)                                   # (B, n)
-    order = torch.argsort(dist, dim=-1, descending=False)
+    order = _F.argsort_rows(dist)                     # (rank-counting kernel on the device, torch.argsort on the host)
     take = lambda idx: torch.gather(xyz, 1, idx.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
     crop_data = take(order[:, :num_crop])
     if padding_zeros:

@@ -459,6 +459,14 @@ int upp_rectify_select(const float *feature, const float *W0, const float *b0, c
                        float factor, const float *pts, float nudge, int B, int N, int keep, float *pred, float *moved, float *score,
                        float *out, int64_t *order, void *stream);
 
+/* Stable argsort of every row of key (B,N) f32 by rank counting (no library sort): order (B,N) int64 with order[b][r] = the index of the
+ * r-th element of row b in ascending (descending != 0: descending) order, equal keys in index order -- what torch.argsort(...,
+ * stable=True) returns, and what torch.argsort returns for distinct keys.  NaN ranks as +inf.  Replaces the reference's device sorts of
+ * short rows: torch.argsort(score, descending=True) of the pre-task noise recall (models/Point_MAE_pretask_dev.py:702-704), the masking
+ * orders of Point-MAE pre-training (models/Point_MAE.py:300-329: argsort of uniform draws / of distances to a random centre, and the
+ * visible-first order argsort(mask)).  Limits: N <= 16384 (the row lives in the LDS), B <= 65535. */
+int upp_argsort_rows(const float *key, int B, int N, int descending, int64_t *order, void *stream);
+
 /* ---- token-matrix Linear (exact f32 on the matrix cores) -------------------------------------
  * Replaces the nn.Linear layers of the Transformer blocks and their data gradients: Attention.qkv / .proj
  * (reference models/Point_MAE_pretask_dev.py:178,181 called :186,:194) and Mlp.fc1 / .fc2 (:158,:160 called

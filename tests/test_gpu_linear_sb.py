@@ -187,7 +187,7 @@ def test_non_finite_operands_stay_visible():
     """include/upp_hip.h "Value range": x - bf16(x) is inf - inf = NaN for x = +-inf.  The one-time split of a WEIGHT is finite-safe (an
     infinite weight gives +-inf / NaN exactly where the exact-f32 kernel does); a non-finite ACTIVATION gives a non-finite output in every
     element it reaches (NaN where the f32 kernel has +-inf), and nothing else is disturbed (round-4 advisor)."""
-    M, N, K = 128, 64, 64
+    M, N, K = 256, 128, 128
     g = torch.Generator(device='cuda').manual_seed(3)
     a = torch.randn(M, K, device='cuda', generator=g)
     w = torch.randn(N, K, device='cuda', generator=g)

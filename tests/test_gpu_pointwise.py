@@ -365,3 +365,58 @@ def test_interpolation_with_geometry_gradients_equals_the_reference_formulation(
     want = [ref.detach(), x1.grad, x2.grad, f.grad]
     for a, b, name in zip(got, want, ("out", "g_xyz1", "g_xyz2", "g_feat")):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * b.abs().max().item(), err_msg=name)
+
+
+@pytest.mark.parametrize("B,N", [(32, 64), (32, 1076), (3, 8192), (1, 1), (5, 257)])
+@pytest.mark.parametrize("descending", [False, True])
+def test_argsort_rows_is_torchs_stable_argsort(B, N, descending):
+    """upp_argsort_rows (rank counting; replaces the device sorts of reference models/Point_MAE_pretask_dev.py:702-704 and
+    models/Point_MAE.py:300-329): the permutation torch.argsort(..., stable=True) returns, bit for bit, with ties and repeated values."""
+    from upp_hip import functional as HF
+    g = torch.Generator(device='cuda').manual_seed(B * 131 + N)
+    key = torch.randn(B, N, device='cuda', generator=g)
+    key[:, ::3] = key[:, ::3].round()                           # many exact ties
+    if N > 4:
+        key[:, 2] = key[:, 4]
+    got = HF.argsort_rows(key, descending=descending)
+    want = torch.argsort(key, dim=-1, descending=descending, stable=True)
+    assert got.dtype == torch.int64 and torch.equal(got, want)
+    mask = torch.rand(B, N, device='cuda', generator=g) < 0.6   # the visible-first order of the masked auto-encoder
+    assert torch.equal(HF.argsort_rows(mask), torch.argsort(mask.int(), dim=1, stable=True))
+
+
+def test_argsort_rows_ranks_nan_as_the_largest_value_and_stays_a_permutation():
+    from upp_hip import functional as HF
+    key = torch.tensor([[0.5, float('nan'), -1.0, float('inf'), float('nan'), 0.5]], device='cuda')
+    asc = HF.argsort_rows(key).cpu().tolist()[0]
+    assert asc == [2, 0, 5, 3, 1, 4]                            # NaN == +inf for ranking, ties in index order
+    assert sorted(HF.argsort_rows(key, descending=True).cpu().tolist()[0]) == list(range(6))
+
+
+@pytest.mark.parametrize("last", [None, 32])
+@pytest.mark.parametrize("grad", [False, True])
+def test_layer_norm_on_the_row_kernel_equals_nn_layer_norm(last, grad):
+    """HF.layer_norm (upp_rowln_fwd with the identity / strip row map): the front-end's `self.norm` (reference models/Point_MAE_unify.py:588)
+    and the decoder's norm over its last tokens (models/Point_MAE_pretask_dev.py:381), forward and -- for the pre-training recipe, where
+    the norm is trainable -- gradients, against nn.LayerNorm."""
+    from upp_hip import functional as HF
+    torch.manual_seed(5)
+    ln = torch.nn.LayerNorm(384).cuda()
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.3, 0.3)
+    x = (torch.randn(8, 64, 384, device='cuda') * 2.0 + 0.5).requires_grad_(grad)
+    if not grad:
+        ln.requires_grad_(False)
+    want = ln(x if last is None else x[:, -last:])
+    got = HF.layer_norm(x, ln, last=last)
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+    if grad:
+        w = torch.randn_like(want)
+        gx, gw, gb = torch.autograd.grad((want * w).sum(), [x, ln.weight, ln.bias])
+        hx, hw, hb = torch.autograd.grad((got * w).sum(), [x, ln.weight, ln.bias])
+        torch.testing.assert_close(hx, gx, rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(hw, gw, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(hb, gb, rtol=1e-4, atol=1e-4)
+    x2 = torch.randn(100, 384, device='cuda')                     # 2-D rows
+    torch.testing.assert_close(HF.layer_norm(x2, ln), ln(x2), rtol=2e-5, atol=2e-5)
