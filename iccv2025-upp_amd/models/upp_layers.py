@@ -160,7 +160,7 @@ def _inverse_distance_interp(xyz1, xyz2, points2, k, eps, out=None, col0=0):
     S = xyz2.shape[1]
     if POOL_TRACE is not None and out is None:      # (test instrument: the torch formulation on the traced neighbour lists)
         sq = square_distance(xyz1, xyz2)
-        idx = trace_idx('interp.knn', sq.sort(dim=-1)[1][:, :, :k])
+        idx = trace_idx('interp.knn', HF.argsort_rows(sq)[:, :, :k])
         recip = 1.0 / (sq.gather(-1, idx) + eps)
         return torch.sum(index_points(points2, idx) * (recip / torch.sum(recip, dim=2, keepdim=True)).unsqueeze(-1), dim=2)
     if (out is None and xyz1.is_cuda and xyz1.dtype == torch.float32 and xyz2.dtype == torch.float32 and points2.dtype == torch.float32
@@ -171,7 +171,9 @@ def _inverse_distance_interp(xyz1, xyz2, points2, k, eps, out=None, col0=0):
             and xyz1.shape[-1] == 3 and _no_grad_needed(xyz1, xyz2)):
         dists, idx = HF.sqdist_topk(xyz1, xyz2, min(k, S))       # one launch for matmul + 5 element-wise passes + full sort
     else:
-        dists, idx = square_distance(xyz1, xyz2).sort(dim=-1)
+        sq = square_distance(xyz1, xyz2)                      # (the reference's full sort: rank-counting kernel, no library sort)
+        idx = HF.argsort_rows(sq)
+        dists = sq.gather(-1, idx)
     if points2.is_cuda and points2.dtype == torch.float32 and k <= 16:
         if _no_grad_needed(xyz1, xyz2, points2):
             return HF.interp(dists, idx, points2, min(k, dists.shape[-1]), eps, out, col0)
@@ -188,7 +190,7 @@ def _prop_lists_torch(c1, c2, i1, i2, gather_idx, B, Lp, off):
     """Index lists of the fused propagation step with the reference's torch ops (what upp_prop_index computes in one
     launch): absolute rows for the neighbour / centre indices and the 8 nearest level-2 centres with their weights."""
     sq = square_distance(c1, c2)
-    idx8 = trace_idx('prop.knn8', sq.sort(dim=-1)[1][:, :, :8])
+    idx8 = trace_idx('prop.knn8', HF.argsort_rows(sq)[:, :, :8])
     d8 = sq.gather(-1, idx8)
     recip = 1.0 / (d8 + 1e-3)
     w8 = (recip / torch.sum(recip, dim=2, keepdim=True)).contiguous()
@@ -1044,7 +1046,7 @@ class RectifyPrompter(nn.Module):
             return ops.rectify_select(feature.contiguous(), l0.weight, l0.bias, l1.weight, l1.bias, x.contiguous(), keep, u,
                                       drop.p if live else 0.0, self.score_factor, nudge)
         pred = HF.linear(drop(HF.linear(feature, l0.weight, l0.bias, act='relu')), l1.weight, l1.bias) * self.score_factor
-        order = trace_idx('rectify.order', torch.argsort(torch.norm(pred, p=2, dim=-1), dim=1, descending=True))
+        order = trace_idx('rectify.order', HF.argsort_rows(torch.norm(pred, p=2, dim=-1), descending=True))
         moved = x + pred * nudge
         return torch.gather(moved, 1, order[:, -keep:, None].expand(-1, -1, 3))
 

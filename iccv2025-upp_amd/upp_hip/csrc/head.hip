@@ -349,9 +349,10 @@ __global__ __launch_bounds__(256) void rectify_select_kernel(const float *__rest
 // workgroup per (row, 256 elements), the row in the LDS, rank of an element = how many elements precede it (smaller key -- greater, if
 // descending -- or equal key and lower index: the order of torch's stable sort).  NaN ranks as +inf, ties by index: always a permutation.
 template <bool DESC>
-__global__ __launch_bounds__(256) void argsort_rows_kernel(const float *__restrict__ key, int N, int64_t *__restrict__ order) {
+__global__ __launch_bounds__(256) void argsort_rows_kernel(const float *__restrict__ key, long long B, int N, int64_t *__restrict__ order) {
     extern __shared__ float sc[];
-    const int b = blockIdx.y;
+    const long long b = (long long)blockIdx.z * 65535 + blockIdx.y;          // (rows beyond the 65,535 of grid.y: grid.z)
+    if (b >= B) return;
     const float *s = key + (size_t)b * N;
     for (int i = threadIdx.x; i < N; i += 256) { const float v = s[i]; sc[i] = v != v ? __builtin_inff() : v; }
     __syncthreads();
@@ -373,11 +374,11 @@ __global__ __launch_bounds__(256) void argsort_rows_kernel(const float *__restri
 
 extern "C" int upp_argsort_rows(const float *key, int B, int N, int descending, int64_t *order, void *stream) {
     if (!key || !order || B < 1 || N < 1) return UPP_E_BADARG;
-    if (N > 16384 || B > 65535) return UPP_E_RANGE;
-    const dim3 grid((N + 255) / 256, B);
+    if (N > 16384) return UPP_E_RANGE;
+    const dim3 grid((N + 255) / 256, B < 65535 ? B : 65535, (B + 65534) / 65535);
     const size_t lds = (size_t)((N + 3) / 4 * 4) * sizeof(float);
-    if (descending) hipLaunchKernelGGL(argsort_rows_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, key, N, order);
-    else hipLaunchKernelGGL(argsort_rows_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, key, N, order);
+    if (descending) hipLaunchKernelGGL(argsort_rows_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, key, (long long)B, N, order);
+    else hipLaunchKernelGGL(argsort_rows_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, key, (long long)B, N, order);
     return upp_launch_status();
 }
 

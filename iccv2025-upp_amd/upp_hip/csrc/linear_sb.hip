@@ -57,10 +57,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 
 // 8 f32 -> the three bf16 planes (8 bf16 = 4 VGPRs each).  x - x1 and (x - x1) - x2 are exact, x3 needs no rounding.
 // Non-finite values: x1 = rne_bf16(x) is +-inf for x = +-inf and for |x| > 0x7F7F0000 (3.39e38, the largest bf16), and x - x1 is then
-// inf - inf = NaN.  SAFE (the one-time split of a WEIGHT, upp_linear_sb_prep): residual terms are zeroed when x1 is not finite, so an
-// infinite weight gives +-inf (or NaN against a zero) exactly as the f32 kernel does.  The in-loop split of the A operand does not pay
-// those 16 instructions per 8 values: a non-finite ACTIVATION gives NaN where the exact-f32 kernel gives +-inf (precondition stated in
-// include/upp_hip.h; tests/test_gpu_linear_sb.py test_non_finite_operands...).
+// inf - inf = NaN.  SAFE (the one-time split of a WEIGHT, upp_linear_sb_prep) zeroes the residual terms when x1 is not finite; the
+// in-loop split of the A operand does not pay those 16 instructions per 8 values.  Either way a non-finite operand makes every output
+// it reaches NON-FINITE, but NaN where the exact-f32 kernel has +-inf: the six-product sum pairs the infinite term with residual terms
+// of the other operand, which carry both signs (inf - inf).  Stated in include/upp_hip.h; tests/test_gpu_linear_sb.py
+// test_non_finite_operands_stay_visible.
 template <bool SAFE = false>
 __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
 #ifdef UPP_SB_NO_SPLIT            // diagnostic build: no split arithmetic (wrong results)

@@ -954,7 +954,7 @@ def argsort_rows(key, descending=False, stable=True):
     """torch.argsort(key, dim=-1, descending=..., stable=True) of short rows (N <= 16384) on the rank-counting kernel (upp_argsort_rows)
     for f32 HIP tensors; anything else (CPU tensors on a GPU-less host, other dtypes, long rows) takes torch.argsort.  Integer / bool
     keys of small magnitude (a mask) are ranked through their exact f32 image."""
-    if isinstance(key, torch.Tensor) and key.is_cuda and key.dim() >= 1 and 1 <= key.shape[-1] <= 16384 and key.numel() // key.shape[-1] <= 65535:
+    if isinstance(key, torch.Tensor) and key.is_cuda and key.dim() >= 1 and 1 <= key.shape[-1] <= 16384 and key.numel() < 2 ** 31:
         if key.dtype == torch.float32:
             return ops.argsort_rows(key.detach(), descending)
         if key.dtype in (torch.bool, torch.uint8, torch.int8, torch.int16):          # exact in f32

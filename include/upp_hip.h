@@ -464,7 +464,7 @@ int upp_rectify_select(const float *feature, const float *W0, const float *b0, c
  * stable=True) returns, and what torch.argsort returns for distinct keys.  NaN ranks as +inf.  Replaces the reference's device sorts of
  * short rows: torch.argsort(score, descending=True) of the pre-task noise recall (models/Point_MAE_pretask_dev.py:702-704), the masking
  * orders of Point-MAE pre-training (models/Point_MAE.py:300-329: argsort of uniform draws / of distances to a random centre, and the
- * visible-first order argsort(mask)).  Limits: N <= 16384 (the row lives in the LDS), B <= 65535. */
+ * visible-first order argsort(mask)).  Limits: N <= 16384 (the row lives in the LDS). */
 int upp_argsort_rows(const float *key, int B, int N, int descending, int64_t *order, void *stream);
 
 /* ---- token-matrix Linear (exact f32 on the matrix cores) -------------------------------------
@@ -543,10 +543,11 @@ int upp_linear_group_bias_f32(const float *A, long long lda, const float *W, lon
  *   upp_linear_sb_f32: epilogues and aux as upp_linear_f32; tile 0 = the library's choice.  Limits: K % 32 == 0 (% 64, % 128 for KS = 2, 4 tiles),
  *       N % 4 == 0, lda % 4 == 0, ldc % 4 == 0, ldaux % 4 == 0, A / C / bias / aux 16-byte aligned; UPP_E_RANGE otherwise (the caller
  *       then takes upp_linear_f32).
- *       Value range: the split is exact for finite operands up to the largest bf16 (|x| <= 0x7F7F0000 = 3.39e38).  A weight beyond it
- *       or infinite is split finite-safely by upp_linear_sb_prep (residual terms zeroed: the product is +-inf as in upp_linear_f32);
- *       a non-finite ACTIVATION (A operand; also both operands of the weight-gradient kernel, which splits in its loop) yields NaN in
- *       every output it reaches where upp_linear_f32 yields +-inf -- overflow still surfaces as a non-finite output, its sign is lost.
+ *       Value range: the split is exact for finite operands up to the largest bf16 (|x| <= 0x7F7F0000 = 3.39e38); a finite weight beyond
+ *       it counts as infinite (upp_linear_sb_prep zeroes its residual terms instead of forming inf - inf).
+ *       Non-finite operands: x = +-inf splits into (inf, NaN, ...) in the loop and into (inf, 0, 0) in upp_linear_sb_prep; either way the
+ *       six-product sum mixes +inf and -inf terms (the residual terms of the OTHER operand carry both signs), so every output a non-finite
+ *       operand reaches is non-finite -- NaN where upp_linear_f32 yields +-inf.  Overflow still surfaces, its sign does not.
  *   upp_linear_sb_group_bias_f32: C = A . W^T + bias[m >> group_shift][:] (a bias per group of 2^group_shift >= 32 rows), the split-bf16
  *       form of upp_linear_group_bias_f32 (reference models/Point_MAE_unify_segment.py:424-433, models/Point_MAE_unify.py:213-216). */
 int upp_linear_sb_tile(int M, int N, int K);

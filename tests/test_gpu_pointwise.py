@@ -367,7 +367,7 @@ def test_interpolation_with_geometry_gradients_equals_the_reference_formulation(
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * b.abs().max().item(), err_msg=name)
 
 
-@pytest.mark.parametrize("B,N", [(32, 64), (32, 1076), (3, 8192), (1, 1), (5, 257)])
+@pytest.mark.parametrize("B,N", [(32, 64), (32, 1076), (3, 8192), (1, 1), (5, 257), (70000, 16)])
 @pytest.mark.parametrize("descending", [False, True])
 def test_argsort_rows_is_torchs_stable_argsort(B, N, descending):
     """upp_argsort_rows (rank counting; replaces the device sorts of reference models/Point_MAE_pretask_dev.py:702-704 and
@@ -389,7 +389,7 @@ def test_argsort_rows_ranks_nan_as_the_largest_value_and_stays_a_permutation():
     from upp_hip import functional as HF
     key = torch.tensor([[0.5, float('nan'), -1.0, float('inf'), float('nan'), 0.5]], device='cuda')
     asc = HF.argsort_rows(key).cpu().tolist()[0]
-    assert asc == [2, 0, 5, 3, 1, 4]                            # NaN == +inf for ranking, ties in index order
+    assert asc == [2, 0, 5, 1, 3, 4]                            # NaN == +inf for ranking: the three 'infinite' keys in index order
     assert sorted(HF.argsort_rows(key, descending=True).cpu().tolist()[0]) == list(range(6))
 
 

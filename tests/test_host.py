@@ -195,3 +195,25 @@ def test_committed_pmc_counters_were_taken_on_the_kernels_this_build_launches():
     # every labelled shape of the step resolves back to its (first) label
     for label, M, N, K, epi in bench.STEP_LINEAR_SHAPES:
         assert bench.linear_label(M, N, K, epi) in [l for l, m, n, k, e in bench.STEP_LINEAR_SHAPES if (m, n, k, e) == (M, N, K, epi)]
+
+
+def test_torch_kernels_the_steps_launch_carry_no_affected_packed_f32_routing():
+    """Round 4 found v_pk_{add,mul,fma}_f32 with op_sel routing src1's HIGH half to the low lane returning wrong low halves beside a
+    bf16-MFMA workgroup; libupp_hip.so is built without packed f32 (tests/test_abi.py), torch's own element-wise kernels -- which the
+    pipelined default still launches beside the split-bf16 GEMMs -- are not ours to rebuild.  tools/torch_pk_scan.py disassembled every
+    gfx950 code object of this image's libtorch_hip.so (profiles/r05_torch_pk_scan.txt; several minutes, so the scan is committed and this
+    test reads it): the affected routing occurs ONLY in complex<float>, BFloat16-reduction and geometric-distribution instantiations --
+    none of the f32 add / mul / fill / cat / copy / layer-norm / reduce / uniform kernels a step launches (profiles/r0N_glue_census*.txt)."""
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "profiles", "r05_torch_pk_scan.txt")).read()
+    head, _, listed = text.partition("instantiations with the affected routing:")
+    assert "gfx950 code objects" in head and "v_pk_{add,mul,fma}_f32" in head
+    rows = [l for l in listed.splitlines() if l.strip()]
+    assert rows, "the scan lists the affected instantiations it found"
+    for l in rows:
+        assert ("complex<float>" in l) or ("BFloat16" in l) or ("geometric_kernel" in l), l
+    # per kernel family: the f32-only families the steps launch report 0 affected instructions
+    for fam in ("FillFunctor", "CatArrayBatchedCopy", "direct_copy_kernel", "vectorized_layer_norm_kernel", "MaxOps<float>", "vectorized_gather_kernel",
+                "BinaryFunctor<float, float, float, at::native::binary_internal::MulFunctor", "AUnaryFunctor<float, float, float, at::native::binary_internal::MulFunctor"):
+        line = next(l for l in head.splitlines() if l.strip().startswith(fam[:60]))
+        assert line.rstrip().endswith("affected routing: 0"), line

@@ -26,8 +26,11 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 tools/prof
 python3 tools/pmc_summary.py "$(ls $O/fetch/*/*counter_collection.csv | head -1)" "$(ls $O/write/*/*counter_collection.csv | head -1)" "$(trace $O/kern)" > $O/r05_pmc_kernels.json || { echo "PMC self-check FAILED (see pmc_summary.py)"; mv $O/r05_pmc_kernels.json $O/r05_pmc_kernels.REJECTED.json; }
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES --output-format csv -d $O/mfma -- python3 tools/prof_kernels.py > $O/mfma.log 2>&1
 python3 tools/pmc_mfma_summary.py "$(ls $O/mfma/*/*counter_collection.csv | head -1)" "$(trace $O/kern)" > $O/r05_pmc_mfma.json
-python3 bench.py --no-cpu-baseline --no-pipeline > $O/r05_bench_sequential.json 2> $O/bench_seq.err
-python3 bench.py > $O/r05_bench.json 2> $O/bench.err
+# the bench lines below join THESE counters (bench.py reads profiles/): copy them in, and refuse a line whose join lost a label
+[ -f $O/r05_pmc_kernels.json ] && cp $O/r05_pmc_kernels.json profiles/r05_pmc_kernels.json
+cp $O/r05_pmc_mfma.json profiles/r05_pmc_mfma.json
+UPP_BENCH_STRICT=1 python3 bench.py --no-cpu-baseline --no-pipeline > $O/r05_bench_sequential.json 2> $O/bench_seq.err
+UPP_BENCH_STRICT=1 python3 bench.py > $O/r05_bench.json 2> $O/bench.err
 rm -rf $O/seq $O/pipe $O/kern $O/fetch $O/write $O/mfma
 fi
 if [ "$PART" = "recipes" ]; then
