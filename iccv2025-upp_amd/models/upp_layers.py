@@ -925,8 +925,13 @@ class PointNetSetAbstraction(nn.Module):
 
     def forward(self, xyz, points):
         B, N, _ = xyz.shape
-        _, center, idx, _ = self.group_divider(xyz if xyz.dtype == torch.float64 else xyz.float(), require_index=True)   # (f64: arbitration runs of the tests)
-        x = points.reshape(B * N, -1)[idx]                              # (B*G*k, C) rows
+        if points.is_cuda and points.dtype == torch.float32 and POOL_TRACE is None:
+            # per-sample indices and a gather whose backward is the deterministic pull kernel (torch's indexing backward sorts on the device)
+            _, center, idx, _ = self.group_divider(xyz.float(), require_index=True, gather_idx=True)
+            x = HF.gather_rows(points.reshape(B, N, -1), idx.reshape(B, -1)).reshape(B * self.num_group * self.group_size, -1)
+        else:
+            _, center, idx, _ = self.group_divider(xyz if xyz.dtype == torch.float64 else xyz.float(), require_index=True)   # (f64: arbitration runs of the tests)
+            x = points.reshape(B * N, -1)[idx]                          # (B*G*k, C) rows
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
             x = _pointwise_bn_relu(x, conv, bn, self.training)
         x = max_over(x.view(B, self.num_group, self.group_size, -1), 2, 'set_abstraction')

@@ -10,7 +10,6 @@
 //             across all blocks, written once at the end) while waves 6, 7 compute dQ_b = dS K.
 //             No atomics: results are deterministic.
 // Every product is a set of 32x32 tiles of v_mfma_f32_32x32x2_f32 dealt round-robin to the waves (attn_tiles.h).
-#include <type_traits>
 #include "attn_tiles.h"
 
 namespace {
@@ -23,7 +22,6 @@ constexpr int kBB = 32;          // backward: query rows per block (P and dS str
 constexpr int kAccW = 6;         // backward: waves 0..5 own the dK / dV accumulator tiles, waves 6, 7 compute dQ
 constexpr int kAccS = 4;         // accumulator tiles per owner wave: ceil(4 * 5 / 6)
 constexpr int kTR = 16;          // FOLD: rows of the tail strips (the queries behind row 128 of a 129 ... 144-token sequence)
-constexpr int kKPF = 144;        // FOLD, backward: rows of the staged K / V (L <= 144)
 
 // rows [0, valid) x 64 of NARR sources (row stride rs floats) -> dst[a][R][kLD], rows >= valid zero; all loads first
 template <int R, int NARR>
@@ -180,21 +178,15 @@ __global__ __launch_bounds__(64 * kLW) void attn_fwd_long_kernel(const float *__
     }
 }
 
-// FOLD (round 5), backward: for 129 ... 144 tokens the rows behind row 128 (at most kTR = 16) used to be a fifth 32-row block (65.3 us
-// at L = 129 against 46.7 at L = 128).  They ride along with the FIRST block instead: their S / dP tiles run on waves 5..7 (idle in
-// phase 1), their dV / dK contributions are a second product per accumulator tile with a contraction of 16 instead of 32 rows, their dQ
-// a second tile pair of waves 6, 7.  K and V are staged on 144 instead of 160 rows to make room (key tile 4 then reads rows 144..159
-// from the array behind: finite values that only meet keys >= L, whose p and dS are exactly 0 and whose dK / dV rows are not stored).
-template <bool FOLD>
+// (round 5: folding the rows behind row 128 into the first 32-row block, as the forward kernel does, was built and measured for this
+//  kernel too -- 64.1 us against 63.7 at L = 129: the fifth KEY tile (one key of 32) costs what the fifth query block cost, in every
+//  block's S / dP phase, accumulator round and dQ contraction; not kept.)
 __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__restrict__ qkv, const float *__restrict__ ctx,
                                                                  const float *__restrict__ d_ctx, const float *__restrict__ lse,
                                                                  float *__restrict__ d_qkv, int L, int H, float scale) {
     extern __shared__ float sm[];
-    constexpr int KP = FOLD ? kKPF : kKP;
-    float *Ks = sm, *Vs = Ks + KP * kLD, *Qb = Vs + KP * kLD, *Gb = Qb + kBB * kLD;
-    float *Qt = Gb + kBB * kLD, *Gt = Qt + (FOLD ? kTR * kLD : 0), *Pt = Gt + (FOLD ? kTR * kLD : 0), *Dt = Pt + (FOLD ? kTR * kSS : 0);
-    float *Ps = Dt + (FOLD ? kTR * kSS : 0), *Ds = Ps + kBB * kSS;
-    float *delta = Ds + kBB * kSS, *lses = delta + kBB, *delta_t = lses + kBB, *lses_t = delta_t + kTR;
+    float *Ks = sm, *Vs = Ks + kKP * kLD, *Qb = Vs + kKP * kLD, *Gb = Qb + kBB * kLD, *Ps = Gb + kBB * kLD, *Ds = Ps + kBB * kSS;
+    float *delta = Ds + kBB * kSS, *lses = delta + kBB;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lk = lane >> 5;
     const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
@@ -207,61 +199,43 @@ __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__
         float *const dst[2] = {Ks, Vs};
         const float *const src[2] = {base + H * 64, base + 2 * H * 64};
         const size_t strides[2] = {rs, rs};
-        stage_block<KP, 2>(dst, src, strides, L);
+        stage_block<kKP, 2>(dst, src, strides, L);
     }
     const int nt = (L + 31) / 32;
-    const int Lmain = FOLD ? 4 * kBB : L, tail = FOLD ? L - 4 * kBB : 0;        // FOLD: 128 < L <= 128 + kTR (checked by the host)
     // dV / dK accumulator tiles: index a = which * 2 nt + jt * 2 + dt, owned by wave a % kAccW, slot a / kAccW
     f32x16 acc[kAccS];
 #pragma unroll
     for (int m = 0; m < kAccS; ++m) zero(acc[m]);
     float *const Ks0 = Ks, *const Vs0 = Vs, *const Qb0 = Qb, *const Gb0 = Gb, *const Ps0 = Ps, *const Ds0 = Ds;
-    float *const Qt0 = Qt, *const Gt0 = Gt, *const Pt0 = Pt, *const Dt0 = Dt;
-    // one query block; WT: with the tail strips riding along (the first block of a FOLD launch).  Two instantiations of the body: the
-    // three plain blocks of a FOLD launch keep the register allocation of the plain kernel (with a runtime flag the tail code pushed
-    // 75 VGPRs and 87 SGPRs of the whole loop into scratch).
-    auto block = [&](int q0, auto wt_tag) {
-        constexpr bool with_tail = decltype(wt_tag)::value;
-        const int qv = min(kBB, Lmain - q0);
+    for (int q0 = 0; q0 < L; q0 += kBB) {
+        const int qv = min(kBB, L - q0);
         // The operand addresses of all tile products are loop-invariant; hoisted out of this loop they would occupy
         // some 300 VGPRs (and spill).  An opaque zero offset keeps their computation inside the iteration.
         int opq = 0;
         asm volatile("" : "+v"(opq));
         Ks = Ks0 + opq; Vs = Vs0 + opq; Qb = Qb0 + opq; Gb = Gb0 + opq; Ps = Ps0 + opq; Ds = Ds0 + opq;
-        Qt = Qt0 + opq; Gt = Gt0 + opq; Pt = Pt0 + opq; Dt = Dt0 + opq;
         {
             float *const dst[2] = {Qb, Gb};
             const float *const src[2] = {base + (size_t)q0 * rs, gbase + (size_t)q0 * cs};
             const size_t strides[2] = {rs, cs};
             stage_block<kBB, 2>(dst, src, strides, qv);
         }
-        if constexpr (with_tail) {
-            float *const dst[2] = {Qt, Gt};
-            const float *const src[2] = {base + (size_t)Lmain * rs, gbase + (size_t)Lmain * cs};
-            const size_t strides[2] = {rs, cs};
-            stage_block<kTR, 2>(dst, src, strides, tail);
-        }
-        {   // delta_i = dO_i . O_i ; lse_i  -- 4 rows per wave (+ 2 tail rows), all loads first
-            constexpr int RW = kBB / kLW, RT = FOLD ? kTR / kLW : 0, RA = RW + RT;
-            float g[RA], o[RA], ls[RA], d[RA];
+        {   // delta_i = dO_i . O_i ; lse_i  -- 4 rows per wave, all loads first
+            constexpr int RW = kBB / kLW;
+            float g[RW], o[RW], ls[RW], d[RW];
 #pragma unroll
-            for (int t = 0; t < RA; ++t) {
-                const bool tl = t >= RW;
-                const int i = wave + kLW * (tl ? t - RW : t);
-                const bool ok = tl ? (with_tail && i < tail) : i < qv;
-                const int row = (tl ? Lmain : q0) + i;
-                g[t] = ok ? gbase[(size_t)row * cs + lane] : 0.0f;
-                o[t] = ok ? obase[(size_t)row * cs + lane] : 0.0f;
-                ls[t] = (ok && lane == 0) ? lse[((size_t)b * H + hh) * L + row] : 0.0f;
+            for (int t = 0; t < RW; ++t) {
+                const int i = wave + kLW * t;
+                const bool ok = i < qv;
+                g[t] = ok ? gbase[(size_t)(q0 + i) * cs + lane] : 0.0f;
+                o[t] = ok ? obase[(size_t)(q0 + i) * cs + lane] : 0.0f;
+                ls[t] = (ok && lane == 0) ? lse[((size_t)b * H + hh) * L + q0 + i] : 0.0f;
             }
 #pragma unroll
-            for (int t = 0; t < RA; ++t) d[t] = wave_sum_f32(g[t] * o[t]);
+            for (int t = 0; t < RW; ++t) d[t] = wave_sum_f32(g[t] * o[t]);
 #pragma unroll
-            for (int t = 0; t < RA; ++t)
-                if (lane == 0) {
-                    if (t < RW) { delta[wave + kLW * t] = d[t]; lses[wave + kLW * t] = ls[t]; }
-                    else if (with_tail) { delta_t[wave + kLW * (t - RW)] = d[t]; lses_t[wave + kLW * (t - RW)] = ls[t]; }
-                }
+            for (int t = 0; t < RW; ++t)
+                if (lane == 0) { delta[wave + kLW * t] = d[t]; lses[wave + kLW * t] = ls[t]; }
         }
         __syncthreads();
         // phase 1: wave jt computes S and dP of key tile jt, writes P and dS = P (dP - delta) scale to the two strips
@@ -278,24 +252,6 @@ __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__
                 Ps[i * kSS + j] = p;
                 Ds[i * kSS + j] = (i < qv && j < L) ? p * (dp[r] - delta[i]) * scale : 0.0f;
             }
-        } else if constexpr (with_tail) {
-            // the tail strips: key tiles dealt to the waves phase 1 leaves idle (nt = 5: waves 5, 6, 7 take tiles {0, 3}, {1, 4}, {2})
-            for (int jt = wave - nt; jt < nt; jt += kLW - nt) {
-                f32x16 s, dp; zero(s); zero(dp);
-                mfma_tile<false, true>(s, Qt, kLD, Ks + jt * 32 * kLD, kLD, 64, lr, lk);
-                mfma_tile<false, true>(dp, Gt, kLD, Vs + jt * 32 * kLD, kLD, 64, lr, lk);
-                const int j = jt * 32 + lr;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = tile_row(r, lk);
-                    if (i < kTR) {
-                        const bool live = i < tail && j < L;
-                        const float p = live ? exp_neg(s[r] * scale - lses_t[i]) : 0.0f;
-                        Pt[i * kSS + j] = p;
-                        Dt[i * kSS + j] = live ? p * (dp[r] - delta_t[i]) * scale : 0.0f;
-                    }
-                }
-            }
         }
         __syncthreads();
         // phase 2: dV += P^T dO_b, dK += dS^T Q_b on the owner waves; dQ_b = dS K on the last two waves
@@ -308,10 +264,6 @@ __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__
                     const int jt = u >> 1, dt = u & 1;
                     if (which == 0) mfma_tile_k<true, false, 32>(acc[m], Ps + jt * 32, kSS, Gb + dt * 32, kLD, lr, lk);
                     else mfma_tile_k<true, false, 32>(acc[m], Ds + jt * 32, kSS, Qb + dt * 32, kLD, lr, lk);
-                    if constexpr (with_tail) {
-                        if (which == 0) mfma_tile_k<true, false, kTR>(acc[m], Pt + jt * 32, kSS, Gt + dt * 32, kLD, lr, lk);
-                        else mfma_tile_k<true, false, kTR>(acc[m], Dt + jt * 32, kSS, Qt + dt * 32, kLD, lr, lk);
-                    }
                 }
             }
         } else {
@@ -321,25 +273,10 @@ __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = q0 + tile_row(r, lk);
-                if (i < Lmain) dbase[(size_t)i * rs + dt * 32 + lr] = dq[r];
-            }
-            if constexpr (with_tail) {
-                zero(dq);
-                mfma_tile<false, false>(dq, Dt, kSS, Ks + dt * 32, kLD, nt * 32, lr, lk);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = tile_row(r, lk);
-                    if (i < tail) dbase[(size_t)(Lmain + i) * rs + dt * 32 + lr] = dq[r];
-                }
+                if (i < L) dbase[(size_t)i * rs + dt * 32 + lr] = dq[r];
             }
         }
         __syncthreads();
-    };
-    if constexpr (FOLD) {
-        block(0, std::true_type{});
-        for (int q0 = kBB; q0 < Lmain; q0 += kBB) block(q0, std::false_type{});
-    } else {
-        for (int q0 = 0; q0 < Lmain; q0 += kBB) block(q0, std::false_type{});
     }
     if (wave < kAccW) {
 #pragma unroll
@@ -361,12 +298,8 @@ __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__
 constexpr size_t kFwdLongLds = ((size_t)2 * kKP * kLD + (size_t)kQB * kLD + (size_t)kQB * kSS) * sizeof(float);
 constexpr size_t kFwdFoldLds = kFwdLongLds + ((size_t)kTR * kLD + (size_t)kTR * kSS) * sizeof(float);
 static_assert(kFwdFoldLds <= 160 * 1024, "LDS budget");
-constexpr size_t kBwdLongLds = ((size_t)2 * kKP * kLD + (size_t)2 * kBB * kLD + (size_t)2 * kBB * kSS + 2 * kBB + 2 * kTR) * sizeof(float);
-constexpr size_t kBwdFoldLds = ((size_t)2 * kKPF * kLD + (size_t)2 * kBB * kLD + (size_t)2 * kTR * kLD + (size_t)2 * kTR * kSS + (size_t)2 * kBB * kSS + 2 * kBB + 2 * kTR) * sizeof(float);
-static_assert(kBwdLongLds <= 160 * 1024 && kBwdFoldLds <= 160 * 1024, "LDS budget");
-// (the 32-row operand reads of the tail tiles run on behind their 16-row strips, and key tile 4 of the 144-row K / V behind row 143:
-//  into the arrays that follow -- Pt/Dt behind Gt, Ps/Ds behind Dt, V behind K, Qb behind V: all inside the allocation)
-static_assert((size_t)(2 * kKPF + 2 * kBB) * kLD >= (size_t)(kKPF + 160) * kLD, "K / V overrun stays inside the allocation");
+constexpr size_t kBwdLongLds = ((size_t)2 * kKP * kLD + (size_t)2 * kBB * kLD + (size_t)2 * kBB * kSS + 2 * kBB) * sizeof(float);
+static_assert(kBwdLongLds <= 160 * 1024, "LDS budget");
 
 // UPP_ATTN_FOLD=0 (read once): the three-block walk of rounds 1-4 for 129 ... 144 tokens (A/B timing, tests)
 inline bool fold_disabled() {
@@ -398,15 +331,10 @@ int upp_attn_bwd_long(const float *qkv, const float *ctx, const float *d_ctx, co
                       float scale, hipStream_t st) {
     static std::atomic<bool> raised{false};
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_long_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLongLds);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_long_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdFoldLds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLongLds);
         if (e != hipSuccess) return (int)e;
         raised = true;
     }
-    if (L > 4 * kBB && L <= 4 * kBB + kTR && !fold_disabled())
-        hipLaunchKernelGGL(attn_bwd_long_kernel<true>, dim3(B * H), dim3(64 * kLW), kBwdFoldLds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
-    else
-        hipLaunchKernelGGL(attn_bwd_long_kernel<false>, dim3(B * H), dim3(64 * kLW), kBwdLongLds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
+    hipLaunchKernelGGL(attn_bwd_long_kernel, dim3(B * H), dim3(64 * kLW), kBwdLongLds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
     return upp_launch_status();
 }

@@ -989,6 +989,33 @@ class _InterpTrain(Function):
         return None, None, ops.interp_bwd(dists, idx, g.contiguous(), ctx.S, ctx.k, ctx.eps), None, None
 
 
+_UNIT_DIST = {}
+
+
+def gather_rows(points, idx):
+    """points (B,S,C) f32, idx (B,M) int64 per-sample row indices -> (B,M,C) = points[b, idx[b, m]] with a DETERMINISTIC, sort-free
+    backward: a gather is the k = 1 inverse-distance interpolation (its single weight is (1/(d+eps)) / (1/(d+eps)) = 1 exactly), so the
+    forward is upp_interp_fwd and the gradient the pull kernel of upp_interp_bwd -- torch's advanced-indexing backward is an
+    index_put_(accumulate=True) behind a device radix sort (reference models/Point_MAE_pretask_dev.py:409-413 set abstraction, whose
+    features carry a gradient in the pre-task and stage-2 recipes).  M <= 4096; anything else takes torch.gather."""
+    B, S, C = points.shape
+    M = idx.shape[1]
+    if not (points.is_cuda and points.dtype == torch.float32 and idx.dtype == torch.int64 and idx.dim() == 2 and 0 < M <= 4096 and S > 0):
+        return torch.gather(points, 1, idx.unsqueeze(-1).expand(-1, -1, C))
+    key = (B, M, str(points.device))
+    d = _UNIT_DIST.get(key)
+    if d is None:
+        d = torch.zeros(B, M, 1, device=points.device)
+        if not torch.cuda.is_current_stream_capturing():          # (memory of a graph's private pool is never cached)
+            if len(_UNIT_DIST) > 64:
+                _UNIT_DIST.clear()
+            _UNIT_DIST[key] = d
+    tab = idx.contiguous().view(B, M, 1)
+    if torch.is_grad_enabled() and points.requires_grad:
+        return _InterpTrain.apply(d, tab, points, 1, 1.0)
+    return ops.interp_fwd(d, tab, points.contiguous(), 1, 1.0)
+
+
 def interp_train(dists, idx, feat, k, eps):
     """Differentiable (w.r.t. feat) inverse-distance interpolation from the k nearest of a sorted neighbour table."""
     return _InterpTrain.apply(dists, idx, feat, k, eps)

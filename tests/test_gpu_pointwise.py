@@ -420,3 +420,25 @@ def test_layer_norm_on_the_row_kernel_equals_nn_layer_norm(last, grad):
         torch.testing.assert_close(hb, gb, rtol=1e-4, atol=1e-4)
     x2 = torch.randn(100, 384, device='cuda')                     # 2-D rows
     torch.testing.assert_close(HF.layer_norm(x2, ln), ln(x2), rtol=2e-5, atol=2e-5)
+
+
+def test_gather_rows_forward_and_sort_free_backward():
+    """HF.gather_rows (the set abstraction's feature gather, reference models/Point_MAE_pretask_dev.py:409-413): rows bit-equal to
+    advanced indexing, gradient equal to torch's index_put_(accumulate) up to the summation order, and the same bits on every call."""
+    from upp_hip import functional as HF
+    g = torch.Generator(device='cuda').manual_seed(9)
+    B, S, C, M = 32, 64, 384, 512
+    pts = torch.randn(B, S, C, device='cuda', generator=g, requires_grad=True)
+    idx = torch.randint(0, S, (B, M), device='cuda', generator=g)
+    idx[:, :40] = 3                                             # many repeats of one source row
+    w = torch.randn(B, M, C, device='cuda', generator=g)
+    got = HF.gather_rows(pts, idx)
+    want = torch.gather(pts, 1, idx.unsqueeze(-1).expand(-1, -1, C))
+    assert torch.equal(got, want)
+    (gg,) = torch.autograd.grad((got * w).sum(), pts)
+    (gw,) = torch.autograd.grad((want * w).sum(), pts)
+    torch.testing.assert_close(gg, gw, rtol=1e-5, atol=1e-5)
+    (gg2,) = torch.autograd.grad((HF.gather_rows(pts, idx) * w).sum(), pts)
+    assert torch.equal(gg, gg2)
+    with torch.no_grad():
+        assert torch.equal(HF.gather_rows(pts, idx), want)
