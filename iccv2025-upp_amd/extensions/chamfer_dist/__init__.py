@@ -27,6 +27,10 @@ class _ChamferBase(torch.nn.Module):
     def _dists(self, xyz1, xyz2):
         if xyz1.size(0) == 1 and self.ignore_zeros:
             xyz1, xyz2 = _strip_zero_points(xyz1, xyz2)
+        if not xyz1.is_cuda:
+            from upp_hip import torch_cpu           # opt-in torch formulation for CPU tensors (upp_hip.torch_cpu); ChamferFunction raises otherwise
+            if torch_cpu.enabled():
+                return torch_cpu.chamfer(xyz1, xyz2)
         return ChamferFunction.apply(xyz1, xyz2)
 
 

@@ -158,13 +158,26 @@ furthest_point_sample = FurthestPointSampling.apply
 gather_operation = GatherOperation.apply
 
 
+def _torch_cpu(*tensors):
+    """CPU tensors and the opt-in torch formulations switched on (upp_hip.torch_cpu: BASELINE configs[0], plumbing on a GPU-less host)?
+    Otherwise the operators below go to upp_hip.ops, which serves HIP tensors only and says so."""
+    from . import torch_cpu
+    return torch_cpu.enabled() and all(isinstance(t, torch.Tensor) and not t.is_cuda for t in tensors)
+
+
 def fps_gather(xyz, npoint):
     """-> (centers (B,npoint,3), idx (B,npoint) int32)."""
+    if _torch_cpu(xyz):
+        from . import torch_cpu
+        return torch_cpu.fps(xyz, int(npoint))
     return _FpsGather.apply(xyz, int(npoint))
 
 
 def knn_query(ref, query, k):
     """-> (dist (B,Q,k) f32, idx (B,Q,k) int64); no gradient (the reference wraps it in no_grad)."""
+    if _torch_cpu(ref, query):
+        from . import torch_cpu
+        return torch_cpu.knn(ref, query, int(k))
     with torch.no_grad():
         dist, idx, _ = ops.knn(ref, query, k, want_dist=True, want_neigh=False)
     return dist, idx
@@ -172,6 +185,9 @@ def knn_query(ref, query, k):
 
 def knn_group(xyz, center, k):
     """-> (neighborhood (B,G,k,3) centred on `center`, idx (B,G,k) int64)."""
+    if _torch_cpu(xyz, center):
+        from . import torch_cpu
+        return torch_cpu.knn_group(xyz, center, int(k))
     return _KnnGroup.apply(xyz, center, int(k))
 
 

@@ -217,3 +217,47 @@ def test_torch_kernels_the_steps_launch_carry_no_affected_packed_f32_routing():
                 "BinaryFunctor<float, float, float, at::native::binary_internal::MulFunctor", "AUnaryFunctor<float, float, float, at::native::binary_internal::MulFunctor"):
         line = next(l for l in head.splitlines() if l.strip().startswith(fam[:60]))
         assert line.rstrip().endswith("affected routing: 0"), line
+
+
+def test_configs0_cpu_plumbing_forward_runs_on_the_opt_in_torch_formulations(oracle_ops):
+    """BASELINE configs[0]: Point_MAE_unify cls forward of one N = 1024 cloud on torch-CPU (utils.misc.fps + a torch.cdist kNN).  The
+    product has no CPU path by default (ops raises); upp_hip.torch_cpu.enable() -- explicit, off by default -- serves CPU tensors with
+    plain torch.  Here: (a) off -> the operators refuse CPU tensors; (b) on -> FPS picks and kNN lists equal the CPU oracle's on a
+    seeded cloud and the model's logits equal the oracle-injected forward to 1e-5 (eval mode; the oracle is only the checker)."""
+    import numpy as np
+    import oracle
+    import _seeded
+    from models import build_model_from_cfg, upp_layers
+    from upp_hip import functional as HF, torch_cpu
+    import knn_cuda
+    x = _seeded.noisy_clouds(1, 1024, seed=5)
+    model = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).eval()
+    with torch.no_grad():
+        want = model(x, completion_prompt=True, denoise=True, point_num=1024)      # (oracle_ops fixture: grouping on the C oracle)
+    saved = dict(upp_layers.OPS)
+    saved_fg = HF.fps_gather
+    try:
+        HF.fps_gather = _PRODUCT_FPS_GATHER                       # back to the product's own entry points (the fixture had replaced them)
+        upp_layers.OPS["fps_gather"] = _PRODUCT_FPS_GATHER
+        upp_layers.OPS["knn_group"] = _PRODUCT_KNN_GROUP
+        assert not torch_cpu.enabled()
+        with pytest.raises(RuntimeError):
+            _PRODUCT_FPS_GATHER(x, 64)
+        torch_cpu.enable()
+        cen, idx = _PRODUCT_FPS_GATHER(x, 64)
+        assert np.array_equal(idx.numpy(), oracle.fps(x.numpy(), 64))
+        d, i = knn_cuda.KNN(32, transpose_mode=True)(x, cen)
+        _, wi = oracle.knn(x.numpy(), cen.numpy(), 32, want_dist=False)
+        assert np.array_equal(np.sort(i.numpy(), -1), np.sort(wi, -1))                 # neighbour SETS (in-list order is not pinned)
+        with torch.no_grad():
+            got = model(x, completion_prompt=True, denoise=True, point_num=1024)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=2e-5)
+    finally:
+        torch_cpu.enable(False)
+        upp_layers.OPS.clear()
+        upp_layers.OPS.update(saved)
+        HF.fps_gather = saved_fg
+
+
+from upp_hip import functional as _HF_for_fallback_test          # noqa: E402  (the product's own entry points, captured before any fixture replaces them)
+_PRODUCT_FPS_GATHER, _PRODUCT_KNN_GROUP = _HF_for_fallback_test.fps_gather, _HF_for_fallback_test.knn_group
