@@ -743,16 +743,24 @@ class Block(nn.Module):
         # that consumes the GEMM result (proj.bias, fc2.bias); fc1's bias, the GELU and -- for backward -- GELU' are the
         # epilogue of the fc1 GEMM, and the fc2 data gradient multiplies by that GELU' in its own epilogue.
         yb = mb = None
-        if fused_attn:
-            qkv = HF.linear(h1, attn.qkv.weight, attn.qkv.bias)
-            ctx = HF.attention(qkv, attn.num_heads, attn.scale)
-            y, yb = HF.linear(ctx, attn.proj.weight), attn.proj.bias
-        else:
-            y = attn(h1)
         fc1, fc2 = mlp.fc1, mlp.fc2
         fused_mlp = (_frozen_bias(fc1) and _frozen_bias(fc2) and isinstance(mlp.act, nn.GELU) and mlp.act.approximate == 'none'
                      and HF.linear_usable(xa, fc1.weight) and fc1.out_features % 32 == 0 and _no_grad_needed(fc1.weight, fc2.weight))
-        x2, h2 = HF.rowln(xa, y=y, ybias=yb, u=None if u is None else u[0], keep=keep, gamma=n2.weight, beta=n2.bias, eps=n2.eps)
+        u0 = None if u is None else u[0]
+        x2 = h2 = None
+        if fused_attn:
+            qkv = HF.linear(h1, attn.qkv.weight, attn.qkv.bias)
+            ctx = HF.attention(qkv, attn.num_heads, attn.scale)
+            if fused_mlp and POOL_TRACE is None and HF.proj_resid_ln_usable(ctx, attn.proj.weight, attn.proj.bias, xa, n2, fc1.weight):
+                # round 5: the residual add rides in the projection GEMM's epilogue (with the row-block statistics of norm2) and norm2 itself
+                # in the A-prologue of fc1 -- no row kernel between the two GEMMs (h2 is a handle, never written)
+                x2, h2 = HF.proj_resid_ln(ctx, attn.proj.weight, attn.proj.bias, xa, u0, keep, n2)
+            else:
+                y, yb = HF.linear(ctx, attn.proj.weight), attn.proj.bias
+        else:
+            y = attn(h1)
+        if x2 is None:
+            x2, h2 = HF.rowln(xa, y=y, ybias=yb, u=u0, keep=keep, gamma=n2.weight, beta=n2.bias, eps=n2.eps)
         if fused_mlp:
             m, mb = HF.mlp_gelu(h2, fc1.weight, fc1.bias, fc2.weight), fc2.bias
         elif _frozen_bias(fc1) and _frozen_bias(fc2) and isinstance(mlp.act, nn.GELU) and fc1.out_features % 4 == 0:

@@ -96,6 +96,11 @@ SIGNATURES = {
     "upp_linear_sb_prep_batched": (_c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong)] + [ctypes.POINTER(ctypes.c_int)] * 3
                                    + [ctypes.POINTER(ctypes.c_void_p), _c_i, _c_f]),
     "upp_linear_sb_group_bias_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
+    "upp_linear_sb_ln_usable": (_c_i, [_c_i, _c_i, _c_i]),
+    "upp_linear_sb_ln_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_i, _c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_longlong, _c_f,
+                                    ctypes.c_longlong, _c_i, _c_i, _c_i, _c_i, _c_f]),
+    "upp_linear_sb_resid_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_f, ctypes.c_longlong, _c_f, ctypes.c_float, _c_i, _c_f, ctypes.c_longlong, _c_f,
+                                       _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_linear_sb_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong] + [_c_i] * 5 + [_c_f]),
     "upp_linear_group_bias_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
     "upp_linear_smallk_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_f, ctypes.c_longlong] + [_c_i] * 4 + [_c_f]),
@@ -118,7 +123,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 3            # include/upp_hip.h UPP_ABI_VERSION
+ABI_VERSION = 4            # include/upp_hip.h UPP_ABI_VERSION
 
 
 def load():

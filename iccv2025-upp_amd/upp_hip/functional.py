@@ -783,8 +783,111 @@ class _MlpGelu(Function):
         return gx, gw1, gb1, gw2, gb2
 
 
+# ---- residual + LayerNorm between two Linear layers without a row kernel (round 5; upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32)
+class LazyLayerNorm:
+    """What `proj_resid_ln` hands on in place of the normalised rows: the rows themselves, their block statistics and the LayerNorm's
+    parameters -- `mlp_gelu` applies the LayerNorm in the A-prologue of its first GEMM, which also writes mean / rstd for the backward."""
+
+    def __init__(self, rows, stats, mean, rstd, gamma, beta, eps):
+        self.rows, self.stats, self.mean, self.rstd, self.gamma, self.beta, self.eps = rows, stats, mean, rstd, gamma, beta, eps
+
+
+class _ProjResidLN(Function):
+    """(x2, h2) = (xa + dp (a . W^T + b), LayerNorm(x2)) where h2 is only a graph handle (a zero-stride dummy): ONE launch -- the
+    projection GEMM with the residual add and the row-block statistics in its epilogue -- for the projection GEMM + upp_rowln_fwd.
+    Backward: upp_rowln_bwd on (g_x2, g_h2) exactly as _RowLN, then the projection's data gradient.  W, b, gamma, beta frozen."""
+
+    @staticmethod
+    def forward(ctx, a, w, bias, xa, u, keep, gamma, beta, eps):
+        B, L, D = xa.shape
+        x2, stats = ops.linear_sb_resid(a, ops.PLANES.get(w), tuple(w.shape), bias, xa, u, keep, L)
+        mean = torch.empty(B * L, dtype=torch.float32, device=xa.device)          # (filled by the GEMM that consumes the handle)
+        rstd = torch.empty(B * L, dtype=torch.float32, device=xa.device)
+        h2 = x2.new_zeros(1).expand(B, L, D)
+        ctx.save_for_backward(x2, mean, rstd, gamma, u, w)
+        ctx.keep, ctx.dims = keep, (B, L, D)
+        ctx.mark_non_differentiable(stats, mean, rstd)
+        return x2, h2, stats, mean, rstd
+
+    @staticmethod
+    def backward(ctx, g_x2, g_h2, _gs, _gm, _gr):
+        x2, mean, rstd, gamma, u, w = ctx.saved_tensors
+        B, L, D = ctx.dims
+        need = ctx.needs_input_grad
+        g_x2 = g_x2.contiguous() if g_x2 is not None else None
+        g_h2 = g_h2.contiguous() if g_h2 is not None else None
+        if g_x2 is None and g_h2 is None:
+            return (None,) * 9
+        g_x, _, g_y, _ = ops.rowln_bwd(g_x2, g_h2, x2, mean.view(B, L), rstd.view(B, L), gamma, ROW_IDENTITY, u, ctx.keep, B, L, L, D, 0,
+                                       need_x=need[3], need_prompt=False, need_y=need[0], need_ln_part=False)
+        g_a = _lin(g_y.view(B * L, D), w, dgrad=True).view(B, L, w.shape[1]) if need[0] else None
+        return g_a, None, None, g_x if need[3] else None, None, None, None, None, None
+
+
+def proj_resid_ln_usable(a, w, bias, xa, ln, fc1_weight):
+    """Can (projection GEMM + residual + LayerNorm + first MLP GEMM) run without the row kernel between them?  Frozen projection and
+    LayerNorm parameters, HIP f32 rows of a multiple of 32 columns, split-bf16 kernels for both GEMMs and a first-MLP-GEMM tile that
+    carries the A-operand prologue."""
+    if not (ops.SPLIT_BF16 and FUSE_RESID_LN and a.is_cuda and a.dtype == torch.float32 and xa.dtype == torch.float32 and xa.dim() == 3):
+        return False
+    D = xa.shape[-1]
+    M = xa.shape[0] * xa.shape[1]
+    grad = torch.is_grad_enabled()
+    if grad and (w.requires_grad or (bias is not None and bias.requires_grad) or ln.weight.requires_grad or ln.bias.requires_grad or fc1_weight.requires_grad):
+        return False
+    return (isinstance(ln, torch.nn.LayerNorm) and ln.elementwise_affine and ln.bias is not None and D % 32 == 0 and D <= 512 and w.shape[0] == D
+            and w.stride(1) == 1 and w.data_ptr() % 16 == 0 and w.stride(0) % 4 == 0 and (bias is None or bias.data_ptr() % 16 == 0)
+            and ops.linear_sb_usable(M, D, w.shape[1]) and fc1_weight.shape[1] == D and ops.linear_sb_ln_usable(M, fc1_weight.shape[0], D))
+
+
+FUSE_RESID_LN = os.environ.get("UPP_FUSE_RESID_LN", "1") != "0"       # (0: the row kernel between the projection and the MLP, as rounds 2-4)
+
+
+def proj_resid_ln(a, w, bias, xa, u, keep, ln):
+    """-> (x2 (B,L,D) = xa + drop_path(a . w^T + bias), handle of LayerNorm(x2) for mlp_gelu).  Ask proj_resid_ln_usable first."""
+    keep = float(keep)
+    if torch.is_grad_enabled() and (a.requires_grad or xa.requires_grad):
+        x2, h2, stats, mean, rstd = _ProjResidLN.apply(a, w, bias, xa, u, keep, ln.weight, ln.bias, float(ln.eps))
+    else:
+        B, L, D = xa.shape
+        x2, stats = ops.linear_sb_resid(a, ops.PLANES.get(w), tuple(w.shape), bias, xa, u, keep, L)
+        h2, mean, rstd = x2.new_zeros(1).expand(B, L, D), None, None
+    h2._upp_lazy_ln = LazyLayerNorm(x2, stats, mean, rstd, ln.weight, ln.bias, float(ln.eps))
+    return x2, h2
+
+
+class _MlpGeluLN(Function):
+    """_MlpGelu for frozen weights whose input is a LazyLayerNorm handle: fc1 runs upp_linear_sb_ln_f32 on the un-normalised rows."""
+
+    @staticmethod
+    def forward(ctx, h_dummy, rows, stats, mean, rstd, gamma, beta, eps, w1, b1, w2, b2):
+        B, L, D = rows.shape
+        # (mean / rstd: the buffers _ProjResidLN saved for ITS backward -- this launch fills them)
+        hid, d, _, _ = ops.linear_sb_ln(rows, stats, gamma, beta, eps, ops.PLANES.get(w1), tuple(w1.shape), b1, ops.LIN_BIAS_GELU_D, mean=mean, rstd=rstd)
+        ctx.save_for_backward(d, w1, w2)
+        return _lin(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE)
+
+    @staticmethod
+    def backward(ctx, g):
+        d, w1, w2 = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        g_z = _lin(g2, w2, None, ops.LIN_MUL, aux=d.view(-1, d.shape[-1]), dgrad=True)
+        gx = _lin(g_z, w1, dgrad=True).view(g.shape[:-1] + (w1.shape[1],)) if ctx.needs_input_grad[0] else None
+        return (gx,) + (None,) * 11
+
+
 def mlp_gelu(x, w1, b1, w2, b2=None):
-    """fc2(GELU(fc1(x) + b1)) (+ b2); both GEMMs and the activation on the Linear kernels (split-bf16 for frozen / managed weights)."""
+    """fc2(GELU(fc1(x) + b1)) (+ b2); both GEMMs and the activation on the Linear kernels (split-bf16 for frozen / managed weights).
+    x may be the handle of proj_resid_ln: the LayerNorm is then applied in fc1's A-prologue."""
+    lazy = getattr(x, '_upp_lazy_ln', None)
+    if lazy is not None:
+        if lazy.mean is not None and torch.is_grad_enabled() and x.requires_grad:
+            return _MlpGeluLN.apply(x, lazy.rows, lazy.stats, lazy.mean, lazy.rstd, lazy.gamma, lazy.beta, lazy.eps, w1, b1, w2, b2)
+        hid, _, _, _ = ops.linear_sb_ln(lazy.rows, lazy.stats, lazy.gamma, lazy.beta, lazy.eps, ops.PLANES.get(w1), tuple(w1.shape), b1, ops.LIN_BIAS_GELU,
+                                        want_rowstats=False)
+        return ops.linear_f32(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE, frozen=True)
     if not torch.is_grad_enabled() or not (x.requires_grad or w1.requires_grad or w2.requires_grad or b1.requires_grad
                                            or (b2 is not None and b2.requires_grad)):
         hid = ops.linear_f32(x, w1, b1, ops.LIN_BIAS_GELU, frozen=not w1.requires_grad)

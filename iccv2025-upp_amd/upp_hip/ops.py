@@ -453,6 +453,73 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None, f
     return (out, d) if epilogue == LIN_BIAS_GELU_D else out
 
 
+def linear_sb_ln_usable(M, N, K):
+    """Does upp_linear_sb_ln_f32 (LayerNorm in the A-prologue) take an (M,K) x (N,K)^T product?"""
+    return bool(SPLIT_BF16 and int(_abi.load().upp_linear_sb_ln_usable(int(M), int(N), int(K))))
+
+
+def linear_sb_resid(a, planes, wshape, bias, resid, u, keep, rows_per_sample):
+    """-> (x (M,N) = resid + dp (a . W^T + bias), row_stats (M, N/32, 2)): the Linear layer with the residual add of the block and the
+    statistics of the LayerNorm that follows in its epilogue (upp_linear_sb_resid_f32).  a (...,K), resid (...,N) f32 contiguous."""
+    N, K = wshape
+    _need(a, "a", torch.float32)
+    _need(resid, "resid", torch.float32)
+    a2, r2 = a.reshape(-1, K), resid.reshape(-1, N)
+    if not a2.is_contiguous():
+        a2 = a2.contiguous()
+    if not r2.is_contiguous():
+        r2 = r2.contiguous()
+    M = a2.shape[0]
+    if r2.shape[0] != M or N % 32:
+        raise RuntimeError("linear_sb_resid: resid must be (M,N) with N % 32 == 0")
+    sb = linear_sb_tile(M, N, K)
+    if not sb:
+        raise RuntimeError("linear_sb_resid: not a problem for the split-bf16 kernel (ask linear_sb_usable first)")
+    out = torch.empty(tuple(resid.shape), dtype=torch.float32, device=a.device)
+    stats = torch.empty((M, N // 32, 2), dtype=torch.float32, device=a.device)
+    scope = time_linear_calls.active
+    if scope is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _call(a.device, "upp_linear_sb_resid_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(planes), _abi.ptr(bias), _abi.ptr(r2), N, _abi.ptr(u), float(keep),
+          int(rows_per_sample), _abi.ptr(out), N, _abi.ptr(stats), M, N, K, sb)
+    if scope is not None:
+        ev1.record()
+        scope.calls.append((M, N, K, 6, ev0, ev1, sb))
+    return out, stats
+
+
+def linear_sb_ln(a, stats, gamma, beta, eps, planes, wshape, bias, epilogue, want_rowstats=True, mean=None, rstd=None):
+    """C = epilogue(LayerNorm(a) . W^T) with the LayerNorm applied in the kernel's A-prologue (upp_linear_sb_ln_f32): `stats` (M, K/32, 2) from
+    linear_sb_resid or (M, 2) = (mean, rstd).  mean / rstd: (M) buffers the kernel fills for the backward pass (allocated here when
+    want_rowstats and none is given).  -> (C, GELU' or None, mean, rstd)."""
+    N, K = wshape
+    _need(a, "a", torch.float32)
+    a2 = a.reshape(-1, K)
+    if not a2.is_contiguous():
+        a2 = a2.contiguous()
+    M = a2.shape[0]
+    nb = stats.shape[1] if stats.dim() == 3 else 0
+    lead = tuple(a.shape[:-1])
+    out = torch.empty(lead + (N,), dtype=torch.float32, device=a.device)
+    d = torch.empty(lead + (N,), dtype=torch.float32, device=a.device) if epilogue == LIN_BIAS_GELU_D else None
+    if want_rowstats and mean is None:
+        mean = torch.empty(M, dtype=torch.float32, device=a.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=a.device)
+    if mean is not None and not (mean.numel() == M and rstd.numel() == M and mean.is_contiguous() and rstd.is_contiguous()):
+        raise RuntimeError("linear_sb_ln: mean / rstd must be contiguous (M) buffers")
+    scope = time_linear_calls.active
+    if scope is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _call(a.device, "upp_linear_sb_ln_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(stats), int(nb), _abi.ptr(gamma), _abi.ptr(beta), float(eps),
+          _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(planes), _abi.ptr(bias), _abi.ptr(out), N, _abi.ptr(d), N, M, N, K, int(epilogue))
+    if scope is not None:
+        ev1.record()
+        scope.calls.append((M, N, K, int(epilogue) + 16, ev0, ev1, linear_sb_tile(M, N, K)))
+    return out, d, mean, rstd
+
+
 def colsum_partials(part, offset, length, chunks=None):
     """(chunks, length) partial column sums of columns [offset, offset + length) of the tall 2-D matrix `part` (upp_colsum_partials)."""
     if not (isinstance(part, torch.Tensor) and part.is_cuda and part.dtype == torch.float32 and part.dim() == 2 and part.stride(1) == 1):

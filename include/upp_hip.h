@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UPP_ABI_VERSION 3   /* 3: split-bf16 Linear (upp_linear_sb_*); the k-parts protocol (upp_linear_parts*, upp_*_parts), the attention
+#define UPP_ABI_VERSION 4   /* 4: + upp_argsort_rows, upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32 / upp_linear_sb_ln_usable (additions only).  3: split-bf16 Linear (upp_linear_sb_*); the k-parts protocol (upp_linear_parts*, upp_*_parts), the attention
                                `variant` entry points (upp_attn_*_ex) and the VALU / 32x32x2 attention kernels behind them are gone.
                                2: grouped weight gradients, register-tiled Linear codes; the round-1 *_set_* toggles are gone */
 
@@ -559,6 +559,29 @@ int upp_linear_sb_f32(const float *A, long long lda, const void *planes, const f
                       long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream);
 int upp_linear_sb_group_bias_f32(const float *A, long long lda, const void *planes, const float *bias, int group_shift, float *C,
                                  long long ldc, int M, int N, int K, void *stream);
+
+/* ---- residual + LayerNorm between two Linear layers without a row kernel (round 5) -----------------------------------
+ * Replaces, for the second half of a Transformer block (reference models/Point_MAE_pretask_dev.py:266,273:
+ * `x = x + drop_path(attn(norm1(x)))` followed by `mlp(norm2(x))`), the launch that added the attention branch to the residual stream
+ * and wrote its LayerNorm (upp_rowln_fwd):
+ *   upp_linear_sb_resid_f32: C (M,N) = resid + dp_row * (A . W^T + bias), dp_row = floor(keep + u[row / rows_per_sample]) / keep (timm
+ *       DropPath; u NULL: 1) -- the projection's GEMM with the residual add in its epilogue -- and row_stats (M, N/32, 2): per row and
+ *       32-column block the pair (sum, sum of squared deviations from the block mean) of the stored values.  N % 32 == 0; resid (M, ld_res)
+ *       16-byte aligned; tile as upp_linear_sb_f32.
+ *   upp_linear_sb_ln_f32: C = epilogue( LayerNorm(A) . W^T ) with LayerNorm(A)[r][k] = ((A[r][k] - mean_r) * rstd_r) * gamma[k] + beta[k]
+ *       applied to the f32 A fragment in front of its split: the normalised rows are never written.  ln_stats: ln_nb = K/32: the
+ *       (M, ln_nb, 2) pairs of upp_linear_sb_resid_f32, combined per row without cancellation (mean = sum S_i / K, M2 = sum M2_i +
+ *       32 sum (S_i/32 - mean)^2, rstd = 1 / sqrt(M2 / K + eps)); ln_nb = 0: (M, 2) = (mean, rstd).  ln_mean / ln_rstd (M) or NULL: the
+ *       statistics, written for the backward pass (upp_rowln_bwd).  Epilogues and aux as upp_linear_sb_f32.  K <= 512 and a problem whose
+ *       tile carries the A-operand prologue: ask upp_linear_sb_ln_usable(M, N, K) (1 / 0) first; UPP_E_RANGE otherwise.
+ * Values equal upp_rowln_fwd + upp_linear_sb_f32 up to the summation order of the row statistics (tests/test_gpu_linear_sb.py). */
+int upp_linear_sb_ln_usable(int M, int N, int K);
+int upp_linear_sb_ln_f32(const float *A, long long lda, const float *ln_stats, int ln_nb, const float *gamma, const float *beta, float eps,
+                         float *ln_mean, float *ln_rstd, const void *planes, const float *bias, float *C, long long ldc, float *aux,
+                         long long ldaux, int M, int N, int K, int epilogue, void *stream);
+int upp_linear_sb_resid_f32(const float *A, long long lda, const void *planes, const float *bias, const float *resid, long long ld_res,
+                            const float *u, float keep, int rows_per_sample, float *C, long long ldc, float *row_stats, int M, int N,
+                            int K, int tile, void *stream);
 /* upp_linear_smallk_f32: y (M,N) = act(x (M,K) . W (N,K)^T + bias) for the Linear layers upp_linear_f32 does not take (K not a
  * multiple of 4, unaligned rows): the first layer of every position MLP (K = 3; reference models/Point_MAE_unify.py pos_embed /
  * models/Point_MAE_pretask_dev.py:395-399 `nn.Linear(3, 128), nn.GELU(), nn.Linear(128, dim)`) and the first point-wise layer of

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_strings():
     lib = _abi.load()
-    assert lib.upp_abi_version() == 3
+    assert lib.upp_abi_version() == 4
     assert b"null pointer" in lib.upp_error_string(-1)
     assert b"range" in lib.upp_error_string(-2)
     assert b"knn" in lib.upp_error_string(-3)

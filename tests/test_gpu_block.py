@@ -823,3 +823,43 @@ def test_linear_with_a_deferred_bias_gradient_matches_autograd(rows, K, N):
     out = HF.linear(x, w, b)
     _, _, hb = torch.autograd.grad(out, (x, w, b), g)
     close(hb, gb, rtol=1e-5, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize("name", ["down0", "down7", "decoder"])
+def test_resid_ln_fold_equals_the_row_kernel_path_at_the_benched_batch(name, train=False):
+    """Round 5: with frozen backbone weights (the PEFT recipes) the residual add of the attention branch rides in the projection GEMM's
+    epilogue and norm2 in the A-prologue of fc1 (upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32; reference
+    models/Point_MAE_pretask_dev.py:266,273) -- no row kernel between the two GEMMs.  At B = 32 (the tile that carries the prologue) the
+    block's output and every gradient equal the row-kernel path (UPP_FUSE_RESID_LN=0) to f32 rounding; the launch list shows the fold.
+    (Eval mode: the stochastic-depth factor of the epilogue is covered draw by draw in tests/test_gpu_linear_sb.py.)"""
+    from upp_hip import ops
+    from upp_hip.train import freeze_for_peft, PEFT_STAGE1
+    m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda()
+    freeze_for_peft(m, PEFT_STAGE1)
+    m.train(train)
+    blk, x, pos, kw = _block_case(m, name, B=32)
+    assert blk.fusable(x)
+    params = [p for p in blk.parameters() if p.requires_grad]
+    outs, kinds = [], []
+    for fold in (True, False):
+        HF.FUSE_RESID_LN = fold
+        try:
+            torch.manual_seed(11)                               # (the same stochastic-depth / dropout draws in both runs)
+            upp_layers.begin_forward(x.device, train)
+            xi, pi = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+            with ops.time_linear_calls() as scope:
+                out = blk.forward_fused(xi, pi, **kw)
+            upp_layers.end_forward()
+            kinds.append(sorted(c[3] for c in scope.calls))
+            w = torch.linspace(-1, 1, out.numel(), device='cuda').view_as(out)
+            grads = torch.autograd.grad((out * w).sum(), [xi, pi] + params, allow_unused=True)
+            outs.append((out.detach(), grads))
+        finally:
+            HF.FUSE_RESID_LN = True
+    assert 6 in kinds[0] and any(e >= 16 for e in kinds[0]), kinds[0]          # the resid-epilogue GEMM and the LayerNorm-prologue GEMM ran
+    assert 6 not in kinds[1] and not any(e >= 16 for e in kinds[1]), kinds[1]
+    close(outs[0][0], outs[1][0], rtol=1e-5, atol_scale=2e-6)
+    for g, r in zip(outs[0][1], outs[1][1]):
+        assert (g is None) == (r is None)
+        if g is not None:
+            close(g, r, rtol=2e-5, atol_scale=5e-6)
