@@ -273,6 +273,12 @@ LINEAR_SHAPES = [("qkv", 2400, 1152, 384, 0), ("proj", 2400, 384, 384, 0), ("fc1
 # and data gradients), the rectify path's three blocks (35 tokens: M = 1120, forward only: GELU without its derivative) and the completion
 # prompter's four decoder blocks (64 tokens: M = 2048, forward only).  tools/prof_kernels.py launches each of them behind a marker and
 # tools/pmc_summary.py keys the counters 'linear:<label>'; roofline.traffic sums them over the step's launch list.
+# round 5: the projection with the residual add + row-block statistics in its epilogue (code 6) and fc1 with the LayerNorm in its A-prologue
+# (code 16 + epilogue) -- built, measured (kernels.linear_proj_resid / linear_fc1_ln_gelu_d below) and NOT the default: the prologue's 24
+# VALU instructions per k-step land on a loop that is already at the vector-issue limit (fc1 21.3 -> 26.3 us, more than the 5.6 us row
+# kernel it removes).  UPP_FUSE_RESID_LN=1 switches the fold on; the replay and the labels then follow the step's launch list.
+LIN_RESID, LIN_LN = 6, 16
+FOLD_SHAPES = [("proj_resid", 2400, 384, 384, LIN_RESID), ("fc1_ln_gelu_d", 2400, 1536, 384, LIN_LN + 3)]
 STEP_LINEAR_SHAPES = (LINEAR_SHAPES
                       + [("%s@2080" % lab, 2080, N, K, e) for lab, _, N, K, e in LINEAR_SHAPES]
                       + [("%s@%d" % (lab, M), M, N, K, e) for M in (1120, 2048)
@@ -288,15 +294,51 @@ def linear_label(M, N, K, epi):
 
 
 def linear_algorithmic_bytes(M, N, K, epi, split):
-    """A + W + C (+ the second (M,N) tensor of the GELU' / multiply epilogues), f32; the split-bf16 kernel reads W as three bf16 planes."""
-    return 4.0 * (M * K + N * K + M * N * (2 if epi in (3, 4) else 1)) + (2.0 * N * K if split else 0.0)
+    """A + W + C (+ the second (M,N) tensor of the GELU' / multiply / residual epilogues, the row-block statistics of the fold), f32; the
+    split-bf16 kernel reads W as three bf16 planes."""
+    base = epi - LIN_LN if epi >= LIN_LN else epi
+    extra = 8.0 * M * (N // 32) if epi == LIN_RESID else (8.0 * M * (K // 32) + 8.0 * M if epi >= LIN_LN else 0.0)
+    return 4.0 * (M * K + N * K + M * N * (2 if base in (3, 4, LIN_RESID) else 1)) + (2.0 * N * K if split else 0.0) + extra
 
 
-def sb_kernel_name(M, N, K):
+def sb_kernel_name(M, N, K, epi=0):
     """Kernel name (as rocprofv3 prints it) that serves a frozen-weight (M,N,K) Linear: host-side tile choice, no GPU needed."""
     from upp_hip import _abi
     sb = max(0, int(_abi.load().upp_linear_sb_tile(int(M), int(N), int(K))))
-    return ("linear_sb_kernel<%s>" % _sb_tile_str(sb)) if sb else ("linear_f32_kernel<%s>" % _abi_tile(M, N, K))
+    return _kname(M, N, K, epi, sb)
+
+
+def _kname(M, N, K, epi, sb):
+    if not sb:
+        return "linear_f32_kernel<%s>" % _abi_tile(M, N, K)
+    name = "linear_sb_kernel<%s>" % _sb_tile_str(sb)
+    return name[:-2] + "2>" if epi >= LIN_LN else name            # (PRO = 2: the LayerNorm prologue instantiation)
+
+
+def make_linear_operands(ops, M, N, K, e, device, gl, w=None):
+    """Synthetic operands of one labelled launch (own weight unless `w` is given) -> dict for run_linear."""
+    if w is None:
+        w = torch.randn(N, K, device=device, generator=gl) * K ** -0.5
+        w._upp_persistent = True                # (stands for a frozen weight: ops.PLANES keeps its plane image)
+    d = {"a": torch.randn(M, K, device=device, generator=gl), "w": w, "b": torch.randn(N, device=device, generator=gl),
+         "x": torch.randn(M, N, device=device, generator=gl), "o": torch.empty(M, N, device=device)}
+    if e >= LIN_LN:
+        rows = d["a"].view(M, K // 32, 32)
+        s1 = rows.sum(-1)
+        d["stats"] = torch.stack([s1, ((rows - (s1 / 32).unsqueeze(-1)) ** 2).sum(-1)], dim=-1).contiguous()
+        d["gamma"], d["beta"] = torch.rand(K, device=device, generator=gl) + 0.5, torch.randn(K, device=device, generator=gl) * 0.1
+    return d
+
+
+def run_linear(ops, d, M, N, K, e, sb, frozen=True):
+    """One Linear launch of the step's list on the kernel variant the step used: plain / GELU / multiply epilogues (upp_linear_sb_f32 or
+    upp_linear_f32), the residual + statistics epilogue (code 6), the LayerNorm prologue (16 + epilogue)."""
+    if e == LIN_RESID:
+        return ops.linear_sb_resid(d["a"], ops.PLANES.get(d["w"]), (N, K), d["b"], d["x"], None, 1.0, 75)
+    if e >= LIN_LN:
+        return ops.linear_sb_ln(d["a"], d["stats"], d["gamma"], d["beta"], 1e-5, ops.PLANES.get(d["w"]), (N, K), d["b"], e - LIN_LN)
+    return ops.linear_f32(d["a"], d["w"], d["b"] if e in (1, 2, 3, 5) else None, e, aux=d["x"] if e == ops.LIN_MUL else None, out=d["o"],
+                          frozen=bool(sb) and frozen)
 
 
 def pmc_linear_entry(raw, label, kname):
@@ -456,23 +498,24 @@ def stage_report(device, B):
     # beside it, on the exact-f32 kernel (csrc/linear.hip)
     gl = torch.Generator(device=device).manual_seed(11)
     missing = []
-    for label, M, N, K, epi in LINEAR_SHAPES:
-        a = torch.randn(M, K, device=device, generator=gl)
-        w = torch.randn(N, K, device=device, generator=gl) * K ** -0.5
-        w._upp_persistent = True
-        bias = torch.randn(N, device=device, generator=gl)
-        aux = torch.randn(M, N, device=device, generator=gl) if epi == ops.LIN_MUL else None
-        res = torch.empty(M, N, device=device)
+    for label, M, N, K, epi in LINEAR_SHAPES + FOLD_SHAPES:
+        d = make_linear_operands(ops, M, N, K, epi, device, gl)
         sb = ops.linear_sb_tile(M, N, K) if ops.SPLIT_BF16 else 0
-        t = time_kernel(lambda: ops.linear_f32(a, w, bias if epi in (1, 2, 3, 5) else None, epi, aux=aux, out=res, frozen=True))
-        t32 = time_kernel(lambda: ops.linear_f32(a, w, bias if epi in (1, 2, 3, 5) else None, epi, aux=aux, out=res))
-        kname = ("linear_sb_kernel<%s>" % _sb_tile_str(sb)) if sb else ("linear_f32_kernel<%s>" % _abi_tile(M, N, K))
+        if epi in (LIN_RESID,) or epi >= LIN_LN:
+            if not sb or (epi >= LIN_LN and not ops.linear_sb_ln_usable(M, N, K)):
+                continue
+        t = time_kernel(lambda: run_linear(ops, d, M, N, K, epi, sb))
+        t32 = time_kernel(lambda: run_linear(ops, d, M, N, K, epi, sb, frozen=False)) if epi < LIN_RESID else None
+        kname = _kname(M, N, K, epi, sb)
         out["linear_" + label] = mfma("%s %s: (%d,%d) x (%d,%d)^T, epilogue %d" % (kname, label, M, K, N, K, epi), t, 2.0 * M * N * K, split=bool(sb))
         e = out["linear_" + label]
-        e["ms_exact_f32_kernel"] = t32
+        if t32 is not None:
+            e["ms_exact_f32_kernel"] = t32
         e["algorithmic_bytes"] = linear_algorithmic_bytes(M, N, K, epi, bool(sb))
         e["traffic"] = pmc_linear_entry(pmc_raw, label, kname)
-        if e["traffic"] is None:
+        if e["traffic"] is None and epi >= LIN_RESID:
+            e["note"] = "fold variant (UPP_FUSE_RESID_LN=1), timed for the record; not launched by the default step, no counters taken"
+        elif e["traffic"] is None:
             missing.append("linear:%s (%s)" % (label, kname))
         else:
             e["traffic_over_algorithmic"] = e["traffic"] / e["algorithmic_bytes"]
@@ -516,29 +559,24 @@ def linear_family_replay(ts, device):
     groups = list(scope.wgrad_groups)           # the weight gradients: one grouped launch per entry (upp_linear_wgrad_grouped_f32)
     gl = torch.Generator(device=device).manual_seed(5)
 
-    def operands(M, N, K):
-        return [torch.randn(M, K, device=device, generator=gl), torch.randn(N, device=device, generator=gl),
-                torch.randn(M, N, device=device, generator=gl), torch.empty(M, N, device=device)]
-
     ring, seen, per_launch = {}, {}, []
     for M, N, K, e, sb in calls:
         w = torch.randn(N, K, device=device, generator=gl) * K ** -0.5
         w._upp_persistent = True                # (stands for a frozen weight: ops.PLANES keeps its plane image)
-        n_prev = seen.get((M, N, K), 0)
-        seen[(M, N, K)] = n_prev + 1
+        n_prev = seen.get((M, N, K, e), 0)
+        seen[(M, N, K, e)] = n_prev + 1
         if 4.0 * M * (K + 2 * N) > 64e6:
-            sets = ring.setdefault((M, N, K), [])
+            sets = ring.setdefault((M, N, K, e), [])
             if len(sets) < 4:
-                sets.append(operands(M, N, K))
-            act = sets[n_prev % 4]
+                sets.append(make_linear_operands(ops, M, N, K, e, device, gl, w=w))
+            d = dict(sets[n_prev % 4], w=w)
         else:
-            act = operands(M, N, K)
-        per_launch.append((w, act))
+            d = make_linear_operands(ops, M, N, K, e, device, gl, w=w)
+        per_launch.append(d)
 
     def launch(i):
         M, N, K, e, sb = calls[i]
-        w, (a, b, x, o) = per_launch[i]
-        ops.linear_f32(a, w, b if e in (1, 2, 3, 5) else None, e, aux=x if e == ops.LIN_MUL else None, out=o, frozen=bool(sb))
+        run_linear(ops, per_launch[i], M, N, K, e, sb)
 
     wbufs = {}
     for grp in groups:
@@ -586,8 +624,7 @@ def family_traffic(calls):
         if lab is None:
             uncovered.append([M, N, K, e])
             continue
-        kname = ("linear_sb_kernel<%s>" % _sb_tile_str(sb)) if sb else ("linear_f32_kernel<%s>" % _abi_tile(M, N, K))
-        t = pmc_linear_entry(raw, lab, kname)
+        t = pmc_linear_entry(raw, lab, _kname(M, N, K, e, sb))
         if t is None:
             return None
         total += t

@@ -199,13 +199,20 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
                 ln_mu = ga.ln_stats[2 * (long long)crow]; ln_rs = ga.ln_stats[2 * (long long)crow + 1];
             } else {
                 // (sum_i, M2_i) of the nb 32-column blocks of the row -> mean, M2 = sum M2_i + 32 sum (mean_i - mean)^2: no cancellation
+                // (all 16 loads issued before the first use: a loop over a run-time count waited for every load in turn -- 6 us per launch)
                 const float2 *p = reinterpret_cast<const float2 *>(ga.ln_stats) + (long long)crow * ga.ln_nb;
+                const int nb = ga.ln_nb;                         // <= 16 (K <= 512)
+                float2 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = p[min(i, nb - 1)];
                 float tot = 0.0f;
-                for (int i = 0; i < ga.ln_nb; ++i) tot += p[i].x;
-                const float n = 32.0f * (float)ga.ln_nb;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tot += i < nb ? v[i].x : 0.0f;
+                const float n = 32.0f * (float)nb;
                 ln_mu = tot / n;
                 float q = 0.0f;
-                for (int i = 0; i < ga.ln_nb; ++i) { const float d = p[i].x * 0.03125f - ln_mu; q += __builtin_fmaf(32.0f * d, d, p[i].y); }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const float d = v[i].x * 0.03125f - ln_mu; q += i < nb ? __builtin_fmaf(32.0f * d, d, v[i].y) : 0.0f; }
                 ln_rs = 1.0f / sqrtf(q / n + ga.ln_eps);
             }
             if (ga.ln_mean && bx == 0 && bnp == 0 && h == 0 && arow < M) { ga.ln_mean[arow] = ln_mu; ga.ln_rstd[arow] = ln_rs; }

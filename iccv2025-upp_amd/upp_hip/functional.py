@@ -840,7 +840,10 @@ def proj_resid_ln_usable(a, w, bias, xa, ln, fc1_weight):
             and ops.linear_sb_usable(M, D, w.shape[1]) and fc1_weight.shape[1] == D and ops.linear_sb_ln_usable(M, fc1_weight.shape[0], D))
 
 
-FUSE_RESID_LN = os.environ.get("UPP_FUSE_RESID_LN", "1") != "0"       # (0: the row kernel between the projection and the MLP, as rounds 2-4)
+# OFF by default: measured on MI355X (profiles/r05_fold_ab.txt) the fold LOSES -- fc1 with the LayerNorm prologue 26.3 us against 21.3 (its
+# k-loop is at the vector-issue limit: MFMA issue + the operand split; 24 more VALU per k-step and wave land on it), the projection with the
+# residual epilogue 8.8 against 8.0, for a 5.6 us row kernel + one launch boundary saved: 4.63-4.66 ms per step against 4.55-4.59.
+FUSE_RESID_LN = os.environ.get("UPP_FUSE_RESID_LN", "0") == "1"
 
 
 def proj_resid_ln(a, w, bias, xa, u, keep, ln):

@@ -830,7 +830,8 @@ def test_resid_ln_fold_equals_the_row_kernel_path_at_the_benched_batch(name, tra
     """Round 5: with frozen backbone weights (the PEFT recipes) the residual add of the attention branch rides in the projection GEMM's
     epilogue and norm2 in the A-prologue of fc1 (upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32; reference
     models/Point_MAE_pretask_dev.py:266,273) -- no row kernel between the two GEMMs.  At B = 32 (the tile that carries the prologue) the
-    block's output and every gradient equal the row-kernel path (UPP_FUSE_RESID_LN=0) to f32 rounding; the launch list shows the fold.
+    block's output and every gradient equal the row-kernel path to f32 rounding; the launch list shows the fold.  (The fold is an
+    OPTION, UPP_FUSE_RESID_LN=1: measured slower than the row kernel -- profiles/r05_fold_ab.txt -- and off by default.)
     (Eval mode: the stochastic-depth factor of the epilogue is covered draw by draw in tests/test_gpu_linear_sb.py.)"""
     from upp_hip import ops
     from upp_hip.train import freeze_for_peft, PEFT_STAGE1
@@ -841,6 +842,7 @@ def test_resid_ln_fold_equals_the_row_kernel_path_at_the_benched_batch(name, tra
     assert blk.fusable(x)
     params = [p for p in blk.parameters() if p.requires_grad]
     outs, kinds = [], []
+    was = HF.FUSE_RESID_LN
     for fold in (True, False):
         HF.FUSE_RESID_LN = fold
         try:
@@ -856,7 +858,10 @@ def test_resid_ln_fold_equals_the_row_kernel_path_at_the_benched_batch(name, tra
             outs.append((out.detach(), grads))
         finally:
             HF.FUSE_RESID_LN = True
-    assert 6 in kinds[0] and any(e >= 16 for e in kinds[0]), kinds[0]          # the resid-epilogue GEMM and the LayerNorm-prologue GEMM ran
+    if ops.linear_sb_ln_usable(x.shape[0] * (x.shape[1] + (10 if name.startswith("down") and blk.downstream_prompts is not None else 0)), 1536, 384):
+        assert 6 in kinds[0] and any(e >= 16 for e in kinds[0]), kinds[0]      # the resid-epilogue GEMM and the LayerNorm-prologue GEMM ran
+    else:
+        assert name == "decoder" and 6 not in kinds[0]                         # (2,048 rows: fc1's tile there carries no A-operand prologue)
     assert 6 not in kinds[1] and not any(e >= 16 for e in kinds[1]), kinds[1]
     close(outs[0][0], outs[1][0], rtol=1e-5, atol_scale=2e-6)
     for g, r in zip(outs[0][1], outs[1][1]):

@@ -184,7 +184,7 @@ def test_committed_pmc_counters_were_taken_on_the_kernels_this_build_launches():
     raw = bench._pmc_raw()
     stale, missing = [], []
     for label, M, N, K, epi in bench.STEP_LINEAR_SHAPES:
-        kname = bench.sb_kernel_name(M, N, K)
+        kname = bench.sb_kernel_name(M, N, K, epi)
         assert kname.startswith("linear_sb_kernel<") and kname.count(",") == 5, kname      # six template arguments, as rocprofv3 prints them
         if "linear:" + label not in raw:
             missing.append(label)

@@ -81,24 +81,18 @@ for _ in range(5):
 # dispatch behind the i-th marker the label LINEAR_ORDER[i % len] -- whatever else of the same kernel name ran before (round 3 counted
 # dispatches modulo 8 and was rotated by five un-labelled launches of the patch embedding).
 sys.path.insert(0, ROOT)
-from bench import LINEAR_SHAPES, STEP_LINEAR_SHAPES  # noqa: E402
+from bench import LINEAR_SHAPES, STEP_LINEAR_SHAPES, make_linear_operands, run_linear  # noqa: E402
 gl = torch.Generator(device='cuda').manual_seed(11)
-lin = []
-for label, M, N, K, epi in STEP_LINEAR_SHAPES:
-    a_ = torch.randn(M, K, device='cuda', generator=gl)
-    w_ = torch.randn(N, K, device='cuda', generator=gl) * K ** -0.5
-    w_._upp_persistent = True
-    b_ = torch.randn(N, device='cuda', generator=gl)
-    x_ = torch.randn(M, N, device='cuda', generator=gl) if epi == ops.LIN_MUL else None
-    lin.append((a_, w_, b_ if epi in (1, 2, 3) else None, epi, x_))
+lin = [(make_linear_operands(ops, M, N, K, epi, torch.device('cuda'), gl), M, N, K, epi, ops.linear_sb_tile(M, N, K)) for _, M, N, K, epi in STEP_LINEAR_SHAPES]
 marker = torch.zeros(8, 8, device='cuda')
-for a_, w_, b_, epi, x_ in lin:            # (plane images made before the labelled section: the split kernel of upp_linear_sb_prep is not a marker)
-    ops.linear_f32(a_, w_, b_, epi, aux=x_, frozen=True)
+for d_, M, N, K, epi, sb in lin:           # (plane images made before the labelled section: the split kernel of upp_linear_sb_prep is not a marker)
+    run_linear(ops, d_, M, N, K, epi, sb)
+plain = [(d_, M, N, K, epi, sb) for (d_, M, N, K, epi, sb), (lab, *_r) in zip(lin, STEP_LINEAR_SHAPES) if (lab, M, N, K, epi) in LINEAR_SHAPES]
 for _ in range(6):
-    for frozen, part in ((True, lin), (False, lin[:len(LINEAR_SHAPES)])):        # == pmc_summary.LINEAR_ORDER
-        for a_, w_, b_, epi, x_ in part:
+    for frozen, part in ((True, lin), (False, plain)):        # == pmc_summary.LINEAR_ORDER
+        for d_, M, N, K, epi, sb in part:
             ops.transpose(marker)
-            ops.linear_f32(a_, w_, b_, epi, aux=x_, frozen=frozen)
+            run_linear(ops, d_, M, N, K, epi, sb, frozen=frozen)
 # round 3: the tall-matrix kernel and the grouped weight gradient at the segmentation head's largest layer (65,536 x 1536 -> 1024), the
 # grouped weight gradients of one pre-training block, the denoising prompter's tail
 xt = torch.randn(65536, 1536, device='cuda', generator=gl)
