@@ -232,6 +232,8 @@ def max_over(x, dim, site=''):
     kernels) compute their own arg-max."""
     t = POOL_TRACE
     if t is None:
+        if x.is_cuda and dim % x.dim() == x.dim() - 2:
+            return HF.group_max(x)          # (max + arg-max kernel, one-pass backward; torch: reduce, then zero-fill + scatter)
         return x.max(dim=dim)[0]
     key = (site, tuple(x.shape), dim)
     if t['mode'] == 'record':

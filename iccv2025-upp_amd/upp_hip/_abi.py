@@ -84,6 +84,8 @@ SIGNATURES = {
     "upp_adamw_scratch_floats": (ctypes.c_longlong, []),
     "upp_colsum_partials": (_c_i, [_c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "upp_copy_batched": (_c_i, [ctypes.POINTER(ctypes.c_void_p)] * 2 + [ctypes.POINTER(ctypes.c_longlong), _c_i, _c_f]),
+    "upp_group_max_fwd": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f]),
+    "upp_group_max_bwd": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "upp_argsort_rows": (_c_i, [_c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "upp_rectify_select": (_c_i, [_c_f] * 6 + [ctypes.c_float, ctypes.c_float, _c_f, ctypes.c_float, _c_i, _c_i, _c_i] + [_c_f] * 6),
     "upp_wcolsum_partials": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f]),

@@ -864,7 +864,69 @@ __global__ __launch_bounds__(256) void interp_geo_src_kernel(const int64_t *__re
     if (lane == 0) { g_xyz2[(size_t)bs * 3] = ax; g_xyz2[(size_t)bs * 3 + 1] = ay; g_xyz2[(size_t)bs * 3 + 2] = az; }
 }
 
+// ---- max-pool over the k rows of every group, with its arg-max; the backward writes the whole gradient in one pass -----------------
+// x (R, k, C): out[r][c] = max_j x[r][j][c], amax[r][c] = the FIRST j that attains it (k <= 255).  One thread per (r, four columns).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void group_max_fwd_kernel(const float *__restrict__ x, int R, int k, int C, float *__restrict__ out,
+                                                            unsigned char *__restrict__ amax) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int C4 = C >> 2;
+    if (t >= (long long)R * C4) return;
+    const long long r = t / C4;
+    const int c = (int)(t - r * C4) * 4;
+    const float *p = x + (r * k) * C + c;
+    f32x4 best = *reinterpret_cast<const f32x4 *>(p);
+    int bi[4] = {0, 0, 0, 0};
+    for (int j0 = 1; j0 < k; j0 += 8) {                       // eight independent row loads in flight
+        f32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4 *>(p + (long long)min(j0 + q, k - 1) * C);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (j0 + q < k) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (v[q][e] > best[e]) { best[e] = v[q][e]; bi[e] = j0 + q; }
+            }
+    }
+    *reinterpret_cast<f32x4 *>(out + r * C + c) = best;
+    *reinterpret_cast<uchar4 *>(amax + r * C + c) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+}
+
+// g_x[r][j][c] = amax[r][c] == j ? g[r][c] : 0 -- every element of g_x written once (no zero-fill launch, no scatter)
+__global__ __launch_bounds__(256) void group_max_bwd_kernel(const float *__restrict__ g, const unsigned char *__restrict__ amax, int R, int k, int C,
+                                                            float *__restrict__ g_x) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int C4 = C >> 2;
+    if (t >= (long long)R * k * C4) return;
+    const long long rj = t / C4;
+    const int c = (int)(t - rj * C4) * 4;
+    const long long r = rj / k;
+    const int j = (int)(rj - r * k);
+    const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + r * C + c);
+    const uchar4 a = *reinterpret_cast<const uchar4 *>(amax + r * C + c);
+    f32x4 o;
+    o[0] = a.x == j ? gv[0] : 0.0f; o[1] = a.y == j ? gv[1] : 0.0f; o[2] = a.z == j ? gv[2] : 0.0f; o[3] = a.w == j ? gv[3] : 0.0f;
+    *reinterpret_cast<f32x4 *>(g_x + rj * C + c) = o;
+}
+
 }  // namespace
+
+extern "C" int upp_group_max_fwd(const float *x, int R, int k, int C, float *out, unsigned char *amax, void *stream) {
+    if (!x || !out || !amax || R < 1 || k < 1 || C < 1) return UPP_E_BADARG;
+    if (k > 255 || C % 4 != 0 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) || (reinterpret_cast<uintptr_t>(amax) & 3)) return UPP_E_RANGE;
+    const long long n = (long long)R * (C / 4);
+    hipLaunchKernelGGL(group_max_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, R, k, C, out, amax);
+    return upp_launch_status();
+}
+
+extern "C" int upp_group_max_bwd(const float *g, const unsigned char *amax, int R, int k, int C, float *g_x, void *stream) {
+    if (!g || !amax || !g_x || R < 1 || k < 1 || C < 1) return UPP_E_BADARG;
+    if (k > 255 || C % 4 != 0 || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(g_x)) & 15) || (reinterpret_cast<uintptr_t>(amax) & 3)) return UPP_E_RANGE;
+    const long long n = (long long)R * k * (C / 4);
+    if ((n + 255) / 256 > 0x7fffffffLL) return UPP_E_RANGE;
+    hipLaunchKernelGGL(group_max_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, amax, R, k, C, g_x);
+    return upp_launch_status();
+}
 
 // shared with prop.hip: finalize of (sum, M2) slab partials
 int upp_bn_finalize_launch(const float *part, int slabs, int per, int rows, int C, int training, float momentum, float eps,

@@ -1072,6 +1072,35 @@ def bn_rows_train(x, bn, relu=False):
     return _BnRowsTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
 
 
+class _GroupMax(Function):
+    """max over the k rows of every group (upp_group_max_fwd) with the one-pass backward (upp_group_max_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        out, amax = ops.group_max_fwd(x)
+        ctx.save_for_backward(amax)
+        ctx.k = x.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (amax,) = ctx.saved_tensors
+        return ops.group_max_bwd(g.contiguous(), amax, ctx.k)
+
+
+def group_max(x):
+    """x (..., k, C) -> (..., C): max over the second-to-last dimension.  f32 HIP tensors with C % 4 == 0, k <= 255 and contiguous rows take
+    the kernel pair (forward: max + arg-max in one read; backward: the gradient tensor written once, no zero-fill + scatter); anything else
+    `x.max(dim=-2)[0]`."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.is_contiguous() and x.shape[-1] % 4 == 0 and 1 <= x.shape[-2] <= 255
+            and x.numel() > 0 and x.data_ptr() % 16 == 0):
+        lead = tuple(x.shape[:-2])
+        x3 = x.reshape(-1, x.shape[-2], x.shape[-1])
+        out = _GroupMax.apply(x3) if (torch.is_grad_enabled() and x.requires_grad) else ops.group_max_fwd(x3)[0]
+        return out.view(lead + (x.shape[-1],))
+    return x.max(dim=-2)[0]
+
+
 def argsort_rows(key, descending=False, stable=True):
     """torch.argsort(key, dim=-1, descending=..., stable=True) of short rows (N <= 16384) on the rank-counting kernel (upp_argsort_rows)
     for f32 HIP tensors; anything else (CPU tensors on a GPU-less host, other dtypes, long rows) takes torch.argsort.  Integer / bool

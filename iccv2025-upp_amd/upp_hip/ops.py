@@ -560,6 +560,25 @@ def rectify_select(feature, w0, b0, w1, b1, pts, keep, u=None, p=0.0, factor=1.0
     return res if len(res) > 1 else out
 
 
+def group_max_fwd(x):
+    """x (R,k,C) f32 contiguous -> (max over k (R,C), arg-max (R,C) uint8)  (upp_group_max_fwd)."""
+    _need(x, "x", torch.float32, ndim=3)
+    R, k, C = x.shape
+    out = torch.empty((R, C), dtype=torch.float32, device=x.device)
+    amax = torch.empty((R, C), dtype=torch.uint8, device=x.device)
+    _call(x.device, "upp_group_max_fwd", _abi.ptr(x), R, k, C, _abi.ptr(out), _abi.ptr(amax))
+    return out, amax
+
+
+def group_max_bwd(g, amax, k):
+    """g (R,C), amax (R,C) uint8 -> g_x (R,k,C): g at the arg-max row of every (group, column), zero elsewhere (upp_group_max_bwd)."""
+    _need(g, "g", torch.float32, ndim=2)
+    R, C = g.shape
+    g_x = torch.empty((R, int(k), C), dtype=torch.float32, device=g.device)
+    _call(g.device, "upp_group_max_bwd", _abi.ptr(g), _abi.ptr(amax), R, int(k), C, _abi.ptr(g_x))
+    return g_x
+
+
 def argsort_rows(key, descending=False):
     """Stable argsort of every row of `key` (..., N) f32 -> int64 indices of the same shape (upp_argsort_rows: rank counting, no library
     sort; NaN ranks as +inf, equal keys in index order)."""

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UPP_ABI_VERSION 4   /* 4: + upp_argsort_rows, upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32 / upp_linear_sb_ln_usable (additions only).  3: split-bf16 Linear (upp_linear_sb_*); the k-parts protocol (upp_linear_parts*, upp_*_parts), the attention
+#define UPP_ABI_VERSION 4   /* 4: + upp_argsort_rows, upp_group_max_fwd / _bwd, upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32 / upp_linear_sb_ln_usable (additions only).  3: split-bf16 Linear (upp_linear_sb_*); the k-parts protocol (upp_linear_parts*, upp_*_parts), the attention
                                `variant` entry points (upp_attn_*_ex) and the VALU / 32x32x2 attention kernels behind them are gone.
                                2: grouped weight gradients, register-tiled Linear codes; the round-1 *_set_* toggles are gone */
 
@@ -466,6 +466,15 @@ int upp_rectify_select(const float *feature, const float *W0, const float *b0, c
  * orders of Point-MAE pre-training (models/Point_MAE.py:300-329: argsort of uniform draws / of distances to a random centre, and the
  * visible-first order argsort(mask)).  Limits: N <= 16384 (the row lives in the LDS). */
 int upp_argsort_rows(const float *key, int B, int N, int descending, int64_t *order, void *stream);
+
+/* Max-pool over the k rows of every group with its arg-max, and the backward that writes the whole gradient in one pass (replaces
+ * `x.max(dim)[0]` under autograd at the max-pool sites whose input carries a gradient -- reference models/Point_MAE_unify.py:205,221 (the
+ * patch embedding when it trains: pre-training, stage 2), models/Point_MAE_pretask_dev.py:413 (set abstraction), :294 (`pooling`) -- where
+ * torch launches a reduce forward and a zero-fill + scatter backward):
+ *   x (R, k, C) -> out (R, C) = max_j x[r][j][c], amax (R, C) uint8 = the first j that attains it;  g_x (R, k, C) = g[r][c] at j = amax[r][c],
+ *   0 elsewhere.  k <= 255, C % 4 == 0, x / out / g / g_x 16-byte and amax 4-byte aligned. */
+int upp_group_max_fwd(const float *x, int R, int k, int C, float *out, unsigned char *amax, void *stream);
+int upp_group_max_bwd(const float *g, const unsigned char *amax, int R, int k, int C, float *g_x, void *stream);
 
 /* ---- token-matrix Linear (exact f32 on the matrix cores) -------------------------------------
  * Replaces the nn.Linear layers of the Transformer blocks and their data gradients: Attention.qkv / .proj

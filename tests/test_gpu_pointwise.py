@@ -442,3 +442,25 @@ def test_gather_rows_forward_and_sort_free_backward():
     assert torch.equal(gg, gg2)
     with torch.no_grad():
         assert torch.equal(HF.gather_rows(pts, idx), want)
+
+
+@pytest.mark.parametrize("shape", [(2048, 32, 384), (1024, 16, 256), (32, 32, 16, 12), (7, 1, 8), (3, 255, 4)])
+def test_group_max_equals_torch_max_with_its_gradient(shape):
+    """HF.group_max (upp_group_max_fwd / _bwd): the max-pool sites under autograd (reference models/Point_MAE_unify.py:205,221 patch
+    embedding, models/Point_MAE_pretask_dev.py:413 set abstraction, :294 pooling) -- values bit-equal to torch.max over the group
+    dimension, gradient equal to torch's scatter on tie-free data, the first maximal row on ties."""
+    from upp_hip import functional as HF
+    g = torch.Generator(device='cuda').manual_seed(sum(shape))
+    x = torch.randn(*shape, device='cuda', generator=g).requires_grad_(True)
+    got = HF.group_max(x)
+    want = x.max(dim=-2)[0]
+    assert torch.equal(got, want)
+    w = torch.randn_like(want)
+    (gg,) = torch.autograd.grad((got * w).sum(), x)
+    (gw,) = torch.autograd.grad((want * w).sum(), x)
+    assert torch.equal(gg, gw)
+    with torch.no_grad():
+        assert torch.equal(HF.group_max(x), want)
+    t = torch.zeros(2, 5, 8, device='cuda', requires_grad=True)          # all ties: the first row of the group takes the gradient
+    (gt,) = torch.autograd.grad(HF.group_max(t).sum(), t)
+    assert float(gt[:, 0].sum()) == 16.0 and float(gt[:, 1:].abs().sum()) == 0.0
