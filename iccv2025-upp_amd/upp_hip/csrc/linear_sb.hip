@@ -38,6 +38,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef UPP_SB_XCD2D_DEFAULT
+#define UPP_SB_XCD2D_DEFAULT 2
+#endif
 constexpr int SB_CHUNK = 6144;          // bytes of one (32-row block, 32-wide k-stage) of the planes: 3 planes x 4 granules x 32 rows x 16 B
 
 struct SbArgs {
@@ -60,6 +63,7 @@ struct SbArgs {
     float *row_stats;
     const float *ln_stats; int ln_nb; float ln_eps;
     float *ln_mean, *ln_rstd;
+    int xcd_gc;                         // > 1: 2-D XCD map with gc column groups (launch_sb decides; the grid is then 8 equal regions)
 };
 constexpr int LEPI_RESID = 6;           // (this file only: linear_shared.h's epilogues end at LEPI_BIAS_RELU = 5)
 
@@ -117,10 +121,23 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
-    const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    const int by = lin / g.tiles_n, bx = lin - by * g.tiles_n;
-    const int m0 = by * BM, n0 = bx * BN;
     const int M = g.M, N = g.N;
+    int by, bx;
+    if (ga.xcd_gc > 1) {
+        // 2-D XCD map (wide outputs): the 8 XCDs form a (8 / gc) x gc grid of tile regions, so an XCD's L2 holds 1 / gc of W and gc / 8 of A
+        // instead of all of W and 1 / 8 of A (row-major ranges).  Block b runs on XCD b % 8 (observed dispatch; for speed only): it takes
+        // tile b / 8 of that XCD's region; the grid is padded to 8 equal regions and the surplus workgroups leave at once.
+        const int tiles_m = (M + BM - 1) / BM, gc = ga.xcd_gc, gr = 8 / gc;
+        const int x = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+        const int rows_per = (tiles_m + gr - 1) / gr, cols_per = g.tiles_n / gc;
+        const int ri = i / cols_per, ci = i - ri * cols_per;
+        by = (x / gc) * rows_per + ri; bx = (x % gc) * cols_per + ci;
+        if (ri >= rows_per || by >= tiles_m) return;
+    } else {
+        const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+        by = lin / g.tiles_n; bx = lin - by * g.tiles_n;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int nsc = g.K / (32 * KS);                                 // k-stages per wave group (K % (32 KS) == 0: checked by the host)
     const int ks = wave / WPG, wb = wave - ks * WPG;
     const int bm = wb / (BNB / RN), bnp = wb - bm * (BNB / RN);
@@ -554,12 +571,26 @@ int pick_sb(int M, int N, int K) {
     return best;
 }
 
+// UPP_SB_XCD2D=<gc> (read once; 0 / unset: row-major XCD ranges): column groups of the 2-D XCD map for one-round launches of wide outputs
+inline int sb_xcd_cols() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("UPP_SB_XCD2D"); v = e ? atoi(e) : UPP_SB_XCD2D_DEFAULT; if (v != 2 && v != 4) v = 0; }
+    return v;
+}
+
 template <int BMB, int BNB, int RN, int KS, int NST>
 int launch_sb(const SbArgs &g0, hipStream_t st) {
     SbArgs g = g0;
     const int tiles_m = (g.l.M + BMB * 32 - 1) / (BMB * 32);
     g.l.tiles_n = (g.l.N + BNB * 32 - 1) / (BNB * 32);
-    hipLaunchKernelGGL((linear_sb_kernel<BMB, BNB, RN, KS, NST>), dim3((unsigned)(tiles_m * g.l.tiles_n)), dim3(BMB * (BNB / RN) * KS * 64), 0, st, g);
+    unsigned grid = (unsigned)(tiles_m * g.l.tiles_n);
+    g.xcd_gc = 0;
+    const int gc = sb_xcd_cols();
+    if (gc > 1 && g.l.tiles_n % gc == 0 && g.l.tiles_n >= 4 * gc && tiles_m >= 8 / gc && tiles_m * g.l.tiles_n <= 256) {
+        const int gr = 8 / gc, rows_per = (tiles_m + gr - 1) / gr, cols_per = g.l.tiles_n / gc;
+        if (8 * rows_per * cols_per <= 256) { g.xcd_gc = gc; grid = (unsigned)(8 * rows_per * cols_per); }
+    }
+    hipLaunchKernelGGL((linear_sb_kernel<BMB, BNB, RN, KS, NST>), dim3(grid), dim3(BMB * (BNB / RN) * KS * 64), 0, st, g);
     return upp_launch_status();
 }
 
