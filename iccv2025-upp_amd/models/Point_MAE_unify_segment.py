@@ -48,7 +48,8 @@ class Point_MAE_unify_seg(PromptedBackbone):
         for conv, bn, act in ((c1, b1, a1), (c2, b2, a2)):
             if self.training and bn.track_running_stats:
                 L.bump_counter(bn.num_batches_tracked)
-            x = act(_bn_rows(HF.linear(x, conv.weight.squeeze(-1), conv.bias, own_wgrad=True), bn, self.training))
+            z = _bn_rows(HF.linear(x, conv.weight.squeeze(-1), conv.bias, own_wgrad=True), bn, self.training)
+            x = L.gate('label_conv', z, act.negative_slope) if (L.POOL_TRACE is not None and isinstance(act, nn.LeakyReLU)) else act(z)
         return x
 
     def _head(self, point_feat, global_feat):
@@ -103,7 +104,7 @@ class Point_MAE_unify_seg(PromptedBackbone):
         feats = self.blocks(tokens, pos, path='downstream', downstream_adapter=pc.downstream_adapter,
                             downstream_prompts=pc.downstream_prompts, classification=False, feature_list=True, **propagation)
         x = torch.cat(feats, dim=-1)                                                  # (B,G,1152)
-        global_feat = torch.cat((torch.max(x, 1)[0], torch.mean(x, 1), self._label_feature(cls_label)), -1)   # (B,2432)
+        global_feat = torch.cat((L.max_over(x, 1, 'seg.global_max'), torch.mean(x, 1), self._label_feature(cls_label)), -1)   # (B,2432)
         target = label_points if label_points is not None else pts
         f0 = self.propagation_0(target, center, target, x)                            # (B,N,1024)
         return self._head(f0, global_feat)

@@ -247,6 +247,27 @@ def max_over(x, dim, site=''):
     return x.max(dim=dim)[0]
 
 
+def gate(site, z, slope=0.0):
+    """relu(z) -- leaky_relu(z, slope) for slope > 0 -- at the ReLU sites that are taken as plain torch ops while POOL_TRACE is set (the same
+    instrument as max_over / trace_idx: every fused kernel that applies a ReLU declines under POOL_TRACE).  'record': the mask z > 0 is
+    kept; 'replay': the RECORDED mask gates z, so that an f32 and an f64 evaluation of the segmentation step -- whose train-mode BatchNorm
+    puts thousands of pre-activations within 1e-7 of zero -- differ by rounding only, not by a redraw of the gates (round-4 verdict 6d)."""
+    t = POOL_TRACE
+    plain = lambda: F.leaky_relu(z, slope) if slope else F.relu(z)          # noqa: E731
+    if t is None:
+        return plain()
+    key = (site, tuple(z.shape), -2)
+    if t['mode'] == 'record':
+        t['items'].append((key, (z > 0).detach().cpu()))
+        return plain()
+    pos = t.setdefault('pos', 0)
+    if pos < len(t['items']) and t['items'][pos][0] == key:
+        t['pos'] = pos + 1
+        m = t['items'][pos][1].to(z.device)
+        return z * torch.where(m, torch.ones((), dtype=z.dtype, device=z.device), torch.full((), slope, dtype=z.dtype, device=z.device))
+    return plain()
+
+
 def trace_idx(site, idx):
     """The same instrument for the other discrete choices of a forward (FPS picks, neighbour lists, the rectify prompter's ranking): the
     index tensor is recorded, or REPLACED by the recorded one.  Callers recompute whatever they derive from the indices."""
@@ -410,6 +431,9 @@ class _SyncBNRows(torch.autograd.Function):
 def _bn_rows(x, bn, training, relu=False):
     """BatchNorm1d of a channels-last (rows, C) matrix: identical statistics to BatchNorm1d on
     the reference's (BG, C, n) layout (both reduce over every position of every group)."""
+    if POOL_TRACE is not None and relu and x.dim() == 2 and not sync_bn_active(training or bn.running_mean is None):
+        # test instrument: the BatchNorm on our kernels (or torch, on the host), the ReLU as a recorded / replayed gate
+        return gate('bn_rows.relu', _bn_rows(x, bn, training, relu=False))
     if x.dim() == 2 and sync_bn_active(training or bn.running_mean is None):
         # (the caller has bumped num_batches_tracked already -- bump_counter is immediate while this switch is on: momentum=None reads it)
         y = _SyncBNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.num_batches_tracked)
@@ -430,6 +454,13 @@ def mlp2(seq, x):
     if not (x.is_cuda and x.dtype == torch.float32 and len(seq) == 3 and isinstance(seq[1], nn.GELU) and seq[1].approximate == 'none'):
         return seq(x)
     return HF.linear(HF.linear(x, seq[0].weight, seq[0].bias, act='gelu'), seq[2].weight, seq[2].bias)
+
+
+def _relu_linear(x, lin):
+    """relu(lin(x)): the ReLU in the GEMM's epilogue; as a recorded / replayed gate while the test instrument is on."""
+    if POOL_TRACE is not None:
+        return gate('score_head.relu', HF.linear(x, lin.weight, lin.bias))
+    return HF.linear(x, lin.weight, lin.bias, act='relu')
 
 
 def _pointwise_bn_relu(x, conv, bn, training):
@@ -1043,7 +1074,7 @@ class RectifyPrompter(nn.Module):
     def forward(self, x, center1, center1_feature, require_shape_feature=False):
         feature, shape_feature = self.features(x, center1, center1_feature)
         l0, _, drop, l1 = self.score_head                                  # Linear(32, 64), ReLU, Dropout(0.2), Linear(64, 3): both on our kernels
-        noise_score = HF.linear(drop(HF.linear(feature, l0.weight, l0.bias, act='relu')), l1.weight, l1.bias) * self.score_factor
+        noise_score = HF.linear(drop(_relu_linear(feature, l0)), l1.weight, l1.bias) * self.score_factor
         return (noise_score, shape_feature) if require_shape_feature else noise_score
 
     def select(self, x, center1, center1_feature, keep, nudge=0.2):
@@ -1060,7 +1091,7 @@ class RectifyPrompter(nn.Module):
             u = UNIFORMS.take((x.shape[0] * x.shape[1], 64), x.device) if live else None
             return ops.rectify_select(feature.contiguous(), l0.weight, l0.bias, l1.weight, l1.bias, x.contiguous(), keep, u,
                                       drop.p if live else 0.0, self.score_factor, nudge)
-        pred = HF.linear(drop(HF.linear(feature, l0.weight, l0.bias, act='relu')), l1.weight, l1.bias) * self.score_factor
+        pred = HF.linear(drop(_relu_linear(feature, l0)), l1.weight, l1.bias) * self.score_factor
         order = trace_idx('rectify.order', HF.argsort_rows(torch.norm(pred, p=2, dim=-1), descending=True))
         moved = x + pred * nudge
         return torch.gather(moved, 1, order[:, -keep:, None].expand(-1, -1, 3))
