@@ -1,7 +1,8 @@
 #!/bin/bash
-# Regenerate profiles/r05_* on a GPU box (run from the repo root through gpurun), in two calls (each fits one gpurun limit):
+# Regenerate profiles/r05_* on a GPU box (run from the repo root through gpurun), in three calls (each fits one gpurun limit):
 #     gpurun --timeout 1200 -- 'bash tools/make_profiles.sh headline'
-#     gpurun --timeout 1200 -- 'bash tools/make_profiles.sh recipes'
+#     gpurun --timeout 1200 -- 'bash tools/make_profiles.sh recipes'      (bench lines + kernel summaries of the secondary recipes)
+#     gpurun --timeout 1200 -- 'bash tools/make_profiles.sh micro'       (stand-alone kernel timings, stamps, censuses)
 # rocprofv3 kernel traces of the headline step (one stream / pipelined), of the stand-alone kernels, two PMC passes
 # (FETCH_SIZE, WRITE_SIZE: separate runs, never combined with a trace domain), then the un-profiled bench lines.
 set -e -o pipefail
@@ -43,33 +44,25 @@ for w in pretrain seg stage2; do
   cp "$(stats $O/p_$w)" $O/r05_workload_${w}_kernel_stats.csv
   rm -rf $O/p_$w
 done
-python3 tools/micro/time_linear_tall.py --tuned 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_linear_tall.txt
-./tools/micro/bin/rt_bench 100 tall > $O/r05_rt_bench.txt 2>&1
-./tools/micro/bin/rt_bench 30 wgrad >> $O/r05_rt_bench.txt 2>&1
-python3 tools/glue_census_recipe.py seg 2> /dev/null | grep -v amdgpu.ids > $O/r05_glue_census_seg.txt
-python3 tools/glue_census_recipe.py stage2 2> /dev/null | grep -v amdgpu.ids > $O/r05_glue_census_stage2.txt
-python3 tools/micro/time_bn_rows.py 50 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_bn_rows.txt
-python3 tools/linear_calls.py seg 2> /dev/null | grep -v amdgpu.ids > $O/r05_linear_calls_seg.txt
+fi
+if [ "$PART" = "micro" ]; then
+set +e          # (a failing helper loses its own file, not the rest)
+python3 tools/glue_census.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_glue_census.txt
+for w in seg stage2 pretask; do python3 tools/glue_census_recipe.py $w 2> /dev/null | grep -v amdgpu.ids > $O/r05_glue_census_$w.txt; done
 python3 tools/linear_calls.py headline 2> /dev/null | grep -v amdgpu.ids > $O/r05_linear_calls_headline.txt
-python3 tools/time_linear.py --tiles --rows 2720,4128,4416,8832 --out $O/time_linear_rows.json > $O/r05_time_linear_rows.jsonl 2> /dev/null
-python3 tools/time_linear.py --tiles > $O/r05_time_linear.jsonl 2> /dev/null
-python3 tools/time_linear_sb.py --tiles --out $O/r05_time_linear_sb.jsonl > /dev/null 2>&1
+python3 tools/linear_calls.py seg 2> /dev/null | grep -v amdgpu.ids > $O/r05_linear_calls_seg.txt
 python3 tools/micro/sb_stamps.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_sb_stamps.txt
-python3 tools/micro/time_wgrad.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_wgrad.txt
-for w in pretrain seg; do echo "== $w" >> $O/r05_time_wgrad.txt; python3 tools/micro/wgrad_groups.py $w 2> /dev/null | grep -v amdgpu.ids >> $O/r05_time_wgrad.txt; done
-python3 tools/micro/time_tall_tiles.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_tall_tiles.txt
-python3 tools/time_patch_embed.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_patch_embed.txt
-UPP_EMBED_SPLIT_BF16=0 python3 tools/time_patch_embed.py 2> /dev/null | grep -v amdgpu.ids | sed 's/^/exact-f32 chain: /' >> $O/r05_time_patch_embed.txt
-python3 tools/fps_sweep.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_fps_sweep.txt
-# the packed-f32 anomaly beside a co-resident bf16-MFMA workgroup (canary kernels with their own inline asm; co-runner: upp_linear_sb_f32)
-mkdir -p tools/micro/bin
-hipcc --offload-arch=gfx950 -O2 tools/micro/src/lds_canary.cpp -o tools/micro/bin/lds_canary -Liccv2025-upp_amd/upp_hip/lib -lupp_hip -Wl,-rpath,$PWD/iccv2025-upp_amd/upp_hip/lib 2> /dev/null
-for a in "384 1536 0 0 2" "384 1536 0 0 0" "384 1536 0 0 1" "384 1536 0 0 3" "1536 384 0 0 1" "384 1536 0 29696 1"; do ./tools/micro/bin/lds_canary $a 2>&1 | grep -v "^VGPR op_sel" ; done > $O/r05_packed_f32_canary.txt
-python3 tools/micro/fps_corun_probe.py 0 1024 2> /dev/null | grep -v amdgpu.ids >> $O/r05_packed_f32_canary.txt
-python3 tools/_fmt_linear.py $O/r05_time_linear.jsonl > $O/r05_time_linear.txt
+python3 tools/time_linear_sb.py --tiles --out $O/r05_time_linear_sb.jsonl > /dev/null 2>&1
 python3 tools/time_attention.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_attention.txt
 python3 tools/micro/time_ln_adapter.py 2> /dev/null | grep -v amdgpu.ids >> $O/r05_time_attention.txt
-python3 tools/glue_census.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_glue_census.txt
-ls -la $O
+python3 tools/micro/time_attention_long.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_time_attention_long.txt
+python3 tools/fps_sweep.py 2> /dev/null | grep -v amdgpu.ids > $O/r05_fps_sweep.txt
+# determinism probes of round 4 (packed f32 beside a bf16-MFMA workgroup), their output kept under profiles/ since round 5: FPS beside a
+# co-running split-bf16 stream, and the pipelined segmentation step against its serialised self
+python3 tools/micro/fps_corun_probe.py 0 1024 2> /dev/null | grep -v amdgpu.ids > $O/r05_fps_corun_probe.txt
+python3 tools/micro/pipe_race_probe.py 6 2> /dev/null | grep -v amdgpu.ids > $O/r05_pipe_race_probe.txt
+mkdir -p tools/micro/bin
+hipcc --offload-arch=gfx950 -O2 tools/micro/src/lds_canary.cpp -o tools/micro/bin/lds_canary -Liccv2025-upp_amd/upp_hip/lib -lupp_hip -Wl,-rpath,$PWD/iccv2025-upp_amd/upp_hip/lib 2> /dev/null
+for a in "384 1536 0 0 2" "384 1536 0 0 0" "384 1536 0 0 1" "1536 384 0 0 1"; do ./tools/micro/bin/lds_canary $a 2>&1 | grep -v "^VGPR op_sel" ; done > $O/r05_packed_f32_canary.txt
 fi
 ls -la $O
