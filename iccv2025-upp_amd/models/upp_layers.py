@@ -893,8 +893,11 @@ class TransformerEncoder(nn.Module):
             pos = pos.detach()
             kwargs['_cls_pos'] = cls_pos
         features = []                       # outputs of blocks 3, 7, 11 for the segmentation head
+        # `pos` with a gradient (stage 2, pre-training: it comes out of a trainable / differentiated position MLP) is read by every block:
+        # hand each block its own alias so that the depth gradients are summed by ONE launch instead of depth - 1 (HF.fan_out)
+        pos_i = HF.fan_out(pos, depth)
         for idx, block in enumerate(self.blocks[:depth]):   # (reference models/Point_MAE_unify_segment.py:223-234)
-            x = block.forward_fused(x, pos, **kwargs) if block.fusable(x) else block(x + pos, **kwargs)
+            x = block.forward_fused(x, pos_i[idx], **kwargs) if block.fusable(x) else block(x + pos_i[idx], **kwargs)
             if kwargs.get('feature_list') and idx in (3, 7, 11):
                 features.append(x)
         return features if kwargs.get('feature_list') else x

@@ -1072,6 +1072,43 @@ def bn_rows_train(x, bn, relu=False):
     return _BnRowsTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
 
 
+class _FanOut(Function):
+    """n aliases of one tensor whose gradients come back TOGETHER: autograd sums the gradients of a tensor that n consumers read with
+    n - 1 element-wise launches (`pos` is added in front of every Transformer block: 11 launches of stage 2's backward); here the n
+    gradients are added in branch order by one upp_batched_sum launch (n jobs of one row sharing the destination)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        first = live[0]
+        if not (first.is_cuda and first.dtype == torch.float32 and all(g.shape == first.shape and g.dtype == first.dtype for g in live)):
+            total = live[0]
+            for g in live[1:]:
+                total = total + g
+            return total, None
+        out = torch.empty(first.shape, dtype=torch.float32, device=first.device)
+        n = out.numel()
+        ops.batched_sum([(g.contiguous().view(1, n), 0, 1, n, n, out, i > 0) for i, g in enumerate(live)])
+        return out, None
+
+
+def fan_out(x, n):
+    """-> n tensors equal to x (views of it); use one per consumer.  With a gradient flowing (HIP f32) the n gradients are summed in one
+    launch; otherwise x itself is handed out n times."""
+    if n > 1 and torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype == torch.float32 and n <= 64:
+        return _FanOut.apply(x, int(n))
+    return (x,) * n
+
+
 class _GroupMax(Function):
     """max over the k rows of every group (upp_group_max_fwd) with the one-pass backward (upp_group_max_bwd)."""
 

@@ -464,3 +464,23 @@ def test_group_max_equals_torch_max_with_its_gradient(shape):
     t = torch.zeros(2, 5, 8, device='cuda', requires_grad=True)          # all ties: the first row of the group takes the gradient
     (gt,) = torch.autograd.grad(HF.group_max(t).sum(), t)
     assert float(gt[:, 0].sum()) == 16.0 and float(gt[:, 1:].abs().sum()) == 0.0
+
+
+def test_fan_out_sums_the_branch_gradients_in_one_launch():
+    """HF.fan_out: n aliases of a tensor read by n consumers (`pos` in front of every Transformer block, reference
+    models/Point_MAE_unify.py:288-294); the n gradients come back summed in branch order -- equal to autograd's own accumulation up to
+    the order of additions, and ONE library launch."""
+    from upp_hip import functional as HF
+    g = torch.Generator(device='cuda').manual_seed(2)
+    x = torch.randn(32, 65, 384, device='cuda', generator=g, requires_grad=True)
+    ws = [torch.randn(32, 65, 384, device='cuda', generator=g) for _ in range(12)]
+    parts = HF.fan_out(x, 12)
+    assert len(parts) == 12 and all(torch.equal(p, x) for p in parts)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        (got,) = torch.autograd.grad(sum((p * w).sum() for p, w in zip(parts, ws)), x)
+        torch.cuda.synchronize()
+    want = torch.stack(ws).sum(0)
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-5)
+    names = [e.key for e in prof.key_averages()]
+    assert sum('batched_sum' in k for k in names) >= 1
+    assert HF.fan_out(x.detach(), 3)[0] is not None and len(HF.fan_out(x.detach(), 3)) == 3
