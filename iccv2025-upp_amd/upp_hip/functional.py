@@ -1097,7 +1097,7 @@ class _FanOut(Function):
             return total, None
         out = torch.empty(first.shape, dtype=torch.float32, device=first.device)
         n = out.numel()
-        ops.batched_sum([(g.contiguous().view(1, n), 0, 1, n, n, out, i > 0) for i, g in enumerate(live)])
+        ops.batched_sum([(g.contiguous().view(1, n), 0, 1, n, n, out, False) for g in live])       # (one group: dst = sum of its jobs, in order)
         return out, None
 
 
