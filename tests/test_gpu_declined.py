@@ -68,6 +68,7 @@ def test_segmentation_step_declines_nothing_and_launches_no_library_gemm():
     declined, gemms = _profile(step)
     assert declined == DOCUMENTED_DECLINES, declined
     assert not gemms, gemms
+    assert not _library_sorts(), _library_sorts()
 
 
 STAGE2_KEYS = ['downstream_adapter', 'downstream_adapter1', 'downstream_prompts', 'dense_pred', 'mask_token', 'rectify_prompter',
@@ -90,6 +91,7 @@ def test_stage2_step_declines_nothing_and_launches_no_library_gemm():
     declined, gemms = _profile(step)
     assert declined == DOCUMENTED_DECLINES, declined
     assert not gemms, gemms
+    assert not _library_sorts(), _library_sorts()
 
 
 # ---- the secondary recipes (round-4 verdict: the same assertions for pretask, pretrain and cls_aux, plus: no library sort) ------------
