@@ -76,6 +76,8 @@ SIGNATURES = {
     "upp_adapter_part_floats": (ctypes.c_longlong, [_c_i, _c_i]),
     "upp_adapter_fwd": (_c_i, [_c_f] * 7 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
     "upp_adapter_bwd": (_c_i, [_c_f] * 6 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
+    "upp_ln_adapter_fwd_next": (_c_i, [_c_f] * 4 + [ctypes.c_float, _c_i, _c_i, _c_f, _c_f, ctypes.c_float] + [_c_f] * 5 + [ctypes.c_float] * 2
+                                + [_c_f] * 5 + [_c_i] * 5 + [_c_f, _c_f, _c_i, _c_i, _c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_f] + [_c_f]),
     "upp_ln_adapter_fwd": (_c_i, [_c_f] * 4 + [ctypes.c_float, _c_i, _c_i, _c_f, _c_f, ctypes.c_float] + [_c_f] * 5 + [ctypes.c_float] * 2
                            + [_c_f] * 5 + [_c_i] * 5 + [_c_f]),
     "upp_ln_adapter_bwd": (_c_i, [_c_f] * 10 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),

@@ -204,13 +204,20 @@ class _RowLN(Function):
     One kernel forward, one backward (+ one for trainable LayerNorm parameters).  See upp_rowln_fwd."""
 
     @staticmethod
-    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps, cls_add=None, ybias=None):
+    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps, cls_add=None, ybias=None, pre=None):
         x = x.contiguous()
         B, Lin, D = x.shape
         Lout = Lin + P if mode in (ROW_INSERT_CLS, ROW_INSERT) else (Lin - P if mode in (ROW_STRIP_CLS, ROW_STRIP) else Lin)
-        add_c = add.contiguous() if add is not None else None
-        y_c = y.contiguous() if y is not None else None
-        xo, h, mean, rstd = ops.rowln_fwd(x, add_c, prompts, mode, P, y_c, u, keep, gamma, beta, eps, Lout, ybias=ybias)
+        if pre is not None:
+            # the rows, their LayerNorm and its statistics were computed by the launch that produced x (the previous block's tail:
+            # upp_ln_adapter_fwd_next) -- this node only carries the backward
+            xo, h, mean, rstd = pre
+            if tuple(xo.shape) != (B, Lout, D) or y is not None or gamma is None:
+                raise RuntimeError("rowln: precomputed head does not match this call")
+        else:
+            add_c = add.contiguous() if add is not None else None
+            y_c = y.contiguous() if y is not None else None
+            xo, h, mean, rstd = ops.rowln_fwd(x, add_c, prompts, mode, P, y_c, u, keep, gamma, beta, eps, Lout, ybias=ybias)
         ctx.save_for_backward(xo, mean, rstd, gamma, u)
         ctx.dims = (B, Lin, Lout, D, P, mode)
         ctx.keep = keep
@@ -230,7 +237,7 @@ class _RowLN(Function):
         g_xo = g_xo.contiguous() if g_xo is not None else None
         g_hc = g_h.contiguous() if (has_ln and g_h is not None) else None
         if g_xo is None and g_hc is None:
-            return (None,) * 13
+            return (None,) * 14
         strip = mode in (ROW_STRIP_CLS, ROW_STRIP) and P > 0
         need_cls = ctx.cls_shape is not None and len(need) > 11 and need[11]
         need_ln = has_ln and g_hc is not None and (need[4] or need[5])
@@ -252,11 +259,11 @@ class _RowLN(Function):
             if g_prompts is not None:
                 g_prompts = g_prompts.view(P, D)
         return (g_x if need[0] else None, g_x if (has_add and need[1]) else None, g_prompts, g_y,
-                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None, g_cls, None)
+                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None, g_cls, None, None)
 
 
 def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDENTITY, P=0, u=None, keep=1.0, eps=1e-5, cls_add=None,
-          ybias=None):
+          ybias=None, pre=None):
     """-> (rows (B,Lout,D), LayerNorm(rows) or None).  mode / P: see ROW_* and upp_rowln_fwd.
     ybias: optional (D) frozen bias added to y (the Linear that produced y then runs its GEMM bias-free).
     cls_add: optional (1,1,D) parameter that `add` (passed detached) carries in its row 0 for every sample; its gradient
@@ -265,7 +272,11 @@ def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDE
         raise ValueError("cls_add needs a detached `add` and a row map that keeps source row 0 in place")
     if ybias is not None and (y is None or (torch.is_grad_enabled() and ybias.requires_grad)):
         raise ValueError("ybias is the frozen bias of the Linear that produced y")
-    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps), cls_add, ybias)
+    if pre is not None and not (torch.is_grad_enabled() and (x.requires_grad or (add is not None and add.requires_grad)
+                                                            or (prompts is not None and prompts.requires_grad)
+                                                            or (gamma is not None and (gamma.requires_grad or beta.requires_grad)))):
+        return pre[0], pre[1]                       # nothing to differentiate: the precomputed head as it is
+    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps), cls_add, ybias, pre)
     return xo, (h if gamma is not None else None)
 
 
@@ -1415,20 +1426,25 @@ class _LnAdapter(Function):
     rows) followed by upp_rowln_bwd -- the two kernels of the unfused path, minus the stored LayerNorm output."""
 
     @staticmethod
-    def forward(ctx, x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, pd, scale):
+    def forward(ctx, x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, pd, scale, next_head=None):
         x = x.contiguous()
         B, Lin, D = x.shape
         Lout = Lin - P if mode in (ROW_STRIP_CLS, ROW_STRIP) else Lin
         y_c = y.contiguous() if y is not None else None
-        out, xo, mean, rstd, s1 = ops.ln_adapter_fwd(x, y_c, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, pd, scale, Lout)
+        res = ops.ln_adapter_fwd(x, y_c, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, pd, scale, Lout, next_head=next_head)
+        out, xo, mean, rstd, s1 = res[:5]
         ctx.save_for_backward(xo, mean, rstd, gamma, beta, u, s1, W1, W2, ud)
         ctx.dims = (B, Lin, Lout, D, P, mode)
         ctx.meta = (keep, pd, scale, y is not None)
         ctx.param_ptrs = (gamma.data_ptr(), beta.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr())
-        return out
+        if next_head is None:
+            return out
+        pre = res[5]
+        ctx.mark_non_differentiable(*pre)
+        return (out,) + tuple(pre)
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, *_unused):
         xo, mean, rstd, gamma, beta, u, s1, W1, W2, ud = ctx.saved_tensors
         B, Lin, Lout, D, P, mode = ctx.dims
         keep, pd, scale, has_y = ctx.meta
@@ -1458,16 +1474,29 @@ class _LnAdapter(Function):
             gW2 = gW2.view(D, H) if gW2 is not None else None
         return (g_x if need[0] else None, g_y, None, None, None, None, None, g_gamma if need[7] else None, g_beta if need[8] else None,
                 None, gW1 if need[10] else None, gb1 if need[11] else None, gW2 if need[12] else None, gb2 if need[13] else None,
-                None, None, None)
+                None, None, None, None)
 
 
-def ln_adapter(x, y, ybias, u, keep, mode, P, ln, W1, b1, W2, b2, ud=None, pd=0.0, scale=0.7):
+FUSE_NEXT_HEAD = os.environ.get("UPP_FUSE_NEXT_HEAD", "1") != "0"     # (0: every block computes its own head with upp_rowln_fwd, as rounds 2-4)
+
+
+def ln_adapter(x, y, ybias, u, keep, mode, P, ln, W1, b1, W2, b2, ud=None, pd=0.0, scale=0.7, next_head=None):
     """One launch for `rowln(x, y=y, ybias=ybias, u=u, keep=keep, mode=mode, P=P, gamma, beta)` + `adapter(ha, rows, ...)`
-    (mode: ROW_IDENTITY / ROW_STRIP_CLS / ROW_STRIP).  Limits: D == 384, 32 hidden units."""
+    (mode: ROW_IDENTITY / ROW_STRIP_CLS / ROW_STRIP).  Limits: D == 384, 32 hidden units.
+    next_head = (add, prompts, mode2, P2, norm): the head of the NEXT block -- rowln(out, add=add, prompts=prompts, mode=mode2, P=P2,
+    gamma / beta of norm) -- computed by the same launch from the rows while they are in the LDS (round 5); -> (out, pre) with
+    pre = (rows2, LayerNorm(rows2), mean2, rstd2) to be handed to that rowln call as `pre`."""
     if ybias is not None and (y is None or (torch.is_grad_enabled() and ybias.requires_grad)):
         raise ValueError("ybias is the frozen bias of the Linear that produced y")
-    return _LnAdapter.apply(x, y, ybias, u, float(keep), int(mode), int(P), ln.weight, ln.bias, float(ln.eps), W1, b1, W2, b2, ud,
-                            float(pd), float(scale))
+    if next_head is None:
+        return _LnAdapter.apply(x, y, ybias, u, float(keep), int(mode), int(P), ln.weight, ln.bias, float(ln.eps), W1, b1, W2, b2, ud,
+                                float(pd), float(scale))
+    add2, prm2, mode2, P2, n2 = next_head
+    spec = (add2.detach().contiguous() if add2 is not None else None, prm2.detach() if prm2 is not None else None, int(mode2), int(P2),
+            n2.weight.detach(), n2.bias.detach(), float(n2.eps))
+    res = _LnAdapter.apply(x, y, ybias, u, float(keep), int(mode), int(P), ln.weight, ln.bias, float(ln.eps), W1, b1, W2, b2, ud,
+                           float(pd), float(scale), spec)
+    return res[0], tuple(res[1:])
 
 
 def adapter(ha, x, W1, b1, W2, b2, u=None, p=0.0, scale=0.7):

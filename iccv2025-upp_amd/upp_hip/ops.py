@@ -1229,8 +1229,10 @@ def adapter_fwd(ha, x, W1, b1, W2, b2, u, p, scale):
     return out, s1
 
 
-def ln_adapter_fwd(x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, Lout):
-    """Residual + prompt strip + adapter LayerNorm + adapter in one launch -> (out, xo, mean, rstd, s1); upp_ln_adapter_fwd."""
+def ln_adapter_fwd(x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, Lout, next_head=None):
+    """Residual + prompt strip + adapter LayerNorm + adapter in one launch -> (out, xo, mean, rstd, s1); upp_ln_adapter_fwd.
+    next_head = (add (B,Lout,D) or None, prompts (P2,D) or None, mode2 (0 | 1 | 2), P2, gamma2, beta2, eps2): the same launch also computes
+    the next block's head (upp_ln_adapter_fwd_next) -> (..., (xo2, h2, mean2, rstd2))."""
     _need(x, "x", torch.float32, ndim=3)
     B, Lin, D = x.shape
     H = W1.shape[0]
@@ -1244,6 +1246,23 @@ def ln_adapter_fwd(x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, 
     mean = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     rstd = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     s1 = torch.empty((B * Lout, H), dtype=torch.float32, device=dev)
+    if next_head is not None:
+        add2, prm2, mode2, P2, g2, b2n, eps2 = next_head
+        L2 = Lout + (int(P2) if mode2 else 0)
+        if add2 is not None:
+            _need(add2, "next add", torch.float32)
+            if tuple(add2.shape) != (B, Lout, D) or not add2.is_contiguous():
+                raise RuntimeError("ln_adapter_fwd: the next block's `add` must be a contiguous (B, Lout, D) tensor")
+        xo2 = torch.empty((B, L2, D), dtype=torch.float32, device=dev)
+        h2 = torch.empty((B, L2, D), dtype=torch.float32, device=dev)
+        mean2 = torch.empty((B, L2), dtype=torch.float32, device=dev)
+        rstd2 = torch.empty((B, L2), dtype=torch.float32, device=dev)
+        _call(dev, "upp_ln_adapter_fwd_next", _abi.ptr(x), _abi.ptr(y), _abi.ptr(ybias), _abi.ptr(u), float(keep), int(mode), int(P), _abi.ptr(gamma),
+              _abi.ptr(beta), float(eps), _abi.ptr(W1), _abi.ptr(b1), _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(ud), float(p), float(scale),
+              _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(s1), _abi.ptr(out), B, Lin, Lout, D, H,
+              _abi.ptr(add2), _abi.ptr(prm2), int(mode2), int(P2), _abi.ptr(g2), _abi.ptr(b2n), float(eps2), _abi.ptr(xo2), _abi.ptr(h2),
+              _abi.ptr(mean2), _abi.ptr(rstd2))
+        return out, xo, mean, rstd, s1, (xo2, h2, mean2, rstd2)
     _call(dev, "upp_ln_adapter_fwd", _abi.ptr(x), _abi.ptr(y), _abi.ptr(ybias), _abi.ptr(u), float(keep), int(mode), int(P), _abi.ptr(gamma),
           _abi.ptr(beta), float(eps), _abi.ptr(W1), _abi.ptr(b1), _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(ud), float(p), float(scale),
           _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(s1), _abi.ptr(out), B, Lin, Lout, D, H)

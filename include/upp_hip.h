@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UPP_ABI_VERSION 4   /* 4: + upp_argsort_rows, upp_group_max_fwd / _bwd, upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32 / upp_linear_sb_ln_usable (additions only).  3: split-bf16 Linear (upp_linear_sb_*); the k-parts protocol (upp_linear_parts*, upp_*_parts), the attention
+#define UPP_ABI_VERSION 4   /* 4: + upp_argsort_rows, upp_group_max_fwd / _bwd, upp_ln_adapter_fwd_next, upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32 / upp_linear_sb_ln_usable (additions only).  3: split-bf16 Linear (upp_linear_sb_*); the k-parts protocol (upp_linear_parts*, upp_*_parts), the attention
                                `variant` entry points (upp_attn_*_ex) and the VALU / 32x32x2 attention kernels behind them are gone.
                                2: grouped weight gradients, register-tiled Linear codes; the round-1 *_set_* toggles are gone */
 
@@ -432,6 +432,17 @@ int upp_ln_adapter_fwd(const float *x, const float *y, const float *ybias, const
                        const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
                        const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
                        float *out, int B, int Lin, int Lout, int D, int H, void *stream);
+/* upp_ln_adapter_fwd_next (round 5): the same launch also computes the HEAD of the next block from the finished rows -- what
+ * upp_rowln_fwd(out, add = nx_add, prompts = nx_prompts, mode = nx_mode (0 identity | 1 insert nx_P prompts behind the cls row | 2 in
+ * front), gamma / beta = nx_gamma / nx_beta) would (reference models/Point_MAE_unify.py:288-294 `block(x + pos)`,
+ * models/Point_MAE_pretask_dev.py:247-266 prompt insertion + norm1): nx_xo, nx_h (B, Lnx, D), nx_mean / nx_rstd (B, Lnx), Lnx = Lout
+ * (+ nx_P).  Values identical to upp_rowln_fwd's (same expressions).  Lout >= nx_P (+ 1 for mode 1). */
+int upp_ln_adapter_fwd_next(const float *x, const float *y, const float *ybias, const float *u, float keep, int mode, int P,
+                            const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
+                            const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
+                            float *out, int B, int Lin, int Lout, int D, int H, const float *nx_add, const float *nx_prompts,
+                            int nx_mode, int nx_P, const float *nx_gamma, const float *nx_beta, float nx_eps, float *nx_xo,
+                            float *nx_h, float *nx_mean, float *nx_rstd, void *stream);
 /* upp_ln_adapter_bwd_fused: the whole backward of upp_ln_adapter_fwd in one launch on 16-row workgroups -- the adapter's backward
  * (g_ha, per-workgroup partials [dW1 (H,D) | dW2 (D,H) | db1 (H) | db2 (D)] in `part`, upp_ln_adapter_part_floats(R, D) floats, or
  * part = NULL), the LayerNorm backward with the residual (g_x / g_y (B, Lin, D): every row is written, zeros for the prompt rows

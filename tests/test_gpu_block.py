@@ -868,3 +868,49 @@ def test_resid_ln_fold_equals_the_row_kernel_path_at_the_benched_batch(name, tra
         assert (g is None) == (r is None)
         if g is not None:
             close(g, r, rtol=2e-5, atol_scale=5e-6)
+
+
+@pytest.mark.parametrize("path", ["downstream", "pretask_decoder"])
+def test_next_head_in_the_tail_launch_equals_a_head_launch_per_block(path):
+    """Round 5: a fused block's tail launch (upp_ln_adapter_fwd_next) also computes the head of the next block -- pos add, prompt insert,
+    norm1 (reference models/Point_MAE_unify.py:288-294, models/Point_MAE_pretask_dev.py:247-266) -- from the rows it still holds in the
+    LDS.  The block loop with the hand-over equals the loop in which every block launches its own head (UPP_FUSE_NEXT_HEAD=0): outputs
+    and every gradient BIT FOR BIT (the same expressions on the same values), and one rowln_fwd launch per block boundary fewer."""
+    from upp_hip.train import freeze_for_peft, PEFT_STAGE1
+    m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda().eval()
+    freeze_for_peft(m, PEFT_STAGE1)
+    B = 8
+    g = torch.Generator(device='cuda').manual_seed(4)
+    if path == "downstream":
+        blk, x, pos, kw = _block_case(m, "down0", B=B)
+        kw = {k: v for k, v in kw.items() if k != '_prop_cache'}
+        run = lambda xi, pi: m.blocks(xi, pi, **dict(kw))                                 # noqa: E731  (12 blocks: 6 with prompts, then 6 without)
+    else:
+        x = torch.randn(B, 64, 384, device='cuda', generator=g)
+        pos = torch.randn(B, 64, 384, device='cuda', generator=g)
+        run = lambda xi, pi: m.MAE_decoder(xi, pi, 32, pretask_adapter=True, path='pretask')   # noqa: E731
+    params = [p for p in m.parameters() if p.requires_grad]
+    outs, launches = [], []
+    was = HF.FUSE_NEXT_HEAD
+    try:
+        for on in (True, False):
+            HF.FUSE_NEXT_HEAD = on
+            xi, pi = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+            upp_layers.begin_forward(x.device, False)
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                out = run(xi, pi)
+                torch.cuda.synchronize()
+            upp_layers.end_forward()
+            launches.append(sum(e.count for e in prof.key_averages() if 'rowln_fwd_kernel' in e.key))
+            w = torch.linspace(-1, 1, out.numel(), device='cuda').view_as(out)
+            grads = torch.autograd.grad((out * w).sum(), [xi, pi] + params, allow_unused=True)
+            outs.append((out.detach(), grads))
+    finally:
+        HF.FUSE_NEXT_HEAD = was
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    nblk = 12 if path == "downstream" else 4
+    assert launches[1] - launches[0] == nblk - 1, launches
