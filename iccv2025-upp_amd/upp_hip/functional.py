@@ -1477,7 +1477,11 @@ class _LnAdapter(Function):
                 None, None, None, None)
 
 
-FUSE_NEXT_HEAD = os.environ.get("UPP_FUSE_NEXT_HEAD", "1") != "0"     # (0: every block computes its own head with upp_rowln_fwd, as rounds 2-4)
+# OFF by default: measured on MI355X the tail launch grows by what the head launch cost (tools/micro/time_ln_adapter.py: 9.75 -> 14.14 us against
+# 9.75 + 4.55 in two launches: the extra phase is one more latency chain on 150 eight-wave workgroups, where upp_rowln_fwd spreads the same
+# rows over 600) and the step gets SLOWER (4.71 against 4.57 ms pipelined, 6.62 against 6.50 on one stream: the separate row kernel fills the
+# gaps of the other stream's GEMMs, the longer tail does not).  UPP_FUSE_NEXT_HEAD=1 switches it on; bit-identical results either way.
+FUSE_NEXT_HEAD = os.environ.get("UPP_FUSE_NEXT_HEAD", "0") == "1"
 
 
 def ln_adapter(x, y, ybias, u, keep, mode, P, ln, W1, b1, W2, b2, ud=None, pd=0.0, scale=0.7, next_head=None):

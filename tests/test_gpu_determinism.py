@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import _seeded
-from models import build_model_from_cfg
+from models import build_model_from_cfg, upp_layers
 from utils.config import builtin_cfg
 from upp_hip.train import PipelinedTrainStep, freeze_for_peft, PEFT_STAGE1
 
@@ -25,6 +25,10 @@ def _run(make_pipe, feed, serial):
         os.environ.pop("UPP_PIPE_SERIAL", None)
     try:
         torch.manual_seed(1234)                      # (the drivers derive their front-end generator from the global seed)
+        # the per-forward uniform bank sizes itself from the previous forward: a run that starts with an empty bank draws its first
+        # forward's uniforms one by one, a later run in one launch -- other values from the same seed.  Every run starts from an empty bank.
+        bank = upp_layers.UNIFORMS
+        bank.buf, bank.pos, bank.asked, bank.need = None, 0, 0, 0
         pipe, model = make_pipe()
         pipe._capture()
         rec = []

@@ -146,6 +146,8 @@ def test_a_write_through_data_needs_refresh_caches_and_a_stale_image_is_refused_
     """ops._WeightPlanes CONTRACT: validity is keyed on torch's version counter.  `.data` writes bypass it (the image stays as it was --
     that is the documented blind spot), functional.refresh_caches() brings every derived copy up to date in place, and a stale image met
     while a stream is capturing raises instead of being baked into the graph (round-4 advisor)."""
+    if not ops.SPLIT_BF16:
+        pytest.skip("UPP_SPLIT_BF16=0: no plane images are made")
     lin = torch.nn.Linear(384, 384, bias=False).cuda().requires_grad_(False)
     x = torch.randn(2400, 384, device='cuda', requires_grad=True)
     y = HF.linear(x, lin.weight)
@@ -363,6 +365,8 @@ def test_resid_epilogue_and_layernorm_prologue_equal_the_row_kernel(M, L, with_u
     """upp_linear_sb_resid_f32 + upp_linear_sb_ln_f32 against upp_linear_sb_f32 + upp_rowln_fwd + upp_linear_sb_f32 (reference
     models/Point_MAE_pretask_dev.py:266,273): the residual rows bit for bit (same fma), the block statistics against float64, and the
     product behind the LayerNorm prologue to f32 rounding of the row statistics."""
+    if not ops.SPLIT_BF16:
+        pytest.skip("UPP_SPLIT_BF16=0: every Linear on the exact-f32 kernels")
     D, Hd = 384, 1536
     B = M // L
     g = torch.Generator(device='cuda').manual_seed(M + with_u)
