@@ -208,6 +208,8 @@ def test_non_finite_operands_stay_visible():
 
 
 def test_a_trainable_weight_stays_on_the_exact_f32_kernel():
+    if not ops.SPLIT_BF16:
+        pytest.skip("UPP_SPLIT_BF16=0: the split kernel is switched off")
     w = torch.randn(384, 384, device='cuda', requires_grad=True)
     x = torch.randn(2400, 384, device='cuda')
     with ops.time_linear_calls() as scope:
@@ -274,6 +276,8 @@ def test_group_bias_epilogue_equals_product_plus_broadcast():
 
 
 def test_trainable_weights_take_the_split_kernel_inside_a_step_driver_only():
+    if not ops.SPLIT_BF16:
+        pytest.skip("UPP_SPLIT_BF16=0: the split kernel is switched off")
     lin = torch.nn.Linear(384, 1536).cuda()
     x = torch.randn(2400, 384, device='cuda', requires_grad=True)
     with ops.time_linear_calls() as scope:
