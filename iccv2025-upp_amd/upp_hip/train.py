@@ -400,7 +400,9 @@ class PipelinedTrainStep(TrainStep):
         self.state = [[torch.zeros_like(t) for t in probe] for _ in range(2)]
         self.labels2 = [torch.zeros(B, dtype=torch.long, device=self.device) for _ in range(2)]
         self.extras2 = [[t.detach().clone().to(self.device) for t in (extras or [])] for _ in range(2)]
-        self.s_front = torch.cuda.Stream(device=self.device)      # (stream priorities change nothing here: measured 5.89-5.92 ms for -1 / 0)
+        # (stream priorities do not help: round 2 5.89-5.92 ms for -1 / 0; round 5: front-end stream at high priority 4.58 against 4.54-4.55 ms,
+        #  the whole driver on a high-priority stream of its own 4.83-4.84 against 4.63-4.64; the runtime offers no priority BELOW normal)
+        self.s_front = torch.cuda.Stream(device=self.device)
         from models import upp_layers as _L
         self._L = _L
         self._gen_front = torch.Generator(device=self.device)          # the front-end's own random stream (see upp_layers.use_rng)
