@@ -21,6 +21,7 @@ constexpr int kLW = 8;           // waves per workgroup (two per SIMD)
 constexpr int kBB = 32;          // backward: query rows per block (P and dS strips both in LDS)
 constexpr int kAccW = 6;         // backward: waves 0..5 own the dK / dV accumulator tiles, waves 6, 7 compute dQ
 constexpr int kAccS = 4;         // accumulator tiles per owner wave: ceil(4 * 5 / 6)
+constexpr int kVT = 4;           // MODE 2: at most this many rows behind row 128 (all of their work on the vector ALU)
 constexpr int kTR = 16;          // FOLD: rows of the tail strips (the queries behind row 128 of a 129 ... 144-token sequence)
 
 // rows [0, valid) x 64 of NARR sources (row stride rs floats) -> dst[a][R][kLD], rows >= valid zero; all loads first
@@ -77,9 +78,14 @@ __device__ __forceinline__ void stage_two(float *const (&dst)[2], const float *c
 // second, 16-row query strip (Qt / St) that rides along with the FIRST block in the slots its tile lists leave idle: S has 10 + 5 tiles
 // for 2 rounds of 8 waves, P V 4 + 2 tiles for one.  Rows >= 16 of the strips are never written; the 32-row operand reads of the tail
 // tiles run on into the arrays behind them (in bounds; such a row only feeds the output row of the same index, which is not stored).
-template <bool FOLD>
+// MODE 2 (1 ... kVT rows behind row 128: cls + 128 groups = 129 tokens): the tail never touches the matrix pipe.  With the strip on MFMA
+// the first block's S list is 8 + 4 tiles -- a second round for one query -- and a fifth key tile doubles every block's S rounds; on
+// the vector ALU the tail KEYS are `tail` dot products per query (one wave each, lane = query) and a rank-`tail` update of the P V
+// accumulators, the tail QUERIES 3 x tail jobs of 64 keys (lane = key) and one P V row per otherwise idle wave (lane = channel).
+template <int MODE>
 __global__ __launch_bounds__(64 * kLW) void attn_fwd_long_kernel(const float *__restrict__ qkv, float *__restrict__ ctx,
                                                                  float *__restrict__ lse, int L, int H, float scale) {
+    constexpr bool FOLD = MODE != 0, VT = MODE == 2;
     extern __shared__ float sm[];
     float *Ks = sm, *Vs = Ks + kKP * kLD, *Qb = Vs + kKP * kLD, *Qt = Qb + kQB * kLD, *St = Qt + (FOLD ? kTR * kLD : 0), *Ss = St + (FOLD ? kTR * kSS : 0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -93,8 +99,8 @@ __global__ __launch_bounds__(64 * kLW) void attn_fwd_long_kernel(const float *__
         const size_t strides[2] = {rs, rs};
         stage_block<kKP, 2>(dst, src, strides, L);
     }
-    const int nt = (L + 31) / 32;                       // key tiles
     const int Lmain = FOLD ? 2 * kQB : L, tail = FOLD ? L - 2 * kQB : 0;       // FOLD: 128 < L <= 128 + kTR (checked by the host)
+    const int nt = VT ? 4 : (L + 31) / 32;              // key tiles on the matrix pipe
     // row softmax of `rows` strip rows (the first `valid` of them are queries q_base + i), lane = key (3 slots cover the 160 columns),
     // four rows per wave and iteration
     auto softmax_rows = [&](float *strip, int rows, int valid, int q_base, int w) {
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(64 * kLW) void attn_fwd_long_kernel(const float *__
             stage_block<kQB, 1>(dst, src, strides, qv);
         }
         __syncthreads();
-        const int n_s = qt * nt + (with_tail ? nt : 0);
+        const int n_s = qt * nt + (with_tail && !VT ? nt : 0);
         for (int t = wave; t < n_s; t += kLW) {         // S = Q_b K^T (and S_tail = Q_tail K^T), scaled
             f32x16 acc; zero(acc);
             if (t < qt * nt) {
@@ -157,21 +163,68 @@ __global__ __launch_bounds__(64 * kLW) void attn_fwd_long_kernel(const float *__
                 for (int r = 0; r < 16; ++r) if (tile_row(r, lk) < kTR) St[tile_row(r, lk) * kSS + jt * 32 + lr] = acc[r] * scale;
             }
         }
+        if constexpr (VT) {
+            // jobs [0, tail): S column of tail key 128 + j for the block's 64 queries (lane = query); first block, jobs tail + 3 t + g: tail
+            // query t against keys 64 g ... 64 g + 63 (lane = key).  (n_s == kLW here: every wave has had one tile.)
+            const int n_j = tail + (with_tail ? 3 * tail : 0);
+            for (int j = wave; j < n_j; j += kLW) {
+                const bool col = j < tail;
+                const int t = col ? j : (j - tail) / 3, g = col ? 0 : (j - tail) - 3 * t;
+                const int key = col ? Lmain + t : min(g * 64 + lane, kKP - 1);
+                const float *ka = Ks + key * kLD, *qa = col ? Qb + lane * kLD : Qt + t * kLD;   // (rows are 65 floats apart: 32-bit reads, no conflicts)
+                float a = 0.0f, c = 0.0f;
+#pragma unroll
+                for (int d0 = 0; d0 < 64; d0 += 16) {
+                    float x[16], y[16];
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) { x[d] = qa[d0 + d]; y[d] = ka[d0 + d]; }
+#pragma unroll
+                    for (int d = 0; d < 16; d += 2) { a = __builtin_fmaf(x[d], y[d], a); c = __builtin_fmaf(x[d + 1], y[d + 1], c); }
+                }
+                a += c;
+                if (col) Ss[lane * kSS + Lmain + t] = a * scale;
+                else if (g * 64 + lane < kKP) St[t * kSS + g * 64 + lane] = a * scale;
+            }
+        }
         __syncthreads();
         softmax_rows(Ss, qt * 32, qv, q0, wave);
-        if (with_tail) softmax_rows(St, kTR, tail, Lmain, kLW - 1 - wave);       // (the last waves first: they are the ones with a short first loop)
+        if (with_tail) softmax_rows(St, VT ? tail : kTR, tail, Lmain, kLW - 1 - wave);       // (the last waves first: they are the ones with a short first loop)
         __syncthreads();
-        const int n_o = qt * 2 + (with_tail ? 2 : 0);
+        const int n_o = qt * 2 + (with_tail && !VT ? 2 : 0);
         for (int t = wave; t < n_o; t += kLW) {         // O_b = P V
             const bool is_tail = t >= qt * 2;
             const int u = is_tail ? t - qt * 2 : t;
             const int it = u >> 1, dt = u & 1;
             f32x16 acc; zero(acc);
-            mfma_tile<false, false>(acc, is_tail ? St : Ss + it * 32 * kSS, kSS, Vs + dt * 32, kLD, nt * 32, lr, lk);
+            const float *prow = is_tail ? St : Ss + it * 32 * kSS;
+            mfma_tile<false, false>(acc, prow, kSS, Vs + dt * 32, kLD, nt * 32, lr, lk);
+            if constexpr (VT) {                          // + sum over the tail keys of p[row][128 + t] v[128 + t][col]
+                for (int t2 = 0; t2 < tail; ++t2) {
+                    const float v = Vs[(Lmain + t2) * kLD + dt * 32 + lr];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(prow[tile_row(r, lk) * kSS + Lmain + t2], v, acc[r]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (is_tail ? Lmain : q0 + it * 32) + tile_row(r, lk);
                 if (i < L && (!is_tail || tile_row(r, lk) < kTR)) ctx[((size_t)b * L + i) * (H * 64) + hh * 64 + dt * 32 + lr] = acc[r];
+            }
+        }
+        if constexpr (VT) {                              // tail query t: one output row on wave 4 + t (the P V list above is 4 tiles), lane = channel
+            static_assert(kVT <= kLW - 4, "one idle wave per tail row");
+            if (with_tail && wave >= 4 && wave - 4 < tail) {
+                const int t = wave - 4;
+                const float *p = St + t * kSS;
+                float a0 = 0.0f, a1 = 0.0f;
+                for (int j0 = 0; j0 < L; j0 += 16) {      // (columns [L, 160) of the strip and rows [L, 160) of V are zero)
+                    float pv[16], vv[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { pv[j] = p[j0 + j]; vv[j] = Vs[(j0 + j) * kLD + lane]; }
+#pragma unroll
+                    for (int j = 0; j < 16; j += 2) { a0 = __builtin_fmaf(pv[j], vv[j], a0); a1 = __builtin_fmaf(pv[j + 1], vv[j + 1], a1); }
+                }
+                ctx[((size_t)b * L + Lmain + t) * (H * 64) + hh * 64 + lane] = a0 + a1;
             }
         }
         __syncthreads();
@@ -181,12 +234,21 @@ __global__ __launch_bounds__(64 * kLW) void attn_fwd_long_kernel(const float *__
 // (round 5: folding the rows behind row 128 into the first 32-row block, as the forward kernel does, was built and measured for this
 //  kernel too -- 64.1 us against 63.7 at L = 129: the fifth KEY tile (one key of 32) costs what the fifth query block cost, in every
 //  block's S / dP phase, accumulator round and dQ contraction; not kept.)
+// VT (129 ... 128 + kVT tokens, as the forward's MODE 2): four 32-row blocks and four key tiles -- the walk of a 128-token sequence --
+// with the 1 ... kVT tokens behind row 128 on the vector ALU, as keys AND as queries:
+//   before the loop   tail queries against all keys (3 tail jobs, lane = key: s, dP, P, dS rows into Pt / Dt); then their rank-1 terms go
+//                     into the dV / dK accumulators where those live (registers of the owner waves), their dQ rows on waves 6 / 7
+//   phase 1           waves 4 ... 4 + tail - 1: S and dP of one tail key for the block's 32 queries (the two half-waves), P / dS columns
+//   phase 2           dQ += dS[:, tail] K[tail] on the dQ waves; dV / dK of the tail keys accumulate in one register per key on waves
+//                     4 / 5 (lane = channel; those two own only 2 of the 16 accumulator tiles)
+template <bool VT>
 __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__restrict__ qkv, const float *__restrict__ ctx,
                                                                  const float *__restrict__ d_ctx, const float *__restrict__ lse,
                                                                  float *__restrict__ d_qkv, int L, int H, float scale) {
     extern __shared__ float sm[];
     float *Ks = sm, *Vs = Ks + kKP * kLD, *Qb = Vs + kKP * kLD, *Gb = Qb + kBB * kLD, *Ps = Gb + kBB * kLD, *Ds = Ps + kBB * kSS;
     float *delta = Ds + kBB * kSS, *lses = delta + kBB;
+    float *Qt = lses + kBB, *Gt = Qt + kVT * kLD, *Pt = Gt + kVT * kLD, *Dt = Pt + kVT * kSS, *delta_t = Dt + kVT * kSS, *lse_t = delta_t + kVT;   // (VT only)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lk = lane >> 5;
     const int b = blockIdx.x / H, hh = blockIdx.x - b * H;
@@ -201,14 +263,89 @@ __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__
         const size_t strides[2] = {rs, rs};
         stage_block<kKP, 2>(dst, src, strides, L);
     }
-    const int nt = (L + 31) / 32;
+    const int Lmain = VT ? 4 * kBB : L, tail = VT ? L - 4 * kBB : 0;
+    const int nt = VT ? 4 : (L + 31) / 32;
     // dV / dK accumulator tiles: index a = which * 2 nt + jt * 2 + dt, owned by wave a % kAccW, slot a / kAccW
-    f32x16 acc[kAccS];
+    constexpr int NS = VT ? 3 : kAccS;
+    f32x16 acc[NS];
 #pragma unroll
-    for (int m = 0; m < kAccS; ++m) zero(acc[m]);
+    for (int m = 0; m < NS; ++m) zero(acc[m]);
+    float tacc[kVT] = {0.0f, 0.0f, 0.0f, 0.0f};          // VT: wave 4: dV rows of the tail keys, wave 5: their dK rows (lane = channel)
+    static_assert(kVT == 4 && kVT <= kLW - 4, "tail keys: one phase-1 wave each");
+    if constexpr (VT) {
+        for (int i = threadIdx.x; i < tail * 64; i += 64 * kLW) {
+            const int t = i >> 6, d = i & 63;
+            Qt[t * kLD + d] = base[(size_t)(Lmain + t) * rs + d];
+            Gt[t * kLD + d] = gbase[(size_t)(Lmain + t) * cs + d];
+        }
+        if (wave < tail) {
+            const float dl = wave_sum_f32(gbase[(size_t)(Lmain + wave) * cs + lane] * obase[(size_t)(Lmain + wave) * cs + lane]);
+            if (lane == 0) { delta_t[wave] = dl; lse_t[wave] = lse[((size_t)b * H + hh) * L + Lmain + wave]; }
+        }
+        __syncthreads();
+        for (int j = wave; j < 3 * tail; j += kLW) {     // tail query t against keys 64 g ... 64 g + 63
+            const int t = j / 3, g = j - 3 * t, key = g * 64 + lane, kc = min(key, kKP - 1);
+            const float *qa = Qt + t * kLD, *ga = Gt + t * kLD, *ka = Ks + kc * kLD, *va = Vs + kc * kLD;
+            float s0 = 0.0f, s1 = 0.0f, p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+            for (int d0 = 0; d0 < 64; d0 += 8) {
+                float x[8], y[8], u[8], w[8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) { x[d] = qa[d0 + d]; y[d] = ka[d0 + d]; u[d] = ga[d0 + d]; w[d] = va[d0 + d]; }
+#pragma unroll
+                for (int d = 0; d < 8; d += 2) {
+                    s0 = __builtin_fmaf(x[d], y[d], s0); s1 = __builtin_fmaf(x[d + 1], y[d + 1], s1);
+                    p0 = __builtin_fmaf(u[d], w[d], p0); p1 = __builtin_fmaf(u[d + 1], w[d + 1], p1);
+                }
+            }
+            if (key < kKP) {
+                const float pr = key < L ? exp_neg((s0 + s1) * scale - lse_t[t]) : 0.0f;
+                Pt[t * kSS + key] = pr;
+                Dt[t * kSS + key] = key < L ? pr * ((p0 + p1) - delta_t[t]) * scale : 0.0f;
+            }
+        }
+        __syncthreads();
+        if (wave < kAccW) {                              // rank-1 terms of the tail queries: dV += P_t^T dO_t, dK += dS_t^T Q_t
+#pragma unroll
+            for (int m = 0; m < NS; ++m) {
+                const int a = wave + kAccW * m;
+                if (a < nt * 4) {
+                    const int which = a / (nt * 2), u = a - which * nt * 2;
+                    const int jt = u >> 1, dt = u & 1;
+                    const float *rowv = (which == 0 ? Pt : Dt) + jt * 32, *colv = (which == 0 ? Gt : Qt) + dt * 32 + lr;
+                    for (int t = 0; t < tail; ++t) {
+                        const float c = colv[t * kLD];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][r] = __builtin_fmaf(rowv[t * kSS + tile_row(r, lk)], c, acc[m][r]);
+                    }
+                }
+            }
+            if (wave >= 4) {                             // ... and into the tail keys' own rows
+                const float *rowv = wave == 4 ? Pt : Dt, *colv = wave == 4 ? Gt : Qt;
+                for (int t = 0; t < tail; ++t) {
+                    const float c = colv[t * kLD + lane];
+#pragma unroll
+                    for (int k = 0; k < kVT; ++k) tacc[k] = __builtin_fmaf(k < tail ? rowv[t * kSS + Lmain + k] : 0.0f, c, tacc[k]);
+                }
+            }
+        } else {                                         // dQ rows of the tail queries (lane = channel): wave 6: t = 0, 2; wave 7: t = 1, 3
+            for (int t = wave - kAccW; t < tail; t += kLW - kAccW) {
+                const float *dsr = Dt + t * kSS;
+                float a0 = 0.0f, a1 = 0.0f;
+                for (int j0 = 0; j0 < L; j0 += 16) {      // (columns [L, 160) of the strip and rows [L, 160) of K are zero)
+                    float x[16], y[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { x[j] = dsr[j0 + j]; y[j] = Ks[(j0 + j) * kLD + lane]; }
+#pragma unroll
+                    for (int j = 0; j < 16; j += 2) { a0 = __builtin_fmaf(x[j], y[j], a0); a1 = __builtin_fmaf(x[j + 1], y[j + 1], a1); }
+                }
+                dbase[(size_t)(Lmain + t) * rs + lane] = a0 + a1;
+            }
+        }
+    }
     float *const Ks0 = Ks, *const Vs0 = Vs, *const Qb0 = Qb, *const Gb0 = Gb, *const Ps0 = Ps, *const Ds0 = Ds;
-    for (int q0 = 0; q0 < L; q0 += kBB) {
-        const int qv = min(kBB, L - q0);
+    for (int q0 = 0; q0 < Lmain; q0 += kBB) {
+        const int qv = min(kBB, Lmain - q0);
         // The operand addresses of all tile products are loop-invariant; hoisted out of this loop they would occupy
         // some 300 VGPRs (and spill).  An opaque zero offset keeps their computation inside the iteration.
         int opq = 0;
@@ -252,12 +389,29 @@ __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__
                 Ps[i * kSS + j] = p;
                 Ds[i * kSS + j] = (i < qv && j < L) ? p * (dp[r] - delta[i]) * scale : 0.0f;
             }
+        } else if (VT && wave - 4 < tail) {              // tail key 128 + t: lanes 0..31 S, lanes 32..63 dP of query lr
+            const int t = wave - 4;
+            const float *x = (lk ? Gb : Qb) + lr * kLD, *y = (lk ? Vs : Ks) + (Lmain + t) * kLD;
+            float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int d0 = 0; d0 < 64; d0 += 16) {
+                float xv[16], yv[16];
+#pragma unroll
+                for (int d = 0; d < 16; ++d) { xv[d] = x[d0 + d]; yv[d] = y[d0 + d]; }
+#pragma unroll
+                for (int d = 0; d < 16; d += 2) { a0 = __builtin_fmaf(xv[d], yv[d], a0); a1 = __builtin_fmaf(xv[d + 1], yv[d + 1], a1); }
+            }
+            const float mine = a0 + a1, other = __shfl_xor(mine, 32);
+            const float sv = lk ? other : mine, dpv = lk ? mine : other;
+            const float p = exp_neg(sv * scale - lses[lr]);
+            if (lk) Ds[lr * kSS + Lmain + t] = p * (dpv - delta[lr]) * scale;
+            else Ps[lr * kSS + Lmain + t] = p;
         }
         __syncthreads();
         // phase 2: dV += P^T dO_b, dK += dS^T Q_b on the owner waves; dQ_b = dS K on the last two waves
         if (wave < kAccW) {
 #pragma unroll
-            for (int m = 0; m < kAccS; ++m) {
+            for (int m = 0; m < NS; ++m) {
                 const int a = wave + kAccW * m;
                 if (a < nt * 4) {
                     const int which = a / (nt * 2), u = a - which * nt * 2;
@@ -266,10 +420,35 @@ __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__
                     else mfma_tile_k<true, false, 32>(acc[m], Ds + jt * 32, kSS, Qb + dt * 32, kLD, lr, lk);
                 }
             }
+            if (VT && wave >= 4) {                       // rows of the tail keys: += P[:, 128 + k]^T dO_b (wave 4), dS[:, 128 + k]^T Q_b (wave 5)
+                const float *strip = (wave == 4 ? Ps : Ds) + Lmain, *opnd = (wave == 4 ? Gb : Qb) + lane;
+#pragma unroll
+                for (int i0 = 0; i0 < kBB; i0 += 16) {
+                    float c[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) c[i] = opnd[(i0 + i) * kLD];
+#pragma unroll
+                    for (int k = 0; k < kVT; ++k)
+                        if (k < tail) {
+                            float pv[16];
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) pv[i] = strip[(i0 + i) * kSS + k];
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) tacc[k] = __builtin_fmaf(pv[i], c[i], tacc[k]);
+                        }
+                }
+            }
         } else {
             const int dt = wave - kAccW;
             f32x16 dq; zero(dq);
             mfma_tile<false, false>(dq, Ds, kSS, Ks + dt * 32, kLD, nt * 32, lr, lk);
+            if constexpr (VT) {
+                for (int t = 0; t < tail; ++t) {
+                    const float kv = Ks[(Lmain + t) * kLD + dt * 32 + lr];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dq[r] = __builtin_fmaf(Ds[tile_row(r, lk) * kSS + Lmain + t], kv, dq[r]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = q0 + tile_row(r, lk);
@@ -280,7 +459,7 @@ __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__
     }
     if (wave < kAccW) {
 #pragma unroll
-        for (int m = 0; m < kAccS; ++m) {
+        for (int m = 0; m < NS; ++m) {
             const int a = wave + kAccW * m;
             if (a < nt * 4) {
                 const int which = a / (nt * 2), u = a - which * nt * 2;
@@ -292,6 +471,11 @@ __global__ __launch_bounds__(64 * kLW) void attn_bwd_long_kernel(const float *__
                 }
             }
         }
+        if (VT && wave >= 4) {
+#pragma unroll
+            for (int k = 0; k < kVT; ++k)
+                if (k < tail) dbase[(size_t)(Lmain + k) * rs + (wave == 4 ? 2 : 1) * H * 64 + lane] = tacc[k];
+        }
     }
 }
 
@@ -299,13 +483,15 @@ constexpr size_t kFwdLongLds = ((size_t)2 * kKP * kLD + (size_t)kQB * kLD + (siz
 constexpr size_t kFwdFoldLds = kFwdLongLds + ((size_t)kTR * kLD + (size_t)kTR * kSS) * sizeof(float);
 static_assert(kFwdFoldLds <= 160 * 1024, "LDS budget");
 constexpr size_t kBwdLongLds = ((size_t)2 * kKP * kLD + (size_t)2 * kBB * kLD + (size_t)2 * kBB * kSS + 2 * kBB) * sizeof(float);
-static_assert(kBwdLongLds <= 160 * 1024, "LDS budget");
+constexpr size_t kBwdTailLds = kBwdLongLds + ((size_t)2 * kVT * kLD + (size_t)2 * kVT * kSS + 2 * kVT) * sizeof(float);
+static_assert(kBwdTailLds <= 160 * 1024, "LDS budget");
 
-// UPP_ATTN_FOLD=0 (read once): the three-block walk of rounds 1-4 for 129 ... 144 tokens (A/B timing, tests)
-inline bool fold_disabled() {
+// UPP_ATTN_FOLD (read once; A/B timing, tests): 0 = the three-block walk of rounds 1-4 for 129 ... 144 tokens; 1 = the tail strip on the
+// matrix pipe for every such length; unset / 2 = 1 ... kVT tail rows on the vector ALU, longer tails as 1.
+inline int fold_mode() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("UPP_ATTN_FOLD"); v = (e && e[0] == '0') ? 1 : 0; }
-    return v == 1;
+    if (v < 0) { const char *e = getenv("UPP_ATTN_FOLD"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
+    return v;
 }
 
 }  // namespace
@@ -314,16 +500,21 @@ inline bool fold_disabled() {
 int upp_attn_fwd_long(const float *qkv, float *ctx, float *lse, int B, int L, int H, float scale, hipStream_t st) {
     static std::atomic<bool> raised{false};
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_long_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLongLds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_long_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLongLds);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_long_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdFoldLds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_long_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdFoldLds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_long_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdFoldLds);
         if (e != hipSuccess) return (int)e;
         raised = true;
     }
-    if (L > 2 * kQB && L <= 2 * kQB + kTR && !fold_disabled())
-        hipLaunchKernelGGL(attn_fwd_long_kernel<true>, dim3(B * H), dim3(64 * kLW), kFwdFoldLds, st, qkv, ctx, lse, L, H, scale);
+    const int mode = (L > 2 * kQB && L <= 2 * kQB + kTR) ? fold_mode() : 0;
+    if (mode == 2 && L <= 2 * kQB + kVT)
+        hipLaunchKernelGGL(attn_fwd_long_kernel<2>, dim3(B * H), dim3(64 * kLW), kFwdFoldLds, st, qkv, ctx, lse, L, H, scale);
+    else if (mode != 0)
+        hipLaunchKernelGGL(attn_fwd_long_kernel<1>, dim3(B * H), dim3(64 * kLW), kFwdFoldLds, st, qkv, ctx, lse, L, H, scale);
     else
-        hipLaunchKernelGGL(attn_fwd_long_kernel<false>, dim3(B * H), dim3(64 * kLW), kFwdLongLds, st, qkv, ctx, lse, L, H, scale);
+        hipLaunchKernelGGL(attn_fwd_long_kernel<0>, dim3(B * H), dim3(64 * kLW), kFwdLongLds, st, qkv, ctx, lse, L, H, scale);
     return upp_launch_status();
 }
 
@@ -331,10 +522,15 @@ int upp_attn_bwd_long(const float *qkv, const float *ctx, const float *d_ctx, co
                       float scale, hipStream_t st) {
     static std::atomic<bool> raised{false};
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLongLds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_long_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLongLds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_long_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdTailLds);
         if (e != hipSuccess) return (int)e;
         raised = true;
     }
-    hipLaunchKernelGGL(attn_bwd_long_kernel, dim3(B * H), dim3(64 * kLW), kBwdLongLds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
+    if (L > 4 * kBB && L <= 4 * kBB + kVT && fold_mode() == 2)
+        hipLaunchKernelGGL(attn_bwd_long_kernel<true>, dim3(B * H), dim3(64 * kLW), kBwdTailLds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
+    else
+        hipLaunchKernelGGL(attn_bwd_long_kernel<false>, dim3(B * H), dim3(64 * kLW), kBwdLongLds, st, qkv, ctx, d_ctx, lse, d_qkv, L, H, scale);
     return upp_launch_status();
 }

@@ -18,7 +18,7 @@ def close(a, b, rtol=1e-5, atol_scale=2e-6):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_scale * max(np.abs(b).max(), 1e-30))
 
 
-@pytest.mark.parametrize("L", [1, 15, 16, 17, 31, 35, 48, 64, 65, 75, 80, 81, 96, 97, 128, 129, 130, 139, 143, 144, 145, 159, 160])
+@pytest.mark.parametrize("L", [1, 15, 16, 17, 31, 35, 48, 64, 65, 75, 80, 81, 96, 97, 128, 129, 130, 131, 132, 133, 139, 143, 144, 145, 159, 160])
 def test_attention_core_forward_backward(L):
     # attn_flash16.hip (L <= 96) / attn_long.hip (L <= 160) against the reference formulation (models/Point_MAE_pretask_dev.py:186-193)
     _attention_case(L)

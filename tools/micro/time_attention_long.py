@@ -5,7 +5,7 @@ import torch
 from bench import time_kernel
 from upp_hip import ops
 B, H = 32, 6
-for L in (96, 97, 112, 128, 129, 138, 139, 144, 160):
+for L in (96, 97, 112, 128, 129, 130, 132, 133, 138, 139, 144, 160):
     qkv = torch.randn(B, L, 3 * H * 64, device='cuda')
     ctx, lse = ops.attn_fwd(qkv, B, L, H, 0.125)
     tf = time_kernel(lambda: ops.attn_fwd(qkv, B, L, H, 0.125))
