@@ -734,6 +734,12 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)"
                          % (args.gpus, world, args.gpus))
     distributed = world > 1
+    if world == 1 and os.environ.get("UPP_FORCE_DIST") == "1":
+        # rehearsal on a one-GPU box: the N > 1 code path (process group, gradient all-reduce between the graph replays, barrier +
+        # max-over-ranks timing, the RCCL probe) with a single rank -- RCCL itself initialises and runs its collectives
+        distributed = True
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531")):
+            os.environ.setdefault(k, v)
     if args.selftest_launch:
         return selftest_launch(args, world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

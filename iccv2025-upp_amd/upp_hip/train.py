@@ -236,7 +236,8 @@ class TrainStep:
             self.opt = FlatAdamW(no_decay, decay, self.flat.flat, lr=lr, max_norm=grad_clip)
         else:                                                   # host runs (gloo tests, CPU baseline): library optimizer
             self.opt = make_adamw(model, lr=lr)
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # (UPP_FORCE_DIST=1: a one-rank group takes the N > 1 path too -- the RCCL rehearsal of a one-GPU box, tests/test_gpu_dist.py)
+        self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("UPP_FORCE_DIST") == "1")
         if self.distributed:
             broadcast_model(model)      # (after FlatAdamW re-pointed the trainable parameters into its flat buffer: views of it)
         self.pts = torch.zeros(batch_shape, device=self.device)

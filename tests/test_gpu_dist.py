@@ -150,6 +150,23 @@ def test_bench_gpus_2_reports_two_ranks(tmp_path):
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["dist_backend"] == "gloo" and rec["value"] > 0
 
 
+def test_bench_runs_the_distributed_path_over_rccl_with_one_rank(tmp_path):
+    """The one piece of the N > 1 path a one-GPU box cannot stand in for with gloo is RCCL itself: with UPP_FORCE_DIST=1 the bench (and
+    TrainStep) take the distributed path with a ONE-rank "nccl" group -- RCCL initialises on the card, broadcasts the model, all-reduces
+    the flat gradient buffer between the graph replays of every step, runs the barrier / max-over-ranks timing and the RCCL probe."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UPP_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 400))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "UPP_DIST_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "8",
+                          "--no-cpu-baseline", "--no-stage-report"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["dist_backend"] == "nccl" and rec["rccl_ranks"] == 1 and rec["value"] > 0
+
+
 def test_learning_rate_changes_reach_a_captured_step():
     """lr / weight decay were by-value kernel arguments frozen into the optimizer graph."""
     import _seeded
