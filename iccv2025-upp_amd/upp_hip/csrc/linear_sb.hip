@@ -536,17 +536,46 @@ struct SbConfig { int bmb, bnb, rn, ks, nst; };
 #define UPP_SB_NST44 3
 #endif
 #define UPP_SB_CONFIGS(X) X(8, 4, 4, 1, 2) X(8, 4, 2, 1, 2) X(4, 4, 2, 1, UPP_SB_NST44) X(4, 3, 1, 1, 4) X(3, 4, 2, 1, 4) X(2, 4, 2, 1, 4) X(2, 3, 1, 1, 4) X(2, 2, 1, 2, 3) X(2, 2, 2, 4, 2) X(1, 2, 1, 2, 4)
+// tiles that pick_sb never chooses, reachable by an explicit tile code: the whole shape space in a -DUPP_SB_SWEEP build (tools/micro/sb_sweep.py)
+#ifdef UPP_SB_SWEEP
+#include "linear_sb_sweep.h"
+#define UPP_SB_EXTRA_CONFIGS(X) UPP_SB_SWEEP_CONFIGS(X)
+#else
+#define UPP_SB_EXTRA_CONFIGS(X)
+#endif
+#include "linear_sb_tuned.h"
 #define UPP_SB_ENTRY(a, b, c, d, e) {a, b, c, d, e},
 constexpr SbConfig kSbConfigs[] = {UPP_SB_CONFIGS(UPP_SB_ENTRY)};
 #undef UPP_SB_ENTRY
 constexpr int kNumSbConfigs = sizeof(kSbConfigs) / sizeof(kSbConfigs[0]);
 inline int sb_code(const SbConfig &c) { return 0x400000 + c.bmb * 65536 + c.bnb * 4096 + c.rn * 256 + c.ks * 16 + c.nst; }     // hex digits 4 BMB BNB RN KS NST
 
+// The measured choice (linear_sb_tuned.h) for a problem of the swept family: same N and K, M within 1 / 16 of a swept M (the nearest one),
+// and still one round of workgroups where the swept problem was.  UPP_SB_TUNED=0 (read once): the cost model alone (A/B).  0: no entry.
+int sb_tuned(int M, int N, int K) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("UPP_SB_TUNED"); on = !(e && e[0] == '0'); }
+    if (!on) return 0;
+    int best = 0;
+    long long best_d = 0;
+    for (const SbTuned &t : kSbTuned) {
+        if (t.N != N || t.K != K) continue;
+        const long long d = M > t.M ? M - t.M : t.M - M;
+        if (d * 16 > t.M) continue;
+        const int bmb = (t.code >> 16) & 15, bnb = (t.code >> 12) & 15;
+        const long long wg_t = (long long)((t.M + 32 * bmb - 1) / (32 * bmb)) * ((N + 32 * bnb - 1) / (32 * bnb));
+        const long long wg = (long long)((M + 32 * bmb - 1) / (32 * bmb)) * ((N + 32 * bnb - 1) / (32 * bnb));
+        if (wg_t <= 256 && wg > 256) continue;
+        if (!best || d < best_d) { best = t.code; best_d = d; }
+    }
+    return best;
+}
+
 // One round of at most 256 workgroups (the big tiles also in several rounds: the tall point-row matrices); among the shapes that fit, the smallest of max(matrix-pipe cycles of the busiest SIMD + 0.7 x the
 // VALU cycles of its A splits, bytes a workgroup stages / 40 B per clock) -- fitted to the in-kernel stamps of tools/micro/sb_stamps.py
 // (fc1 128 x 128: 23.7k cycles for 18.4k + 0.7 x 9.6k; fc2 64 x 64 with one block per wave: 34k for 18.4k + 0.7 x 19.2k, which is why
 // the narrow shapes take the tile whose waves own both column blocks).  0: not a problem for this file.
-int pick_sb(int M, int N, int K) {
+int pick_sb_model(int M, int N, int K) {
     if (K % 32 != 0 || K < 64) return 0;
     const int mb = (M + 31) / 32, nb = (N + 31) / 32;
     int best = 0;
@@ -569,6 +598,13 @@ int pick_sb(int M, int N, int K) {
         if (!best || cost < best_cost) { best = sb_code(c); best_cost = cost; }
     }
     return best;
+}
+
+// the measured choice where the table has one, the cost model's otherwise
+int pick_sb(int M, int N, int K) {
+    if (K % 32 != 0 || K < 64) return 0;
+    const int t = sb_tuned(M, N, K);
+    return t ? t : pick_sb_model(M, N, K);
 }
 
 // UPP_SB_XCD2D=<gc> (read once; 0 / unset: row-major XCD ranges): column groups of the 2-D XCD map for one-round launches of wide outputs
@@ -684,6 +720,10 @@ static int linear_sb_launch(const float *A, long long lda, const void *planes, c
         return launch_sb<a, b, c, d, e>(g, st);
     switch (tile) {
         UPP_SB_CONFIGS(UPP_SB_CASE)
+#ifndef UPP_SB_SWEEP                                      // (the sweep build's list contains these)
+        UPP_SB_TUNED_CONFIGS(UPP_SB_CASE)
+#endif
+        UPP_SB_EXTRA_CONFIGS(UPP_SB_CASE)
         default: return UPP_E_RANGE;
     }
 #undef UPP_SB_CASE
@@ -732,7 +772,7 @@ extern "C" int upp_linear_sb_f32(const float *A, long long lda, const void *plan
 
 // Does upp_linear_sb_ln_f32 take (M,N,K)?  The tile the library picks must be one of the two that carry an A-operand prologue.
 static bool sb_ln_tile(int M, int N, int K, int &tile) {
-    tile = pick_sb(M, N, K);
+    tile = pick_sb_model(M, N, K);                       // (not the tuned table: only these two shapes are instantiated with the prologue)
     return K <= 512 && K % 32 == 0 && (tile == 0x444210 + UPP_SB_NST44 || tile == 0x484412);
 }
 

@@ -12,7 +12,9 @@ from upp_hip import functional as HF, ops, _abi
 pytestmark = pytest.mark.gpu
 
 SB_CONFIGS = [0x400000 + a * 65536 + b * 4096 + c * 256 + d * 16 + e for (a, b, c, d, e) in
-              [(8, 4, 4, 1, 2), (8, 4, 2, 1, 2), (4, 4, 2, 1, 3), (4, 3, 1, 1, 4), (3, 4, 2, 1, 4), (2, 4, 2, 1, 4), (2, 3, 1, 1, 4), (2, 2, 1, 2, 3), (2, 2, 2, 4, 2), (1, 2, 1, 2, 4)]]
+              [(8, 4, 4, 1, 2), (8, 4, 2, 1, 2), (4, 4, 2, 1, 3), (4, 3, 1, 1, 4), (3, 4, 2, 1, 4), (2, 4, 2, 1, 4), (2, 3, 1, 1, 4), (2, 2, 1, 2, 3), (2, 2, 2, 4, 2), (1, 2, 1, 2, 4),
+               # the tuned table's shapes (csrc/linear_sb_tuned.h)
+               (2, 4, 1, 1, 3), (2, 3, 1, 2, 3), (2, 1, 1, 2, 3), (4, 3, 1, 1, 3), (2, 2, 1, 2, 2), (4, 4, 2, 1, 2), (1, 1, 1, 4, 3), (4, 4, 2, 2, 2), (3, 2, 1, 2, 3), (3, 4, 2, 2, 2)]]
 TOKENS = [2400, 2080, 2048, 1120]
 LAYERS = [("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536), ("dqkv", 384, 1152)]
 
@@ -101,6 +103,8 @@ def test_block_shapes_are_as_accurate_as_the_exact_f32_kernel(M, layer, spread):
 @pytest.mark.parametrize("cfg", SB_CONFIGS, ids=[hex(c) for c in SB_CONFIGS])
 def test_epilogues_match_the_exact_f32_kernel(cfg):
     M, N, K = 333, 224, 256
+    if K // (32 * ((cfg >> 4) & 15)) < (cfg & 15):       # (fewer k-stages per wave group than LDS stages: a deeper problem for this shape)
+        K = 512
     a, w, b = _operands(M, N, K, seed=cfg)
     tol = dict(rtol=1e-5, atol=5e-6)
     torch.testing.assert_close(_sb(a, w, b, ops.LIN_BIAS, tile=cfg), ops.linear_f32(a, w, b, ops.LIN_BIAS), **tol)
