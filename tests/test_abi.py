@@ -97,6 +97,39 @@ def test_linear_decomposition_choice_is_a_host_function():
     assert lib.upp_linear_tile(65536, 1024, 1536) == RT and lib.upp_linear_tile(65536, 512, 256) == RT
 
 
+def test_split_bf16_tuned_tile_table_is_well_formed_and_answers_for_its_own_problems():
+    """csrc/linear_sb_tuned.h (generated from the sweep in profiles/r05_sb_sweep.json): every row names a compiled tile shape whose wave
+    groups' k-stages divide K and fill its LDS stages, upp_linear_sb_tile (a host function) answers with the row's tile for the row's
+    problem, with the nearest row's for a neighbouring M, and never with a tile that would need a second round of workgroups where the
+    swept problem ran in one."""
+    import re
+    from conftest import ROOT
+    csrc = os.path.join(ROOT, "iccv2025-upp_amd", "upp_hip", "csrc")
+    compiled = set()
+    for f, macro in (("linear_sb.hip", "UPP_SB_CONFIGS"), ("linear_sb_tuned.h", "UPP_SB_TUNED_CONFIGS")):
+        m = re.search(r'#define %s\(X\) (.*)\n' % macro, open(os.path.join(csrc, f)).read())
+        for t in re.findall(r'X\(([^)]*)\)', m.group(1).replace('UPP_SB_NST44', '3')):
+            a, b, c, d, e = (int(v) for v in t.split(','))
+            compiled.add(0x400000 + a * 65536 + b * 4096 + c * 256 + d * 16 + e)
+    rows = [(int(a), int(b), int(c), int(d, 16)) for a, b, c, d in
+            re.findall(r'\{(\d+), (\d+), (\d+), 0x([0-9a-f]+)\}', open(os.path.join(csrc, "linear_sb_tuned.h")).read())]
+    assert len(rows) >= 40
+    lib = _abi.load()
+    for M, N, K, code in rows:
+        bmb, bnb, ks, nst = (code >> 16) & 15, (code >> 12) & 15, (code >> 4) & 15, code & 15
+        assert code in compiled, hex(code)
+        assert K % (32 * ks) == 0 and K // (32 * ks) >= nst, (M, N, K, hex(code))
+        assert lib.upp_linear_sb_tile(M, N, K) == code, (M, N, K, hex(code))
+    # the headline block at a neighbouring batch (B = 31: 2,325 token rows): the rows swept at 2,400
+    assert lib.upp_linear_sb_tile(2325, 384, 1536) == lib.upp_linear_sb_tile(2400, 384, 1536)
+    # 4,096 rows take 128 x 96 tiles in one round (256 workgroups); 4,100 rows would need 260: not that row
+    t4096 = lib.upp_linear_sb_tile(4096, 384, 384)
+    if ((t4096 >> 16) & 15, (t4096 >> 12) & 15) == (2, 3):
+        assert lib.upp_linear_sb_tile(4100, 384, 384) != t4096
+    # far from every swept M: the cost model
+    assert lib.upp_linear_sb_tile(300, 384, 384) > 0
+
+
 def test_exported_symbols_are_exactly_the_declared_ones():
     """nm -D libupp_hip.so | grep ' T upp_'  ==  the prototypes of include/upp_hip.h: no undeclared hooks, no global switches."""
     import subprocess

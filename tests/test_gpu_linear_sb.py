@@ -11,10 +11,22 @@ from upp_hip import functional as HF, ops, _abi
 
 pytestmark = pytest.mark.gpu
 
-SB_CONFIGS = [0x400000 + a * 65536 + b * 4096 + c * 256 + d * 16 + e for (a, b, c, d, e) in
-              [(8, 4, 4, 1, 2), (8, 4, 2, 1, 2), (4, 4, 2, 1, 3), (4, 3, 1, 1, 4), (3, 4, 2, 1, 4), (2, 4, 2, 1, 4), (2, 3, 1, 1, 4), (2, 2, 1, 2, 3), (2, 2, 2, 4, 2), (1, 2, 1, 2, 4),
-               # the tuned table's shapes (csrc/linear_sb_tuned.h)
-               (2, 4, 1, 1, 3), (2, 3, 1, 2, 3), (2, 1, 1, 2, 3), (4, 3, 1, 1, 3), (2, 2, 1, 2, 2), (4, 4, 2, 1, 2), (1, 1, 1, 4, 3), (4, 4, 2, 2, 2), (3, 2, 1, 2, 3), (3, 4, 2, 2, 2)]]
+def _compiled_tiles():
+    """Every tile shape the library compiles: pick_sb's candidates (UPP_SB_CONFIGS, csrc/linear_sb.hip) and the tuned table's (csrc/linear_sb_tuned.h)."""
+    import os
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "iccv2025-upp_amd", "upp_hip", "csrc")
+    out = []
+    for f, macro in (("linear_sb.hip", "UPP_SB_CONFIGS"), ("linear_sb_tuned.h", "UPP_SB_TUNED_CONFIGS")):
+        m = re.search(r'#define %s\(X\) (.*)\n' % macro, open(os.path.join(csrc, f)).read())
+        for t in re.findall(r'X\(([^)]*)\)', m.group(1).replace('UPP_SB_NST44', '3')):
+            a, b, c, d, e = (int(v) for v in t.split(','))
+            out.append(0x400000 + a * 65536 + b * 4096 + c * 256 + d * 16 + e)
+    return out
+
+
+SB_CONFIGS = _compiled_tiles()
+assert len(SB_CONFIGS) >= 10 and len(set(SB_CONFIGS)) == len(SB_CONFIGS)
 TOKENS = [2400, 2080, 2048, 1120]
 LAYERS = [("qkv", 1152, 384), ("proj", 384, 384), ("fc1", 1536, 384), ("fc2", 384, 1536), ("dqkv", 384, 1152)]
 

@@ -64,7 +64,7 @@ for (M, N, K) in SHAPES:
         if K % (32 * ks) or K // (32 * ks) < nst:
             continue
         wgs = -(-M // (32 * bmb)) * -(-N // (32 * bnb))
-        if wgs > 1024:
+        if wgs > 1024 and (M < 16384 or bmb * bnb < 8):
             continue
 
         def chain():
@@ -81,4 +81,4 @@ for (M, N, K) in SHAPES:
     print("%5d x %4d x %4d  shipped %x %s | " % (M, N, K, shipped, ("%.1f us" % ship_t[0][0]) if ship_t else "-")
           + "  ".join("%x %.1f (%d wg)" % (t, us, wgs) for us, t, wgs in res[:6]), flush=True)
 import json
-json.dump(ALL, open(os.path.join(ROOT, "gpurun_out", "r05", "sb_sweep.json"), "w"))
+json.dump(ALL, open(os.path.join(ROOT, "gpurun_out", "r05", os.environ.get("SB_SWEEP_OUT", "sb_sweep.json")), "w"))
