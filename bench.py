@@ -609,6 +609,30 @@ def linear_family_replay(ts, device):
     return flops, ms, len(calls) + len(groups), shapes, sb_flops, calls
 
 
+L2_TO_LDS_PEAK_GBS = 17800.0      # MI355X_MICROARCH.md "Indexed rows: gather into LDS": 66-73 GB/s per CU served by the XCD's L2 = 16.8-18.8 TB/s chip-wide
+
+
+def operand_stream(calls, ms):
+    """What the split-bf16 launches of the recorded list move from the L2 into the LDS (the quantity their k-loops are bound by, DESIGN
+    section 4): a workgroup of tile BM x BN stages BM rows x 128 B of f32 A and BN / 32 blocks x 6,144 B of bf16 W planes per 32-wide
+    k-stage, whatever its waves do with them -- host arithmetic on the tile codes, no counter.  -> dict or None."""
+    total = 0.0
+    for M, N, K, e, sb in calls:
+        if not sb:
+            continue
+        bmb, bnb = (sb >> 16) & 15, (sb >> 12) & 15
+        wgs = -(-M // (32 * bmb)) * -(-N // (32 * bnb))
+        total += float(wgs) * -(-K // 32) * (bmb * 32 * 128 + bnb * 6144)
+    if total == 0.0:
+        return None
+    gbs = total / ms / 1e6
+    return {"bytes_per_step": total, "achieved": gbs, "peak": L2_TO_LDS_PEAK_GBS, "unit": "GB/s", "frac": gbs / L2_TO_LDS_PEAK_GBS,
+            "note": "L2 -> LDS operand stream of the split-bf16 launches over the family's WHOLE time (prologues, epilogues and launch "
+                    "boundaries included; inside the k-loops the stamps of tools/micro/sb_stamps.py read 12-14.5 TB/s): the block GEMMs at "
+                    "2,400 rows are bound by this stream, not by the matrix pipe -- one round of <= 256 workgroups leaves 64 x 64 ... "
+                    "128 x 128 tiles, 13-26 flop per staged byte"}
+
+
 def family_traffic(calls):
     """HBM-side bytes of the family per step from the committed counters: every launch of the recorded list whose (M, N, K, epilogue) carries
     a label in STEP_LINEAR_SHAPES contributes that label's measured bytes (taken on the same kernel: pmc_linear_entry); the rest -- heads,
@@ -879,6 +903,7 @@ def main():
                 "ms": ms, "launches": n, "algorithmic_flops": flops,
                 "traffic": None if fam is None else fam["traffic"],
                 "traffic_detail": fam,
+                "l2_to_lds": operand_stream(calls, ms),
                 "traffic_note": "HBM-side bytes of the family per STEP (like achieved: per replay of the launch list): sum over the recorded "
                                 "launches of the committed rocprofv3 --pmc counters of that launch's shape (2 x FETCH_SIZE + WRITE_SIZE, "
                                 "profiles/r05_pmc_kernels.json 'linear:<label>', each taken on the kernel this run launches); launches "
