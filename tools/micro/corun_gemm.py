@@ -1,5 +1,6 @@
 """Two independent chains of Linear launches on two streams against the same chains on one stream: what co-residency of two workgroups
-per CU (half-LDS tiles) buys the pipelined step, whose two streams' GEMMs otherwise take turns (every default tile holds 120-160 KB)."""
+per CU (half-LDS tiles) buys the pipelined step, whose two streams' GEMMs otherwise take turns (every default tile holds 120-160 KB).
+Needs a -DUPP_SB_SWEEP build of the library (tools/micro/sb_sweep_gen.py): the half-LDS shapes are not shipped."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "iccv2025-upp_amd")]
