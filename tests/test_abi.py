@@ -104,6 +104,8 @@ def test_split_bf16_tuned_tile_table_is_well_formed_and_answers_for_its_own_prob
     swept problem ran in one."""
     import re
     from conftest import ROOT
+    if os.environ.get("UPP_SB_TUNED", "1")[:1] == "0":
+        pytest.skip("UPP_SB_TUNED=0: the library answers with the cost model alone")
     csrc = os.path.join(ROOT, "iccv2025-upp_amd", "upp_hip", "csrc")
     compiled = set()
     for f, macro in (("linear_sb.hip", "UPP_SB_CONFIGS"), ("linear_sb_tuned.h", "UPP_SB_TUNED_CONFIGS")):
