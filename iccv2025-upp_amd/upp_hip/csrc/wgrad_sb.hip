@@ -485,7 +485,8 @@ extern "C" int upp_linear_wgrad_grouped_sb_rows(int count, const int *M, const i
         double work = 0.0;
         for (int p = 0; p < count; ++p)
             if ((cls[p] == WS_TALL_SWAPPED ? WS_TALL : cls[p]) == launch) work += (double)ws_tiles(cls[p], N[p], K[p]) * M[p];
-        long long per_unit = (long long)(work / (launch == WS_NARROW ? 512.0 * 3.0 : 256.0 * 3.0));
+        static const double rounds = [] { const char *e = getenv("UPP_WGRAD_ROUNDS"); const double v = e ? atof(e) : 0.0; return v >= 0.5 && v <= 16.0 ? v : 3.0; }();   // (A/B switch)
+        long long per_unit = (long long)(work / (launch == WS_NARROW ? 512.0 * rounds : 256.0 * rounds));
         per_unit = (per_unit + 31) / 32 * 32;
         if (per_unit < 256) per_unit = 256;
         for (int p = 0; p < count; ++p) {
