@@ -206,7 +206,9 @@ class _TrainingState:
 def broadcast_model(model, src=0):
     """Rank `src`'s parameters and buffers to every rank (what DistributedDataParallel does when it wraps a model,
     reference tools/runner_module.py:53-57): replicas start identical whatever seed / checkpoint each process used."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_world_size() == 1 and os.environ.get("UPP_FORCE_DIST") != "1":        # (the one-rank RCCL rehearsal runs the broadcasts)
         return
     with torch.no_grad():
         for t in list(model.parameters()) + list(model.buffers()):

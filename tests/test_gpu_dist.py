@@ -167,6 +167,47 @@ def test_bench_runs_the_distributed_path_over_rccl_with_one_rank(tmp_path):
     assert rec["n_gpus"] == 1 and rec["dist_backend"] == "nccl" and rec["rccl_ranks"] == 1 and rec["value"] > 0
 
 
+def test_gradient_all_reduce_and_model_broadcast_run_over_a_one_rank_rccl_group(tmp_path):
+    """... and the two collectives of the product's own step driver (utils.dist_utils.FlatGradAllReduce.reduce, train.broadcast_model) really
+    issue under the rehearsal switch: counted through torch.distributed's wrappers in a child process with a one-rank nccl group."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import os, sys
+sys.path[:0] = [%r, %r, %r]
+import torch, torch.distributed as dist
+dist.init_process_group(backend='nccl')
+torch.cuda.set_device(0)
+calls = {'all_reduce': 0, 'broadcast': 0}
+real_ar, real_bc = dist.all_reduce, dist.broadcast
+def ar(*a, **k):
+    calls['all_reduce'] += 1
+    return real_ar(*a, **k)
+def bc(*a, **k):
+    calls['broadcast'] += 1
+    return real_bc(*a, **k)
+dist.all_reduce, dist.broadcast = ar, bc
+import _seeded
+from models import build_model_from_cfg
+from utils.config import builtin_cfg
+from upp_hip.train import TrainStep, freeze_for_peft
+m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda().train()
+freeze_for_peft(m)
+ts = TrainStep(m, (4, 1096, 3), use_graph=True)
+assert ts.distributed
+x = _seeded.noisy_clouds(4, 1024, seed=0).cuda(); y = torch.tensor([1, 2, 3, 4], device='cuda')
+l0 = float(ts.step(x, y)); l1 = float(ts.step(x, y))
+torch.cuda.synchronize()
+assert calls['broadcast'] > 100 and calls['all_reduce'] == 2, calls
+assert l0 == l0 and l1 == l1
+print('OK', calls)
+""" % (root, os.path.join(root, "iccv2025-upp_amd"), os.path.join(root, "tests"))
+    env = dict(os.environ, UPP_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
+
+
 def test_learning_rate_changes_reach_a_captured_step():
     """lr / weight decay were by-value kernel arguments frozen into the optimizer graph."""
     import _seeded
