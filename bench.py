@@ -729,6 +729,17 @@ def selftest_launch(args, world):
     return 0
 
 
+_STDOUT_FD = []          # the real stdout of a distributed run (see main)
+
+
+def emit(line):
+    """The run's ONE line on the real stdout."""
+    sys.stdout.flush()
+    if _STDOUT_FD:
+        os.dup2(_STDOUT_FD.pop(), 1)
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -769,6 +780,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_rank %= max(torch.cuda.device_count(), 1)       # (rehearsals with more ranks than GPUs share a device)
     if distributed:
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line there.  File
+        # descriptor 1 points at stderr from here until the line is printed (emit()).
+        sys.stdout.flush()
+        _STDOUT_FD.append(os.dup(1))
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         # RCCL ("nccl") over xGMI; UPP_DIST_BACKEND=gloo only to rehearse the N > 1 code path on a one-GPU box
@@ -828,7 +844,7 @@ def main():
                     "how": "launch list recorded from an eager step, replayed in step order as one HIP graph (own weight per launch), HIP "
                            "events on the launch stream",
                     "by_shape": shapes[:14]}
-        print(json.dumps({
+        emit({
             "metric": "point-clouds/sec fwd+bwd, secondary recipe '%s'" % args.workload,
             "value": args.batch * world * args.steps / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -836,7 +852,7 @@ def main():
             "config": {"workload": tr.workload, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph,
                        "pipeline": "front-end(k+1) || back-end(k) on two streams" if pipeline else "none"},
-            "roofline": roof}))
+            "roofline": roof})
     rccl_ranks = 0
     if distributed and backend == "nccl" and args.workload == "cls":
         # "rccl_ranks": only after RCCL has summed a buffer of the gradient all-reduce's size across the ranks and every rank saw the sum
@@ -916,7 +932,7 @@ def main():
             line["kernels"] = stages
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(batch=args.batch)
-        print(json.dumps(line))
+        emit(line)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

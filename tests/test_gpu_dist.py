@@ -165,6 +165,8 @@ def test_bench_runs_the_distributed_path_over_rccl_with_one_rank(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["dist_backend"] == "nccl" and rec["rccl_ranks"] == 1 and rec["value"] > 0
+    # RCCL's version banner goes to stdout when the first communicator comes up: the line must still be the ONLY thing there
+    assert [l for l in out.stdout.splitlines() if l.strip()] == [l for l in out.stdout.splitlines() if l.startswith("{")] and out.stdout.count("\n") == 1
 
 
 def test_gradient_all_reduce_and_model_broadcast_run_over_a_one_rank_rccl_group(tmp_path):
