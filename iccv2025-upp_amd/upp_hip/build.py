@@ -46,6 +46,11 @@ def build(force=False, verbose=True):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "..", "include", "upp_hip.h"))
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    # the objects on disk belong to ONE flag list: another UPP_HIPCC_FLAGS (an A/B or sweep build) recompiles everything, and so does the way back
+    flags_now = " ".join(FLAGS + os.environ.get("UPP_HIPCC_FLAGS", "").split())
+    stamp = os.path.join(OBJ, "flags.txt")
+    if not (os.path.exists(stamp) and open(stamp).read() == flags_now):
+        force = True
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
@@ -66,6 +71,8 @@ def build(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs]
     if force or jobs or _newer(LIB, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

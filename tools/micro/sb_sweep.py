@@ -49,15 +49,23 @@ SHAPES = [(32, 96, 384), (32, 256, 256), (32, 256, 768), (32, 384, 512), (32, 51
           (2400, 384, 384), (2400, 384, 1152), (2400, 384, 1536), (2400, 1152, 384), (2400, 1536, 384),
           (4096, 384, 128), (4096, 384, 384), (4096, 384, 1152), (4096, 384, 1536), (4096, 1152, 384), (4096, 1152, 1536), (4096, 1536, 384), (4096, 1536, 1152),
           (4128, 384, 384), (4128, 384, 1152), (4128, 384, 1536), (4128, 1152, 384), (4128, 1536, 384)]
-if len(sys.argv) > 1:
-    SHAPES = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]]
+EPI = []
+if len(sys.argv) > 1:                       # MxNxK or MxNxK:e (epilogue code of include/upp_hip.h: 1 bias, 2 bias + GELU, 3 bias + GELU + GELU', 4 multiply)
+    SHAPES = []
+    for a in sys.argv[1:]:
+        dims, _, e = a.partition(':')
+        SHAPES.append(tuple(int(v) for v in dims.split('x')))
+        EPI.append(int(e or 0))
 ALL = []
-for (M, N, K) in SHAPES:
+for si, (M, N, K) in enumerate(SHAPES):
     ops_ = []
     for _ in range(N_CHAIN):
         a = torch.randn(M, K, device=dev)
         w = (torch.randn(N, K, device=dev) * 0.05).requires_grad_(False)
         ops_.append((a, ops.PLANES.get(w), w, torch.empty(M, N, device=dev)))
+    epi = EPI[si] if EPI else 0
+    bias = torch.randn(N, device=dev) if epi in (1, 2, 3) else None
+    auxs = [torch.randn(M, N, device=dev) for _ in range(N_CHAIN)] if epi in (3, 4) else [None] * N_CHAIN
     res = []
     for t in configs():
         bmb, bnb, ks, nst = (t >> 16) & 15, (t >> 12) & 15, (t >> 4) & 15, t & 15
@@ -68,17 +76,17 @@ for (M, N, K) in SHAPES:
             continue
 
         def chain():
-            for (a, planes, w, c) in ops_:
-                ops._call(dev, "upp_linear_sb_f32", _abi.ptr(a), a.stride(0), _abi.ptr(planes), None, _abi.ptr(c), N, None, N, M, N, K, 0, t)
+            for (a, planes, w, c), x in zip(ops_, auxs):
+                ops._call(dev, "upp_linear_sb_f32", _abi.ptr(a), a.stride(0), _abi.ptr(planes), _abi.ptr(bias), _abi.ptr(c), N, _abi.ptr(x), N, M, N, K, epi, t)
         try:
             res.append((timed(chain) / N_CHAIN, t, wgs))
         except RuntimeError:
             pass
     res.sort()
-    ALL.append({"M": M, "N": N, "K": K, "shipped": ops.linear_sb_tile(M, N, K), "us": {"%x" % t: us for us, t, _ in res}})
+    ALL.append({"M": M, "N": N, "K": K, "epilogue": epi, "shipped": ops.linear_sb_tile(M, N, K), "us": {"%x" % t: us for us, t, _ in res}})
     shipped = ops.linear_sb_tile(M, N, K)
     ship_t = [r for r in res if r[1] == shipped]
-    print("%5d x %4d x %4d  shipped %x %s | " % (M, N, K, shipped, ("%.1f us" % ship_t[0][0]) if ship_t else "-")
+    print("%5d x %4d x %4d e%d  shipped %x %s | " % (M, N, K, epi, shipped, ("%.1f us" % ship_t[0][0]) if ship_t else "-")
           + "  ".join("%x %.1f (%d wg)" % (t, us, wgs) for us, t, wgs in res[:6]), flush=True)
 import json
 json.dump(ALL, open(os.path.join(ROOT, "gpurun_out", "r05", os.environ.get("SB_SWEEP_OUT", "sb_sweep.json")), "w"))
