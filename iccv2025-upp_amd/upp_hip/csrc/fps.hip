@@ -68,15 +68,23 @@ struct FpsGeom {
     int U;         // virtual threads per lane = max(1, T / L)
 };
 
-template <int S, int W, bool USE_LDS>
-__global__ __launch_bounds__(64 * W) void fps_kernel(const float *__restrict__ xyz, int32_t *__restrict__ idx,
-                                                     float *__restrict__ centers, FpsGeom g) {
+// CPW clouds per workgroup (round 5): the W waves of cloud blockIdx.x * CPW + c are waves c W ... c W + W - 1, with their own LDS region;
+// the per-round barrier spans the workgroup (every cloud runs the same M - 1 rounds).  Nothing else changes -- a cloud's waves never
+// look at another cloud's records -- so the indices are those of CPW = 1.  Why: 32 clouds on 32 CUs keep a one-round GEMM of the other
+// stream (228 workgroups on 256 CUs) from fitting, and every such GEMM then runs two rounds for as long as FPS is resident (back-end
+// chain 3.26 -> 3.61 ms beside 0.8 ms of FPS: tools/micro/fps_beside_backend.py); 8 CUs leave room.
+template <int S, int W, bool USE_LDS, int CPW = 1>
+__global__ __launch_bounds__(64 * W * CPW) void fps_kernel(const float *__restrict__ xyz, int32_t *__restrict__ idx,
+                                                           float *__restrict__ centers, FpsGeom g) {
     static_assert(S % 2 == 0, "slots are processed in packed pairs");
+    static_assert(CPW == 1 || USE_LDS, "several clouds per workgroup: the LDS form only");
     constexpr int L = 64 * W;
-    extern __shared__ float lds[];  // 2*W*2 words of wave records, a [3*N] copy of the cloud, then the M winners
+    extern __shared__ float lds_all[];  // per cloud: 2*W*2 words of wave records, a [3*N] copy of the cloud, then the M winners
     const int N = g.N, M = g.M;
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x;
+    const int cslot = CPW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / L) : 0;
+    const int tid = (int)threadIdx.x - cslot * L;
+    const int b = blockIdx.x * CPW + cslot;
+    float *lds = lds_all + (size_t)cslot * (size_t)((4 * W + 3 * N + M + 3) / 4 * 4);
     const float *p = xyz + (size_t)b * N * 3;
     uint32_t *rec = reinterpret_cast<uint32_t *>(lds);
     float *cloud = lds + 4 * W;
@@ -289,10 +297,27 @@ int fps_block_size(int n) {
     return t;
 }
 
+// UPP_FPS_CPW = 1 | 2 | 4 (read once): clouds per workgroup for the 4-wave kernels (default UPP_FPS_CPW_DEFAULT)
+#ifndef UPP_FPS_CPW_DEFAULT
+#define UPP_FPS_CPW_DEFAULT 1
+#endif
+inline int fps_clouds_per_wg() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("UPP_FPS_CPW"); v = e ? atoi(e) : UPP_FPS_CPW_DEFAULT; if (v != 2 && v != 4) v = 1; }
+    return v;
+}
+
+// UPP_FPS_EXCL=1 (read once): a packed launch asks for the whole LDS of its CU, so that no workgroup of another kernel shares the CU
+inline bool fps_exclusive() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("UPP_FPS_EXCL"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 constexpr int kFpsLdsBytes = 160 * 1024 - 256;  // cloud copy + winner list + wave records must fit the CU's LDS
 
 template <int S, int W>
-int launch(const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom &g, hipStream_t st) {
+int launch(const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom &g, int form, hipStream_t st) {
     const size_t lds_bytes = (size_t)(4 * W + 3 * g.N + g.M) * 4;
 #ifdef UPP_FPS_DIAG_NOLDS
     if (false) {
@@ -308,6 +333,32 @@ int launch(const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom 
                 raised = true;
             }
         }
+        // clouds per workgroup: as many of {4, 2} as divide B and fit 1,024 threads and the LDS (W = 4, the shapes of the recipes: S <= 8)
+        if constexpr (W == 4 && S <= 8) {
+            const size_t stride = (size_t)((4 * W + 3 * g.N + g.M + 3) / 4 * 4) * 4;
+            const int want = (form & 0xF) ? (form & 0xF) : fps_clouds_per_wg();        // (the caller's form, or the environment's)
+            const bool excl = (form & 0xF) ? (form & 0x10) != 0 : fps_exclusive();
+            if (want >= 4 && B % 4 == 0 && 4 * stride <= (size_t)kFpsLdsBytes) {
+                static std::atomic<bool> raised4{false};
+                if (!raised4) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fps_kernel<S, W, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kFpsLdsBytes);
+                    if (e != hipSuccess) return (int)e;
+                    raised4 = true;
+                }
+                hipLaunchKernelGGL((fps_kernel<S, W, true, 4>), dim3(B / 4), dim3(64 * W * 4), excl ? (size_t)kFpsLdsBytes : 4 * stride, st, xyz, idx, centers, g);
+                return upp_launch_status();
+            }
+            if (want >= 2 && B % 2 == 0 && 2 * stride <= (size_t)kFpsLdsBytes) {
+                static std::atomic<bool> raised2{false};
+                if (!raised2) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fps_kernel<S, W, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kFpsLdsBytes);
+                    if (e != hipSuccess) return (int)e;
+                    raised2 = true;
+                }
+                hipLaunchKernelGGL((fps_kernel<S, W, true, 2>), dim3(B / 2), dim3(64 * W * 2), excl ? (size_t)kFpsLdsBytes : 2 * stride, st, xyz, idx, centers, g);
+                return upp_launch_status();
+            }
+        }
         hipLaunchKernelGGL((fps_kernel<S, W, true>), dim3(B), dim3(64 * W), lds_bytes, st, xyz, idx, centers, g);
     } else {
         hipLaunchKernelGGL((fps_kernel<S, W, false>), dim3(B), dim3(64 * W), (size_t)(4 * W) * 4, st, xyz, idx, centers, g);
@@ -316,18 +367,18 @@ int launch(const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom 
 }
 
 template <int W>
-int dispatch_s(int slots, const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom &g, hipStream_t st) {
-    if (slots <= 2) return launch<2, W>(xyz, idx, centers, B, g, st);
-    if (slots <= 4) return launch<4, W>(xyz, idx, centers, B, g, st);
-    if (slots <= 6) return launch<6, W>(xyz, idx, centers, B, g, st);
-    if (slots <= 8) return launch<8, W>(xyz, idx, centers, B, g, st);
-    if (slots <= 10) return launch<10, W>(xyz, idx, centers, B, g, st);
-    if (slots <= 12) return launch<12, W>(xyz, idx, centers, B, g, st);
-    if (slots <= 16) return launch<16, W>(xyz, idx, centers, B, g, st);
-    if (slots <= 20) return launch<20, W>(xyz, idx, centers, B, g, st);
-    if (slots <= 24) return launch<24, W>(xyz, idx, centers, B, g, st);
-    if (slots <= 32) return launch<32, W>(xyz, idx, centers, B, g, st);
-    if (slots <= 64) return launch<64, W>(xyz, idx, centers, B, g, st);
+int dispatch_s(int slots, const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom &g, int form, hipStream_t st) {
+    if (slots <= 2) return launch<2, W>(xyz, idx, centers, B, g, form, st);
+    if (slots <= 4) return launch<4, W>(xyz, idx, centers, B, g, form, st);
+    if (slots <= 6) return launch<6, W>(xyz, idx, centers, B, g, form, st);
+    if (slots <= 8) return launch<8, W>(xyz, idx, centers, B, g, form, st);
+    if (slots <= 10) return launch<10, W>(xyz, idx, centers, B, g, form, st);
+    if (slots <= 12) return launch<12, W>(xyz, idx, centers, B, g, form, st);
+    if (slots <= 16) return launch<16, W>(xyz, idx, centers, B, g, form, st);
+    if (slots <= 20) return launch<20, W>(xyz, idx, centers, B, g, form, st);
+    if (slots <= 24) return launch<24, W>(xyz, idx, centers, B, g, form, st);
+    if (slots <= 32) return launch<32, W>(xyz, idx, centers, B, g, form, st);
+    if (slots <= 64) return launch<64, W>(xyz, idx, centers, B, g, form, st);
     return UPP_E_RANGE;
 }
 
@@ -335,6 +386,11 @@ int dispatch_s(int slots, const float *xyz, int32_t *idx, float *centers, int B,
 
 extern "C" int upp_fps_ex(const float *xyz, int32_t *idx, float *centers, int B, int N, int M, int waves, void *stream) {
     if (!xyz || !idx || B < 0 || N < 1 || M < 1) return UPP_E_BADARG;
+    // bits 8-11 of `waves`: clouds per workgroup (0: the library's default form, 1 / 2 / 4), bit 12: the launch reserves its CUs' whole LDS
+    const int cpw = (waves >> 8) & 0xF;
+    if ((waves & ~0x1FFF) || (cpw != 0 && cpw != 1 && cpw != 2 && cpw != 4)) return UPP_E_BADARG;
+    const int form = cpw | (((waves >> 12) & 1) << 4);
+    waves &= 0xFF;
     if (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8) return UPP_E_BADARG;
     if (N > 32768) return UPP_E_RANGE;  // 15-bit point ids, 64 slots x 512 lanes
     if (B == 0) return 0;
@@ -352,10 +408,10 @@ extern "C" int upp_fps_ex(const float *xyz, int32_t *idx, float *centers, int B,
     const int slots = g.U * g.Q;
     hipStream_t st = (hipStream_t)stream;
     switch (W) {
-        case 1: return dispatch_s<1>(slots, xyz, idx, centers, B, g, st);
-        case 2: return dispatch_s<2>(slots, xyz, idx, centers, B, g, st);
-        case 4: return dispatch_s<4>(slots, xyz, idx, centers, B, g, st);
-        default: return dispatch_s<8>(slots, xyz, idx, centers, B, g, st);
+        case 1: return dispatch_s<1>(slots, xyz, idx, centers, B, g, form, st);
+        case 2: return dispatch_s<2>(slots, xyz, idx, centers, B, g, form, st);
+        case 4: return dispatch_s<4>(slots, xyz, idx, centers, B, g, form, st);
+        default: return dispatch_s<8>(slots, xyz, idx, centers, B, g, form, st);
     }
 }
 

@@ -42,6 +42,29 @@ def _call(dev, name, *args):
 
 
 # ------------------------------------------------------------------ FPS / gather
+_FPS_FORM = [0]          # bits 8-12 of upp_fps_ex's `waves`: clouds per workgroup, whole-LDS reservation (see fps_form)
+
+
+class fps_form:
+    """with ops.fps_form(2, True): ... -- FPS launches inside pack `clouds` (1 / 2 / 4) clouds into a workgroup and, with `exclusive`, reserve
+    their CUs' whole LDS.  Same indices.  For a stream that runs BESIDE another one (the pipelined step's front-end): a 32-cloud FPS that
+    shares 32 CUs with the other stream's workgroups slows every one-round GEMM of that stream for as long as it is resident; 16 CUs of its own
+    cost the FPS 11 % and return 1.5 % of the step (tools/micro/fps_cpw_ab.sh).  Stand-alone the spread form is the faster one: the default."""
+
+    def __init__(self, clouds, exclusive=False):
+        if clouds not in (1, 2, 4):
+            raise ValueError("clouds per workgroup: 1, 2 or 4")
+        self.form = (int(clouds) << 8) | (0x1000 if exclusive else 0)
+
+    def __enter__(self):
+        self.prev = _FPS_FORM[0]
+        _FPS_FORM[0] = self.form
+
+    def __exit__(self, *exc):
+        _FPS_FORM[0] = self.prev
+        return False
+
+
 def fps(xyz, npoint, want_centers=False, waves=0):
     """(B,N,3) f32 -> idx (B,npoint) int32 [, centers (B,npoint,3)].  waves: wavefronts per cloud (0 = the library's choice).
     Precondition: finite coordinates (include/upp_hip.h upp_fps: with a NaN in a cloud the indices stay in range but need not be the
@@ -53,7 +76,7 @@ def fps(xyz, npoint, want_centers=False, waves=0):
     centers = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if want_centers else None
     if B == 0:                               # an empty batch: nothing to launch (an empty tensor has no device pointer to hand over)
         return (idx, centers) if want_centers else idx
-    _call(xyz.device, "upp_fps_ex", _abi.ptr(xyz), _abi.ptr(idx), _abi.ptr(centers), B, N, npoint, int(waves))
+    _call(xyz.device, "upp_fps_ex", _abi.ptr(xyz), _abi.ptr(idx), _abi.ptr(centers), B, N, npoint, int(waves) | _FPS_FORM[0])
     return (idx, centers) if want_centers else idx
 
 

@@ -406,6 +406,7 @@ class PipelinedTrainStep(TrainStep):
         # (stream priorities do not help: round 2 5.89-5.92 ms for -1 / 0; round 5: front-end stream at high priority 4.58 against 4.54-4.55 ms,
         #  the whole driver on a high-priority stream of its own 4.83-4.84 against 4.63-4.64; the runtime offers no priority BELOW normal)
         self.s_front = torch.cuda.Stream(device=self.device)
+        self._fps_form = (1, False) if os.environ.get("UPP_PIPE_FPS_FORM") == "0" else (2, True)
         from models import upp_layers as _L
         self._L = _L
         self._gen_front = torch.Generator(device=self.device)          # the front-end's own random stream (see upp_layers.use_rng)
@@ -428,7 +429,8 @@ class PipelinedTrainStep(TrainStep):
 
     # -- the three parts of a step -----------------------------------------------------------
     def _front(self, p):
-        with torch.no_grad(), self._L.use_rng(self._bank_front):
+        # (the front-end runs beside the back-end: its FPS launches keep to CUs of their own -- ops.fps_form; UPP_PIPE_FPS_FORM=0: the spread form)
+        with torch.no_grad(), self._L.use_rng(self._bank_front), HF.ops.fps_form(*self._fps_form):
             if self.front_fn is not None:
                 state = self.front_fn(self.model, self.pts)
             else:

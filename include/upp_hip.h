@@ -52,8 +52,13 @@ const char *upp_error_string(int code);
  * Limits: 1 <= M, 1 <= N <= 32768. */
 int upp_fps(const float *xyz, int32_t *idx, float *centers,
             int B, int N, int M, void *stream);
-/* the same with the number of wavefronts per cloud forced (waves in {1,2,4,8}; 0 = the
- * library's choice = upp_fps): identical results, for measurements and tests. */
+/* the same with the launch form forced: identical results.
+ *   bits 0-7 of `waves`: wavefronts per cloud (1, 2, 4, 8; 0 = the library's choice = upp_fps) -- for measurements and tests;
+ *   bits 8-11: clouds per workgroup (1, 2, 4; 0 = the default, one), bit 12: the launch reserves the whole LDS of the CUs it runs on.
+ *       Several clouds per workgroup (4-wave launches of at most 8 points per lane, B divisible by the count) put a 32-cloud call on 16 or
+ *       8 CUs instead of 32; with bit 12 no workgroup of another stream shares those CUs.  For callers that run FPS BESIDE another stream
+ *       (the pipelined training step): the call itself is 11-39 % slower, the other stream's one-round GEMMs are no longer slowed by the
+ *       workgroups they shared CUs with (tools/micro/fps_cpw_ab.sh).  Any other bit: UPP_E_BADARG. */
 int upp_fps_ex(const float *xyz, int32_t *idx, float *centers,
                int B, int N, int M, int waves, void *stream);
 

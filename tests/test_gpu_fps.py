@@ -3,7 +3,7 @@ import pytest
 import torch
 
 import _seeded
-from upp_hip import ops
+from upp_hip import _abi, ops
 
 
 @pytest.mark.gpu
@@ -61,3 +61,20 @@ def test_knn_and_chamfer_indices_are_bit_stable_beside_a_co_running_split_bf16_l
         torch.cuda.synchronize()
         for g_, r_ in zip(got, ref):
             assert torch.equal(g_, r_), it
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(32, 1228, 1024), (32, 1024, 64), (32, 1024, 256), (8, 2048, 512), (6, 1552, 1536), (4, 1096, 64), (3, 1024, 64)])
+@pytest.mark.parametrize("form", [(2, False), (2, True), (4, False), (4, True)])
+def test_fps_packed_forms_return_the_indices_of_the_spread_form(shape, form):
+    """ops.fps_form: 2 / 4 clouds per workgroup, with and without the whole-LDS reservation (the pipelined step's front-end uses (2, True)):
+    bit-identical indices and centres; a batch the count does not divide (B = 6 with 4, B = 3) takes the next smaller form."""
+    B, N, M = shape
+    g = torch.Generator(device='cuda').manual_seed(N + M)
+    x = torch.rand(B, N, 3, device='cuda', generator=g) * 2 - 1
+    ref, cref = ops.fps(x, M, want_centers=True)
+    with ops.fps_form(*form):
+        got, cgot = ops.fps(x, M, want_centers=True)
+    assert torch.equal(got, ref) and torch.equal(cgot, cref)
+    lib = _abi.load()
+    assert lib.upp_fps_ex(None, None, None, 1, 64, 8, 0x300, None) == -1 and lib.upp_fps_ex(None, None, None, 1, 64, 8, 0x2000, None) == -1
