@@ -417,6 +417,18 @@ def stage_report(device, B):
     flops = 2.0 * R * (128 * 256 + 256 * 512 + 512 * 384) + 2.0 * (R / 32) * 256 * 512 + 2.0 * R * 3 * 128
     out["patch_embed_chain"] = mfma("upp_patch_embed_fwd: 4 gemm_f32_kernel launches + BN finalize (R=%d)" % R, t, flops,
                                     "whole 7-launch chain; the three big GEMMs alone run at 82/99/106 TFLOP/s (profiles/)")
+    if ops.SPLIT_BF16 and os.environ.get("UPP_EMBED_SPLIT_BF16", "1") != "0":
+        # the chain is MIXED: its 256 -> 512 and 512 -> C products run on linear_sb_kernel (ceiling 419.4), the rest on the f32 matrix
+        # instruction (157.3).  One scale: peak = flops / (time of each part at the ceiling of ITS arithmetic), as the family's is priced
+        sb_fl = 2.0 * R * (256 * 512 + 512 * 384)
+        t_min = (flops - sb_fl) / MFMA_F32_PEAK_TF + sb_fl / SPLIT_BF16_PEAK_TF
+        e = out["patch_embed_chain"]
+        e["kernel"] = "upp_patch_embed_fwd: 2 gemm_f32_kernel + 2 linear_sb_kernel<8,4,4,1,2,{0,1}> launches + BN finalize (R=%d)" % R
+        e["peak"] = flops / t_min
+        e["frac_of_f32_mfma_peak"] = e["frac"]
+        e["frac"] = e["achieved"] / e["peak"]
+        e["note"] = ("mixed chain priced on one scale: peak = flops / (f32-MFMA part at 157.3 + split-bf16 part (%.0f %% of the flops) at "
+                     "419.4 TFLOP/s)" % (100.0 * sb_fl / flops))
     out["patch_embed_chain"]["traffic"] = traffic(["gemm_f32_kernel<2, 21>", "gemm_f32_kernel<0, 14>", "gemm_f32_kernel<0, 5>",
                                                    "gemm_f32_kernel<1, 17>", "bn_finalize_kernel<0>", "bn_finalize_kernel<1>"])
     tok = torch.randn(B, 65, 384, device=device)
@@ -732,12 +744,79 @@ def selftest_launch(args, world):
 _STDOUT_FD = []          # the real stdout of a distributed run (see main)
 
 
+LINE_BUDGET = 6000      # bytes: the driver keeps the last 8 KB of stdout + stderr; round 5's 22 KB line was cut and went unparsed
+DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
+_ROOF_KEEP = ("kernel", "bound", "ms", "launches", "achieved", "peak", "unit", "frac", "frac_of_f32_mfma_peak", "algorithmic_flops",
+              "algorithmic_bytes", "traffic", "traffic_over_algorithmic")
+_PROSE = ("dtype_note", "peak_note", "how", "traffic_note", "note")
+
+
+def compact_line(line, detail_path="bench_detail.json"):
+    """(stdout line, detail) of a full report.  The stdout line keeps the contract's keys, a compact `roofline` (scalars only; `kernel`
+    cut to 200 characters) and `cpu_baseline`; `kernels`, `roofline.by_shape`, `roofline.traffic_detail`, `roofline.block_layers` and the
+    prose notes go to the detail (bench_detail.json next to this script; `detail` names it).  tests/test_host.py asserts the budget."""
+    out = {k: v for k, v in line.items() if k not in ("kernels", "roofline") and k not in _PROSE}
+    roof = line.get("roofline")
+    if roof is not None:
+        c = {k: roof[k] for k in _ROOF_KEEP if k in roof}
+        if isinstance(c.get("kernel"), str) and len(c["kernel"]) > 200:
+            c["kernel"] = c["kernel"][:197] + "..."
+        fam = roof.get("traffic_detail") or {}
+        for k in ("algorithmic_bytes", "traffic_over_algorithmic"):
+            if k not in c and fam.get(k) is not None:
+                c[k] = fam[k]
+        l2 = roof.get("l2_to_lds")
+        if l2:
+            c["l2_to_lds"] = {"frac": l2["frac"], "achieved": l2["achieved"], "peak": l2["peak"], "unit": l2["unit"]}
+        out["roofline"] = c
+    elif "roofline" in line:
+        out["roofline"] = None
+    if line.get("kernels"):
+        # [ms, fraction of the kernel's roofline, bound] per main kernel -- BASELINE.json's metric also names "FPS+kNN HBM GB/s":
+        # fps_* / knn_* carry it as frac x 8,000 GB/s; everything else about a kernel is in the detail
+        brief = {k: [float("%.4g" % v["ms"]), float("%.4g" % v["frac"]), v.get("bound", "")] for k, v in line["kernels"].items()
+                 if isinstance(v, dict) and "ms" in v and "frac" in v}
+        if len(json.dumps(out)) + len(json.dumps(brief)) < LINE_BUDGET - 400:
+            out["kernels_brief"] = brief
+    if "kernels" in line or roof is not None:
+        out["detail"] = detail_path
+    # key order: the contract's keys first (a cut tail must lose the END of the line, never metric / value)
+    return out, line
+
+
 def emit(line):
-    """The run's ONE line on the real stdout."""
+    """The run's ONE line on the real stdout (compact, <= LINE_BUDGET bytes); the full report goes to bench_detail.json.  Nothing long is
+    written to stderr: the driver's record is the tail of stdout FOLLOWED by stderr, so a long stderr pushes the line out of it."""
+    compact, detail = compact_line(line, os.path.relpath(DETAIL_PATH, ROOT))
+    text = json.dumps(compact)
+    if len(text) > LINE_BUDGET:                      # (cannot happen with the keys above; keep the contract's keys whatever else grows)
+        compact.pop("roofline", None)
+        compact["roofline_dropped"] = "line over %d bytes: see detail" % LINE_BUDGET
+        text = json.dumps(compact)
+    try:
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(detail, f, indent=1)
+    except OSError as e:
+        print("bench.py: detail not written (%s)" % e, file=sys.stderr)
     sys.stdout.flush()
     if _STDOUT_FD:
         os.dup2(_STDOUT_FD.pop(), 1)
-    print(json.dumps(line), flush=True)
+    print(text, flush=True)
+
+
+def timed_repeats(step, fence, steps, repeats, reduce_max=None):
+    """`repeats` timings of EXACTLY `steps` steps each, every one bracketed by fence() (barrier + synchronize) on both sides and, for
+    N > 1, reduced to the max over ranks -> sorted list of seconds.  The line reports the median with min / max beside it."""
+    out = []
+    for _ in range(repeats):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        out.append(reduce_max(el) if reduce_max else el)
+    return sorted(out)
 
 
 def main():
@@ -746,9 +825,11 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--repeats", type=int, default=3, help="timings of --steps steps each; the line reports their median (min / max beside it)")
     ap.add_argument("--workload", default="cls", choices=["cls", "cls_aux", "stage2", "pretask", "pretrain", "seg"],
                     help="cls = the headline workload (default); the others are secondary recipes, see RecipeTrainer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail", default=None, help="where the full report goes (default: bench_detail.json next to this script)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay (debug)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the prompting front-end and the trainable back-end of a step one after the other (one stream)")
@@ -759,6 +840,9 @@ def main():
                     help="ranks only rendezvous, barrier and reduce a dummy time, rank 0 prints the JSON skeleton: checks the "
                          "--gpus N launcher and the process-group plumbing on a host without a GPU (tests/test_host.py)")
     args = ap.parse_args()
+    if args.detail:
+        global DETAIL_PATH
+        DETAIL_PATH = os.path.abspath(args.detail)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: start N ranks (one process per GPU) as CHILDREN of this process, which has
@@ -773,7 +857,11 @@ def main():
         # rehearsal on a one-GPU box: the N > 1 code path (process group, gradient all-reduce between the graph replays, barrier +
         # max-over-ranks timing, the RCCL probe) with a single rank -- RCCL itself initialises and runs its collectives
         distributed = True
-        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531")):
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))                      # a free port: two rehearsals on one box must not meet on a fixed one
+        port = sock.getsockname()[1]
+        sock.close()
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port))):
             os.environ.setdefault(k, v)
     if args.selftest_launch:
         return selftest_launch(args, world)
@@ -813,16 +901,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    def reduce_max(el):
+        if not distributed:
+            return el
+        t = torch.tensor([el], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        return t.item()
+
+    # `repeats` timings of exactly --steps steps each (barrier + synchronize on both sides, max over ranks); the line's figure is the
+    # MEDIAN, min / max beside it: boxes of the pool differ by up to 9 % and one timing of 20 steps is 90 ms
+    times = timed_repeats(tr.step, fence, args.steps, args.repeats, reduce_max)
+    elapsed = times[len(times) // 2]
+    timing = {"repeats": args.repeats, "ms_per_step_min": 1000.0 * times[0] / args.steps, "ms_per_step_max": 1000.0 * times[-1] / args.steps}
 
     if rank == 0 and args.workload != "cls":
         # secondary recipe: throughput + the roofline of its dominant kernel family (the exact-f32 MFMA Linear launches: forward, data
@@ -847,7 +937,7 @@ def main():
         emit({
             "metric": "point-clouds/sec fwd+bwd, secondary recipe '%s'" % args.workload,
             "value": args.batch * world * args.steps / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, **timing, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "dtype_note": DTYPE_NOTE, "data": "synthetic",
             "config": {"workload": tr.workload, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph,
@@ -866,7 +956,7 @@ def main():
         line = {
             "metric": "point-clouds/sec fwd+bwd, UPP/Point-MAE N=1024 G=64 k=32",
             "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1000.0 * elapsed / args.steps, **timing, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "dtype_note": DTYPE_NOTE, "data": "synthetic",
             "rccl_ranks": rccl_ranks, "dist_backend": backend,
             "config": {"workload": "Point_MAE_unify unify_modelnet_cls noisy-train fwd+bwd+AdamW, PEFT stage-1, "
@@ -882,12 +972,8 @@ def main():
                 seq = Trainer(device, args.batch, False, use_graph=not args.no_graph, pipeline=False)
                 for _ in range(max(args.warmup, 2)):
                     seq.step()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    seq.step()
-                torch.cuda.synchronize()
-                line["ms_per_step_sequential"] = 1000.0 * (time.perf_counter() - t1) / args.steps
+                ts_ = timed_repeats(seq.step, torch.cuda.synchronize, args.steps, args.repeats)
+                line["ms_per_step_sequential"] = 1000.0 * ts_[len(ts_) // 2] / args.steps
             elif not pipeline:
                 line["ms_per_step_sequential"] = line["ms_per_step"]
             flops, ms, n, shapes, sb_flops, calls = linear_family_replay(seq.ts, device)
