@@ -273,12 +273,6 @@ LINEAR_SHAPES = [("qkv", 2400, 1152, 384, 0), ("proj", 2400, 384, 384, 0), ("fc1
 # and data gradients), the rectify path's three blocks (35 tokens: M = 1120, forward only: GELU without its derivative) and the completion
 # prompter's four decoder blocks (64 tokens: M = 2048, forward only).  tools/prof_kernels.py launches each of them behind a marker and
 # tools/pmc_summary.py keys the counters 'linear:<label>'; roofline.traffic sums them over the step's launch list.
-# round 5: the projection with the residual add + row-block statistics in its epilogue (code 6) and fc1 with the LayerNorm in its A-prologue
-# (code 16 + epilogue) -- built, measured (kernels.linear_proj_resid / linear_fc1_ln_gelu_d below) and NOT the default: the prologue's 24
-# VALU instructions per k-step land on a loop that is already at the vector-issue limit (fc1 21.3 -> 26.3 us, more than the 5.6 us row
-# kernel it removes).  UPP_FUSE_RESID_LN=1 switches the fold on; the replay and the labels then follow the step's launch list.
-LIN_RESID, LIN_LN = 6, 16
-FOLD_SHAPES = [("proj_resid", 2400, 384, 384, LIN_RESID), ("fc1_ln_gelu_d", 2400, 1536, 384, LIN_LN + 3)]
 STEP_LINEAR_SHAPES = (LINEAR_SHAPES
                       + [("%s@2080" % lab, 2080, N, K, e) for lab, _, N, K, e in LINEAR_SHAPES]
                       + [("%s@%d" % (lab, M), M, N, K, e) for M in (1120, 2048)
@@ -294,11 +288,8 @@ def linear_label(M, N, K, epi):
 
 
 def linear_algorithmic_bytes(M, N, K, epi, split):
-    """A + W + C (+ the second (M,N) tensor of the GELU' / multiply / residual epilogues, the row-block statistics of the fold), f32; the
-    split-bf16 kernel reads W as three bf16 planes."""
-    base = epi - LIN_LN if epi >= LIN_LN else epi
-    extra = 8.0 * M * (N // 32) if epi == LIN_RESID else (8.0 * M * (K // 32) + 8.0 * M if epi >= LIN_LN else 0.0)
-    return 4.0 * (M * K + N * K + M * N * (2 if base in (3, 4, LIN_RESID) else 1)) + (2.0 * N * K if split else 0.0) + extra
+    """A + W + C (+ the second (M,N) tensor of the GELU' / multiply epilogues), f32; the split-bf16 kernel reads W as three bf16 planes."""
+    return 4.0 * (M * K + N * K + M * N * (2 if epi in (3, 4) else 1)) + (2.0 * N * K if split else 0.0)
 
 
 def sb_kernel_name(M, N, K, epi=0):
@@ -311,8 +302,7 @@ def sb_kernel_name(M, N, K, epi=0):
 def _kname(M, N, K, epi, sb):
     if not sb:
         return "linear_f32_kernel<%s>" % _abi_tile(M, N, K)
-    name = "linear_sb_kernel<%s>" % _sb_tile_str(sb)
-    return name[:-2] + "2>" if epi >= LIN_LN else name            # (PRO = 2: the LayerNorm prologue instantiation)
+    return "linear_sb_kernel<%s>" % _sb_tile_str(sb)
 
 
 def make_linear_operands(ops, M, N, K, e, device, gl, w=None):
@@ -322,21 +312,12 @@ def make_linear_operands(ops, M, N, K, e, device, gl, w=None):
         w._upp_persistent = True                # (stands for a frozen weight: ops.PLANES keeps its plane image)
     d = {"a": torch.randn(M, K, device=device, generator=gl), "w": w, "b": torch.randn(N, device=device, generator=gl),
          "x": torch.randn(M, N, device=device, generator=gl), "o": torch.empty(M, N, device=device)}
-    if e >= LIN_LN:
-        rows = d["a"].view(M, K // 32, 32)
-        s1 = rows.sum(-1)
-        d["stats"] = torch.stack([s1, ((rows - (s1 / 32).unsqueeze(-1)) ** 2).sum(-1)], dim=-1).contiguous()
-        d["gamma"], d["beta"] = torch.rand(K, device=device, generator=gl) + 0.5, torch.randn(K, device=device, generator=gl) * 0.1
     return d
 
 
 def run_linear(ops, d, M, N, K, e, sb, frozen=True):
     """One Linear launch of the step's list on the kernel variant the step used: plain / GELU / multiply epilogues (upp_linear_sb_f32 or
-    upp_linear_f32), the residual + statistics epilogue (code 6), the LayerNorm prologue (16 + epilogue)."""
-    if e == LIN_RESID:
-        return ops.linear_sb_resid(d["a"], ops.PLANES.get(d["w"]), (N, K), d["b"], d["x"], None, 1.0, 75)
-    if e >= LIN_LN:
-        return ops.linear_sb_ln(d["a"], d["stats"], d["gamma"], d["beta"], 1e-5, ops.PLANES.get(d["w"]), (N, K), d["b"], e - LIN_LN)
+    upp_linear_f32)."""
     return ops.linear_f32(d["a"], d["w"], d["b"] if e in (1, 2, 3, 5) else None, e, aux=d["x"] if e == ops.LIN_MUL else None, out=d["o"],
                           frozen=bool(sb) and frozen)
 
@@ -417,7 +398,7 @@ def stage_report(device, B):
     flops = 2.0 * R * (128 * 256 + 256 * 512 + 512 * 384) + 2.0 * (R / 32) * 256 * 512 + 2.0 * R * 3 * 128
     out["patch_embed_chain"] = mfma("upp_patch_embed_fwd: 4 gemm_f32_kernel launches + BN finalize (R=%d)" % R, t, flops,
                                     "whole 7-launch chain; the three big GEMMs alone run at 82/99/106 TFLOP/s (profiles/)")
-    if ops.SPLIT_BF16 and os.environ.get("UPP_EMBED_SPLIT_BF16", "1") != "0":
+    if ops.SPLIT_BF16 and ops.get_option("EMBED_SPLIT_BF16"):
         # the chain is MIXED: its 256 -> 512 and 512 -> C products run on linear_sb_kernel (ceiling 419.4), the rest on the f32 matrix
         # instruction (157.3).  One scale: peak = flops / (time of each part at the ceiling of ITS arithmetic), as the family's is priced
         sb_fl = 2.0 * R * (256 * 512 + 512 * 384)
@@ -510,14 +491,11 @@ def stage_report(device, B):
     # beside it, on the exact-f32 kernel (csrc/linear.hip)
     gl = torch.Generator(device=device).manual_seed(11)
     missing = []
-    for label, M, N, K, epi in LINEAR_SHAPES + FOLD_SHAPES:
+    for label, M, N, K, epi in LINEAR_SHAPES:
         d = make_linear_operands(ops, M, N, K, epi, device, gl)
         sb = ops.linear_sb_tile(M, N, K) if ops.SPLIT_BF16 else 0
-        if epi in (LIN_RESID,) or epi >= LIN_LN:
-            if not sb or (epi >= LIN_LN and not ops.linear_sb_ln_usable(M, N, K)):
-                continue
         t = time_kernel(lambda: run_linear(ops, d, M, N, K, epi, sb))
-        t32 = time_kernel(lambda: run_linear(ops, d, M, N, K, epi, sb, frozen=False)) if epi < LIN_RESID else None
+        t32 = time_kernel(lambda: run_linear(ops, d, M, N, K, epi, sb, frozen=False))
         kname = _kname(M, N, K, epi, sb)
         out["linear_" + label] = mfma("%s %s: (%d,%d) x (%d,%d)^T, epilogue %d" % (kname, label, M, K, N, K, epi), t, 2.0 * M * N * K, split=bool(sb))
         e = out["linear_" + label]
@@ -525,9 +503,7 @@ def stage_report(device, B):
             e["ms_exact_f32_kernel"] = t32
         e["algorithmic_bytes"] = linear_algorithmic_bytes(M, N, K, epi, bool(sb))
         e["traffic"] = pmc_linear_entry(pmc_raw, label, kname)
-        if e["traffic"] is None and epi >= LIN_RESID:
-            e["note"] = "fold variant (UPP_FUSE_RESID_LN=1), timed for the record; not launched by the default step, no counters taken"
-        elif e["traffic"] is None:
+        if e["traffic"] is None:
             missing.append("linear:%s (%s)" % (label, kname))
         else:
             e["traffic_over_algorithmic"] = e["traffic"] / e["algorithmic_bytes"]

@@ -751,22 +751,10 @@ class Block(nn.Module):
                 and isinstance(self.norm1, nn.LayerNorm) and self.mlp.drop.p == 0 and self.attn.proj_drop.p == 0
                 and x.shape[1] + 16 <= 144)
 
-    def head_spec(self, pos, kw):
-        """What the PREVIOUS block's tail needs to compute this block's head in its own launch (HF.ln_adapter next_head):
-        (add, prompts, row map, prompt count, norm1)."""
-        path = kw['path']
-        prompts = getattr(self, f'{path}_prompts', None) if path in _PATHS else None
-        P = 0 if prompts is None else prompts.shape[0]
-        ins = (HF.ROW_INSERT_CLS if kw.get('classification') else HF.ROW_INSERT) if P else HF.ROW_IDENTITY
-        return (pos, prompts, ins, P, self.norm1)
-
-    def forward_fused(self, x, pos, next_head=None, pre_head=None, **kw):
+    def forward_fused(self, x, pos, **kw):
         """Same function as forward(x + pos, **kw); the element-wise glue runs in the row kernels of
         csrc/block.hip (pos add + prompt insert + norm1 | drop-path residual + norm2 | drop-path residual
-        + prompt strip + adapter LayerNorm) and the attention core in attn_fwd/bwd.
-        next_head (round 5): the next block's head_spec -- its head is then computed by this block's tail launch and returned as the
-        second element of a pair (out, pre) (pre None when this block's tail is not the fused one); pre_head: what the previous block
-        returned for THIS block (its head is then not launched)."""
+        + prompt strip + adapter LayerNorm) and the attention core in attn_fwd/bwd."""
         path = kw['path']
         is_cls = bool(kw.get('classification', False))
         prompts = getattr(self, f'{path}_prompts', None) if path in _PATHS else None
@@ -774,8 +762,6 @@ class Block(nn.Module):
         P = 0 if prompts is None else prompts.shape[0]
         ins = (HF.ROW_INSERT_CLS if is_cls else HF.ROW_INSERT) if P else HF.ROW_IDENTITY
         rem = (HF.ROW_STRIP_CLS if is_cls else HF.ROW_STRIP) if P else HF.ROW_IDENTITY
-        want_pair = next_head is not None
-        done = (lambda out, pre=None: (out, pre)) if want_pair else (lambda out, pre=None: out)
         u = None
         keep = 1.0
         if isinstance(self.drop_path, DropPath) and self.training and self.drop_path.drop_prob > 0:
@@ -785,7 +771,7 @@ class Block(nn.Module):
         attn, mlp = self.attn, self.mlp
         fused_attn = _frozen_bias(attn.proj) and attn.proj_drop.p == 0
         xa, h1 = HF.rowln(x, add=pos, prompts=prompts, mode=ins, P=P, gamma=n1.weight, beta=n1.bias, eps=n1.eps,
-                          cls_add=kw.get('_cls_pos'), pre=pre_head)
+                          cls_add=kw.get('_cls_pos'))
         # The four Linear layers run on upp_linear_f32 (csrc/linear.hip).  Frozen output biases ride along in the row kernel
         # that consumes the GEMM result (proj.bias, fc2.bias); fc1's bias, the GELU and -- for backward -- GELU' are the
         # epilogue of the fc1 GEMM, and the fc2 data gradient multiplies by that GELU' in its own epilogue.
@@ -794,20 +780,13 @@ class Block(nn.Module):
         fused_mlp = (_frozen_bias(fc1) and _frozen_bias(fc2) and isinstance(mlp.act, nn.GELU) and mlp.act.approximate == 'none'
                      and HF.linear_usable(xa, fc1.weight) and fc1.out_features % 32 == 0 and _no_grad_needed(fc1.weight, fc2.weight))
         u0 = None if u is None else u[0]
-        x2 = h2 = None
         if fused_attn:
             qkv = HF.linear(h1, attn.qkv.weight, attn.qkv.bias)
             ctx = HF.attention(qkv, attn.num_heads, attn.scale)
-            if fused_mlp and POOL_TRACE is None and HF.proj_resid_ln_usable(ctx, attn.proj.weight, attn.proj.bias, xa, n2, fc1.weight):
-                # round 5: the residual add rides in the projection GEMM's epilogue (with the row-block statistics of norm2) and norm2 itself
-                # in the A-prologue of fc1 -- no row kernel between the two GEMMs (h2 is a handle, never written)
-                x2, h2 = HF.proj_resid_ln(ctx, attn.proj.weight, attn.proj.bias, xa, u0, keep, n2)
-            else:
-                y, yb = HF.linear(ctx, attn.proj.weight), attn.proj.bias
+            y, yb = HF.linear(ctx, attn.proj.weight), attn.proj.bias
         else:
             y = attn(h1)
-        if x2 is None:
-            x2, h2 = HF.rowln(xa, y=y, ybias=yb, u=u0, keep=keep, gamma=n2.weight, beta=n2.bias, eps=n2.eps)
+        x2, h2 = HF.rowln(xa, y=y, ybias=yb, u=u0, keep=keep, gamma=n2.weight, beta=n2.bias, eps=n2.eps)
         if fused_mlp:
             m, mb = HF.mlp_gelu(h2, fc1.weight, fc1.bias, fc2.weight), fc2.bias
         elif _frozen_bias(fc1) and _frozen_bias(fc2) and isinstance(mlp.act, nn.GELU) and fc1.out_features % 4 == 0:
@@ -830,30 +809,22 @@ class Block(nn.Module):
             m, mb, u2, x2 = None, None, None, x3
         if adapter is None:
             x4, _ = HF.rowln(x2, y=m, ybias=mb, u=u2, keep=keep, mode=rem, P=P)
-            return done(x4)
+            return x4
         ln = adapter.layer_norm
         if D == 384 and adapter.ln1.weight.shape[0] == 32 and isinstance(adapter.activate, nn.GELU) and FUSE_LN_ADAPTER:
             # one launch: residual + strip + the adapter's LayerNorm + the adapter (csrc/adapter.hip ln_adapter_fwd_kernel)
             pd = adapter.dropout.p if self.training else 0.0
             Lo = x2.shape[1] - (P if rem != HF.ROW_IDENTITY else 0)
             ud = UNIFORMS.take((B * Lo, 32), x.device) if pd > 0 else None
-            nh = None
-            if want_pair and HF.FUSE_NEXT_HEAD and POOL_TRACE is None:
-                add2, prm2, mode2, P2, n1n = next_head
-                # (the next head in this launch: its rows are the output rows + pos, its prompts are spread over the waves of a sample)
-                if (isinstance(n1n, nn.LayerNorm) and n1n.elementwise_affine and n1n.bias is not None and (add2 is None or tuple(add2.shape) == (B, Lo, D))
-                        and Lo >= P2 + (1 if mode2 == HF.ROW_INSERT_CLS else 0) and (add2 is None or add2.dtype == torch.float32)):
-                    nh = next_head
-            res = HF.ln_adapter(x2, m, mb, u2, keep, rem, P, ln, adapter.ln1.weight, adapter.ln1.bias, adapter.ln2.weight,
-                                adapter.ln2.bias, ud, pd, 0.7, next_head=nh)
-            return res if (nh is not None or not want_pair) else (res, None)
+            return HF.ln_adapter(x2, m, mb, u2, keep, rem, P, ln, adapter.ln1.weight, adapter.ln1.bias, adapter.ln2.weight,
+                                 adapter.ln2.bias, ud, pd, 0.7)
         x4, ha = HF.rowln(x2, y=m, ybias=mb, u=u2, keep=keep, mode=rem, P=P, gamma=ln.weight, beta=ln.bias, eps=ln.eps)
         if D == 384 and adapter.ln1.weight.shape[0] == 32 and isinstance(adapter.activate, nn.GELU):
             pd = adapter.dropout.p if self.training else 0.0
             ud = UNIFORMS.take((x4.shape[0] * x4.shape[1], 32), x.device) if pd > 0 else None
-            return done(HF.adapter(ha, x4, adapter.ln1.weight, adapter.ln1.bias, adapter.ln2.weight, adapter.ln2.bias, ud, pd, 0.7))
+            return HF.adapter(ha, x4, adapter.ln1.weight, adapter.ln1.bias, adapter.ln2.weight, adapter.ln2.bias, ud, pd, 0.7)
         z = adapter.ln2(adapter.dropout(adapter.activate(adapter.ln1(ha))))
-        return done(torch.add(x4, z, alpha=0.7))
+        return torch.add(x4, z, alpha=0.7)
 
     def forward(self, x, **kw):
         path = kw['path']
@@ -892,19 +863,9 @@ def _make_blocks(embed_dim, depth, num_heads, mlp_ratio, qkv_bias, qk_scale, dro
 
 def _run_blocks(blocks, x, pos_i, kwargs, features):
     """The block loop of the encoder / decoder (reference models/Point_MAE_unify.py:288-294, models/Point_MAE_pretask_dev.py:374-377):
-    `pos` is added in front of every block.  A fused block's tail launch also computes the head of the next fused block (its `pre`)."""
-    pre = None
-    n = len(blocks)
+    `pos` is added in front of every block."""
     for idx, block in enumerate(blocks):
-        if not block.fusable(x):
-            x, pre = block(x + pos_i[idx], **kwargs), None
-        else:
-            nxt = blocks[idx + 1] if idx + 1 < n else None
-            nh = nxt.head_spec(pos_i[idx + 1], kwargs) if (nxt is not None and x.is_cuda and x.shape[-1] == 384 and HF.FUSE_NEXT_HEAD) else None
-            if nh is not None:
-                x, pre = block.forward_fused(x, pos_i[idx], next_head=nh, pre_head=pre, **kwargs)
-            else:
-                x, pre = block.forward_fused(x, pos_i[idx], pre_head=pre, **kwargs), None
+        x = block.forward_fused(x, pos_i[idx], **kwargs) if block.fusable(x) else block(x + pos_i[idx], **kwargs)
         if features is not None and idx in (3, 7, 11):
             features.append(x)
     return x

@@ -18,6 +18,8 @@ _c_i = ctypes.c_int
 SIGNATURES = {
     "upp_abi_version": (_c_i, []),
     "upp_error_string": (ctypes.c_char_p, [_c_i]),
+    "upp_set_option": (_c_i, [_c_i, _c_i]),
+    "upp_get_option": (_c_i, [_c_i]),
     "upp_fps": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f]),
     "upp_fps_ex": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_gather_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
@@ -76,8 +78,6 @@ SIGNATURES = {
     "upp_adapter_part_floats": (ctypes.c_longlong, [_c_i, _c_i]),
     "upp_adapter_fwd": (_c_i, [_c_f] * 7 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
     "upp_adapter_bwd": (_c_i, [_c_f] * 6 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
-    "upp_ln_adapter_fwd_next": (_c_i, [_c_f] * 4 + [ctypes.c_float, _c_i, _c_i, _c_f, _c_f, ctypes.c_float] + [_c_f] * 5 + [ctypes.c_float] * 2
-                                + [_c_f] * 5 + [_c_i] * 5 + [_c_f, _c_f, _c_i, _c_i, _c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_f] + [_c_f]),
     "upp_ln_adapter_fwd": (_c_i, [_c_f] * 4 + [ctypes.c_float, _c_i, _c_i, _c_f, _c_f, ctypes.c_float] + [_c_f] * 5 + [ctypes.c_float] * 2
                            + [_c_f] * 5 + [_c_i] * 5 + [_c_f]),
     "upp_ln_adapter_bwd": (_c_i, [_c_f] * 10 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
@@ -100,11 +100,6 @@ SIGNATURES = {
     "upp_linear_sb_prep_batched": (_c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_longlong)] + [ctypes.POINTER(ctypes.c_int)] * 3
                                    + [ctypes.POINTER(ctypes.c_void_p), _c_i, _c_f]),
     "upp_linear_sb_group_bias_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
-    "upp_linear_sb_ln_usable": (_c_i, [_c_i, _c_i, _c_i]),
-    "upp_linear_sb_ln_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_i, _c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_longlong, _c_f,
-                                    ctypes.c_longlong, _c_i, _c_i, _c_i, _c_i, _c_f]),
-    "upp_linear_sb_resid_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_f, ctypes.c_longlong, _c_f, ctypes.c_float, _c_i, _c_f, ctypes.c_longlong, _c_f,
-                                       _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_linear_sb_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong] + [_c_i] * 5 + [_c_f]),
     "upp_linear_group_bias_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
     "upp_linear_smallk_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_f, ctypes.c_longlong] + [_c_i] * 4 + [_c_f]),
@@ -127,7 +122,8 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 4            # include/upp_hip.h UPP_ABI_VERSION
+OPTIONS = {"SB_TUNED": 0, "SB_XCD2D": 1, "STORE_WT": 2, "EMBED_SPLIT_BF16": 3}      # include/upp_hip.h UPP_OPT_*
+ABI_VERSION = 5            # include/upp_hip.h UPP_ABI_VERSION
 
 
 def load():
@@ -146,6 +142,14 @@ def load():
         fn.argtypes = args
     if lib.upp_abi_version() != ABI_VERSION:
         raise RuntimeError("libupp_hip.so ABI version mismatch")
+    # The library never reads the environment (include/upp_hip.h "options"); the A/B scripts under tools/ set these variables, and the
+    # host forwards them ONCE, here.  Inside a process use ops.option(name, value).
+    for name, key in OPTIONS.items():
+        v = os.environ.get("UPP_" + name)
+        if v is not None and v.strip().lstrip("-").isdigit():
+            rc = lib.upp_set_option(key, int(v))
+            if rc != 0:
+                raise RuntimeError("UPP_%s=%s: %s" % (name, v, lib.upp_error_string(rc).decode()))
     _lib = lib
     return lib
 

@@ -347,13 +347,6 @@ struct LnAdapterArgs {
     float *xo, *mean, *rstd, *s1, *out;
     int B, Lin, Lout;
     int yparts; long long ystride;      // y = sum of yparts partial matrices ystride floats apart (upp_linear_parts_f32), added in order
-    // round 5 -- the HEAD of the next block in the same launch (nx_xo != null): what upp_rowln_fwd would compute from `out`,
-    //   rows2[b][t2] = out[b][t] + nx_add[b][t]  (t2 = t, or t + nx_P behind / in front of the inserted prompts: nx_mode 0 / 1 / 2),
-    //   rows2[b][prompt slot p] = nx_prompts[p];   nx_xo = rows2, nx_h = LayerNorm(rows2; nx_gamma, nx_beta), nx_mean / nx_rstd (B Lnx)
-    const float *nx_add, *nx_prompts, *nx_gamma, *nx_beta;
-    float nx_eps;
-    int nx_mode, nx_P, Lnx;
-    float *nx_xo, *nx_h, *nx_mean, *nx_rstd;
 };
 
 template <int D, int kFW>
@@ -513,52 +506,6 @@ __global__ __launch_bounds__(64 * kFW) void ln_adapter_fwd_kernel(LnAdapterArgs 
         const int idx = threadIdx.x + q * 64 * kFW, i = idx / (D / 4), c4 = idx - i * (D / 4);
         if (row0 + i < R)
             *reinterpret_cast<float4 *>(a.out + (size_t)(row0 + i) * D + 4 * c4) = *reinterpret_cast<const float4 *>(&Vs[i * LDH + 4 * c4]);
-    }
-    if (a.nx_xo == nullptr) return;
-    // ---- the next block's head from the finished rows in the LDS (the arithmetic of rowln_fwd_kernel: same values, same statistics).
-    //      A wave owns RW output rows; the wave whose row is token t = 1 .. nx_P of a sample (t = 0 .. nx_P - 1 for a leading insert)
-    //      also writes that sample's prompt row t - 1 (t): the P prompt rows of a sample are spread over P waves, not piled on one.
-    {
-        float gv[E], bv[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) { gv[e] = a.nx_gamma[lane + 64 * e]; bv[e] = a.nx_beta[lane + 64 * e]; }
-        auto emit = [&](const float (&v)[E], size_t orow) {
-            float s = 0.0f;
-#pragma unroll
-            for (int e = 0; e < E; ++e) s += v[e];
-            const float mean = wave_sum_f32(s) / (float)D;
-            float qq = 0.0f;
-#pragma unroll
-            for (int e = 0; e < E; ++e) { const float dv = v[e] - mean; qq = __builtin_fmaf(dv, dv, qq); }
-            const float rstd = 1.0f / sqrtf(wave_sum_f32(qq) / (float)D + a.nx_eps);
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                a.nx_xo[orow * D + lane + 64 * e] = v[e];
-                a.nx_h[orow * D + lane + 64 * e] = __builtin_fmaf((v[e] - mean) * rstd, gv[e], bv[e]);
-            }
-            if (lane == 0) { a.nx_mean[orow] = mean; a.nx_rstd[orow] = rstd; }
-        };
-#pragma unroll
-        for (int q = 0; q < RW; ++q) {
-            const int rr = wave * RW + q, row = row0 + rr;
-            if (row >= R) continue;                                  // wave-uniform
-            const int b = row / a.Lout, t = row - b * a.Lout;
-            const int t2 = a.nx_mode == 1 ? (t == 0 ? 0 : t + a.nx_P) : (a.nx_mode == 2 ? t + a.nx_P : t);
-            float v[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                v[e] = Vs[rr * LDH + lane + 64 * e];
-                if (a.nx_add) v[e] += a.nx_add[(size_t)row * D + lane + 64 * e];
-            }
-            emit(v, (size_t)b * a.Lnx + t2);
-            const int p = a.nx_mode == 1 ? t - 1 : (a.nx_mode == 2 ? t : -1);
-            if (p >= 0 && p < a.nx_P) {
-                float pv[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) pv[e] = a.nx_prompts[(size_t)p * D + lane + 64 * e];
-                emit(pv, (size_t)b * a.Lnx + (a.nx_mode == 1 ? 1 + p : p));
-            }
-        }
     }
 }
 
@@ -835,8 +782,7 @@ extern "C" int upp_adapter_fwd(const float *ha, const float *x, const float *W1,
 static int ln_adapter_fwd_impl(const float *x, const float *y, int yparts, long long ystride, const float *ybias, const float *u, float keep,
                                         int mode, int P, const float *gamma, const float *beta, float eps, const float *W1, const float *b1,
                                         const float *W2, const float *b2, const float *ud, float p, float scale, float *xo, float *mean,
-                                        float *rstd, float *s1, float *out, int B, int Lin, int Lout, int D, int H, void *stream,
-                                        const LnAdapterArgs *next = nullptr) {
+                                        float *rstd, float *s1, float *out, int B, int Lin, int Lout, int D, int H, void *stream) {
     if (yparts < 1 || (yparts > 1 && (!y || ystride < (long long)B * Lin * D))) return UPP_E_BADARG;
     if (!x || !gamma || !beta || !W1 || !b1 || !W2 || !b2 || !xo || !mean || !rstd || !s1 || !out || B < 0 || Lin < 1 || Lout < 1)
         return UPP_E_BADARG;
@@ -845,33 +791,8 @@ static int ln_adapter_fwd_impl(const float *x, const float *y, int yparts, long 
     if (!(mode == 0 || mode == 3 || mode == 4) || P < 0 || (mode == 0 && Lout != Lin) || (mode != 0 && Lout != Lin - P)) return UPP_E_BADARG;
     if (B == 0) return 0;
     LnAdapterArgs a{x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, xo, mean, rstd, s1, out, B, Lin, Lout, yparts, ystride};
-    a.nx_xo = nullptr;
-    if (next) {
-        a.nx_add = next->nx_add; a.nx_prompts = next->nx_prompts; a.nx_gamma = next->nx_gamma; a.nx_beta = next->nx_beta; a.nx_eps = next->nx_eps;
-        a.nx_mode = next->nx_mode; a.nx_P = next->nx_P; a.Lnx = next->Lnx;
-        a.nx_xo = next->nx_xo; a.nx_h = next->nx_h; a.nx_mean = next->nx_mean; a.nx_rstd = next->nx_rstd;
-    }
     hipLaunchKernelGGL((ln_adapter_fwd_kernel<384, 8>), dim3((B * Lout + kFR - 1) / kFR), dim3(64 * 8), 0, (hipStream_t)stream, a);
     return upp_launch_status();
-}
-
-// upp_ln_adapter_fwd + the HEAD of the next block (upp_rowln_fwd on `out`: + nx_add, prompt insert nx_mode 0 / 1 / 2, LayerNorm) in the same
-// launch: the finished rows are still in the LDS.  Lnx = Lout (+ nx_P for an insert); every sample must have at least nx_P (+ 1 behind a cls
-// row) output rows (its prompt rows are written by the waves that own those rows).
-extern "C" int upp_ln_adapter_fwd_next(const float *x, const float *y, const float *ybias, const float *u, float keep, int mode, int P,
-                                       const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
-                                       const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
-                                       float *out, int B, int Lin, int Lout, int D, int H, const float *nx_add, const float *nx_prompts,
-                                       int nx_mode, int nx_P, const float *nx_gamma, const float *nx_beta, float nx_eps, float *nx_xo,
-                                       float *nx_h, float *nx_mean, float *nx_rstd, void *stream) {
-    if (!nx_gamma || !nx_beta || !nx_xo || !nx_h || !nx_mean || !nx_rstd || nx_P < 0 || nx_mode < 0 || nx_mode > 2) return UPP_E_BADARG;
-    if ((nx_mode != 0 && nx_P > 0 && !nx_prompts) || (nx_mode == 0 && nx_P != 0)) return UPP_E_BADARG;
-    if ((nx_mode == 1 && Lout < nx_P + 1) || (nx_mode == 2 && Lout < nx_P)) return UPP_E_RANGE;
-    LnAdapterArgs n{};
-    n.nx_add = nx_add; n.nx_prompts = nx_prompts; n.nx_gamma = nx_gamma; n.nx_beta = nx_beta; n.nx_eps = nx_eps; n.nx_mode = nx_mode; n.nx_P = nx_P;
-    n.Lnx = Lout + (nx_mode ? nx_P : 0); n.nx_xo = nx_xo; n.nx_h = nx_h; n.nx_mean = nx_mean; n.nx_rstd = nx_rstd;
-    return ln_adapter_fwd_impl(x, y, 1, 0, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, xo, mean, rstd, s1, out, B, Lin,
-                               Lout, D, H, stream, &n);
 }
 
 extern "C" int upp_ln_adapter_fwd(const float *x, const float *y, const float *ybias, const float *u, float keep, int mode, int P,

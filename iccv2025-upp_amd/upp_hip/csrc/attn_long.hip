@@ -486,13 +486,9 @@ constexpr size_t kBwdLongLds = ((size_t)2 * kKP * kLD + (size_t)2 * kBB * kLD + 
 constexpr size_t kBwdTailLds = kBwdLongLds + ((size_t)2 * kVT * kLD + (size_t)2 * kVT * kSS + 2 * kVT) * sizeof(float);
 static_assert(kBwdTailLds <= 160 * 1024, "LDS budget");
 
-// UPP_ATTN_FOLD (read once; A/B timing, tests): 0 = the three-block walk of rounds 1-4 for 129 ... 144 tokens; 1 = the tail strip on the
-// matrix pipe for every such length; unset / 2 = 1 ... kVT tail rows on the vector ALU, longer tails as 1.
-inline int fold_mode() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("UPP_ATTN_FOLD"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
-    return v;
-}
+// 129 ... 144 tokens: 1 ... kVT tail rows on the vector ALU (kernel variant 2), longer tails as a strip on the matrix pipe (variant 1);
+// every other length the three-block walk (variant 0).  (round 5 carried an environment switch for A/B timing: profiles/r05_time_attention_long*.txt)
+constexpr int fold_mode() { return 2; }
 
 }  // namespace
 

@@ -121,6 +121,10 @@ __device__ __forceinline__ void stage_floats(float *dst, const float *__restrict
     }
 }
 
+// Process-wide options (include/upp_hip.h: upp_set_option / upp_get_option) -- the library's ONLY mutable state; every other choice is an
+// argument.  Defined in abi.hip (relaxed atomics); the library never reads the environment.
+int upp_option(int key);
+
 static inline int upp_launch_status(void) {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

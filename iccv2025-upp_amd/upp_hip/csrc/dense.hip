@@ -408,8 +408,7 @@ extern "C" int upp_patch_embed_fwd(const float *pts, int R, int n, const float *
         if (rc) return rc;
     }
     // h3 = f . W3[:, 256:]^T + hg[group] ; BN3 statistics ;  out = group max( relu(bn3(h3)) . W4^T + b4 )
-    const char *env = getenv("UPP_EMBED_SPLIT_BF16");       // (read per call: tests switch between the two chains inside one process)
-    const bool split_bf16 = !(env && env[0] == '0');
+    const bool split_bf16 = upp_option(UPP_OPT_EMBED_SPLIT_BF16) != 0;       // (read per call: tests switch between the two chains inside one process)
     if (split_bf16 && C <= kMaxEmbedC) {
         // the two large products on the BF16 matrix pipe (linear_sb.hip: f32 operands split into three bf16 terms, six products; error of an
         // f32 GEMM), with this chain's fusions as that kernel's prologue / epilogues: 100 -> 180-200 TFLOP/s on 65,536 rows

@@ -297,23 +297,6 @@ int fps_block_size(int n) {
     return t;
 }
 
-// UPP_FPS_CPW = 1 | 2 | 4 (read once): clouds per workgroup for the 4-wave kernels (default UPP_FPS_CPW_DEFAULT)
-#ifndef UPP_FPS_CPW_DEFAULT
-#define UPP_FPS_CPW_DEFAULT 1
-#endif
-inline int fps_clouds_per_wg() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("UPP_FPS_CPW"); v = e ? atoi(e) : UPP_FPS_CPW_DEFAULT; if (v != 2 && v != 4) v = 1; }
-    return v;
-}
-
-// UPP_FPS_EXCL=1 (read once): a packed launch asks for the whole LDS of its CU, so that no workgroup of another kernel shares the CU
-inline bool fps_exclusive() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("UPP_FPS_EXCL"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
-
 constexpr int kFpsLdsBytes = 160 * 1024 - 256;  // cloud copy + winner list + wave records must fit the CU's LDS
 
 template <int S, int W>
@@ -336,8 +319,8 @@ int launch(const float *xyz, int32_t *idx, float *centers, int B, const FpsGeom 
         // clouds per workgroup: as many of {4, 2} as divide B and fit 1,024 threads and the LDS (W = 4, the shapes of the recipes: S <= 8)
         if constexpr (W == 4 && S <= 8) {
             const size_t stride = (size_t)((4 * W + 3 * g.N + g.M + 3) / 4 * 4) * 4;
-            const int want = (form & 0xF) ? (form & 0xF) : fps_clouds_per_wg();        // (the caller's form, or the environment's)
-            const bool excl = (form & 0xF) ? (form & 0x10) != 0 : fps_exclusive();
+            const int want = (form & 0xF) ? (form & 0xF) : 1;                          // (the caller's form: upp_fps_ex `waves` bits 8-12; default one cloud per workgroup)
+            const bool excl = (form & 0xF) && (form & 0x10) != 0;
             if (want >= 4 && B % 4 == 0 && 4 * stride <= (size_t)kFpsLdsBytes) {
                 static std::atomic<bool> raised4{false};
                 if (!raised4) {

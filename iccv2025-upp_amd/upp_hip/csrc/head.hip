@@ -347,26 +347,33 @@ __global__ __launch_bounds__(256) void rectify_select_kernel(const float *__rest
 
 // order[b][rank] = i: the stable argsort of every row of `key` (B,N) by rank counting, as rectify_select_kernel ranks its scores -- one
 // workgroup per (row, 256 elements), the row in the LDS, rank of an element = how many elements precede it (smaller key -- greater, if
-// descending -- or equal key and lower index: the order of torch's stable sort).  NaN ranks as +inf, ties by index: always a permutation.
+// descending -- or equal key and lower index: the order of torch's stable sort).  The comparison runs on a TOTAL-ORDER image of the
+// floats: -0 == +0 (ties by index), NaN above +inf -- last ascending, first descending, as torch.sort ranks it; always a permutation.
+__device__ __forceinline__ uint32_t sort_key_f32(float v) {
+    if (v != v) return 0xFFFFFFFFu;                        // NaN: above +inf (0xFF800000)
+    const uint32_t u = __float_as_uint(v + 0.0f);          // (-0 + 0 = +0)
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 template <bool DESC>
 __global__ __launch_bounds__(256) void argsort_rows_kernel(const float *__restrict__ key, long long B, int N, int64_t *__restrict__ order) {
-    extern __shared__ float sc[];
+    extern __shared__ uint32_t sk[];
     const long long b = (long long)blockIdx.z * 65535 + blockIdx.y;          // (rows beyond the 65,535 of grid.y: grid.z)
     if (b >= B) return;
     const float *s = key + (size_t)b * N;
-    for (int i = threadIdx.x; i < N; i += 256) { const float v = s[i]; sc[i] = v != v ? __builtin_inff() : v; }
+    for (int i = threadIdx.x; i < N; i += 256) sk[i] = sort_key_f32(s[i]);
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const float mine = sc[i];
+    const uint32_t mine = sk[i];
     int rank = 0;
     int j = 0;
-    auto before = [&](float v, int jj) { return (DESC ? v > mine : v < mine) || (v == mine && jj < i); };
+    auto before = [&](uint32_t v, int jj) { return (DESC ? v > mine : v < mine) || (v == mine && jj < i); };
     for (; j + 4 <= N; j += 4) {                          // (every lane reads the same address: LDS broadcast)
-        const float4 v = *reinterpret_cast<const float4 *>(sc + j);
+        const uint4 v = *reinterpret_cast<const uint4 *>(sk + j);
         rank += before(v.x, j) + before(v.y, j + 1) + before(v.z, j + 2) + before(v.w, j + 3);
     }
-    for (; j < N; ++j) rank += before(sc[j], j);
+    for (; j < N; ++j) rank += before(sk[j], j);
     order[(size_t)b * N + rank] = i;
 }
 

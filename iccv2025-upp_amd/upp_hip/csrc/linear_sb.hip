@@ -38,9 +38,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef UPP_SB_XCD2D_DEFAULT
-#define UPP_SB_XCD2D_DEFAULT 2
-#endif
 constexpr int SB_CHUNK = 6144;          // bytes of one (32-row block, 32-wide k-stage) of the planes: 3 planes x 4 granules x 32 rows x 16 B
 
 struct SbArgs {
@@ -51,21 +48,8 @@ struct SbArgs {
     const float *pro_scale, *pro_shift; // a' = max(a * scale[k] + shift[k], 0) applied to the A fragment in front of its split (K <= 512)
     float *gmax; int ldgmax, gshift;    // gmax[row >> gshift][col] = max over the 2^gshift (16 | 32) rows of a group of C (+ bias); C is NOT stored
     float *stat_part;                   // [2][ceil(M / 32)][N]: column sums / sums of squares of C over each 32-row block (rows < M)
-    // round 5 -- the residual + LayerNorm between two Linear layers of a Transformer block without a row kernel (reference
-    // models/Point_MAE_pretask_dev.py:266,273: x = x + drop_path(attn(norm1 x)); x + drop_path(mlp(norm2 x))):
-    //   producer (epilogue LEPI_RESID, every instantiation):  C = resid + dp * (A . W^T + bias),  dp = floor(keep + u[row / dp_rows]) / keep,
-    //     and per (row, 32-column block) the pair (sum, M2 about the block mean) of the stored values -> row_stats[row][N / 32][2]
-    //   consumer (PRO = 2):  A' = ((A - mean_r) * rstd_r) * gamma_k + beta_k applied to the f32 fragment in front of its split; mean_r / rstd_r
-    //     from ln_stats: ln_nb > 0: the producer's block pairs of row r, combined exactly (Chan et al.); ln_nb == 0: (mean, rstd) pairs.
-    //     gamma / beta ride in pro_scale / pro_shift.  Workgroups of column tile 0 write ln_mean / ln_rstd (M) for the backward pass.
-    const float *resid; long long ld_res;
-    const float *dp_u; float dp_keep; int dp_rows;
-    float *row_stats;
-    const float *ln_stats; int ln_nb; float ln_eps;
-    float *ln_mean, *ln_rstd;
     int xcd_gc;                         // > 1: 2-D XCD map with gc column groups (launch_sb decides; the grid is then 8 equal regions)
 };
-constexpr int LEPI_RESID = 6;           // (this file only: linear_shared.h's epilogues end at LEPI_BIAS_RELU = 5)
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     f32x2 v = {a, b};
@@ -100,7 +84,7 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, u32x4 &p1
     }
 }
 
-template <int BMB, int BNB, int RN, int KS, int NST, int PRO = 0>
+template <int BMB, int BNB, int RN, int KS, int NST, int PRO = 0>      // PRO = 1: BatchNorm + ReLU applied to the A fragment (pro_scale / pro_shift)
 __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(SbArgs ga) {
     static_assert(BNB % RN == 0 && (RN == 1 || RN == 2 || RN == 4), "wave tile: 1 x RN blocks");
     static_assert(!PRO || ((RN == 2 || RN == 4) && KS == 1 && BMB * (BNB / RN) >= 8), "the prologue variant: 8-wave tiles with two or four blocks per wave");
@@ -203,36 +187,11 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
     f32x4 ra0, ra1;                       // the f32 A fragment of the step being fetched (split as soon as it has landed)
     f32x4 sc0, sc1, sh0, sh1;             // PRO: scale / shift of its 8 values of k
     const unsigned adrT = lds0 + TABOFF + h * 32;
-    float ln_mu = 0.0f, ln_rs = 1.0f;     // PRO = 2: LayerNorm statistics of this lane's A row
     if constexpr (PRO) {                  // the table: plain stores, visible behind the barrier in front of the first fragment read
         float *tab = reinterpret_cast<float *>(lds + TABOFF);
         for (int i = threadIdx.x; i < 512; i += NW * 64) {
             tab[i] = i < g.K ? ga.pro_scale[i] : 0.0f;
             tab[512 + i] = i < g.K ? ga.pro_shift[i] : 0.0f;
-        }
-        if constexpr (PRO == 2) {
-            const int arow = m0 + bm * 32 + r, crow = min(arow, M - 1);
-            if (ga.ln_nb == 0) {
-                ln_mu = ga.ln_stats[2 * (long long)crow]; ln_rs = ga.ln_stats[2 * (long long)crow + 1];
-            } else {
-                // (sum_i, M2_i) of the nb 32-column blocks of the row -> mean, M2 = sum M2_i + 32 sum (mean_i - mean)^2: no cancellation
-                // (all 16 loads issued before the first use: a loop over a run-time count waited for every load in turn -- 6 us per launch)
-                const float2 *p = reinterpret_cast<const float2 *>(ga.ln_stats) + (long long)crow * ga.ln_nb;
-                const int nb = ga.ln_nb;                         // <= 16 (K <= 512)
-                float2 v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = p[min(i, nb - 1)];
-                float tot = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) tot += i < nb ? v[i].x : 0.0f;
-                const float n = 32.0f * (float)nb;
-                ln_mu = tot / n;
-                float q = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { const float d = v[i].x * 0.03125f - ln_mu; q += i < nb ? __builtin_fmaf(32.0f * d, d, v[i].y) : 0.0f; }
-                ln_rs = 1.0f / sqrtf(q / n + ga.ln_eps);
-            }
-            if (ga.ln_mean && bx == 0 && bnp == 0 && h == 0 && arow < M) { ga.ln_mean[arow] = ln_mu; ga.ln_rstd[arow] = ln_rs; }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -303,16 +262,10 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
 #define SB_PROD_LO(X, WS, JJ) SB_MFMA(X.p3, WS.w[JJ][0], JJ) SB_MFMA(X.p1, WS.w[JJ][2], JJ) SB_MFMA(X.p2, WS.w[JJ][1], JJ)
 #define SB_PROD_HI(X, WS, JJ) SB_MFMA(X.p2, WS.w[JJ][0], JJ) SB_MFMA(X.p1, WS.w[JJ][1], JJ) SB_MFMA(X.p1, WS.w[JJ][0], JJ)
 #define SB_PRO()                                                                               \
-    if constexpr (PRO == 1) {                                                                  \
+    if constexpr (PRO) {                                                                       \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                     \
             ra0[e_] = fmaxf(__builtin_fmaf(ra0[e_], sc0[e_], sh0[e_]), 0.0f);                  \
             ra1[e_] = fmaxf(__builtin_fmaf(ra1[e_], sc1[e_], sh1[e_]), 0.0f);                  \
-        }                                                                                      \
-    }                                                                                          \
-    if constexpr (PRO == 2) {                  /* LayerNorm of the row, as rowln_fwd_kernel forms it: ((a - mean) rstd) gamma + beta */ \
-        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                     \
-            ra0[e_] = __builtin_fmaf((ra0[e_] - ln_mu) * ln_rs, sc0[e_], sh0[e_]);             \
-            ra1[e_] = __builtin_fmaf((ra1[e_] - ln_mu) * ln_rs, sc1[e_], sh1[e_]);             \
         }                                                                                      \
     }
 #define SB_HALF2(X, WS, XN)                                                                    \
@@ -414,7 +367,7 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
         const int col = cb + 4 * (lane & 7);
         const bool col_ok = col < N;
         f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (g.epi != LEPI_NONE && g.epi != LEPI_MUL && col_ok && g.bias_shift == 0 && (g.epi != LEPI_RESID || g.bias)) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
+        if (g.epi != LEPI_NONE && g.epi != LEPI_MUL && col_ok && g.bias_shift == 0) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
         // the patch embedding's epilogues (KS = 1 tiles): group max over 16 | 32 rows instead of the store, column sums of the stored values
         const bool want_max = KS == 1 && ga.gmax != nullptr, want_stats = KS == 1 && ga.stat_part != nullptr;
         const float ninf = -__builtin_inff();
@@ -449,27 +402,6 @@ __global__ __launch_bounds__(BMB *(BNB / RN) * KS * 64) void linear_sb_kernel(Sb
                     }
                     continue;
                 }
-            }
-            if (g.epi == LEPI_RESID) {
-                // C = resid + dp (acc + bias) as rowln_fwd_kernel forms it (one fma per value), and the (sum, M2) pair of the 32 stored values of
-                // this row and column block: the 8 lanes lane & 7 hold them, 4 each
-                const bool live = col_ok && row < M;
-                const int rr = min(row, M - 1), cq = min(col, N - 4);
-                const f32x4 res = *reinterpret_cast<const f32x4 *>(ga.resid + (long long)rr * ga.ld_res + cq);
-                const float dp = ga.dp_u ? floorf(ga.dp_keep + ga.dp_u[rr / ga.dp_rows]) / ga.dp_keep : 1.0f;
-                f32x4 x;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = __builtin_fmaf(v[e] + bias4[e], dp, res[e]);
-                if (live) store4(g.C + (long long)row * g.ldc + col, x, g.wt);
-                float sum = (x[0] + x[1]) + (x[2] + x[3]);
-                sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
-                const float mb = sum * 0.03125f;
-                float q = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = x[e] - mb; q = __builtin_fmaf(d, d, q); }
-                q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
-                if ((lane & 7) == 0 && live) *reinterpret_cast<float2 *>(ga.row_stats + ((long long)row * (N >> 5) + (cb >> 5)) * 2) = make_float2(sum, q);
-                continue;
             }
             epilogue_store4(g, g.epi, v, bias4, row, col, col_ok && row < M);
         }
@@ -551,11 +483,9 @@ constexpr int kNumSbConfigs = sizeof(kSbConfigs) / sizeof(kSbConfigs[0]);
 inline int sb_code(const SbConfig &c) { return 0x400000 + c.bmb * 65536 + c.bnb * 4096 + c.rn * 256 + c.ks * 16 + c.nst; }     // hex digits 4 BMB BNB RN KS NST
 
 // The measured choice (linear_sb_tuned.h) for a problem of the swept family: same N and K, M within 1 / 16 of a swept M (the nearest one),
-// and still one round of workgroups where the swept problem was.  UPP_SB_TUNED=0 (read once): the cost model alone (A/B).  0: no entry.
+// and still one round of workgroups where the swept problem was.  option UPP_OPT_SB_TUNED = 0: the cost model alone (A/B).  0: no entry.
 int sb_tuned(int M, int N, int K) {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("UPP_SB_TUNED"); on = !(e && e[0] == '0'); }
-    if (!on) return 0;
+    if (!upp_option(UPP_OPT_SB_TUNED)) return 0;
     int best = 0;
     long long best_d = 0;
     for (const SbTuned &t : kSbTuned) {
@@ -607,12 +537,8 @@ int pick_sb(int M, int N, int K) {
     return t ? t : pick_sb_model(M, N, K);
 }
 
-// UPP_SB_XCD2D=<gc> (read once; 0 / unset: row-major XCD ranges): column groups of the 2-D XCD map for one-round launches of wide outputs
-inline int sb_xcd_cols() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("UPP_SB_XCD2D"); v = e ? atoi(e) : UPP_SB_XCD2D_DEFAULT; if (v != 2 && v != 4) v = 0; }
-    return v;
-}
+// option UPP_OPT_SB_XCD2D = gc (0: row-major XCD ranges; default 2): column groups of the 2-D XCD map for one-round launches of wide outputs
+inline int sb_xcd_cols() { return upp_option(UPP_OPT_SB_XCD2D); }
 
 template <int BMB, int BNB, int RN, int KS, int NST>
 int launch_sb(const SbArgs &g0, hipStream_t st) {
@@ -677,12 +603,12 @@ extern "C" int upp_linear_sb_prep_batched(const float *const *W, const long long
 }
 
 static int linear_sb_launch(const float *A, long long lda, const void *planes, const float *bias, int bias_shift, float *C, long long ldc, float *aux,
-                            long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream, const SbArgs *extra = nullptr) {
+                            long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream) {
     if (!A || !planes || !C || M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
     if (K % 32 != 0 || lda % 4 != 0 || lda < K || ldc < N || N % 4 != 0 || ldc % 4 != 0) return UPP_E_RANGE;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(C)) & 15) return UPP_E_RANGE;
     if (ldc > (1LL << 24) || ldaux > (1LL << 24)) return UPP_E_RANGE;
-    if (epilogue < LEPI_NONE || (epilogue > LEPI_BIAS_RELU && !(epilogue == LEPI_RESID && extra && extra->resid))) return UPP_E_RANGE;
+    if (epilogue < LEPI_NONE || epilogue > LEPI_BIAS_RELU) return UPP_E_RANGE;
     if ((epilogue == LEPI_BIAS || epilogue == LEPI_BIAS_GELU || epilogue == LEPI_BIAS_GELU_D || epilogue == LEPI_BIAS_RELU) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15))) return UPP_E_BADARG;
     if ((epilogue == LEPI_BIAS_GELU_D || epilogue == LEPI_MUL) && (!aux || ldaux < N || ldaux % 4 != 0 || (reinterpret_cast<uintptr_t>(aux) & 15))) return UPP_E_BADARG;
     if (tile <= 0) tile = pick_sb(M, N, K);
@@ -696,24 +622,6 @@ static int linear_sb_launch(const float *A, long long lda, const void *planes, c
     g.planes = reinterpret_cast<const unsigned char *>(planes);
     g.nblocks = (N + 31) / 32; g.kstages = (K + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
-    if (extra) {
-        g.resid = extra->resid; g.ld_res = extra->ld_res; g.dp_u = extra->dp_u; g.dp_keep = extra->dp_keep; g.dp_rows = extra->dp_rows; g.row_stats = extra->row_stats;
-        g.ln_stats = extra->ln_stats; g.ln_nb = extra->ln_nb; g.ln_eps = extra->ln_eps; g.ln_mean = extra->ln_mean; g.ln_rstd = extra->ln_rstd;
-        g.pro_scale = extra->pro_scale; g.pro_shift = extra->pro_shift;
-        if (extra->ln_stats) {                       // the LayerNorm prologue: the two 8-wave tiles that carry an A-operand prologue
-            if (K > 512) return UPP_E_RANGE;
-            g.l.tiles_n = (N + 127) / 128;
-            if (tile == 0x444210 + UPP_SB_NST44) {
-                if (K / 32 < UPP_SB_NST44) return UPP_E_RANGE;
-                hipLaunchKernelGGL((linear_sb_kernel<4, 4, 2, 1, UPP_SB_NST44, 2>), dim3((unsigned)(((M + 127) / 128) * g.l.tiles_n)), dim3(512), 0, st, g);
-            } else if (tile == 0x484412) {
-                hipLaunchKernelGGL((linear_sb_kernel<8, 4, 4, 1, 2, 2>), dim3((unsigned)(((M + 255) / 256) * g.l.tiles_n)), dim3(512), 0, st, g);
-            } else {
-                return UPP_E_RANGE;
-            }
-            return upp_launch_status();
-        }
-    }
 #define UPP_SB_CASE(a, b, c, d, e)                                                                    \
     case 0x400000 + a * 65536 + b * 4096 + c * 256 + d * 16 + e:                                          \
         if (K % (32 * d) != 0 || K / (32 * d) < e) return UPP_E_RANGE;                                \
@@ -768,46 +676,6 @@ __attribute__((visibility("hidden"))) int upp_detail_linear_sb_chain(const float
 extern "C" int upp_linear_sb_f32(const float *A, long long lda, const void *planes, const float *bias, float *C, long long ldc, float *aux,
                                  long long ldaux, int M, int N, int K, int epilogue, int tile, void *stream) {
     return linear_sb_launch(A, lda, planes, bias, 0, C, ldc, aux, ldaux, M, N, K, epilogue, tile, stream);
-}
-
-// Does upp_linear_sb_ln_f32 take (M,N,K)?  The tile the library picks must be one of the two that carry an A-operand prologue.
-static bool sb_ln_tile(int M, int N, int K, int &tile) {
-    tile = pick_sb_model(M, N, K);                       // (not the tuned table: only these two shapes are instantiated with the prologue)
-    return K <= 512 && K % 32 == 0 && (tile == 0x444210 + UPP_SB_NST44 || tile == 0x484412);
-}
-
-extern "C" int upp_linear_sb_ln_usable(int M, int N, int K) {
-    int tile;
-    return (M >= 1 && N >= 1 && K >= 1 && sb_ln_tile(M, N, K, tile)) ? 1 : 0;
-}
-
-// C = epilogue( LayerNorm(A) . W^T ): the LayerNorm over the K columns of every A row is applied to the f32 A fragment in front of its
-// split (PRO = 2), so the normalised rows are never written.  ln_stats: ln_nb > 0: (M, ln_nb, 2) block pairs written by
-// upp_linear_sb_resid_f32 (ln_nb = K / 32); ln_nb == 0: (M, 2) = (mean, rstd) per row.
-extern "C" int upp_linear_sb_ln_f32(const float *A, long long lda, const float *ln_stats, int ln_nb, const float *gamma, const float *beta, float eps,
-                                    float *ln_mean, float *ln_rstd, const void *planes, const float *bias, float *C, long long ldc, float *aux,
-                                    long long ldaux, int M, int N, int K, int epilogue, void *stream) {
-    if (!ln_stats || !gamma || !beta || ln_nb < 0 || (ln_nb > 0 && ln_nb * 32 != K) || (ln_mean == nullptr) != (ln_rstd == nullptr)) return UPP_E_BADARG;
-    if ((reinterpret_cast<uintptr_t>(ln_stats) & 7)) return UPP_E_RANGE;
-    int tile;
-    if (M < 1 || N < 1 || K < 1 || !sb_ln_tile(M, N, K, tile)) return UPP_E_RANGE;
-    SbArgs e{};
-    e.ln_stats = ln_stats; e.ln_nb = ln_nb; e.ln_eps = eps; e.ln_mean = ln_mean; e.ln_rstd = ln_rstd; e.pro_scale = gamma; e.pro_shift = beta;
-    return linear_sb_launch(A, lda, planes, bias, 0, C, ldc, aux, ldaux, M, N, K, epilogue, tile, stream, &e);
-}
-
-// C = resid + dp (A . W^T + bias) with dp = floor(keep + u[row / rows_per_sample]) / keep (u NULL: 1; bias NULL: none), and the (sum, M2)
-// pair of every (row, 32-column block) of C -> row_stats (M, N / 32, 2): residual add and the statistics of the LayerNorm that follows, in
-// the epilogue of the Linear layer that produced the branch (N % 32 == 0).
-extern "C" int upp_linear_sb_resid_f32(const float *A, long long lda, const void *planes, const float *bias, const float *resid, long long ld_res,
-                                       const float *u, float keep, int rows_per_sample, float *C, long long ldc, float *row_stats, int M, int N,
-                                       int K, int tile, void *stream) {
-    if (!resid || !row_stats || (u && (rows_per_sample < 1 || !(keep > 0.0f)))) return UPP_E_BADARG;
-    if (N % 32 != 0 || ld_res < N || ld_res % 4 != 0 || (reinterpret_cast<uintptr_t>(resid) & 15) || (reinterpret_cast<uintptr_t>(row_stats) & 7)) return UPP_E_RANGE;
-    if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) return UPP_E_RANGE;
-    SbArgs e{};
-    e.resid = resid; e.ld_res = ld_res; e.dp_u = u; e.dp_keep = keep; e.dp_rows = rows_per_sample > 0 ? rows_per_sample : 1; e.row_stats = row_stats;
-    return linear_sb_launch(A, lda, planes, bias, 0, C, ldc, nullptr, 0, M, N, K, LEPI_RESID, tile, stream, &e);
 }
 
 // C (M,N) = A . W^T + bias[m >> group_shift][:] -- a bias per GROUP of 2^group_shift >= 5 consecutive rows, as upp_linear_group_bias_f32.

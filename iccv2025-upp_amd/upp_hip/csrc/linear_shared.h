@@ -2,9 +2,6 @@
 // the token matrices of the Transformer blocks; linear_rt.hip: register-tiled waves, the tall point-row matrices and the grouped
 // weight gradients).  Included inside each file's anonymous namespace.
 #pragma once
-#ifndef UPP_STORE_WT_DEFAULT
-#define UPP_STORE_WT_DEFAULT 1
-#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -88,12 +85,8 @@ __device__ __forceinline__ void store4(float *dst, f32x4 v, int wt) {
     else *reinterpret_cast<f32x4 *>(dst) = v;
 }
 
-// UPP_STORE_WT=0|1 (read once): the store policy of the Linear kernels' epilogues.
-static inline int upp_store_policy(void) {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("UPP_STORE_WT"); v = e ? (e[0] != '0') : UPP_STORE_WT_DEFAULT; }
-    return v;
-}
+// the store policy of the Linear kernels' epilogues (option UPP_OPT_STORE_WT, default 1)
+static inline int upp_store_policy(void) { return upp_option(UPP_OPT_STORE_WT); }
 
 // Epilogue of four consecutive columns of one output row (a lane of the LDS-turned tile: 16-byte loads and stores): v = the
 // accumulated products, bias4 = the four biases (zeros when the epilogue has none).

@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256) void group_max_fwd_kernel(const float *__restr
         for (int q = 0; q < 8; ++q)
             if (j0 + q < k) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (v[q][e] > best[e]) { best[e] = v[q][e]; bi[e] = j0 + q; }
+                for (int e = 0; e < 4; ++e) if (v[q][e] > best[e] || (v[q][e] != v[q][e] && best[e] == best[e])) { best[e] = v[q][e]; bi[e] = j0 + q; }   // (NaN propagates: the FIRST NaN of a column wins, as torch.max(dim))
             }
     }
     *reinterpret_cast<f32x4 *>(out + r * C + c) = best;

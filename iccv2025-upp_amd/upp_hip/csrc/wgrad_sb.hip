@@ -282,163 +282,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void wgrad_sb_kernel(WgGroup g) 
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Wave-specialised variant (round 4, late): the ablations of the kernel above show its three costs -- matrix instructions, fragment reads,
-// operand split -- ADDING UP, because the two waves of a SIMD sit behind the same barrier and do the same thing at the same time.  Here a
-// workgroup is 4 CONSUMER waves (one per SIMD; each a 64 x 128 piece of a 256 x 128 tile: transposed fragment reads + 48 MFMAs per step,
-// nothing else) and 4 PRODUCER waves (loads, split, LDS writes of the step after next); the roles meet at ONE barrier per step.
-constexpr int WS2_TN = 256, WS2_TK = 128, WS2_COLS = WS2_TN + WS2_TK, WS2_PIECES = WS2_COLS / 4;
-constexpr int WS2_PITCH = WS2_COLS * 2 + 64, WS2_PLANE = 16 * WS2_PITCH, WS2_STAGE = 3 * WS2_PLANE, WS2_PASSES = 16 * WS2_PIECES / 256;
-static_assert(WS2_PITCH % 256 == 64 && 16 * WS2_PIECES % 256 == 0, "geometry");
-
-__global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgGroup g) {
-    constexpr int BA = 2, BB = 4, NB = BA * BB, NF = BA + BB, PITCH = WS2_PITCH, PLANE = WS2_PLANE, STAGE = WS2_STAGE, PASSES = WS2_PASSES;
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int u = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    int p = 0;
-    while (u >= g.unit0[p + 1]) ++p;
-    const int local = u - g.unit0[p], tiles = g.tiles[p];
-    const int split = local / tiles, tile = local - split * tiles;
-    const int tn = tile / g.tiles_k[p], tk = tile - tn * g.tiles_k[p];
-    const int n0 = tn * WS2_TN, k0 = tk * WS2_TK;
-    const int M = g.M[p], N = g.N[p], K = g.K[p];
-    const int ms = split * g.rows[p], me = min(M, ms + g.rows[p]);
-    const int nst = (me - ms + 15) >> 4;
-    if (nst <= 0) return;
-
-    if (wave >= 4) {
-        // ---------------- producers: thread t owns the pieces t + 256 i of a step (row = piece index / 96, 16-byte piece = index % 96)
-        const int t = (int)threadIdx.x - 256;
-        const float *src[PASSES];
-        long long ld[PASSES];
-        int rowi[PASSES];
-        unsigned wofs[PASSES];
-#pragma unroll
-        for (int i = 0; i < PASSES; ++i) {
-            const int idx = t + 256 * i, row = idx / WS2_PIECES, piece = idx - row * WS2_PIECES;
-            const bool isG = piece < WS2_TN / 4;
-            const int col = isG ? min(n0 + 4 * piece, N - 4) : min(k0 + 4 * (piece - WS2_TN / 4), K - 4);
-            src[i] = (isG ? g.G[p] : g.X[p]) + col;
-            ld[i] = isG ? g.ldg[p] : g.ldx[p];
-            rowi[i] = row;
-            wofs[i] = row * PITCH + piece * 8;
-        }
-        f32x4 raw[PASSES];
-        auto load = [&](int c) {
-#pragma unroll
-            for (int i = 0; i < PASSES; ++i) raw[i] = *reinterpret_cast<const f32x4 *>(src[i] + (long long)min(ms + 16 * c + rowi[i], M - 1) * ld[i]);
-        };
-        auto split_store = [&](int c) {
-            char *wb = lds + (c & 1) * STAGE;
-#pragma unroll
-            for (int i = 0; i < PASSES; ++i) {
-                f32x4 v = raw[i];
-                if (ms + 16 * c + rowi[i] >= me) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                u32x2 p1, p2, p3;
-                split4(v, p1, p2, p3);
-                *reinterpret_cast<u32x2 *>(wb + wofs[i]) = p1;
-                *reinterpret_cast<u32x2 *>(wb + wofs[i] + PLANE) = p2;
-                *reinterpret_cast<u32x2 *>(wb + wofs[i] + 2 * PLANE) = p3;
-            }
-        };
-        load(0);
-        split_store(0);
-        if (nst > 1) load(1);
-        __syncthreads();
-        for (int c = 0; c < nst; ++c) {
-            if (c + 1 < nst) split_store(c + 1);           // (stage (c + 1) & 1 was last read before the barrier of step c - 1)
-            if (c + 2 < nst) load(c + 2);
-            __syncthreads();
-        }
-        return;
-    }
-
-    // ---------------- consumers
-    const int r = lane & 31, h = lane >> 5, wm = wave;
-    const int grp = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
-    const char *rbase = lds + (8 * (grp >> 1) + q4) * PITCH + (16 * (grp & 1) + 4 * pp) * 2;
-    const char *rG = rbase + wm * (BA * 64), *rX = rbase + WS2_TN * 2;
-    auto frag = [&](const char *base, int off) -> s16x8 {
-        typedef __attribute__((address_space(3))) s16x4 *lp;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + off));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + off + 4 * PITCH));
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-    f32x16 acc[BA][BB];
-#pragma unroll
-    for (int a = 0; a < BA; ++a)
-#pragma unroll
-        for (int b = 0; b < BB; ++b)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[a][b][t] = 0.0f;
-    s16x8 fg[BA][3], fx[BB][3];
-    auto read_frag = [&](int stage_off, auto plc, auto fc) {
-        constexpr int pl = decltype(plc)::value, f = decltype(fc)::value;
-        if constexpr (f < BA) fg[f][pl] = frag(rG, stage_off + pl * PLANE + f * 64);
-        else fx[f - BA][pl] = frag(rX, stage_off + pl * PLANE + (f - BA) * 64);
-    };
-    auto body = [&](int c, auto st_c) {
-        constexpr bool ST = decltype(st_c)::value;
-        const int sb = (c & 1) * STAGE, sn = ((c + 1) & 1) * STAGE;
-        static_for<0, 6 * NB>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            constexpr int pr = m / NB, blk = m % NB, a = blk / BB, b = blk % BB, sl = m % NB;
-            constexpr int gp = pr == 0 ? 0 : pr == 1 ? 0 : pr == 2 ? 1 : pr == 3 ? 0 : pr == 4 ? 2 : 1;
-            constexpr int xp = pr == 0 ? 0 : pr == 1 ? 1 : pr == 2 ? 0 : pr == 3 ? 2 : pr == 4 ? 0 : 1;
-            if constexpr (m == 4 * NB) {
-                __syncthreads();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fg[a][gp]), __builtin_bit_cast(bf16x8, fx[b][xp]), acc[a][b], 0, 0, 0);
-            auto rd = [&](int stage_off, auto plc, auto oc) {          // read order of a plane: X fragments first
-                constexpr int o = decltype(oc)::value;
-                read_frag(stage_off, plc, std::integral_constant<int, (o < BB ? BA + o : o - BB)>{});
-            };
-            if constexpr (m < 2 * NB) {
-                static_for<sl * NF / NB, (sl + 1) * NF / NB>([&](auto oc) { rd(sb, std::integral_constant<int, 1 + m / NB>{}, oc); });
-            } else if constexpr (m >= 4 * NB && ST) {
-                if constexpr (m < 5 * NB && sl < BA) read_frag(sn, std::integral_constant<int, 0>{}, std::integral_constant<int, sl>{});
-                if constexpr (m >= 5 * NB && sl < BB) read_frag(sn, std::integral_constant<int, 0>{}, std::integral_constant<int, BA + sl>{});
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    __syncthreads();
-    static_for<0, NF>([&](auto fc) { read_frag(0, std::integral_constant<int, 0>{}, fc); });
-    int c = 0;
-    for (; c + 1 < nst; ++c) body(c, std::true_type{});
-    body(c, std::false_type{});
-
-    float *out = g.P[p] + (long long)split * N * K;
-    if (g.tr[p]) {
-#pragma unroll
-        for (int a = 0; a < BA; ++a)
-#pragma unroll
-            for (int b = 0; b < BB; ++b) {
-                const int k = k0 + 32 * b + r;
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int n = n0 + 32 * (wm * BA + a) + 8 * t4 + 4 * h;
-                    const f32x4 v = {acc[a][b][4 * t4], acc[a][b][4 * t4 + 1], acc[a][b][4 * t4 + 2], acc[a][b][4 * t4 + 3]};
-                    if (n < N && k < K) *reinterpret_cast<f32x4 *>(out + (long long)k * N + n) = v;
-                }
-            }
-        return;
-    }
-#pragma unroll
-    for (int a = 0; a < BA; ++a)
-#pragma unroll
-        for (int b = 0; b < BB; ++b) {
-            const int k = k0 + 32 * b + r;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int n = n0 + 32 * (wm * BA + a) + (t & 3) + 8 * (t >> 2) + 4 * h;
-                if (n < N && k < K) out[(long long)n * K + k] = acc[a][b][t];
-            }
-        }
-}
+// (round 4's wave-specialised variant -- 4 producer + 4 consumer waves on 256 x 128 tiles -- was measured slower than the kernel above and
+// left the library in round 6: NOTEBOOK section 10.4, profiles/r04_*)
 
 }  // namespace
 
@@ -449,8 +294,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_ws_kernel(WgGroup g) {
 // every CU, and every other problem, runs on 128 x 128 tiles (4 waves, two workgroups per CU).  At most three launches.
 enum { WS_NARROW = 0, WS_WIDE = 1, WS_TALL = 2, WS_TALL_SWAPPED = 3 };
 struct WsTile { int tn, tk; };
-static bool ws_specialised() { static const bool on = [] { const char *e = getenv("UPP_WGRAD_WS"); return e && e[0] == '1'; }(); return on; }
-static WsTile ws_tile(int cls) { return cls == WS_WIDE ? (ws_specialised() ? WsTile{256, 128} : WsTile{256, 256}) : cls == WS_TALL ? WsTile{128, 384} : cls == WS_TALL_SWAPPED ? WsTile{384, 128} : WsTile{128, 128}; }
+static WsTile ws_tile(int cls) { return cls == WS_WIDE ? WsTile{256, 256} : cls == WS_TALL ? WsTile{128, 384} : cls == WS_TALL_SWAPPED ? WsTile{384, 128} : WsTile{128, 128}; }
 static long long ws_tiles(int cls, int N, int K) { const WsTile t = ws_tile(cls); return (long long)((N + t.tn - 1) / t.tn) * ((K + t.tk - 1) / t.tk); }
 static void ws_classify(int count, const int *M, const int *N, const int *K, int *cls) {
     double work[4] = {0.0, 0.0, 0.0, 0.0};
@@ -485,7 +329,7 @@ extern "C" int upp_linear_wgrad_grouped_sb_rows(int count, const int *M, const i
         double work = 0.0;
         for (int p = 0; p < count; ++p)
             if ((cls[p] == WS_TALL_SWAPPED ? WS_TALL : cls[p]) == launch) work += (double)ws_tiles(cls[p], N[p], K[p]) * M[p];
-        static const double rounds = [] { const char *e = getenv("UPP_WGRAD_ROUNDS"); const double v = e ? atof(e) : 0.0; return v >= 0.5 && v <= 16.0 ? v : 3.0; }();   // (A/B switch)
+        const double rounds = 3.0;                           // (A/B: profiles/r05_wgrad_rounds.txt)
         long long per_unit = (long long)(work / (launch == WS_NARROW ? 512.0 * rounds : 256.0 * rounds));
         per_unit = (per_unit + 31) / 32 * 32;
         if (per_unit < 256) per_unit = 256;
@@ -522,8 +366,7 @@ extern "C" int upp_linear_wgrad_grouped_sb(const float *const *G, const long lon
             if (!np) return 0;
             g.unit0[np] = (int)units;
             for (int q = np + 1; q <= kMaxWgProblems; ++q) g.unit0[q] = 0x7fffffff;
-            if (launch == WS_WIDE && ws_specialised()) hipLaunchKernelGGL(wgrad_ws_kernel, dim3((unsigned)units), dim3(512), 0, (hipStream_t)stream, g);
-            else if (launch == WS_WIDE) hipLaunchKernelGGL((wgrad_sb_kernel<4, 2, 2, 4, 1>), dim3((unsigned)units), dim3(512), 0, (hipStream_t)stream, g);
+            if (launch == WS_WIDE) hipLaunchKernelGGL((wgrad_sb_kernel<4, 2, 2, 4, 1>), dim3((unsigned)units), dim3(512), 0, (hipStream_t)stream, g);
             else if (launch == WS_TALL) hipLaunchKernelGGL((wgrad_sb_kernel<2, 4, 2, 3, 1>), dim3((unsigned)units), dim3(512), 0, (hipStream_t)stream, g);
             else hipLaunchKernelGGL((wgrad_sb_kernel<2, 2, 2, 2, 2>), dim3((unsigned)units), dim3(256), 0, (hipStream_t)stream, g);
             np = 0;

@@ -204,20 +204,13 @@ class _RowLN(Function):
     One kernel forward, one backward (+ one for trainable LayerNorm parameters).  See upp_rowln_fwd."""
 
     @staticmethod
-    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps, cls_add=None, ybias=None, pre=None):
+    def forward(ctx, x, add, prompts, y, gamma, beta, mode, P, u, keep, eps, cls_add=None, ybias=None):
         x = x.contiguous()
         B, Lin, D = x.shape
         Lout = Lin + P if mode in (ROW_INSERT_CLS, ROW_INSERT) else (Lin - P if mode in (ROW_STRIP_CLS, ROW_STRIP) else Lin)
-        if pre is not None:
-            # the rows, their LayerNorm and its statistics were computed by the launch that produced x (the previous block's tail:
-            # upp_ln_adapter_fwd_next) -- this node only carries the backward
-            xo, h, mean, rstd = pre
-            if tuple(xo.shape) != (B, Lout, D) or y is not None or gamma is None:
-                raise RuntimeError("rowln: precomputed head does not match this call")
-        else:
-            add_c = add.contiguous() if add is not None else None
-            y_c = y.contiguous() if y is not None else None
-            xo, h, mean, rstd = ops.rowln_fwd(x, add_c, prompts, mode, P, y_c, u, keep, gamma, beta, eps, Lout, ybias=ybias)
+        add_c = add.contiguous() if add is not None else None
+        y_c = y.contiguous() if y is not None else None
+        xo, h, mean, rstd = ops.rowln_fwd(x, add_c, prompts, mode, P, y_c, u, keep, gamma, beta, eps, Lout, ybias=ybias)
         ctx.save_for_backward(xo, mean, rstd, gamma, u)
         ctx.dims = (B, Lin, Lout, D, P, mode)
         ctx.keep = keep
@@ -237,7 +230,7 @@ class _RowLN(Function):
         g_xo = g_xo.contiguous() if g_xo is not None else None
         g_hc = g_h.contiguous() if (has_ln and g_h is not None) else None
         if g_xo is None and g_hc is None:
-            return (None,) * 14
+            return (None,) * 13
         strip = mode in (ROW_STRIP_CLS, ROW_STRIP) and P > 0
         need_cls = ctx.cls_shape is not None and len(need) > 11 and need[11]
         need_ln = has_ln and g_hc is not None and (need[4] or need[5])
@@ -259,11 +252,11 @@ class _RowLN(Function):
             if g_prompts is not None:
                 g_prompts = g_prompts.view(P, D)
         return (g_x if need[0] else None, g_x if (has_add and need[1]) else None, g_prompts, g_y,
-                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None, g_cls, None, None)
+                g_gamma if need[4] else None, g_beta if need[5] else None, None, None, None, None, None, g_cls, None)
 
 
 def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDENTITY, P=0, u=None, keep=1.0, eps=1e-5, cls_add=None,
-          ybias=None, pre=None):
+          ybias=None):
     """-> (rows (B,Lout,D), LayerNorm(rows) or None).  mode / P: see ROW_* and upp_rowln_fwd.
     ybias: optional (D) frozen bias added to y (the Linear that produced y then runs its GEMM bias-free).
     cls_add: optional (1,1,D) parameter that `add` (passed detached) carries in its row 0 for every sample; its gradient
@@ -272,11 +265,7 @@ def rowln(x, add=None, prompts=None, y=None, gamma=None, beta=None, mode=ROW_IDE
         raise ValueError("cls_add needs a detached `add` and a row map that keeps source row 0 in place")
     if ybias is not None and (y is None or (torch.is_grad_enabled() and ybias.requires_grad)):
         raise ValueError("ybias is the frozen bias of the Linear that produced y")
-    if pre is not None and not (torch.is_grad_enabled() and (x.requires_grad or (add is not None and add.requires_grad)
-                                                            or (prompts is not None and prompts.requires_grad)
-                                                            or (gamma is not None and (gamma.requires_grad or beta.requires_grad)))):
-        return pre[0], pre[1]                       # nothing to differentiate: the precomputed head as it is
-    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps), cls_add, ybias, pre)
+    xo, h = _RowLN.apply(x, add, prompts, y, gamma, beta, int(mode), int(P), u, float(keep), float(eps), cls_add, ybias)
     return xo, (h if gamma is not None else None)
 
 
@@ -794,114 +783,13 @@ class _MlpGelu(Function):
         return gx, gw1, gb1, gw2, gb2
 
 
-# ---- residual + LayerNorm between two Linear layers without a row kernel (round 5; upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32)
-class LazyLayerNorm:
-    """What `proj_resid_ln` hands on in place of the normalised rows: the rows themselves, their block statistics and the LayerNorm's
-    parameters -- `mlp_gelu` applies the LayerNorm in the A-prologue of its first GEMM, which also writes mean / rstd for the backward."""
-
-    def __init__(self, rows, stats, mean, rstd, gamma, beta, eps):
-        self.rows, self.stats, self.mean, self.rstd, self.gamma, self.beta, self.eps = rows, stats, mean, rstd, gamma, beta, eps
-
-
-class _ProjResidLN(Function):
-    """(x2, h2) = (xa + dp (a . W^T + b), LayerNorm(x2)) where h2 is only a graph handle (a zero-stride dummy): ONE launch -- the
-    projection GEMM with the residual add and the row-block statistics in its epilogue -- for the projection GEMM + upp_rowln_fwd.
-    Backward: upp_rowln_bwd on (g_x2, g_h2) exactly as _RowLN, then the projection's data gradient.  W, b, gamma, beta frozen."""
-
-    @staticmethod
-    def forward(ctx, a, w, bias, xa, u, keep, gamma, beta, eps):
-        B, L, D = xa.shape
-        x2, stats = ops.linear_sb_resid(a, ops.PLANES.get(w), tuple(w.shape), bias, xa, u, keep, L)
-        mean = torch.empty(B * L, dtype=torch.float32, device=xa.device)          # (filled by the GEMM that consumes the handle)
-        rstd = torch.empty(B * L, dtype=torch.float32, device=xa.device)
-        h2 = x2.new_zeros(1).expand(B, L, D)
-        ctx.save_for_backward(x2, mean, rstd, gamma, u, w)
-        ctx.keep, ctx.dims = keep, (B, L, D)
-        ctx.mark_non_differentiable(stats, mean, rstd)
-        return x2, h2, stats, mean, rstd
-
-    @staticmethod
-    def backward(ctx, g_x2, g_h2, _gs, _gm, _gr):
-        x2, mean, rstd, gamma, u, w = ctx.saved_tensors
-        B, L, D = ctx.dims
-        need = ctx.needs_input_grad
-        g_x2 = g_x2.contiguous() if g_x2 is not None else None
-        g_h2 = g_h2.contiguous() if g_h2 is not None else None
-        if g_x2 is None and g_h2 is None:
-            return (None,) * 9
-        g_x, _, g_y, _ = ops.rowln_bwd(g_x2, g_h2, x2, mean.view(B, L), rstd.view(B, L), gamma, ROW_IDENTITY, u, ctx.keep, B, L, L, D, 0,
-                                       need_x=need[3], need_prompt=False, need_y=need[0], need_ln_part=False)
-        g_a = _lin(g_y.view(B * L, D), w, dgrad=True).view(B, L, w.shape[1]) if need[0] else None
-        return g_a, None, None, g_x if need[3] else None, None, None, None, None, None
-
-
-def proj_resid_ln_usable(a, w, bias, xa, ln, fc1_weight):
-    """Can (projection GEMM + residual + LayerNorm + first MLP GEMM) run without the row kernel between them?  Frozen projection and
-    LayerNorm parameters, HIP f32 rows of a multiple of 32 columns, split-bf16 kernels for both GEMMs and a first-MLP-GEMM tile that
-    carries the A-operand prologue."""
-    if not (ops.SPLIT_BF16 and FUSE_RESID_LN and a.is_cuda and a.dtype == torch.float32 and xa.dtype == torch.float32 and xa.dim() == 3):
-        return False
-    D = xa.shape[-1]
-    M = xa.shape[0] * xa.shape[1]
-    grad = torch.is_grad_enabled()
-    if grad and (w.requires_grad or (bias is not None and bias.requires_grad) or ln.weight.requires_grad or ln.bias.requires_grad or fc1_weight.requires_grad):
-        return False
-    return (isinstance(ln, torch.nn.LayerNorm) and ln.elementwise_affine and ln.bias is not None and D % 32 == 0 and D <= 512 and w.shape[0] == D
-            and w.stride(1) == 1 and w.data_ptr() % 16 == 0 and w.stride(0) % 4 == 0 and (bias is None or bias.data_ptr() % 16 == 0)
-            and ops.linear_sb_usable(M, D, w.shape[1]) and fc1_weight.shape[1] == D and ops.linear_sb_ln_usable(M, fc1_weight.shape[0], D))
-
-
-# OFF by default: measured on MI355X (profiles/r05_fold_ab.txt) the fold LOSES -- fc1 with the LayerNorm prologue 26.3 us against 21.3 (its
-# k-loop is at the vector-issue limit: MFMA issue + the operand split; 24 more VALU per k-step and wave land on it), the projection with the
-# residual epilogue 8.8 against 8.0, for a 5.6 us row kernel + one launch boundary saved: 4.63-4.66 ms per step against 4.55-4.59.
-FUSE_RESID_LN = os.environ.get("UPP_FUSE_RESID_LN", "0") == "1"
-
-
-def proj_resid_ln(a, w, bias, xa, u, keep, ln):
-    """-> (x2 (B,L,D) = xa + drop_path(a . w^T + bias), handle of LayerNorm(x2) for mlp_gelu).  Ask proj_resid_ln_usable first."""
-    keep = float(keep)
-    if torch.is_grad_enabled() and (a.requires_grad or xa.requires_grad):
-        x2, h2, stats, mean, rstd = _ProjResidLN.apply(a, w, bias, xa, u, keep, ln.weight, ln.bias, float(ln.eps))
-    else:
-        B, L, D = xa.shape
-        x2, stats = ops.linear_sb_resid(a, ops.PLANES.get(w), tuple(w.shape), bias, xa, u, keep, L)
-        h2, mean, rstd = x2.new_zeros(1).expand(B, L, D), None, None
-    h2._upp_lazy_ln = LazyLayerNorm(x2, stats, mean, rstd, ln.weight, ln.bias, float(ln.eps))
-    return x2, h2
-
-
-class _MlpGeluLN(Function):
-    """_MlpGelu for frozen weights whose input is a LazyLayerNorm handle: fc1 runs upp_linear_sb_ln_f32 on the un-normalised rows."""
-
-    @staticmethod
-    def forward(ctx, h_dummy, rows, stats, mean, rstd, gamma, beta, eps, w1, b1, w2, b2):
-        B, L, D = rows.shape
-        # (mean / rstd: the buffers _ProjResidLN saved for ITS backward -- this launch fills them)
-        hid, d, _, _ = ops.linear_sb_ln(rows, stats, gamma, beta, eps, ops.PLANES.get(w1), tuple(w1.shape), b1, ops.LIN_BIAS_GELU_D, mean=mean, rstd=rstd)
-        ctx.save_for_backward(d, w1, w2)
-        return _lin(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE)
-
-    @staticmethod
-    def backward(ctx, g):
-        d, w1, w2 = ctx.saved_tensors
-        g2 = g.reshape(-1, g.shape[-1])
-        if not g2.is_contiguous():
-            g2 = g2.contiguous()
-        g_z = _lin(g2, w2, None, ops.LIN_MUL, aux=d.view(-1, d.shape[-1]), dgrad=True)
-        gx = _lin(g_z, w1, dgrad=True).view(g.shape[:-1] + (w1.shape[1],)) if ctx.needs_input_grad[0] else None
-        return (gx,) + (None,) * 11
+# (round 5's residual + LayerNorm fold -- residual add + row-block statistics in the projection GEMM's epilogue, LayerNorm in fc1's A-prologue --
+# was measured slower than the row kernel it removed (profiles/r05_fold_ab.txt: 4.63-4.66 against 4.55-4.59 ms per step) and left the library
+# with ABI 5; NOTEBOOK section 11.3 keeps the account.)
 
 
 def mlp_gelu(x, w1, b1, w2, b2=None):
-    """fc2(GELU(fc1(x) + b1)) (+ b2); both GEMMs and the activation on the Linear kernels (split-bf16 for frozen / managed weights).
-    x may be the handle of proj_resid_ln: the LayerNorm is then applied in fc1's A-prologue."""
-    lazy = getattr(x, '_upp_lazy_ln', None)
-    if lazy is not None:
-        if lazy.mean is not None and torch.is_grad_enabled() and x.requires_grad:
-            return _MlpGeluLN.apply(x, lazy.rows, lazy.stats, lazy.mean, lazy.rstd, lazy.gamma, lazy.beta, lazy.eps, w1, b1, w2, b2)
-        hid, _, _, _ = ops.linear_sb_ln(lazy.rows, lazy.stats, lazy.gamma, lazy.beta, lazy.eps, ops.PLANES.get(w1), tuple(w1.shape), b1, ops.LIN_BIAS_GELU,
-                                        want_rowstats=False)
-        return ops.linear_f32(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE, frozen=True)
+    """fc2(GELU(fc1(x) + b1)) (+ b2); both GEMMs and the activation on the Linear kernels (split-bf16 for frozen / managed weights)."""
     if not torch.is_grad_enabled() or not (x.requires_grad or w1.requires_grad or w2.requires_grad or b1.requires_grad
                                            or (b2 is not None and b2.requires_grad)):
         hid = ops.linear_f32(x, w1, b1, ops.LIN_BIAS_GELU, frozen=not w1.requires_grad)
@@ -1152,7 +1040,8 @@ def group_max(x):
 def argsort_rows(key, descending=False, stable=True):
     """torch.argsort(key, dim=-1, descending=..., stable=True) of short rows (N <= 16384) on the rank-counting kernel (upp_argsort_rows)
     for f32 HIP tensors; anything else (CPU tensors on a GPU-less host, other dtypes, long rows) takes torch.argsort.  Integer / bool
-    keys of small magnitude (a mask) are ranked through their exact f32 image."""
+    keys of small magnitude (a mask) are ranked through their exact f32 image.  The kernel's order IS the stable one (ties by index, NaN
+    above +inf as torch ranks it), so `stable=False` -- which only permits another tie order -- is served by the same launch."""
     if isinstance(key, torch.Tensor) and key.is_cuda and key.dim() >= 1 and 1 <= key.shape[-1] <= 16384 and key.numel() < 2 ** 31:
         if key.dtype == torch.float32:
             return ops.argsort_rows(key.detach(), descending)
@@ -1206,8 +1095,8 @@ def gather_rows(points, idx):
     if d is None:
         d = torch.zeros(B, M, 1, device=points.device)
         if not torch.cuda.is_current_stream_capturing():          # (memory of a graph's private pool is never cached)
-            if len(_UNIT_DIST) > 64:
-                _UNIT_DIST.clear()
+            # never evicted (B M 4 bytes per shape): a HIP graph captured earlier has the address of a cached tensor baked into its interp
+            # launches -- returning that memory to the allocator would let a later tensor put anything under a replayed graph's weights
             _UNIT_DIST[key] = d
     tab = idx.contiguous().view(B, M, 1)
     if torch.is_grad_enabled() and points.requires_grad:
@@ -1426,25 +1315,20 @@ class _LnAdapter(Function):
     rows) followed by upp_rowln_bwd -- the two kernels of the unfused path, minus the stored LayerNorm output."""
 
     @staticmethod
-    def forward(ctx, x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, pd, scale, next_head=None):
+    def forward(ctx, x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, pd, scale):
         x = x.contiguous()
         B, Lin, D = x.shape
         Lout = Lin - P if mode in (ROW_STRIP_CLS, ROW_STRIP) else Lin
         y_c = y.contiguous() if y is not None else None
-        res = ops.ln_adapter_fwd(x, y_c, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, pd, scale, Lout, next_head=next_head)
-        out, xo, mean, rstd, s1 = res[:5]
+        out, xo, mean, rstd, s1 = ops.ln_adapter_fwd(x, y_c, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, pd, scale, Lout)
         ctx.save_for_backward(xo, mean, rstd, gamma, beta, u, s1, W1, W2, ud)
         ctx.dims = (B, Lin, Lout, D, P, mode)
         ctx.meta = (keep, pd, scale, y is not None)
         ctx.param_ptrs = (gamma.data_ptr(), beta.data_ptr(), W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr())
-        if next_head is None:
-            return out
-        pre = res[5]
-        ctx.mark_non_differentiable(*pre)
-        return (out,) + tuple(pre)
+        return out
 
     @staticmethod
-    def backward(ctx, g_out, *_unused):
+    def backward(ctx, g_out):
         xo, mean, rstd, gamma, beta, u, s1, W1, W2, ud = ctx.saved_tensors
         B, Lin, Lout, D, P, mode = ctx.dims
         keep, pd, scale, has_y = ctx.meta
@@ -1474,33 +1358,18 @@ class _LnAdapter(Function):
             gW2 = gW2.view(D, H) if gW2 is not None else None
         return (g_x if need[0] else None, g_y, None, None, None, None, None, g_gamma if need[7] else None, g_beta if need[8] else None,
                 None, gW1 if need[10] else None, gb1 if need[11] else None, gW2 if need[12] else None, gb2 if need[13] else None,
-                None, None, None, None)
+                None, None, None)
 
 
-# OFF by default: measured on MI355X the tail launch grows by what the head launch cost (tools/micro/time_ln_adapter.py: 9.75 -> 14.14 us against
-# 9.75 + 4.55 in two launches: the extra phase is one more latency chain on 150 eight-wave workgroups, where upp_rowln_fwd spreads the same
-# rows over 600) and the step gets SLOWER (4.71 against 4.57 ms pipelined, 6.62 against 6.50 on one stream: the separate row kernel fills the
-# gaps of the other stream's GEMMs, the longer tail does not).  UPP_FUSE_NEXT_HEAD=1 switches it on; bit-identical results either way.
-FUSE_NEXT_HEAD = os.environ.get("UPP_FUSE_NEXT_HEAD", "0") == "1"
-
-
-def ln_adapter(x, y, ybias, u, keep, mode, P, ln, W1, b1, W2, b2, ud=None, pd=0.0, scale=0.7, next_head=None):
+# (round 5 also let this launch compute the NEXT block's head -- upp_ln_adapter_fwd_next: bit-identical, and slower: the tail grew by what the
+# head launch cost and the step went 4.57 -> 4.71 ms; it left the library with ABI 5, NOTEBOOK section 11.6.)
+def ln_adapter(x, y, ybias, u, keep, mode, P, ln, W1, b1, W2, b2, ud=None, pd=0.0, scale=0.7):
     """One launch for `rowln(x, y=y, ybias=ybias, u=u, keep=keep, mode=mode, P=P, gamma, beta)` + `adapter(ha, rows, ...)`
-    (mode: ROW_IDENTITY / ROW_STRIP_CLS / ROW_STRIP).  Limits: D == 384, 32 hidden units.
-    next_head = (add, prompts, mode2, P2, norm): the head of the NEXT block -- rowln(out, add=add, prompts=prompts, mode=mode2, P=P2,
-    gamma / beta of norm) -- computed by the same launch from the rows while they are in the LDS (round 5); -> (out, pre) with
-    pre = (rows2, LayerNorm(rows2), mean2, rstd2) to be handed to that rowln call as `pre`."""
+    (mode: ROW_IDENTITY / ROW_STRIP_CLS / ROW_STRIP).  Limits: D == 384, 32 hidden units."""
     if ybias is not None and (y is None or (torch.is_grad_enabled() and ybias.requires_grad)):
         raise ValueError("ybias is the frozen bias of the Linear that produced y")
-    if next_head is None:
-        return _LnAdapter.apply(x, y, ybias, u, float(keep), int(mode), int(P), ln.weight, ln.bias, float(ln.eps), W1, b1, W2, b2, ud,
-                                float(pd), float(scale))
-    add2, prm2, mode2, P2, n2 = next_head
-    spec = (add2.detach().contiguous() if add2 is not None else None, prm2.detach() if prm2 is not None else None, int(mode2), int(P2),
-            n2.weight.detach(), n2.bias.detach(), float(n2.eps))
-    res = _LnAdapter.apply(x, y, ybias, u, float(keep), int(mode), int(P), ln.weight, ln.bias, float(ln.eps), W1, b1, W2, b2, ud,
-                           float(pd), float(scale), spec)
-    return res[0], tuple(res[1:])
+    return _LnAdapter.apply(x, y, ybias, u, float(keep), int(mode), int(P), ln.weight, ln.bias, float(ln.eps), W1, b1, W2, b2, ud,
+                            float(pd), float(scale))
 
 
 def adapter(ha, x, W1, b1, W2, b2, u=None, p=0.0, scale=0.7):

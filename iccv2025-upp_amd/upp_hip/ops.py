@@ -42,14 +42,21 @@ def _call(dev, name, *args):
 
 
 # ------------------------------------------------------------------ FPS / gather
-_FPS_FORM = [0]          # bits 8-12 of upp_fps_ex's `waves`: clouds per workgroup, whole-LDS reservation (see fps_form)
+import threading
+
+_FPS_FORM = threading.local()          # .form: bits 8-12 of upp_fps_ex's `waves` (clouds per workgroup, whole-LDS reservation); per THREAD
+
+
+def _fps_form_bits():
+    return getattr(_FPS_FORM, "form", 0)
 
 
 class fps_form:
-    """with ops.fps_form(2, True): ... -- FPS launches inside pack `clouds` (1 / 2 / 4) clouds into a workgroup and, with `exclusive`, reserve
-    their CUs' whole LDS.  Same indices.  For a stream that runs BESIDE another one (the pipelined step's front-end): a 32-cloud FPS that
-    shares 32 CUs with the other stream's workgroups slows every one-round GEMM of that stream for as long as it is resident; 16 CUs of its own
-    cost the FPS 11 % and return 1.5 % of the step (tools/micro/fps_cpw_ab.sh).  Stand-alone the spread form is the faster one: the default."""
+    """with ops.fps_form(2, True): ... -- FPS launches of THIS thread inside pack `clouds` (1 / 2 / 4) clouds into a workgroup and, with
+    `exclusive`, reserve their CUs' whole LDS.  Same indices.  For a stream that runs BESIDE another one (the pipelined step's front-end): a
+    32-cloud FPS that shares 32 CUs with the other stream's workgroups slows every one-round GEMM of that stream for as long as it is resident;
+    16 CUs of its own cost the FPS 11 % and return 1.5 % of the step (tools/micro/fps_cpw_ab.sh).  Stand-alone the spread form is the faster
+    one: the default.  The form is thread-local: another thread's FPS calls issued meanwhile keep their own."""
 
     def __init__(self, clouds, exclusive=False):
         if clouds not in (1, 2, 4):
@@ -57,12 +64,33 @@ class fps_form:
         self.form = (int(clouds) << 8) | (0x1000 if exclusive else 0)
 
     def __enter__(self):
-        self.prev = _FPS_FORM[0]
-        _FPS_FORM[0] = self.form
+        self.prev = _fps_form_bits()
+        _FPS_FORM.form = self.form
 
     def __exit__(self, *exc):
-        _FPS_FORM[0] = self.prev
+        _FPS_FORM.form = self.prev
         return False
+
+
+class option:
+    """with ops.option("EMBED_SPLIT_BF16", 0): ... -- one of the library's four documented process-wide options (include/upp_hip.h
+    upp_set_option: SB_TUNED, SB_XCD2D, STORE_WT, EMBED_SPLIT_BF16) set for the duration of the block; tests and A/B measurements."""
+
+    def __init__(self, name, value):
+        self.key, self.value = _abi.OPTIONS[name], int(value)
+
+    def __enter__(self):
+        lib = _abi.load()
+        self.prev = int(lib.upp_get_option(self.key))
+        _abi.check(lib.upp_set_option(self.key, self.value))
+
+    def __exit__(self, *exc):
+        _abi.check(_abi.load().upp_set_option(self.key, self.prev))
+        return False
+
+
+def get_option(name):
+    return int(_abi.load().upp_get_option(_abi.OPTIONS[name]))
 
 
 def fps(xyz, npoint, want_centers=False, waves=0):
@@ -76,7 +104,7 @@ def fps(xyz, npoint, want_centers=False, waves=0):
     centers = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if want_centers else None
     if B == 0:                               # an empty batch: nothing to launch (an empty tensor has no device pointer to hand over)
         return (idx, centers) if want_centers else idx
-    _call(xyz.device, "upp_fps_ex", _abi.ptr(xyz), _abi.ptr(idx), _abi.ptr(centers), B, N, npoint, int(waves) | _FPS_FORM[0])
+    _call(xyz.device, "upp_fps_ex", _abi.ptr(xyz), _abi.ptr(idx), _abi.ptr(centers), B, N, npoint, int(waves) | _fps_form_bits())
     return (idx, centers) if want_centers else idx
 
 
@@ -474,73 +502,6 @@ def linear_f32(a, w, bias=None, epilogue=LIN_NONE, aux=None, tile=0, out=None, f
         ev1.record()
         scope.calls.append((M, N, K, int(epilogue), ev0, ev1, sb))
     return (out, d) if epilogue == LIN_BIAS_GELU_D else out
-
-
-def linear_sb_ln_usable(M, N, K):
-    """Does upp_linear_sb_ln_f32 (LayerNorm in the A-prologue) take an (M,K) x (N,K)^T product?"""
-    return bool(SPLIT_BF16 and int(_abi.load().upp_linear_sb_ln_usable(int(M), int(N), int(K))))
-
-
-def linear_sb_resid(a, planes, wshape, bias, resid, u, keep, rows_per_sample):
-    """-> (x (M,N) = resid + dp (a . W^T + bias), row_stats (M, N/32, 2)): the Linear layer with the residual add of the block and the
-    statistics of the LayerNorm that follows in its epilogue (upp_linear_sb_resid_f32).  a (...,K), resid (...,N) f32 contiguous."""
-    N, K = wshape
-    _need(a, "a", torch.float32)
-    _need(resid, "resid", torch.float32)
-    a2, r2 = a.reshape(-1, K), resid.reshape(-1, N)
-    if not a2.is_contiguous():
-        a2 = a2.contiguous()
-    if not r2.is_contiguous():
-        r2 = r2.contiguous()
-    M = a2.shape[0]
-    if r2.shape[0] != M or N % 32:
-        raise RuntimeError("linear_sb_resid: resid must be (M,N) with N % 32 == 0")
-    sb = linear_sb_tile(M, N, K)
-    if not sb:
-        raise RuntimeError("linear_sb_resid: not a problem for the split-bf16 kernel (ask linear_sb_usable first)")
-    out = torch.empty(tuple(resid.shape), dtype=torch.float32, device=a.device)
-    stats = torch.empty((M, N // 32, 2), dtype=torch.float32, device=a.device)
-    scope = time_linear_calls.active
-    if scope is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    _call(a.device, "upp_linear_sb_resid_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(planes), _abi.ptr(bias), _abi.ptr(r2), N, _abi.ptr(u), float(keep),
-          int(rows_per_sample), _abi.ptr(out), N, _abi.ptr(stats), M, N, K, sb)
-    if scope is not None:
-        ev1.record()
-        scope.calls.append((M, N, K, 6, ev0, ev1, sb))
-    return out, stats
-
-
-def linear_sb_ln(a, stats, gamma, beta, eps, planes, wshape, bias, epilogue, want_rowstats=True, mean=None, rstd=None):
-    """C = epilogue(LayerNorm(a) . W^T) with the LayerNorm applied in the kernel's A-prologue (upp_linear_sb_ln_f32): `stats` (M, K/32, 2) from
-    linear_sb_resid or (M, 2) = (mean, rstd).  mean / rstd: (M) buffers the kernel fills for the backward pass (allocated here when
-    want_rowstats and none is given).  -> (C, GELU' or None, mean, rstd)."""
-    N, K = wshape
-    _need(a, "a", torch.float32)
-    a2 = a.reshape(-1, K)
-    if not a2.is_contiguous():
-        a2 = a2.contiguous()
-    M = a2.shape[0]
-    nb = stats.shape[1] if stats.dim() == 3 else 0
-    lead = tuple(a.shape[:-1])
-    out = torch.empty(lead + (N,), dtype=torch.float32, device=a.device)
-    d = torch.empty(lead + (N,), dtype=torch.float32, device=a.device) if epilogue == LIN_BIAS_GELU_D else None
-    if want_rowstats and mean is None:
-        mean = torch.empty(M, dtype=torch.float32, device=a.device)
-        rstd = torch.empty(M, dtype=torch.float32, device=a.device)
-    if mean is not None and not (mean.numel() == M and rstd.numel() == M and mean.is_contiguous() and rstd.is_contiguous()):
-        raise RuntimeError("linear_sb_ln: mean / rstd must be contiguous (M) buffers")
-    scope = time_linear_calls.active
-    if scope is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    _call(a.device, "upp_linear_sb_ln_f32", _abi.ptr(a2), a2.stride(0), _abi.ptr(stats), int(nb), _abi.ptr(gamma), _abi.ptr(beta), float(eps),
-          _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(planes), _abi.ptr(bias), _abi.ptr(out), N, _abi.ptr(d), N, M, N, K, int(epilogue))
-    if scope is not None:
-        ev1.record()
-        scope.calls.append((M, N, K, int(epilogue) + 16, ev0, ev1, linear_sb_tile(M, N, K)))
-    return out, d, mean, rstd
 
 
 def colsum_partials(part, offset, length, chunks=None):
@@ -1252,10 +1213,8 @@ def adapter_fwd(ha, x, W1, b1, W2, b2, u, p, scale):
     return out, s1
 
 
-def ln_adapter_fwd(x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, Lout, next_head=None):
-    """Residual + prompt strip + adapter LayerNorm + adapter in one launch -> (out, xo, mean, rstd, s1); upp_ln_adapter_fwd.
-    next_head = (add (B,Lout,D) or None, prompts (P2,D) or None, mode2 (0 | 1 | 2), P2, gamma2, beta2, eps2): the same launch also computes
-    the next block's head (upp_ln_adapter_fwd_next) -> (..., (xo2, h2, mean2, rstd2))."""
+def ln_adapter_fwd(x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, b2, ud, p, scale, Lout):
+    """Residual + prompt strip + adapter LayerNorm + adapter in one launch -> (out, xo, mean, rstd, s1); upp_ln_adapter_fwd."""
     _need(x, "x", torch.float32, ndim=3)
     B, Lin, D = x.shape
     H = W1.shape[0]
@@ -1269,23 +1228,6 @@ def ln_adapter_fwd(x, y, ybias, u, keep, mode, P, gamma, beta, eps, W1, b1, W2, 
     mean = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     rstd = torch.empty((B, Lout), dtype=torch.float32, device=dev)
     s1 = torch.empty((B * Lout, H), dtype=torch.float32, device=dev)
-    if next_head is not None:
-        add2, prm2, mode2, P2, g2, b2n, eps2 = next_head
-        L2 = Lout + (int(P2) if mode2 else 0)
-        if add2 is not None:
-            _need(add2, "next add", torch.float32)
-            if tuple(add2.shape) != (B, Lout, D) or not add2.is_contiguous():
-                raise RuntimeError("ln_adapter_fwd: the next block's `add` must be a contiguous (B, Lout, D) tensor")
-        xo2 = torch.empty((B, L2, D), dtype=torch.float32, device=dev)
-        h2 = torch.empty((B, L2, D), dtype=torch.float32, device=dev)
-        mean2 = torch.empty((B, L2), dtype=torch.float32, device=dev)
-        rstd2 = torch.empty((B, L2), dtype=torch.float32, device=dev)
-        _call(dev, "upp_ln_adapter_fwd_next", _abi.ptr(x), _abi.ptr(y), _abi.ptr(ybias), _abi.ptr(u), float(keep), int(mode), int(P), _abi.ptr(gamma),
-              _abi.ptr(beta), float(eps), _abi.ptr(W1), _abi.ptr(b1), _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(ud), float(p), float(scale),
-              _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(s1), _abi.ptr(out), B, Lin, Lout, D, H,
-              _abi.ptr(add2), _abi.ptr(prm2), int(mode2), int(P2), _abi.ptr(g2), _abi.ptr(b2n), float(eps2), _abi.ptr(xo2), _abi.ptr(h2),
-              _abi.ptr(mean2), _abi.ptr(rstd2))
-        return out, xo, mean, rstd, s1, (xo2, h2, mean2, rstd2)
     _call(dev, "upp_ln_adapter_fwd", _abi.ptr(x), _abi.ptr(y), _abi.ptr(ybias), _abi.ptr(u), float(keep), int(mode), int(P), _abi.ptr(gamma),
           _abi.ptr(beta), float(eps), _abi.ptr(W1), _abi.ptr(b1), _abi.ptr(W2), _abi.ptr(b2), _abi.ptr(ud), float(p), float(scale),
           _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(s1), _abi.ptr(out), B, Lin, Lout, D, H)

@@ -45,10 +45,13 @@ def fps(xyz, npoint):
 
 
 def knn(ref, query, k):
-    """ref (B,N,3), query (B,Q,3) -> (dist (B,Q,k) f32 squared distances ascending, idx (B,Q,k) int64; ties by index)."""
-    d = torch.cdist(query.detach(), ref.detach()) ** 2
-    order = torch.argsort(d, dim=-1, stable=True)[:, :, :k]
-    return torch.gather(d, -1, order), order
+    """ref (B,N,3), query (B,Q,3) -> (dist (B,Q,k) f32 EUCLIDEAN distances ascending, idx (B,Q,k) int64; ties by index) -- what KNN_CUDA
+    (its sqrt kernel) and ops.knn (csrc/knn.hip sqrtf) return.  Ranked on the direct squared distance sum_c (q_c - r_c)^2, not on
+    cdist ** 2 (whose rounding perturbs the tie order)."""
+    q, r = query.detach(), ref.detach()
+    d2 = ((q.unsqueeze(2) - r.unsqueeze(1)) ** 2).sum(-1)
+    order = torch.argsort(d2, dim=-1, stable=True)[:, :, :k]
+    return torch.gather(d2, -1, order).sqrt(), order
 
 
 def knn_group(xyz, center, k):

@@ -406,7 +406,9 @@ class PipelinedTrainStep(TrainStep):
         # (stream priorities do not help: round 2 5.89-5.92 ms for -1 / 0; round 5: front-end stream at high priority 4.58 against 4.54-4.55 ms,
         #  the whole driver on a high-priority stream of its own 4.83-4.84 against 4.63-4.64; the runtime offers no priority BELOW normal)
         self.s_front = torch.cuda.Stream(device=self.device)
-        self._fps_form = (1, False) if os.environ.get("UPP_PIPE_FPS_FORM") == "0" else (2, True)
+        # UPP_PIPE_FPS_FORM (host-side A/B switch, tools/micro/fps_cpw_ab.sh): "0" = the spread form, "<clouds>,<exclusive>" = that packed form
+        form = os.environ.get("UPP_PIPE_FPS_FORM", "2,1")
+        self._fps_form = (1, False) if form == "0" else (int(form.split(",")[0]), form.split(",")[1:] == ["1"])
         from models import upp_layers as _L
         self._L = _L
         self._gen_front = torch.Generator(device=self.device)          # the front-end's own random stream (see upp_layers.use_rng)

@@ -6,8 +6,10 @@
  * operator the reference binds through a torch C++/CUDA extension (file:line
  * of the replaced interface is cited per function).  The signatures use only
  * plain device pointers, sizes and a HIP stream (passed as void*): no torch
- * types, no allocation inside the library, no global state (the *_ex entry
- * points take the kernel variant of a measurement as an ARGUMENT).  The caller owns
+ * types, no allocation inside the library, and no global state other than the
+ * four documented options of upp_set_option() below (the *_ex entry points take
+ * the kernel variant of a measurement as an ARGUMENT; the library never reads
+ * the environment -- `grep getenv csrc/` is empty since ABI 5).  The caller owns
  * every buffer (including scratch) and the library never synchronises; all
  * work is enqueued on `stream` (hipStream_t; NULL = the default stream).
  *
@@ -27,7 +29,10 @@
 extern "C" {
 #endif
 
-#define UPP_ABI_VERSION 4   /* 4: + upp_argsort_rows, upp_group_max_fwd / _bwd, upp_ln_adapter_fwd_next, upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32 / upp_linear_sb_ln_usable (additions only).  3: split-bf16 Linear (upp_linear_sb_*); the k-parts protocol (upp_linear_parts*, upp_*_parts), the attention
+#define UPP_ABI_VERSION 5   /* 5 (round 6): SMALLER than 4 -- the measured-slower experiments left the library: upp_ln_adapter_fwd_next, upp_linear_sb_resid_f32,
+                               upp_linear_sb_ln_f32, upp_linear_sb_ln_usable (and the PRO = 2 instantiations, the wave-specialised weight-gradient kernel and the
+                               nine environment reads behind them); + upp_set_option / upp_get_option.
+                               4: + upp_argsort_rows, upp_group_max_fwd / _bwd.  3: split-bf16 Linear (upp_linear_sb_*); the k-parts protocol, the attention
                                `variant` entry points (upp_attn_*_ex) and the VALU / 32x32x2 attention kernels behind them are gone.
                                2: grouped weight gradients, register-tiled Linear codes; the round-1 *_set_* toggles are gone */
 
@@ -37,6 +42,23 @@ extern "C" {
 
 int         upp_abi_version(void);
 const char *upp_error_string(int code);
+
+/* ---- options: the library's only process-wide state -------------------------
+ * Every knob of the library, each with the product's default (an A/B-measured choice; the other values exist for measurements and
+ * tests).  Relaxed atomics: set them before launching work from several threads.  No entry point reads the environment; the Python
+ * host (upp_hip/_abi.py) forwards the variables of the same names ONCE at load time so that the A/B scripts under tools/ keep working.
+ *   UPP_OPT_SB_TUNED          1 | 0   upp_linear_sb_tile consults the measured tile table (csrc/linear_sb_tuned.h) before its cost
+ *                                     model | the model alone                                          [env UPP_SB_TUNED]
+ *   UPP_OPT_SB_XCD2D          2 | 0 | 4   column groups of the 2-D XCD tile map of one-round split-bf16 Linear launches with wide
+ *                                     outputs (0: row-major XCD ranges); traffic only, same results    [env UPP_SB_XCD2D]
+ *   UPP_OPT_STORE_WT          1 | 0   epilogue stores of the Linear kernels are agent-scope write-through (`sc1`) | plain
+ *                                     (same results; the end-of-kernel write-back is what differs)     [env UPP_STORE_WT]
+ *   UPP_OPT_EMBED_SPLIT_BF16  1 | 0   upp_patch_embed_fwd runs its two large products on the split-bf16 kernel | the exact-f32 chain
+ *                                     of rounds 1-3 (read per call)                                    [env UPP_EMBED_SPLIT_BF16]
+ * upp_set_option: 0, UPP_E_BADARG (unknown key) or UPP_E_RANGE (value not listed above).  upp_get_option: the value (>= 0) or UPP_E_BADARG. */
+enum { UPP_OPT_SB_TUNED = 0, UPP_OPT_SB_XCD2D = 1, UPP_OPT_STORE_WT = 2, UPP_OPT_EMBED_SPLIT_BF16 = 3, UPP_OPT_COUNT = 4 };
+int upp_set_option(int key, int value);
+int upp_get_option(int key);
 
 /* ---- furthest point sampling ------------------------------------------------
  * Replaces pointnet2_ops._ext.furthest_point_sampling(xyz, npoint)
@@ -166,7 +188,7 @@ int upp_emd_matchcost_bwd(const float *grad_cost, const float *xyz1, const float
  * Forward only (the encoder is frozen in every UPP recipe).
  * Arithmetic (round 4): the 256 -> 512 and 512 -> C products run on the split-bf16 kernel of upp_linear_sb_f32 (both f32 operands as
  * three bf16 terms, six products, f32 accumulation: the error of an f32 GEMM) for C <= 1024, their weights split into `work` by every
- * call; the environment variable UPP_EMBED_SPLIT_BF16=0 (read per call) keeps the exact-f32 chain of rounds 1-3.  BatchNorm batch
+ * call; option UPP_OPT_EMBED_SPLIT_BF16 = 0 (read per call) keeps the exact-f32 chain of rounds 1-3.  BatchNorm batch
  * statistics are sums of per-workgroup partial sums in a fixed order (no atomics): the call is deterministic.
  * Limits: n in {16, 32}, R % n == 0, C % 4 == 0. */
 long long upp_patch_embed_work_floats(int R, int n);
@@ -437,17 +459,6 @@ int upp_ln_adapter_fwd(const float *x, const float *y, const float *ybias, const
                        const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
                        const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
                        float *out, int B, int Lin, int Lout, int D, int H, void *stream);
-/* upp_ln_adapter_fwd_next (round 5): the same launch also computes the HEAD of the next block from the finished rows -- what
- * upp_rowln_fwd(out, add = nx_add, prompts = nx_prompts, mode = nx_mode (0 identity | 1 insert nx_P prompts behind the cls row | 2 in
- * front), gamma / beta = nx_gamma / nx_beta) would (reference models/Point_MAE_unify.py:288-294 `block(x + pos)`,
- * models/Point_MAE_pretask_dev.py:247-266 prompt insertion + norm1): nx_xo, nx_h (B, Lnx, D), nx_mean / nx_rstd (B, Lnx), Lnx = Lout
- * (+ nx_P).  Values identical to upp_rowln_fwd's (same expressions).  Lout >= nx_P (+ 1 for mode 1). */
-int upp_ln_adapter_fwd_next(const float *x, const float *y, const float *ybias, const float *u, float keep, int mode, int P,
-                            const float *gamma, const float *beta, float eps, const float *W1, const float *b1, const float *W2,
-                            const float *b2, const float *ud, float p, float scale, float *xo, float *mean, float *rstd, float *s1,
-                            float *out, int B, int Lin, int Lout, int D, int H, const float *nx_add, const float *nx_prompts,
-                            int nx_mode, int nx_P, const float *nx_gamma, const float *nx_beta, float nx_eps, float *nx_xo,
-                            float *nx_h, float *nx_mean, float *nx_rstd, void *stream);
 /* upp_ln_adapter_bwd_fused: the whole backward of upp_ln_adapter_fwd in one launch on 16-row workgroups -- the adapter's backward
  * (g_ha, per-workgroup partials [dW1 (H,D) | dW2 (D,H) | db1 (H) | db2 (D)] in `part`, upp_ln_adapter_part_floats(R, D) floats, or
  * part = NULL), the LayerNorm backward with the residual (g_x / g_y (B, Lin, D): every row is written, zeros for the prompt rows
@@ -477,7 +488,7 @@ int upp_rectify_select(const float *feature, const float *W0, const float *b0, c
 
 /* Stable argsort of every row of key (B,N) f32 by rank counting (no library sort): order (B,N) int64 with order[b][r] = the index of the
  * r-th element of row b in ascending (descending != 0: descending) order, equal keys in index order -- what torch.argsort(...,
- * stable=True) returns, and what torch.argsort returns for distinct keys.  NaN ranks as +inf.  Replaces the reference's device sorts of
+ * stable=True) returns, and what torch.argsort returns for distinct keys.  NaN ranks ABOVE +inf (last ascending, first descending: torch.sort's order) and -0 equals +0; always a permutation.  Replaces the reference's device sorts of
  * short rows: torch.argsort(score, descending=True) of the pre-task noise recall (models/Point_MAE_pretask_dev.py:702-704), the masking
  * orders of Point-MAE pre-training (models/Point_MAE.py:300-329: argsort of uniform draws / of distances to a random centre, and the
  * visible-first order argsort(mask)).  Limits: N <= 16384 (the row lives in the LDS). */
@@ -566,7 +577,7 @@ int upp_linear_group_bias_f32(const float *A, long long lda, const float *W, lon
  *       BMB x BNB blocks of 32 x 32, a wave owns 1 x RN of them, the contraction cut over KS wave groups, NST LDS stages of 32 KS values
  *       of k), or 0 when the problem is not one for this kernel (K % 32, fewer k-stages than LDS stages, no tile fits).  The choice is the
  *       measured one for the Linear problems of the six recipes (csrc/linear_sb_tuned.h: same N and K, M within 1/16 of a swept M;
- *       profiles/r05_sb_sweep.json) and a cost model's otherwise; environment UPP_SB_TUNED=0 (read once) leaves the model alone.  Any
+ *       profiles/r05_sb_sweep.json) and a cost model's otherwise; option UPP_OPT_SB_TUNED = 0 leaves the model alone.  Any
  *       compiled tile code is valid for any problem whose K its wave groups' k-stages divide (a forced code: upp_linear_sb_f32's `tile`).
  *   upp_linear_sb_f32: epilogues and aux as upp_linear_f32; tile 0 = the library's choice.  Limits: K % 32 == 0 (% 64, % 128 for KS = 2, 4 tiles),
  *       N % 4 == 0, lda % 4 == 0, ldc % 4 == 0, ldaux % 4 == 0, A / C / bias / aux 16-byte aligned; UPP_E_RANGE otherwise (the caller
@@ -588,28 +599,6 @@ int upp_linear_sb_f32(const float *A, long long lda, const void *planes, const f
 int upp_linear_sb_group_bias_f32(const float *A, long long lda, const void *planes, const float *bias, int group_shift, float *C,
                                  long long ldc, int M, int N, int K, void *stream);
 
-/* ---- residual + LayerNorm between two Linear layers without a row kernel (round 5) -----------------------------------
- * Replaces, for the second half of a Transformer block (reference models/Point_MAE_pretask_dev.py:266,273:
- * `x = x + drop_path(attn(norm1(x)))` followed by `mlp(norm2(x))`), the launch that added the attention branch to the residual stream
- * and wrote its LayerNorm (upp_rowln_fwd):
- *   upp_linear_sb_resid_f32: C (M,N) = resid + dp_row * (A . W^T + bias), dp_row = floor(keep + u[row / rows_per_sample]) / keep (timm
- *       DropPath; u NULL: 1) -- the projection's GEMM with the residual add in its epilogue -- and row_stats (M, N/32, 2): per row and
- *       32-column block the pair (sum, sum of squared deviations from the block mean) of the stored values.  N % 32 == 0; resid (M, ld_res)
- *       16-byte aligned; tile as upp_linear_sb_f32.
- *   upp_linear_sb_ln_f32: C = epilogue( LayerNorm(A) . W^T ) with LayerNorm(A)[r][k] = ((A[r][k] - mean_r) * rstd_r) * gamma[k] + beta[k]
- *       applied to the f32 A fragment in front of its split: the normalised rows are never written.  ln_stats: ln_nb = K/32: the
- *       (M, ln_nb, 2) pairs of upp_linear_sb_resid_f32, combined per row without cancellation (mean = sum S_i / K, M2 = sum M2_i +
- *       32 sum (S_i/32 - mean)^2, rstd = 1 / sqrt(M2 / K + eps)); ln_nb = 0: (M, 2) = (mean, rstd).  ln_mean / ln_rstd (M) or NULL: the
- *       statistics, written for the backward pass (upp_rowln_bwd).  Epilogues and aux as upp_linear_sb_f32.  K <= 512 and a problem whose
- *       tile carries the A-operand prologue: ask upp_linear_sb_ln_usable(M, N, K) (1 / 0) first; UPP_E_RANGE otherwise.
- * Values equal upp_rowln_fwd + upp_linear_sb_f32 up to the summation order of the row statistics (tests/test_gpu_linear_sb.py). */
-int upp_linear_sb_ln_usable(int M, int N, int K);
-int upp_linear_sb_ln_f32(const float *A, long long lda, const float *ln_stats, int ln_nb, const float *gamma, const float *beta, float eps,
-                         float *ln_mean, float *ln_rstd, const void *planes, const float *bias, float *C, long long ldc, float *aux,
-                         long long ldaux, int M, int N, int K, int epilogue, void *stream);
-int upp_linear_sb_resid_f32(const float *A, long long lda, const void *planes, const float *bias, const float *resid, long long ld_res,
-                            const float *u, float keep, int rows_per_sample, float *C, long long ldc, float *row_stats, int M, int N,
-                            int K, int tile, void *stream);
 /* upp_linear_smallk_f32: y (M,N) = act(x (M,K) . W (N,K)^T + bias) for the Linear layers upp_linear_f32 does not take (K not a
  * multiple of 4, unaligned rows): the first layer of every position MLP (K = 3; reference models/Point_MAE_unify.py pos_embed /
  * models/Point_MAE_pretask_dev.py:395-399 `nn.Linear(3, 128), nn.GELU(), nn.Linear(128, dim)`) and the first point-wise layer of

@@ -27,11 +27,50 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_strings():
     lib = _abi.load()
-    assert lib.upp_abi_version() == 4
+    assert lib.upp_abi_version() == 5 == _abi.ABI_VERSION
     assert b"null pointer" in lib.upp_error_string(-1)
     assert b"range" in lib.upp_error_string(-2)
     assert b"knn" in lib.upp_error_string(-3)
     assert lib.upp_emd_work_floats(2, 10, 20) == 2 * 30 * 11
+
+
+def test_options_are_the_librarys_only_state_and_nothing_reads_the_environment():
+    """ABI 5 (include/upp_hip.h "options"): four documented process-wide options behind upp_set_option / upp_get_option, the product's
+    defaults, values outside the documented sets refused; no getenv left in the library (sources AND the built object's imports); the
+    measured-slower experiments of round 5 are gone from the export table."""
+    import subprocess
+    lib = _abi.load()
+    assert _abi.OPTIONS == {"SB_TUNED": 0, "SB_XCD2D": 1, "STORE_WT": 2, "EMBED_SPLIT_BF16": 3}
+    hdr = open(os.path.join(ROOT, "include", "upp_hip.h")).read()
+    for name, key in _abi.OPTIONS.items():
+        assert re.search(r"UPP_OPT_%s = %d\b" % (name, key), hdr), name
+        assert ("env UPP_" + name) in hdr
+    assert lib.upp_get_option(99) == -1 and lib.upp_set_option(99, 0) == -1 and lib.upp_set_option(-1, 0) == -1
+    was = [lib.upp_get_option(k) for k in range(4)]
+    try:
+        assert lib.upp_set_option(1, 3) == -2 and lib.upp_set_option(0, 2) == -2 and lib.upp_set_option(2, -1) == -2
+        for k, vals in ((0, (0, 1)), (1, (0, 2, 4)), (2, (0, 1)), (3, (0, 1))):
+            for v in vals:
+                assert lib.upp_set_option(k, v) == 0 and lib.upp_get_option(k) == v
+        # the option is live: the tile choice of a swept problem with and without the measured table (host functions)
+        lib.upp_set_option(0, 1)
+        t_on = lib.upp_linear_sb_tile(2400, 384, 1536)
+        lib.upp_set_option(0, 0)
+        t_off = lib.upp_linear_sb_tile(2400, 384, 1536)
+        assert t_on > 0 and t_off > 0
+    finally:
+        for k, v in enumerate(was):
+            lib.upp_set_option(k, v)
+    if "UPP_SB_TUNED" not in os.environ and "UPP_SB_XCD2D" not in os.environ and "UPP_STORE_WT" not in os.environ and "UPP_EMBED_SPLIT_BF16" not in os.environ:
+        assert was == [1, 2, 1, 1]                        # the product's defaults
+    csrc = os.path.join(ROOT, "iccv2025-upp_amd", "upp_hip", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    exported = subprocess.run(["nm", "-D", "--defined-only", _abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for gone in ("upp_ln_adapter_fwd_next", "upp_linear_sb_resid_f32", "upp_linear_sb_ln_f32", "upp_linear_sb_ln_usable"):
+        assert gone not in exported and gone not in hdr.split("#define UPP_E_BADARG")[1]
 
 
 def test_argument_validation_happens_before_any_launch():
@@ -104,8 +143,8 @@ def test_split_bf16_tuned_tile_table_is_well_formed_and_answers_for_its_own_prob
     swept problem ran in one."""
     import re
     from conftest import ROOT
-    if os.environ.get("UPP_SB_TUNED", "1")[:1] == "0":
-        pytest.skip("UPP_SB_TUNED=0: the library answers with the cost model alone")
+    if _abi.load().upp_get_option(_abi.OPTIONS["SB_TUNED"]) == 0:
+        pytest.skip("option SB_TUNED = 0: the library answers with the cost model alone")
     csrc = os.path.join(ROOT, "iccv2025-upp_amd", "upp_hip", "csrc")
     compiled = set()
     for f, macro in (("linear_sb.hip", "UPP_SB_CONFIGS"), ("linear_sb_tuned.h", "UPP_SB_TUNED_CONFIGS")):

@@ -823,96 +823,3 @@ def test_linear_with_a_deferred_bias_gradient_matches_autograd(rows, K, N):
     out = HF.linear(x, w, b)
     _, _, hb = torch.autograd.grad(out, (x, w, b), g)
     close(hb, gb, rtol=1e-5, atol_scale=1e-5)
-
-
-@pytest.mark.parametrize("name", ["down0", "down7", "decoder"])
-def test_resid_ln_fold_equals_the_row_kernel_path_at_the_benched_batch(name, train=False):
-    """Round 5: with frozen backbone weights (the PEFT recipes) the residual add of the attention branch rides in the projection GEMM's
-    epilogue and norm2 in the A-prologue of fc1 (upp_linear_sb_resid_f32 / upp_linear_sb_ln_f32; reference
-    models/Point_MAE_pretask_dev.py:266,273) -- no row kernel between the two GEMMs.  At B = 32 (the tile that carries the prologue) the
-    block's output and every gradient equal the row-kernel path to f32 rounding; the launch list shows the fold.  (The fold is an
-    OPTION, UPP_FUSE_RESID_LN=1: measured slower than the row kernel -- profiles/r05_fold_ab.txt -- and off by default.)
-    (Eval mode: the stochastic-depth factor of the epilogue is covered draw by draw in tests/test_gpu_linear_sb.py.)"""
-    from upp_hip import ops
-    from upp_hip.train import freeze_for_peft, PEFT_STAGE1
-    if not ops.SPLIT_BF16:
-        pytest.skip("the fold lives in the split-bf16 Linear kernel (UPP_SPLIT_BF16=0 runs every Linear on the exact-f32 kernels)")
-    m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda()
-    freeze_for_peft(m, PEFT_STAGE1)
-    m.train(train)
-    blk, x, pos, kw = _block_case(m, name, B=32)
-    assert blk.fusable(x)
-    params = [p for p in blk.parameters() if p.requires_grad]
-    outs, kinds = [], []
-    was = HF.FUSE_RESID_LN
-    for fold in (True, False):
-        HF.FUSE_RESID_LN = fold
-        try:
-            torch.manual_seed(11)                               # (the same stochastic-depth / dropout draws in both runs)
-            upp_layers.begin_forward(x.device, train)
-            xi, pi = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
-            with ops.time_linear_calls() as scope:
-                out = blk.forward_fused(xi, pi, **kw)
-            upp_layers.end_forward()
-            kinds.append(sorted(c[3] for c in scope.calls))
-            w = torch.linspace(-1, 1, out.numel(), device='cuda').view_as(out)
-            grads = torch.autograd.grad((out * w).sum(), [xi, pi] + params, allow_unused=True)
-            outs.append((out.detach(), grads))
-        finally:
-            HF.FUSE_RESID_LN = True
-    if ops.linear_sb_ln_usable(x.shape[0] * (x.shape[1] + (10 if name.startswith("down") and blk.downstream_prompts is not None else 0)), 1536, 384):
-        assert 6 in kinds[0] and any(e >= 16 for e in kinds[0]), kinds[0]      # the resid-epilogue GEMM and the LayerNorm-prologue GEMM ran
-    else:
-        assert name == "decoder" and 6 not in kinds[0]                         # (2,048 rows: fc1's tile there carries no A-operand prologue)
-    assert 6 not in kinds[1] and not any(e >= 16 for e in kinds[1]), kinds[1]
-    close(outs[0][0], outs[1][0], rtol=1e-5, atol_scale=2e-6)
-    for g, r in zip(outs[0][1], outs[1][1]):
-        assert (g is None) == (r is None)
-        if g is not None:
-            close(g, r, rtol=2e-5, atol_scale=5e-6)
-
-
-@pytest.mark.parametrize("path", ["downstream", "pretask_decoder"])
-def test_next_head_in_the_tail_launch_equals_a_head_launch_per_block(path):
-    """Round 5: a fused block's tail launch (upp_ln_adapter_fwd_next) also computes the head of the next block -- pos add, prompt insert,
-    norm1 (reference models/Point_MAE_unify.py:288-294, models/Point_MAE_pretask_dev.py:247-266) -- from the rows it still holds in the
-    LDS.  The block loop with the hand-over (an OPTION, UPP_FUSE_NEXT_HEAD=1: measured slower, off by default) equals the loop in which every block launches its own head: outputs
-    and every gradient BIT FOR BIT (the same expressions on the same values), and one rowln_fwd launch per block boundary fewer."""
-    from upp_hip.train import freeze_for_peft, PEFT_STAGE1
-    m = _seeded.fill(build_model_from_cfg(builtin_cfg('unify_modelnet_cls').model)).cuda().eval()
-    freeze_for_peft(m, PEFT_STAGE1)
-    B = 8
-    g = torch.Generator(device='cuda').manual_seed(4)
-    if path == "downstream":
-        blk, x, pos, kw = _block_case(m, "down0", B=B)
-        kw = {k: v for k, v in kw.items() if k != '_prop_cache'}
-        run = lambda xi, pi: m.blocks(xi, pi, **dict(kw))                                 # noqa: E731  (12 blocks: 6 with prompts, then 6 without)
-    else:
-        x = torch.randn(B, 64, 384, device='cuda', generator=g)
-        pos = torch.randn(B, 64, 384, device='cuda', generator=g)
-        run = lambda xi, pi: m.MAE_decoder(xi, pi, 32, pretask_adapter=True, path='pretask')   # noqa: E731
-    params = [p for p in m.parameters() if p.requires_grad]
-    outs, launches = [], []
-    was = HF.FUSE_NEXT_HEAD
-    try:
-        for on in (True, False):
-            HF.FUSE_NEXT_HEAD = on
-            xi, pi = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
-            upp_layers.begin_forward(x.device, False)
-            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
-                out = run(xi, pi)
-                torch.cuda.synchronize()
-            upp_layers.end_forward()
-            launches.append(sum(e.count for e in prof.key_averages() if 'rowln_fwd_kernel' in e.key))
-            w = torch.linspace(-1, 1, out.numel(), device='cuda').view_as(out)
-            grads = torch.autograd.grad((out * w).sum(), [xi, pi] + params, allow_unused=True)
-            outs.append((out.detach(), grads))
-    finally:
-        HF.FUSE_NEXT_HEAD = was
-    assert torch.equal(outs[0][0], outs[1][0])
-    for a, b in zip(outs[0][1], outs[1][1]):
-        assert (a is None) == (b is None)
-        if a is not None:
-            assert torch.equal(a, b)
-    nblk = 12 if path == "downstream" else 4
-    assert launches[1] - launches[0] == nblk - 1, launches

@@ -377,51 +377,3 @@ def test_wgrad_sb_special_values_and_determinism():
     g[17, 5] = float('inf')
     dw = _wgrad([(g, x)], True)[0]
     assert not torch.isfinite(dw[5]).any() and torch.isfinite(dw[6]).all()
-
-
-@pytest.mark.parametrize("M,L", [(2400, 75), (2080, 65), (300, 75)])
-@pytest.mark.parametrize("with_u", [False, True])
-def test_resid_epilogue_and_layernorm_prologue_equal_the_row_kernel(M, L, with_u):
-    """upp_linear_sb_resid_f32 + upp_linear_sb_ln_f32 against upp_linear_sb_f32 + upp_rowln_fwd + upp_linear_sb_f32 (reference
-    models/Point_MAE_pretask_dev.py:266,273): the residual rows bit for bit (same fma), the block statistics against float64, and the
-    product behind the LayerNorm prologue to f32 rounding of the row statistics."""
-    if not ops.SPLIT_BF16:
-        pytest.skip("UPP_SPLIT_BF16=0: every Linear on the exact-f32 kernels")
-    D, Hd = 384, 1536
-    B = M // L
-    g = torch.Generator(device='cuda').manual_seed(M + with_u)
-    a = torch.randn(B, L, D, device='cuda', generator=g)
-    xa = torch.randn(B, L, D, device='cuda', generator=g) * 2.0 + 0.3
-    wp = torch.randn(D, D, device='cuda', generator=g) * D ** -0.5
-    bp = torch.randn(D, device='cuda', generator=g)
-    w1 = torch.randn(Hd, D, device='cuda', generator=g) * D ** -0.5
-    b1 = torch.randn(Hd, device='cuda', generator=g)
-    gamma = torch.rand(D, device='cuda', generator=g) + 0.5
-    beta = torch.randn(D, device='cuda', generator=g) * 0.2
-    for w in (wp, w1):
-        w._upp_persistent = True
-    u = torch.rand(B, device='cuda', generator=g) if with_u else None
-    keep = 0.9
-    # the row-kernel path
-    y = ops.linear_f32(a, wp, frozen=True)
-    x_ref, h_ref, mean_ref, rstd_ref = ops.rowln_fwd(xa, None, None, HF.ROW_IDENTITY, 0, y, u, keep, gamma, beta, 1e-5, L, ybias=bp)
-    hid_ref, d_ref = ops.linear_f32(h_ref, w1, b1, ops.LIN_BIAS_GELU_D, frozen=True)
-    # the fold
-    x2, stats = ops.linear_sb_resid(a, ops.PLANES.get(wp), (D, D), bp, xa, u, keep, L)
-    assert torch.equal(x2, x_ref)
-    blocks = x2.double().view(M, D // 32, 32)
-    torch.testing.assert_close(stats[:, :, 0].double(), blocks.sum(-1), rtol=1e-5, atol=1e-4)
-    torch.testing.assert_close(stats[:, :, 1].double(), ((blocks - blocks.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=2e-5, atol=1e-4)
-    if not ops.linear_sb_ln_usable(M, Hd, D):
-        assert M < 1024
-        return
-    hid, d, mean, rstd = ops.linear_sb_ln(x2, stats, gamma, beta, 1e-5, ops.PLANES.get(w1), (Hd, D), b1, ops.LIN_BIAS_GELU_D)
-    torch.testing.assert_close(mean, mean_ref.reshape(-1), rtol=1e-5, atol=2e-6)
-    torch.testing.assert_close(rstd, rstd_ref.reshape(-1), rtol=1e-5, atol=0)
-    scale = float(hid_ref.abs().max())
-    torch.testing.assert_close(hid, hid_ref, rtol=1e-5, atol=3e-6 * scale)
-    torch.testing.assert_close(d, d_ref, rtol=1e-5, atol=3e-6)
-    # (mean, rstd) pairs instead of block statistics: the same product
-    pairs = torch.stack([mean, rstd], dim=1).contiguous()
-    hid2, _, _, _ = ops.linear_sb_ln(x2, pairs, gamma, beta, 1e-5, ops.PLANES.get(w1), (Hd, D), b1, ops.LIN_BIAS_GELU_D, want_rowstats=False)
-    assert torch.equal(hid2, hid)

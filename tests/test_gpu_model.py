@@ -109,7 +109,7 @@ def test_stage2_gradients_with_the_hip_runs_own_discrete_choices(model, oracle_o
     """Round-3 verdict, item 6: a stage-2 comparison without a flip allowance.  The forward makes discrete choices (FPS picks, neighbour
     lists, max-pool arg-maxes, the rectify prompter's ranking); upp_layers.trace_idx / max_over record them on a HIP run and REPLAY them in
     CPU evaluations of this repository's torch formulation (== the reference's classes to 1e-14 in float64: test_model_golden.py):
-      * with the exact-f32 patch embedding (UPP_EMBED_SPLIT_BF16=0) the product path (fused kernels, no instrument) and the instrumented
+      * with the exact-f32 patch embedding (option EMBED_SPLIT_BF16 = 0) the product path (fused kernels, no instrument) and the instrumented
         HIP run both agree with the CPU *float32* evaluation to 2e-5 of every gradient array's scale (measured 5.6e-6 / 5.4e-6): the
         denoised coordinates then come out bit-identical on both sides;
       * against *float64* that HIP path is exactly as far as the CPU float32 evaluation is (8e-4 on the rectify prompter's BatchNorm
@@ -148,21 +148,16 @@ def test_stage2_gradients_with_the_hip_runs_own_discrete_choices(model, oracle_o
     # (model is on the GPU: its grouping primitives are the HIP ones whatever the oracle_ops fixture put into the table)
     L.OPS.update(fps_gather=HF.fps_gather, knn_group=HF.knn_group)
     trace = {'mode': 'record', 'items': []}
-    import os
-    env0 = os.environ.get('UPP_EMBED_SPLIT_BF16')
+    from upp_hip import ops
     try:
         default, loss_d = grads(model, pts.cuda(), labels.cuda())
-        os.environ['UPP_EMBED_SPLIT_BF16'] = '0'
-        product, loss_p = grads(model, pts.cuda(), labels.cuda())
-        L.POOL_TRACE = trace
-        traced, loss_t = grads(model, pts.cuda(), labels.cuda())
+        with ops.option("EMBED_SPLIT_BF16", 0):
+            product, loss_p = grads(model, pts.cuda(), labels.cuda())
+            L.POOL_TRACE = trace
+            traced, loss_t = grads(model, pts.cuda(), labels.cuda())
     finally:
         L.POOL_TRACE = None
         L.OPS.clear(); L.OPS.update(saved)
-        if env0 is None:
-            os.environ.pop('UPP_EMBED_SPLIT_BF16', None)
-        else:
-            os.environ['UPP_EMBED_SPLIT_BF16'] = env0
     sites = {k[0] for k, _ in trace['items']}
     assert {'group.fps', 'group.knn', 'interp.knn', 'rectify.order', 'misc.fps', 'encoder.pool1', 'block.pooling', 'cls.max'} <= sites
 

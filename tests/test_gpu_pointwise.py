@@ -385,12 +385,18 @@ def test_argsort_rows_is_torchs_stable_argsort(B, N, descending):
     assert torch.equal(HF.argsort_rows(mask), torch.argsort(mask.int(), dim=1, stable=True))
 
 
-def test_argsort_rows_ranks_nan_as_the_largest_value_and_stays_a_permutation():
+def test_argsort_rows_ranks_nan_above_inf_like_torch_and_stays_a_permutation():
+    """Total order of the rank-counting kernel: NaN above +inf (last ascending, FIRST descending), -0 == +0 with ties by index -- the
+    permutation torch.argsort(stable=True) returns for rows holding NaN, both infinities and both zeros."""
     from upp_hip import functional as HF
-    key = torch.tensor([[0.5, float('nan'), -1.0, float('inf'), float('nan'), 0.5]], device='cuda')
-    asc = HF.argsort_rows(key).cpu().tolist()[0]
-    assert asc == [2, 0, 5, 1, 3, 4]                            # NaN == +inf for ranking: the three 'infinite' keys in index order
-    assert sorted(HF.argsort_rows(key, descending=True).cpu().tolist()[0]) == list(range(6))
+    nan, inf = float('nan'), float('inf')
+    key = torch.tensor([[0.5, nan, -1.0, inf, nan, 0.5, -inf, 0.0, -0.0, inf],
+                        [nan, nan, -0.0, 0.0, 1e-45, -1e-45, 3.4e38, -3.4e38, inf, -inf]], device='cuda')
+    for desc in (False, True):
+        got = HF.argsort_rows(key, descending=desc)
+        assert torch.equal(got, torch.argsort(key, dim=-1, descending=desc, stable=True)), desc
+        assert torch.equal(HF.argsort_rows(key, descending=desc, stable=False), got)      # (stable=False permits this order too)
+    assert HF.argsort_rows(key).cpu().tolist()[0] == [6, 2, 7, 8, 0, 5, 3, 9, 1, 4]
 
 
 @pytest.mark.parametrize("last", [None, 32])
@@ -464,6 +470,16 @@ def test_group_max_equals_torch_max_with_its_gradient(shape):
     t = torch.zeros(2, 5, 8, device='cuda', requires_grad=True)          # all ties: the first row of the group takes the gradient
     (gt,) = torch.autograd.grad(HF.group_max(t).sum(), t)
     assert float(gt[:, 0].sum()) == 16.0 and float(gt[:, 1:].abs().sum()) == 0.0
+    # a NaN anywhere in a group reaches the pooled value (torch.max(dim) propagates it; a diverged activation must stay visible), and the
+    # FIRST NaN row takes the gradient
+    n = torch.randn(4, 9, 8, device='cuda', generator=g)
+    n[0, 0, 1] = n[1, 3, 2] = n[1, 7, 2] = n[2, 8, 5] = float('nan')
+    n.requires_grad_(True)
+    got_n, want_n = HF.group_max(n), n.max(dim=-2)[0]
+    assert torch.equal(torch.isnan(got_n), torch.isnan(want_n)) and torch.isnan(got_n).sum().item() == 3
+    assert torch.equal(torch.nan_to_num(got_n, nan=7.0), torch.nan_to_num(want_n, nan=7.0))
+    (gn,) = torch.autograd.grad(got_n, n, torch.ones_like(got_n))
+    assert gn[1, 3, 2] == 1 and gn[1, 7, 2] == 0 and gn[0, 0, 1] == 1 and gn[2, 8, 5] == 1 and gn.sum() == got_n.numel()
 
 
 def test_fan_out_sums_the_branch_gradients_in_one_launch():

@@ -251,6 +251,8 @@ def test_configs0_cpu_plumbing_forward_runs_on_the_opt_in_torch_formulations(ora
         d, i = knn_cuda.KNN(32, transpose_mode=True)(x, cen)
         _, wi = oracle.knn(x.numpy(), cen.numpy(), 32, want_dist=False)
         assert np.array_equal(np.sort(i.numpy(), -1), np.sort(wi, -1))                 # neighbour SETS (in-list order is not pinned)
+        wd, _ = oracle.knn(x.numpy(), cen.numpy(), 32, want_dist=True)                   # EUCLIDEAN distances, as KNN_CUDA / the HIP path
+        np.testing.assert_allclose(np.sort(d.numpy(), -1), np.sort(wd, -1), rtol=2e-6, atol=1e-7)
         with torch.no_grad():
             got = model(x, completion_prompt=True, denoise=True, point_num=1024)
         np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=2e-5)

@@ -18,7 +18,7 @@ import statistics
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import LINEAR_SHAPES, STEP_LINEAR_SHAPES, LIN_LN, LIN_RESID, linear_algorithmic_bytes  # noqa: E402
+from bench import LINEAR_SHAPES, STEP_LINEAR_SHAPES, linear_algorithmic_bytes  # noqa: E402
 LINEAR_ORDER = [("linear:", s) for s in STEP_LINEAR_SHAPES] + [("linear_f32:", s) for s in LINEAR_SHAPES]      # prof_kernels.py: frozen=True (every block shape), then False (M = 2400)
 MARKER = 'transpose_kernel'
 
@@ -77,8 +77,7 @@ def main():
         alg = linear_algorithmic_bytes(M, N, K, epi, split)
         e['algorithmic_bytes'] = alg
         e['traffic_bytes'] = (2.0 * e['fetch_kb_raw'] + e['write_kb']) * 1024.0
-        base = epi - LIN_LN if epi >= LIN_LN else epi
-        want_w = (M * N * 4.0 * (2 if base == 3 else 1) + (8.0 * M * (N // 32) if epi == LIN_RESID else 0.0) + (8.0 * M if epi >= LIN_LN else 0.0)) / 1024.0
+        want_w = M * N * 4.0 * (2 if epi == 3 else 1) / 1024.0
         if abs(e['write_kb'] - want_w) > 0.10 * want_w:
             bad.append("%s: wrote %.0f KB, the shape writes %.0f KB" % (k, e['write_kb'], want_w))
         if e['traffic_bytes'] < 0.9 * alg:
