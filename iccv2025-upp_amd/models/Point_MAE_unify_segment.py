@@ -62,7 +62,7 @@ class Point_MAE_unify_seg(PromptedBackbone):
             else HF.linear(point_feat.reshape(B * N, C), w1[:, :C]).view(B, N, -1) + per_sample.unsqueeze(1)    # (per-sample term: GEMM epilogue)
         if self.training and bn1.track_running_stats:
             L.bump_counter(bn1.num_batches_tracked)
-        h = drop(_bn_rows(h.view(B * N, -1), bn1, self.training, relu=True))
+        h = _bn_rows(h.view(B * N, -1), bn1, self.training, relu=True, drop=drop)      # (the dropout rides in the BatchNorm's passes)
         h = _pointwise_bn_relu(h, c2, bn2, self.training)
         h = HF.linear(h, c3.weight.squeeze(-1), c3.bias)
         return F.log_softmax(h, dim=-1).view(B, N, -1)

@@ -428,9 +428,19 @@ class _SyncBNRows(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None
 
 
-def _bn_rows(x, bn, training, relu=False):
+def _bn_rows(x, bn, training, relu=False, drop=None):
     """BatchNorm1d of a channels-last (rows, C) matrix: identical statistics to BatchNorm1d on
-    the reference's (BG, C, n) layout (both reduce over every position of every group)."""
+    the reference's (BG, C, n) layout (both reduce over every position of every group).
+    drop: an nn.Dropout that follows (the segmentation head's `BatchNorm1d, ReLU, Dropout(0.5)`): applied in the BatchNorm's own passes on
+    the GPU training path (masks from bn.num_batches_tracked, which the caller has bumped for this forward), by the module elsewhere."""
+    if drop is not None:
+        p = float(drop.p) if (drop.training and training) else 0.0
+        fused = (p > 0.0 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and POOL_TRACE is None and bn.track_running_stats
+                 and bn.num_batches_tracked is not None and bn.momentum is not None and not _no_grad_needed(x, bn.weight, bn.bias)
+                 and not sync_bn_active(True) and not drop.inplace)
+        if fused:
+            return HF.bn_rows_train(x, bn, relu, drop_p=p, salt=x.shape[1], bump_pending=_pending_counters is not None)
+        return drop(_bn_rows(x, bn, training, relu))
     if POOL_TRACE is not None and relu and x.dim() == 2 and not sync_bn_active(training or bn.running_mean is None):
         # test instrument: the BatchNorm on our kernels (or torch, on the host), the ReLU as a recorded / replayed gate
         return gate('bn_rows.relu', _bn_rows(x, bn, training, relu=False))

@@ -53,7 +53,7 @@ SIGNATURES = {
     "upp_prop_pool_bwd": (_c_i, [_c_f] * 4 + [ctypes.c_float] + [_c_f] + [_c_i] * 3 + [_c_f]),
     "upp_prop_interp_fwd": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f]),
     "upp_prop_interp_bwd": (_c_i, [_c_f] * 6 + [_c_i] * 5 + [_c_f]),
-    "upp_batched_sum": (_c_i, [ctypes.POINTER(ctypes.c_void_p)] * 2 + [ctypes.POINTER(ctypes.c_int)] * 4 + [_c_i, _c_f]),
+    "upp_batched_sum": (_c_i, [ctypes.POINTER(ctypes.c_void_p)] * 2 + [ctypes.POINTER(ctypes.c_int)] * 6 + [_c_i, _c_f]),
     "upp_cls_pool_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 4 + [_c_i] * 3 + [_c_f]),
     "upp_cls_pool_bwd": (_c_i, [_c_f] * 7 + [_c_i] * 3 + [_c_f]),
     "upp_ce_acc": (_c_i, [_c_f] * 4 + [_c_i] * 2 + [_c_f]),
@@ -64,6 +64,8 @@ SIGNATURES = {
     "upp_bn_rows_part_floats": (ctypes.c_longlong, [_c_i] * 2),
     "upp_bn_rows_fwd": (_c_i, [_c_f] * 5 + [ctypes.c_float] * 2 + [_c_i] * 2 + [_c_f] * 4 + [_c_i] * 2 + [_c_f]),
     "upp_bn_rows_bwd": (_c_i, [_c_f] * 6 + [_c_i] + [_c_f] * 4 + [_c_i] * 2 + [_c_f]),
+    "upp_bn_rows_drop_fwd": (_c_i, [_c_f] * 5 + [ctypes.c_float] * 2 + [_c_i] + [ctypes.c_float, _c_f, ctypes.c_longlong, ctypes.c_uint] + [_c_f] * 4 + [_c_i] * 2 + [_c_f]),
+    "upp_bn_rows_drop_bwd": (_c_i, [_c_f] * 6 + [_c_i] + [ctypes.c_float, _c_f, ctypes.c_longlong, ctypes.c_uint] + [_c_f] * 4 + [_c_i] * 2 + [_c_f]),
     "upp_sqdist_topk": (_c_i, [_c_f] * 4 + [_c_i] * 4 + [_c_f]),
     "upp_interp_fwd": (_c_i, [_c_f] * 2 + [_c_i] + [_c_f] * 2 + [_c_i] * 7 + [ctypes.c_float] + [_c_f]),
     "upp_interp_affine_fwd": (_c_i, [_c_f] * 2 + [_c_i] + [_c_f] * 4 + [_c_i] * 5 + [ctypes.c_float] + [_c_f]),

@@ -92,6 +92,8 @@ struct SumJobs {
     int n[kMaxSumJobs], ld[kMaxSumJobs];
     float *dst[kMaxSumJobs];                   // per group
     int len[kMaxSumJobs], acc[kMaxSumJobs];    // per group
+    int dw[kMaxSumJobs], dpitch[kMaxSumJobs];  // per group: dw > 0: the destination is a (len / dw, dw) WINDOW of rows dpitch floats apart --
+                                               // flat element c lives at (c / dw) * dpitch + c % dw (a column range of a wider gradient matrix)
     int first[kMaxSumJobs + 1];                // per group: its jobs are [first[g], first[g+1])
     int wg0[kMaxSumJobs + 1];                  // per group: first workgroup (256 columns per workgroup)
     int groups;
@@ -107,7 +109,9 @@ __global__ __launch_bounds__(256) void batched_sum_kernel(SumJobs t) {
     const int c = (((int)blockIdx.x - t.wg0[g]) * 256 + threadIdx.x) * V;
     const int len = t.len[g];
     if (c >= len) return;
-    vec_t acc = t.acc[g] ? *reinterpret_cast<const vec_t *>(t.dst[g] + c) : vec_t(0.0f);
+    const int dw = t.dw[g];
+    float *dptr = t.dst[g] + (dw > 0 ? (size_t)(c / dw) * t.dpitch[g] + c % dw : (size_t)c);      // (V = 4: dw % 4 == 0, dpitch % 4 == 0 -- checked by the host)
+    vec_t acc = t.acc[g] ? *reinterpret_cast<const vec_t *>(dptr) : vec_t(0.0f);
     for (int j = t.first[g]; j < t.first[g + 1]; ++j) {
         const float *src = t.src[j] + c;
         const int n = t.n[j], ld = t.ld[j];
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void batched_sum_kernel(SumJobs t) {
             for (int q = 0; q < U; ++q) if (i0 + q < n) acc += v[q];
         }
     }
-    *reinterpret_cast<vec_t *>(t.dst[g] + c) = acc;
+    *reinterpret_cast<vec_t *>(dptr) = acc;
 }
 
 // Tall jobs (more than kTallRows rows: the bias gradients of trainable Linear layers are column sums of (B L, N) output
@@ -151,7 +155,9 @@ __global__ __launch_bounds__(256) void batched_sum_tall_kernel(SumJobs t) {
     __syncthreads();
     if (wave == 0 && c < len) {
         const float s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-        t.dst[g][c] = t.acc[g] ? t.dst[g][c] + s : s;
+        const int dw = t.dw[g];
+        float *dptr = t.dst[g] + (dw > 0 ? (size_t)(c / dw) * t.dpitch[g] + c % dw : (size_t)c);
+        *dptr = t.acc[g] ? *dptr + s : s;
     }
 }
 
@@ -261,10 +267,13 @@ extern "C" int upp_wcolsum_partials(const float *src, long long ld, const float 
 }
 
 extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, const int *ld,
-                               const int *accumulate, int jobs, void *stream) {
+                               const int *accumulate, const int *dst_width, const int *dst_pitch, int jobs, void *stream) {
     if (jobs < 0 || (jobs > 0 && (!src || !dst || !n || !len || !ld || !accumulate))) return UPP_E_BADARG;
-    for (int j = 0; j < jobs; ++j)
+    if ((dst_width == nullptr) != (dst_pitch == nullptr)) return UPP_E_BADARG;
+    for (int j = 0; j < jobs; ++j) {
         if (!src[j] || !dst[j] || n[j] < 1 || len[j] < 1 || ld[j] < len[j]) return UPP_E_BADARG;
+        if (dst_width && dst_width[j] != 0 && (dst_width[j] < 1 || len[j] % dst_width[j] != 0 || dst_pitch[j] < dst_width[j])) return UPP_E_BADARG;
+    }
     // group the jobs by destination (first-seen order; submission order inside a group), then launch in batches
     int order[4096], gstart[4096 + 1];
     if (jobs > 4096) return UPP_E_RANGE;
@@ -277,6 +286,7 @@ extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const
         for (int k = j; k < jobs; ++k)
             if (!taken[k] && dst[k] == dst[j]) {
                 if (len[k] != len[j] || accumulate[k] != accumulate[j]) return UPP_E_BADARG;   // one destination, one shape
+                if (dst_width && (dst_width[k] != dst_width[j] || dst_pitch[k] != dst_pitch[j])) return UPP_E_BADARG;
                 taken[k] = true; order[filled++] = k;
             }
     }
@@ -292,6 +302,7 @@ extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const
     for (int g = 0; g < ngroups; ++g) {
         const int head = order[gstart[g]];
         bool wide = !tall[g] && len[head] >= 4096 && len[head] % 4 == 0 && (reinterpret_cast<uintptr_t>(dst[head]) & 15) == 0;
+        if (dst_width && dst_width[head] > 0) wide = wide && dst_width[head] % 4 == 0 && dst_pitch[head] % 4 == 0;
         for (int q = gstart[g]; q < gstart[g + 1] && wide; ++q) {
             const int k = order[q];
             wide = ld[k] % 4 == 0 && (reinterpret_cast<uintptr_t>(src[k]) & 15) == 0;
@@ -312,6 +323,7 @@ extern "C" int upp_batched_sum(const float *const *src, float *const *dst, const
                 t.first[g] = nj;
                 for (int q = lo; q < hi; ++q) { const int k = order[q]; t.src[nj] = src[k]; t.n[nj] = n[k]; t.ld[nj] = ld[k]; ++nj; }
                 t.dst[g] = dst[head]; t.len[g] = len[head]; t.acc[g] = accumulate[head]; t.wg0[g] = wg;
+                t.dw[g] = dst_width ? dst_width[head] : 0; t.dpitch[g] = dst_width ? dst_pitch[head] : 0;
                 wg += (len[head] + cols - 1) / cols;
                 ++g; ++used;
             }

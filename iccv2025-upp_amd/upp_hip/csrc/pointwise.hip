@@ -124,6 +124,24 @@ __global__ __launch_bounds__(64 * kBnWaves) void bn_finalize_rows_kernel(const f
     }
 }
 
+// Dropout behind BatchNorm + ReLU (round 6; reference models/Point_MAE_unify_segment.py:424-427 `Conv1d, BatchNorm1d, ReLU, Dropout(0.5)`):
+// the mask of element i is a counter-based hash of (seed, i) -- recomputed by the backward kernels, never stored, no uniform tensor --
+// with seed = the BatchNorm layer's own num_batches_tracked (a device scalar the step bumps once per forward, inside the captured graph)
+// mixed with a per-site salt.  thresh = p * 2^32 (0: no dropout); kept values are scaled by 1 / (1 - p) as torch.nn.Dropout does.  The
+// stream is this library's own (lowbias32 mixer), not torch's Philox: dropout is a stochastic regulariser, parity tests run it at p = 0.
+struct BnDrop { const long long *seed; long long seed_add; unsigned salt, thresh; float scale; };
+__device__ __forceinline__ unsigned drop_seed(const BnDrop &d) {
+    if (!d.thresh) return 0u;
+    unsigned h = (unsigned)(*d.seed + d.seed_add) * 0x9E3779B1u + d.salt;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ float drop_factor(const BnDrop &d, unsigned seed, long long elem) {
+    unsigned h = ((unsigned)elem * 0x9E3779B1u) ^ ((unsigned)(elem >> 32) * 0x85EBCA77u) ^ seed;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h >= d.thresh ? d.scale : 0.0f;
+}
+
 // y = ((x - mean) * rstd) * gamma + beta, optionally max(., 0); 4 consecutive elements per thread
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 nt_load4(const float *p) {
@@ -138,7 +156,7 @@ constexpr long long kStreamElems = 32ll << 20;   // 128 MB of f32: beyond this a
 __global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, int relu, float *__restrict__ y,
-                                                            long long total, int C, int nt) {
+                                                            long long total, int C, int nt, BnDrop dr) {
     // nt: streams larger than the last-level cache (the 65,536-row activations of the per-point heads) are read and written
     // with non-temporal accesses -- a written-once stream that allocates in L2 costs a third of the HBM write rate
     const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -164,6 +182,11 @@ __global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float *__restr
         o[q] = ((v[q] - mu[q]) * rs[q]) * ga[q] + be[q];
         if (relu) o[q] = fmaxf(o[q], 0.0f);
     }
+    if (dr.thresh) {
+        const unsigned sd = drop_seed(dr);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] *= drop_factor(dr, sd, i0 + q);
+    }
     if ((C & 3) == 0) { if (nt) nt_store4(y + i0, o[0], o[1], o[2], o[3]); else *reinterpret_cast<float4 *>(y + i0) = make_float4(o[0], o[1], o[2], o[3]); }
     else {
 #pragma unroll
@@ -179,13 +202,14 @@ __global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float *__restr
 __global__ __launch_bounds__(256) void bn_rows_bwd_partial_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                                   const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                   const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
-                                                                  int R, int C, int Cp, int per, float *__restrict__ part) {
+                                                                  int R, int C, int Cp, int per, float *__restrict__ part, BnDrop dr) {
     __shared__ float s1[256], s2[256];
     const int tid = threadIdx.x;
     const int col = blockIdx.y * 256 + tid % Cp, rl = tid / Cp, RL = 256 / Cp;
     const int r0 = blockIdx.x * per, r1 = min(R, r0 + per);
     const int cc = min(col, C - 1);
     const float mu = mean[cc], rs = rstd[cc], ga = gamma ? gamma[cc] : 1.0f, be = beta ? beta[cc] : 0.0f;
+    const unsigned sd = drop_seed(dr);
     float a1 = 0.0f, a2 = 0.0f;
     for (int rb = r0 + rl; rb < r1; rb += RL * 8) {         // 2 x 8 independent row loads in flight
         float xv[8], gv[8];
@@ -193,6 +217,7 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_partial_kernel(const float *_
         for (int t = 0; t < 8; ++t) {
             const size_t o = (size_t)min(rb + t * RL, r1 - 1) * C + cc;
             xv[t] = x[o]; gv[t] = g[o];
+            if (dr.thresh) gv[t] *= drop_factor(dr, sd, (long long)o);
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t)
@@ -244,7 +269,7 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                 const float *__restrict__ g_gamma, const float *__restrict__ g_beta, int relu,
-                                                                float inv_rows, float *__restrict__ g_x, long long total, int C, int nt) {
+                                                                float inv_rows, float *__restrict__ g_x, long long total, int C, int nt, BnDrop dr) {
     const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= total) return;
     float xv[4], gv[4];
@@ -260,6 +285,11 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const long long i = min(i0 + q, total - 1); xv[q] = x[i]; gv[q] = g[i]; c[q] = (int)(i % C); }
+    }
+    if (dr.thresh) {
+        const unsigned sd = drop_seed(dr);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gv[q] *= drop_factor(dr, sd, i0 + q);
     }
     float mu[4], rs[4], ga[4], be[4], gg[4], gb[4];
 #pragma unroll
@@ -291,13 +321,14 @@ template <bool NT>
 __global__ __launch_bounds__(256) void bn_rows_apply_tall_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                                  const float *__restrict__ rstd, const float *__restrict__ gamma,
                                                                  const float *__restrict__ beta, int relu, float *__restrict__ y, int R,
-                                                                 int C) {
+                                                                 int C, BnDrop dr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.y * 256 + lane * 4;
     const float4 mu = *reinterpret_cast<const float4 *>(mean + c0), rs = *reinterpret_cast<const float4 *>(rstd + c0);
     const float4 ga = gamma ? *reinterpret_cast<const float4 *>(gamma + c0) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     const float4 be = beta ? *reinterpret_cast<const float4 *>(beta + c0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int r0 = blockIdx.x * kTallRows + wave;
+    const unsigned sd = drop_seed(dr);
     constexpr int U = kTallRows / 4;
     float4 v[U];
 #pragma unroll
@@ -311,6 +342,10 @@ __global__ __launch_bounds__(256) void bn_rows_apply_tall_kernel(const float *__
         float o0 = ((v[j].x - mu.x) * rs.x) * ga.x + be.x, o1 = ((v[j].y - mu.y) * rs.y) * ga.y + be.y;
         float o2 = ((v[j].z - mu.z) * rs.z) * ga.z + be.z, o3 = ((v[j].w - mu.w) * rs.w) * ga.w + be.w;
         if (relu) { o0 = fmaxf(o0, 0.0f); o1 = fmaxf(o1, 0.0f); o2 = fmaxf(o2, 0.0f); o3 = fmaxf(o3, 0.0f); }
+        if (dr.thresh) {
+            const long long e0 = (long long)(r0 + 4 * j) * C + c0;
+            o0 *= drop_factor(dr, sd, e0); o1 *= drop_factor(dr, sd, e0 + 1); o2 *= drop_factor(dr, sd, e0 + 2); o3 *= drop_factor(dr, sd, e0 + 3);
+        }
         float *dst = y + (size_t)(r0 + 4 * j) * C + c0;
         if (NT) nt_store4(dst, o0, o1, o2, o3); else *reinterpret_cast<float4 *>(dst) = make_float4(o0, o1, o2, o3);
     }
@@ -321,7 +356,7 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_tall_kernel(const float
                                                                      const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                      const float *__restrict__ g_gamma, const float *__restrict__ g_beta,
-                                                                     int relu, float inv_rows, float *__restrict__ g_x, int R, int C) {
+                                                                     int relu, float inv_rows, float *__restrict__ g_x, int R, int C, BnDrop dr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.y * 256 + lane * 4;
     const float4 mu4 = *reinterpret_cast<const float4 *>(mean + c0), rs4 = *reinterpret_cast<const float4 *>(rstd + c0);
@@ -331,6 +366,7 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_tall_kernel(const float
     const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w}, ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
     const float be[4] = {be4.x, be4.y, be4.z, be4.w}, gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, gb[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
     const int r0 = blockIdx.x * kTallRows + wave;
+    const unsigned sd = drop_seed(dr);
     constexpr int U = kTallRows / 8;                           // two streams: 2 x 4 row loads in flight per lane, twice
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -345,7 +381,13 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_tall_kernel(const float
         for (int j = 0; j < U; ++j) {
             const int r = r0 + 4 * (h * U + j);
             if (r >= R) break;
-            const float xs[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, gs[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
+            const float xs[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+            float gs[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
+            if (dr.thresh) {
+                const long long e0 = (long long)r * C + c0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gs[q] *= drop_factor(dr, sd, e0 + q);
+            }
             float o[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -942,9 +984,20 @@ extern "C" long long upp_bn_rows_part_floats(int R, int C) {
     return (long long)((R + per - 1) / per) * 2 * C;
 }
 
-extern "C" int upp_bn_rows_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
-                               float momentum, float eps, int training, int relu, float *part, float *mean, float *rstd, float *y,
-                               int R, int C, void *stream) {
+static int bn_drop_args(float p, const long long *seed, long long seed_add, unsigned salt, BnDrop &d) {
+    d = BnDrop{nullptr, 0, 0u, 0u, 1.0f};
+    if (!(p >= 0.0f) || p >= 1.0f) return UPP_E_BADARG;
+    if (p > 0.0f) {
+        if (!seed) return UPP_E_BADARG;
+        const double t = (double)p * 4294967296.0;
+        d.seed = seed; d.seed_add = seed_add; d.salt = salt; d.thresh = t < 1.0 ? 1u : (t > 4294967295.0 ? 4294967295u : (unsigned)t); d.scale = 1.0f / (1.0f - p);
+    }
+    return 0;
+}
+
+static int bn_rows_fwd_impl(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                            float momentum, float eps, int training, int relu, const BnDrop &dr, float *part, float *mean, float *rstd, float *y,
+                            int R, int C, void *stream) {
     if (!x || !mean || !rstd || !y || R < 1 || C < 1) return UPP_E_BADARG;
     if (training && !part) return UPP_E_BADARG;
     if (!training && (!running_mean || !running_var)) return UPP_E_BADARG;
@@ -958,22 +1011,38 @@ extern "C" int upp_bn_rows_fwd(const float *x, const float *gamma, const float *
     const long long total = (long long)R * C;
     if (C % 256 == 0 && R >= 4096) {
         const dim3 grid((unsigned)((R + kTallRows - 1) / kTallRows), (unsigned)(C / 256));
-        if (total >= kStreamElems) hipLaunchKernelGGL(bn_rows_apply_tall_kernel<true>, grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y, R, C);
-        else hipLaunchKernelGGL(bn_rows_apply_tall_kernel<false>, grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y, R, C);
+        if (total >= kStreamElems) hipLaunchKernelGGL(bn_rows_apply_tall_kernel<true>, grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y, R, C, dr);
+        else hipLaunchKernelGGL(bn_rows_apply_tall_kernel<false>, grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y, R, C, dr);
         return upp_launch_status();
     }
     hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y,
-                       total, C, total >= kStreamElems ? 1 : 0);
+                       total, C, total >= kStreamElems ? 1 : 0, dr);
     return upp_launch_status();
 }
 
-extern "C" int upp_bn_rows_bwd(const float *x, const float *g, const float *mean, const float *rstd, const float *gamma, const float *beta,
-                               int relu, float *part, float *g_gamma, float *g_beta, float *g_x, int R, int C, void *stream) {
+extern "C" int upp_bn_rows_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                               float momentum, float eps, int training, int relu, float *part, float *mean, float *rstd, float *y,
+                               int R, int C, void *stream) {
+    return bn_rows_fwd_impl(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, BnDrop{nullptr, 0, 0u, 0u, 1.0f}, part, mean, rstd,
+                            y, R, C, stream);
+}
+
+extern "C" int upp_bn_rows_drop_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                    float momentum, float eps, int relu, float p, const long long *seed, long long seed_add, unsigned salt, float *part,
+                                    float *mean, float *rstd, float *y, int R, int C, void *stream) {
+    BnDrop dr;
+    const int rc = bn_drop_args(p, seed, seed_add, salt, dr);
+    if (rc) return rc;
+    return bn_rows_fwd_impl(x, gamma, beta, running_mean, running_var, momentum, eps, 1, relu, dr, part, mean, rstd, y, R, C, stream);
+}
+
+static int bn_rows_bwd_impl(const float *x, const float *g, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                            int relu, const BnDrop &dr, float *part, float *g_gamma, float *g_beta, float *g_x, int R, int C, void *stream) {
     if (!x || !g || !mean || !rstd || !part || !g_gamma || !g_beta || R < 1 || C < 1) return UPP_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int per = bn_per(R), slabs = (R + per - 1) / per, Cp = pow2_at_least(C);
     hipLaunchKernelGGL(bn_rows_bwd_partial_kernel, dim3(slabs, (C + 255) / 256), dim3(256), 0, st, x, g, mean, rstd, gamma, beta, relu, R, C, Cp,
-                       per, part);
+                       per, part, dr);
     hipLaunchKernelGGL(bn_rows_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64 * kBnWaves), 0, st, part, slabs, C, g_gamma, g_beta);
     if (g_x) {
         const long long total = (long long)R * C;
@@ -981,16 +1050,30 @@ extern "C" int upp_bn_rows_bwd(const float *x, const float *g, const float *mean
             const dim3 grid((unsigned)((R + kTallRows - 1) / kTallRows), (unsigned)(C / 256));
             if (total >= kStreamElems)
                 hipLaunchKernelGGL(bn_rows_bwd_apply_tall_kernel<true>, grid, dim3(256), 0, st, x, g, mean, rstd, gamma, beta, g_gamma, g_beta, relu,
-                                   1.0f / (float)R, g_x, R, C);
+                                   1.0f / (float)R, g_x, R, C, dr);
             else
                 hipLaunchKernelGGL(bn_rows_bwd_apply_tall_kernel<false>, grid, dim3(256), 0, st, x, g, mean, rstd, gamma, beta, g_gamma, g_beta, relu,
-                                   1.0f / (float)R, g_x, R, C);
+                                   1.0f / (float)R, g_x, R, C, dr);
             return upp_launch_status();
         }
         hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, g, mean, rstd, gamma, beta,
-                           g_gamma, g_beta, relu, 1.0f / (float)R, g_x, total, C, total >= kStreamElems ? 1 : 0);
+                           g_gamma, g_beta, relu, 1.0f / (float)R, g_x, total, C, total >= kStreamElems ? 1 : 0, dr);
     }
     return upp_launch_status();
+}
+
+extern "C" int upp_bn_rows_bwd(const float *x, const float *g, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                               int relu, float *part, float *g_gamma, float *g_beta, float *g_x, int R, int C, void *stream) {
+    return bn_rows_bwd_impl(x, g, mean, rstd, gamma, beta, relu, BnDrop{nullptr, 0, 0u, 0u, 1.0f}, part, g_gamma, g_beta, g_x, R, C, stream);
+}
+
+extern "C" int upp_bn_rows_drop_bwd(const float *x, const float *g, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                                    int relu, float p, const long long *seed, long long seed_add, unsigned salt, float *part, float *g_gamma, float *g_beta,
+                                    float *g_x, int R, int C, void *stream) {
+    BnDrop dr;
+    const int rc = bn_drop_args(p, seed, seed_add, salt, dr);
+    if (rc) return rc;
+    return bn_rows_bwd_impl(x, g, mean, rstd, gamma, beta, relu, dr, part, g_gamma, g_beta, g_x, R, C, stream);
 }
 
 extern "C" int upp_sqdist_topk(const float *q, const float *src, float *dist, int64_t *idx, int B, int N, int S, int k, void *stream) {
@@ -1054,6 +1137,9 @@ extern "C" int upp_interp_bwd(const float *dist, const int64_t *idx, int ld_tab,
             return upp_launch_status();
         }
     }
+    // (round 6 measured a PUSH form for the wide rows of the segmentation head -- a workgroup streams a sample's gradient rows once and
+    //  accumulates into an [S][columns] LDS tile: 693 us as register read-modify-writes (a 6,144-long LDS latency chain per wave), 1,780 us
+    //  with ds_add_f32, against 226 us for the pull kernel below, whose re-reads are served by the L2: NOTEBOOK section 12)
     hipLaunchKernelGGL(interp_bwd_kernel, dim3((unsigned)(B * S)), dim3(256), 0, (hipStream_t)stream, dist, idx, ld_tab, g_out, ld_g, col0, S, C,
                        pow2_at_least(C), k, eps, N, g_feat);
     return upp_launch_status();

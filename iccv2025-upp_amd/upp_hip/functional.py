@@ -357,6 +357,26 @@ class _DeferredSums:
         self.routed.add(ptr)
         return True
 
+    def wgrad_window(self, w, g2, x2):
+        """The same for a weight that is a COLUMN RANGE w = P[:, a:b] of a registered 2-D parameter P (the segmentation head's first layer
+        multiplies [per-point | per-sample] column ranges of one weight; the feature propagation's first layer [xyz | features]): the
+        partials are added into that range of P's gradient buffer (upp_batched_sum window destination) -- autograd is handed None, so the
+        slice's backward (zero-fill of P's shape, strided copy, add) never runs.  -> True when queued."""
+        root = w._base
+        if self.targets is None or root is None or not g2.is_cuda or w.dim() != 2 or w.stride(1) != 1:
+            return False
+        dst = self.targets.get(root.data_ptr())
+        N, K = w.shape
+        if dst is None or dst.numel() != root.numel() or root.numel() % N or not root.is_contiguous():
+            return False
+        Kt = root.numel() // N                        # P viewed as (N, Kt): trailing singleton dimensions of a Conv1d weight fold away
+        off = w.storage_offset() - root.storage_offset()
+        if w.stride(0) != Kt or off < 0 or off + K > Kt or (g2.shape[1], x2.shape[1]) != (N, K):
+            return False
+        self.wgrads.append((g2, x2, dst.view(N, Kt)[:, off:off + K]))
+        self.routed.add(root.data_ptr())
+        return True
+
     def flush(self):
         jobs, self.jobs = self.jobs, []
         wg, self.wgrads = self.wgrads, []
@@ -534,7 +554,9 @@ def _lin(a, w, bias=None, epi=None, aux=None, dgrad=False):
         return ops.linear_f32(a, _wt(w) if dgrad else w, bias, epi, aux=aux, frozen=True)
     N, K = (w.shape[1], w.shape[0]) if dgrad else w.shape
     M = a.numel() // a.shape[-1]
-    if (ops.PLANES.managed and w.is_cuda and w.dim() == 2 and w.stride(1) == 1 and w.data_ptr() % 16 == 0 and w.stride(0) % 4 == 0
+    # (the plane image is a buffer of its own, written by upp_linear_sb_prep with scalar reads of w: a column window of a wider weight whose
+    #  rows start off a 16-byte boundary -- w[:, 3:] of a (1536, 1155) weight -- is served where it lies)
+    if (ops.PLANES.managed and w.is_cuda and w.dim() == 2 and w.stride(1) == 1
             and ops.linear_sb_usable(M, N, K) and (bias is None or bias.data_ptr() % 16 == 0)):
         return ops.linear_f32(a, None, bias, epi, aux=aux, planes=ops.PLANES.get_trainable(w, transposed=dgrad), wshape=(N, K))
     return ops.linear_f32(a, _wt(w) if dgrad else w, bias, epi, aux=aux)
@@ -591,7 +613,7 @@ def weight_grad(g2, x2, w, own=False):
         g2 = g2.contiguous()
     if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
         x2 = x2.contiguous()
-    if _DEFERRED.wgrad(w.data_ptr(), g2, x2):
+    if _DEFERRED.wgrad(w.data_ptr(), g2, x2) or _DEFERRED.wgrad_window(w, g2, x2):
         return None
     part = ops.linear_wgrad(g2, x2)
     return part.sum(dim=0) if part.shape[0] > 1 else part[0]
@@ -661,7 +683,11 @@ class _LinearGroupBias(Function):
         if ctx.needs_input_grad[1]:
             gw = weight_grad(g2, x, w, True)
         if ctx.needs_input_grad[2]:
-            ggb = g2.view(g2.shape[0] // ctx.rows, ctx.rows, g2.shape[1]).sum(dim=1)
+            groups = g2.shape[0] // ctx.rows
+            if g2.is_cuda and g2.dtype == torch.float32 and groups * ctx.rows == g2.shape[0] and 1 <= groups <= 65535:
+                ggb = ops.colsum_partials(g2, 0, g2.shape[1], chunks=groups)        # chunk = group: (groups, N) in one launch, wave-ordered sums
+            else:
+                ggb = g2.view(groups, ctx.rows, g2.shape[1]).sum(dim=1)
         return gx, gw, ggb, None
 
 
@@ -709,7 +735,16 @@ def linear(x, weight, bias=None, own_wgrad=False, act=None):
     if (x.is_cuda and weight.dim() == 2 and weight.dtype == torch.float32 and weight.shape[1] % 4 == 0 and weight.shape[1] > 64
             and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16)):
         # a column window of a wider weight whose rows start off a 16-byte boundary (w[:, 3:] of the (1536, 1155) first layer of the
-        # segmentation head's feature propagation): one differentiable copy makes it servable
+        # segmentation head's feature propagation): inside a step driver a trainable window of a parameter is multiplied through its
+        # persistent bf16 plane image and its gradient lands in the parameter's gradient window (_DeferredSums.wgrad_window) -- no copy;
+        # anywhere else one differentiable copy makes it servable
+        rows = x.numel() // max(x.shape[-1], 1)
+        window_ok = bool(needs_grad and weight.requires_grad and ops.PLANES.managed and weight.stride(1) == 1 and x.dtype == torch.float32
+                         and isinstance(weight._base, torch.nn.Parameter) and x.shape[-1] == weight.shape[1] and weight.shape[0] % 4 == 0
+                         and ops.linear_sb_usable(rows, weight.shape[0], weight.shape[1])
+                         and (not x.requires_grad or ops.linear_sb_usable(rows, weight.shape[1], weight.shape[0])))
+        if window_ok:
+            return _act_torch(_LinearMFMA.apply(x, weight, bias, bool(own_wgrad)), act)
         weight = weight.contiguous()
     if needs_grad and weight.dim() == 2 and weight.shape[0] % 4 and weight.shape[0] > 16 and linear_usable(x, weight):
         # the data gradient contracts over the N outputs and the weight gradient is (N, K): both want N % 4 == 0 (the 50 part classes of
@@ -946,28 +981,36 @@ def bn_rows(x, bn, training, relu=False):
 
 
 class _BnRowsTrain(Function):
-    """Training-mode BatchNorm(+ReLU) over rows with its backward (upp_bn_rows_fwd / upp_bn_rows_bwd): the trainable
-    BatchNorm1d layers of the per-point heads.  The running statistics are updated in place by the forward."""
+    """Training-mode BatchNorm(+ReLU)(+Dropout) over rows with its backward (upp_bn_rows_fwd / upp_bn_rows_bwd, upp_bn_rows_drop_*): the
+    trainable BatchNorm1d layers of the per-point heads.  The running statistics are updated in place by the forward."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, drop_p=0.0, seed=None, salt=0, bump_pending=False):
         x = x.contiguous()
-        y, mean, rstd = ops.bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, True, relu, want_stats=True)
+        # the mask is a hash of the counter's value for THIS forward: when the host bumps its counters at the end of the forward
+        # (upp_layers.end_forward) the forward reads the old value + 1 and the backward, which runs behind the bump, the new value
+        drop = (drop_p, seed, 1 if bump_pending else 0, salt) if drop_p > 0.0 else None
+        y, mean, rstd = ops.bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, True, relu, want_stats=True, drop=drop)
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
-        ctx.relu = relu
+        ctx.relu, ctx.drop = relu, (None if drop is None else (drop_p, seed, 0, salt))
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
-        g_x, g_gamma, g_beta = ops.bn_rows_bwd(x, g.contiguous(), mean, rstd, gamma, beta, ctx.relu, want_gx=ctx.needs_input_grad[0])
+        g_x, g_gamma, g_beta = ops.bn_rows_bwd(x, g.contiguous(), mean, rstd, gamma, beta, ctx.relu, want_gx=ctx.needs_input_grad[0], drop=ctx.drop)
         return (g_x, g_gamma if ctx.needs_input_grad[1] else None, g_beta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
-def bn_rows_train(x, bn, relu=False):
-    """Differentiable training-mode BatchNorm(+ReLU) over the rows of a channels-last (R,C) matrix."""
+def bn_rows_train(x, bn, relu=False, drop_p=0.0, salt=0, bump_pending=False):
+    """Differentiable training-mode BatchNorm(+ReLU) over the rows of a channels-last (R,C) matrix; drop_p > 0: nn.Dropout(drop_p) on the
+    output in the same passes, its masks a hash of (bn.num_batches_tracked, salt, element) -- the caller bumps the counter once per forward
+    (upp_layers.bump_counter, as nn.BatchNorm1d does); bump_pending: that bump has been queued for the end of the forward, not applied."""
     momentum = 0.0 if bn.momentum is None else bn.momentum
+    if drop_p > 0.0:
+        return _BnRowsTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu, float(drop_p),
+                                  bn.num_batches_tracked, int(salt), bool(bump_pending))
     return _BnRowsTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
 
 

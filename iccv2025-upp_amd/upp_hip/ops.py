@@ -946,7 +946,16 @@ def prop_weights_bwd(c1, c2, idx8, g_w8, eps):
 
 
 # ------------------------------------------------------------------ row operators of the frozen prompter branches
-def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, want_stats=False):
+def _drop_seed(drop):
+    """drop = (p, seed int64 device scalar, seed_add, salt) -> checked tuple for upp_bn_rows_drop_fwd / _bwd."""
+    p, seed, add, salt = drop
+    if not (isinstance(seed, torch.Tensor) and seed.is_cuda and seed.dtype == torch.int64 and seed.numel() == 1):
+        raise RuntimeError("dropout seed must be a one-element int64 HIP (cuda) tensor (the layer's num_batches_tracked)")
+    return float(p), seed, int(add), int(salt) & 0xFFFFFFFF
+
+
+def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, want_stats=False, drop=None):
+    """drop = (p, seed, seed_add, salt): nn.Dropout(p) on the output in the same pass (training only; upp_bn_rows_drop_fwd)."""
     _need(x, "x", torch.float32, ndim=2)
     R, C = x.shape
     dev = x.device
@@ -954,13 +963,20 @@ def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, traini
     mean = torch.empty(C, dtype=torch.float32, device=dev)
     rstd = torch.empty(C, dtype=torch.float32, device=dev)
     y = torch.empty_like(x)
-    _call(dev, "upp_bn_rows_fwd", _abi.ptr(x), _abi.ptr(gamma), _abi.ptr(beta), _abi.ptr(running_mean), _abi.ptr(running_var),
-          float(momentum), float(eps), int(bool(training)), int(bool(relu)), _abi.ptr(part), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(y), R, C)
+    if drop is not None and drop[0] > 0.0:
+        if not training:
+            raise RuntimeError("bn_rows_fwd: dropout belongs to the training-mode form")
+        p, seed, add, salt = _drop_seed(drop)
+        _call(dev, "upp_bn_rows_drop_fwd", _abi.ptr(x), _abi.ptr(gamma), _abi.ptr(beta), _abi.ptr(running_mean), _abi.ptr(running_var),
+              float(momentum), float(eps), int(bool(relu)), p, _abi.ptr(seed), add, salt, _abi.ptr(part), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(y), R, C)
+    else:
+        _call(dev, "upp_bn_rows_fwd", _abi.ptr(x), _abi.ptr(gamma), _abi.ptr(beta), _abi.ptr(running_mean), _abi.ptr(running_var),
+              float(momentum), float(eps), int(bool(training)), int(bool(relu)), _abi.ptr(part), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(y), R, C)
     return (y, mean, rstd) if want_stats else y
 
 
-def bn_rows_bwd(x, g, mean, rstd, gamma, beta, relu, want_gx=True):
-    """Backward of the training-mode bn_rows_fwd: -> (g_x or None, g_gamma, g_beta)."""
+def bn_rows_bwd(x, g, mean, rstd, gamma, beta, relu, want_gx=True, drop=None):
+    """Backward of the training-mode bn_rows_fwd: -> (g_x or None, g_gamma, g_beta).  drop: (p, seed, seed_add, salt) -- the forward's mask."""
     _need(x, "x", torch.float32, ndim=2)
     _need(g, "g", torch.float32, ndim=2)
     R, C = x.shape
@@ -973,8 +989,13 @@ def bn_rows_bwd(x, g, mean, rstd, gamma, beta, relu, want_gx=True):
     g_gamma = torch.empty(C, dtype=torch.float32, device=dev)
     g_beta = torch.empty(C, dtype=torch.float32, device=dev)
     g_x = torch.empty_like(x) if want_gx else None
-    _call(dev, "upp_bn_rows_bwd", _abi.ptr(x), _abi.ptr(g), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma), _abi.ptr(beta), int(bool(relu)),
-          _abi.ptr(part), _abi.ptr(g_gamma), _abi.ptr(g_beta), _abi.ptr(g_x), R, C)
+    if drop is not None and drop[0] > 0.0:
+        p, seed, add, salt = _drop_seed(drop)
+        _call(dev, "upp_bn_rows_drop_bwd", _abi.ptr(x), _abi.ptr(g), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma), _abi.ptr(beta), int(bool(relu)),
+              p, _abi.ptr(seed), add, salt, _abi.ptr(part), _abi.ptr(g_gamma), _abi.ptr(g_beta), _abi.ptr(g_x), R, C)
+    else:
+        _call(dev, "upp_bn_rows_bwd", _abi.ptr(x), _abi.ptr(g), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma), _abi.ptr(beta), int(bool(relu)),
+              _abi.ptr(part), _abi.ptr(g_gamma), _abi.ptr(g_beta), _abi.ptr(g_x), R, C)
     return g_x, g_gamma, g_beta
 
 
@@ -1137,25 +1158,36 @@ def bn_relu_drop_bwd(g_a, z, gamma, beta, mean, rstd, training, u, p):
 
 # ------------------------------------------------------------------ optimizer tail
 def batched_sum(jobs):
-    """jobs: list of (part 2-D f32, column offset, rows n, length, row stride, dst f32 (length elems), accumulate):
-    dst (+)= sum over the n rows of part[:, offset:offset+length], every job in one launch (upp_batched_sum)."""
+    """jobs: list of (part 2-D f32, column offset, rows n, length, row stride, dst f32, accumulate):
+    dst (+)= sum over the n rows of part[:, offset:offset+length], every job in one launch (upp_batched_sum).  dst: `length` contiguous
+    elements, or a 2-D WINDOW (rows, w) with rows * w == length, unit column stride and any row pitch (a column range of a wider matrix)."""
     if not jobs:
         return
     import ctypes
     k = len(jobs)
+    dw, dp = [], []
     for part, off, n, length, ld, dst, acc in jobs:
-        _need(dst, "dst", torch.float32)
+        if not (isinstance(dst, torch.Tensor) and dst.is_cuda and dst.dtype == torch.float32):
+            raise RuntimeError("batched_sum: dst must be an f32 HIP (cuda) tensor; upp_hip has no CPU path")
         if not part.is_cuda or part.dtype != torch.float32 or part.dim() != 2 or part.stride(1) != 1 or part.stride(0) != ld:
             raise RuntimeError("batched_sum: part must be a HIP f32 matrix with contiguous rows")
         if n != part.shape[0] or off < 0 or off + length > part.shape[1] or dst.numel() != length:
             raise RuntimeError("batched_sum: job geometry does not match its tensors")
+        if dst.is_contiguous():
+            dw.append(0), dp.append(0)
+        elif dst.dim() == 2 and dst.stride(1) == 1 and dst.stride(0) >= dst.shape[1]:
+            dw.append(dst.shape[1]), dp.append(dst.stride(0))
+        else:
+            raise RuntimeError("batched_sum: dst must be contiguous or a 2-D window with contiguous rows")
     src = (ctypes.c_void_p * k)(*[j[0].data_ptr() + 4 * j[1] for j in jobs])
     dst = (ctypes.c_void_p * k)(*[j[5].data_ptr() for j in jobs])
     n = (ctypes.c_int * k)(*[j[2] for j in jobs])
     ln = (ctypes.c_int * k)(*[j[3] for j in jobs])
     ld = (ctypes.c_int * k)(*[j[4] for j in jobs])
     acc = (ctypes.c_int * k)(*[int(bool(j[6])) for j in jobs])
-    _call(jobs[0][0].device, "upp_batched_sum", src, dst, n, ln, ld, acc, k)
+    windows = any(dw)
+    _call(jobs[0][0].device, "upp_batched_sum", src, dst, n, ln, ld, acc, (ctypes.c_int * k)(*dw) if windows else None,
+          (ctypes.c_int * k)(*dp) if windows else None, k)
 
 
 def copy_batched(dsts, srcs):

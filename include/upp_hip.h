@@ -331,6 +331,14 @@ int upp_prop_weights_bwd(const float *c1, const float *c2, const int32_t *idx8, 
  *                     pre-training): x, g (R,C), mean / rstd from the forward; with xh = (x-mean)*rstd and
  *                     gm = g * [xh*gamma+beta > 0] (relu != 0; gm = g otherwise):  g_beta = sum gm, g_gamma = sum gm*xh,
  *                     g_x = gamma*rstd*(gm - (g_beta + xh*g_gamma)/R).  g_x may be NULL (parameter gradients only).
+ *   upp_bn_rows_drop_fwd / _bwd (round 6): the training-mode pair with nn.Dropout(p) applied to the output in the same passes (the
+ *                     segmentation head's `Conv1d, BatchNorm1d, ReLU, Dropout(0.5)`, reference models/Point_MAE_unify_segment.py:424-427):
+ *                     y = dropout(relu?(bn(x))), kept values scaled by 1 / (1 - p).  The mask of element i is a counter-based hash of
+ *                     (*seed + seed_add, salt, i) recomputed by the backward (nothing is stored; no uniform tensor is read): `seed` is a
+ *                     DEVICE int64 the caller changes once per forward -- the layer's own num_batches_tracked -- so steps differ; seed_add
+ *                     lets forward and backward of ONE step agree when the counter moves between them (a host that bumps its counters at
+ *                     the end of the forward hands the forward 1 and the backward 0).  0 <= p < 1 (p = 0: the plain pair).
+ *                     The stream of masks is this library's (not torch's Philox).
  *   upp_sqdist_topk : dist / idx (B,N,k) = the k nearest of the S points src[b] for every query q[b,n], by the reference's
  *                     square_distance form d = |a|^2 + |b|^2 - 2 a.b (models/modules.py:13-32), ascending (d, index):
  *                     `square_distance(q, src).sort(dim=-1)` cut to k columns.  S <= 256, k <= min(S, 64).
@@ -353,6 +361,12 @@ int upp_bn_rows_fwd(const float *x, const float *gamma, const float *beta, float
                     int R, int C, void *stream);
 int upp_bn_rows_bwd(const float *x, const float *g, const float *mean, const float *rstd, const float *gamma, const float *beta,
                     int relu, float *part, float *g_gamma, float *g_beta, float *g_x, int R, int C, void *stream);
+int upp_bn_rows_drop_fwd(const float *x, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                         float momentum, float eps, int relu, float p, const long long *seed, long long seed_add, unsigned salt, float *part,
+                         float *mean, float *rstd, float *y, int R, int C, void *stream);
+int upp_bn_rows_drop_bwd(const float *x, const float *g, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                         int relu, float p, const long long *seed, long long seed_add, unsigned salt, float *part, float *g_gamma, float *g_beta,
+                         float *g_x, int R, int C, void *stream);
 int upp_sqdist_topk(const float *q, const float *src, float *dist, int64_t *idx, int B, int N, int S, int k, void *stream);
 int upp_interp_fwd(const float *dist, const int64_t *idx, int ld_tab, const float *feat, float *out, int ld_out, int col0,
                    int B, int N, int S, int C, int k, float eps, void *stream);
@@ -411,9 +425,14 @@ long long upp_adamw_scratch_floats(void);
  * applied one after the other in submission order by the same workgroups: race-free and deterministic).  src / dst / n / len / ld /
  * accumulate are HOST arrays; the pointers in src / dst are device pointers.  Used for the parameter-gradient partials of
  * a backward pass (upp_adapter_bwd partials per workgroup, upp_ln_param_grad partials per chunk, upp_rowln_bwd per-sample
- * prompt gradients), summed straight into the flat gradient buffer after the pass. */
+ * prompt gradients), summed straight into the flat gradient buffer after the pass.
+ * dst_width / dst_pitch (ABI 5; HOST arrays, both NULL = every destination flat): dst_width_j > 0 makes destination j a WINDOW of
+ * (len_j / dst_width_j) rows of dst_width_j floats, dst_pitch_j floats apart -- element c lives at dst_j[(c / w) * pitch + c % w]: the
+ * weight gradient of a Linear layer applied to a column range of a wider weight (the segmentation head's first layer acts on
+ * [per-point 1024 | per-sample 2432] columns of one (512, 3456) weight, reference models/Point_MAE_unify_segment.py:424-433) lands in
+ * that range of the weight's gradient without a zero-fill, a strided copy and an add.  len_j % dst_width_j == 0. */
 int upp_batched_sum(const float *const *src, float *const *dst, const int *n, const int *len, const int *ld,
-                    const int *accumulate, int jobs, void *stream);
+                    const int *accumulate, const int *dst_width, const int *dst_pitch, int jobs, void *stream);
 /* upp_copy_batched: dst_j[0 .. bytes_j) = src_j[0 .. bytes_j) for `count` non-overlapping device buffers in one launch (host arrays of
  * device pointers and byte counts): the hand-over state a pipelined training step passes from its front-end to its back-end. */
 int upp_copy_batched(const void *const *src, void *const *dst, const long long *bytes, int count, void *stream);

@@ -823,3 +823,53 @@ def test_linear_with_a_deferred_bias_gradient_matches_autograd(rows, K, N):
     out = HF.linear(x, w, b)
     _, _, hb = torch.autograd.grad(out, (x, w, b), g)
     close(hb, gb, rtol=1e-5, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize("N,Kt,a", [(1536, 1155, 3), (512, 3456, 1024), (64, 200, 72)])
+def test_column_windows_of_a_weight_train_without_copies(N, Kt, a):
+    """Round 6: a Linear layer applied to COLUMN RANGES of one wider weight (the segmentation head's first layer on [per-point 1024 |
+    per-sample 2432] columns of a (512, 3456, 1) Conv1d weight, the feature propagation's first layer on [xyz 3 | features 1152] of a
+    (1536, 1155, 1) one: reference models/Point_MAE_unify_segment.py:424-433, models/Point_MAE_pretask_dev.py:425-473).  Inside a step
+    driver (managed plane images + deferred sums) each range is multiplied where it lies -- also when its rows start off a 16-byte
+    boundary -- and its weight gradient lands in that range of the parameter's gradient buffer: autograd sees None for the weight, no
+    zero-fill / strided copy / add of the slice's backward, no torch reduction.  Against F.linear's autograd."""
+    from upp_hip import ops
+    torch.manual_seed(N + a)
+    P = torch.nn.Parameter(torch.randn(N, Kt, 1, device='cuda') * 0.05)            # a Conv1d weight: trailing singleton dimension
+    w = P.squeeze(-1)
+    rows = 4096
+    x1 = torch.randn(rows, a, device='cuda', requires_grad=True)
+    x2 = torch.randn(rows, Kt - a, device='cuda', requires_grad=True)
+    g = torch.randn(rows, N, device='cuda')
+    ref = torch.nn.functional.linear(x1, w[:, :a]) + torch.nn.functional.linear(x2, w[:, a:])
+    gx1, gx2, gP = torch.autograd.grad(ref, (x1, x2, P), g)
+    buf = torch.full((N * Kt,), 0.25, device='cuda')
+    was = ops.PLANES.managed
+    ops.PLANES.managed = True
+    try:
+        ops.PLANES.refresh_trainable()
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            with HF.deferred_sums({P.data_ptr(): buf.view(N, Kt, 1)}) as scope:
+                out = HF.linear(x1, w[:, :a]) + HF.linear(x2, w[:, a:])
+                ops.PLANES.refresh_trainable()                                       # (windows first seen in this pass get their images)
+                hx1, hx2, hP = torch.autograd.grad(out, (x1, x2, P), g, allow_unused=True)
+            torch.cuda.synchronize()
+    finally:
+        ops.PLANES.managed = was
+    close(out, ref, rtol=1e-5, atol_scale=2e-6)
+    close(hx1, gx1, rtol=1e-5, atol_scale=2e-6)
+    close(hx2, gx2, rtol=1e-5, atol_scale=2e-6)
+    got = (buf - 0.25).view(N, Kt)
+    routed = [(lo, hi) for lo, hi in ((0, a), (a, Kt)) if (hi - lo) % 4 == 0 and (hi - lo) > 64]
+    assert routed, "at least the wide range is one for the matrix-core kernels"
+    for lo, hi in routed:
+        close(got[:, lo:hi], gP.squeeze(-1)[:, lo:hi], rtol=2e-5, atol_scale=5e-6)
+    if len(routed) == 2:
+        assert hP is None and P.data_ptr() in scope.routed
+    else:                                                                              # the narrow range went through autograd: the two add up
+        assert hP is not None
+        close(got + hP.squeeze(-1), gP.squeeze(-1), rtol=2e-5, atol_scale=5e-6)
+    names = [e.key for e in prof.key_averages()]
+    assert not any("reduce_kernel" in n_ for n_ in names), names                      # no torch reduction of weight-gradient partials
+    if len(routed) == 2:
+        assert not any("FillFunctor" in n_ for n_ in names), names                     # no zero-fill of the slice backward

@@ -157,6 +157,71 @@ def test_rectify_prompter_fused_path_equals_torch_path():
                 assert int(stats_fused[k]) == int(rp.state_dict()[k])
 
 
+@pytest.mark.parametrize("pending", [False, True])
+@pytest.mark.parametrize("R,C,p", [(65536, 512, 0.5), (8192, 256, 0.2), (1000, 300, 0.5), (4096, 40, 0.7)])
+def test_bn_relu_dropout_in_the_batchnorm_passes(R, C, p, pending):
+    """Round 6: `BatchNorm1d, ReLU, Dropout(p)` of the segmentation head (reference models/Point_MAE_unify_segment.py:424-427) in the
+    BatchNorm's own passes (upp_bn_rows_drop_fwd / _bwd): kept values are relu(bn(x)) / (1 - p) exactly, the keep rate is 1 - p, the mask
+    is a function of (num_batches_tracked, element) -- the same for forward and backward of a step, another one after the counter moved,
+    nothing stored -- and the gradients equal torch's for that mask.  Tall kernels (C % 256 == 0) and flat ones.  pending: inside a model
+    forward the counter bump is queued for the end of the forward (upp_layers.end_forward), i.e. it lands BETWEEN this layer's forward and
+    its backward: both must still see one mask."""
+    torch.manual_seed(R + C)
+    x0 = torch.randn(R, C, device='cuda') * torch.linspace(0.5, 2.0, C, device='cuda') + torch.linspace(-1.0, 1.0, C, device='cuda')
+    gy = torch.randn(R, C, device='cuda')
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    drop = torch.nn.Dropout(p).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+    if pending:
+        upp_layers.begin_forward(x0.device, True)
+    upp_layers.bump_counter(bn.num_batches_tracked)
+    x = x0.clone().requires_grad_(True)
+    y = upp_layers._bn_rows(x, bn, True, relu=True, drop=drop)
+    assert type(y.grad_fn).__name__ == '_BnRowsTrainBackward'
+    if pending:
+        assert int(bn.num_batches_tracked) == 0
+        upp_layers.end_forward()
+    assert int(bn.num_batches_tracked) == 1
+    y.backward(gy)
+    bn_ref = torch.nn.BatchNorm1d(C).cuda().train()
+    with torch.no_grad():
+        bn_ref.weight.copy_(bn.weight); bn_ref.bias.copy_(bn.bias)
+        plain = upp_layers._bn_rows(x0, bn_ref, True, relu=True)          # relu(bn(x)) on the same kernels, no dropout
+    pos = plain > 0
+    kept = (y != 0)
+    assert not (kept & ~pos).any()
+    rate = kept[pos].float().mean().item()
+    assert abs(rate - (1.0 - p)) < 4.0 * (p * (1 - p) / pos.sum().item()) ** 0.5 + 1e-3, rate
+    assert torch.equal(y[kept], (plain * (1.0 / (1.0 - p)))[kept])
+    col_rate = (kept & pos).float().sum(0) / pos.float().sum(0).clamp_min(1.0)          # no column (or row) is systematically kept / dropped
+    assert (col_rate - (1.0 - p)).abs().max().item() < 0.2 if R >= 4096 else True
+    # the same counter value -> the same mask; another value -> another mask
+    with torch.no_grad():
+        rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+        y2 = upp_layers._bn_rows(x0, bn, True, relu=True)                   # (no gradient asked: the frozen-branch path, no dropout here)
+        bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    x2 = x0.clone().requires_grad_(True)
+    y_same = upp_layers._bn_rows(x2, bn, True, relu=True, drop=drop)
+    assert torch.equal(y_same != 0, kept)
+    upp_layers.bump_counter(bn.num_batches_tracked)
+    y_next = upp_layers._bn_rows(x0.clone().requires_grad_(True), bn, True, relu=True, drop=drop)
+    differ = ((y_next != 0) != kept)[pos].float().mean().item()
+    assert abs(differ - 2 * p * (1 - p)) < 0.02, differ
+    # gradients against torch for that mask
+    mask = torch.where(pos, kept.float(), torch.ones_like(plain)) / (1.0 - p)
+    xt = x0.clone().requires_grad_(True)
+    y_lin = F.batch_norm(xt, None, None, bn_ref.weight, bn_ref.bias, True, 0.1, bn.eps)
+    (y_lin * pos.float() * mask).backward(gy)
+    close(x.grad, xt.grad, rtol=5e-5, atol_scale=1e-5)
+    close(bn.weight.grad, bn_ref.weight.grad, rtol=2e-5, atol_scale=2e-5)
+    close(bn.bias.grad, bn_ref.bias.grad, rtol=2e-5, atol_scale=2e-5)
+    # eval mode / p = 0: the module's identity
+    bn.eval(); drop.eval()
+    with torch.no_grad():
+        assert torch.equal(upp_layers._bn_rows(x0, bn, False, relu=True, drop=drop), upp_layers._bn_rows(x0, bn, False, relu=True))
+
+
 @pytest.mark.parametrize("B,N,S,C,k", [(8, 2048, 128, 1152, 3), (4, 1076, 32, 32, 16), (2, 32, 32, 12, 16), (3, 33, 40, 300, 3), (1, 1, 16, 1, 1),
                                        (2, 4096, 5, 7, 5), (2, 64, 200, 96, 6), (2, 300, 150, 70, 4), (2, 500, 64, 64, 8), (3, 257, 16, 20, 5), (2, 1000, 128, 32, 3)])
 def test_interp_train_forward_and_feature_gradient(B, N, S, C, k):
