@@ -250,7 +250,8 @@ def _pmc_raw():
     """The committed rocprofv3 --pmc passes (profiles/r0N_pmc_kernels.json, produced by tools/make_profiles.sh: FETCH_SIZE and WRITE_SIZE in
     KB, separate passes; kernels not re-profiled in a round keep the entry of the last round that profiled them)."""
     raw = {}
-    for name in ("r01_pmc_kernels.json", "r02_pmc_kernels.json", "r03_pmc_kernels.json", "r04_pmc_kernels.json", "r05_pmc_kernels.json"):
+    for name in ("r01_pmc_kernels.json", "r02_pmc_kernels.json", "r03_pmc_kernels.json", "r04_pmc_kernels.json", "r05_pmc_kernels.json",
+                 "r06_pmc_kernels.json"):
         try:
             raw.update(json.load(open(os.path.join(ROOT, "profiles", name))))
         except Exception:
@@ -341,7 +342,7 @@ def stage_report(device, B):
     pmc_raw = _pmc_raw()
 
     mfma_pmc = {}
-    for name in ("r04_pmc_mfma.json", "r05_pmc_mfma.json"):
+    for name in ("r04_pmc_mfma.json", "r05_pmc_mfma.json", "r06_pmc_mfma.json"):
         try:
             mfma_pmc.update(json.load(open(os.path.join(ROOT, "profiles", name))))
         except Exception:
@@ -984,12 +985,12 @@ def main():
                 "l2_to_lds": operand_stream(calls, ms),
                 "traffic_note": "HBM-side bytes of the family per STEP (like achieved: per replay of the launch list): sum over the recorded "
                                 "launches of the committed rocprofv3 --pmc counters of that launch's shape (2 x FETCH_SIZE + WRITE_SIZE, "
-                                "profiles/r05_pmc_kernels.json 'linear:<label>', each taken on the kernel this run launches); launches "
+                                "profiles/r06_pmc_kernels.json 'linear:<label>', each taken on the kernel this run launches); launches "
                                 "without a label (heads, position MLPs: < 1 % of the flops) are not counted on either side",
                 "how": "the step's launch sequence (recorded from an eager step: shapes, epilogues and which of the two kernels served each "
                        "launch) replayed in step order as one HIP graph, every launch with its own weight / input / output, HIP events on "
-                       "the launch stream; kernel-to-kernel boundaries included.  profiles/r05_bench_sequential_kernel_stats.csv holds the "
-                       "same launches inside the step under rocprofv3, profiles/r05_step_census.txt ONE replayed step",
+                       "the launch stream; kernel-to-kernel boundaries included.  profiles/r06_bench_sequential_kernel_stats.csv holds the "
+                       "same launches inside the step under rocprofv3, profiles/r06_step_census.txt ONE replayed step",
                 "by_shape": shapes}
             line["kernels"] = stages
         if not args.no_cpu_baseline and world == 1:

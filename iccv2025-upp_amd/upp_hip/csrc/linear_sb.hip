@@ -463,7 +463,6 @@ __global__ __launch_bounds__(128) void linear_sb_prep_batched_kernel(PrepJobs t)
     prep_chunk(t.W[j], t.ldw[j], t.N[j], t.K[j], t.tr[j], (t.K[j] + 31) / 32, b - t.first[j], t.out[j]);
 }
 
-struct SbConfig { int bmb, bnb, rn, ks, nst; };
 #ifndef UPP_SB_NST44
 #define UPP_SB_NST44 3
 #endif
@@ -476,56 +475,39 @@ struct SbConfig { int bmb, bnb, rn, ks, nst; };
 #define UPP_SB_EXTRA_CONFIGS(X)
 #endif
 #include "linear_sb_tuned.h"
-#define UPP_SB_ENTRY(a, b, c, d, e) {a, b, c, d, e},
-constexpr SbConfig kSbConfigs[] = {UPP_SB_CONFIGS(UPP_SB_ENTRY)};
-#undef UPP_SB_ENTRY
-constexpr int kNumSbConfigs = sizeof(kSbConfigs) / sizeof(kSbConfigs[0]);
-inline int sb_code(const SbConfig &c) { return 0x400000 + c.bmb * 65536 + c.bnb * 4096 + c.rn * 256 + c.ks * 16 + c.nst; }     // hex digits 4 BMB BNB RN KS NST
+// (tile code: hex digits 4 BMB BNB RN KS NST)
 
-// The measured choice (linear_sb_tuned.h) for a problem of the swept family: same N and K, M within 1 / 16 of a swept M (the nearest one),
-// and still one round of workgroups where the swept problem was.  option UPP_OPT_SB_TUNED = 0: the cost model alone (A/B).  0: no entry.
+// The measured choice (linear_sb_tuned.h) for the swept problems on which the fitted model is still behind: EXACT (M, N, K) matches only --
+// round 5's table, the main source of choices then, also answered for M within 1 / 16 of a row; with nine residual rows a neighbouring
+// problem is better served by the model (a row's tile cost a neighbour 6.8 % in the sweep).  Option UPP_OPT_SB_TUNED = 0: the model alone.
 int sb_tuned(int M, int N, int K) {
     if (!upp_option(UPP_OPT_SB_TUNED)) return 0;
-    int best = 0;
-    long long best_d = 0;
-    for (const SbTuned &t : kSbTuned) {
-        if (t.N != N || t.K != K) continue;
-        const long long d = M > t.M ? M - t.M : t.M - M;
-        if (d * 16 > t.M) continue;
-        const int bmb = (t.code >> 16) & 15, bnb = (t.code >> 12) & 15;
-        const long long wg_t = (long long)((t.M + 32 * bmb - 1) / (32 * bmb)) * ((N + 32 * bnb - 1) / (32 * bnb));
-        const long long wg = (long long)((M + 32 * bmb - 1) / (32 * bmb)) * ((N + 32 * bnb - 1) / (32 * bnb));
-        if (wg_t <= 256 && wg > 256) continue;
-        if (!best || d < best_d) { best = t.code; best_d = d; }
-    }
-    return best;
+    for (const SbTuned &t : kSbTuned)
+        if (t.M == M && t.N == N && t.K == K) return t.code;
+    return 0;
 }
 
-// One round of at most 256 workgroups (the big tiles also in several rounds: the tall point-row matrices); among the shapes that fit, the smallest of max(matrix-pipe cycles of the busiest SIMD + 0.7 x the
-// VALU cycles of its A splits, bytes a workgroup stages / 40 B per clock) -- fitted to the in-kernel stamps of tools/micro/sb_stamps.py
-// (fc1 128 x 128: 23.7k cycles for 18.4k + 0.7 x 9.6k; fc2 64 x 64 with one block per wave: 34k for 18.4k + 0.7 x 19.2k, which is why
-// the narrow shapes take the tile whose waves own both column blocks).  0: not a problem for this file.
+// The cost model (round 6): per compiled tile shape a seven-coefficient time estimate FITTED to the tile sweep of round 5 (197 Linear
+// problems of the six recipes x every shape that fits the LDS: profiles/r05_sb_sweep.json, tools/micro/sb_model_fit.py ->
+// linear_sb_model.h) --  t = c0 + c1 R + c2 R s + c3 Rc + c4 Rc s + c5 R s u + c6 u  with R = ceil(wgs / 256) rounds of workgroups,
+// Rc = max(1, wgs / 256) (a partial last round costs less than a whole one), s = K / (32 KS) k-stages per wave group and u the idle share
+// of the chip.  The per-tile constants carry what round 5's analytic model left out (the k-split's LDS reduction, prologue and store burst
+// per round, the operand split at its measured weight): that model's choice was within 3 % of the measured best on 23 of the 197 swept
+// problems, this one's on 188, and on 95 % of problems held out of the fit (5-fold cross-validation).  0: not a problem for this file.
+#include "linear_sb_model.h"
 int pick_sb_model(int M, int N, int K) {
     if (K % 32 != 0 || K < 64) return 0;
-    const int mb = (M + 31) / 32, nb = (N + 31) / 32;
     int best = 0;
-    long long best_cost = 0;
-    for (int i = 0; i < kNumSbConfigs; ++i) {
-        const SbConfig c = kSbConfigs[i];
-        if (K % (32 * c.ks) != 0 || K / (32 * c.ks) < c.nst) continue;          // (every LDS stage is filled before the loop starts)
-        const long long wgs = (long long)((mb + c.bmb - 1) / c.bmb) * ((nb + c.bnb - 1) / c.bnb);
-        const long long rounds = (wgs + 255) / 256;
-        if (c.bmb == 8 && wgs < 192) continue;                   // (the 256-row tiles: tall matrices only -- two LDS stages; <8,4,4>: 8 waves of 1 x 4 blocks, half the split
-                                                                 //  and A-fragment work per matrix instruction of <8,4,2>'s 16 waves: 207 -> 222 TFLOP/s at 65,536 rows)
-        if (rounds > 1 && c.bmb * c.bnb < 12) continue;          // (several rounds: the big tiles only -- one workgroup per CU, prologue and store burst per round)
-        const int waves = c.bmb * (c.bnb / c.rn) * c.ks;
-        const long long mfma = (long long)((waves + 3) / 4) * c.rn * (K / c.ks / 16) * 192;
-        const long long bytes = (long long)(c.bmb * 32 * 128 + c.bnb * SB_CHUNK) * (K / 32);
-        const long long valu = (long long)((waves + 3) / 4) * (K / c.ks / 16) * 200;          // ~44 instructions per split of 8 values
-        const long long pipe = mfma + valu * 7 / 10;
-        long long cost = rounds * ((pipe > bytes / 40 ? pipe : bytes / 40) + (rounds > 1 ? 8000 : 0)) * 1000 + (256 - (wgs < 256 ? wgs : 256));
-        if (wgs < 128) cost += cost / 2;                       // half the chip idle: the stream beside it gains, this launch does not
-        if (!best || cost < best_cost) { best = sb_code(c); best_cost = cost; }
+    double best_t = 0.0;
+    for (const SbModel &m : kSbModel) {
+        const int bmb = (m.code >> 16) & 15, bnb = (m.code >> 12) & 15, ks = (m.code >> 4) & 15, nst = m.code & 15;
+        if (K % (32 * ks) != 0 || K / (32 * ks) < nst) continue;          // (every LDS stage is filled before the loop starts)
+        const long long wgs = (long long)((M + 32 * bmb - 1) / (32 * bmb)) * ((N + 32 * bnb - 1) / (32 * bnb));
+        const double R = (double)((wgs + 255) / 256), Rc = wgs > 256 ? (double)wgs / 256.0 : 1.0, u = wgs < 256 ? 1.0 - (double)wgs / 256.0 : 0.0;
+        const double s = (double)(K / (32 * ks));
+        double t = m.c[0] + m.c[1] * R + m.c[2] * R * s + m.c[3] * Rc + m.c[4] * Rc * s + m.c[5] * R * s * u + m.c[6] * u;
+        if (t < 0.5) t = 0.5;                                            // (an extrapolation far outside the sweep must not go negative)
+        if (!best || t < best_t) { best = m.code; best_t = t; }
     }
     return best;
 }

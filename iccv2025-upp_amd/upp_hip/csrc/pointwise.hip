@@ -137,8 +137,8 @@ __device__ __forceinline__ unsigned drop_seed(const BnDrop &d) {
     return h;
 }
 __device__ __forceinline__ float drop_factor(const BnDrop &d, unsigned seed, long long elem) {
-    unsigned h = ((unsigned)elem * 0x9E3779B1u) ^ ((unsigned)(elem >> 32) * 0x85EBCA77u) ^ seed;
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    unsigned h = ((unsigned)elem ^ __builtin_rotateleft32((unsigned)(elem >> 32), 13)) ^ seed;       // (the high word only matters beyond 2^32 elements)
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;      // lowbias32: two quarter-rate multiplies per element
     return h >= d.thresh ? d.scale : 0.0f;
 }
 

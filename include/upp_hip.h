@@ -594,9 +594,11 @@ int upp_linear_group_bias_f32(const float *A, long long lda, const float *W, lon
  *       device pointers / sizes): the trainable weights of a step driver, re-split at the start of every step.
  *   upp_linear_sb_tile(M, N, K): the tile code the library would take (hex digits 0x4 BMB BNB RN KS NST: workgroups of
  *       BMB x BNB blocks of 32 x 32, a wave owns 1 x RN of them, the contraction cut over KS wave groups, NST LDS stages of 32 KS values
- *       of k), or 0 when the problem is not one for this kernel (K % 32, fewer k-stages than LDS stages, no tile fits).  The choice is the
- *       measured one for the Linear problems of the six recipes (csrc/linear_sb_tuned.h: same N and K, M within 1/16 of a swept M;
- *       profiles/r05_sb_sweep.json) and a cost model's otherwise; option UPP_OPT_SB_TUNED = 0 leaves the model alone.  Any
+ *       of k), or 0 when the problem is not one for this kernel (K % 32, fewer k-stages than LDS stages, no tile fits).  The choice is that
+ *       of a cost model fitted to a measured sweep of every tile shape over the Linear problems of the six recipes (csrc/linear_sb_model.h,
+ *       tools/micro/sb_model_fit.py, profiles/r05_sb_sweep.json: within 3 % of the measured best on 95 % of the problems, also of problems
+ *       held out of the fit), behind a nine-row table of the swept problems where the model is still behind (csrc/linear_sb_tuned.h, exact
+ *       (M, N, K) matches); option UPP_OPT_SB_TUNED = 0 leaves the model alone.  Any
  *       compiled tile code is valid for any problem whose K its wave groups' k-stages divide (a forced code: upp_linear_sb_f32's `tile`).
  *   upp_linear_sb_f32: epilogues and aux as upp_linear_f32; tile 0 = the library's choice.  Limits: K % 32 == 0 (% 64, % 128 for KS = 2, 4 tiles),
  *       N % 4 == 0, lda % 4 == 0, ldc % 4 == 0, ldaux % 4 == 0, A / C / bias / aux 16-byte aligned; UPP_E_RANGE otherwise (the caller

@@ -136,15 +136,8 @@ def test_linear_decomposition_choice_is_a_host_function():
     assert lib.upp_linear_tile(65536, 1024, 1536) == RT and lib.upp_linear_tile(65536, 512, 256) == RT
 
 
-def test_split_bf16_tuned_tile_table_is_well_formed_and_answers_for_its_own_problems():
-    """csrc/linear_sb_tuned.h (generated from the sweep in profiles/r05_sb_sweep.json): every row names a compiled tile shape whose wave
-    groups' k-stages divide K and fill its LDS stages, upp_linear_sb_tile (a host function) answers with the row's tile for the row's
-    problem, with the nearest row's for a neighbouring M, and never with a tile that would need a second round of workgroups where the
-    swept problem ran in one."""
+def _sb_compiled_and_rows():
     import re
-    from conftest import ROOT
-    if _abi.load().upp_get_option(_abi.OPTIONS["SB_TUNED"]) == 0:
-        pytest.skip("option SB_TUNED = 0: the library answers with the cost model alone")
     csrc = os.path.join(ROOT, "iccv2025-upp_amd", "upp_hip", "csrc")
     compiled = set()
     for f, macro in (("linear_sb.hip", "UPP_SB_CONFIGS"), ("linear_sb_tuned.h", "UPP_SB_TUNED_CONFIGS")):
@@ -154,21 +147,66 @@ def test_split_bf16_tuned_tile_table_is_well_formed_and_answers_for_its_own_prob
             compiled.add(0x400000 + a * 65536 + b * 4096 + c * 256 + d * 16 + e)
     rows = [(int(a), int(b), int(c), int(d, 16)) for a, b, c, d in
             re.findall(r'\{(\d+), (\d+), (\d+), 0x([0-9a-f]+)\}', open(os.path.join(csrc, "linear_sb_tuned.h")).read())]
-    assert len(rows) >= 40
+    return compiled, rows
+
+
+def test_split_bf16_tuned_tile_table_is_well_formed_and_answers_for_its_own_problems():
+    """csrc/linear_sb_tuned.h (round 6: the RESIDUAL of the fitted cost model, generated by tools/micro/sb_model_fit.py): fewer than 30
+    rows; every row names a compiled tile shape whose wave groups' k-stages divide K and fill its LDS stages, upp_linear_sb_tile (a host
+    function) answers with the row's tile for the row's problem (exact matches only: a neighbouring problem takes the model's choice)."""
+    if _abi.load().upp_get_option(_abi.OPTIONS["SB_TUNED"]) == 0:
+        pytest.skip("option SB_TUNED = 0: the library answers with the cost model alone")
+    compiled, rows = _sb_compiled_and_rows()
+    assert 1 <= len(rows) < 30
     lib = _abi.load()
     for M, N, K, code in rows:
         bmb, bnb, ks, nst = (code >> 16) & 15, (code >> 12) & 15, (code >> 4) & 15, code & 15
         assert code in compiled, hex(code)
         assert K % (32 * ks) == 0 and K // (32 * ks) >= nst, (M, N, K, hex(code))
         assert lib.upp_linear_sb_tile(M, N, K) == code, (M, N, K, hex(code))
-    # the headline block at a neighbouring batch (B = 31: 2,325 token rows): the rows swept at 2,400
-    assert lib.upp_linear_sb_tile(2325, 384, 1536) == lib.upp_linear_sb_tile(2400, 384, 1536)
-    # 4,096 rows take 128 x 96 tiles in one round (256 workgroups); 4,100 rows would need 260: not that row
-    t4096 = lib.upp_linear_sb_tile(4096, 384, 384)
-    if ((t4096 >> 16) & 15, (t4096 >> 12) & 15) == (2, 3):
-        assert lib.upp_linear_sb_tile(4100, 384, 384) != t4096
-    # far from every swept M: the cost model
-    assert lib.upp_linear_sb_tile(300, 384, 384) > 0
+    # far from every swept M, and shapes of no recipe: the cost model answers with a compiled tile that serves the problem
+    for M, N, K in ((300, 384, 384), (1800, 1152, 384), (3600, 384, 1536), (5000, 640, 320), (77, 96, 64), (100000, 2048, 4096)):
+        t = lib.upp_linear_sb_tile(M, N, K)
+        assert t in compiled and K % (32 * ((t >> 4) & 15)) == 0 and K // (32 * ((t >> 4) & 15)) >= (t & 15), (M, N, K, hex(t))
+    assert lib.upp_linear_sb_tile(64, 64, 48) == 0 and lib.upp_linear_sb_tile(64, 64, 32) == 0      # K % 32, K < 64: not this kernel's
+
+
+def test_split_bf16_cost_model_picks_within_3_percent_of_the_measured_best():
+    """Round 5's verdict: the analytic model behind the table chose within 3 % of the measured best on 23 of the 197 swept problems.  The
+    model is now fitted to that sweep (profiles/r05_sb_sweep.json; per compiled tile seven coefficients in rounds, k-stages and chip fill:
+    csrc/linear_sb_model.h).  Asserted on the library's own answers (host code): with the table OFF the choice is within 3 % of the best
+    compiled tile on >= 90 % of the swept problems and costs < 1.5 % of summed time; with the residual table on, every swept problem is
+    within 3.5 %.  Generalisation to problems outside the sweep: tools/micro/sb_model_fit.py (cross-validation) and
+    profiles/r06_sb_model_b24_b48.txt (a new sweep at B = 24 and 48, measured)."""
+    import json
+    lib = _abi.load()
+    compiled, _ = _sb_compiled_and_rows()
+    sweep = json.load(open(os.path.join(ROOT, "profiles", "r05_sb_sweep.json")))
+    key = _abi.OPTIONS["SB_TUNED"]
+    was = lib.upp_get_option(key)
+
+    def regrets():
+        out, tot_pick, tot_best = [], 0.0, 0.0
+        for r in sweep:
+            cand = {int(c, 16): us for c, us in r["us"].items()
+                    if int(c, 16) in compiled and r["K"] % (32 * ((int(c, 16) >> 4) & 15)) == 0 and r["K"] // (32 * ((int(c, 16) >> 4) & 15)) >= (int(c, 16) & 15)}
+            pick = lib.upp_linear_sb_tile(r["M"], r["N"], r["K"])
+            assert pick in cand, (r["M"], r["N"], r["K"], hex(pick))
+            best = min(cand.values())
+            out.append(cand[pick] / best - 1.0)
+            tot_pick += cand[pick]; tot_best += best
+        return out, tot_pick / tot_best - 1.0
+    try:
+        lib.upp_set_option(key, 0)
+        reg, extra = regrets()
+        assert len(reg) == 197
+        assert sum(r <= 0.03 for r in reg) >= 0.90 * len(reg), sum(r <= 0.03 for r in reg)
+        assert extra < 0.015 and max(reg) < 0.12, (extra, max(reg))
+        lib.upp_set_option(key, 1)
+        reg, extra = regrets()
+        assert max(reg) <= 0.035 and extra < 0.01, (max(reg), extra)
+    finally:
+        lib.upp_set_option(key, was)
 
 
 def test_exported_symbols_are_exactly_the_declared_ones():

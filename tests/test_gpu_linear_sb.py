@@ -132,7 +132,12 @@ def test_epilogues_match_the_exact_f32_kernel(cfg):
 
 def test_shapes_the_kernel_does_not_take_fall_back_to_the_exact_f32_kernel():
     assert ops.linear_sb_tile(2400, 384, 100) == 0          # K % 32
-    assert ops.linear_sb_tile(2400, 384, 64) == 0           # fewer k-stages than LDS stages
+    assert ops.linear_sb_tile(2400, 384, 32) == 0           # fewer k-stages than any compiled tile's LDS stages
+    t64 = ops.linear_sb_tile(2400, 384, 64)                 # (round 6: two k-stages fill a two-stage tile -- the fitted model may take one)
+    assert t64 == 0 or (64 // (32 * ((t64 >> 4) & 15)) >= (t64 & 15))
+    if t64:
+        a, w, b = _operands(2400, 384, 64)
+        torch.testing.assert_close(ops.linear_f32(a, w, b, ops.LIN_BIAS, frozen=True), ops.linear_f32(a, w, b, ops.LIN_BIAS), rtol=1e-5, atol=5e-6)
     a, w, _ = _operands(64, 48, 100)
     assert torch.equal(ops.linear_f32(a, w, frozen=True), ops.linear_f32(a, w))
     lib = _abi.load()
