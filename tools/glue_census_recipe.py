@@ -20,7 +20,8 @@ def main():
     for _ in range(2):
         ts._forward_backward()
     torch.cuda.synchronize()
-    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA], record_shapes=True, with_stack=stack) as prof:
+    kw = {"experimental_config": torch._C._profiler._ExperimentalConfig(verbose=True)} if stack else {}      # (without it e.stack stays empty)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA], record_shapes=True, with_stack=stack, **kw) as prof:
         ts._forward_backward()
         torch.cuda.synchronize()
     agg = collections.OrderedDict()
@@ -32,14 +33,20 @@ def main():
             continue
         where = ""
         if stack:
-            mine = [f for f in (e.stack or []) if "iccv2025-upp_amd" in f or "bench.py" in f]
-            where = mine[0].replace(ROOT + "/", "").replace("iccv2025-upp_amd/", "")[:60] if mine else "?"
-        key = (e.name, str(e.input_shapes)[:100], (where + " " if stack else "") + ks[0].name[:46])
+            # (frames come as paths relative to their sys.path entry: "models/upp_layers.py(1093): select"; innermost first)
+            mine = [f for f in (e.stack or []) if f.startswith(("models/", "upp_hip/", "utils/", "extensions/", "knn_cuda/", "pointnet2_ops/", "emd/", "bench.py"))]
+            where = " < ".join(f.split(": ")[0].replace("models/", "").replace("upp_hip/", "") + ":" + f.split(": ")[-1] for f in mine[:3])[:90] if mine else "?"
+            if not mine:                          # a backward op: name the autograd node that issued it
+                p_ = e.cpu_parent
+                while p_ is not None and "Backward" not in p_.name:
+                    p_ = p_.cpu_parent
+                where = p_.name.replace("autograd::engine::evaluate_function: ", "")[:60] if p_ is not None else "?"
+        key = (e.name, str(e.input_shapes)[:60 if stack else 100], (where + " | " if stack else "") + ks[0].name.replace("void at::native::", "")[:30 if stack else 46])
         a = agg.setdefault(key, [0, 0.0])
         a[0] += 1; a[1] += sum(k.duration for k in ks)
     print("== %s: %d launches, %.1f us" % (kind, sum(a[0] for a in agg.values()), sum(a[1] for a in agg.values())))
     for (op, shp, kn), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print("  %-26s x%-3d %7.1f us  %-100s | %s" % (op, n, t, shp, kn))
+        print(("  %-26s x%-3d %7.1f us  %-60s | %s" if stack else "  %-26s x%-3d %7.1f us  %-100s | %s") % (op, n, t, shp, kn))
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@ rm -rf $O/seq $O/pipe $O/kern $O/fetch $O/write $O/mfma
 fi
 if [ "$PART" = "recipes" ]; then
 # secondary recipes: un-profiled lines + one kernel summary for the pre-training step (8 executions: 2 eager + 1 replay + 5 timed)
-for w in cls_aux stage2 pretask pretrain seg; do python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --detail $O/r06_workload_${w}_detail.json > $O/r06_workload_$w.json 2> $O/w_$w.err; done
+for w in cls_aux stage2 pretask pretrain seg; do python3 bench.py --workload $w --steps 10 --warmup 3 --detail $O/r06_workload_${w}_detail.json > $O/r06_workload_$w.json 2> $O/w_$w.err; done
 python3 bench.py --workload seg --steps 10 --warmup 3 --no-cpu-baseline --no-pipeline --no-stage-report > $O/r06_workload_seg_sequential.json 2>> $O/w_seg.err
 # kernel summaries of the recipes that used to run library GEMMs / unfused torch formulations (8 executions of the step each: 2 eager + 1 replay + 5 timed; one stream)
 for w in pretrain seg stage2; do
