@@ -42,16 +42,18 @@ python3 bench.py --workload seg --steps 10 --warmup 3 --no-cpu-baseline --no-pip
 for w in pretrain seg stage2; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_$w -- python3 bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline --no-pipeline --no-stage-report > $O/p_$w.log 2>&1
   cp "$(stats $O/p_$w)" $O/r06_workload_${w}_kernel_stats.csv
+  python3 tools/step_census.py "$(trace $O/p_$w)" > $O/r06_workload_${w}_step_census.txt       # ONE replayed step (the stats file above divides construction and warm-up in)
   rm -rf $O/p_$w
 done
 fi
 if [ "$PART" = "micro" ]; then
 set +e          # (a failing helper loses its own file, not the rest)
 python3 tools/glue_census.py 2> /dev/null | grep -v amdgpu.ids > $O/r06_glue_census.txt
-for w in seg stage2 pretask; do python3 tools/glue_census_recipe.py $w 2> /dev/null | grep -v amdgpu.ids > $O/r06_glue_census_$w.txt; done
+for w in seg stage2 pretask; do python3 tools/glue_census_recipe.py $w --stack 2> /dev/null | grep -v amdgpu.ids > $O/r06_glue_census_$w.txt; done
 python3 tools/linear_calls.py headline 2> /dev/null | grep -v amdgpu.ids > $O/r06_linear_calls_headline.txt
 python3 tools/linear_calls.py seg 2> /dev/null | grep -v amdgpu.ids > $O/r06_linear_calls_seg.txt
 python3 tools/micro/sb_stamps.py 2> /dev/null | grep -v amdgpu.ids > $O/r06_sb_stamps.txt
+SB_CHECK_OUT=r06_sb_sweep_b24_b48.json python3 tools/micro/sb_model_check.py 24 48 2> /dev/null | grep -v amdgpu.ids > $O/r06_sb_model_b24_b48.txt
 python3 tools/time_linear_sb.py --tiles --out $O/r06_time_linear_sb.jsonl > /dev/null 2>&1
 python3 tools/time_attention.py 2> /dev/null | grep -v amdgpu.ids > $O/r06_time_attention.txt
 python3 tools/micro/time_ln_adapter.py 2> /dev/null | grep -v amdgpu.ids >> $O/r06_time_attention.txt
