@@ -20,8 +20,9 @@ from .upp_layers import Group, PointNetFeaturePropagation, PositionalEmbedding, 
 class get_loss(nn.Module):
     def forward(self, pred, target):
         if pred.is_cuda and pred.dim() == 2:
-            # F.nll_loss reduces 65,536 rows in a single workgroup on this stack (0.1 ms); gather + mean is the same number
-            return -pred.gather(1, target.view(-1, 1)).mean()
+            # F.nll_loss reduces 65,536 rows in a single workgroup on this stack (0.1 ms); here two launches with fixed-order sums
+            # forward and one dense write backward (upp_nll_mean_fwd / _bwd) -- torch: gather, mean, neg, div, zero-fill + scatter_add
+            return HF.nll_mean(pred, target)
         return F.nll_loss(pred, target)
 
 
@@ -64,7 +65,15 @@ class Point_MAE_unify_seg(PromptedBackbone):
             L.bump_counter(bn1.num_batches_tracked)
         h = _bn_rows(h.view(B * N, -1), bn1, self.training, relu=True, drop=drop)      # (the dropout rides in the BatchNorm's passes)
         h = _pointwise_bn_relu(h, c2, bn2, self.training)
-        h = HF.linear(h, c3.weight.squeeze(-1), c3.bias)
+        w3 = c3.weight.squeeze(-1)
+        if L.POOL_TRACE is None and HF.linear_pad_n_usable(h, w3):
+            # the 50 part classes: the GEMM writes a 52-column matrix from the un-padded weight's plane image; bias + log-softmax read it
+            # where it lies (no padded weight / bias copies, no [:, :50] slice and its backward)
+            ypad = HF._LinearPadN.apply(h, w3) if (torch.is_grad_enabled() and (h.requires_grad or w3.requires_grad)) else \
+                HF.ops.linear_f32(h, None, None, HF.ops.LIN_NONE, planes=HF.ops.PLANES.get(w3) if not w3.requires_grad else HF.ops.PLANES._split(w3.detach()),
+                                  wshape=((w3.shape[0] + 3) // 4 * 4, w3.shape[1]))
+            return HF.log_softmax_rows(ypad, c3.bias, w3.shape[0]).view(B, N, -1)
+        h = HF.linear(h, w3, c3.bias)
         return F.log_softmax(h, dim=-1).view(B, N, -1)
 
     def forward(self, pts, cls_label, label_points=None, completion_prompt=True, denoise=True, point_num=1024, **kwargs):

@@ -57,6 +57,11 @@ SIGNATURES = {
     "upp_cls_pool_fwd": (_c_i, [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 4 + [_c_i] * 3 + [_c_f]),
     "upp_cls_pool_bwd": (_c_i, [_c_f] * 7 + [_c_i] * 3 + [_c_f]),
     "upp_ce_acc": (_c_i, [_c_f] * 4 + [_c_i] * 2 + [_c_f]),
+    "upp_logsoftmax_rows_fwd": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_i, _c_f, _c_f]),
+    "upp_logsoftmax_rows_bwd": (_c_i, [_c_f, _c_f, ctypes.c_longlong, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_f]),
+    "upp_nll_mean_part_floats": (ctypes.c_longlong, [ctypes.c_longlong]),
+    "upp_nll_mean_fwd": (_c_i, [_c_f, _c_f, ctypes.c_longlong, _c_i, _c_f, _c_f, _c_f]),
+    "upp_nll_mean_bwd": (_c_i, [_c_f, _c_f, ctypes.c_longlong, _c_i, _c_f, _c_f]),
     "upp_bn_relu_drop_fwd": (_c_i, [_c_f] * 5 + [ctypes.c_float] * 2 + [_c_i] + [_c_f] + [ctypes.c_float] + [_c_f] * 3 + [_c_i] * 2 + [_c_f]),
     "upp_bn_relu_drop_bwd": (_c_i, [_c_f] * 6 + [_c_i] + [_c_f] + [ctypes.c_float] + [_c_f] * 3 + [_c_i] * 2 + [_c_f]),
     "upp_csr_build": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f] * 3),

@@ -190,6 +190,89 @@ __global__ __launch_bounds__(1024) void ce_acc_kernel(const float *__restrict__ 
     }
 }
 
+// ---- per-point log-softmax + NLL of the segmentation head (round 6; reference models/Point_MAE_unify_segment.py:433 `F.log_softmax`,
+// :20-25 get_loss = F.nll_loss): C <= 64 classes over tens of thousands of point rows.  One wave per row, kLsRows rows per wave; the row
+// arrives as a lane-per-class load from a matrix whose rows may be wider than C (the 50-class layer's output lives in a 52-column
+// matrix: the GEMM kernels want N % 4 == 0) and the class bias is added here (the GEMM then runs bias-free on the un-padded weight's
+// plane image).  torch formulation replaced: softmax_warp_forward / _backward, gather, mean, neg, div, zero-fill + scatter_add, and the
+// zero-fill + copy of the [:, :C] slice's backward.
+constexpr int kLsRows = 8;
+__global__ __launch_bounds__(256) void logsoftmax_rows_fwd_kernel(const float *__restrict__ y, long long ld_y, const float *__restrict__ bias,
+                                                                  long long R, int C, float *__restrict__ logp) {
+    const int lane = threadIdx.x & 63;
+    const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kLsRows;
+    const float bv = (bias && lane < C) ? bias[lane] : 0.0f;
+    float v[kLsRows];
+#pragma unroll
+    for (int i = 0; i < kLsRows; ++i) v[i] = (lane < C && r0 + i < R) ? y[(r0 + i) * ld_y + lane] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < kLsRows; ++i) {
+        if (r0 + i >= R) break;
+        const float x = lane < C ? v[i] + bv : -__builtin_inff();
+        const float mx = wave_max_f32(x);
+        const float se = wave_sum_f32(lane < C ? expf(x - mx) : 0.0f);
+        if (lane < C) logp[(r0 + i) * C + lane] = (x - mx) - logf(se);
+    }
+}
+
+// g_y[r][c] = g[r][c] - exp(logp[r][c]) * sum_c g[r][c]  (c < C);  0 for C <= c < Cpad (the pad columns of the producing GEMM's output)
+__global__ __launch_bounds__(256) void logsoftmax_rows_bwd_kernel(const float *__restrict__ g, const float *__restrict__ logp, long long R, int C,
+                                                                  float *__restrict__ g_y, long long ld_gy, int Cpad) {
+    const int lane = threadIdx.x & 63;
+    const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kLsRows;
+    float gv[kLsRows], lv[kLsRows];
+#pragma unroll
+    for (int i = 0; i < kLsRows; ++i) {
+        const bool ok = lane < C && r0 + i < R;
+        gv[i] = ok ? g[(r0 + i) * C + lane] : 0.0f;
+        lv[i] = ok ? logp[(r0 + i) * C + lane] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < kLsRows; ++i) {
+        if (r0 + i >= R) break;
+        const float sg = wave_sum_f32(gv[i]);
+        if (lane < Cpad) g_y[(r0 + i) * ld_gy + lane] = lane < C ? gv[i] - expf(lv[i]) * sg : 0.0f;
+    }
+}
+
+// part[wg] = sum over the workgroup's rows of logp[r][target[r]] (rows in order inside a wave, waves in order); the second launch adds the
+// partials in workgroup order and scales by -1 / R: out[0] = F.nll_loss(logp, target) (mean), deterministic.
+constexpr int kNllRows = 64;          // rows per wave
+__global__ __launch_bounds__(256) void nll_partial_kernel(const float *__restrict__ logp, const int64_t *__restrict__ target, long long R, int C,
+                                                          float *__restrict__ part) {
+    __shared__ float sw[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r = ((long long)blockIdx.x * 4 + wave) * kNllRows + lane;
+    float v = 0.0f;
+    if (r < R) { const long long t = target[r]; v = (t >= 0 && t < C) ? logp[r * C + t] : 0.0f; }
+    v = wave_sum_f32(v);
+    if (lane == 0) sw[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+}
+__global__ __launch_bounds__(1024) void nll_final_kernel(const float *__restrict__ part, int n, float scale, float *__restrict__ out) {
+    __shared__ float sh[1024];
+    float acc = 0.0f;
+    const int per = (n + 1023) / 1024, i0 = (int)threadIdx.x * per;           // thread t owns a contiguous run: order = index order
+    for (int i = i0; i < min(n, i0 + per); ++i) acc += part[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.0f;
+        for (int t = 0; t < 1024; ++t) tot += sh[t];
+        out[0] = tot * scale;
+    }
+}
+// g_logp[r][c] = c == target[r] ? -g_loss / R : 0  -- every element written once (no zero-fill + scatter)
+__global__ __launch_bounds__(256) void nll_bwd_kernel(const float *__restrict__ g_loss, const int64_t *__restrict__ target, long long R, int C,
+                                                      float *__restrict__ g_logp) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * C) return;
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    g_logp[i] = (long long)c == target[r] ? -g_loss[0] / (float)R : 0.0f;
+}
+
 // BatchNorm1d (batch statistics over the R rows) + ReLU + Dropout of a small (R, C) matrix, one workgroup per 64 columns:
 // lane = column, the 4 waves stride the rows; two passes over the column (mean, then M2 about it) from registers/L2.
 // Forward saves mean / rstd; the dropout mask is (u >= p) from caller-supplied uniforms, kept values scaled by 1/(1-p).
@@ -430,6 +513,40 @@ extern "C" int upp_ce_acc(const float *logits, const int64_t *labels, float *out
     if (C > 64 * kMaxE) return UPP_E_RANGE;
     int waves = B < 16 ? B : 16;
     hipLaunchKernelGGL(ce_acc_kernel, dim3(1), dim3(64 * waves), 0, (hipStream_t)stream, logits, labels, out2, dlogits, B, C);
+    return upp_launch_status();
+}
+
+extern "C" int upp_logsoftmax_rows_fwd(const float *y, long long ld_y, const float *bias, long long R, int C, float *logp, void *stream) {
+    if (!y || !logp || R < 1 || C < 1 || ld_y < C) return UPP_E_BADARG;
+    if (C > 64 || (R + 4 * kLsRows - 1) / (4 * kLsRows) > 0x7fffffffLL) return UPP_E_RANGE;
+    hipLaunchKernelGGL(logsoftmax_rows_fwd_kernel, dim3((unsigned)((R + 4 * kLsRows - 1) / (4 * kLsRows))), dim3(256), 0, (hipStream_t)stream, y, ld_y, bias, R, C, logp);
+    return upp_launch_status();
+}
+
+extern "C" int upp_logsoftmax_rows_bwd(const float *g_logp, const float *logp, long long R, int C, float *g_y, long long ld_gy, int Cpad, void *stream) {
+    if (!g_logp || !logp || !g_y || R < 1 || C < 1 || Cpad < C || ld_gy < Cpad) return UPP_E_BADARG;
+    if (Cpad > 64 || (R + 4 * kLsRows - 1) / (4 * kLsRows) > 0x7fffffffLL) return UPP_E_RANGE;
+    hipLaunchKernelGGL(logsoftmax_rows_bwd_kernel, dim3((unsigned)((R + 4 * kLsRows - 1) / (4 * kLsRows))), dim3(256), 0, (hipStream_t)stream, g_logp, logp, R, C,
+                       g_y, ld_gy, Cpad);
+    return upp_launch_status();
+}
+
+extern "C" long long upp_nll_mean_part_floats(long long R) { return R < 1 ? 0 : (R + 4 * kNllRows - 1) / (4 * kNllRows); }
+
+extern "C" int upp_nll_mean_fwd(const float *logp, const int64_t *target, long long R, int C, float *part, float *out, void *stream) {
+    if (!logp || !target || !part || !out || R < 1 || C < 1) return UPP_E_BADARG;
+    const long long n = (R + 4 * kNllRows - 1) / (4 * kNllRows);
+    if (n > 0x7fffffffLL) return UPP_E_RANGE;
+    hipLaunchKernelGGL(nll_partial_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, logp, target, R, C, part);
+    hipLaunchKernelGGL(nll_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, (int)n, -1.0f / (float)R, out);
+    return upp_launch_status();
+}
+
+extern "C" int upp_nll_mean_bwd(const float *g_loss, const int64_t *target, long long R, int C, float *g_logp, void *stream) {
+    if (!g_loss || !target || !g_logp || R < 1 || C < 1) return UPP_E_BADARG;
+    const long long blocks = (R * C + 255) / 256;
+    if (blocks > 0x7fffffffLL) return UPP_E_RANGE;
+    hipLaunchKernelGGL(nll_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_loss, target, R, C, g_logp);
     return upp_launch_status();
 }
 

@@ -357,6 +357,16 @@ class _DeferredSums:
         self.routed.add(ptr)
         return True
 
+    def wgrad_rows(self, ptr, g2, x2, n_rows):
+        """dW = (g2^T . x2)[:n_rows] for a parameter whose output was computed wider than it is (g2 has n_pad >= n_rows columns whose
+        pad columns are zero): the partial tiles are (n_pad, K); only their first n_rows rows are summed into the buffer."""
+        dst = self.targets.get(ptr) if (self.targets is not None and g2.is_cuda) else None
+        if dst is None or dst.numel() != n_rows * x2.shape[1] or n_rows > g2.shape[1]:
+            return False
+        self.wgrads.append((g2, x2, dst))
+        self.routed.add(ptr)
+        return True
+
     def wgrad_window(self, w, g2, x2):
         """The same for a weight that is a COLUMN RANGE w = P[:, a:b] of a registered 2-D parameter P (the segmentation head's first layer
         multiplies [per-point | per-sample] column ranges of one weight; the feature propagation's first layer [xyz | features]): the
@@ -382,8 +392,8 @@ class _DeferredSums:
         wg, self.wgrads = self.wgrads, []
         if wg:
             for part, (_, _, dst) in zip(ops.linear_wgrad_grouped([(g, x) for g, x, _ in wg]), wg):
-                n = dst.numel()
-                jobs.append((part.view(part.shape[0], n), 0, part.shape[0], n, n, dst, True))
+                n, full = dst.numel(), part[0].numel()                # (full > n: the pad rows of a wgrad_rows problem are not summed)
+                jobs.append((part.view(part.shape[0], full), 0, part.shape[0], n, full, dst, True))
         ops.batched_sum(jobs)
 
 
@@ -494,6 +504,19 @@ class _TransposedWeights:
             self.trainable[key] = [weakref.ref(w), wt, w.is_contiguous()]
             return wt
         return e[1]
+
+    def get_trainable_padded(self, w, n_pad):
+        """W^T of a trainable (N,K) weight as the first N columns of a persistent zero-initialised (K, n_pad) matrix (n_pad >= N): the B
+        operand of the data gradient of a Linear layer whose OUTPUT was computed n_pad columns wide (the 50-class layer of the segmentation
+        head in a 52-column matrix: _LinearPadN).  Refreshed with the other copies by refresh_trainable."""
+        key = ("tp", w.data_ptr(), tuple(w.shape), tuple(w.stride()), int(n_pad))
+        e = self.trainable.get(key)
+        if e is None or e[0]() is None:
+            full = torch.zeros((w.shape[1], int(n_pad)), dtype=w.dtype, device=w.device)
+            ops.transpose(w.detach(), out=full[:, :w.shape[0]])
+            self.trainable[key] = [weakref.ref(w), full[:, :w.shape[0]], False, full]
+            return full
+        return e[3]
 
     def refresh_trainable(self):
         pairs, strided = [], []
@@ -1220,6 +1243,103 @@ def interp_affine_train(dists, idx, feat, x3, wt, k, eps):
 def posenc(x, freqs, out=None, col0=0):
     """(x, sin(f x), cos(f x))_f positional embedding of (...,3) coordinates; no autograd."""
     return ops.posenc_fwd(x.contiguous(), freqs, out, col0)
+
+
+# ------------------------------------------------------------------ per-point segmentation tail
+class _LinearPadN(Function):
+    """y (M, Np) = x . Wp^T for Wp = the (N,K) weight W zero-padded to Np = ceil4(N) rows, WITHOUT materialising Wp (reference
+    models/Point_MAE_unify_segment.py:432 the 50-class Conv1d; the GEMM kernels want N % 4 == 0): the forward multiplies through W's own
+    bf16 plane image (upp_linear_sb_prep zero-fills beyond N), the data gradient through a persistent zero-padded W^T (K, Np), and the
+    weight gradient's partial tiles are (Np, K) of which the first N rows are summed into W's gradient.  F.pad of weight and bias (two
+    fills + two copies per step), the [:, :N] slice of the output and its backward (a zero-fill + a copy of the (M, Np) matrix) are gone."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        N, K = w.shape
+        Np = (N + 3) // 4 * 4
+        planes = ops.PLANES.get_trainable(w) if w.requires_grad else ops.PLANES.get(w)
+        ctx.save_for_backward(x if w.requires_grad else None, w)
+        ctx.Np = Np
+        return ops.linear_f32(x, None, None, ops.LIN_NONE, planes=planes, wshape=(Np, K))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        N, K = w.shape
+        g = g if g.is_contiguous() else g.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = (TRANSPOSED.get_trainable_padded(w, ctx.Np) if w.requires_grad and TRANSPOSED.managed
+                  else F.pad(w.detach().t(), (0, ctx.Np - N)).contiguous())           # (outside a step driver: a fresh padded copy)
+            gx = ops.linear_f32(g, wt)
+        if ctx.needs_input_grad[1]:
+            if not _DEFERRED.wgrad_rows(w.data_ptr(), g, x, N):
+                part = ops.linear_wgrad(g, x)
+                gw = (part.sum(dim=0) if part.shape[0] > 1 else part[0])[:N]
+        return gx, gw
+
+
+def linear_pad_n_usable(x, w):
+    """Can _LinearPadN serve F.linear(x, w) for an (N,K) weight with N % 4 != 0?  HIP f32 rows, the split-bf16 kernel takes (M, ceil4(N), K),
+    and the weight is frozen or managed by a step driver (persistent plane image and padded W^T, refreshed once per step)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and w.dim() == 2 and w.dtype == torch.float32 and w.stride(1) == 1 and x.shape[1] == w.shape[1] and w.shape[0] % 4 != 0):
+        return False
+    if w.requires_grad and torch.is_grad_enabled() and not (ops.PLANES.managed and TRANSPOSED.managed and isinstance(w._base if w._base is not None else w, torch.nn.Parameter)):
+        return False
+    if not w.requires_grad and torch.is_grad_enabled() and x.requires_grad:
+        return False            # (a frozen weight under a gradient for x: the padded frozen W^T is not kept -- the padded-weight path serves it)
+    return ops.linear_sb_usable(x.shape[0], (w.shape[0] + 3) // 4 * 4, w.shape[1])
+
+
+class _LogSoftmaxRows(Function):
+    """log_softmax(y[:, :C] + bias) over the rows of a (R, Cpad) matrix (upp_logsoftmax_rows_fwd / _bwd): the gradient comes back in the
+    padded layout, pad columns zero; a trainable bias takes the deferred column sum of that gradient."""
+
+    @staticmethod
+    def forward(ctx, y, bias, C):
+        logp = ops.logsoftmax_rows_fwd(y, bias, C)
+        ctx.save_for_backward(logp)
+        ctx.Cpad, ctx.C = y.shape[1], C
+        ctx.bias_ptr = bias.data_ptr() if bias is not None else 0
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        (logp,) = ctx.saved_tensors
+        g_y = ops.logsoftmax_rows_bwd(g if g.is_contiguous() else g.contiguous(), logp, ctx.Cpad)
+        gb = None
+        if ctx.bias_ptr and ctx.needs_input_grad[1]:
+            _, gb = _DEFERRED.reduce(ctx.bias_ptr, g_y, 0, ctx.C)
+        return g_y, gb, None
+
+
+def log_softmax_rows(y, bias, C):
+    """F.log_softmax(y[:, :C] + bias, dim=-1) for a 2-D f32 HIP matrix y (R, >= C), C <= 64."""
+    return _LogSoftmaxRows.apply(y, bias, int(C))
+
+
+class _NllMean(Function):
+    """F.nll_loss(logp, target) (mean reduction) in two launches forward, one backward (upp_nll_mean_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, logp, target):
+        ctx.save_for_backward(target)
+        ctx.shape = tuple(logp.shape)
+        return ops.nll_mean_fwd(logp, target).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (target,) = ctx.saved_tensors
+        return ops.nll_mean_bwd(g.reshape(1).contiguous(), target, ctx.shape[0], ctx.shape[1]), None
+
+
+def nll_mean(logp, target):
+    """F.nll_loss(logp, target) for contiguous f32 HIP log-probabilities (R, C) and int64 targets (R); torch elsewhere."""
+    if (logp.is_cuda and logp.dtype == torch.float32 and logp.dim() == 2 and logp.is_contiguous() and target.dtype == torch.int64
+            and target.is_cuda and target.numel() == logp.shape[0]):
+        return _NllMean.apply(logp, target.contiguous().view(-1))
+    return F.nll_loss(logp, target)
 
 
 # ------------------------------------------------------------------ classification tail

@@ -519,6 +519,50 @@ def colsum_partials(part, offset, length, chunks=None):
     return dst
 
 
+def logsoftmax_rows_fwd(y, bias, C):
+    """log_softmax over the first C columns of the rows of y (R, >= C) (+ bias (C)) -> logp (R, C); upp_logsoftmax_rows_fwd."""
+    if not (isinstance(y, torch.Tensor) and y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1 and y.shape[1] >= C):
+        raise RuntimeError("logsoftmax_rows_fwd: a 2-D f32 HIP (cuda) matrix with contiguous rows of at least C columns is required; upp_hip has no CPU path")
+    if bias is not None:
+        _need(bias, "bias", torch.float32, 1, int(C))
+    R = y.shape[0]
+    logp = torch.empty((R, int(C)), dtype=torch.float32, device=y.device)
+    _call(y.device, "upp_logsoftmax_rows_fwd", _abi.ptr(y), y.stride(0), _abi.ptr(bias), R, int(C), _abi.ptr(logp))
+    return logp
+
+
+def logsoftmax_rows_bwd(g_logp, logp, Cpad):
+    """-> g_y (R, Cpad): the log-softmax backward in the first C columns, zeros in the pad columns; upp_logsoftmax_rows_bwd."""
+    _need(g_logp, "g_logp", torch.float32, ndim=2)
+    _need(logp, "logp", torch.float32, ndim=2)
+    R, C = logp.shape
+    if tuple(g_logp.shape) != (R, C):
+        raise RuntimeError("logsoftmax_rows_bwd: g_logp must match logp")
+    g_y = torch.empty((R, int(Cpad)), dtype=torch.float32, device=logp.device)
+    _call(logp.device, "upp_logsoftmax_rows_bwd", _abi.ptr(g_logp), _abi.ptr(logp), R, C, _abi.ptr(g_y), int(Cpad), int(Cpad))
+    return g_y
+
+
+def nll_mean_fwd(logp, target):
+    """F.nll_loss(logp, target) (mean) -> (1,) f32; upp_nll_mean_fwd (two launches, fixed-order sums)."""
+    _need(logp, "logp", torch.float32, ndim=2)
+    R, C = logp.shape
+    if not (isinstance(target, torch.Tensor) and target.is_cuda and target.dtype == torch.int64 and target.numel() == R and target.is_contiguous()):
+        raise RuntimeError("nll_mean_fwd: target must be a contiguous int64 HIP (cuda) tensor with one entry per row")
+    part = torch.empty(int(_abi.load().upp_nll_mean_part_floats(R)), dtype=torch.float32, device=logp.device)
+    out = torch.empty(1, dtype=torch.float32, device=logp.device)
+    _call(logp.device, "upp_nll_mean_fwd", _abi.ptr(logp), _abi.ptr(target), R, C, _abi.ptr(part), _abi.ptr(out))
+    return out
+
+
+def nll_mean_bwd(g_loss, target, R, C):
+    """-> g_logp (R, C) = -g_loss / R at (r, target[r]), 0 elsewhere; g_loss a one-element device tensor; upp_nll_mean_bwd."""
+    _need(g_loss, "g_loss", torch.float32)
+    g_logp = torch.empty((int(R), int(C)), dtype=torch.float32, device=target.device)
+    _call(target.device, "upp_nll_mean_bwd", _abi.ptr(g_loss), _abi.ptr(target), int(R), int(C), _abi.ptr(g_logp))
+    return g_logp
+
+
 def rectify_select(feature, w0, b0, w1, b1, pts, keep, u=None, p=0.0, factor=1.0, nudge=0.2, want_pred=False, want_order=False, want_score=False):
     """Tail of the denoising prompter in two launches (upp_rectify_select): pred = score head(feature) * factor, moved = pts + nudge * pred,
     the `keep` least suspicious points of every cloud in descending-score order.  -> out (B,keep,3) [, pred (B,N,3)] [, order (B,N) int64] [, score (B,N)]."""

@@ -396,6 +396,22 @@ int upp_cls_pool_fwd(const float *x, const float *gamma, const float *beta, floa
 int upp_cls_pool_bwd(const float *g_feat, const float *x, const float *mean, const float *rstd, const float *gamma,
                      const int32_t *amax, float *g_x, int B, int L, int D, void *stream);
 int upp_ce_acc(const float *logits, const int64_t *labels, float *out2, float *dlogits, int B, int C, void *stream);
+/* ---- per-point log-softmax + NLL of the segmentation head (round 6) ---------------------------------------------------
+ * Replaces `F.log_softmax(x, dim=-1)` (reference models/Point_MAE_unify_segment.py:433) and `F.nll_loss(pred, target)`
+ * (:20-25 get_loss) over R = B * N point rows of C <= 64 classes, and the torch glue around them (gather, mean, neg, div, zero-fill +
+ * scatter_add, zero-fill + copy of a column slice's backward):
+ *   upp_logsoftmax_rows_fwd : logp (R,C) = log_softmax over c of y[r * ld_y + c] + bias[c] (bias NULL: none).  ld_y >= C: the rows may
+ *                             be wider than C (the 50-class layer's GEMM writes a 52-column matrix).
+ *   upp_logsoftmax_rows_bwd : g_y[r * ld_gy + c] = g_logp[r][c] - exp(logp[r][c]) * sum_c g_logp[r][c] for c < C and 0 for
+ *                             C <= c < Cpad <= ld_gy: the gradient in the producing GEMM's padded layout, every element written once.
+ *   upp_nll_mean_fwd        : out[0] = -(1 / R) sum_r logp[r][target[r]] (targets outside [0, C) contribute 0); `part`:
+ *                             upp_nll_mean_part_floats(R) floats of scratch; two launches, sums in a fixed order (deterministic).
+ *   upp_nll_mean_bwd        : g_logp (R,C) = -g_loss[0] / R at (r, target[r]), 0 elsewhere; g_loss a DEVICE scalar. */
+int upp_logsoftmax_rows_fwd(const float *y, long long ld_y, const float *bias, long long R, int C, float *logp, void *stream);
+int upp_logsoftmax_rows_bwd(const float *g_logp, const float *logp, long long R, int C, float *g_y, long long ld_gy, int Cpad, void *stream);
+long long upp_nll_mean_part_floats(long long R);
+int upp_nll_mean_fwd(const float *logp, const int64_t *target, long long R, int C, float *part, float *out, void *stream);
+int upp_nll_mean_bwd(const float *g_loss, const int64_t *target, long long R, int C, float *g_logp, void *stream);
 /*   upp_bn_relu_drop_fwd / bwd : BatchNorm1d + ReLU + Dropout of a (R, C) matrix with few rows (the Linear outputs of
  *                      cls_head_finetune, R = batch size), one launch each way.  training != 0: batch statistics (mean / rstd
  *                      outputs, running statistics updated with momentum / unbiased variance when non-NULL); else running

@@ -565,3 +565,81 @@ def test_fan_out_sums_the_branch_gradients_in_one_launch():
     names = [e.key for e in prof.key_averages()]
     assert sum('batched_sum' in k for k in names) >= 1
     assert HF.fan_out(x.detach(), 3)[0] is not None and len(HF.fan_out(x.detach(), 3)) == 3
+
+
+@pytest.mark.parametrize("R,C,Cpad,with_bias", [(65536, 50, 52, True), (1000, 64, 64, False), (33, 7, 8, True), (4096, 50, 50, True)])
+def test_log_softmax_rows_and_nll_mean_match_torch(R, C, Cpad, with_bias):
+    """Round 6: the per-point tail of the segmentation head -- F.log_softmax over the first C columns of a (R, Cpad) matrix (+ class bias)
+    and F.nll_loss (mean) -- on upp_logsoftmax_rows_* / upp_nll_mean_* (reference models/Point_MAE_unify_segment.py:433, :20-25): values,
+    the gradient in the padded layout (pad columns exactly zero), the bias gradient, determinism."""
+    g = torch.Generator(device='cuda').manual_seed(R + C)
+    y0 = torch.randn(R, Cpad, device='cuda', generator=g) * 3
+    b0 = torch.randn(C, device='cuda', generator=g) if with_bias else None
+    target = torch.randint(0, C, (R,), device='cuda', generator=g)
+    y = y0.clone().requires_grad_(True)
+    b = b0.clone().requires_grad_(True) if with_bias else None
+    logp = HF.log_softmax_rows(y, b, C)
+    loss = HF.nll_mean(logp, target)
+    assert type(loss.grad_fn).__name__ == '_NllMeanBackward' and type(logp.grad_fn).__name__ == '_LogSoftmaxRowsBackward'
+    loss.backward()
+    yt = y0.clone().requires_grad_(True)
+    bt = b0.clone().requires_grad_(True) if with_bias else None
+    logp_t = F.log_softmax(yt[:, :C] + (bt if with_bias else 0.0), dim=-1)
+    loss_t = F.nll_loss(logp_t, target)
+    loss_t.backward()
+    close(logp, logp_t, rtol=1e-5, atol_scale=2e-6)
+    np.testing.assert_allclose(loss.item(), loss_t.item(), rtol=2e-6)
+    close(y.grad[:, :C], yt.grad[:, :C], rtol=1e-5, atol_scale=2e-6)
+    assert Cpad == C or float(y.grad[:, C:].abs().max()) == 0.0
+    if with_bias:
+        close(b.grad, bt.grad, rtol=2e-5, atol_scale=5e-6)
+    y2 = y0.clone().requires_grad_(True)
+    loss2 = HF.nll_mean(HF.log_softmax_rows(y2, b0, C), target)
+    loss2.backward()
+    assert torch.equal(loss2, loss.detach()) and torch.equal(y2.grad, y.grad)                # deterministic
+    # a general upstream gradient (not the NLL's one-hot): the log-softmax backward on its own
+    w = torch.randn(R, C, device='cuda', generator=g)
+    y3, yt3 = y0.clone().requires_grad_(True), y0.clone().requires_grad_(True)
+    (HF.log_softmax_rows(y3, b0, C) * w).sum().backward()
+    (F.log_softmax(yt3[:, :C] + (b0 if with_bias else 0.0), dim=-1) * w).sum().backward()
+    close(y3.grad[:, :C], yt3.grad[:, :C], rtol=2e-5, atol_scale=5e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(65536, 50, 256), (4096, 50, 256), (2048, 30, 128)])
+def test_linear_with_an_output_width_that_is_no_multiple_of_4_needs_no_padded_weight(M, N, K):
+    """Round 6: the 50-class layer of the segmentation head (reference models/Point_MAE_unify_segment.py:432) inside a step driver:
+    HF._LinearPadN multiplies through the un-padded weight's persistent plane image into a ceil4(N)-column matrix, takes the data
+    gradient through a persistent zero-padded W^T and sums only the first N rows of the weight-gradient tiles into the parameter's
+    buffer -- against F.linear's autograd; no torch pad / fill / copy kernels."""
+    from upp_hip import ops
+    torch.manual_seed(M + N)
+    w = torch.nn.Parameter(torch.randn(N, K, device='cuda') * 0.05)
+    x = torch.randn(M, K, device='cuda', requires_grad=True)
+    Np = (N + 3) // 4 * 4
+    gy = torch.randn(M, Np, device='cuda')
+    gy[:, N:] = 0.0                                                       # (what the log-softmax backward hands over)
+    ref = torch.nn.functional.linear(x, w)
+    gx_t, gw_t = torch.autograd.grad(ref, (x, w), gy[:, :N])
+    buf = torch.full((N * K,), 0.125, device='cuda')
+    was = ops.PLANES.managed, HF.TRANSPOSED.managed
+    ops.PLANES.managed = HF.TRANSPOSED.managed = True
+    try:
+        assert HF.linear_pad_n_usable(x, w)
+        warm = torch.zeros(N * K, device='cuda')                          # first use: the persistent plane image and padded W^T are made (one zero-fill)
+        with HF.deferred_sums({w.data_ptr(): warm.view(N, K)}):
+            torch.autograd.grad(HF._LinearPadN.apply(x, w), (x, w), gy, allow_unused=True)
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            HF.TRANSPOSED.refresh_trainable(); ops.PLANES.refresh_trainable()          # what a step driver does at the start of a step
+            with HF.deferred_sums({w.data_ptr(): buf.view(N, K)}) as scope:
+                y = HF._LinearPadN.apply(x, w)
+                hx, hw = torch.autograd.grad(y, (x, w), gy, allow_unused=True)
+            torch.cuda.synchronize()
+    finally:
+        ops.PLANES.managed, HF.TRANSPOSED.managed = was
+    assert tuple(y.shape) == (M, Np) and hw is None and w.data_ptr() in scope.routed
+    close(y[:, :N], ref, rtol=1e-5, atol_scale=2e-6)
+    assert Np == N or float(y[:, N:].abs().max()) == 0.0
+    close(hx, gx_t, rtol=1e-5, atol_scale=2e-6)
+    close((buf - 0.125).view(N, K), gw_t, rtol=2e-5, atol_scale=5e-6)
+    names = [e.key for e in prof.key_averages()]
+    assert not any(("FillFunctor" in n_ or "reduce_kernel" in n_ or "direct_copy" in n_) for n_ in names), names
