@@ -55,12 +55,18 @@ class Point_MAE_pretask_dev(PromptedBackbone):
             # exactly the centred neighbourhood the fused kNN+group kernel writes
             neigh, _ = L.OPS["knn_group"](partial.contiguous(), noise.contiguous(), 4)
             noise_vector = neigh.mean(dim=-2)
-        if self.rectify_prompter.out_channels == 1:
-            positive = torch.mean((pred_noise - torch.norm(noise_vector, 2, dim=-1, keepdim=True)) ** 2)
+        if (pred.is_cuda and pred.dtype == torch.float32 and pred.shape[-1] == 3 and self.rectify_prompter.out_channels == 3
+                and 0 < point_num < P and L.POOL_TRACE is None):
+            # the two means of squared norms and the ranking score in two launches (+ one backward) instead of ~30 element-wise ones
+            loss_pn, score = HF.noise_loss(pred, noise_vector, point_num)
+            positive, negative = loss_pn, 0.0
         else:
-            positive = torch.mean(torch.norm(pred_noise - noise_vector, 2, dim=-1, keepdim=True) ** 2)
-        negative = torch.mean(torch.norm(pred_pure, 2, dim=-1, keepdim=True) ** 2)
-        score = torch.norm(pred, p=2, dim=-1)
+            if self.rectify_prompter.out_channels == 1:
+                positive = torch.mean((pred_noise - torch.norm(noise_vector, 2, dim=-1, keepdim=True)) ** 2)
+            else:
+                positive = torch.mean(torch.norm(pred_noise - noise_vector, 2, dim=-1, keepdim=True) ** 2)
+            negative = torch.mean(torch.norm(pred_pure, 2, dim=-1, keepdim=True) ** 2)
+            score = torch.norm(pred, p=2, dim=-1)
         order = HF.argsort_rows(score, descending=True)          # (rank-counting kernel: no library sort in the step)
         recall = torch.mean(torch.sum(order[:, :-point_num].detach() > point_num, dim=-1) / (P - point_num))
         kept = torch.gather(pts, 1, order[:, -point_num:, None].expand(-1, -1, 3)).detach()

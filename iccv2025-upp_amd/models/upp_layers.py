@@ -463,7 +463,16 @@ def mlp2(seq, x):
     in the first layer's epilogue, K = 3 takes the small-K kernel (reference models/Point_MAE_pretask_dev.py:395-399, 46)."""
     if not (x.is_cuda and x.dtype == torch.float32 and len(seq) == 3 and isinstance(seq[1], nn.GELU) and seq[1].approximate == 'none'):
         return seq(x)
-    return HF.linear(HF.linear(x, seq[0].weight, seq[0].bias, act='gelu'), seq[2].weight, seq[2].bias)
+    l0, l2 = seq[0], seq[2]
+    if torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in (l0.weight, l0.bias, l2.weight, l2.bias))):
+        # with gradients (stage 2, the pre-task and pre-training recipes): GELU' is saved by the first launch and multiplied in the second
+        # layer's data-gradient epilogue -- no torch gelu / gelu_backward pair
+        if HF.mlp_smallk_gelu_usable(x, l0.weight, l0.bias, l2.weight, l2.bias):
+            return HF.mlp_smallk_gelu(x, l0.weight, l0.bias, l2.weight, l2.bias)
+        if (HF.linear_usable(x, l0.weight) and l0.bias is not None and l0.out_features % 4 == 0 and l2.weight.shape[0] % 4 == 0
+                and HF.linear_usable(x.new_empty((1, l0.out_features)), l2.weight)):
+            return HF.mlp_gelu(x, l0.weight, l0.bias, l2.weight, l2.bias)
+    return HF.linear(HF.linear(x, l0.weight, l0.bias, act='gelu'), l2.weight, l2.bias)
 
 
 def _relu_linear(x, lin):
@@ -738,11 +747,16 @@ class Block(nn.Module):
             # stage 2 of the recipe: the centres carry a gradient back to the prompters, and the interpolation weights 1 / (d + eps)
             # are functions of them -- one autograd node per forward (HF.prop_weights), shared by every block like the index itself
             wkey = ('w8',) + key
-            w8 = None if cache is None else cache.get(wkey)
-            if w8 is None:
+            slot = None if cache is None else cache.get(wkey)
+            if slot is None:
                 w8 = HF.prop_weights(c1, c2, entry, eps=1e-3)
+                # every block of the path reads the weights: one alias per consumer, so that their gradients come back summed by ONE
+                # launch (HF.fan_out) instead of consumers - 1 element-wise additions of autograd
+                n = int(kw.get('_prop_consumers') or 1)
+                slot = [w8, list(HF.fan_out(w8, n)) if n > 1 else []]
                 if cache is not None:
-                    cache[wkey] = w8
+                    cache[wkey] = slot
+            w8 = slot[1].pop() if slot[1] else slot[0]
         u, keep = None, 1.0
         if isinstance(self.drop_path, DropPath) and self.training and self.drop_path.drop_prob > 0:
             u = UNIFORMS.take((B * G2,), x.device)
@@ -899,6 +913,9 @@ class TransformerEncoder(nn.Module):
             depth = kwargs['rectify_depth']
         if 'center1' in kwargs:
             kwargs['_prop_cache'] = {}      # per-forward scratch shared by the blocks (see Block._propagate_fused)
+            path = kwargs.get('path')
+            kwargs['_prop_consumers'] = (sum(1 for b in self.blocks[:depth] if getattr(b, f'{path}_prompts', None) is not None)
+                                         if (path in _PATHS and kwargs.get('prompt_propagation_after')) else 1)
         cls_pos = kwargs.pop('cls_pos_param', None)
         if cls_pos is not None and all(b.fusable(x) for b in self.blocks[:depth]):
             # `pos` is re-added in front of every block, so autograd would sum its (B,L,D) gradient once per block although

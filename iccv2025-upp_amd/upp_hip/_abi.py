@@ -28,6 +28,7 @@ SIGNATURES = {
     "upp_knn_ex": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_group_fwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_group_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
+    "upp_fps_gather_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f]),
     "upp_chamfer_fwd": (_c_i, [_c_f] * 6 + [_c_i] * 3 + [_c_f]),
     "upp_chamfer_bwd": (_c_i, [_c_f] * 8 + [_c_i] * 3 + [_c_f]),
     "upp_chamfer_loss_work_floats": (ctypes.c_longlong, []),
@@ -62,6 +63,9 @@ SIGNATURES = {
     "upp_nll_mean_part_floats": (ctypes.c_longlong, [ctypes.c_longlong]),
     "upp_nll_mean_fwd": (_c_i, [_c_f, _c_f, ctypes.c_longlong, _c_i, _c_f, _c_f, _c_f]),
     "upp_nll_mean_bwd": (_c_i, [_c_f, _c_f, ctypes.c_longlong, _c_i, _c_f, _c_f]),
+    "upp_noise_loss_part_floats": (ctypes.c_longlong, [_c_i, _c_i]),
+    "upp_noise_loss_fwd": (_c_i, [_c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f, _c_f, _c_f]),
+    "upp_noise_loss_bwd": (_c_i, [_c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "upp_bn_relu_drop_fwd": (_c_i, [_c_f] * 5 + [ctypes.c_float] * 2 + [_c_i] + [_c_f] + [ctypes.c_float] + [_c_f] * 3 + [_c_i] * 2 + [_c_f]),
     "upp_bn_relu_drop_bwd": (_c_i, [_c_f] * 6 + [_c_i] + [_c_f] + [ctypes.c_float] + [_c_f] * 3 + [_c_i] * 2 + [_c_f]),
     "upp_csr_build": (_c_i, [_c_f] + [_c_i] * 4 + [_c_f] * 3),
@@ -110,6 +114,7 @@ SIGNATURES = {
     "upp_linear_sb_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, _c_f, _c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong] + [_c_i] * 5 + [_c_f]),
     "upp_linear_group_bias_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
     "upp_linear_smallk_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_f, ctypes.c_longlong] + [_c_i] * 4 + [_c_f]),
+    "upp_linear_smallk_gelu_d_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f]),
     "upp_linear_smallk_wgrad_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_f, _c_i, _c_i, _c_i, _c_i, _c_f]),
     "upp_transpose_f32": (_c_i, [_c_f, ctypes.c_longlong, _c_f, ctypes.c_longlong, _c_i, _c_i, _c_f]),
     "upp_transpose_batched_f32": (_c_i, [_c_f, _c_f, _c_f, _c_f, _c_i, _c_f]),

@@ -79,6 +79,24 @@ __global__ void group_bwd_center_kernel(const float *__restrict__ grad_out, floa
     }
 }
 
+// Backward of the FPS centre gather (reference utils/misc.py:19 gather_operation under autograd: stage 2 and the pre-task recipe, where the
+// sampled coordinates carry a gradient): g_xyz (B,N,3) = 0 everywhere except rows idx[b][j], which receive g_centers[b][j].  ONE launch, one
+// workgroup per cloud: the cloud's slice is zeroed, then the M rows are added -- torch.zeros + an int32 -> int64 index copy + the scatter
+// kernel were three launches per FPS call.  FPS indices of a cloud are distinct unless it has fewer distinct points than samples; equal
+// indices are added atomically (two addends commute exactly; three or more depend on order in the last bit, as torch's index_add does).
+__global__ __launch_bounds__(256) void fps_gather_bwd_kernel(const float *__restrict__ g_centers, const int32_t *__restrict__ idx,
+                                                             float *__restrict__ g_xyz, int N, int M) {
+    const int b = blockIdx.x;
+    float *gx = g_xyz + (size_t)b * N * 3;
+    for (int i = threadIdx.x; i < N * 3; i += 256) gx[i] = 0.0f;
+    __syncthreads();                                  // (the zeros of this workgroup's own slice are visible to its own atomics)
+    for (int i = threadIdx.x; i < M * 3; i += 256) {
+        const int j = i / 3, c = i - 3 * j;
+        const int r = idx[(size_t)b * M + j];
+        if (r >= 0 && r < N) atomicAdd(&gx[(size_t)r * 3 + c], g_centers[((size_t)b * M + j) * 3 + c]);
+    }
+}
+
 }  // namespace
 
 extern "C" int upp_gather_fwd(const float *feat, const int32_t *idx, float *out, int B, int C, int N, int M, void *stream) {
@@ -94,6 +112,13 @@ extern "C" int upp_gather_bwd(const float *grad_out, const int32_t *idx, float *
     const long long total = (long long)B * C * M;
     if (total == 0) return 0;
     hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, grad_out, idx, grad_feat, C, N, M, total);
+    return upp_launch_status();
+}
+
+extern "C" int upp_fps_gather_bwd(const float *g_centers, const int32_t *idx, float *g_xyz, int B, int N, int M, void *stream) {
+    if (!g_centers || !idx || !g_xyz || B < 0 || N < 1 || M < 0) return UPP_E_BADARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(fps_gather_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, g_centers, idx, g_xyz, N, M);
     return upp_launch_status();
 }
 

@@ -273,6 +273,45 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(const float *__restrict__ 
     g_logp[i] = (long long)c == target[r] ? -g_loss[0] / (float)R : 0.0f;
 }
 
+// ---- noise-vector supervision of the pre-task recipe (round 6; reference models/Point_MAE_pretask_dev.py:685-692:
+//   positive = mean(norm(pred_noise - noise_vector, dim=-1, keepdim=True) ** 2),  negative = mean(norm(pred_pure, dim=-1, keepdim=True) ** 2),
+//   score = norm(pred, dim=-1)) -- ~30 element-wise torch launches forward and backward (norm, pow, mean, the zero guards of norm's backward).
+// pred (B,P,3): the first pn points of a cloud are shape points (target 0), the rest noise points (target nv (B, P - pn, 3)).
+// Forward: per-workgroup partial sums in a fixed order -> nll_final_kernel adds them; score (B,P) = |pred| beside it.
+__global__ __launch_bounds__(256) void noise_loss_partial_kernel(const float *__restrict__ pred, const float *__restrict__ nv, int B, int P, int pn,
+                                                                 float w_pure, float w_noise, float *__restrict__ part, float *__restrict__ score) {
+    __shared__ float sw[4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x, total = (long long)B * P;
+    float v = 0.0f;
+    if (i < total) {
+        const int b = (int)(i / P), t = (int)(i - (long long)b * P);
+        const float x = pred[i * 3], y = pred[i * 3 + 1], z = pred[i * 3 + 2];
+        if (score) score[i] = sqrtf(sumsq3(x, y, z));
+        if (t < pn) v = w_pure * sumsq3(x, y, z);
+        else {
+            const float *q = nv + ((long long)b * (P - pn) + (t - pn)) * 3;
+            v = w_noise * sumsq3(x - q[0], y - q[1], z - q[2]);
+        }
+    }
+    v = wave_sum_f32(v);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+}
+__global__ __launch_bounds__(256) void noise_loss_bwd_kernel(const float *__restrict__ g_loss, const float *__restrict__ pred, const float *__restrict__ nv,
+                                                             int B, int P, int pn, float w_pure, float w_noise, float *__restrict__ g_pred) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x, total = (long long)B * P;
+    if (i >= total) return;
+    const int b = (int)(i / P), t = (int)(i - (long long)b * P);
+    const float g = g_loss[0];
+    float dx = pred[i * 3], dy = pred[i * 3 + 1], dz = pred[i * 3 + 2], w = 2.0f * w_pure * g;
+    if (t >= pn) {
+        const float *q = nv + ((long long)b * (P - pn) + (t - pn)) * 3;
+        dx -= q[0]; dy -= q[1]; dz -= q[2]; w = 2.0f * w_noise * g;
+    }
+    g_pred[i * 3] = w * dx; g_pred[i * 3 + 1] = w * dy; g_pred[i * 3 + 2] = w * dz;
+}
+
 // BatchNorm1d (batch statistics over the R rows) + ReLU + Dropout of a small (R, C) matrix, one workgroup per 64 columns:
 // lane = column, the 4 waves stride the rows; two passes over the column (mean, then M2 about it) from registers/L2.
 // Forward saves mean / rstd; the dropout mask is (u >= p) from caller-supplied uniforms, kept values scaled by 1/(1-p).
@@ -547,6 +586,28 @@ extern "C" int upp_nll_mean_bwd(const float *g_loss, const int64_t *target, long
     const long long blocks = (R * C + 255) / 256;
     if (blocks > 0x7fffffffLL) return UPP_E_RANGE;
     hipLaunchKernelGGL(nll_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_loss, target, R, C, g_logp);
+    return upp_launch_status();
+}
+
+extern "C" long long upp_noise_loss_part_floats(int B, int P) { return (B < 1 || P < 1) ? 0 : ((long long)B * P + 255) / 256; }
+
+extern "C" int upp_noise_loss_fwd(const float *pred, const float *noise_vector, int B, int P, int pn, float *part, float *loss, float *score,
+                                  void *stream) {
+    if (!pred || !noise_vector || !part || !loss || B < 1 || P < 2 || pn < 1 || pn >= P) return UPP_E_BADARG;
+    const long long n = ((long long)B * P + 255) / 256;
+    if (n > 0x7fffffffLL) return UPP_E_RANGE;
+    hipLaunchKernelGGL(noise_loss_partial_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, pred, noise_vector, B, P, pn,
+                       1.0f / ((float)B * (float)pn), 1.0f / ((float)B * (float)(P - pn)), part, score);
+    hipLaunchKernelGGL(nll_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, (int)n, 1.0f, loss);
+    return upp_launch_status();
+}
+
+extern "C" int upp_noise_loss_bwd(const float *g_loss, const float *pred, const float *noise_vector, int B, int P, int pn, float *g_pred, void *stream) {
+    if (!g_loss || !pred || !noise_vector || !g_pred || B < 1 || P < 2 || pn < 1 || pn >= P) return UPP_E_BADARG;
+    const long long n = ((long long)B * P + 255) / 256;
+    if (n > 0x7fffffffLL) return UPP_E_RANGE;
+    hipLaunchKernelGGL(noise_loss_bwd_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, g_loss, pred, noise_vector, B, P, pn,
+                       1.0f / ((float)B * (float)pn), 1.0f / ((float)B * (float)(P - pn)), g_pred);
     return upp_launch_status();
 }
 

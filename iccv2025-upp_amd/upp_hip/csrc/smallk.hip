@@ -23,7 +23,7 @@ __device__ __forceinline__ float act_f(float v, int act) {
 
 __global__ __launch_bounds__(256) void linear_smallk_kernel(const float *__restrict__ x, long long ldx, const float *__restrict__ W,
                                                            long long ldw, const float *__restrict__ bias, float *__restrict__ y,
-                                                           long long ldy, int M, int N, int K, int act) {
+                                                           long long ldy, int M, int N, int K, int act, float *__restrict__ d, long long ldd) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Kp = (K + 3) & ~3;
     const int groups = 256 / N;                       // row groups per workgroup (N <= 256)
@@ -61,7 +61,13 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float *__restr
 #pragma unroll
     for (int t = 0; t < kTR; ++t) {
         const int row = row0 + grp * kTR + t;
-        if (row < M) y[(long long)row * ldy + n] = act_f(acc[t] + b, act);
+        if (row < M) {
+            y[(long long)row * ldy + n] = act_f(acc[t] + b, act);
+            if (d) {                                  // GELU'(z) beside GELU(z): the factor of the backward pass (upp_linear_smallk_gelu_d_f32)
+                const float z = acc[t] + b;
+                d[(long long)row * ldd + n] = 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * expf(-0.5f * z * z);
+            }
+        }
     }
 }
 
@@ -188,7 +194,28 @@ extern "C" int upp_linear_smallk_f32(const float *x, long long ldx, const float 
             raised = true;
         }
     }
-    hipLaunchKernelGGL(linear_smallk_kernel, dim3((M + RB - 1) / RB), dim3(256), lds, (hipStream_t)stream, x, ldx, W, ldw, bias, y, ldy, M, N, K, act);
+    hipLaunchKernelGGL(linear_smallk_kernel, dim3((M + RB - 1) / RB), dim3(256), lds, (hipStream_t)stream, x, ldx, W, ldw, bias, y, ldy, M, N, K, act,
+                       (float *)nullptr, 0LL);
+    return upp_launch_status();
+}
+
+// y = GELU(x . W^T + bias) and d = GELU'(x . W^T + bias) in one pass: the first layer of a TRAINABLE position MLP (Linear(3,128) - GELU -
+// Linear(128,D)) keeps the derivative for its backward instead of a torch gelu / gelu_backward pair (stage 2, the pre-task recipe).
+extern "C" int upp_linear_smallk_gelu_d_f32(const float *x, long long ldx, const float *W, long long ldw, const float *bias, float *y, long long ldy,
+                                            float *d, long long ldd, int M, int N, int K, void *stream) {
+    if (!x || !W || !y || !d || M < 1 || N < 1 || K < 1) return UPP_E_BADARG;
+    if (K > 64 || N > 256 || ldx < K || ldw < K || ldy < N || ldd < N) return UPP_E_RANGE;
+    const int Kp = (K + 3) & ~3, RB = (256 / N) * kTR;
+    const size_t lds = (size_t)(Kp * N + RB * Kp) * sizeof(float);
+    if (lds > 64 * 1024) {
+        static std::atomic<bool> raised{false};
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(linear_smallk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(linear_smallk_kernel, dim3((M + RB - 1) / RB), dim3(256), lds, (hipStream_t)stream, x, ldx, W, ldw, bias, y, ldy, M, N, K, 2, d, ldd);
     return upp_launch_status();
 }
 

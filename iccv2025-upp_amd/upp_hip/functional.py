@@ -53,10 +53,7 @@ class _FpsGather(Function):
     @staticmethod
     def backward(ctx, grad_centers, _grad_idx):
         (idx,) = ctx.saved_tensors
-        B, M = idx.shape
-        gx, _ = ops.group_bwd(grad_centers.contiguous().view(B, M, 1, 3), idx.long().view(B, M, 1), ctx.N,
-                              need_xyz=True, need_center=False)
-        return gx, None
+        return ops.fps_gather_bwd(grad_centers.contiguous(), idx, ctx.N), None        # (one launch: zero-fill + int32 indices + scatter)
 
 
 class _KnnGroup(Function):
@@ -846,6 +843,65 @@ class _MlpGelu(Function):
 # with ABI 5; NOTEBOOK section 11.3 keeps the account.)
 
 
+class _MlpSmallKGelu(Function):
+    """lin2(GELU(lin1(x))) for a first layer the small-K kernel serves (K <= 64: the 3 -> 128 layer of a position MLP, reference
+    models/Point_MAE_pretask_dev.py:395-399) WITH gradients: GELU and GELU' come out of the first launch (upp_linear_smallk_gelu_d_f32), the
+    data gradient of the second layer is multiplied by the saved GELU' in its epilogue -- no torch gelu / gelu_backward pair.  Weight and
+    bias gradients as _LinearSmallK / _LinearMFMA (deferred sums inside a step driver)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        hid, d = ops.linear_smallk_gelu_d(x, w1, b1)
+        ctx.save_for_backward(x if (w1.requires_grad or x.requires_grad) else None, w1, w2, d, hid if w2.requires_grad else None)
+        ctx.ptrs = (w1.data_ptr(), b1.data_ptr() if b1 is not None else 0, b2.data_ptr() if b2 is not None else 0)
+        return _lin(hid, w2, b2, ops.LIN_BIAS if b2 is not None else ops.LIN_NONE)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w1, w2, d, hid = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        H, K = w1.shape
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        g_z = _lin(g2, w2, None, ops.LIN_MUL, aux=d.view(-1, H), dgrad=True)                 # (rows, H) = gradient at the pre-activation
+        gx = gw1 = gb1 = gw2 = gb2 = None
+        if need[0]:
+            if H > 64:
+                gx = ops.linear_f32(g_z, TRANSPOSED.get_padded(w1))[:, :K]                   # (_smallk_gelu_usable: w1 frozen then)
+            else:
+                gx = ops.linear_smallk(g_z, w1.detach().t().contiguous() if not w1.requires_grad else ops.transpose(w1.detach()), None, 0)
+            gx = gx.reshape(g.shape[:-1] + (K,))
+        if need[1]:
+            x2 = x.reshape(-1, K)
+            if x2.stride(1) != 1:
+                x2 = x2.contiguous()
+            part = ops.linear_smallk_wgrad(g_z, x2)
+            _, gw1 = _DEFERRED.reduce(ctx.ptrs[0], part.view(part.shape[0], H * K), 0, H * K)
+            gw1 = None if gw1 is None else gw1.view(H, K)
+        if need[2]:
+            _, gb1 = _DEFERRED.reduce(ctx.ptrs[1], g_z, 0, H)
+        if need[3]:
+            gw2 = weight_grad(g2, hid.reshape(-1, H), w2)
+        if need[4]:
+            _, gb2 = _DEFERRED.reduce(ctx.ptrs[2], g2, 0, g2.shape[1])
+        return gx, gw1, gb1, gw2, gb2
+
+
+def mlp_smallk_gelu_usable(x, w1, b1, w2, b2):
+    """Can _MlpSmallKGelu serve lin2(GELU(lin1(x)))?  The first layer is the small-K kernel's (with the gradient rules of _smallk_with_grad:
+    a trainable first weight of more than 64 outputs only when x needs no gradient), its bias exists, the second layer is the matrix-core
+    kernels' and the hidden width allows a small-K weight gradient."""
+    H = w1.shape[0]
+    return (_smallk_with_grad(x, w1) and b1 is not None and H % 4 == 0 and H * w1.shape[1] <= 2048 and w2.dim() == 2 and w2.shape[1] == H
+            and w2.dtype == torch.float32 and w2.stride(1) == 1 and w2.stride(0) % 4 == 0 and w2.data_ptr() % 16 == 0 and w2.shape[0] % 4 == 0
+            and (b2 is None or b2.data_ptr() % 16 == 0))
+
+
+def mlp_smallk_gelu(x, w1, b1, w2, b2):
+    return _MlpSmallKGelu.apply(x, w1, b1, w2, b2)
+
+
 def mlp_gelu(x, w1, b1, w2, b2=None):
     """fc2(GELU(fc1(x) + b1)) (+ b2); both GEMMs and the activation on the Linear kernels (split-bf16 for frozen / managed weights)."""
     if not torch.is_grad_enabled() or not (x.requires_grad or w1.requires_grad or w2.requires_grad or b1.requires_grad
@@ -1340,6 +1396,30 @@ def nll_mean(logp, target):
             and target.is_cuda and target.numel() == logp.shape[0]):
         return _NllMean.apply(logp, target.contiguous().view(-1))
     return F.nll_loss(logp, target)
+
+
+class _NoiseLoss(Function):
+    """(positive + negative, score) of the pre-task noise supervision in two launches forward, one backward (upp_noise_loss_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, pred, noise_vector, pn):
+        pred, noise_vector = pred.contiguous(), noise_vector.contiguous()
+        loss, score = ops.noise_loss_fwd(pred, noise_vector, pn)
+        ctx.save_for_backward(pred, noise_vector)
+        ctx.pn = pn
+        ctx.mark_non_differentiable(score)
+        return loss.view(()), score
+
+    @staticmethod
+    def backward(ctx, g, _g_score):
+        pred, nv = ctx.saved_tensors
+        return ops.noise_loss_bwd(g.reshape(1).contiguous(), pred, nv, ctx.pn), None, None
+
+
+def noise_loss(pred, noise_vector, point_num):
+    """mean |pred_noise - noise_vector|^2 + mean |pred_pure|^2 and score = |pred| (reference models/Point_MAE_pretask_dev.py:685-692, a
+    3-channel rectify prompter): pred (B,P,3) = [point_num shape points | noise points].  -> (loss, score (B,P))."""
+    return _NoiseLoss.apply(pred, noise_vector, int(point_num))
 
 
 # ------------------------------------------------------------------ classification tail

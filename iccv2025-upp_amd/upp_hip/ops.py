@@ -172,6 +172,19 @@ def group_bwd(grad_out, idx, N, need_xyz=True, need_center=True):
     return gx, gc
 
 
+def fps_gather_bwd(grad_centers, idx, N):
+    """Gradient of the FPS centre gather: grad_centers (B,M,3), idx (B,M) int32 -> (B,N,3) (upp_fps_gather_bwd: one launch)."""
+    _need(grad_centers, "grad_centers", torch.float32, 3, 3)
+    _need(idx, "idx", torch.int32, 2)
+    B, M = idx.shape
+    if tuple(grad_centers.shape) != (B, M, 3):
+        raise RuntimeError("fps_gather_bwd: grad_centers must be (B, M, 3) for idx (B, M)")
+    gx = torch.empty((B, int(N), 3), dtype=torch.float32, device=grad_centers.device)
+    if B:
+        _call(grad_centers.device, "upp_fps_gather_bwd", _abi.ptr(grad_centers), _abi.ptr(idx), _abi.ptr(gx), B, int(N), M)
+    return gx
+
+
 # ------------------------------------------------------------------ Chamfer
 def chamfer_fwd(xyz1, xyz2):
     _need(xyz1, "xyz1", torch.float32, 3, 3)
@@ -563,6 +576,28 @@ def nll_mean_bwd(g_loss, target, R, C):
     return g_logp
 
 
+def noise_loss_fwd(pred, noise_vector, pn, want_score=True):
+    """-> (loss (1,), score (B,P) or None) of the pre-task noise supervision (upp_noise_loss_fwd): pred (B,P,3), noise_vector (B,P-pn,3)."""
+    _need(pred, "pred", torch.float32, 3, 3)
+    _need(noise_vector, "noise_vector", torch.float32, 3, 3)
+    B, P, _ = pred.shape
+    if tuple(noise_vector.shape) != (B, P - int(pn), 3):
+        raise RuntimeError("noise_loss_fwd: noise_vector must be (B, P - pn, 3)")
+    part = torch.empty(int(_abi.load().upp_noise_loss_part_floats(B, P)), dtype=torch.float32, device=pred.device)
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    score = torch.empty((B, P), dtype=torch.float32, device=pred.device) if want_score else None
+    _call(pred.device, "upp_noise_loss_fwd", _abi.ptr(pred), _abi.ptr(noise_vector), B, P, int(pn), _abi.ptr(part), _abi.ptr(loss), _abi.ptr(score))
+    return loss, score
+
+
+def noise_loss_bwd(g_loss, pred, noise_vector, pn):
+    _need(g_loss, "g_loss", torch.float32)
+    B, P, _ = pred.shape
+    g_pred = torch.empty_like(pred)
+    _call(pred.device, "upp_noise_loss_bwd", _abi.ptr(g_loss), _abi.ptr(pred), _abi.ptr(noise_vector), B, P, int(pn), _abi.ptr(g_pred))
+    return g_pred
+
+
 def rectify_select(feature, w0, b0, w1, b1, pts, keep, u=None, p=0.0, factor=1.0, nudge=0.2, want_pred=False, want_order=False, want_score=False):
     """Tail of the denoising prompter in two launches (upp_rectify_select): pred = score head(feature) * factor, moved = pts + nudge * pred,
     the `keep` least suspicious points of every cloud in descending-score order.  -> out (B,keep,3) [, pred (B,N,3)] [, order (B,N) int64] [, score (B,N)]."""
@@ -674,6 +709,29 @@ def linear_smallk_wgrad(g, x, chunks=None):
     part = torch.empty((chunks, N, K), dtype=torch.float32, device=g.device)
     _call(g.device, "upp_linear_smallk_wgrad_f32", _abi.ptr(g), g.stride(0), _abi.ptr(x), x.stride(0), _abi.ptr(part), M, N, K, chunks)
     return part
+
+
+def linear_smallk_gelu_d(x, w, bias):
+    """-> (GELU(x . w^T + bias), GELU'(x . w^T + bias)) for K <= 64, N <= 256 in one pass (upp_linear_smallk_gelu_d_f32)."""
+    for t_, n_ in ((x, "x"), (w, "w")):
+        if not (isinstance(t_, torch.Tensor) and t_.is_cuda and t_.dtype == torch.float32):
+            raise RuntimeError(f"{n_} must be a f32 HIP (cuda) tensor; upp_hip has no CPU path")
+    _same_device(x, w)
+    K, N = x.shape[-1], w.shape[0]
+    if w.dim() != 2 or w.shape[1] != K or K > 64 or N > 256:
+        raise RuntimeError(f"linear_smallk_gelu_d: x (...,{K}) against w {tuple(w.shape)} (K <= 64, N <= 256)")
+    if bias is not None:
+        _need(bias, "bias", torch.float32, 1, N)
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+    d = torch.empty_like(out)
+    _call(x.device, "upp_linear_smallk_gelu_d_f32", _abi.ptr(x2), x2.stride(0), _abi.ptr(w), w.stride(0), _abi.ptr(bias), _abi.ptr(out), N,
+          _abi.ptr(d), N, x2.shape[0], N, K)
+    return out, d
 
 
 def transpose(w, out=None):

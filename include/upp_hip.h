@@ -127,6 +127,10 @@ int upp_group_fwd(const float *xyz, const float *center, const int64_t *idx, flo
                   int B, int N, int G, int K, void *stream);
 int upp_group_bwd(const float *grad_out, const int64_t *idx, float *grad_xyz, float *grad_center,
                   int B, int N, int G, int K, void *stream);
+/* upp_fps_gather_bwd (round 6): the backward of the centre gather that upp_fps fuses (reference utils/misc.py:19 gather_operation under
+ * autograd): g_xyz (B,N,3) = zeros with g_centers[b][j] added at row idx[b][j] (int32, as upp_fps writes it) -- zero-fill, index
+ * conversion and scatter in ONE launch, one workgroup per cloud. */
+int upp_fps_gather_bwd(const float *g_centers, const int32_t *idx, float *g_xyz, int B, int N, int M, void *stream);
 
 /* ---- Chamfer distance ----------------------------------------------------------
  * Replaces chamfer.forward / chamfer.backward (reference
@@ -412,6 +416,16 @@ int upp_logsoftmax_rows_bwd(const float *g_logp, const float *logp, long long R,
 long long upp_nll_mean_part_floats(long long R);
 int upp_nll_mean_fwd(const float *logp, const int64_t *target, long long R, int C, float *part, float *out, void *stream);
 int upp_nll_mean_bwd(const float *g_loss, const int64_t *target, long long R, int C, float *g_logp, void *stream);
+/* ---- noise-vector supervision of the pre-task recipe (round 6) -------------------------------------------------------
+ * Replaces reference models/Point_MAE_pretask_dev.py:685-692 for a 3-channel rectify prompter:
+ *   loss = mean_{b, noise i} |pred_noise - noise_vector|^2 + mean_{b, shape i} |pred_pure|^2,   score = |pred|
+ * (`torch.mean(torch.norm(x, 2, dim=-1, keepdim=True) ** 2)` twice and `torch.norm(pred, dim=-1)`: ~30 element-wise launches with the
+ * zero guards of norm's backward) where pred (B,P,3) holds pn shape points then P - pn noise points per cloud and noise_vector is
+ * (B, P - pn, 3).  upp_noise_loss_fwd: loss[0], score (B,P) or NULL, `part` upp_noise_loss_part_floats(B, P) floats of scratch; two launches,
+ * fixed-order sums.  upp_noise_loss_bwd: g_pred (B,P,3) = g_loss[0] * d loss / d pred (g_loss a device scalar), every element written. */
+long long upp_noise_loss_part_floats(int B, int P);
+int upp_noise_loss_fwd(const float *pred, const float *noise_vector, int B, int P, int pn, float *part, float *loss, float *score, void *stream);
+int upp_noise_loss_bwd(const float *g_loss, const float *pred, const float *noise_vector, int B, int P, int pn, float *g_pred, void *stream);
 /*   upp_bn_relu_drop_fwd / bwd : BatchNorm1d + ReLU + Dropout of a (R, C) matrix with few rows (the Linear outputs of
  *                      cls_head_finetune, R = batch size), one launch each way.  training != 0: batch statistics (mean / rstd
  *                      outputs, running statistics updated with momentum / unbiased variance when non-NULL); else running
@@ -645,6 +659,10 @@ int upp_linear_sb_group_bias_f32(const float *A, long long lda, const void *plan
  * weight (frozen ones are transposed once and cached by the caller). */
 int upp_linear_smallk_f32(const float *x, long long ldx, const float *W, long long ldw, const float *bias, float *y, long long ldy,
                           int M, int N, int K, int act, void *stream);
+/* upp_linear_smallk_gelu_d_f32 (round 6): y = GELU(x . W^T + bias) and d = GELU'(x . W^T + bias) in the same pass (erf form, as
+ * upp_linear_f32's epilogue 3): the first layer of a TRAINABLE position MLP keeps the derivative for its backward. */
+int upp_linear_smallk_gelu_d_f32(const float *x, long long ldx, const float *W, long long ldw, const float *bias, float *y, long long ldy,
+                                 float *d, long long ldd, int M, int N, int K, void *stream);
 /* upp_linear_smallk_wgrad_f32: partials (chunks, N, K)[c][n][k] = sum over the rows m of chunk c of G[m][n] * X[m][k] -- the weight gradient of
  * a small Linear (N K <= 2048, any alignment) over many rows, rows added in ascending order; the caller sums the chunks (upp_batched_sum).
  * (The rectify prompter's point-wise layers in the pre-task recipe: 32 x 27, 64 x 3, ... over 34,432 rows.) */

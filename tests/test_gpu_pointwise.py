@@ -643,3 +643,71 @@ def test_linear_with_an_output_width_that_is_no_multiple_of_4_needs_no_padded_we
     close((buf - 0.125).view(N, K), gw_t, rtol=2e-5, atol_scale=5e-6)
     names = [e.key for e in prof.key_averages()]
     assert not any(("FillFunctor" in n_ or "reduce_kernel" in n_ or "direct_copy" in n_) for n_ in names), names
+
+
+@pytest.mark.parametrize("B,P,pn", [(32, 1076, 1024), (3, 40, 7), (1, 2, 1)])
+def test_noise_supervision_loss_in_two_launches_matches_the_torch_formula(B, P, pn):
+    """Round 6: HF.noise_loss (upp_noise_loss_fwd / _bwd) against the reference's formula for the pre-task noise supervision
+    (models/Point_MAE_pretask_dev.py:685-692): mean(norm(pred_noise - nv) ** 2) + mean(norm(pred_pure) ** 2), score = norm(pred),
+    and the gradient w.r.t. pred -- including points that sit exactly on their target (norm's backward is guarded there; 2 (p - t) is 0)."""
+    g = torch.Generator(device='cuda').manual_seed(B + P)
+    pred0 = torch.randn(B, P, 3, device='cuda', generator=g) * 0.3
+    nv = torch.randn(B, P - pn, 3, device='cuda', generator=g) * 0.2
+    pred0[0, 0] = 0.0                                                    # a shape point with zero offset
+    pred0[0, pn] = nv[0, 0]                                              # a noise point exactly on its target
+    pred = pred0.clone().requires_grad_(True)
+    loss, score = HF.noise_loss(pred, nv, pn)
+    (loss * 1.7).backward()
+    pt = pred0.clone().requires_grad_(True)
+    positive = torch.mean(torch.norm(pt[:, pn:] - nv, 2, dim=-1, keepdim=True) ** 2)
+    negative = torch.mean(torch.norm(pt[:, :pn], 2, dim=-1, keepdim=True) ** 2)
+    ((positive + negative) * 1.7).backward()
+    np.testing.assert_allclose(loss.item(), (positive + negative).item(), rtol=3e-6)
+    close(score, torch.norm(pred0, p=2, dim=-1), rtol=1e-6, atol_scale=1e-7)
+    close(pred.grad, pt.grad, rtol=1e-5, atol_scale=1e-6)
+    assert not score.requires_grad
+    l2, _ = HF.noise_loss(pred0.clone().requires_grad_(True), nv, pn)
+    assert torch.equal(l2, loss.detach())                                 # deterministic
+
+
+@pytest.mark.parametrize("B,N,M", [(32, 1096, 32), (4, 64, 64), (2, 5, 3)])
+def test_fps_centres_gradient_in_one_launch(B, N, M):
+    """Round 6: the backward of HF.fps_gather (upp_fps_gather_bwd): zero-fill + scatter of the centre gradients by the int32 FPS indices in one
+    launch, against torch's index_add on the same indices."""
+    g = torch.Generator(device='cuda').manual_seed(B * N + M)
+    xyz = torch.randn(B, N, 3, device='cuda', generator=g).requires_grad_(True)
+    centers, idx = HF.fps_gather(xyz, M)
+    w = torch.randn(B, M, 3, device='cuda', generator=g)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        (gx,) = torch.autograd.grad((centers * w).sum(), xyz)
+        torch.cuda.synchronize()
+    want = torch.zeros(B, N, 3, device='cuda')
+    want.scatter_add_(1, idx.long().unsqueeze(-1).expand(-1, -1, 3), w)
+    assert torch.equal(gx, want)
+    names = [e.key for e in prof.key_averages()]
+    assert sum("fps_gather_bwd_kernel" in n_ for n_ in names) == 1 and not any("FillFunctor" in n_ or "direct_copy" in n_ for n_ in names), names
+
+
+@pytest.mark.parametrize("K,H,D,x_grad", [(3, 128, 384, False), (3, 64, 384, True), (12, 32, 64, True)])
+def test_position_mlp_with_gradients_keeps_gelu_in_the_kernels(K, H, D, x_grad):
+    """Round 6: Linear(K, H) - GELU - Linear(H, D) with trainable weights (the position MLPs of stage 2 and the pre-task recipe, reference
+    models/Point_MAE_pretask_dev.py:395-399) through upp_layers.mlp2: GELU and GELU' come out of the small-K launch, the second layer's
+    data gradient is multiplied by GELU' in its epilogue -- values and every gradient against torch, and no torch gelu kernels."""
+    torch.manual_seed(K + H)
+    seq = torch.nn.Sequential(torch.nn.Linear(K, H), torch.nn.GELU(), torch.nn.Linear(H, D)).cuda()
+    x0 = torch.randn(32, 33, K, device='cuda')
+    w = torch.randn(32, 33, D, device='cuda')
+    x = x0.clone().requires_grad_(x_grad)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        y = upp_layers.mlp2(seq, x)
+        leaves = ([x] if x_grad else []) + list(seq.parameters())
+        got = torch.autograd.grad((y * w).sum(), leaves)
+        torch.cuda.synchronize()
+    xt = x0.clone().requires_grad_(x_grad)
+    yt = seq(xt)
+    want = torch.autograd.grad((yt * w).sum(), ([xt] if x_grad else []) + list(seq.parameters()))
+    close(y, yt, rtol=1e-5, atol_scale=2e-6)
+    for a, b in zip(got, want):
+        close(a, b, rtol=2e-5, atol_scale=5e-6)
+    names = [e.key for e in prof.key_averages()]
+    assert not any("gelu" in n_.lower() and "at::native" in n_ for n_ in names), names
