@@ -1121,10 +1121,17 @@ class RectifyPrompter(nn.Module):
             u = UNIFORMS.take((x.shape[0] * x.shape[1], 64), x.device) if live else None
             return ops.rectify_select(feature.contiguous(), l0.weight, l0.bias, l1.weight, l1.bias, x.contiguous(), keep, u,
                                       drop.p if live else 0.0, self.score_factor, nudge)
-        pred = HF.linear(drop(_relu_linear(feature, l0)), l1.weight, l1.bias) * self.score_factor
-        order = trace_idx('rectify.order', HF.argsort_rows(torch.norm(pred, p=2, dim=-1), descending=True))
-        moved = x + pred * nudge
-        return torch.gather(moved, 1, order[:, -keep:, None].expand(-1, -1, 3))
+        pred = HF.linear(drop(_relu_linear(feature, l0)), l1.weight, l1.bias)
+        if self.score_factor != 1.0:                   # (1.0 in every shipped configuration: a multiplication and its backward saved)
+            pred = pred * self.score_factor
+        with torch.no_grad():
+            score = torch.norm(pred, p=2, dim=-1)
+        order = trace_idx('rectify.order', HF.argsort_rows(score, descending=True))
+        moved = x + pred * nudge           # (NOT torch.add(x, pred, alpha=nudge): the device fuses that into one rounding, the host does not, and the
+                                           #  ill-conditioned interpolation weights downstream turn an ulp of the coordinates into 2.5e-4 of mask_token's gradient)
+        # (HF.gather_rows: forward and a sort-free, deterministic backward on the interpolation kernels instead of torch's gather +
+        #  zero-fill + scatter_add)
+        return HF.gather_rows(moved, order[:, -keep:].contiguous())
 
     def features(self, x, center1, center1_feature):
         """-> (per-point feature (B,N,32) in front of the score head, shape feature (B, num_group * top_center_dim))."""

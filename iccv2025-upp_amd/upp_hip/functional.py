@@ -48,10 +48,13 @@ class _FpsGather(Function):
         ctx.save_for_backward(idx)
         ctx.N = xyz.shape[1]
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)          # (no zero tensor for the index output's "gradient": a fill launch per backward)
         return centers, idx
 
     @staticmethod
     def backward(ctx, grad_centers, _grad_idx):
+        if grad_centers is None:
+            return None, None
         (idx,) = ctx.saved_tensors
         return ops.fps_gather_bwd(grad_centers.contiguous(), idx, ctx.N), None        # (one launch: zero-fill + int32 indices + scatter)
 
@@ -67,10 +70,13 @@ class _KnnGroup(Function):
         ctx.save_for_backward(idx)
         ctx.N = xyz.shape[1]
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
         return neigh, idx
 
     @staticmethod
     def backward(ctx, grad_neigh, _grad_idx):
+        if grad_neigh is None:
+            return None, None, None
         (idx,) = ctx.saved_tensors
         gx, gc = ops.group_bwd(grad_neigh.contiguous(), idx, ctx.N,
                                need_xyz=ctx.needs_input_grad[0], need_center=ctx.needs_input_grad[1])
@@ -1408,10 +1414,13 @@ class _NoiseLoss(Function):
         ctx.save_for_backward(pred, noise_vector)
         ctx.pn = pn
         ctx.mark_non_differentiable(score)
+        ctx.set_materialize_grads(False)
         return loss.view(()), score
 
     @staticmethod
     def backward(ctx, g, _g_score):
+        if g is None:
+            return None, None, None
         pred, nv = ctx.saved_tensors
         return ops.noise_loss_bwd(g.reshape(1).contiguous(), pred, nv, ctx.pn), None, None
 
@@ -1453,10 +1462,13 @@ class _CrossEntropyAcc(Function):
         ctx.save_for_backward(dlogits)
         loss, acc = out2[0], out2[1]
         ctx.mark_non_differentiable(acc)
+        ctx.set_materialize_grads(False)          # (no zero scalar for the accuracy's "gradient")
         return loss, acc
 
     @staticmethod
     def backward(ctx, g_loss, _g_acc):
+        if g_loss is None:
+            return None, None
         (dlogits,) = ctx.saved_tensors
         return dlogits * g_loss, None
 
