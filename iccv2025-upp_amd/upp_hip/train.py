@@ -256,6 +256,8 @@ class TrainStep:
             HF.refresh_caches(model)
 
     # -- the two halves of a step ------------------------------------------------------------
+    _seed = None
+
     def _forward_backward(self, pts=None, labels=None, kw=None):
         pts = self.pts if pts is None else pts
         labels = self.labels if labels is None else labels
@@ -276,7 +278,10 @@ class TrainStep:
                 loss, acc = self.model.get_loss_acc(logits, labels)
             # partial-sum reductions of parameter gradients: one launch after the pass, straight into the (zeroed) flat buffer
             with HF.deferred_sums(self._grad_targets) as scope:
-                loss.backward()
+                # (loss.backward() builds its seed with a fill launch; a persistent one is handed over instead)
+                if self._seed is None or self._seed.device != loss.device or self._seed.dtype != loss.dtype:
+                    self._seed = torch.ones((), dtype=loss.dtype, device=loss.device)
+                torch.autograd.backward(loss, grad_tensors=self._seed)
         finally:
             HF.TRANSPOSED.managed, HF.ops.PLANES.managed = was, was_p
         got = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None and p.data_ptr() not in scope.routed]
@@ -288,9 +293,10 @@ class TrainStep:
             torch._foreach_add_([v for v, _ in both], [g for _, g in both])
         for p, v in zip(self.trainable, self.flat.views):
             p.grad = v
-        self.flat.scalars[0].copy_(loss.detach())
-        self.flat.scalars[1].copy_(acc.detach())
-        self.loss.copy_(loss.detach())
+        # loss and metric into the flat buffer's scalar slots and the report slot: ONE launch (three runtime copies of 4 bytes were three
+        # launches on the back-end's chain)
+        l0, a0 = loss.detach().reshape(1), acc.detach().reshape(1).to(torch.float32)
+        _copy_many([self.flat.scalars[0:1], self.flat.scalars[1:2], self.loss.reshape(1)], [l0, a0, l0])
 
     def _update(self):
         if isinstance(self.opt, FlatAdamW):

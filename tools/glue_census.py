@@ -23,7 +23,8 @@ def main():
     torch.cuda.synchronize()
     for name, fn in (("front", lambda: ts._front(0)), ("back", lambda: ts._back(0))):
         with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA],
-                                    record_shapes=True, with_stack=True) as prof:
+                                    record_shapes=True, with_stack=True,
+                                    experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:      # (without it e.stack stays empty)
             fn()
             torch.cuda.synchronize()
         evs = prof.events()
@@ -36,11 +37,14 @@ def main():
             # leaf operators only (a parent aten op lists its children's kernels too)
             if any(c.kernels for c in e.cpu_children if c.name.startswith("aten::")):
                 continue
-            site = "?"
-            for fr in e.stack:
-                if "iccv2025-upp_amd" in fr or "/bench.py" in fr:
-                    site = fr.replace(ROOT + "/", "").strip()
-                    break
+            # (frames come as paths relative to their sys.path entry, innermost first: "models/upp_layers.py(1093): select")
+            mine = [fr for fr in (e.stack or []) if fr.startswith(("models/", "upp_hip/", "utils/", "extensions/", "bench.py"))]
+            site = " < ".join(fr.split(": ")[0] + ":" + fr.split(": ")[-1] for fr in mine[:2]) if mine else "?"
+            if not mine:
+                p_ = e.cpu_parent
+                while p_ is not None and "Backward" not in p_.name:
+                    p_ = p_.cpu_parent
+                site = p_.name.replace("autograd::engine::evaluate_function: ", "") if p_ is not None else "?"
             key = (e.name, str(e.input_shapes)[:90], site[:110])
             t = sum(k.duration for k in ks)
             a = agg.setdefault(key, [0, 0.0, ks[0].name[:50]])
