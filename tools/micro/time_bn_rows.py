@@ -1,5 +1,6 @@
 """BatchNorm-over-rows kernels at the per-point heads' shapes: microseconds and bytes / s per launch (HIP events, many launches).
-   python tools/micro/time_bn_rows.py [launches]"""
+   python tools/micro/time_bn_rows.py [launches] [R,C ...]      (shapes: default the heads' list; one shape under rocprofv3 --stats
+   gives the per-kernel split)"""
 import os
 import sys
 
@@ -26,7 +27,9 @@ def timed(fn, n):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     dev = "cuda"
-    for R, C in ((65536, 1536), (65536, 1024), (65536, 512), (65536, 256), (16384, 512), (4096, 384), (2048, 512)):
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]] or [(65536, 1536), (65536, 1024), (65536, 512), (65536, 256), (65536, 128),
+                                                                            (16384, 512), (4096, 384), (2048, 512)]
+    for R, C in shapes:
         x = torch.randn(R, C, device=dev)
         g = torch.randn(R, C, device=dev)
         ga, be = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
