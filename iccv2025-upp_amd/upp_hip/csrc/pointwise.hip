@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
     }
 }
 
-// Tall matrices (the 65,536-row activations of the per-point heads), C % 256 == 0: a wave owns 256 consecutive columns -- one 1 KB
+// Tall matrices (the 65,536-row activations of the per-point heads), C % 256 == 0 (or C = 64 / 128: `rpw` = 4 / 2 whole rows per
+// wave-load; the flat kernel ran the head's 128-channel layer at 2 TB/s): a wave owns 256 consecutive columns -- one 1 KB
 // row segment per load instruction -- and walks down the rows with the column parameters in registers (the flat kernels above spend
 // 16-24 dword parameter loads per 16 bytes of payload and read at a third of the HBM rate).  Block = 4 waves on 4 interleaved rows
 // of the same 256 columns, kTallRows rows per block, 8 row loads in flight per lane.  Same expressions: same bits as the flat kernels.
@@ -321,32 +322,33 @@ template <bool NT>
 __global__ __launch_bounds__(256) void bn_rows_apply_tall_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                                  const float *__restrict__ rstd, const float *__restrict__ gamma,
                                                                  const float *__restrict__ beta, int relu, float *__restrict__ y, int R,
-                                                                 int C, BnDrop dr) {
+                                                                 int C, int rpw, BnDrop dr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = blockIdx.y * 256 + lane * 4;
+    const int c0 = C >= 256 ? blockIdx.y * 256 + lane * 4 : (lane * 4) % C;          // C = 64 / 128: a wave-load covers `rpw` whole rows
+    const int sub = C >= 256 ? 0 : (lane * 4) / C;
     const float4 mu = *reinterpret_cast<const float4 *>(mean + c0), rs = *reinterpret_cast<const float4 *>(rstd + c0);
     const float4 ga = gamma ? *reinterpret_cast<const float4 *>(gamma + c0) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     const float4 be = beta ? *reinterpret_cast<const float4 *>(beta + c0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const int r0 = blockIdx.x * kTallRows + wave;
+    const int r0 = (blockIdx.x * kTallRows + wave) * rpw + sub, rs4 = 4 * rpw;
     const unsigned sd = drop_seed(dr);
     constexpr int U = kTallRows / 4;
     float4 v[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-        const size_t o = (size_t)min(r0 + 4 * j, R - 1) * C + c0;
+        const size_t o = (size_t)min(r0 + rs4 * j, R - 1) * C + c0;
         v[j] = NT ? nt_load4(x + o) : *reinterpret_cast<const float4 *>(x + o);
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-        if (r0 + 4 * j >= R) break;
+        if (r0 + rs4 * j >= R) continue;
         float o0 = ((v[j].x - mu.x) * rs.x) * ga.x + be.x, o1 = ((v[j].y - mu.y) * rs.y) * ga.y + be.y;
         float o2 = ((v[j].z - mu.z) * rs.z) * ga.z + be.z, o3 = ((v[j].w - mu.w) * rs.w) * ga.w + be.w;
         if (relu) { o0 = fmaxf(o0, 0.0f); o1 = fmaxf(o1, 0.0f); o2 = fmaxf(o2, 0.0f); o3 = fmaxf(o3, 0.0f); }
         if (dr.thresh) {
-            const long long e0 = (long long)(r0 + 4 * j) * C + c0;
+            const long long e0 = (long long)(r0 + rs4 * j) * C + c0;
             o0 *= drop_factor(dr, sd, e0); o1 *= drop_factor(dr, sd, e0 + 1); o2 *= drop_factor(dr, sd, e0 + 2); o3 *= drop_factor(dr, sd, e0 + 3);
         }
-        float *dst = y + (size_t)(r0 + 4 * j) * C + c0;
+        float *dst = y + (size_t)(r0 + rs4 * j) * C + c0;
         if (NT) nt_store4(dst, o0, o1, o2, o3); else *reinterpret_cast<float4 *>(dst) = make_float4(o0, o1, o2, o3);
     }
 }
@@ -356,16 +358,17 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_tall_kernel(const float
                                                                      const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                      const float *__restrict__ g_gamma, const float *__restrict__ g_beta,
-                                                                     int relu, float inv_rows, float *__restrict__ g_x, int R, int C, BnDrop dr) {
+                                                                     int relu, float inv_rows, float *__restrict__ g_x, int R, int C, int rpw, BnDrop dr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = blockIdx.y * 256 + lane * 4;
+    const int c0 = C >= 256 ? blockIdx.y * 256 + lane * 4 : (lane * 4) % C;
+    const int sub = C >= 256 ? 0 : (lane * 4) / C;
     const float4 mu4 = *reinterpret_cast<const float4 *>(mean + c0), rs4 = *reinterpret_cast<const float4 *>(rstd + c0);
     const float4 ga4 = gamma ? *reinterpret_cast<const float4 *>(gamma + c0) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     const float4 be4 = beta ? *reinterpret_cast<const float4 *>(beta + c0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const float4 gg4 = *reinterpret_cast<const float4 *>(g_gamma + c0), gb4 = *reinterpret_cast<const float4 *>(g_beta + c0);
     const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w}, ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
     const float be[4] = {be4.x, be4.y, be4.z, be4.w}, gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, gb[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
-    const int r0 = blockIdx.x * kTallRows + wave;
+    const int r0 = (blockIdx.x * kTallRows + wave) * rpw + sub, rstep = 4 * rpw;
     const unsigned sd = drop_seed(dr);
     constexpr int U = kTallRows / 8;                           // two streams: 2 x 4 row loads in flight per lane, twice
 #pragma unroll
@@ -373,14 +376,14 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_tall_kernel(const float
         float4 xv[U], gv[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const size_t o = (size_t)min(r0 + 4 * (h * U + j), R - 1) * C + c0;
+            const size_t o = (size_t)min(r0 + rstep * (h * U + j), R - 1) * C + c0;
             xv[j] = NT ? nt_load4(x + o) : *reinterpret_cast<const float4 *>(x + o);
             gv[j] = NT ? nt_load4(g + o) : *reinterpret_cast<const float4 *>(g + o);
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int r = r0 + 4 * (h * U + j);
-            if (r >= R) break;
+            const int r = r0 + rstep * (h * U + j);
+            if (r >= R) continue;
             const float xs[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
             float gs[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
             if (dr.thresh) {
@@ -832,6 +835,8 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float *__restrict__ x
 
 int bn_per(int R) { int per = (R + 255) / 256; return per < 8 ? 8 : per; }
 int pow2_at_least(int c) { int p = 4; while (p < c && p < 256) p <<= 1; return p; }
+// the row-walking apply kernels: whole 1 KB wave-loads -- C a multiple of 256, or 64 / 128 (4 / 2 whole rows per load)
+bool bn_tall(int R, int C) { return R >= 4096 && (C % 256 == 0 || C == 128 || C == 64); }
 
 
 // Backward of the interpolation w.r.t. the GEOMETRY (the queries xyz1 and the sources xyz2; stage 2 of the recipe and the pre-task
@@ -1009,10 +1014,11 @@ static int bn_rows_fwd_impl(const float *x, const float *gamma, const float *bet
     }
     upp_bn_finalize_launch(part, slabs, per, R, C, training, momentum, eps, running_mean, running_var, mean, rstd, st);
     const long long total = (long long)R * C;
-    if (C % 256 == 0 && R >= 4096) {
-        const dim3 grid((unsigned)((R + kTallRows - 1) / kTallRows), (unsigned)(C / 256));
-        if (total >= kStreamElems) hipLaunchKernelGGL(bn_rows_apply_tall_kernel<true>, grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y, R, C, dr);
-        else hipLaunchKernelGGL(bn_rows_apply_tall_kernel<false>, grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y, R, C, dr);
+    if (bn_tall(R, C)) {
+        const int rpw = C >= 256 ? 1 : 256 / C;
+        const dim3 grid((unsigned)((R + kTallRows * rpw - 1) / (kTallRows * rpw)), (unsigned)(C >= 256 ? C / 256 : 1));
+        if (total >= kStreamElems) hipLaunchKernelGGL(bn_rows_apply_tall_kernel<true>, grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y, R, C, rpw, dr);
+        else hipLaunchKernelGGL(bn_rows_apply_tall_kernel<false>, grid, dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y, R, C, rpw, dr);
         return upp_launch_status();
     }
     hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, mean, rstd, gamma, beta, relu, y,
@@ -1046,14 +1052,15 @@ static int bn_rows_bwd_impl(const float *x, const float *g, const float *mean, c
     hipLaunchKernelGGL(bn_rows_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64 * kBnWaves), 0, st, part, slabs, C, g_gamma, g_beta);
     if (g_x) {
         const long long total = (long long)R * C;
-        if (C % 256 == 0 && R >= 4096) {
-            const dim3 grid((unsigned)((R + kTallRows - 1) / kTallRows), (unsigned)(C / 256));
+        if (bn_tall(R, C)) {
+            const int rpw = C >= 256 ? 1 : 256 / C;
+            const dim3 grid((unsigned)((R + kTallRows * rpw - 1) / (kTallRows * rpw)), (unsigned)(C >= 256 ? C / 256 : 1));
             if (total >= kStreamElems)
                 hipLaunchKernelGGL(bn_rows_bwd_apply_tall_kernel<true>, grid, dim3(256), 0, st, x, g, mean, rstd, gamma, beta, g_gamma, g_beta, relu,
-                                   1.0f / (float)R, g_x, R, C, dr);
+                                   1.0f / (float)R, g_x, R, C, rpw, dr);
             else
                 hipLaunchKernelGGL(bn_rows_bwd_apply_tall_kernel<false>, grid, dim3(256), 0, st, x, g, mean, rstd, gamma, beta, g_gamma, g_beta, relu,
-                                   1.0f / (float)R, g_x, R, C, dr);
+                                   1.0f / (float)R, g_x, R, C, rpw, dr);
             return upp_launch_status();
         }
         hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, st, x, g, mean, rstd, gamma, beta,
