@@ -1,10 +1,12 @@
+"""The batched_sum jobs of one step (partial matrices per destination, bytes read):  python tools/micro/sum_jobs.py [cls|seg|pretrain|...]"""
 import os, sys, collections
 ROOT='/root/repo'
 sys.path[:0] = [ROOT, os.path.join(ROOT, "iccv2025-upp_amd")]
 import torch, bench
 from upp_hip import ops
 kind = sys.argv[1] if len(sys.argv) > 1 else "pretrain"
-ts = bench.RecipeTrainer(kind, torch.device("cuda", 0), 32, use_graph=False).ts
+dev = torch.device("cuda", 0)
+ts = (bench.Trainer(dev, 32, False, use_graph=False) if kind == "cls" else bench.RecipeTrainer(kind, dev, 32, use_graph=False)).ts
 for _ in range(2): ts._forward_backward()
 orig = ops.batched_sum
 log = []
