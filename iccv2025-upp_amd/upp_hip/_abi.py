@@ -94,6 +94,10 @@ SIGNATURES = {
     "upp_ln_adapter_bwd": (_c_i, [_c_f] * 10 + [ctypes.c_float] * 2 + [_c_f] * 2 + [_c_i] * 3 + [_c_f]),
     "upp_ln_adapter_part_floats": (ctypes.c_longlong, [_c_i, _c_i]),
     "upp_ln_adapter_bwd_fused": (_c_i, [_c_f] * 10 + [ctypes.c_float] * 2 + [_c_f, ctypes.c_float, _c_i, _c_i] + [_c_f] * 4 + [_c_i] * 5 + [_c_f]),
+    "upp_ln_adapter_bwd_factors": (_c_i, [_c_f] * 10 + [ctypes.c_float] * 2 + [_c_f, ctypes.c_float, _c_i, _c_i] + [_c_f] * 4 + [_c_i] * 5 + [_c_f]),
+    "upp_adapter_wgrad_splits": (_c_i, [_c_i]),
+    "upp_adapter_wgrad_batched": (_c_i, [ctypes.POINTER(ctypes.c_void_p)] * 7 + [ctypes.POINTER(_c_i), ctypes.POINTER(ctypes.c_float)] +
+                                  [ctypes.POINTER(ctypes.c_void_p)] + [_c_i] * 4 + [_c_f]),
     "upp_adamw_scratch_floats": (ctypes.c_longlong, []),
     "upp_colsum_partials": (_c_i, [_c_f, ctypes.c_longlong, _c_i, _c_i, _c_i, _c_f, _c_f]),
     "upp_copy_batched": (_c_i, [ctypes.POINTER(ctypes.c_void_p)] * 2 + [ctypes.POINTER(ctypes.c_longlong), _c_i, _c_f]),

@@ -529,6 +529,7 @@ struct LnAdapterBwdArgs {
     int mode, P;
     float *g_x, *g_y, *part, *ln_part;     // part: [workgroup][dW1 (32,D) | dW2 (D,32) | db1 (32) | db2 (D)];  ln_part: [workgroup][2][D]
     int B, Lin, Lout;
+    float *fac;                            // or (part == null): the FACTORS of the weight gradients per row, [ga (32) | d (32)] -- adapter_wgrad_kernel
 };
 
 template <int D, int NW>
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(64 * NW) void ln_adapter_bwd_kernel(LnAdapterBwdArg
         }
         GAs[i * LDG + jn] = ga;
         Ds[i * LDG + jn] = d;
+        if (a.fac && row0 + i < R) { a.fac[(size_t)(row0 + i) * (2 * kH) + jn] = ga; a.fac[(size_t)(row0 + i) * (2 * kH) + kH + jn] = d; }
     }
     __syncthreads();
 
@@ -751,6 +753,103 @@ __global__ __launch_bounds__(64 * NW) void ln_adapter_bwd_kernel(LnAdapterBwdArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The adapter weight gradients from their FACTORS (round 6).  ln_adapter_bwd_kernel forms dW1 / dW2 per 16-row workgroup -- 24,992
+// floats of partial results per workgroup, 130 ... 258 workgroups per block: 153 MB written and read again per headline step, 302 MB
+// per segmentation step, most of what upp_batched_sum moves.  With `fac` it writes only ga / d (64 floats per row); this kernel, ONE
+// launch for all blocks of a backward pass, then contracts over many rows per workgroup:
+//     dW1 (32, D) = sum_rows ga^T . ha,   dW2 (D, 32) = sum_rows g_out^T . d,   db1 = sum_rows ga,   db2 = scale sum_rows g_out
+// with ha = LayerNorm(xo) rebuilt from the saved rows and statistics (the expression of the forward).  Workgroup = (job, 64-column tile
+// of D, row split): 16 rows per step through two LDS buffers (the next step's rows are in flight while this one is multiplied), wave w
+// owns columns 16 w .. 16 w + 15 of the tile: two 16 x 16 tiles of each matrix on v_mfma_f32_16x16x4_f32.  part[job]: `splits` rows of
+// the per-workgroup layout above, summed by upp_batched_sum.  Rows ascending inside a split, splits ascending in the sum: deterministic.
+constexpr int kWgJobs = 16, kWgLd = 68;
+struct AdapterWgradJobs {
+    const float *xo[kWgJobs], *mean[kWgJobs], *rstd[kWgJobs], *gamma[kWgJobs], *beta[kWgJobs], *g_out[kWgJobs], *fac[kWgJobs];
+    float *part[kWgJobs];
+    int R[kWgJobs];
+    float scale[kWgJobs];
+    int splits;
+};
+template <int D>
+__global__ __launch_bounds__(256) void adapter_wgrad_kernel(AdapterWgradJobs a) {
+    __shared__ __attribute__((aligned(16))) float Zs[2][kFR * kWgLd], Hs[2][kFR * kWgLd], Fs[2][kFR * kWgLd];   // g_out, ha, [ga | d]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    int bx = blockIdx.x;
+    const int per_job = (D / 64) * a.splits;
+    const int j = bx / per_job;
+    bx -= j * per_job;
+    const int t = bx / a.splits, sp = bx - t * a.splits;
+    const int R = a.R[j];
+    const int per = ((R + a.splits - 1) / a.splits + kFR - 1) / kFR * kFR;
+    const int r_lo = sp * per, r_hi = min(R, r_lo + per);
+    const int c0 = 64 * t;
+    const float *xo = a.xo[j], *go = a.g_out[j], *fac = a.fac[j], *mean = a.mean[j], *rstd = a.rstd[j];
+    const int lr = tid >> 4, c4 = (tid & 15) * 4;          // this thread's 16-byte piece of a 16 x 64 tile
+    const float4 gm = *reinterpret_cast<const float4 *>(a.gamma[j] + c0 + c4), bt = *reinterpret_cast<const float4 *>(a.beta[j] + c0 + c4);
+    float4 vz, vx, vf;
+    float mu = 0.0f, rs = 0.0f;
+    bool live = false;
+    auto load = [&](int row0) {
+        const int row = min(row0 + lr, R - 1);
+        live = row0 + lr < r_hi;
+        vz = *reinterpret_cast<const float4 *>(go + (size_t)row * D + c0 + c4);
+        vx = *reinterpret_cast<const float4 *>(xo + (size_t)row * D + c0 + c4);
+        vf = *reinterpret_cast<const float4 *>(fac + (size_t)row * (2 * kH) + c4);
+        mu = mean[row]; rs = rstd[row];
+    };
+    auto store = [&](int buf) {
+        const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 h;
+        h.x = __builtin_fmaf((vx.x - mu) * rs, gm.x, bt.x); h.y = __builtin_fmaf((vx.y - mu) * rs, gm.y, bt.y);
+        h.z = __builtin_fmaf((vx.z - mu) * rs, gm.z, bt.z); h.w = __builtin_fmaf((vx.w - mu) * rs, gm.w, bt.w);
+        *reinterpret_cast<float4 *>(&Zs[buf][lr * kWgLd + c4]) = live ? vz : z0;
+        *reinterpret_cast<float4 *>(&Hs[buf][lr * kWgLd + c4]) = live ? h : z0;
+        *reinterpret_cast<float4 *>(&Fs[buf][lr * kWgLd + c4]) = live ? vf : z0;
+    };
+    f32x4v w1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, w2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float bsum = 0.0f;                                      // tid < 64: db2 of column c0 + tid; 64 <= tid < 96 (tile 0): db1 of unit tid - 64
+    if (r_lo < r_hi) {
+        load(r_lo);
+        store(0);
+        __syncthreads();
+        int buf = 0;
+        for (int row0 = r_lo; row0 < r_hi; row0 += kFR, buf ^= 1) {
+            const bool more = row0 + kFR < r_hi;
+            if (more) load(row0 + kFR);
+            const float *Z = Zs[buf], *Hh = Hs[buf], *F = Fs[buf];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int ro = (4 * s4 + g) * kWgLd;
+                const float zc = Z[ro + 16 * wave + r];         // g_out[row][n]   (A of dW2, rows = n)
+                const float hc = Hh[ro + 16 * wave + r];        // ha[row][n]      (B of dW1)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    const float gc = F[ro + 16 * tj + r];       // ga[row][j]      (A of dW1, rows = j)
+                    const float dc = F[ro + kH + 16 * tj + r];  // d[row][j]       (B of dW2)
+                    w2[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc, dc, w2[tj], 0, 0, 0);
+                    w1[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc, hc, w1[tj], 0, 0, 0);
+                }
+            }
+            if (tid < 64) { for (int i = 0; i < kFR; ++i) bsum += Z[i * kWgLd + tid]; }
+            else if (tid < 64 + kH && t == 0) { for (int i = 0; i < kFR; ++i) bsum += F[i * kWgLd + tid - 64]; }
+            if (more) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float *out = a.part[j] + (size_t)sp * ((size_t)2 * kH * D + kH + D);
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            out[(size_t)(16 * tj + 4 * g + reg) * D + c0 + 16 * wave + r] = w1[tj][reg];                          // dW1[j][n]
+            out[(size_t)kH * D + (size_t)(c0 + 16 * wave + 4 * g + reg) * kH + 16 * tj + r] = w2[tj][reg];        // dW2[n][j]
+        }
+    if (tid < 64) out[(size_t)2 * kH * D + kH + c0 + tid] = bsum * a.scale[j];
+    else if (tid < 64 + kH && t == 0) out[(size_t)2 * kH * D + tid - 64] = bsum;
+}
+
 template <typename K>
 int raise_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) {
@@ -826,10 +925,10 @@ extern "C" long long upp_ln_adapter_part_floats(int R, int D) {
     return (long long)((R + kFR - 1) / kFR) * (2LL * kH * D + kH + D);
 }
 
-extern "C" int upp_ln_adapter_bwd_fused(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
-                                        const float *beta, const float *s1, const float *W1, const float *W2, const float *ud, float p,
-                                        float scale, const float *u, float keep, int mode, int P, float *g_x, float *g_y, float *part,
-                                        float *ln_part, int B, int Lin, int Lout, int D, int H, void *stream) {
+static int ln_adapter_bwd_fused_launch(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
+                                       const float *beta, const float *s1, const float *W1, const float *W2, const float *ud, float p,
+                                       float scale, const float *u, float keep, int mode, int P, float *g_x, float *g_y, float *part, float *fac,
+                                       float *ln_part, int B, int Lin, int Lout, int D, int H, void *stream) {
     if (!g_out || !xo || !mean || !rstd || !gamma || !beta || !s1 || !W1 || !W2 || B < 0 || Lin < 1 || Lout < 1) return UPP_E_BADARG;
     if (D != 384 || H != kH) return UPP_E_RANGE;
     if (!(mode == 0 || mode == 3 || mode == 4) || P < 0 || (mode == 0 && Lout != Lin) || (mode != 0 && Lout != Lin - P)) return UPP_E_BADARG;
@@ -838,8 +937,54 @@ extern "C" int upp_ln_adapter_bwd_fused(const float *g_out, const float *xo, con
     const size_t lds = ((size_t)2 * kFR * 400 + kFR * (384 + 4) + NW * kFR * (kH + 1) + 2 * kFR * 48) * sizeof(float);
     static std::atomic<bool> raised{false};
     if (!raised) { int rc = raise_lds(ln_adapter_bwd_kernel<384, NW>, lds); if (rc) return rc; raised = true; }
-    LnAdapterBwdArgs a{g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, u, p, scale, keep, mode, P, g_x, g_y, part, ln_part, B, Lin, Lout};
+    LnAdapterBwdArgs a{g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, u, p, scale, keep, mode, P, g_x, g_y, part, ln_part, B, Lin, Lout, fac};
     hipLaunchKernelGGL((ln_adapter_bwd_kernel<384, NW>), dim3((B * Lout + kFR - 1) / kFR), dim3(64 * NW), lds, (hipStream_t)stream, a);
+    return upp_launch_status();
+}
+
+extern "C" int upp_ln_adapter_bwd_fused(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
+                                        const float *beta, const float *s1, const float *W1, const float *W2, const float *ud, float p,
+                                        float scale, const float *u, float keep, int mode, int P, float *g_x, float *g_y, float *part,
+                                        float *ln_part, int B, int Lin, int Lout, int D, int H, void *stream) {
+    return ln_adapter_bwd_fused_launch(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, p, scale, u, keep, mode, P, g_x, g_y, part, nullptr, ln_part,
+                                       B, Lin, Lout, D, H, stream);
+}
+
+extern "C" int upp_ln_adapter_bwd_factors(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
+                                          const float *beta, const float *s1, const float *W1, const float *W2, const float *ud, float p,
+                                          float scale, const float *u, float keep, int mode, int P, float *g_x, float *g_y, float *fac,
+                                          float *ln_part, int B, int Lin, int Lout, int D, int H, void *stream) {
+    if (!fac) return UPP_E_BADARG;
+    return ln_adapter_bwd_fused_launch(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, p, scale, u, keep, mode, P, g_x, g_y, nullptr, fac, ln_part,
+                                       B, Lin, Lout, D, H, stream);
+}
+
+extern "C" int upp_adapter_wgrad_splits(int R) {
+    if (R < 1) return 0;
+    const int s = (R + 127) / 128;
+    return s > 64 ? 64 : s;
+}
+
+extern "C" int upp_adapter_wgrad_batched(const float *const *xo, const float *const *mean, const float *const *rstd, const float *const *gamma,
+                                         const float *const *beta, const float *const *g_out, const float *const *fac, const int *R,
+                                         const float *scale, float *const *part, int jobs, int splits, int D, int H, void *stream) {
+    if (jobs < 0 || (jobs > 0 && (!xo || !mean || !rstd || !gamma || !beta || !g_out || !fac || !R || !scale || !part))) return UPP_E_BADARG;
+    if (D != 384 || H != kH || splits < 1 || splits > 64) return UPP_E_RANGE;
+    for (int j = 0; j < jobs; ++j) {
+        if (!xo[j] || !mean[j] || !rstd[j] || !gamma[j] || !beta[j] || !g_out[j] || !fac[j] || !part[j] || R[j] < 1) return UPP_E_BADARG;
+        if ((reinterpret_cast<uintptr_t>(xo[j]) | reinterpret_cast<uintptr_t>(g_out[j]) | reinterpret_cast<uintptr_t>(fac[j]) |
+             reinterpret_cast<uintptr_t>(gamma[j]) | reinterpret_cast<uintptr_t>(beta[j])) & 15) return UPP_E_RANGE;
+    }
+    for (int j0 = 0; j0 < jobs; j0 += kWgJobs) {
+        AdapterWgradJobs a{};
+        const int n = jobs - j0 < kWgJobs ? jobs - j0 : kWgJobs;
+        for (int j = 0; j < n; ++j) {
+            a.xo[j] = xo[j0 + j]; a.mean[j] = mean[j0 + j]; a.rstd[j] = rstd[j0 + j]; a.gamma[j] = gamma[j0 + j]; a.beta[j] = beta[j0 + j];
+            a.g_out[j] = g_out[j0 + j]; a.fac[j] = fac[j0 + j]; a.part[j] = part[j0 + j]; a.R[j] = R[j0 + j]; a.scale[j] = scale[j0 + j];
+        }
+        a.splits = splits;
+        hipLaunchKernelGGL((adapter_wgrad_kernel<384>), dim3((unsigned)(n * (D / 64) * splits)), dim3(256), 0, (hipStream_t)stream, a);
+    }
     return upp_launch_status();
 }
 

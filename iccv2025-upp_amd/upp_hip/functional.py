@@ -333,6 +333,7 @@ class _DeferredSums:
         self.targets = None
         self.jobs = []
         self.wgrads = []
+        self.adapters = []
         self.routed = set()
 
     def reduce(self, ptr, part, offset, length):
@@ -390,9 +391,29 @@ class _DeferredSums:
         self.routed.add(root.data_ptr())
         return True
 
+    def adapter(self, ptrs, sizes, job):
+        """Queue the weight gradients of one block's adapter (ptrs / sizes of W1, b1, W2, b2; job: see ops.adapter_wgrad_batched): formed
+        from the per-row factors for every block of the backward pass in ONE launch at scope exit, instead of one partial matrix per
+        16-row workgroup (153 MB per headline step through upp_batched_sum).  -> True when all four buffers are registered."""
+        if self.targets is None:
+            return False
+        dsts = [self.targets.get(p_) for p_ in ptrs]
+        if any(d is None or d.numel() != n for d, n in zip(dsts, sizes)):
+            return False
+        self.adapters.append((job, dsts))
+        self.routed.update(ptrs)
+        return True
+
     def flush(self):
         jobs, self.jobs = self.jobs, []
         wg, self.wgrads = self.wgrads, []
+        ad, self.adapters = self.adapters, []
+        if ad:
+            for part, (_, dsts) in zip(ops.adapter_wgrad_batched([j for j, _ in ad]), ad):
+                off = 0
+                for dst in dsts:                                   # [dW1 | dW2 | db1 | db2], the order of `ptrs`: W1, W2, b1, b2
+                    jobs.append((part, off, part.shape[0], dst.numel(), part.stride(0), dst, True))
+                    off += dst.numel()
         if wg:
             for part, (_, _, dst) in zip(ops.linear_wgrad_grouped([(g, x) for g, x, _ in wg]), wg):
                 n, full = dst.numel(), part[0].numel()                # (full > n: the pad rows of a wgrad_rows problem are not summed)
@@ -425,6 +446,7 @@ class deferred_sums:
         else:
             _DEFERRED.jobs = []
             _DEFERRED.wgrads = []
+            _DEFERRED.adapters = []
         return False
 
 
@@ -1562,6 +1584,7 @@ class _Adapter(Function):
 
 
 FUSE_TAIL_BACKWARD = True     # _LnAdapter.backward: one launch (upp_ln_adapter_bwd_fused) instead of adapter backward + row backward
+ADAPTER_FACTORS = True        # ... which inside a deferred scope writes per-row factors; the weight gradients of all blocks in one launch at its exit
 
 
 class _LnAdapter(Function):
@@ -1591,20 +1614,33 @@ class _LnAdapter(Function):
         g_out = g_out.contiguous()
         need_ln = need[7] or need[8]
         need_ad = need[10] or need[11] or need[12] or need[13]
-        if FUSE_TAIL_BACKWARD:
+        p_gamma, p_beta, pW1, pb1, pW2, pb2 = ctx.param_ptrs
+        H = W1.shape[0]
+        # inside a deferred scope (TrainStep) with all four adapter buffers registered: per-row factors now, the weight gradients of every
+        # block in one launch at scope exit
+        factors = (FUSE_TAIL_BACKWARD and ADAPTER_FACTORS and need[10] and need[11] and need[12] and need[13]
+                   and _DEFERRED.targets is not None and all(_DEFERRED.targets.get(p_) is not None for p_ in (pW1, pb1, pW2, pb2)))
+        if factors:
+            g_x, g_y, fac, ln_part = ops.ln_adapter_bwd_fused(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, pd, scale, u, keep, mode, P, Lin,
+                                                              need[0], has_y and need[1], True, need_ln, factors=True)
+            R = B * Lout
+            factors = _DEFERRED.adapter((pW1, pW2, pb1, pb2), (H * D, H * D, H, D),
+                                        (xo.view(R, D), mean.view(R), rstd.view(R), gamma, beta, g_out.view(R, D), fac, scale))
+            if not factors:
+                raise RuntimeError("ln_adapter backward: the registered adapter gradient buffers do not match the adapter's shapes")
+            part = None
+        elif FUSE_TAIL_BACKWARD:
             g_x, g_y, part, ln_part = ops.ln_adapter_bwd_fused(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, pd, scale, u, keep, mode, P, Lin,
                                                                need[0], has_y and need[1], need_ad, need_ln)
         else:       # the two kernels of the unfused path (kept: tests compare the fused launch against them)
             g_ha, part = ops.ln_adapter_bwd(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, pd, scale)
             g_x, _, g_y, ln_part = ops.rowln_bwd(g_out, g_ha, xo, mean, rstd, gamma, mode, u, keep, B, Lin, Lout, D, P,
                                                  need_x=need[0], need_prompt=False, need_y=has_y and need[1], need_ln_part=need_ln)
-        p_gamma, p_beta, pW1, pb1, pW2, pb2 = ctx.param_ptrs
         g_gamma = g_beta = gW1 = gb1 = gW2 = gb2 = None
         if need_ln:
             _, g_gamma = _DEFERRED.reduce(p_gamma, ln_part, 0, D)
             _, g_beta = _DEFERRED.reduce(p_beta, ln_part, D, D)
-        if need_ad:
-            H = W1.shape[0]
+        if need_ad and not factors:
             _, gW1 = _DEFERRED.reduce(pW1, part, 0, H * D)
             _, gW2 = _DEFERRED.reduce(pW2, part, H * D, H * D)
             _, gb1 = _DEFERRED.reduce(pb1, part, 2 * H * D, H)

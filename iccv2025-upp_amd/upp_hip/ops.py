@@ -1383,8 +1383,10 @@ def ln_adapter_bwd(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, u, p, scale):
 
 
 def ln_adapter_bwd_fused(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, p, scale, u, keep, mode, P, Lin, need_x, need_y, need_adapter,
-                         need_ln):
-    """Backward of ln_adapter_fwd in one launch -> (g_x, g_y, adapter partials, LayerNorm partials); upp_ln_adapter_bwd_fused."""
+                         need_ln, factors=False):
+    """Backward of ln_adapter_fwd in one launch -> (g_x, g_y, adapter partials, LayerNorm partials); upp_ln_adapter_bwd_fused.
+    factors=True: the third result is `fac` (B*Lout, 2 H) = [ga | d] per row instead of the per-workgroup partial matrices
+    (upp_ln_adapter_bwd_factors; the weight gradients are then formed by adapter_wgrad_batched)."""
     B, Lout, D = xo.shape
     H = W1.shape[0]
     dev = xo.device
@@ -1392,12 +1394,42 @@ def ln_adapter_bwd_fused(g_out, xo, mean, rstd, gamma, beta, s1, W1, W2, ud, p, 
     nwg = (R + 15) // 16
     g_x = torch.empty((B, Lin, D), dtype=torch.float32, device=dev) if need_x else None
     g_y = torch.empty((B, Lin, D), dtype=torch.float32, device=dev) if need_y else None
-    part = torch.empty((nwg, int(_abi.load().upp_ln_adapter_part_floats(R, D)) // nwg), dtype=torch.float32, device=dev) if need_adapter else None
     ln_part = torch.empty((nwg, 2 * D), dtype=torch.float32, device=dev) if need_ln else None
-    _call(dev, "upp_ln_adapter_bwd_fused", _abi.ptr(g_out), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd), _abi.ptr(gamma), _abi.ptr(beta),
-          _abi.ptr(s1), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(ud), float(p), float(scale), _abi.ptr(u), float(keep), int(mode), int(P),
-          _abi.ptr(g_x), _abi.ptr(g_y), _abi.ptr(part), _abi.ptr(ln_part), B, Lin, Lout, D, H)
+    if factors:
+        part = torch.empty((R, 2 * H), dtype=torch.float32, device=dev)
+    else:
+        part = torch.empty((nwg, int(_abi.load().upp_ln_adapter_part_floats(R, D)) // nwg), dtype=torch.float32, device=dev) if need_adapter else None
+    _call(dev, "upp_ln_adapter_bwd_factors" if factors else "upp_ln_adapter_bwd_fused", _abi.ptr(g_out), _abi.ptr(xo), _abi.ptr(mean), _abi.ptr(rstd),
+          _abi.ptr(gamma), _abi.ptr(beta), _abi.ptr(s1), _abi.ptr(W1), _abi.ptr(W2), _abi.ptr(ud), float(p), float(scale), _abi.ptr(u), float(keep),
+          int(mode), int(P), _abi.ptr(g_x), _abi.ptr(g_y), _abi.ptr(part), _abi.ptr(ln_part), B, Lin, Lout, D, H)
     return g_x, g_y, part, ln_part
+
+
+def adapter_wgrad_batched(jobs, H=32):
+    """jobs: list of (xo (R, D), mean (R), rstd (R), gamma, beta, g_out (R, D), fac (R, 2 H), scale) -- the saved rows and statistics of a
+    block's tail, the gradient that reached it and the factors ln_adapter_bwd_fused(factors=True) wrote.  ONE launch (per 16 jobs) forms
+    every block's [dW1 | dW2 | db1 | db2] over `splits` row ranges -> list of (splits, 2 H D + H + D) partial matrices, to be summed over
+    their rows (batched_sum); upp_adapter_wgrad_batched."""
+    if not jobs:
+        return []
+    import ctypes
+    k = len(jobs)
+    lib = _abi.load()
+    D = jobs[0][0].shape[-1]
+    for xo, mean, rstd, gamma, beta, g_out, fac, _ in jobs:
+        R = xo.numel() // D
+        for t, name, n in ((xo, "xo", R * D), (g_out, "g_out", R * D), (mean, "mean", R), (rstd, "rstd", R), (gamma, "gamma", D), (beta, "beta", D),
+                           (fac, "fac", R * 2 * H)):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+                raise RuntimeError("adapter_wgrad_batched: %s must be a contiguous f32 HIP tensor of %d elements" % (name, n))
+    rows = [j[0].numel() // D for j in jobs]
+    splits = int(lib.upp_adapter_wgrad_splits(max(rows)))
+    psz = 2 * H * D + H + D
+    parts = [torch.empty((splits, psz), dtype=torch.float32, device=jobs[0][0].device) for _ in jobs]
+    arr = lambda i: (ctypes.c_void_p * k)(*[j[i].data_ptr() for j in jobs])
+    _call(jobs[0][0].device, "upp_adapter_wgrad_batched", arr(0), arr(1), arr(2), arr(3), arr(4), arr(5), arr(6), (ctypes.c_int * k)(*rows),
+          (ctypes.c_float * k)(*[float(j[7]) for j in jobs]), (ctypes.c_void_p * k)(*[p_.data_ptr() for p_ in parts]), k, splits, D, H)
+    return parts
 
 
 def adapter_bwd(g_out, ha, s1, W1, W2, u, p, scale):

@@ -353,6 +353,45 @@ class TrainStep:
         return self.step()
 
 
+def _runs_beside(a, b, cycles=400000):
+    """Do kernels on streams a and b run side by side?  torch hands out streams from a pool of 32 and the runtime maps streams onto a
+    handful of hardware queues: two streams on ONE queue run their kernels one after the other, and a two-stream pipeline on them is the
+    one-stream step (measured: 6.05 instead of 4.18 ms, depending only on how many streams the process had created before).  Two
+    single-thread spin kernels (torch.cuda._sleep), timed alone and together."""
+    def timed(streams):
+        torch.cuda.synchronize(a.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(a)
+        for s_ in streams:
+            if s_ is not a:
+                s_.wait_event(e0)
+            with torch.cuda.stream(s_):
+                torch.cuda._sleep(cycles)
+        for s_ in streams:
+            if s_ is not a:
+                a.wait_stream(s_)
+        e1.record(a)
+        torch.cuda.synchronize(a.device)
+        return e0.elapsed_time(e1)
+    timed([a, b])                    # (first use of a stream creates its queue)
+    one = min(timed([a]), timed([a]))
+    both = min(timed([a, b]), timed([a, b]))
+    return both < 1.5 * one
+
+
+def _concurrent_stream(device, tries=12):
+    """A stream whose kernels run beside those of the CURRENT stream (the step driver replays its back-end graph there)."""
+    cur = torch.cuda.current_stream(device)
+    s = None
+    for _ in range(tries):
+        s = torch.cuda.Stream(device=device)
+        if _runs_beside(cur, s):
+            return s
+    import warnings
+    warnings.warn("upp_hip: no stream that runs beside the current one was found in %d tries; the pipelined step will run its halves one after the other" % tries)
+    return s
+
+
 _BACK_END_KEYS = ('downstream', 'bnorm', 'cls_')     # trainable parameters the prompting front-end never reads
 
 
@@ -411,7 +450,7 @@ class PipelinedTrainStep(TrainStep):
         self.extras2 = [[t.detach().clone().to(self.device) for t in (extras or [])] for _ in range(2)]
         # (stream priorities do not help: round 2 5.89-5.92 ms for -1 / 0; round 5: front-end stream at high priority 4.58 against 4.54-4.55 ms,
         #  the whole driver on a high-priority stream of its own 4.83-4.84 against 4.63-4.64; the runtime offers no priority BELOW normal)
-        self.s_front = torch.cuda.Stream(device=self.device)
+        self.s_front = _concurrent_stream(self.device)
         # UPP_PIPE_FPS_FORM (host-side A/B switch, tools/micro/fps_cpw_ab.sh): "0" = the spread form, "<clouds>,<exclusive>" = that packed form
         form = os.environ.get("UPP_PIPE_FPS_FORM", "2,1")
         self._fps_form = (1, False) if form == "0" else (int(form.split(",")[0]), form.split(",")[1:] == ["1"])

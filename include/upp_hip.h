@@ -521,6 +521,25 @@ int upp_ln_adapter_bwd_fused(const float *g_out, const float *xo, const float *m
 int upp_ln_adapter_bwd(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
                        const float *beta, const float *s1, const float *W1, const float *W2, const float *u, float p,
                        float scale, float *g_ha, float *part, int R, int D, int H, void *stream);
+/* The adapter weight gradients from their factors (round 6; reference: autograd through Adapter.forward,
+ * models/Point_MAE_pretask_dev.py:96-104, for the trainable `downstream_adapter` of every block).  upp_ln_adapter_bwd_fused writes
+ * 24,992 floats of partial results per 16-row workgroup (153 MB per headline step, summed by upp_batched_sum).
+ * upp_ln_adapter_bwd_factors is the same launch with `fac` (B*Lout, 2 H) = [ga | d] per row instead of `part`:
+ *   ga = gradient at the hidden pre-activation, d = scale * dropout(gelu(s1)).
+ * upp_adapter_wgrad_batched then forms, in ONE launch for `jobs` blocks (any number; 16 per kernel launch),
+ *   dW1 = sum_rows ga^T . LayerNorm(xo),  dW2 = sum_rows g_out^T . d,  db1 = sum_rows ga,  db2 = scale sum_rows g_out
+ * over `splits` row ranges per block: part[j] = (splits, 2 H D + H + D) floats in the per-workgroup layout above, to be summed over
+ * its rows (upp_batched_sum).  upp_adapter_wgrad_splits(R): the split count the host side uses (128 rows per split, at most 64).
+ * D = 384, H = 32; xo / g_out / fac / gamma / beta 16-byte aligned.  Deterministic; the association of the row sum differs from the
+ * per-workgroup form's. */
+int upp_ln_adapter_bwd_factors(const float *g_out, const float *xo, const float *mean, const float *rstd, const float *gamma,
+                               const float *beta, const float *s1, const float *W1, const float *W2, const float *ud, float p,
+                               float scale, const float *u, float keep, int mode, int P, float *g_x, float *g_y, float *fac,
+                               float *ln_part, int B, int Lin, int Lout, int D, int H, void *stream);
+int upp_adapter_wgrad_splits(int R);
+int upp_adapter_wgrad_batched(const float *const *xo, const float *const *mean, const float *const *rstd, const float *const *gamma,
+                              const float *const *beta, const float *const *g_out, const float *const *fac, const int *R,
+                              const float *scale, float *const *part, int jobs, int splits, int D, int H, void *stream);
 
 /* ---- tail of the denoising prompter ---------------------------------------------------------
  * Replaces RectifyPrompter.score_head (reference models/Point_MAE_pretask_dev.py:491-493,512: Linear(32,64) -> ReLU -> Dropout(0.2)

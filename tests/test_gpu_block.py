@@ -276,6 +276,27 @@ def test_block_tail_in_one_launch_equals_row_kernel_plus_adapter(B, Lin, P, mode
     if m != HF.ROW_IDENTITY:      # the prompt rows the strip map dropped: exactly zero
         rows = slice(1, 1 + P) if m == HF.ROW_STRIP_CLS else slice(0, P)
         assert float(grads[0][:, rows].abs().max()) == 0.0
+    # inside a deferred scope (the step driver's): the adapter weight gradients from per-row factors (upp_ln_adapter_bwd_factors +
+    # upp_adapter_wgrad_batched, ONE launch for all queued blocks -- two here) against the per-workgroup partial matrices, and both
+    # against float64 of the same products
+    params = [ln.weight, ln.bias, W1, b1, W2, b2]
+    got = {}
+    for fac in (True, False):
+        HF.ADAPTER_FACTORS = fac
+        try:
+            targets = {p_.data_ptr(): torch.zeros_like(p_) for p_ in params}
+            with HF.deferred_sums(targets) as scope:
+                o_a = HF.ln_adapter(x, y, yb, u, 0.9, m, P, ln, W1, b1, W2, b2, ud, pd, 0.7)
+                o_b = HF.ln_adapter(x, y, yb, u, 0.9, m, P, ln, W1, b1, W2, b2, ud, pd, 0.7)          # a second "block" with the same parameters
+                g_in = torch.autograd.grad((o_a * w).sum() + ((o_b * w).sum() * 0.5), [x], allow_unused=True)
+            assert scope.routed == set(targets)
+            got[fac] = ([targets[p_.data_ptr()] for p_ in params], g_in[0])
+        finally:
+            HF.ADAPTER_FACTORS = True
+    for a_, b_, r_ in zip(got[True][0], got[False][0], grads[len(leaves) - 6:]):
+        close(a_, b_, rtol=2e-5, atol_scale=4e-6)
+        close(a_, 1.5 * r_, rtol=5e-5, atol_scale=1e-5)                # (autograd of one application, scaled: 1 + 0.5)
+    assert torch.equal(got[True][1], got[False][1])                    # the data gradient does not depend on the form
 
 
 # ------------------------------------------------------------------ fused propagation step (CSR + in-kernel BatchNorm)
@@ -442,6 +463,21 @@ def test_batched_sum_and_deferred_scope():
     close(got[0], want[0], rtol=1e-6, atol_scale=1e-6)
     for p_, w in zip(params, want[1:]):      # same partials, summed sequentially (kernel) vs torch's tree order: f32 reassociation
         close(targets[p_.data_ptr()], w, rtol=1e-4, atol_scale=2e-4)
+
+
+def test_the_pipelines_side_stream_runs_beside_the_current_one():
+    """torch hands out streams from a pool and the runtime maps them onto a few hardware queues: a side stream that shares the current
+    stream's queue serialises the two-stream step (measured: 6.05 instead of 4.18 ms, by nothing but the number of streams created
+    before).  PipelinedTrainStep therefore probes: whatever the pool hands out next, the stream it keeps runs beside the current one."""
+    from upp_hip.train import _runs_beside, _concurrent_stream
+    dev = torch.device('cuda', torch.cuda.current_device())
+    cur = torch.cuda.current_stream(dev)
+    assert not _runs_beside(cur, cur)                      # (one queue: one after the other -- the probe can tell)
+    for shift in range(6):
+        for _ in range(shift):
+            torch.cuda.Stream(device=dev)                  # move the pool on
+        s = _concurrent_stream(dev)
+        assert s != cur and _runs_beside(cur, s)
 
 
 def test_train_step_flat_gradients_equal_plain_autograd():
