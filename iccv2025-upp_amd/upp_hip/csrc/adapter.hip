@@ -763,7 +763,7 @@ __global__ __launch_bounds__(64 * NW) void ln_adapter_bwd_kernel(LnAdapterBwdArg
 // of D, row split): 16 rows per step through two LDS buffers (the next step's rows are in flight while this one is multiplied), wave w
 // owns columns 16 w .. 16 w + 15 of the tile: two 16 x 16 tiles of each matrix on v_mfma_f32_16x16x4_f32.  part[job]: `splits` rows of
 // the per-workgroup layout above, summed by upp_batched_sum.  Rows ascending inside a split, splits ascending in the sum: deterministic.
-constexpr int kWgJobs = 16, kWgLd = 68;
+constexpr int kWgJobs = 16, kWgLd = 80;       // LDS row stride = 16 mod 64 floats: the column-wise operand reads (lane (r, g) -> row 4 s + g, column 16 t + r) are conflict-free
 struct AdapterWgradJobs {
     const float *xo[kWgJobs], *mean[kWgJobs], *rstd[kWgJobs], *gamma[kWgJobs], *beta[kWgJobs], *g_out[kWgJobs], *fac[kWgJobs];
     float *part[kWgJobs];
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void adapter_wgrad_kernel(AdapterWgradJobs a) 
     const int per_job = (D / 64) * a.splits;
     const int j = bx / per_job;
     bx -= j * per_job;
-    const int t = bx / a.splits, sp = bx - t * a.splits;
+    const int sp = bx / (D / 64), t = bx - sp * (D / 64);       // the six column tiles of a row range are neighbours: together they read whole rows
     const int R = a.R[j];
     const int per = ((R + a.splits - 1) / a.splits + kFR - 1) / kFR * kFR;
     const int r_lo = sp * per, r_hi = min(R, r_lo + per);
@@ -788,37 +788,44 @@ __global__ __launch_bounds__(256) void adapter_wgrad_kernel(AdapterWgradJobs a) 
     const float *xo = a.xo[j], *go = a.g_out[j], *fac = a.fac[j], *mean = a.mean[j], *rstd = a.rstd[j];
     const int lr = tid >> 4, c4 = (tid & 15) * 4;          // this thread's 16-byte piece of a 16 x 64 tile
     const float4 gm = *reinterpret_cast<const float4 *>(a.gamma[j] + c0 + c4), bt = *reinterpret_cast<const float4 *>(a.beta[j] + c0 + c4);
+    // (plain statements, component-wise selects: a lambda that captured the staging registers by reference and selected whole float4s put
+    //  them into scratch memory -- 80 bytes of private segment, 31 of the kernel's 46 us)
     float4 vz, vx, vf;
-    float mu = 0.0f, rs = 0.0f;
-    bool live = false;
-    auto load = [&](int row0) {
-        const int row = min(row0 + lr, R - 1);
-        live = row0 + lr < r_hi;
-        vz = *reinterpret_cast<const float4 *>(go + (size_t)row * D + c0 + c4);
-        vx = *reinterpret_cast<const float4 *>(xo + (size_t)row * D + c0 + c4);
-        vf = *reinterpret_cast<const float4 *>(fac + (size_t)row * (2 * kH) + c4);
-        mu = mean[row]; rs = rstd[row];
-    };
-    auto store = [&](int buf) {
-        const float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 h;
-        h.x = __builtin_fmaf((vx.x - mu) * rs, gm.x, bt.x); h.y = __builtin_fmaf((vx.y - mu) * rs, gm.y, bt.y);
-        h.z = __builtin_fmaf((vx.z - mu) * rs, gm.z, bt.z); h.w = __builtin_fmaf((vx.w - mu) * rs, gm.w, bt.w);
-        *reinterpret_cast<float4 *>(&Zs[buf][lr * kWgLd + c4]) = live ? vz : z0;
-        *reinterpret_cast<float4 *>(&Hs[buf][lr * kWgLd + c4]) = live ? h : z0;
-        *reinterpret_cast<float4 *>(&Fs[buf][lr * kWgLd + c4]) = live ? vf : z0;
-    };
+    float mu = 0.0f, rs = 0.0f, keepf = 0.0f;
+#define ADWG_LOAD(ROW0)                                                                        \
+    {                                                                                          \
+        const int row_ = min((ROW0) + lr, R - 1);                                              \
+        keepf = (ROW0) + lr < r_hi ? 1.0f : 0.0f;                                              \
+        vz = *reinterpret_cast<const float4 *>(go + (size_t)row_ * D + c0 + c4);               \
+        vx = *reinterpret_cast<const float4 *>(xo + (size_t)row_ * D + c0 + c4);               \
+        vf = *reinterpret_cast<const float4 *>(fac + (size_t)row_ * (2 * kH) + c4);            \
+        mu = mean[row_]; rs = rstd[row_];                                                      \
+    }
+    // rows beyond the split: zeros (select, not multiply: the clamped row may hold anything)
+#define ADWG_SEL(V) (keepf != 0.0f ? (V) : 0.0f)
+#define ADWG_STORE(BUF)                                                                        \
+    {                                                                                          \
+        float *z_ = &Zs[BUF][lr * kWgLd + c4], *h_ = &Hs[BUF][lr * kWgLd + c4], *f_ = &Fs[BUF][lr * kWgLd + c4];   \
+        const float h0 = __builtin_fmaf((vx.x - mu) * rs, gm.x, bt.x), h1 = __builtin_fmaf((vx.y - mu) * rs, gm.y, bt.y);   \
+        const float h2 = __builtin_fmaf((vx.z - mu) * rs, gm.z, bt.z), h3 = __builtin_fmaf((vx.w - mu) * rs, gm.w, bt.w);   \
+        *reinterpret_cast<float4 *>(z_) = make_float4(ADWG_SEL(vz.x), ADWG_SEL(vz.y), ADWG_SEL(vz.z), ADWG_SEL(vz.w));      \
+        *reinterpret_cast<float4 *>(h_) = make_float4(ADWG_SEL(h0), ADWG_SEL(h1), ADWG_SEL(h2), ADWG_SEL(h3));              \
+        *reinterpret_cast<float4 *>(f_) = make_float4(ADWG_SEL(vf.x), ADWG_SEL(vf.y), ADWG_SEL(vf.z), ADWG_SEL(vf.w));      \
+    }
     f32x4v w1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, w2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float bsum = 0.0f;                                      // tid < 64: db2 of column c0 + tid; 64 <= tid < 96 (tile 0): db1 of unit tid - 64
     if (r_lo < r_hi) {
-        load(r_lo);
-        store(0);
+        ADWG_LOAD(r_lo)
+        ADWG_STORE(0)
         __syncthreads();
         int buf = 0;
         for (int row0 = r_lo; row0 < r_hi; row0 += kFR, buf ^= 1) {
             const bool more = row0 + kFR < r_hi;
-            if (more) load(row0 + kFR);
+#ifndef UPP_ADWG_NO_LOAD          // (diagnostic builds, tools/micro/src/adwg_ablate.hip: wrong results)
+            if (more) ADWG_LOAD(row0 + kFR)
+#endif
             const float *Z = Zs[buf], *Hh = Hs[buf], *F = Fs[buf];
+#ifndef UPP_ADWG_NO_COMPUTE
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int ro = (4 * s4 + g) * kWgLd;
@@ -832,22 +839,44 @@ __global__ __launch_bounds__(256) void adapter_wgrad_kernel(AdapterWgradJobs a) 
                     w1[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc, hc, w1[tj], 0, 0, 0);
                 }
             }
+#endif
+#ifdef UPP_ADWG_SKELETON           // (one LDS read per step keeps the staging alive)
+            bsum += Z[tid] + Hh[tid] + F[tid];
+#endif
+#ifndef UPP_ADWG_NO_BIAS
             if (tid < 64) { for (int i = 0; i < kFR; ++i) bsum += Z[i * kWgLd + tid]; }
             else if (tid < 64 + kH && t == 0) { for (int i = 0; i < kFR; ++i) bsum += F[i * kWgLd + tid - 64]; }
-            if (more) store(buf ^ 1);
+#endif
+            if (more) ADWG_STORE(buf ^ 1)
             __syncthreads();
         }
     }
+    // ---- the tile leaves through the LDS: dW1 as 32 rows of 256 contiguous bytes, dW2 as ONE contiguous 8 KB block (64 x 32), 16 bytes per
+    // lane (straight from the accumulators a wave-store is four 64-byte pieces: the 20 MB of partials took longer than the contraction)
     float *out = a.part[j] + (size_t)sp * ((size_t)2 * kH * D + kH + D);
+    float *T1 = &Zs[0][0], *T2 = &Hs[0][0];                  // [32][68], [64][36]   (both buffers of a staging array: 2,560 floats each)
+    static_assert(2 * kFR * kWgLd >= 32 * 68 && 2 * kFR * kWgLd >= 64 * 36, "staging tiles fit the operand buffers");
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            out[(size_t)(16 * tj + 4 * g + reg) * D + c0 + 16 * wave + r] = w1[tj][reg];                          // dW1[j][n]
-            out[(size_t)kH * D + (size_t)(c0 + 16 * wave + 4 * g + reg) * kH + 16 * tj + r] = w2[tj][reg];        // dW2[n][j]
+            T1[(16 * tj + 4 * g + reg) * 68 + 16 * wave + r] = w1[tj][reg];                 // dW1[j][n - c0]
+            T2[(16 * wave + 4 * g + reg) * 36 + 16 * tj + r] = w2[tj][reg];                 // dW2[n - c0][j]
         }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + 256 * q;                         // 512 16-byte pieces per matrix
+        const int r1 = e >> 4, p1 = (e & 15) * 4;            // dW1: row j = r1 (32 rows), 16 pieces of its 64 columns
+        *reinterpret_cast<float4 *>(out + (size_t)r1 * D + c0 + p1) = *reinterpret_cast<const float4 *>(&T1[r1 * 68 + p1]);
+        const int r2 = e >> 3, p2 = (e & 7) * 4;             // dW2: row n = c0 + r2 (64 rows), 8 pieces of its 32 columns
+        *reinterpret_cast<float4 *>(out + (size_t)kH * D + (size_t)(c0 + r2) * kH + p2) = *reinterpret_cast<const float4 *>(&T2[r2 * 36 + p2]);
+    }
     if (tid < 64) out[(size_t)2 * kH * D + kH + c0 + tid] = bsum * a.scale[j];
     else if (tid < 64 + kH && t == 0) out[(size_t)2 * kH * D + tid - 64] = bsum;
+#undef ADWG_LOAD
+#undef ADWG_SEL
+#undef ADWG_STORE
 }
 
 template <typename K>

@@ -217,6 +217,58 @@ def test_exported_symbols_are_exactly_the_declared_ones():
     assert exported == _declared()
 
 
+def _gfx950_disassembly():
+    """Disassembly text of every gfx950 code object inside libupp_hip.so (llvm-objdump -d)."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    from upp_hip import build as B
+    data = open(os.path.join(os.path.dirname(B.__file__), "lib", "libupp_hip.so"), "rb").read()
+    texts = []
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data):
+        p = m.start()
+        (n,) = struct.unpack_from("<Q", data, p + 24)
+        q = p + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, q)
+            q += 24
+            triple = data[q:q + tl].decode()
+            q += tl
+            if "gfx950" not in triple or size == 0:
+                continue
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(data[p + off:p + off + size])
+                f.flush()
+                texts.append(subprocess.run([objdump, "-d", f.name], capture_output=True, text=True, check=True).stdout)
+    return texts
+
+
+def test_only_the_listed_kernels_touch_scratch_memory():
+    """Round 6: a lambda that captured three float4 staging registers by reference and selected between whole vectors put them into
+    scratch memory -- 80 bytes of private segment that cost adapter_wgrad_kernel 31 of its 46 us (NOTEBOOK 12.10).  No error, no warning.
+    Here: every kernel of the library is disassembled; `scratch_` instructions may appear only in the two kernels that are known to
+    spill a few registers at their 256-register limit (attn_bwd_long_kernel: 4-12 VGPRs in a depth-1 loop) or to index a per-lane
+    array (fps_kernel with 64 points per lane: the large-cloud form of the batch preparation)."""
+    import re
+    allowed = ("attn_bwd_long_kernel", "fps_kernelILi64")
+    offenders, kernels = {}, 0
+    for text in _gfx950_disassembly():
+        name = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                name = m.group(1)
+                kernels += 1
+            elif name and "scratch_" in line and not any(a in name for a in allowed):
+                offenders[name] = offenders.get(name, 0) + 1
+    assert kernels > 200
+    assert not offenders, "kernels with scratch accesses: %s" % sorted(offenders.items())
+
+
 def test_library_contains_no_packed_f32_instruction():
     """Round 4: v_pk_add_f32 with op_sel:[0,1] returns a - 0 in its low half every so often while a bf16-MFMA workgroup shares the CU
     (tools/micro/src/lds_canary.cpp; it changed FPS picks in the pipelined step), so the library is built with -target-feature
