@@ -29,9 +29,11 @@
 extern "C" {
 #endif
 
-#define UPP_ABI_VERSION 5   /* 5 (round 6): SMALLER than 4 -- the measured-slower experiments left the library: upp_ln_adapter_fwd_next, upp_linear_sb_resid_f32,
+#define UPP_ABI_VERSION 5   /* 5 (round 6): the measured-slower experiments left the library: upp_ln_adapter_fwd_next, upp_linear_sb_resid_f32,
                                upp_linear_sb_ln_f32, upp_linear_sb_ln_usable (and the PRO = 2 instantiations, the wave-specialised weight-gradient kernel and the
-                               nine environment reads behind them); + upp_set_option / upp_get_option.
+                               nine environment reads behind them); + upp_set_option / upp_get_option, and the fused operators of the secondary recipes'
+                               tails: upp_bn_rows_drop_*, upp_logsoftmax_rows_*, upp_nll_mean_*, upp_noise_loss_*, upp_linear_smallk_gelu_d_f32,
+                               upp_fps_gather_bwd, upp_ln_adapter_bwd_factors / upp_adapter_wgrad_* (106 prototypes; 4 had 93).
                                4: + upp_argsort_rows, upp_group_max_fwd / _bwd.  3: split-bf16 Linear (upp_linear_sb_*); the k-parts protocol, the attention
                                `variant` entry points (upp_attn_*_ex) and the VALU / 32x32x2 attention kernels behind them are gone.
                                2: grouped weight gradients, register-tiled Linear codes; the round-1 *_set_* toggles are gone */
