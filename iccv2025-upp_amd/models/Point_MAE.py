@@ -165,7 +165,7 @@ class Point_MAE(nn.Module):
         c_sorted = torch.gather(center, 1, order.unsqueeze(-1).expand(-1, -1, 3))        # visible centres, then masked
         pos_full = L.mlp2(self.decoder_pos_embed, c_sorted)
         N = order.shape[1] - n_vis
-        x_full = torch.cat([x_vis, self.mask_token.expand(B, N, -1)], dim=1)
+        x_full = torch.cat([x_vis, HF.expand_rows(self.mask_token, B, N)], dim=1)
         x_rec = self.MAE_decoder(x_full, pos_full, N)
         head = self.increase_dim[0]
         rebuild = HF.linear(x_rec, head.weight.squeeze(-1), head.bias).reshape(B * N, -1, 3)

@@ -134,7 +134,7 @@ class PromptedBackbone(nn.Module):
         predict_token = L.mlp2(self.predict_token_generator, x_vis)
         pos_mask = L.mlp2(self.decoder_pos_embed, predict_center).reshape(B, -1, self.trans_dim)
         N = pos_mask.shape[1]
-        mask_token = propagate(predict_center, vis_center, self.mask_token.expand(B, N, -1), predict_token,
+        mask_token = propagate(predict_center, vis_center, HF.expand_rows(self.mask_token, B, N), predict_token,
                                de_neighbors=6)
         x_rec = self.MAE_decoder(torch.cat([x_vis, mask_token], dim=1), torch.cat([pos_vis, pos_mask], dim=1), N,
                                  pretask_adapter=True, path='pretask')

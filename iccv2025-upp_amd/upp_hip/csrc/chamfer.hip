@@ -219,9 +219,8 @@ extern "C" int upp_chamfer_bwd(const float *xyz1, const float *xyz2, const int32
     const long long total = (long long)B * (n + m);
     long long grid = (total + 255) / 256;
     if (grid > 2048) grid = 2048;
-    if (hipMemsetAsync(g1, 0, sizeof(float) * 3 * (size_t)B * n, (hipStream_t)stream) != hipSuccess ||
-        hipMemsetAsync(g2, 0, sizeof(float) * 3 * (size_t)B * m, (hipStream_t)stream) != hipSuccess)
-        return upp_launch_status();
+    upp_zero_async(g1, 3LL * B * n, (hipStream_t)stream);            // (a kernel, not a memset node: common.h)
+    upp_zero_async(g2, 3LL * B * m, (hipStream_t)stream);
     hipLaunchKernelGGL(chamfer_grad_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, xyz1, xyz2, idx1, idx2,
                        grad_dist1, grad_dist2, g1, g2, B, n, m);
     return upp_launch_status();

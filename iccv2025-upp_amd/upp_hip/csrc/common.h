@@ -129,3 +129,23 @@ static inline int upp_launch_status(void) {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
+
+// Zero `n` floats on `stream` with a KERNEL.  Never hipMemsetAsync: on this stack (ROCm 7.2.0) a memset NODE of a captured graph works in
+// the first replay and writes garbage from the second on (tools/micro/memset_graph_check.py: EMD cost -1.15e37, Chamfer gradients inf) --
+// and every entry point of this library may be captured into a step graph.
+__global__ __launch_bounds__(256) static void upp_zero_kernel(float *__restrict__ p, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) *reinterpret_cast<float4 *>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);          // (p is 16-byte aligned: checked by the caller)
+    else for (long long j = i; j < n; ++j) p[j] = 0.0f;
+}
+static inline void upp_zero_async(float *p, long long n, hipStream_t stream) {
+    if (n <= 0) return;
+    if (reinterpret_cast<uintptr_t>(p) & 15) {            // an unaligned head (1 ... 3 floats): the scalar path of one extra launch
+        long long head = (long long)((16 - (reinterpret_cast<uintptr_t>(p) & 15)) / 4);
+        if (head > n) head = n;
+        hipLaunchKernelGGL(upp_zero_kernel, dim3(1), dim3(256), 0, stream, p, head);
+        p += head; n -= head;
+        if (n <= 0) return;
+    }
+    hipLaunchKernelGGL(upp_zero_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, p, n);
+}

@@ -338,8 +338,7 @@ extern "C" int upp_emd_matchcost(const float *xyz1, const float *xyz2, const flo
     if (B == 0) return 0;
     if (B > 65535) return UPP_E_RANGE;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(cost, 0, sizeof(float) * (size_t)B, st);
-    if (e != hipSuccess) return (int)e;
+    upp_zero_async(cost, B, st);                                     // (a kernel, not a memset node: common.h)
     hipLaunchKernelGGL(emd_cost_kernel, dim3((n + 63) / 64, B), dim3(256), 0, st, xyz1, xyz2, match, cost, n, m);
     return upp_launch_status();
 }

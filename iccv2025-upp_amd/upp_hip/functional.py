@@ -345,6 +345,8 @@ class _DeferredSums:
             part, offset = ops.colsum_partials(part, offset, length), 0
         dst = self.targets.get(ptr) if (self.targets is not None and part.is_cuda) else None
         if dst is None or dst.numel() != length:
+            if part.is_cuda and part.dtype == torch.float32 and part.dim() == 2 and part.stride(1) == 1:
+                return False, ops.sum_rows(part, offset, length)                  # (never a torch reduction inside a step: ops.sum_rows)
             return False, part[:, offset:offset + length].sum(dim=0)
         self.jobs.append((part, offset, part.shape[0], length, part.stride(0), dst, True))
         self.routed.add(ptr)
@@ -664,7 +666,7 @@ def weight_grad(g2, x2, w, own=False):
     if _DEFERRED.wgrad(w.data_ptr(), g2, x2) or _DEFERRED.wgrad_window(w, g2, x2):
         return None
     part = ops.linear_wgrad(g2, x2)
-    return part.sum(dim=0) if part.shape[0] > 1 else part[0]
+    return ops.sum_rows(part.view(part.shape[0], -1)).view(part.shape[1:]) if part.shape[0] > 1 else part[0]
 
 
 def b_needed(ctx):
@@ -739,6 +741,53 @@ class _LinearGroupBias(Function):
         return gx, gw, ggb, None
 
 
+class _GroupBiasAdd(Function):
+    """y (M,N) + gb[m // rows]: the broadcast add of linear_group_bias when the GEMM cannot take the term in its epilogue (few rows).
+    As its own node so that the group term's gradient is upp_colsum_partials (chunk = group) and not torch's sum over the rows of a
+    group -- a reduction that splits 2,048 rows over workgroups and zeroes its semaphores with a memset: inside a captured step that
+    node is right in the first replay only (NOTEBOOK 12.11; the B = 4 segmentation step of tests/test_gpu_determinism.py)."""
+
+    @staticmethod
+    def forward(ctx, y, gb, rows):
+        ctx.rows = rows
+        M, N = y.shape
+        return (y.view(M // rows, rows, N) + gb.unsqueeze(1)).view(M, N)
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = g if g.is_contiguous() else g.contiguous()
+        ggb = ops.colsum_partials(g2, 0, g2.shape[1], chunks=g2.shape[0] // ctx.rows) if ctx.needs_input_grad[1] else None
+        return (g2 if ctx.needs_input_grad[0] else None), ggb, None
+
+
+class _ExpandRows(Function):
+    """token (1,1,D) or (D,) -> (B, N, D) (the mask token of the MAE decoders: `mask_token.expand(B, N, -1)`), with the backward's sum
+    over the B N rows on this library's kernels (and routed into the step driver's deferred sums): torch's sum over 1,024 ... 1,216 rows
+    per column splits them over workgroups behind a memset -- see _GroupBiasAdd."""
+
+    @staticmethod
+    def forward(ctx, token, B, N):
+        ctx.ptr, ctx.shape = token.data_ptr(), tuple(token.shape)
+        return token.reshape(1, 1, -1).expand(B, N, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        D = g.shape[-1]
+        g2 = g.reshape(-1, D)
+        g2 = g2 if g2.is_contiguous() else g2.contiguous()
+        if not (g2.is_cuda and g2.dtype == torch.float32):
+            return g2.sum(dim=0).view(ctx.shape), None, None
+        routed, gt = _DEFERRED.reduce(ctx.ptr, g2, 0, D)
+        return (None if routed else gt.view(ctx.shape)), None, None
+
+
+def expand_rows(token, B, N):
+    """token.expand(B, N, -1) whose gradient is summed by this library's kernels (see _ExpandRows)."""
+    if token.is_cuda and torch.is_grad_enabled() and token.requires_grad:
+        return _ExpandRows.apply(token, int(B), int(N))
+    return token.reshape(1, 1, -1).expand(B, N, -1)
+
+
 def linear_group_bias(x, weight, group_bias, rows_per_group):
     """F.linear(x, weight) + group_bias.repeat_interleave(rows_per_group, 0) for a (M,K) matrix x whose rows come in groups of
     `rows_per_group` (a power of two >= 32) that share one bias row: in the GEMM's epilogue when the problem is tall enough for the
@@ -754,7 +803,10 @@ def linear_group_bias(x, weight, group_bias, rows_per_group):
         if not torch.is_grad_enabled() or not (x.requires_grad or weight.requires_grad or gb.requires_grad):
             return ops.linear_group_bias(x, weight, gb, r, frozen=not weight.requires_grad)
         return _LinearGroupBias.apply(x, weight, gb, r)
-    return (linear(x, weight, own_wgrad=True).view(M // r, r, N) + group_bias.unsqueeze(1)).view(M, N)
+    y = linear(x, weight, own_wgrad=True)
+    if y.is_cuda and y.dtype == torch.float32 and M % r == 0 and 1 <= M // r <= 65535 and torch.is_grad_enabled() and group_bias.requires_grad:
+        return _GroupBiasAdd.apply(y, group_bias, r)
+    return (y.view(M // r, r, N) + group_bias.unsqueeze(1)).view(M, N)
 
 
 def _smallk_with_grad(x, weight):

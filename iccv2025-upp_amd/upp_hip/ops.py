@@ -532,6 +532,17 @@ def colsum_partials(part, offset, length, chunks=None):
     return dst
 
 
+def sum_rows(part, offset=0, length=None):
+    """Column sums of columns [offset, offset + length) of a 2-D f32 HIP matrix on this library's kernels (two stages of
+    upp_colsum_partials for tall matrices) -> (length,).  NOT torch.sum: a torch reduction that splits its rows over workgroups zeroes its
+    semaphores with a memset, and a memset NODE of a captured step graph works in the first replay only on this stack (NOTEBOOK 12.11)."""
+    if length is None:
+        length = part.shape[1] - offset
+    while part.shape[0] > 256:
+        part, offset = colsum_partials(part, offset, length), 0
+    return colsum_partials(part, offset, length, chunks=1)[0]
+
+
 def logsoftmax_rows_fwd(y, bias, C):
     """log_softmax over the first C columns of the rows of y (R, >= C) (+ bias (C)) -> logp (R, C); upp_logsoftmax_rows_fwd."""
     if not (isinstance(y, torch.Tensor) and y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1 and y.shape[1] >= C):

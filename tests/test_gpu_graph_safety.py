@@ -1,0 +1,94 @@
+"""A captured step must contain no memset node.  On this stack (ROCm 7.2.0 / torch 2.10.0+rocm7.0) a memset NODE of a HIP graph works in
+the first replay and writes garbage from the second on (measured: tools/micro/memset_graph_check.py; NOTEBOOK 12.11).  torch reductions
+that split their rows over workgroups zero their semaphores with cudaMemsetAsync; this library used hipMemsetAsync in two fallback
+paths.  Round 6 removed both kinds from every recipe's step (own column-sum kernels, a zero-fill kernel); these tests keep it that way:
+the torch profiler lists the memsets of one eager forward + backward + update of every shipped recipe (what a capture would turn into
+nodes), and the two entry points that used to memset are replayed from a graph against their eager results."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,batch", [("cls", 32), ("cls_aux", 32), ("stage2", 32), ("pretask", 32), ("pretrain", 32), ("seg", 32), ("seg", 4), ("cls", 4)])
+def test_a_step_issues_no_memset(kind, batch):
+    import bench
+    from memset_census import memsets_of
+    dev = torch.device("cuda", 0)
+    tr = bench.Trainer(dev, batch, False, use_graph=False) if kind == "cls" else bench.RecipeTrainer(kind, dev, batch, use_graph=False)
+    for _ in range(2):
+        tr.ts._forward_backward()
+        tr.ts._update()
+    torch.cuda.synchronize()
+
+    def step():
+        tr.ts._forward_backward()
+        tr.ts._update()
+    found = memsets_of(step)
+    assert not found, "memsets in the %s step (memset nodes once captured):\n%s" % (kind, "\n".join("  %s %s | %s" % f for f in found))
+
+
+def test_the_profiler_sees_a_memset_when_there_is_one():
+    """(the check above must not pass because the profiler is blind: torch's own multi-workgroup reduction has one)"""
+    from memset_census import memsets_of
+    x = torch.randn(4, 2048, 512, device='cuda')
+    x.sum(1)
+    torch.cuda.synchronize()
+    assert memsets_of(lambda: x.sum(1))
+
+
+def test_entry_points_that_used_to_memset_replay_correctly_from_a_graph():
+    from upp_hip import ops
+    torch.manual_seed(0)
+    B, n, m = 4, 256, 256
+    x1, x2 = torch.rand(B, n, 3, device='cuda'), torch.rand(B, m, 3, device='cuda')
+    match = ops.emd_approxmatch(x1, x2)
+    cost = ops.emd_matchcost(x1, x2, match).clone()
+    y1, y2 = torch.rand(2, 2048, 3, device='cuda'), torch.rand(2, 8192, 3, device='cuda')         # n + m > 5,461: the atomic-add path
+    d1, d2, i1, i2 = ops.chamfer_fwd(y1, y2)
+    gd1, gd2 = torch.rand_like(d1), torch.rand_like(d2)
+    e1, e2 = [t.clone() for t in ops.chamfer_bwd(y1, y2, i1, i2, gd1, gd2)]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.emd_matchcost(x1, x2, match)
+        ops.chamfer_bwd(y1, y2, i1, i2, gd1, gd2)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        c = ops.emd_matchcost(x1, x2, match)
+        g1, g2 = ops.chamfer_bwd(y1, y2, i1, i2, gd1, gd2)
+    for _ in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.allclose(c, cost, rtol=1e-5, atol=0)                                 # (atomic adds: order, not bits)
+        assert torch.allclose(g1, e1, rtol=1e-4, atol=1e-6) and torch.allclose(g2, e2, rtol=1e-4, atol=1e-6)
+
+
+def test_own_column_sums_replace_torch_reductions():
+    from upp_hip import ops
+    import upp_hip.functional as HF
+    torch.manual_seed(1)
+    for rows, cols, off, length in ((130, 768, 0, 384), (1, 40, 4, 36), (5000, 96, 0, 96), (70000, 64, 8, 40)):
+        x = torch.randn(rows, cols, device='cuda')
+        ref = x[:, off:off + length].double().sum(0)
+        got = ops.sum_rows(x, off, length)
+        assert got.shape == (length,) and float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())) * (rows ** 0.5)
+    tok = torch.randn(1, 1, 384, device='cuda', requires_grad=True)
+    w = torch.randn(8, 152, 384, device='cuda')
+    (gt,) = torch.autograd.grad((HF.expand_rows(tok, 8, 152) * w).sum(), [tok])
+    assert gt.shape == tok.shape and torch.allclose(gt.view(-1), w.view(-1, 384).sum(0), rtol=1e-5, atol=1e-4)
+    y = torch.randn(4 * 2048, 512, device='cuda', requires_grad=True)
+    gb = torch.randn(4, 512, device='cuda', requires_grad=True)
+    wg = torch.randn(4 * 2048, 512, device='cuda')
+    out = HF._GroupBiasAdd.apply(y, gb, 2048)
+    assert torch.equal(out, (y.view(4, 2048, 512) + gb.unsqueeze(1)).view(-1, 512))
+    gy, ggb = torch.autograd.grad(out, [y, gb], grad_outputs=wg)
+    assert torch.equal(gy, wg) and torch.allclose(ggb, wg.view(4, 2048, 512).sum(1), rtol=1e-5, atol=1e-3)
