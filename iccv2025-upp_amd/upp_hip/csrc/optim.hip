@@ -164,23 +164,25 @@ __global__ __launch_bounds__(256) void batched_sum_tall_kernel(SumJobs t) {
 // Column sums of ONE very tall matrix (the bias gradient of a trainable Linear over 65,536 point rows is the column sum of its
 // output gradient): chunk ch of the rows -> dst[ch][c]; the caller sums the `chunks` partial rows (upp_batched_sum).  grid =
 // (ceil(len / 64), chunks); the four waves take the chunk's rows in 16-row batches and are combined in wave order.
+// (accumulated in f64: these sums replace torch reductions -- ops.sum_rows -- whose pairwise order loses less to cancellation than a
+//  sequential f32 sum; the kernel is bound by its loads)
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float *__restrict__ src, long long ld, int n, int len, float *__restrict__ dst) {
-    __shared__ float part[4][64];
+    __shared__ double part[4][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + lane, cc = min(c, len - 1);
     const int chunks = gridDim.y, per = (n + chunks - 1) / chunks;
     const int r0 = blockIdx.y * per, r1 = min(n, r0 + per);
-    float acc = 0.0f;
+    double acc = 0.0;
     for (int i0 = r0 + wave * 16; i0 < r1; i0 += 64) {
         float v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = src[(size_t)min(i0 + q, r1 - 1) * ld + cc];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) if (i0 + q < r1) acc += v[q];
+        for (int q = 0; q < 16; ++q) if (i0 + q < r1) acc += (double)v[q];
     }
     part[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && c < len) dst[(size_t)blockIdx.y * len + c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (wave == 0 && c < len) dst[(size_t)blockIdx.y * len + c] = (float)(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
 }
 
 // Weighted column sums of ONE very tall matrix: dst[ch][w][c] = sum over the rows r of chunk ch of wts[r][w] * src[r][c], w < W <= 4 --

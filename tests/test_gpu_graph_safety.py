@@ -34,6 +34,30 @@ def test_a_step_issues_no_memset(kind, batch):
     assert not found, "memsets in the %s step (memset nodes once captured):\n%s" % (kind, "\n".join("  %s %s | %s" % f for f in found))
 
 
+@pytest.mark.parametrize("kind", ["cls_aux", "stage2", "pretask", "pretrain", "seg"])
+def test_replayed_steps_stay_finite_and_follow_the_eager_loss(kind):
+    """Six replays of every secondary recipe's captured step: loss and gradient buffer finite in every one (a memset node that
+    misfired wrote -1.15e37 into the EMD cost and inf into Chamfer gradients from the SECOND replay on), and the first losses within
+    the spread of the eager driver's (same weights, same batches; dropout and masks draw different numbers)."""
+    import bench
+    dev = torch.device("cuda", 0)
+    B = 8
+    losses = {}
+    for use_graph in (False, True):
+        torch.manual_seed(7)
+        tr = bench.RecipeTrainer(kind, dev, B, use_graph=use_graph, pipeline=False)
+        out = []
+        for _ in range(6):
+            loss = tr.step()
+            torch.cuda.synchronize()
+            out.append(float(loss))
+            assert torch.isfinite(tr.ts.flat.flat).all() and float(tr.ts.flat.flat.abs().max()) > 0.0, (kind, use_graph, out)
+        assert all(v == v and abs(v) < 1e6 for v in out), (kind, use_graph, out)
+        losses[use_graph] = out
+    e, g = losses[False], losses[True]
+    assert abs(sum(g) / len(g) - sum(e) / len(e)) <= 0.25 * abs(sum(e) / len(e)) + 0.05, (kind, e, g)
+
+
 def test_the_profiler_sees_a_memset_when_there_is_one():
     """(the check above must not pass because the profiler is blind: torch's own multi-workgroup reduction has one)"""
     from memset_census import memsets_of
