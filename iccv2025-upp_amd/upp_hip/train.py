@@ -284,6 +284,14 @@ class TrainStep:
                 torch.autograd.backward(loss, grad_tensors=self._seed)
         finally:
             HF.TRANSPOSED.managed, HF.ops.PLANES.managed = was, was_p
+        # by-products the model keeps of its last forward (`aux`: the completion prompter's rebuilt points) must not keep this pass's autograd
+        # graph alive: its AccumulateGrad nodes would be reused by the next pass with the stream THIS pass ran on -- under capture that is a
+        # fork into the warm-up's stream inside the graph (torch warns "AccumulateGrad node's stream does not match"; a fork costs 65-115 us)
+        aux = getattr(self.model, "aux", None)
+        if isinstance(aux, dict):
+            for k_, v_ in list(aux.items()):
+                if isinstance(v_, torch.Tensor) and v_.grad_fn is not None:
+                    aux[k_] = v_.detach()
         got = [(v, p.grad) for p, v in zip(self.trainable, self.flat.views) if p.grad is not None and p.data_ptr() not in scope.routed]
         # into the flat buffer in launches of 64 (upp_copy_batched): torch._foreach_copy_ issues one runtime copy per tensor here -- 55 ...
         # 100 `__amd_rocclr_copyBuffer` launches per step, 0.2 ... 0.35 ms in the round-2 / early round-3 kernel summaries
