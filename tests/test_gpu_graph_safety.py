@@ -116,3 +116,28 @@ def test_own_column_sums_replace_torch_reductions():
     assert torch.equal(out, (y.view(4, 2048, 512) + gb.unsqueeze(1)).view(-1, 512))
     gy, ggb = torch.autograd.grad(out, [y, gb], grad_outputs=wg)
     assert torch.equal(gy, wg) and torch.allclose(ggb, wg.view(4, 2048, 512).sum(1), rtol=1e-5, atol=1e-3)
+
+
+def test_memcpy_nodes_replay_correctly():
+    """(the step drivers feed their static input buffers with device-to-device copies, some of them memcpy NODES of a graph: unlike memset
+    nodes they replay correctly -- checked here so that a runtime that changes this is noticed)"""
+    src = torch.zeros(1 << 20, device='cuda')
+    dst = torch.empty_like(src)
+    small_src, small_dst = torch.zeros(3, device='cuda'), torch.empty(3, device='cuda')
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        dst.copy_(src)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        dst.copy_(src)
+        small_dst.copy_(small_src)
+    for it in range(4):
+        src.fill_(float(it + 1))
+        small_src.fill_(float(10 * it + 1))
+        g.replay()
+        torch.cuda.synchronize()
+        assert float(dst.min()) == float(dst.max()) == float(it + 1)
+        assert small_dst.tolist() == [float(10 * it + 1)] * 3
