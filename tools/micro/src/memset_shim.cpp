@@ -56,3 +56,26 @@ extern "C" hipError_t hipMemset2DAsync(void *dst, size_t pitch, int value, size_
     note("hipMemset2DAsync", dst, width * height, stream);
     return real(dst, pitch, value, width, height, stream);
 }
+
+// cross-stream edges while capturing: a wait that pulls a second stream into the capture is a FORK inside the graph (65-115 us per fork
+// and join on this stack: NOTEBOOK 12.8); logged as "edge" lines
+extern "C" hipError_t hipStreamWaitEvent(hipStream_t stream, hipEvent_t event, unsigned int flags) {
+    static auto real = (hipError_t(*)(hipStream_t, hipEvent_t, unsigned int))hip_sym("hipStreamWaitEvent");
+    static auto is_capturing = (hipError_t(*)(hipStream_t, hipStreamCaptureStatus *))hip_sym("hipStreamIsCapturing");
+    hipStreamCaptureStatus before = hipStreamCaptureStatusNone, after = hipStreamCaptureStatusNone;
+    if (is_capturing) is_capturing(stream, &before);
+    const hipError_t rc = real(stream, event, flags);
+    if (is_capturing) is_capturing(stream, &after);
+    if (before == hipStreamCaptureStatusActive || after == hipStreamCaptureStatusActive) {
+        const char *path = getenv("UPP_MEMSET_LOG");
+        const int fd = open(path ? path : "/tmp/upp_memsets.txt", O_WRONLY | O_CREAT | O_APPEND, 0644);
+        if (fd >= 0) {
+            char line[160];
+            const int n = snprintf(line, sizeof line, "edge hipStreamWaitEvent stream=%p capturing before=%d after=%d\n", (void *)stream, (int)(before == hipStreamCaptureStatusActive),
+                                   (int)(after == hipStreamCaptureStatusActive));
+            if (write(fd, line, n) < 0) {}
+            close(fd);
+        }
+    }
+    return rc;
+}
