@@ -11,7 +11,12 @@
  * the kernel variant of a measurement as an ARGUMENT; the library never reads
  * the environment -- `grep getenv csrc/` is empty since ABI 5).  The caller owns
  * every buffer (including scratch) and the library never synchronises; all
- * work is enqueued on `stream` (hipStream_t; NULL = the default stream).
+ * work is enqueued on `stream` (hipStream_t; NULL = the default stream), and
+ * all of it is KERNEL LAUNCHES: every entry point may be captured into a HIP
+ * graph (the step drivers do so), and on ROCm 7.2.0 a memset node of a graph
+ * works in its first replay only -- the library imports four runtime symbols
+ * (hipLaunchKernel, hipFuncSetAttribute, hipGetLastError, hipGetErrorString;
+ * tests/test_abi.py) and zeroes buffers with a kernel.
  *
  * Return value: 0 on success; a negative UPP_E_* code for an argument the
  * kernels cannot serve (nothing is launched); a positive value is a

@@ -269,6 +269,16 @@ def test_only_the_listed_kernels_touch_scratch_memory():
     assert not offenders, "kernels with scratch accesses: %s" % sorted(offenders.items())
 
 
+def test_the_library_only_launches_kernels():
+    """Every entry point may be captured into a HIP graph, and a memset node of a graph replays correctly ONCE on this stack (ROCm 7.2.0:
+    NOTEBOOK 12.11) -- so the library must not memset, memcpy, allocate or synchronise: the runtime symbols it imports are the launch,
+    the dynamic-LDS attribute and the two error queries."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", _abi.LIB_PATH]).decode()
+    imported = sorted({l.split()[-1].split("@")[0] for l in out.splitlines() if " U hip" in l})
+    assert imported == ["hipFuncSetAttribute", "hipGetErrorString", "hipGetLastError", "hipLaunchKernel"], imported
+
+
 def test_library_contains_no_packed_f32_instruction():
     """Round 4: v_pk_add_f32 with op_sel:[0,1] returns a - 0 in its low half every so often while a bf16-MFMA workgroup shares the CU
     (tools/micro/src/lds_canary.cpp; it changed FPS picks in the pipelined step), so the library is built with -target-feature
