@@ -58,6 +58,40 @@ def test_replayed_steps_stay_finite_and_follow_the_eager_loss(kind):
     assert abs(sum(g) / len(g) - sum(e) / len(e)) <= 0.25 * abs(sum(e) / len(e)) + 0.05, (kind, e, g)
 
 
+@pytest.mark.parametrize("kind,batch", [("seg", 4), ("seg", 8), ("cls_aux", 8), ("stage2", 8), ("pretask", 8)])
+def test_replays_equal_the_eager_steps(kind, batch):
+    """With every random draw switched off (dropout and stochastic depth at 0) a step is a function of the weights and the batch: the
+    captured step's replays must walk the eager driver's trajectory -- loss and gradient buffer of steps 1 ... 4, which covers the
+    first replay, the second (where a memset node first misfired) and two more.  Segmentation at B = 4 takes the small-batch forms
+    (per-group bias as an own node, GEMMs below the tall-tile limit), at B = 8 the tall ones.  (The pre-training recipe draws its mask.)"""
+    import bench
+    dev = torch.device("cuda", 0)
+    runs = {}
+    for use_graph in (False, True):
+        tr = bench.RecipeTrainer(kind, dev, batch, use_graph=use_graph, pipeline=False)
+        for m in tr.model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if hasattr(m, "drop_prob"):
+                m.drop_prob = 0.0
+        out = []
+        for _ in range(4):
+            loss = tr.step()
+            torch.cuda.synchronize()
+            out.append((float(loss), tr.ts.flat.flat.clone()))
+        runs[use_graph] = out
+    # (stage 2 and the pre-task recipe differentiate through atomic-add kernels -- the interpolation's geometry gradient, the Chamfer
+    #  gradient of the 2,048 x 8,192 pair: the order of the adds differs from run to run, and AdamW carries the last bits forward)
+    #  -- and there the comparison stops after the second step: from the third on two EAGER runs part company too, a discrete choice of
+    #  the forward (FPS picks on the completed cloud) flips on the carried bits: tools/micro/replay_vs_eager.py)
+    loose = kind in ("stage2", "pretask")
+    tol = 2e-3 if loose else 2e-5
+    for k, ((le, ge), (lg, gg)) in enumerate(list(zip(runs[False], runs[True]))[:2 if loose else 4]):
+        assert abs(le - lg) <= max(2e-6, 0.1 * tol) * abs(le), (k, le, lg)
+        scale = float(ge.abs().max())
+        assert float((ge - gg).abs().max()) <= tol * scale, (k, float((ge - gg).abs().max()), scale)
+
+
 def test_the_profiler_sees_a_memset_when_there_is_one():
     """(the check above must not pass because the profiler is blind: torch's own multi-workgroup reduction has one)"""
     from memset_census import memsets_of
