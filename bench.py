@@ -730,6 +730,31 @@ _ROOF_KEEP = ("kernel", "bound", "ms", "launches", "achieved", "peak", "unit", "
 _PROSE = ("dtype_note", "peak_note", "how", "traffic_note", "note")
 
 
+def device_info():
+    """{name, cus, arch, max_power_w, power_w_after}: what box the figures come from.  The pool has two populations of boxes (headline 4.1 and
+    4.4 ms for one build); the board's power limit and draw are the first things to look at.  rocm-smi is read-only for an ordinary
+    user; anything that fails leaves its key out."""
+    info = {}
+    try:
+        p = torch.cuda.get_device_properties(torch.cuda.current_device())
+        info["name"], info["cus"], info["arch"] = p.name, p.multi_processor_count, getattr(p, "gcnArchName", None)
+    except Exception:
+        pass
+    try:
+        import re
+        import subprocess
+        out = subprocess.run(["rocm-smi", "-d", str(torch.cuda.current_device()), "--showmaxpower", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", out)
+        if m:
+            info["max_power_w"] = float(m.group(1))
+        m = re.search(r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)", out)
+        if m:
+            info["power_w_after"] = float(m.group(1))
+    except Exception:
+        pass
+    return info
+
+
 def compact_line(line, detail_path="bench_detail.json"):
     """(stdout line, detail) of a full report.  The stdout line keeps the contract's keys, a compact `roofline` (scalars only; `kernel`
     cut to 200 characters) and `cpu_baseline`; `kernels`, `roofline.by_shape`, `roofline.traffic_detail`, `roofline.block_layers` and the
@@ -933,7 +958,7 @@ def main():
             "metric": "point-clouds/sec fwd+bwd, secondary recipe '%s'" % args.workload,
             "value": args.batch * world * args.steps / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, **timing, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "dtype_note": DTYPE_NOTE, "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "dtype_note": DTYPE_NOTE, "data": "synthetic", "device": device_info(),
             "config": {"workload": tr.workload, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph,
                        "pipeline": "front-end(k+1) || back-end(k) on two streams" if pipeline else "none"},
@@ -953,7 +978,7 @@ def main():
             "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, **timing, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "dtype_note": DTYPE_NOTE, "data": "synthetic",
-            "rccl_ranks": rccl_ranks, "dist_backend": backend,
+            "rccl_ranks": rccl_ranks, "dist_backend": backend, "device": device_info(),
             "config": {"workload": "Point_MAE_unify unify_modelnet_cls noisy-train fwd+bwd+AdamW, PEFT stage-1, "
                                    "B=%d/GPU x (1024+72) pts, G=64 k=32" % args.batch,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
